@@ -1,0 +1,156 @@
+"""ctypes binding of ``libgn2v.so`` (C ABI declared in ``include/gn2v.h``).
+
+This is the seam that replaces the PyO3 boundary of the reference,
+``self._model.fit_transform(graph)`` (embiggen/embedders/ensmallen_embedders/node2vec.py:99).
+There is no CPU fallback: if the shared object is missing or no AMD GPU is visible the engine
+raises, it never silently computes elsewhere.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libgn2v.so")
+_SOURCES = ["gn2v_api.hip", "rng.h", "walk_kernels.h", "train_kernels.h", "util_kernels.h"]
+_HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v.h")
+
+SENTINEL = 0xFFFFFFFF
+GRAPH_DEVICE_PTRS = 1
+TRAIN_SCALE_FREE = 1
+TRAIN_DOWNSAMPLE = 2
+TRAIN_NORM_LR = 4
+TRAIN_DETERMINISTIC = 8
+TRAIN_HOGWILD_STORES = 16
+MODEL_SKIPGRAM = 0
+MODEL_CBOW = 1
+
+# every symbol include/gn2v.h declares (checked by tests/test_cabi.py)
+EXPORTS = [
+    "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
+    "gn2v_graph_destroy", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_init_table",
+    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_train", "gn2v_stats_reset", "gn2v_stats_read",
+]
+
+
+class WalkParams(C.Structure):
+    _fields_ = [
+        ("walk_length", C.c_uint32),
+        ("iterations", C.c_uint32),
+        ("return_weight", C.c_float),
+        ("explore_weight", C.c_float),
+        ("max_neighbours", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class TrainParams(C.Structure):
+    _fields_ = [
+        ("model", C.c_uint32),
+        ("d", C.c_uint32),
+        ("ld", C.c_uint32),
+        ("epochs", C.c_uint32),
+        ("k", C.c_uint32),
+        ("window", C.c_uint32),
+        ("lr", C.c_float),
+        ("lr_decay", C.c_float),
+        ("clip", C.c_float),
+        ("flags", C.c_uint32),
+        ("init_scale", C.c_float),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("pairs", C.c_uint64),
+        ("walk_steps", C.c_uint64),
+        ("centres", C.c_uint64),
+        ("train_ms", C.c_double),
+        ("walk_ms", C.c_double),
+        ("train_launches", C.c_uint32),
+        ("walk_launches", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class Gn2vError(RuntimeError):
+    """An entry point of libgn2v.so returned a non-zero status."""
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile ``libgn2v.so`` for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in _SOURCES] + [_HEADER]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(s) for s in srcs)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [
+        hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared",
+        "-fPIC", os.path.join(_CSRC, "gn2v_api.hip"), "-o", LIB_PATH,
+    ]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libgn2v.so failed:\n" + res.stderr)
+    if verbose and res.stderr:
+        print(res.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared object; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ModuleNotFoundError(
+            f"The gn2v HIP engine `{LIB_PATH}` has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc from ROCm); "
+            "there is deliberately no CPU fallback for this path."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, f32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_int
+    L.gn2v_version.restype = i32
+    L.gn2v_last_error.restype = C.c_char_p
+    L.gn2v_device_count.restype = i32
+    L.gn2v_graph_create.argtypes = [vp, vp, vp, vp, u64, u64, u64, u32, i32, C.POINTER(vp)]
+    L.gn2v_graph_destroy.argtypes = [vp]
+    L.gn2v_ba_edges.argtypes = [u64, u32, u64, vp, vp, vp]
+    L.gn2v_walks.argtypes = [vp, C.POINTER(WalkParams), u64, u64, u64, u64, vp, vp]
+    L.gn2v_window_batch.argtypes = [vp, u64, u32, u32, vp, vp, vp]
+    L.gn2v_init_table.argtypes = [vp, u64, u32, u32, u64, u32, f32, vp]
+    step = [vp, C.POINTER(TrainParams), vp, u64, u32, u64, u64, u64, f32, vp, vp, vp, vp]
+    L.gn2v_sgns_step.argtypes = step
+    L.gn2v_cbow_step.argtypes = step
+    L.gn2v_train.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64, vp, vp,
+                             C.POINTER(Stats), vp]
+    L.gn2v_stats_reset.argtypes = [vp, vp]
+    L.gn2v_stats_read.argtypes = [vp, C.POINTER(Stats), vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("gn2v_last_error",):
+            fn.restype = i32
+    _lib = L
+    return L
+
+
+def check(status: int):
+    if status != 0:
+        raise Gn2vError(lib().gn2v_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return lib().gn2v_device_count()
+
+
+def require_device():
+    """Fail loudly when the engine cannot run (missing library or no GPU)."""
+    if device_count() < 1:
+        raise RuntimeError(
+            "No AMD GPU is visible to HIP. The gn2v engine (embiggen_amd) only runs on a ROCm "
+            "device such as MI355X; it has no CPU execution path."
+        )

@@ -1,0 +1,457 @@
+// libgn2v.so -- C ABI (include/gn2v.h) over the gfx950 kernels in this directory.
+// Host side of the drop-in for `models.SkipGram/CBOW(...).fit_transform(graph)`
+// (reference: embiggen/embedders/ensmallen_embedders/node2vec.py:65-69,:99).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gn2v.h"
+#include "rng.h"
+#include "train_kernels.h"
+#include "util_kernels.h"
+#include "walk_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ \
+                                                                           ":" +          \
+                        std::to_string(__LINE__) + ")");                                  \
+    } while (0)
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct gn2v_graph {
+    gn2v::GraphView view{};
+    int device = 0;
+    int n_cus = 256;
+    bool owns = false;
+    void *own_row_ptr = nullptr, *own_col_idx = nullptr, *own_cumw = nullptr,
+         *own_sources = nullptr;
+    unsigned long long *counters = nullptr;  // device, 4 x u64
+    std::vector<EventPair> train_events, walk_events, free_events;
+    double train_ms = 0.0, walk_ms = 0.0;
+    uint32_t train_launches = 0, walk_launches = 0;
+};
+
+namespace {
+
+int get_events(gn2v_graph *g, EventPair *ev) {
+    if (!g->free_events.empty()) {
+        *ev = g->free_events.back();
+        g->free_events.pop_back();
+        return 0;
+    }
+    HIP_TRY(hipEventCreate(&ev->a));
+    HIP_TRY(hipEventCreate(&ev->b));
+    return 0;
+}
+
+// fold finished event pairs into the ms accumulators (caller has synchronised the stream)
+int fold_events(gn2v_graph *g) {
+    for (auto &ev : g->train_events) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        g->train_ms += ms;
+        g->free_events.push_back(ev);
+    }
+    g->train_events.clear();
+    for (auto &ev : g->walk_events) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        g->walk_ms += ms;
+        g->free_events.push_back(ev);
+    }
+    g->walk_events.clear();
+    return 0;
+}
+
+int check_walk_params(const gn2v_walk_params *wp) {
+    if (!wp) return fail("walk params are NULL");
+    if (wp->walk_length < 2) return fail("walk_length must be >= 2");
+    if (wp->iterations < 1) return fail("iterations must be >= 1");
+    if (!(wp->return_weight > 0.f) || !(wp->explore_weight > 0.f) ||
+        !std::isfinite(wp->return_weight) || !std::isfinite(wp->explore_weight))
+        return fail("return_weight and explore_weight must be finite and strictly positive");
+    return 0;
+}
+
+gn2v::WalkConsts walk_consts(const gn2v_walk_params *wp) {
+    gn2v::WalkConsts c{};
+    c.walk_length = wp->walk_length;
+    c.second_order = !(wp->return_weight == 1.0f && wp->explore_weight == 1.0f);
+    const double rw = wp->return_weight, ew = wp->explore_weight;
+    double mx = rw > ew ? rw : ew;
+    if (mx < 1.0) mx = 1.0;
+    const double s = 4294967296.0;
+    c.t_ret = (uint64_t)std::floor(rw / mx * s);
+    c.t_common = (uint64_t)std::floor(1.0 / mx * s);
+    c.t_explore = (uint64_t)std::floor(ew / mx * s);
+    return c;
+}
+
+int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
+                 uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, hipStream_t s) {
+    if (n_walks == 0) return 0;
+    const gn2v::WalkConsts c = walk_consts(wp);
+    const uint64_t blocks = (n_walks + gn2v::kWalkBlock - 1) / gn2v::kWalkBlock;
+    if (blocks > 0x7FFFFFFFULL) return fail("too many walks in one launch");
+    EventPair ev;
+    if (get_events(g, &ev)) return 1;
+    HIP_TRY(hipEventRecord(ev.a, s));
+    hipLaunchKernelGGL(gn2v::walk_kernel, dim3((unsigned)blocks), dim3(gn2v::kWalkBlock), 0, s,
+                       g->view, c, gn2v::epoch_key(seed, epoch), first_walk, n_walks, d_out,
+                       g->counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.b, s));
+    g->walk_events.push_back(ev);
+    g->walk_launches++;
+    return 0;
+}
+
+int check_train_params(const gn2v_train_params *tp, uint32_t L) {
+    if (!tp) return fail("train params are NULL");
+    if (tp->d == 0) return fail("embedding size must be strictly positive");
+    if (tp->ld < tp->d || (tp->ld & 3)) return fail("ld must be a multiple of 4 and >= d");
+    if (tp->ld > 512) return fail("embedding sizes above 512 are not supported yet");
+    if (tp->window < 1) return fail("window_size must be >= 1");
+    if (L < 2) return fail("walk_length must be >= 2");
+    if (!std::isfinite(tp->lr) || !std::isfinite(tp->clip) || tp->clip <= 0.f)
+        return fail("learning rate / clipping value must be finite, clipping value positive");
+    return 0;
+}
+
+template <int CH>
+int launch_train_ch(bool cbow, bool atomic, bool det, dim3 grid, dim3 block, size_t lds,
+                    hipStream_t s, const gn2v::TrainArgs &a) {
+#define GN2V_LAUNCH(KERNEL, AT, DT) \
+    hipLaunchKernelGGL((gn2v::KERNEL<CH, AT, DT>), grid, block, lds, s, a)
+    if (!cbow) {
+        if (det)
+            GN2V_LAUNCH(sgns_kernel, false, true);
+        else if (atomic)
+            GN2V_LAUNCH(sgns_kernel, true, false);
+        else
+            GN2V_LAUNCH(sgns_kernel, false, false);
+    } else {
+        if (det)
+            GN2V_LAUNCH(cbow_kernel, false, true);
+        else if (atomic)
+            GN2V_LAUNCH(cbow_kernel, true, false);
+        else
+            GN2V_LAUNCH(cbow_kernel, false, false);
+    }
+#undef GN2V_LAUNCH
+    return 0;
+}
+
+int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const uint32_t *d_walks,
+                 uint64_t n_walks, uint32_t L, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                 float lr, float *d_central, float *d_contextual, const uint32_t *d_neg_override,
+                 hipStream_t s) {
+    if (check_train_params(tp, L)) return 1;
+    if (!d_walks || !d_central || !d_contextual) return fail("NULL walks / table pointer");
+    if (n_walks == 0) return 0;
+    gn2v::TrainArgs a{};
+    a.g = g->view;
+    a.walks = d_walks;
+    a.neg_override = d_neg_override;
+    a.central = d_central;
+    a.contextual = d_contextual;
+    a.counters = g->counters;
+    a.n_walks = n_walks;
+    a.first_walk = first_walk;
+    a.ekey = gn2v::epoch_key(seed, epoch);
+    a.L = L;
+    a.window = tp->window;
+    a.k = tp->k;
+    a.ld = tp->ld;
+    a.flags = tp->flags & 7u;
+    a.max_samples = cbow ? (tp->k + 1) : 2 * tp->window * (tp->k + 1);
+    a.lr = lr;
+    a.clip = tp->clip;
+
+    const bool det = tp->flags & GN2V_TRAIN_DETERMINISTIC;
+    const bool atomic = !(tp->flags & GN2V_TRAIN_HOGWILD_STORES);
+    const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
+    const size_t lds = (size_t)waves_per_block * (L + 2 * (size_t)a.max_samples) * 4;
+    if (lds > 64 * 1024) return fail("walk_length / window / negatives too large for the LDS plan");
+    uint64_t blocks = det ? 1 : (n_walks + waves_per_block - 1) / waves_per_block;
+    const uint64_t cap = (uint64_t)g->n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kTrainBlock);
+
+    EventPair ev;
+    if (get_events(g, &ev)) return 1;
+    HIP_TRY(hipEventRecord(ev.a, s));
+    const uint32_t nchunks = tp->ld / 4;
+    if (nchunks <= 16)
+        launch_train_ch<1>(cbow, atomic, det, grid, block, lds, s, a);
+    else if (nchunks <= 32)
+        launch_train_ch<2>(cbow, atomic, det, grid, block, lds, s, a);
+    else if (nchunks <= 64)
+        launch_train_ch<4>(cbow, atomic, det, grid, block, lds, s, a);
+    else
+        launch_train_ch<8>(cbow, atomic, det, grid, block, lds, s, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.b, s));
+    g->train_events.push_back(ev);
+    g->train_launches++;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gn2v_version(void) { return GN2V_VERSION; }
+
+const char *gn2v_last_error(void) { return g_err.c_str(); }
+
+int gn2v_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const float *cumw,
+                      const uint32_t *sources, uint64_t n_nodes, uint64_t n_edges,
+                      uint64_t n_sources, uint32_t flags, int device, gn2v_graph **out) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    if (!row_ptr || !col_idx) return fail("row_ptr / col_idx are NULL");
+    if (n_nodes == 0) return fail("the graph has no nodes");
+    if (n_nodes >= 0xFFFFFFFFULL) return fail("node ids must fit in 32 bits (minus the sentinel)");
+    if (n_edges == 0) return fail("the graph has no edges");
+    if (sources == nullptr) n_sources = n_nodes;
+    if (n_sources == 0) return fail("the graph has no source nodes");
+    if (gn2v_device_count() <= device || device < 0)
+        return fail("no HIP device " + std::to_string(device) +
+                    " is visible: the gn2v engine requires an AMD GPU (there is no CPU fallback)");
+    HIP_TRY(hipSetDevice(device));
+    gn2v_graph *g = new gn2v_graph();
+    g->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        g->n_cus = prop.multiProcessorCount;
+    auto cleanup = [&]() { gn2v_graph_destroy(g); };
+    if (flags & GN2V_GRAPH_DEVICE_PTRS) {
+        g->view.row_ptr = row_ptr;
+        g->view.col_idx = col_idx;
+        g->view.cumw = cumw;
+        g->view.sources = sources;
+    } else {
+        g->owns = true;
+#define GN2V_UPLOAD(dst, src, bytes)                                                       \
+    do {                                                                                   \
+        if (hipMalloc(&(dst), (bytes)) != hipSuccess ||                                    \
+            hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice) != hipSuccess) {       \
+            cleanup();                                                                     \
+            return fail("uploading the CSR graph to the device failed (out of memory?)"); \
+        }                                                                                  \
+    } while (0)
+        GN2V_UPLOAD(g->own_row_ptr, row_ptr, (n_nodes + 1) * sizeof(uint64_t));
+        GN2V_UPLOAD(g->own_col_idx, col_idx, n_edges * sizeof(uint32_t));
+        if (cumw) GN2V_UPLOAD(g->own_cumw, cumw, n_edges * sizeof(float));
+        if (sources) GN2V_UPLOAD(g->own_sources, sources, n_sources * sizeof(uint32_t));
+#undef GN2V_UPLOAD
+        g->view.row_ptr = (const uint64_t *)g->own_row_ptr;
+        g->view.col_idx = (const uint32_t *)g->own_col_idx;
+        g->view.cumw = (const float *)g->own_cumw;
+        g->view.sources = (const uint32_t *)g->own_sources;
+    }
+    g->view.n_nodes = n_nodes;
+    g->view.n_edges = n_edges;
+    g->view.n_sources = n_sources;
+    if (hipMalloc(&g->counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(g->counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        cleanup();
+        return fail("allocating device counters failed");
+    }
+    *out = g;
+    return 0;
+}
+
+int gn2v_graph_destroy(gn2v_graph *g) {
+    if (!g) return 0;
+    (void)hipSetDevice(g->device);
+    (void)hipDeviceSynchronize();
+    if (g->own_row_ptr) (void)hipFree(g->own_row_ptr);
+    if (g->own_col_idx) (void)hipFree(g->own_col_idx);
+    if (g->own_cumw) (void)hipFree(g->own_cumw);
+    if (g->own_sources) (void)hipFree(g->own_sources);
+    if (g->counters) (void)hipFree(g->counters);
+    for (auto *v : {&g->train_events, &g->walk_events, &g->free_events})
+        for (auto &ev : *v) {
+            (void)hipEventDestroy(ev.a);
+            (void)hipEventDestroy(ev.b);
+        }
+    delete g;
+    return 0;
+}
+
+int gn2v_ba_edges(uint64_t n_nodes, uint32_t m, uint64_t seed, uint32_t *d_src, uint32_t *d_dst,
+                  void *stream) {
+    if (n_nodes < 2 || m < 1) return fail("need n_nodes >= 2 and m >= 1");
+    if (n_nodes >= 0xFFFFFFFFULL) return fail("node ids must fit in 32 bits");
+    if (!d_src || !d_dst) return fail("NULL output pointer");
+    const uint64_t n_e = (n_nodes - 1) * (uint64_t)m;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_e + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(gn2v::ba_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       gn2v::mix64(seed ^ gn2v::kTagBA), n_e, m, d_src, d_dst);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
+               uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    if (check_walk_params(wp)) return 1;
+    if (!d_out) return fail("NULL output pointer");
+    HIP_TRY(hipSetDevice(g->device));
+    return launch_walks(g, wp, seed, epoch, first_walk, n_walks, d_out, (hipStream_t)stream);
+}
+
+int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
+                      uint32_t window, int32_t *d_contexts, int32_t *d_words, void *stream) {
+    if (window < 1 || walk_length <= 2 * window)
+        return fail("walk_length must exceed 2 * window_size");
+    if (!d_walks || !d_contexts || !d_words) return fail("NULL pointer");
+    const uint64_t n = n_walks * (walk_length - 2 * window);
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(gn2v::window_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       d_walks, n_walks, walk_length, window, d_contexts, d_words);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_init_table(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
+                    uint32_t table_id, float scale, void *stream) {
+    if (!d_table) return fail("NULL table pointer");
+    if (d == 0 || ld < d) return fail("need 0 < d <= ld");
+    const uint64_t n = n_rows * ld;
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(gn2v::init_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_table,
+                       n_rows, d, ld, gn2v::mix64(seed ^ (gn2v::kTagInit + table_id)), scale);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_sgns_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d_walks,
+                   uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
+                   uint64_t first_walk, float lr, float *d_central, float *d_contextual,
+                   const uint32_t *d_neg_override, void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    HIP_TRY(hipSetDevice(g->device));
+    return launch_train(g, false, tp, d_walks, n_walks, walk_length, seed, epoch, first_walk, lr,
+                        d_central, d_contextual, d_neg_override, (hipStream_t)stream);
+}
+
+int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d_walks,
+                   uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
+                   uint64_t first_walk, float lr, float *d_central, float *d_contextual,
+                   const uint32_t *d_neg_override, void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    HIP_TRY(hipSetDevice(g->device));
+    return launch_train(g, true, tp, d_walks, n_walks, walk_length, seed, epoch, first_walk, lr,
+                        d_central, d_contextual, d_neg_override, (hipStream_t)stream);
+}
+
+int gn2v_stats_reset(gn2v_graph *g, void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (fold_events(g)) return 1;
+    g->train_ms = g->walk_ms = 0.0;
+    g->train_launches = g->walk_launches = 0;
+    HIP_TRY(hipMemsetAsync(g->counters, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int gn2v_stats_read(gn2v_graph *g, gn2v_stats *stats, void *stream) {
+    if (!g || !stats) return fail("NULL handle / stats");
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (fold_events(g)) return 1;
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpy(h, g->counters, sizeof(h), hipMemcpyDeviceToHost));
+    stats->pairs = h[0];
+    stats->walk_steps = h[1];
+    stats->centres = h[2];
+    stats->train_ms = g->train_ms;
+    stats->walk_ms = g->walk_ms;
+    stats->train_launches = g->train_launches;
+    stats->walk_launches = g->walk_launches;
+    return 0;
+}
+
+int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
+               uint64_t seed, uint64_t max_walks_per_epoch, float *d_central,
+               float *d_contextual, gn2v_stats *stats, void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    if (check_walk_params(wp)) return 1;
+    if (check_train_params(tp, wp->walk_length)) return 1;
+    if (tp->model > GN2V_MODEL_CBOW) return fail("unknown model id");
+    if (!d_central || !d_contextual) return fail("NULL table pointer");
+    HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = (hipStream_t)stream;
+    const bool cbow = tp->model == GN2V_MODEL_CBOW;
+    const uint32_t L = wp->walk_length;
+
+    if (gn2v_init_table(d_central, g->view.n_nodes, tp->d, tp->ld, seed, 0, tp->init_scale, s) ||
+        gn2v_init_table(d_contextual, g->view.n_nodes, tp->d, tp->ld, seed, 1, tp->init_scale, s))
+        return 1;
+
+    uint64_t walks_per_epoch = g->view.n_sources * (uint64_t)wp->iterations;
+    if (max_walks_per_epoch && max_walks_per_epoch < walks_per_epoch)
+        walks_per_epoch = max_walks_per_epoch;
+    // walk batches: large enough to fill the chip several times, small enough to stay cheap
+    const uint64_t batch = std::min<uint64_t>(walks_per_epoch, (uint64_t)1 << 16);
+    uint32_t *d_walks = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_walks, batch * L * sizeof(uint32_t)));
+    float lr = tp->lr;
+    int rc = 0;
+    for (uint32_t e = 0; e < tp->epochs && !rc; ++e) {
+        for (uint64_t first = 0; first < walks_per_epoch && !rc; first += batch) {
+            const uint64_t n = std::min(batch, walks_per_epoch - first);
+            rc = launch_walks(g, wp, seed, e, first, n, d_walks, s);
+            if (!rc)
+                rc = launch_train(g, cbow, tp, d_walks, n, L, seed, e, first, lr, d_central,
+                                  d_contextual, nullptr, s);
+        }
+        lr *= tp->lr_decay;
+    }
+    hipError_t se = hipStreamSynchronize(s);
+    (void)hipFree(d_walks);
+    if (rc) return rc;
+    if (se != hipSuccess) return fail(std::string("training failed: ") + hipGetErrorString(se));
+    if (stats) return gn2v_stats_read(g, stats, stream);
+    return 0;
+}
+
+}  // extern "C"

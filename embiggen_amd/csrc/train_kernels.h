@@ -1,0 +1,430 @@
+// Fused negative-sampling kernels: gather -> dot -> sigmoid -> scatter-add on two f32 tables.
+// Replaces the SGD inside ensmallen's `SkipGram/CBOW.fit_transform`
+// (reference call site embedders/ensmallen_embedders/node2vec.py:99; parameter semantics
+//  node2vec_skipgram.py:37-119; model statement tensorflow_embedders/skipgram.py:28-61,
+//  cbow.py:26-60).
+//
+// Mapping (gfx950, wave64): one wavefront owns one walk at a time.  A wave is four groups of 16
+// lanes; a group owns one embedding row per round: lane q of a group holds float4 chunks
+// q, q+16, ... of the row (d = 128 -> 2 x 16 B per lane, one 512 B row per group, 2 KiB per wave
+// round trip).  Dot products reduce inside a group with 4 DPP steps (quad_perm, quad_perm,
+// row_half_mirror, row_mirror) -- no LDS, bit-identical in every lane of the group.  The centre
+// row and its gradient stay in registers across the <= 2w*(k+1) samples of a centre.  Sample rows
+// are updated with hardware f32 atomics on HBM (default) or racy read-modify-write stores
+// (Hogwild, like the CPU reference).  HBM-bound: ~0.75 flop/B, MFMA is not used.
+#pragma once
+#include "rng.h"
+#include "walk_kernels.h"
+
+namespace gn2v {
+
+constexpr uint32_t kFlagScaleFree = 1u, kFlagDownsample = 2u, kFlagNormLr = 4u;
+
+struct TrainArgs {
+    GraphView g;
+    const uint32_t *walks;
+    const uint32_t *neg_override;
+    float *central;
+    float *contextual;
+    unsigned long long *counters;  // [0] pairs, [1] walk steps, [2] centres
+    uint64_t n_walks;
+    uint64_t first_walk;
+    uint64_t ekey;
+    uint32_t L, window, k, ld, flags;
+    uint32_t max_samples;  // LDS list capacity per wave
+    float lr, clip;
+};
+
+template <int CH>
+struct Row {
+    float4 c[CH];
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+
+// sum over the 16 lanes of a DPP row; every lane gets the bit-identical result
+__device__ __forceinline__ float group16_sum(float x) {
+    x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);  // row_half_mirror
+    x += dpp_mov<0x140>(x);  // row_mirror
+    return x;
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CH>
+__device__ __forceinline__ void load_row(Row<CH> &r, const float *base, int q, uint32_t nchunks,
+                                         bool valid) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        const uint32_t ci = cc * 16 + q;
+        r.c[cc] = (valid && ci < nchunks) ? *reinterpret_cast<const float4 *>(base + ci * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int CH>
+__device__ __forceinline__ float dot_rows(const Row<CH> &a, const Row<CH> &b) {
+    float s = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        s += a.c[cc].x * b.c[cc].x;
+        s += a.c[cc].y * b.c[cc].y;
+        s += a.c[cc].z * b.c[cc].z;
+        s += a.c[cc].w * b.c[cc].w;
+    }
+    return group16_sum(s);
+}
+
+// acc += s * x
+template <int CH>
+__device__ __forceinline__ void axpy(Row<CH> &acc, float s, const Row<CH> &x) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        acc.c[cc].x += s * x.c[cc].x;
+        acc.c[cc].y += s * x.c[cc].y;
+        acc.c[cc].z += s * x.c[cc].z;
+        acc.c[cc].w += s * x.c[cc].w;
+    }
+}
+
+// table row += s * x   (ATOMIC: hardware f32 atomics; else store old + s*x)
+template <int CH, bool ATOMIC>
+__device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks, float s,
+                                            const Row<CH> &x, const Row<CH> &old) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        const uint32_t ci = cc * 16 + q;
+        if (ci < nchunks) {
+            float *p = base + ci * 4;
+            if constexpr (ATOMIC) {
+                unsafeAtomicAdd(p + 0, s * x.c[cc].x);
+                unsafeAtomicAdd(p + 1, s * x.c[cc].y);
+                unsafeAtomicAdd(p + 2, s * x.c[cc].z);
+                unsafeAtomicAdd(p + 3, s * x.c[cc].w);
+            } else {
+                float4 o = old.c[cc];
+                o.x += s * x.c[cc].x;
+                o.y += s * x.c[cc].y;
+                o.z += s * x.c[cc].z;
+                o.w += s * x.c[cc].w;
+                *reinterpret_cast<float4 *>(p) = o;
+            }
+        }
+    }
+}
+
+// sum a register row over the four 16-lane groups of the wave
+template <int CH>
+__device__ __forceinline__ void reduce_groups(Row<CH> &r) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        float *f = reinterpret_cast<float *>(&r.c[cc]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = f[e];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            f[e] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ float sigmoid_clipped(float dot, float clip) {
+    dot = fminf(fmaxf(dot, -clip), clip);
+    return 1.0f / (1.0f + __expf(-dot));
+}
+
+__device__ __forceinline__ uint32_t draw_negative(const TrainArgs &a, uint64_t nkey, uint64_t qi) {
+    const uint64_t r = draw(nkey, qi);
+    if (a.flags & kFlagScaleFree) return a.g.col_idx[mulhi64(r, a.g.n_edges)];
+    return (uint32_t)mulhi64(r, a.g.n_nodes);
+}
+
+__device__ __forceinline__ bool keep_centre(const TrainArgs &a, uint64_t wkey, uint32_t i,
+                                            uint32_t c) {
+    if (!(a.flags & kFlagDownsample)) return true;
+    const uint64_t deg = a.g.row_ptr[c + 1] - a.g.row_ptr[c];
+    if (deg == 0) return true;
+    const uint64_t r32 = draw(wkey ^ kTagDown, i) >> 32;
+    const uint64_t x = r32 * deg;  // < 2^64
+    const uint64_t lhs_lo = x * a.g.n_nodes, lhs_hi = mulhi64(x, a.g.n_nodes);
+    const uint64_t rhs_lo = a.g.n_edges << 32, rhs_hi = a.g.n_edges >> 32;
+    return lhs_hi < rhs_hi || (lhs_hi == rhs_hi && lhs_lo < rhs_lo);
+}
+
+__device__ __forceinline__ float centre_lr(const TrainArgs &a, uint32_t c) {
+    if (!(a.flags & kFlagNormLr)) return a.lr;
+    const uint64_t deg = a.g.row_ptr[c + 1] - a.g.row_ptr[c];
+    return deg ? a.lr / (float)deg : a.lr;
+}
+
+// Load walk b into LDS and return its effective length (first sentinel).
+__device__ __forceinline__ uint32_t stage_walk(const TrainArgs &a, uint64_t b, uint32_t *s_walk,
+                                               int lane) {
+    uint32_t first_bad = a.L;
+    for (uint32_t t = lane; t < a.L; t += 64) {
+        const uint32_t v = a.walks[b * a.L + t];
+        s_walk[t] = v;
+        if (v == kSentinel) first_bad = min(first_bad, t);
+    }
+    for (int off = 32; off > 0; off >>= 1) first_bad = min(first_bad, (uint32_t)__shfl_xor(first_bad, off));
+    wave_sync();
+    return first_bad;
+}
+
+// Score the staged sample list against the register row `u` (replicated in every group):
+// for each sample row v: var = (label - sigmoid(clip(u.v))) * lr ; g += var * v ; v += var * u.
+// DET: one sample at a time, all groups redundantly, group 0 writes (strict sequential semantics).
+template <int CH, bool ATOMIC, bool DET>
+__device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, const Row<CH> &u,
+                                              Row<CH> &g, const uint32_t *s_rows,
+                                              const float *s_lab, uint32_t n_samples, float lrc,
+                                              int grp, int q) {
+    const uint32_t nchunks = a.ld >> 2;
+    if constexpr (DET) {
+        for (uint32_t t = 0; t < n_samples; ++t) {
+            const uint32_t row = s_rows[t];
+            if (row == kSentinel) continue;
+            float *base = table + (uint64_t)row * a.ld;
+            Row<CH> v;
+            load_row<CH>(v, base, q, nchunks, true);
+            const float dot = dot_rows<CH>(u, v);
+            const float var = (s_lab[t] - sigmoid_clipped(dot, a.clip)) * lrc;
+            axpy<CH>(g, var, v);
+            if (grp == 0) scatter_add<CH, false>(base, q, nchunks, var, u, v);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        }
+    } else {
+        for (uint32_t t0 = 0; t0 < n_samples; t0 += 4) {
+            const uint32_t t = t0 + grp;
+            const bool in = t < n_samples;
+            const uint32_t row = in ? s_rows[t] : kSentinel;
+            const float lab = in ? s_lab[t] : 0.f;
+            const bool valid = row != kSentinel;
+            float *base = table + (uint64_t)(valid ? row : 0) * a.ld;
+            Row<CH> v;
+            load_row<CH>(v, base, q, nchunks, valid);
+            const float dot = dot_rows<CH>(u, v);
+            const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+            axpy<CH>(g, var, v);
+            if (valid) scatter_add<CH, ATOMIC>(base, q, nchunks, var, u, v);
+        }
+    }
+}
+
+template <int CH>
+__device__ __forceinline__ void zero_row(Row<CH> &r) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) r.c[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+constexpr int kTrainBlock = 256;
+
+// SkipGram with negative sampling over a batch of walks.
+// LDS per wave: walk[L] | rows[max_samples] | labels[max_samples].
+template <int CH, bool ATOMIC, bool DET>
+__global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint32_t per_wave = a.L + 2 * a.max_samples;
+    uint32_t *s_walk = smem + wave * per_wave;
+    uint32_t *s_rows = s_walk + a.L;
+    float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
+    const uint32_t nchunks = a.ld >> 2;
+    const uint32_t w = a.window, k = a.k;
+    const uint64_t per_walk_neg = (uint64_t)a.L * 2 * w * k;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
+
+    for (uint64_t b = (uint64_t)blockIdx.x * waves_per_block + wave; b < a.n_walks;
+         b += wave_stride) {
+        const uint32_t Le = stage_walk(a, b, s_walk, lane);
+        const uint64_t wkey = draw(a.ekey, a.first_walk + b);
+        const uint64_t nkey = wkey ^ kTagNeg;
+        const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
+        uint32_t pairs = 0, centres = 0;
+
+        for (uint32_t i = 0; i < Le; ++i) {
+            const uint32_t c = s_walk[i];
+            if (!keep_centre(a, wkey, i, c)) continue;
+            const float lrc = centre_lr(a, c);
+            const uint32_t lo = i > w ? i - w : 0;
+            const uint32_t hi = min(i + w, Le - 1);
+            const uint32_t n_ctx = hi - lo;
+            const uint32_t n_samples = n_ctx * (k + 1);
+            if (n_ctx == 0) continue;
+
+            // stage the sample list of this centre: [ctx, neg_0 .. neg_{k-1}] per context slot
+            wave_sync();
+            for (uint32_t t = lane; t < n_samples; t += 64) {
+                const uint32_t rank = t / (k + 1);
+                const uint32_t s = t - rank * (k + 1);
+                uint32_t j = lo + rank;
+                if (j >= i) ++j;
+                const uint32_t slot = j < i ? (j + w - i) : (j + w - i - 1);
+                const uint32_t ctx = s_walk[j];
+                uint32_t row = ctx;
+                float lab = 1.f;
+                if (s != 0) {
+                    const uint64_t qi = ((uint64_t)i * 2 * w + slot) * k + (s - 1);
+                    row = ov ? ov[qi] : draw_negative(a, nkey, qi);
+                    lab = 0.f;
+                    if (row == c || row == ctx) row = kSentinel;
+                }
+                s_rows[t] = row;
+                s_lab[t] = lab;
+            }
+            wave_sync();
+
+            float *crow = a.central + (uint64_t)c * a.ld;
+            Row<CH> u, g;
+            load_row<CH>(u, crow, q, nchunks, true);
+            zero_row<CH>(g);
+            score_samples<CH, ATOMIC, DET>(a, a.contextual, u, g, s_rows, s_lab, n_samples, lrc,
+                                           grp, q);
+            if constexpr (!DET) reduce_groups<CH>(g);
+            if (grp == 0) scatter_add<CH, ATOMIC && !DET>(crow, q, nchunks, 1.0f, g, u);
+            if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            pairs += n_ctx;
+            ++centres;
+        }
+        if (a.counters && lane == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)pairs);
+            atomicAdd(&a.counters[2], (unsigned long long)centres);
+        }
+        wave_sync();
+    }
+}
+
+// CBOW with negative sampling: h = mean of the window's *contextual* rows (input side), scored
+// against the centre and k negatives in the *central* table (output side); the input gradient / C
+// goes back to every context row.
+template <int CH, bool ATOMIC, bool DET>
+__global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint32_t per_wave = a.L + 2 * a.max_samples;
+    uint32_t *s_walk = smem + wave * per_wave;
+    uint32_t *s_rows = s_walk + a.L;
+    float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
+    const uint32_t nchunks = a.ld >> 2;
+    const uint32_t w = a.window, k = a.k;
+    const uint64_t per_walk_neg = (uint64_t)a.L * k;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
+
+    for (uint64_t b = (uint64_t)blockIdx.x * waves_per_block + wave; b < a.n_walks;
+         b += wave_stride) {
+        const uint32_t Le = stage_walk(a, b, s_walk, lane);
+        const uint64_t wkey = draw(a.ekey, a.first_walk + b);
+        const uint64_t nkey = wkey ^ kTagNeg;
+        const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
+        uint32_t pairs = 0, centres = 0;
+
+        for (uint32_t i = 0; i < Le; ++i) {
+            const uint32_t c = s_walk[i];
+            if (!keep_centre(a, wkey, i, c)) continue;
+            const float lrc = centre_lr(a, c);
+            const uint32_t lo = i > w ? i - w : 0;
+            const uint32_t hi = min(i + w, Le - 1);
+            const uint32_t n_ctx = hi - lo;
+            if (n_ctx == 0) continue;
+            const float invC = 1.0f / (float)n_ctx;
+
+            wave_sync();
+            for (uint32_t t = lane; t <= k; t += 64) {
+                uint32_t row = c;
+                float lab = 1.f;
+                if (t != 0) {
+                    const uint64_t qi = (uint64_t)i * k + (t - 1);
+                    row = ov ? ov[qi] : draw_negative(a, nkey, qi);
+                    lab = 0.f;
+                    if (row == c) row = kSentinel;
+                }
+                s_rows[t] = row;
+                s_lab[t] = lab;
+            }
+            wave_sync();
+
+            // h = mean of context rows; in DET mode every group sums all rows in walk order
+            Row<CH> h, g;
+            zero_row<CH>(h);
+            zero_row<CH>(g);
+            if constexpr (DET) {
+                for (uint32_t j = lo; j <= hi; ++j) {
+                    if (j == i) continue;
+                    Row<CH> v;
+                    load_row<CH>(v, a.contextual + (uint64_t)s_walk[j] * a.ld, q, nchunks, true);
+                    axpy<CH>(h, 1.0f, v);
+                }
+            } else {
+                for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
+                    const uint32_t rank = r0 + grp;
+                    const bool in = rank < n_ctx;
+                    uint32_t j = lo + rank;
+                    if (j >= i) ++j;
+                    Row<CH> v;
+                    load_row<CH>(v, a.contextual + (uint64_t)(in ? s_walk[j] : 0) * a.ld, q,
+                                 nchunks, in);
+                    axpy<CH>(h, 1.0f, v);
+                }
+                reduce_groups<CH>(h);
+            }
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc) {
+                h.c[cc].x *= invC;
+                h.c[cc].y *= invC;
+                h.c[cc].z *= invC;
+                h.c[cc].w *= invC;
+            }
+
+            score_samples<CH, ATOMIC, DET>(a, a.central, h, g, s_rows, s_lab, k + 1, lrc, grp, q);
+            if constexpr (!DET) reduce_groups<CH>(g);
+
+            // every context row += g / C
+            if constexpr (DET) {
+                for (uint32_t j = lo; j <= hi; ++j) {
+                    if (j == i) continue;
+                    float *base = a.contextual + (uint64_t)s_walk[j] * a.ld;
+                    Row<CH> v;
+                    load_row<CH>(v, base, q, nchunks, true);
+                    if (grp == 0) scatter_add<CH, false>(base, q, nchunks, invC, g, v);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                }
+            } else {
+                for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
+                    const uint32_t rank = r0 + grp;
+                    if (rank < n_ctx) {
+                        uint32_t j = lo + rank;
+                        if (j >= i) ++j;
+                        float *base = a.contextual + (uint64_t)s_walk[j] * a.ld;
+                        Row<CH> v;
+                        if constexpr (!ATOMIC) load_row<CH>(v, base, q, nchunks, true);
+                        scatter_add<CH, ATOMIC>(base, q, nchunks, invC, g, v);
+                    }
+                }
+            }
+            pairs += n_ctx;
+            ++centres;
+        }
+        if (a.counters && lane == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)pairs);
+            atomicAdd(&a.counters[2], (unsigned long long)centres);
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace gn2v

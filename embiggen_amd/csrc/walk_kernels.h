@@ -1,0 +1,231 @@
+// Random-walk sampler: one walker per wavefront lane over a CSR graph.
+// Replaces the walk generation inside ensmallen's `fit_transform` / `Graph.node2vec`
+// (reference call sites: embedders/ensmallen_embedders/node2vec.py:99,
+//  sequences/tensorflow_sequences/node2vec_sequence.py:190-201).
+//
+// Second-order (return_weight = 1/p, explore_weight = 1/q; node2vec_skipgram.py:58-71) bias is
+// sampled exactly by rejection: candidate ~ uniform (or weight-proportional) over N(cur), accepted
+// against an integer threshold chosen by the candidate's class {prev, common neighbour, other};
+// after kMaxTrials rejections the lane falls back to an exact integer-weighted scan of the row.
+// All arithmetic that decides a transition is integer (or single rounded f32/f64 ops), so the
+// walks are bit-identical to oracle/gn2v_oracle.c.
+#pragma once
+#include "rng.h"
+
+namespace gn2v {
+
+constexpr int kMaxTrials = 32;
+
+struct GraphView {
+    const uint64_t *row_ptr;
+    const uint32_t *col_idx;
+    const float *cumw;        // nullptr for unweighted graphs
+    const uint32_t *sources;  // nullptr when every node is a source
+    uint64_t n_nodes;
+    uint64_t n_edges;
+    uint64_t n_sources;
+};
+
+struct WalkConsts {
+    uint32_t walk_length;
+    uint32_t second_order;
+    uint64_t t_ret, t_common, t_explore;  // acceptance thresholds on a 2^32 scale
+};
+
+__device__ __forceinline__ bool adj_contains(const uint32_t *__restrict__ col, uint64_t lo,
+                                             uint64_t hi, uint32_t x) {
+    const uint64_t end = hi;
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (col[mid] < x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo < end && col[lo] == x;
+}
+
+__device__ __forceinline__ uint64_t pick_index(const GraphView &g, uint64_t start, uint64_t deg,
+                                               uint64_t r) {
+    if (g.cumw == nullptr) return ((r >> 32) * deg) >> 32;
+    const float total = g.cumw[start + deg - 1];
+    const float f = __fmul_rn(__fmul_rn((float)(r >> 40), 1.0f / 16777216.0f), total);
+    uint64_t lo = 0, hi = deg;
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (g.cumw[start + mid] > f)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo < deg ? lo : deg - 1;
+}
+
+__device__ __forceinline__ uint64_t class_threshold(const GraphView &g, const WalkConsts &c,
+                                                    uint32_t x, uint32_t prev, uint64_t pstart,
+                                                    uint64_t pend) {
+    return (x == prev) ? c.t_ret
+           : adj_contains(g.col_idx, pstart, pend, x) ? c.t_common
+                                                      : c.t_explore;
+}
+
+// exact fallback after kMaxTrials rejections (rare: only for extreme p/q on low-weight rows)
+__device__ __noinline__ uint32_t exact_scan(const GraphView &g, const WalkConsts &c, uint64_t r,
+                                            uint64_t start, uint64_t deg, uint32_t prev,
+                                            uint64_t pstart, uint64_t pend) {
+    if (g.cumw == nullptr) {
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < deg; ++i)
+            total += class_threshold(g, c, g.col_idx[start + i], prev, pstart, pend);
+        if (total == 0) return g.col_idx[start + (((r >> 32) * deg) >> 32)];
+        const uint64_t target = mulhi64(r, total);
+        uint64_t acc = 0;
+        for (uint64_t i = 0; i < deg; ++i) {
+            const uint32_t x = g.col_idx[start + i];
+            acc += class_threshold(g, c, x, prev, pstart, pend);
+            if (acc > target) return x;
+        }
+        return g.col_idx[start + deg - 1];
+    }
+    double total = 0.0;
+    for (uint64_t i = 0; i < deg; ++i) {
+        const double w = __dsub_rn((double)g.cumw[start + i],
+                                   i ? (double)g.cumw[start + i - 1] : 0.0);
+        const uint64_t thr = class_threshold(g, c, g.col_idx[start + i], prev, pstart, pend);
+        total = __dadd_rn(total, __dmul_rn(w, (double)thr));
+    }
+    const double target =
+        __dmul_rn(__dmul_rn((double)(r >> 11), 1.0 / 9007199254740992.0), total);
+    double acc = 0.0;
+    for (uint64_t i = 0; i < deg; ++i) {
+        const uint32_t x = g.col_idx[start + i];
+        const double w = __dsub_rn((double)g.cumw[start + i],
+                                   i ? (double)g.cumw[start + i - 1] : 0.0);
+        const uint64_t thr = class_threshold(g, c, x, prev, pstart, pend);
+        acc = __dadd_rn(acc, __dmul_rn(w, (double)thr));
+        if (acc > target) return x;
+    }
+    return g.col_idx[start + deg - 1];
+}
+
+// One lane = one walker.  Output row-major u32[n_walks][walk_length]; every 16 steps a wave
+// flushes a [64 walks][16 steps] LDS tile so each walk row is written as whole 64-byte segments.
+constexpr int kWalkBlock = 256;
+constexpr int kTileSteps = 16;
+
+__global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConsts c, uint64_t ekey,
+                                                          uint64_t first_walk, uint64_t n_walks,
+                                                          uint32_t *__restrict__ out,
+                                                          unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t tile[kWalkBlock / 64][64][kTileSteps + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * kWalkBlock + (uint64_t)wave * 64);
+    if (wave_base >= n_walks) return;
+    const uint64_t b = wave_base + lane;
+    const bool live = b < n_walks;
+    const uint32_t L = c.walk_length;
+
+    uint64_t wkey = 0, ctr = 0;
+    uint32_t cur = kSentinel, prev = kSentinel;
+    uint64_t pstart = 0, pend = 0;
+    if (live) {
+        const uint64_t wid = first_walk + b;
+        const uint64_t si = wid % g.n_sources;
+        cur = g.sources ? g.sources[si] : (uint32_t)si;
+        wkey = draw(ekey, wid);
+    }
+    bool dead = !live;
+    uint32_t steps = 0;
+
+    for (uint32_t t0 = 0; t0 < L; t0 += kTileSteps) {
+        const uint32_t tn = min((uint32_t)kTileSteps, L - t0);
+        for (uint32_t tt = 0; tt < tn; ++tt) {
+            const uint32_t t = t0 + tt;
+            uint32_t val = kSentinel;
+            if (t == 0) {
+                val = cur;
+            } else if (!dead) {
+                const uint64_t start = g.row_ptr[cur];
+                const uint64_t end = g.row_ptr[cur + 1];
+                const uint64_t deg = end - start;
+                if (deg == 0) {
+                    dead = true;
+                } else {
+                    uint32_t nxt;
+                    if (!c.second_order || prev == kSentinel || deg == 1) {
+                        const uint64_t r = draw(wkey, ctr++);
+                        nxt = g.col_idx[start + pick_index(g, start, deg, r)];
+                    } else {
+                        bool accepted = false;
+                        nxt = 0;
+                        for (int trial = 0; trial < kMaxTrials; ++trial) {
+                            const uint64_t r = draw(wkey, ctr++);
+                            const uint32_t x = g.col_idx[start + pick_index(g, start, deg, r)];
+                            const uint64_t thr = class_threshold(g, c, x, prev, pstart, pend);
+                            if ((r & 0xFFFFFFFFULL) < thr) {
+                                nxt = x;
+                                accepted = true;
+                                break;
+                            }
+                        }
+                        if (!accepted) {
+                            const uint64_t r = draw(wkey, ctr++);
+                            nxt = exact_scan(g, c, r, start, deg, prev, pstart, pend);
+                        }
+                    }
+                    val = nxt;
+                    prev = cur;
+                    pstart = start;
+                    pend = end;
+                    cur = nxt;
+                    ++steps;
+                }
+            }
+            tile[wave][lane][tt] = val;
+        }
+        // flush: 64 walks x tn steps; lane -> (walk = lane/4 + 16*pass, 4-step quarter = lane%4)
+        __builtin_amdgcn_wave_barrier();
+        for (int pass = 0; pass < 4; ++pass) {
+            const int wrow = (lane >> 2) + 16 * pass;
+            const uint64_t wb = wave_base + wrow;
+            const int q = lane & 3;
+            if (wb < n_walks) {
+                uint32_t *dst = out + wb * L + t0 + q * 4;
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t tt = q * 4 + e;
+                    if (tt < tn) dst[e] = tile[wave][wrow][tt];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (counters) {
+        // one atomic per wave
+        uint32_t s = steps;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) atomicAdd(&counters[1], (unsigned long long)s);
+    }
+}
+
+// Node2VecSequence batch form: words / contexts of every full-window position.
+__global__ void window_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L,
+                              uint32_t w, int32_t *__restrict__ contexts,
+                              int32_t *__restrict__ words) {
+    const uint32_t per = L - 2 * w;
+    const uint64_t n = n_walks * per;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = i / per;
+        const uint32_t pos = (uint32_t)(i % per) + w;
+        const uint32_t *wk = walks + b * L;
+        words[i] = (int32_t)wk[pos];
+        int32_t *dst = contexts + i * 2 * w;
+        for (uint32_t s = 0; s < w; ++s) {
+            dst[s] = (int32_t)wk[pos - w + s];
+            dst[w + s] = (int32_t)wk[pos + 1 + s];
+        }
+    }
+}
+
+}  // namespace gn2v

@@ -1,0 +1,213 @@
+"""Engine-side model objects: the stand-ins for ``ensmallen.models.SkipGram`` / ``.CBOW``.
+
+The reference constructs ``models.SkipGram(embedding_size=..., random_state=..., **kwargs)``
+(embiggen/embedders/ensmallen_embedders/node2vec.py:65-69) and calls ``.fit_transform(graph)``
+(:99), receiving ``[central, contextual]`` float32 ``[N, d]`` numpy arrays.  These classes keep
+that interface and run the whole call on the GPU through ``gn2v_train`` (include/gn2v.h).
+PyTorch only allocates the two tables in HBM and provides the stream.
+"""
+import ctypes as C
+import os
+import sys
+import time
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from .graph import CSRGraph
+
+
+def _as_csr(graph) -> CSRGraph:
+    if isinstance(graph, CSRGraph):
+        return graph
+    if hasattr(graph, "get_cumulative_node_degrees"):
+        return CSRGraph.from_ensmallen(graph)
+    raise TypeError(
+        "The graph must be an embiggen_amd.CSRGraph (or an ensmallen.Graph, converted through "
+        f"its CSR getters); got {type(graph)}."
+    )
+
+
+class _WalkBasedModel:
+    MODEL_ID = None
+    NAME = None
+
+    def __init__(
+        self,
+        embedding_size: int = 100,
+        random_state: int = 42,
+        epochs: int = 30,
+        clipping_value: float = 6.0,
+        number_of_negative_samples: int = 10,
+        walk_length: int = 128,
+        iterations: int = 10,
+        window_size: int = 5,
+        return_weight: float = 0.25,
+        explore_weight: float = 4.0,
+        change_node_type_weight: float = 1.0,
+        change_edge_type_weight: float = 1.0,
+        max_neighbours: Optional[int] = 100,
+        learning_rate: float = 0.01,
+        learning_rate_decay: float = 0.9,
+        central_nodes_embedding_path: Optional[str] = None,
+        contextual_nodes_embedding_path: Optional[str] = None,
+        normalize_by_degree: bool = False,
+        stochastic_downsample_by_degree: bool = False,
+        normalize_learning_rate_by_degree: bool = False,
+        use_scale_free_distribution: bool = True,
+        dtype: str = "f32",
+        verbose: bool = True,
+        alpha: float = 0.75,
+        deterministic: bool = False,
+        hogwild: bool = False,
+        device: int = 0,
+    ):
+        if not isinstance(embedding_size, int) or embedding_size < 1:
+            raise ValueError("The embedding size must be a strictly positive integer.")
+        if embedding_size > 512:
+            raise ValueError("Embedding sizes above 512 are not supported by the gn2v engine yet.")
+        if epochs < 0 or walk_length < 2 or iterations < 1 or window_size < 1:
+            raise ValueError(
+                "epochs must be >= 0, walk_length >= 2, iterations >= 1 and window_size >= 1."
+            )
+        if number_of_negative_samples < 0:
+            raise ValueError("number_of_negative_samples must be >= 0.")
+        if not (return_weight > 0 and explore_weight > 0):
+            raise ValueError("return_weight and explore_weight must be strictly positive.")
+        if not clipping_value > 0:
+            raise ValueError("clipping_value must be strictly positive.")
+        if dtype != "f32":
+            raise ValueError(f"Only dtype 'f32' is supported by the gn2v engine, got {dtype!r}.")
+        if normalize_by_degree:
+            raise NotImplementedError(
+                "normalize_by_degree is not supported by the gn2v engine yet."
+            )
+        if change_node_type_weight != 1.0 or change_edge_type_weight != 1.0:
+            raise NotImplementedError(
+                "Node/edge type transition weights need typed graphs, which the gn2v engine "
+                "does not model yet."
+            )
+        self.embedding_size = embedding_size
+        self.random_state = int(random_state)
+        self.epochs = epochs
+        self.clipping_value = float(clipping_value)
+        self.number_of_negative_samples = number_of_negative_samples
+        self.walk_length = walk_length
+        self.iterations = iterations
+        self.window_size = window_size
+        self.return_weight = float(return_weight)
+        self.explore_weight = float(explore_weight)
+        self.max_neighbours = max_neighbours
+        self.learning_rate = float(learning_rate)
+        self.learning_rate_decay = float(learning_rate_decay)
+        self.central_nodes_embedding_path = central_nodes_embedding_path
+        self.contextual_nodes_embedding_path = contextual_nodes_embedding_path
+        self.stochastic_downsample_by_degree = bool(stochastic_downsample_by_degree)
+        self.normalize_learning_rate_by_degree = bool(normalize_learning_rate_by_degree)
+        self.use_scale_free_distribution = bool(use_scale_free_distribution)
+        self.verbose = bool(verbose)
+        self.alpha = alpha
+        self.deterministic = bool(deterministic)
+        self.hogwild = bool(hogwild)
+        self.device = int(device)
+        self.last_stats = None
+        self.last_seconds = None
+
+    # ------------------------------------------------------------------ C structs
+    @property
+    def padded_size(self) -> int:
+        return (self.embedding_size + 3) // 4 * 4
+
+    def walk_params(self) -> _lib.WalkParams:
+        return _lib.WalkParams(
+            self.walk_length, self.iterations, self.return_weight, self.explore_weight,
+            0 if self.max_neighbours is None else int(self.max_neighbours), 0,
+        )
+
+    def train_params(self) -> _lib.TrainParams:
+        flags = 0
+        if self.use_scale_free_distribution:
+            flags |= _lib.TRAIN_SCALE_FREE
+        if self.stochastic_downsample_by_degree:
+            flags |= _lib.TRAIN_DOWNSAMPLE
+        if self.normalize_learning_rate_by_degree:
+            flags |= _lib.TRAIN_NORM_LR
+        if self.deterministic:
+            flags |= _lib.TRAIN_DETERMINISTIC
+        if self.hogwild:
+            flags |= _lib.TRAIN_HOGWILD_STORES
+        return _lib.TrainParams(
+            self.MODEL_ID, self.embedding_size, self.padded_size, self.epochs,
+            self.number_of_negative_samples, self.window_size, self.learning_rate,
+            self.learning_rate_decay, self.clipping_value, flags, self.init_scale(),
+        )
+
+    def init_scale(self) -> float:
+        """Both tables start uniform in +-1/sqrt(d) ("Initialisation")."""
+        return float(1.0 / np.sqrt(self.embedding_size))
+
+    # ------------------------------------------------------------------ the hot call
+    def fit_transform_device(self, graph, max_walks_per_epoch: int = 0):
+        """Run the fit and leave both tables in HBM: returns (central, contextual) torch tensors
+        of shape [N, padded_size] (columns >= embedding_size are zero padding) and the stats."""
+        import torch
+
+        csr = _as_csr(graph)
+        _lib.require_device()
+        if not torch.cuda.is_available():
+            raise RuntimeError("PyTorch does not see a ROCm device; cannot allocate the tables.")
+        dev = torch.device("cuda", self.device)
+        dgraph = csr.device_graph(self.device)
+        n, ld = csr.get_number_of_nodes(), self.padded_size
+        with torch.cuda.device(dev):
+            central = torch.empty((n, ld), dtype=torch.float32, device=dev)
+            contextual = torch.empty((n, ld), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            wp, tp, stats = self.walk_params(), self.train_params(), _lib.Stats()
+            L = _lib.lib()
+            _lib.check(L.gn2v_stats_reset(dgraph.handle, stream))
+            start = time.perf_counter()
+            _lib.check(L.gn2v_train(dgraph.handle, C.byref(wp), C.byref(tp), self.random_state,
+                                    max_walks_per_epoch, central.data_ptr(),
+                                    contextual.data_ptr(), C.byref(stats), stream))
+            self.last_seconds = time.perf_counter() - start
+        self.last_stats = stats.as_dict()
+        if self.verbose:
+            secs = max(self.last_seconds, 1e-9)
+            print(
+                f"[gn2v] {self.NAME}: {stats.pairs} pairs, {stats.walk_steps} walk steps in "
+                f"{secs:.3f}s ({stats.pairs / secs:.3e} pairs/s; train kernels "
+                f"{stats.train_ms:.1f} ms, walk kernels {stats.walk_ms:.1f} ms)",
+                file=sys.stderr,
+            )
+        return central, contextual, self.last_stats
+
+    def fit_transform(self, graph) -> List[np.ndarray]:
+        """``[central, contextual]`` as freshly allocated C-contiguous float32 [N, d] arrays
+        (or ``np.memmap``s when the ``*_embedding_path`` arguments are given)."""
+        central, contextual, _ = self.fit_transform_device(graph)
+        d = self.embedding_size
+        out = []
+        for tensor, path in ((central, self.central_nodes_embedding_path),
+                             (contextual, self.contextual_nodes_embedding_path)):
+            host = tensor[:, :d].contiguous().cpu().numpy()
+            if path is not None:
+                os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+                mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32,
+                                               shape=host.shape)
+                mm[:] = host
+                mm.flush()
+                host = mm
+            out.append(host)
+        return out
+
+
+class SkipGram(_WalkBasedModel):
+    MODEL_ID = _lib.MODEL_SKIPGRAM
+    NAME = "SkipGram"
+
+
+class CBOW(_WalkBasedModel):
+    MODEL_ID = _lib.MODEL_CBOW
+    NAME = "CBOW"

@@ -1,0 +1,112 @@
+"""Thin Python handles on the single-batch entry points of the C ABI (include/gn2v.h).
+
+Everything stays in HBM: inputs and outputs are torch CUDA tensors used purely as device buffers
+(`data_ptr()` + current stream).  uint32 node ids are carried in int32 tensors (same bits).
+These are the building blocks `gn2v_train` is made of; parity tests and the
+``Node2VecSequence`` batch emitter call them directly.
+"""
+import ctypes as C
+from typing import Optional
+
+from . import _lib
+from .graph import CSRGraph
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _stream(device):
+    return _torch().cuda.current_stream(device).cuda_stream
+
+
+def walk_params(walk_length: int, iterations: int = 1, return_weight: float = 1.0,
+                explore_weight: float = 1.0, max_neighbours: Optional[int] = 100):
+    return _lib.WalkParams(walk_length, iterations, return_weight, explore_weight,
+                           0 if max_neighbours is None else max_neighbours, 0)
+
+
+def train_params(model: int, d: int, k: int, window: int, lr: float = 0.01,
+                 lr_decay: float = 0.9, clip: float = 6.0, epochs: int = 1, flags: int = 1,
+                 init_scale: Optional[float] = None, ld: Optional[int] = None):
+    ld = (d + 3) // 4 * 4 if ld is None else ld
+    scale = d ** -0.5 if init_scale is None else init_scale
+    return _lib.TrainParams(model, d, ld, epochs, k, window, lr, lr_decay, clip, flags, scale)
+
+
+def walks(graph: CSRGraph, wp, seed: int, epoch: int, first_walk: int, n_walks: int,
+          device: int = 0):
+    """u32 walks [n_walks, walk_length] (int32 tensor) of (seed, epoch) on the device."""
+    torch = _torch()
+    dg = graph.device_graph(device)
+    dev = torch.device("cuda", device)
+    out = torch.empty((n_walks, wp.walk_length), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().gn2v_walks(dg.handle, C.byref(wp), seed, epoch, first_walk, n_walks,
+                                     out.data_ptr(), _stream(dev)))
+    return out
+
+
+def window_batch(walks_tensor, window: int):
+    """(contexts int32 [n, 2w], words int32 [n]) for every full-window walk position."""
+    torch = _torch()
+    n_walks, L = walks_tensor.shape
+    n = n_walks * (L - 2 * window)
+    dev = walks_tensor.device
+    contexts = torch.empty((n, 2 * window), dtype=torch.int32, device=dev)
+    words = torch.empty((n,), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().gn2v_window_batch(walks_tensor.data_ptr(), n_walks, L, window,
+                                            contexts.data_ptr(), words.data_ptr(), _stream(dev)))
+    return contexts, words
+
+
+def init_table(n_rows: int, d: int, seed: int, table_id: int, scale: float, device: int = 0,
+               ld: Optional[int] = None):
+    torch = _torch()
+    ld = (d + 3) // 4 * 4 if ld is None else ld
+    dev = torch.device("cuda", device)
+    t = torch.empty((n_rows, ld), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().gn2v_init_table(t.data_ptr(), n_rows, d, ld, seed, table_id, scale,
+                                          _stream(dev)))
+    return t
+
+
+def _step(fn_name: str, graph: CSRGraph, tp, walks_tensor, seed, epoch, first_walk, lr, central,
+          contextual, neg_override=None):
+    dev = central.device
+    dg = graph.device_graph(dev.index or 0)
+    assert walks_tensor.is_contiguous() and central.is_contiguous() and contextual.is_contiguous()
+    assert central.shape[1] == tp.ld and contextual.shape[1] == tp.ld
+    n_walks, L = walks_tensor.shape
+    fn = getattr(_lib.lib(), fn_name)
+    _lib.check(fn(dg.handle, C.byref(tp), walks_tensor.data_ptr(), n_walks, L, seed, epoch,
+                  first_walk, lr, central.data_ptr(), contextual.data_ptr(),
+                  None if neg_override is None else neg_override.data_ptr(), _stream(dev)))
+
+
+def sgns_step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, contextual,
+              neg_override=None):
+    """One SkipGram negative-sampling pass over a batch of walks (tables updated in place)."""
+    _step("gn2v_sgns_step", graph, tp, walks_tensor, seed, epoch, first_walk, lr, central,
+          contextual, neg_override)
+
+
+def cbow_step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, contextual,
+              neg_override=None):
+    """One CBOW negative-sampling pass over a batch of walks (tables updated in place)."""
+    _step("gn2v_cbow_step", graph, tp, walks_tensor, seed, epoch, first_walk, lr, central,
+          contextual, neg_override)
+
+
+def stats_reset(graph: CSRGraph, device: int = 0):
+    dg = graph.device_graph(device)
+    _lib.check(_lib.lib().gn2v_stats_reset(dg.handle, _stream(_torch().device("cuda", device))))
+
+
+def stats_read(graph: CSRGraph, device: int = 0) -> dict:
+    dg = graph.device_graph(device)
+    st = _lib.Stats()
+    _lib.check(_lib.lib().gn2v_stats_read(dg.handle, C.byref(st),
+                                          _stream(_torch().device("cuda", device))))
+    return st.as_dict()

@@ -1,0 +1,149 @@
+/*
+ * gn2v.h -- C ABI of libgn2v.so, the MI355X (gfx950) Node2Vec / SkipGram / CBOW engine.
+ *
+ * This is the drop-in boundary for the one hot call of the reference,
+ *     node_embeddings = self._model.fit_transform(graph)
+ *         (embiggen/embedders/ensmallen_embedders/node2vec.py:99, model constructed at :65-69)
+ * and for the batch generator
+ *     graph.node2vec(batch_size, walk_length, window_size, iterations, ...)
+ *         (embiggen/sequences/tensorflow_sequences/node2vec_sequence.py:190-201).
+ * In the reference both are PyO3 calls into the `ensmallen` wheel; here they are plain C entry
+ * points a ctypes / cffi / cgo stub can bind.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; gn2v_last_error() returns the
+ *     message of the last failure on the calling thread.
+ *   - no C++ types, exceptions or torch types cross the boundary: pointers + sizes only.
+ *   - pointers named d_* are DEVICE pointers (HBM of the graph's device); the caller owns them.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
+ *     asynchronous on it unless documented otherwise.
+ *   - a handle may be used from one thread at a time.
+ */
+#ifndef GN2V_H
+#define GN2V_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GN2V_VERSION 100 /* 0.1.0 */
+
+#define GN2V_SENTINEL 0xFFFFFFFFu /* walk positions after a trap node */
+
+/* gn2v_graph_create flags */
+#define GN2V_GRAPH_DEVICE_PTRS 1u /* arrays are device pointers, borrowed (not copied) */
+
+/* gn2v_train_params.flags */
+#define GN2V_TRAIN_SCALE_FREE 1u     /* use_scale_free_distribution (node2vec_skipgram.py:101) */
+#define GN2V_TRAIN_DOWNSAMPLE 2u     /* stochastic_downsample_by_degree (:97-98)                */
+#define GN2V_TRAIN_NORM_LR 4u        /* normalize_learning_rate_by_degree (:99-100)             */
+#define GN2V_TRAIN_DETERMINISTIC 8u  /* one wavefront, strict walk order: oracle-exact, slow    */
+#define GN2V_TRAIN_HOGWILD_STORES 16u /* racy read-modify-write stores instead of HBM atomics   */
+
+#define GN2V_MODEL_SKIPGRAM 0u
+#define GN2V_MODEL_CBOW 1u
+
+/* Walk parameters; names follow Node2VecSkipGramEnsmallen.__init__ (node2vec_skipgram.py:9-36). */
+typedef struct {
+    uint32_t walk_length;    /* nodes per walk (walk_length-1 steps)              */
+    uint32_t iterations;     /* walks per source node per epoch                   */
+    float return_weight;     /* 1/p                                                */
+    float explore_weight;    /* 1/q                                                */
+    uint32_t max_neighbours; /* accepted; walks are exact regardless   */
+    uint32_t flags;          /* reserved                                           */
+} gn2v_walk_params;
+
+typedef struct {
+    uint32_t model;   /* GN2V_MODEL_*                                            */
+    uint32_t d;       /* embedding_size                                          */
+    uint32_t ld;      /* row stride of both tables in floats, multiple of 4, >= d */
+    uint32_t epochs;
+    uint32_t k;       /* number_of_negative_samples                              */
+    uint32_t window;  /* window_size                                             */
+    float lr;         /* learning_rate                                           */
+    float lr_decay;   /* learning_rate_decay (per epoch)                         */
+    float clip;       /* clipping_value                                          */
+    uint32_t flags;   /* GN2V_TRAIN_*                                            */
+    float init_scale; /* tables start uniform(-init_scale, init_scale)           */
+} gn2v_train_params;
+
+/* Filled by gn2v_train / gn2v_stats_read.  Times are HIP-event milliseconds measured on the
+ * stream the kernels were launched on. */
+typedef struct {
+    uint64_t pairs;        /* (centre, context) training pairs processed        */
+    uint64_t walk_steps;   /* sampled walk transitions                          */
+    uint64_t centres;      /* centres processed (CBOW unit)                     */
+    double train_ms;       /* sum of training-kernel durations                  */
+    double walk_ms;        /* sum of walk-kernel durations                      */
+    uint32_t train_launches;
+    uint32_t walk_launches;
+} gn2v_stats;
+
+typedef struct gn2v_graph gn2v_graph;
+
+int gn2v_version(void);
+const char *gn2v_last_error(void);
+/* number of visible HIP devices; 0 when there is none (never fails) */
+int gn2v_device_count(void);
+
+/* CSR graph: row_ptr u64[n_nodes+1], col_idx u32[n_edges] (neighbours ascending per row, no
+ * duplicates), cumw f32[n_edges] = per-row inclusive prefix sums of positive edge weights or NULL,
+ * sources u32[n_sources] = nodes with out-degree > 0 or NULL when every node is a source.
+ * CSR convention as exported at embedders/pecanpy_embedders/node2vec.py:139-163.
+ * Host arrays are uploaded (and may be freed on return); with GN2V_GRAPH_DEVICE_PTRS the device
+ * arrays are borrowed and must outlive the handle. */
+int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const float *cumw,
+                      const uint32_t *sources, uint64_t n_nodes, uint64_t n_edges,
+                      uint64_t n_sources, uint32_t flags, int device, gn2v_graph **out);
+int gn2v_graph_destroy(gn2v_graph *g);
+
+/* Seeded Barabasi-Albert edge list on the device: (n_nodes-1)*m edges (src > dst). */
+int gn2v_ba_edges(uint64_t n_nodes, uint32_t m, uint64_t seed, uint32_t *d_src, uint32_t *d_dst,
+                  void *stream);
+
+/* Walks [first_walk, first_walk+n_walks) of (seed, epoch) -> d_out u32[n_walks][walk_length].
+ * walk_id = iteration * n_sources + source_index.  Replaces Graph.complete_walks / the walk half
+ * of Graph.node2vec (node2vec_sequence.py:190-201). */
+int gn2v_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
+               uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, void *stream);
+
+/* Node2VecSequence batch (node2vec_sequence.py:115-128): every walk position with a full window
+ * -> d_words i32[n], d_contexts i32[n][2w], n = n_walks * (walk_length - 2w). */
+int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
+                      uint32_t window, int32_t *d_contexts, int32_t *d_words, void *stream);
+
+/* table[r][c] = uniform(-scale, scale) from a hash of (seed, table_id, r, c); padding = 0 */
+int gn2v_init_table(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
+                    uint32_t table_id, float scale, void *stream);
+
+/* One batch of explicit walks through the fused gather->dot->sigmoid->scatter-add kernel
+ * (tables updated in place).  Walk b has id first_walk + b in (seed, epoch); d_neg_override
+ * (optional) supplies explicit negatives u32[n_walks][walk_length][2w][k] (SkipGram) or
+ * [n_walks][walk_length][k] (CBOW) instead of sampled ones.  tp->model is ignored. */
+int gn2v_sgns_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d_walks,
+                   uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
+                   uint64_t first_walk, float lr, float *d_central, float *d_contextual,
+                   const uint32_t *d_neg_override, void *stream);
+int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d_walks,
+                   uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
+                   uint64_t first_walk, float lr, float *d_central, float *d_contextual,
+                   const uint32_t *d_neg_override, void *stream);
+
+/* The whole of `models.SkipGram/CBOW(...).fit_transform(graph)` (node2vec.py:99): initialise both
+ * caller-allocated tables f32[n_nodes][ld], then per epoch generate every walk and train on it.
+ * max_walks_per_epoch = 0 trains on all iterations*n_sources walks; otherwise only that many
+ * (benchmark budget).  Synchronises `stream` before returning and fills *stats. */
+int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
+               uint64_t seed, uint64_t max_walks_per_epoch, float *d_central,
+               float *d_contextual, gn2v_stats *stats, void *stream);
+
+/* counters accumulated on the handle by the step / walk entry points since the last reset */
+int gn2v_stats_reset(gn2v_graph *g, void *stream);
+int gn2v_stats_read(gn2v_graph *g, gn2v_stats *stats, void *stream); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GN2V_H */

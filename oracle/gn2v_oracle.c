@@ -1,0 +1,530 @@
+/*
+ * gn2v_oracle.c -- CPU restatement of the Node2Vec / SkipGram / CBOW hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call anything in oracle/.
+ *
+ * PARITY UNPINNED.  The reference (monarch-initiative/embiggen 0.11.96) performs this path in one
+ * opaque call, `self._model.fit_transform(graph)`
+ * (embiggen/embedders/ensmallen_embedders/node2vec.py:99), into the third-party Rust wheel
+ * `ensmallen` (setup.py:76, pinned ">=0.8.94"), whose source is not in /root/reference and which
+ * cannot be installed here.  The reference's own tests hold no golden vectors for walks, losses
+ * or embeddings (tests/test_node_embedding_pipelines.py:17-42 is does-not-raise only).  This
+ * file therefore restates the *published* algorithm (node2vec second-order walks + word2vec
+ * negative-sampling SGD) under the semantics the reference documents at its call sites:
+ *
+ *   - kwargs & their meaning ............ node2vec_skipgram.py:37-119, node2vec_cbow.py:37-119
+ *       return_weight = 1/p, explore_weight = 1/q (:58-71); window trimmed at walk borders
+ *       (:55-57); dot product clipped at +-clipping_value (:45-47); negatives drawn
+ *       proportionally to degree when use_scale_free_distribution (:101-102); learning rate
+ *       multiplied by learning_rate_decay each epoch (:84-85); iterations = walks per source
+ *       node (:53-54).
+ *   - two N x d f32 tables [central, contextual] ... node2vec.py:99-112 and the in-tree model
+ *       statement tensorflow_embedders/skipgram.py:28-61 (centre embedding . output weights,
+ *       1 positive + k sampled negatives) and cbow.py:26-60 (mean of context embeddings vs
+ *       centre + k sampled negatives).
+ *   - batch form of walk + window ........ sequences/tensorflow_sequences/node2vec_sequence.py
+ *       :115-128,:190-203  (contexts[n,2w], words[n]; n = walks*(walk_length-2w)).
+ *   - CSR convention ..................... pecanpy_embedders/node2vec.py:139-163.
+ *
+ * Everything random is counter based (splitmix64 finaliser keyed by seed/epoch/walk/draw) so the
+ * HIP implementation can reproduce walks bit-exactly and training to float tolerance.
+ *
+ * Plain C11; build: see oracle/Makefile.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define O_GOLDEN 0x9E3779B97F4A7C15ULL
+#define O_TAG_EPOCH 0x6E32764B45590A01ULL
+#define O_TAG_NEG 0xA5A5F00DC0FFEE11ULL
+#define O_TAG_DOWN 0x5BD1E995D00D1E55ULL
+#define O_TAG_BA 0xBA5EBA11BA5EBA11ULL
+#define O_TAG_INIT 0x1417AB1E00000000ULL
+#define O_SENTINEL 0xFFFFFFFFu
+#define O_MAX_TRIALS 32
+
+#define O_FLAG_SCALE_FREE 1u
+#define O_FLAG_DOWNSAMPLE 2u
+#define O_FLAG_NORM_LR 4u
+
+typedef struct {
+    uint32_t walk_length;
+    uint32_t iterations;
+    float return_weight;
+    float explore_weight;
+    uint32_t max_neighbours; /* accepted for API parity; walks are always exact */
+    uint32_t flags;
+} o_walk_params;
+
+typedef struct {
+    uint32_t model; /* 0 = SkipGram, 1 = CBOW */
+    uint32_t d;
+    uint32_t ld; /* row stride in floats (>= d) */
+    uint32_t epochs;
+    uint32_t k;
+    uint32_t window;
+    float lr;
+    float lr_decay;
+    float clip;
+    uint32_t flags;
+    float init_scale;
+} o_train_params;
+
+typedef struct {
+    uint64_t n_nodes;
+    uint64_t n_edges; /* directed */
+    const uint64_t *row_ptr;
+    const uint32_t *col_idx;
+    const float *cumw; /* per-row inclusive prefix sums of weights, or NULL */
+} o_graph;
+
+/* ---------------------------------------------------------------- RNG */
+
+uint64_t o_mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+
+uint64_t o_draw(uint64_t key, uint64_t t) { return o_mix64(key + (t + 1) * O_GOLDEN); }
+
+static inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+}
+
+uint64_t o_epoch_key(uint64_t seed, uint64_t epoch) {
+    return o_draw(o_mix64(seed ^ O_TAG_EPOCH), epoch);
+}
+
+uint64_t o_walk_key(uint64_t seed, uint64_t epoch, uint64_t walk_id) {
+    return o_draw(o_epoch_key(seed, epoch), walk_id);
+}
+
+/* ---------------------------------------------------------------- synthetic graph */
+
+/* Parallel-friendly Barabasi-Albert (pointer-chasing form of Batagelj-Brandes): edge e belongs
+ * to node v = e/m + 1 and attaches to the endpoint stored at a uniformly random earlier position
+ * of the virtual endpoint array; odd positions are resolved by re-deriving that edge's own draw. */
+static uint32_t ba_target(uint64_t bkey, uint64_t e, uint32_t m) {
+    for (;;) {
+        uint64_t v = e / m + 1;
+        uint64_t limit = 2 * (v - 1) * m + 1;
+        uint64_t x = mulhi64(o_draw(bkey, e), limit);
+        if (x == 0) return 0;
+        uint64_t p = x - 1;
+        uint64_t e2 = p >> 1;
+        if ((p & 1) == 0) return (uint32_t)(e2 / m + 1);
+        e = e2;
+    }
+}
+
+void o_ba_edges(uint64_t n_nodes, uint32_t m, uint64_t seed, uint32_t *src, uint32_t *dst) {
+    uint64_t bkey = o_mix64(seed ^ O_TAG_BA);
+    uint64_t n_e = (n_nodes - 1) * (uint64_t)m;
+    for (uint64_t e = 0; e < n_e; ++e) {
+        src[e] = (uint32_t)(e / m + 1);
+        dst[e] = ba_target(bkey, e, m);
+    }
+}
+
+/* ---------------------------------------------------------------- walks */
+
+static inline int adj_contains(const uint32_t *col, uint64_t lo, uint64_t hi, uint32_t x) {
+    uint64_t end = hi;
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (col[mid] < x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo < end && col[lo] == x;
+}
+
+/* integer acceptance thresholds on a 2^32 scale */
+static void thresholds(const o_walk_params *wp, uint64_t *t_ret, uint64_t *t_common,
+                       uint64_t *t_explore) {
+    double rw = wp->return_weight, ew = wp->explore_weight;
+    double mx = rw > ew ? rw : ew;
+    if (mx < 1.0) mx = 1.0;
+    double s = 4294967296.0;
+    *t_ret = (uint64_t)floor(rw / mx * s);
+    *t_common = (uint64_t)floor(1.0 / mx * s);
+    *t_explore = (uint64_t)floor(ew / mx * s);
+}
+
+/* candidate index within the row of `cur` (uniform, or weight proportional via cumw) */
+static inline uint64_t pick_index(const o_graph *g, uint64_t start, uint64_t deg, uint64_t r) {
+    if (g->cumw == NULL) return ((r >> 32) * deg) >> 32;
+    float total = g->cumw[start + deg - 1];
+    float f = (float)(r >> 40) * (1.0f / 16777216.0f) * total;
+    uint64_t lo = 0, hi = deg;
+    while (lo < hi) { /* first idx with cumw > f */
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (g->cumw[start + mid] > f)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo < deg ? lo : deg - 1;
+}
+
+void o_walk_one(const o_graph *g, const o_walk_params *wp, uint64_t wkey, uint32_t start_node,
+                uint32_t *out) {
+    uint32_t L = wp->walk_length;
+    int second = !(wp->return_weight == 1.0f && wp->explore_weight == 1.0f);
+    uint64_t t_ret, t_common, t_explore;
+    thresholds(wp, &t_ret, &t_common, &t_explore);
+    uint64_t ctr = 0;
+    uint32_t cur = start_node, prev = O_SENTINEL;
+    uint64_t pstart = 0, pend = 0;
+    out[0] = cur;
+    uint32_t t = 1;
+    for (; t < L; ++t) {
+        uint64_t start = g->row_ptr[cur], end = g->row_ptr[cur + 1];
+        uint64_t deg = end - start;
+        if (deg == 0) break;
+        uint32_t nxt;
+        if (!second || prev == O_SENTINEL || deg == 1) {
+            uint64_t r = o_draw(wkey, ctr++);
+            nxt = g->col_idx[start + pick_index(g, start, deg, r)];
+        } else {
+            int accepted = 0;
+            nxt = 0;
+            for (int trial = 0; trial < O_MAX_TRIALS; ++trial) {
+                uint64_t r = o_draw(wkey, ctr++);
+                uint32_t x = g->col_idx[start + pick_index(g, start, deg, r)];
+                uint64_t thr = (x == prev) ? t_ret
+                               : adj_contains(g->col_idx, pstart, pend, x) ? t_common
+                                                                           : t_explore;
+                if ((r & 0xFFFFFFFFULL) < thr) {
+                    nxt = x;
+                    accepted = 1;
+                    break;
+                }
+            }
+            if (!accepted) {
+                /* exact fallback: integer-weighted scan over the whole row (unweighted graphs);
+                 * weighted graphs scale each class threshold by the edge weight in double. */
+                uint64_t r = o_draw(wkey, ctr++);
+                if (g->cumw == NULL) {
+                    uint64_t total = 0;
+                    for (uint64_t i = 0; i < deg; ++i) {
+                        uint32_t x = g->col_idx[start + i];
+                        total += (x == prev) ? t_ret
+                                 : adj_contains(g->col_idx, pstart, pend, x) ? t_common
+                                                                             : t_explore;
+                    }
+                    if (total == 0) {
+                        nxt = g->col_idx[start + (((r >> 32) * deg) >> 32)];
+                    } else {
+                        uint64_t target = mulhi64(r, total), acc = 0;
+                        nxt = g->col_idx[start + deg - 1];
+                        for (uint64_t i = 0; i < deg; ++i) {
+                            uint32_t x = g->col_idx[start + i];
+                            acc += (x == prev) ? t_ret
+                                   : adj_contains(g->col_idx, pstart, pend, x) ? t_common
+                                                                               : t_explore;
+                            if (acc > target) {
+                                nxt = x;
+                                break;
+                            }
+                        }
+                    }
+                } else {
+                    double total = 0.0;
+                    for (uint64_t i = 0; i < deg; ++i) {
+                        uint32_t x = g->col_idx[start + i];
+                        double w = (double)g->cumw[start + i] -
+                                   (i ? (double)g->cumw[start + i - 1] : 0.0);
+                        uint64_t thr = (x == prev) ? t_ret
+                                       : adj_contains(g->col_idx, pstart, pend, x) ? t_common
+                                                                                   : t_explore;
+                        total += w * (double)thr;
+                    }
+                    double target = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+                    double acc = 0.0;
+                    nxt = g->col_idx[start + deg - 1];
+                    for (uint64_t i = 0; i < deg; ++i) {
+                        uint32_t x = g->col_idx[start + i];
+                        double w = (double)g->cumw[start + i] -
+                                   (i ? (double)g->cumw[start + i - 1] : 0.0);
+                        uint64_t thr = (x == prev) ? t_ret
+                                       : adj_contains(g->col_idx, pstart, pend, x) ? t_common
+                                                                                   : t_explore;
+                        acc += w * (double)thr;
+                        if (acc > target) {
+                            nxt = x;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        out[t] = nxt;
+        prev = cur;
+        pstart = start;
+        pend = end;
+        cur = nxt;
+    }
+    for (; t < L; ++t) out[t] = O_SENTINEL;
+}
+
+/* walks [first_walk, first_walk + n_walks) of the given epoch.  walk_id = iteration * n_sources +
+ * source_index; start node = sources[source_index] (or source_index when sources == NULL). */
+void o_walks(const o_graph *g, const o_walk_params *wp, const uint32_t *sources,
+             uint64_t n_sources, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+             uint64_t n_walks, uint32_t *out) {
+    uint64_t ekey = o_epoch_key(seed, epoch);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (uint64_t b = 0; b < n_walks; ++b) {
+        uint64_t wid = first_walk + b;
+        uint64_t si = wid % n_sources;
+        uint32_t s = sources ? sources[si] : (uint32_t)si;
+        o_walk_one(g, wp, o_draw(ekey, wid), s, out + b * wp->walk_length);
+    }
+}
+
+/* ---------------------------------------------------------------- tables */
+
+/* value(row, col) = (2 * u24 - 1) * scale, u24 from a hash of (seed, table, row * d + col) */
+void o_init_table(float *t, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
+                  uint32_t table_id, float scale) {
+    uint64_t key = o_mix64(seed ^ (O_TAG_INIT + table_id));
+    for (uint64_t r = 0; r < n_rows; ++r) {
+        for (uint32_t c = 0; c < ld; ++c) {
+            if (c >= d) {
+                t[r * ld + c] = 0.0f;
+                continue;
+            }
+            uint64_t h = o_draw(key, r * d + c);
+            float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+            t[r * ld + c] = (2.0f * u - 1.0f) * scale;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- training */
+
+static inline uint32_t draw_negative(const o_graph *g, const o_train_params *tp, uint64_t nkey,
+                                     uint64_t q) {
+    uint64_t r = o_draw(nkey, q);
+    if (tp->flags & O_FLAG_SCALE_FREE) return g->col_idx[mulhi64(r, g->n_edges)];
+    return (uint32_t)mulhi64(r, g->n_nodes);
+}
+
+static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+static inline uint32_t effective_len(const uint32_t *w, uint32_t L) {
+    uint32_t n = 0;
+    while (n < L && w[n] != O_SENTINEL) ++n;
+    return n;
+}
+
+/* stochastic_downsample_by_degree: keep a centre with probability min(1, mean_degree/degree) */
+static inline int keep_centre(const o_graph *g, const o_train_params *tp, uint64_t wkey,
+                              uint32_t i, uint32_t c) {
+    if (!(tp->flags & O_FLAG_DOWNSAMPLE)) return 1;
+    uint64_t deg = g->row_ptr[c + 1] - g->row_ptr[c];
+    if (deg == 0) return 1;
+    /* keep iff r32 * deg < mean_deg * 2^32  (integer form) */
+    uint64_t r32 = o_draw(wkey ^ O_TAG_DOWN, i) >> 32;
+    unsigned __int128 lhs = (unsigned __int128)r32 * deg * g->n_nodes;
+    unsigned __int128 rhs = (unsigned __int128)g->n_edges << 32;
+    return lhs < rhs;
+}
+
+static inline float centre_lr(const o_graph *g, const o_train_params *tp, float lr, uint32_t c) {
+    if (!(tp->flags & O_FLAG_NORM_LR)) return lr;
+    uint64_t deg = g->row_ptr[c + 1] - g->row_ptr[c];
+    return deg ? lr / (float)deg : lr;
+}
+
+/* One walk, SkipGram with negative sampling, strictly sequential ("Semantic S"):
+ * per centre the central row is copied to u, every (context, negatives...) sample updates the
+ * contextual table immediately, the accumulated gradient is added to the central row at the end
+ * of the centre.  neg_override (optional) = explicit negatives [L][2w][k] for this walk. */
+void o_sgns_walk(const o_graph *g, const o_train_params *tp, const uint32_t *walk, uint32_t L,
+                 uint64_t wkey, float lr, float *central, float *contextual,
+                 const uint32_t *neg_override, float *u, float *gacc) {
+    uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k;
+    uint32_t Le = effective_len(walk, L);
+    uint64_t nkey = wkey ^ O_TAG_NEG;
+    for (uint32_t i = 0; i < Le; ++i) {
+        uint32_t c = walk[i];
+        if (!keep_centre(g, tp, wkey, i, c)) continue;
+        float lrc = centre_lr(g, tp, lr, c);
+        float *crow = central + (uint64_t)c * ld;
+        memcpy(u, crow, d * sizeof(float));
+        memset(gacc, 0, d * sizeof(float));
+        uint32_t lo = i > w ? i - w : 0;
+        uint32_t hi = i + w < Le - 1 ? i + w : Le - 1;
+        for (uint32_t j = lo; j <= hi; ++j) {
+            if (j == i) continue;
+            uint32_t slot = j < i ? (j + w - i) : (j + w - i - 1); /* 0 .. 2w-1 */
+            uint32_t ctx = walk[j];
+            for (uint32_t s = 0; s <= k; ++s) {
+                uint32_t row;
+                float label;
+                if (s == 0) {
+                    row = ctx;
+                    label = 1.0f;
+                } else {
+                    uint64_t q = ((uint64_t)i * 2 * w + slot) * k + (s - 1);
+                    row = neg_override ? neg_override[q] : draw_negative(g, tp, nkey, q);
+                    label = 0.0f;
+                    if (row == c || row == ctx) continue;
+                }
+                float *v = contextual + (uint64_t)row * ld;
+                float dot = 0.0f;
+                for (uint32_t x = 0; x < d; ++x) dot += u[x] * v[x];
+                if (dot > tp->clip) dot = tp->clip;
+                if (dot < -tp->clip) dot = -tp->clip;
+                float var = (label - sigmoidf(dot)) * lrc;
+                for (uint32_t x = 0; x < d; ++x) {
+                    gacc[x] += var * v[x];
+                    v[x] += var * u[x];
+                }
+            }
+        }
+        for (uint32_t x = 0; x < d; ++x) crow[x] += gacc[x];
+    }
+}
+
+/* One walk, CBOW with negative sampling.  h = mean of the *contextual* rows of the window (the
+ * input side, cbow.py:37-42); the centre and k negatives are scored against the *central* table
+ * (the output side); the input gradient / C is added to every context row at the end. */
+void o_cbow_walk(const o_graph *g, const o_train_params *tp, const uint32_t *walk, uint32_t L,
+                 uint64_t wkey, float lr, float *central, float *contextual,
+                 const uint32_t *neg_override, float *h, float *gacc) {
+    uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k;
+    uint32_t Le = effective_len(walk, L);
+    uint64_t nkey = wkey ^ O_TAG_NEG;
+    for (uint32_t i = 0; i < Le; ++i) {
+        uint32_t c = walk[i];
+        if (!keep_centre(g, tp, wkey, i, c)) continue;
+        float lrc = centre_lr(g, tp, lr, c);
+        uint32_t lo = i > w ? i - w : 0;
+        uint32_t hi = i + w < Le - 1 ? i + w : Le - 1;
+        uint32_t C = hi - lo; /* window positions minus the centre */
+        if (C == 0) continue;
+        memset(h, 0, d * sizeof(float));
+        memset(gacc, 0, d * sizeof(float));
+        for (uint32_t j = lo; j <= hi; ++j) {
+            if (j == i) continue;
+            const float *row = contextual + (uint64_t)walk[j] * ld;
+            for (uint32_t x = 0; x < d; ++x) h[x] += row[x];
+        }
+        float invC = 1.0f / (float)C;
+        for (uint32_t x = 0; x < d; ++x) h[x] *= invC;
+        for (uint32_t s = 0; s <= k; ++s) {
+            uint32_t row;
+            float label;
+            if (s == 0) {
+                row = c;
+                label = 1.0f;
+            } else {
+                uint64_t q = (uint64_t)i * k + (s - 1);
+                row = neg_override ? neg_override[q] : draw_negative(g, tp, nkey, q);
+                label = 0.0f;
+                if (row == c) continue;
+            }
+            float *v = central + (uint64_t)row * ld;
+            float dot = 0.0f;
+            for (uint32_t x = 0; x < d; ++x) dot += h[x] * v[x];
+            if (dot > tp->clip) dot = tp->clip;
+            if (dot < -tp->clip) dot = -tp->clip;
+            float var = (label - sigmoidf(dot)) * lrc;
+            for (uint32_t x = 0; x < d; ++x) {
+                gacc[x] += var * v[x];
+                v[x] += var * h[x];
+            }
+        }
+        for (uint32_t j = lo; j <= hi; ++j) {
+            if (j == i) continue;
+            float *row = contextual + (uint64_t)walk[j] * ld;
+            for (uint32_t x = 0; x < d; ++x) row[x] += gacc[x] * invC;
+        }
+    }
+}
+
+/* Train on explicit walks [n_walks][L]; walk b has id first_walk + b in (seed, epoch).
+ * threads <= 1: strictly sequential in walk order (the parity oracle).
+ * threads  > 1: OpenMP over walks, unsynchronised updates (Hogwild) -- the CPU baseline. */
+void o_train_walks(const o_graph *g, const o_train_params *tp, const uint32_t *walks,
+                   uint64_t n_walks, uint32_t L, uint64_t seed, uint64_t epoch,
+                   uint64_t first_walk, float lr, float *central, float *contextual,
+                   const uint32_t *neg_override, int threads) {
+    uint64_t ekey = o_epoch_key(seed, epoch);
+    uint64_t per_walk_neg =
+        tp->model == 0 ? (uint64_t)L * 2 * tp->window * tp->k : (uint64_t)L * tp->k;
+#pragma omp parallel num_threads(threads > 1 ? threads : 1)
+    {
+        float *u = (float *)malloc(sizeof(float) * tp->d);
+        float *gacc = (float *)malloc(sizeof(float) * tp->d);
+#pragma omp for schedule(dynamic, 16)
+        for (uint64_t b = 0; b < n_walks; ++b) {
+            uint64_t wkey = o_draw(ekey, first_walk + b);
+            const uint32_t *ov = neg_override ? neg_override + b * per_walk_neg : NULL;
+            if (tp->model == 0)
+                o_sgns_walk(g, tp, walks + b * L, L, wkey, lr, central, contextual, ov, u, gacc);
+            else
+                o_cbow_walk(g, tp, walks + b * L, L, wkey, lr, central, contextual, ov, u, gacc);
+        }
+        free(u);
+        free(gacc);
+    }
+}
+
+/* Full fit: init both tables, then per epoch generate all walks and train on them in order.
+ * Returns the number of (centre, context) training pairs processed. */
+uint64_t o_fit(const o_graph *g, const o_walk_params *wp, const o_train_params *tp,
+               const uint32_t *sources, uint64_t n_sources, uint64_t seed, float *central,
+               float *contextual, int threads) {
+    o_init_table(central, g->n_nodes, tp->d, tp->ld, seed, 0, tp->init_scale);
+    o_init_table(contextual, g->n_nodes, tp->d, tp->ld, seed, 1, tp->init_scale);
+    uint64_t n_walks = n_sources * wp->iterations;
+    uint32_t L = wp->walk_length;
+    uint32_t *walks = (uint32_t *)malloc(sizeof(uint32_t) * n_walks * L);
+    float lr = tp->lr;
+    uint64_t pairs = 0;
+    for (uint32_t e = 0; e < tp->epochs; ++e) {
+        o_walks(g, wp, sources, n_sources, seed, e, 0, n_walks, walks);
+        o_train_walks(g, tp, walks, n_walks, L, seed, e, 0, lr, central, contextual, NULL,
+                      threads);
+        for (uint64_t b = 0; b < n_walks; ++b) {
+            uint32_t Le = effective_len(walks + b * L, L), w = tp->window;
+            for (uint32_t i = 0; i < Le; ++i) {
+                uint32_t lo = i > w ? i - w : 0, hi = i + w < Le - 1 ? i + w : Le - 1;
+                pairs += hi - lo;
+            }
+        }
+        lr *= tp->lr_decay;
+    }
+    free(walks);
+    return pairs;
+}
+
+/* Node2VecSequence batch form (node2vec_sequence.py:115-128,190-203): for every walk position
+ * with a full window emit words[n] = centre and contexts[n][2w] = the 2w surrounding nodes. */
+uint64_t o_window_batch(const uint32_t *walks, uint64_t n_walks, uint32_t L, uint32_t w,
+                        int32_t *contexts, int32_t *words) {
+    uint64_t n = 0;
+    for (uint64_t b = 0; b < n_walks; ++b) {
+        const uint32_t *wk = walks + b * L;
+        for (uint32_t i = w; i + w < L; ++i) {
+            words[n] = (int32_t)wk[i];
+            uint32_t s = 0;
+            for (uint32_t j = i - w; j <= i + w; ++j)
+                if (j != i) contexts[n * 2 * w + s++] = (int32_t)wk[j];
+            ++n;
+        }
+    }
+    return n;
+}

@@ -1,0 +1,185 @@
+"""ctypes front-end of the CPU oracle (``oracle/gn2v_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY -- imported by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``; never by ``embiggen_amd``.  PARITY UNPINNED: see the header
+of ``gn2v_oracle.c`` (the reference's arithmetic lives in the un-vendored ``ensmallen`` wheel,
+``embiggen/embedders/ensmallen_embedders/node2vec.py:99``).
+
+Everything takes / returns plain numpy arrays.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SENTINEL = 0xFFFFFFFF
+
+FLAG_SCALE_FREE = 1
+FLAG_DOWNSAMPLE = 2
+FLAG_NORM_LR = 4
+
+
+class WalkParams(C.Structure):
+    _fields_ = [
+        ("walk_length", C.c_uint32),
+        ("iterations", C.c_uint32),
+        ("return_weight", C.c_float),
+        ("explore_weight", C.c_float),
+        ("max_neighbours", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class TrainParams(C.Structure):
+    _fields_ = [
+        ("model", C.c_uint32),
+        ("d", C.c_uint32),
+        ("ld", C.c_uint32),
+        ("epochs", C.c_uint32),
+        ("k", C.c_uint32),
+        ("window", C.c_uint32),
+        ("lr", C.c_float),
+        ("lr_decay", C.c_float),
+        ("clip", C.c_float),
+        ("flags", C.c_uint32),
+        ("init_scale", C.c_float),
+    ]
+
+
+class Graph(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_uint64),
+        ("n_edges", C.c_uint64),
+        ("row_ptr", C.c_void_p),
+        ("col_idx", C.c_void_p),
+        ("cumw", C.c_void_p),
+    ]
+
+
+def build(force: bool = False, asan: bool = False) -> str:
+    """Compile the oracle with gcc (idempotent) and return the path of the shared object."""
+    target = "libgn2v_oracle_asan.so" if asan else "libgn2v_oracle.so"
+    path = os.path.join(_HERE, target)
+    src = os.path.join(_HERE, "gn2v_oracle.c")
+    if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
+    return path
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.o_mix64.restype = C.c_uint64
+        _lib.o_mix64.argtypes = [C.c_uint64]
+        _lib.o_draw.restype = C.c_uint64
+        _lib.o_draw.argtypes = [C.c_uint64, C.c_uint64]
+        _lib.o_walk_key.restype = C.c_uint64
+        _lib.o_walk_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        _lib.o_fit.restype = C.c_uint64
+        _lib.o_window_batch.restype = C.c_uint64
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class OracleGraph:
+    """Holds CSR arrays (kept alive) and the C struct that points at them."""
+
+    def __init__(self, row_ptr, col_idx, cumw=None):
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        self.col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        self.cumw = None if cumw is None else np.ascontiguousarray(cumw, dtype=np.float32)
+        self.n_nodes = len(self.row_ptr) - 1
+        self.n_edges = len(self.col_idx)
+        self.c = Graph(
+            self.n_nodes,
+            self.n_edges,
+            self.row_ptr.ctypes.data,
+            self.col_idx.ctypes.data,
+            None if self.cumw is None else self.cumw.ctypes.data,
+        )
+
+
+def mix64(z: int) -> int:
+    return lib().o_mix64(C.c_uint64(z & (2**64 - 1)))
+
+
+def ba_edges(n_nodes: int, m: int, seed: int):
+    n_e = (n_nodes - 1) * m
+    src = np.empty(n_e, dtype=np.uint32)
+    dst = np.empty(n_e, dtype=np.uint32)
+    lib().o_ba_edges(C.c_uint64(n_nodes), C.c_uint32(m), C.c_uint64(seed), _ptr(src), _ptr(dst))
+    return src, dst
+
+
+def walks(g: OracleGraph, wp: WalkParams, seed: int, epoch: int, first_walk: int, n_walks: int,
+          sources=None):
+    if sources is None:
+        n_sources = g.n_nodes
+    else:
+        sources = np.ascontiguousarray(sources, dtype=np.uint32)
+        n_sources = len(sources)
+    out = np.empty((n_walks, wp.walk_length), dtype=np.uint32)
+    lib().o_walks(C.byref(g.c), C.byref(wp), _ptr(sources), C.c_uint64(n_sources),
+                  C.c_uint64(seed), C.c_uint64(epoch), C.c_uint64(first_walk),
+                  C.c_uint64(n_walks), _ptr(out))
+    return out
+
+
+def init_table(n_rows: int, d: int, ld: int, seed: int, table_id: int, scale: float):
+    t = np.empty((n_rows, ld), dtype=np.float32)
+    lib().o_init_table(_ptr(t), C.c_uint64(n_rows), C.c_uint32(d), C.c_uint32(ld),
+                       C.c_uint64(seed), C.c_uint32(table_id), C.c_float(scale))
+    return t
+
+
+def train_walks(g: OracleGraph, tp: TrainParams, walks_arr, seed: int, epoch: int,
+                first_walk: int, lr: float, central, contextual, neg_override=None,
+                threads: int = 1):
+    """In-place update of ``central`` / ``contextual`` ([N, ld] float32, C-contiguous)."""
+    walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
+    assert central.flags.c_contiguous and contextual.flags.c_contiguous
+    assert central.dtype == np.float32 and contextual.dtype == np.float32
+    if neg_override is not None:
+        neg_override = np.ascontiguousarray(neg_override, dtype=np.uint32)
+    n_walks, L = walks_arr.shape
+    lib().o_train_walks(C.byref(g.c), C.byref(tp), _ptr(walks_arr), C.c_uint64(n_walks),
+                        C.c_uint32(L), C.c_uint64(seed), C.c_uint64(epoch),
+                        C.c_uint64(first_walk), C.c_float(lr), _ptr(central), _ptr(contextual),
+                        _ptr(neg_override), C.c_int(threads))
+
+
+def fit(g: OracleGraph, wp: WalkParams, tp: TrainParams, seed: int, sources=None,
+        threads: int = 1):
+    """Full fit_transform restatement -> (central, contextual, n_pairs)."""
+    if sources is None:
+        n_sources = g.n_nodes
+    else:
+        sources = np.ascontiguousarray(sources, dtype=np.uint32)
+        n_sources = len(sources)
+    central = np.empty((g.n_nodes, tp.ld), dtype=np.float32)
+    contextual = np.empty((g.n_nodes, tp.ld), dtype=np.float32)
+    pairs = lib().o_fit(C.byref(g.c), C.byref(wp), C.byref(tp), _ptr(sources),
+                        C.c_uint64(n_sources), C.c_uint64(seed), _ptr(central),
+                        _ptr(contextual), C.c_int(threads))
+    return central, contextual, int(pairs)
+
+
+def window_batch(walks_arr, window: int):
+    walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
+    n_walks, L = walks_arr.shape
+    n = n_walks * max(L - 2 * window, 0)
+    contexts = np.empty((n, 2 * window), dtype=np.int32)
+    words = np.empty(n, dtype=np.int32)
+    got = lib().o_window_batch(_ptr(walks_arr), C.c_uint64(n_walks), C.c_uint32(L),
+                               C.c_uint32(window), _ptr(contexts), _ptr(words))
+    assert got == n
+    return contexts, words
