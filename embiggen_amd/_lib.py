@@ -20,7 +20,8 @@ TRAIN_SCALE_FREE = 1
 TRAIN_DOWNSAMPLE = 2
 TRAIN_NORM_LR = 4
 TRAIN_DETERMINISTIC = 8
-TRAIN_HOGWILD_STORES = 16
+TRAIN_ATOMIC = 16
+TRAIN_WRITE_BACK = 32
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 

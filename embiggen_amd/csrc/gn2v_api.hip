@@ -141,24 +141,28 @@ int check_train_params(const gn2v_train_params *tp, uint32_t L) {
 }
 
 template <int CH>
-int launch_train_ch(bool cbow, bool atomic, bool det, dim3 grid, dim3 block, size_t lds,
+int launch_train_ch(bool cbow, int wm, bool det, dim3 grid, dim3 block, size_t lds,
                     hipStream_t s, const gn2v::TrainArgs &a) {
-#define GN2V_LAUNCH(KERNEL, AT, DT) \
-    hipLaunchKernelGGL((gn2v::KERNEL<CH, AT, DT>), grid, block, lds, s, a)
+#define GN2V_LAUNCH(KERNEL, WM, DT) \
+    hipLaunchKernelGGL((gn2v::KERNEL<CH, WM, DT>), grid, block, lds, s, a)
     if (!cbow) {
         if (det)
-            GN2V_LAUNCH(sgns_kernel, false, true);
-        else if (atomic)
-            GN2V_LAUNCH(sgns_kernel, true, false);
+            GN2V_LAUNCH(sgns_kernel, gn2v::kWriteBack, true);
+        else if (wm == gn2v::kAtomic)
+            GN2V_LAUNCH(sgns_kernel, gn2v::kAtomic, false);
+        else if (wm == gn2v::kWriteBack)
+            GN2V_LAUNCH(sgns_kernel, gn2v::kWriteBack, false);
         else
-            GN2V_LAUNCH(sgns_kernel, false, false);
+            GN2V_LAUNCH(sgns_kernel, gn2v::kWriteThrough, false);
     } else {
         if (det)
-            GN2V_LAUNCH(cbow_kernel, false, true);
-        else if (atomic)
-            GN2V_LAUNCH(cbow_kernel, true, false);
+            GN2V_LAUNCH(cbow_kernel, gn2v::kWriteBack, true);
+        else if (wm == gn2v::kAtomic)
+            GN2V_LAUNCH(cbow_kernel, gn2v::kAtomic, false);
+        else if (wm == gn2v::kWriteBack)
+            GN2V_LAUNCH(cbow_kernel, gn2v::kWriteBack, false);
         else
-            GN2V_LAUNCH(cbow_kernel, false, false);
+            GN2V_LAUNCH(cbow_kernel, gn2v::kWriteThrough, false);
     }
 #undef GN2V_LAUNCH
     return 0;
@@ -191,7 +195,9 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const ui
     a.clip = tp->clip;
 
     const bool det = tp->flags & GN2V_TRAIN_DETERMINISTIC;
-    const bool atomic = !(tp->flags & GN2V_TRAIN_HOGWILD_STORES);
+    const int wm = (tp->flags & GN2V_TRAIN_ATOMIC)       ? gn2v::kAtomic
+                   : (tp->flags & GN2V_TRAIN_WRITE_BACK) ? gn2v::kWriteBack
+                                                         : gn2v::kWriteThrough;
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
     const size_t lds = (size_t)waves_per_block * (L + 2 * (size_t)a.max_samples) * 4;
     if (lds > 64 * 1024) return fail("walk_length / window / negatives too large for the LDS plan");
@@ -205,13 +211,13 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const ui
     HIP_TRY(hipEventRecord(ev.a, s));
     const uint32_t nchunks = tp->ld / 4;
     if (nchunks <= 16)
-        launch_train_ch<1>(cbow, atomic, det, grid, block, lds, s, a);
+        launch_train_ch<1>(cbow, wm, det, grid, block, lds, s, a);
     else if (nchunks <= 32)
-        launch_train_ch<2>(cbow, atomic, det, grid, block, lds, s, a);
+        launch_train_ch<2>(cbow, wm, det, grid, block, lds, s, a);
     else if (nchunks <= 64)
-        launch_train_ch<4>(cbow, atomic, det, grid, block, lds, s, a);
+        launch_train_ch<4>(cbow, wm, det, grid, block, lds, s, a);
     else
-        launch_train_ch<8>(cbow, atomic, det, grid, block, lds, s, a);
+        launch_train_ch<8>(cbow, wm, det, grid, block, lds, s, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, s));
     g->train_events.push_back(ev);

@@ -10,8 +10,9 @@
 // round trip).  Dot products reduce inside a group with 4 DPP steps (quad_perm, quad_perm,
 // row_half_mirror, row_mirror) -- no LDS, bit-identical in every lane of the group.  The centre
 // row and its gradient stay in registers across the <= 2w*(k+1) samples of a centre.  Sample rows
-// are updated with hardware f32 atomics on HBM (default) or racy read-modify-write stores
-// (Hogwild, like the CPU reference).  HBM-bound: ~0.75 flop/B, MFMA is not used.
+// are updated by racy read-modify-write 16 B stores (Hogwild, like the CPU reference; default
+// write-through so every XCD sees them) or by hardware f32 atomics on HBM (exact accumulation,
+// measured ~10x slower: 128 atomics per row).  HBM-bound: ~0.75 flop/B, MFMA is not used.
 #pragma once
 #include "rng.h"
 #include "walk_kernels.h"
@@ -97,8 +98,24 @@ __device__ __forceinline__ void axpy(Row<CH> &acc, float s, const Row<CH> &x) {
     }
 }
 
-// table row += s * x   (ATOMIC: hardware f32 atomics; else store old + s*x)
-template <int CH, bool ATOMIC>
+// How a row update reaches memory.
+//   kWriteThrough: read-modify-write, 16 B stores with sc1 (write-through, line dropped from the
+//                  XCD's L2) -- Hogwild like the CPU reference, visible to every XCD at once.
+//   kWriteBack:    read-modify-write, plain stores (dirty lines stay private to an XCD's L2
+//                  until evicted: hot rows diverge per XCD inside a launch).
+//   kAtomic:       hardware f32 atomics, one per element (no lost update, ~10x the store cost).
+enum WriteMode : int { kWriteThrough = 0, kWriteBack = 1, kAtomic = 2 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store_sc1(float *p, float4 v) {
+    f32x4 r = {v.x, v.y, v.z, v.w};
+    // the trailing s_nop keeps hipcc from reusing the data registers before the store read them
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+}
+
+// table row += s * x
+template <int CH, int WM>
 __device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks, float s,
                                             const Row<CH> &x, const Row<CH> &old) {
 #pragma unroll
@@ -106,7 +123,7 @@ __device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks
         const uint32_t ci = cc * 16 + q;
         if (ci < nchunks) {
             float *p = base + ci * 4;
-            if constexpr (ATOMIC) {
+            if constexpr (WM == kAtomic) {
                 unsafeAtomicAdd(p + 0, s * x.c[cc].x);
                 unsafeAtomicAdd(p + 1, s * x.c[cc].y);
                 unsafeAtomicAdd(p + 2, s * x.c[cc].z);
@@ -117,7 +134,10 @@ __device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks
                 o.y += s * x.c[cc].y;
                 o.z += s * x.c[cc].z;
                 o.w += s * x.c[cc].w;
-                *reinterpret_cast<float4 *>(p) = o;
+                if constexpr (WM == kWriteThrough)
+                    store_sc1(p, o);
+                else
+                    *reinterpret_cast<float4 *>(p) = o;
             }
         }
     }
@@ -185,7 +205,7 @@ __device__ __forceinline__ uint32_t stage_walk(const TrainArgs &a, uint64_t b, u
 // Score the staged sample list against the register row `u` (replicated in every group):
 // for each sample row v: var = (label - sigmoid(clip(u.v))) * lr ; g += var * v ; v += var * u.
 // DET: one sample at a time, all groups redundantly, group 0 writes (strict sequential semantics).
-template <int CH, bool ATOMIC, bool DET>
+template <int CH, int WM, bool DET>
 __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, const Row<CH> &u,
                                               Row<CH> &g, const uint32_t *s_rows,
                                               const float *s_lab, uint32_t n_samples, float lrc,
@@ -201,7 +221,7 @@ __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, 
             const float dot = dot_rows<CH>(u, v);
             const float var = (s_lab[t] - sigmoid_clipped(dot, a.clip)) * lrc;
             axpy<CH>(g, var, v);
-            if (grp == 0) scatter_add<CH, false>(base, q, nchunks, var, u, v);
+            if (grp == 0) scatter_add<CH, kWriteBack>(base, q, nchunks, var, u, v);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         }
     } else {
@@ -217,7 +237,7 @@ __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, 
             const float dot = dot_rows<CH>(u, v);
             const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
             axpy<CH>(g, var, v);
-            if (valid) scatter_add<CH, ATOMIC>(base, q, nchunks, var, u, v);
+            if (valid) scatter_add<CH, WM>(base, q, nchunks, var, u, v);
         }
     }
 }
@@ -232,7 +252,7 @@ constexpr int kTrainBlock = 256;
 
 // SkipGram with negative sampling over a batch of walks.
 // LDS per wave: walk[L] | rows[max_samples] | labels[max_samples].
-template <int CH, bool ATOMIC, bool DET>
+template <int CH, int WM, bool DET>
 __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -291,10 +311,10 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
             Row<CH> u, g;
             load_row<CH>(u, crow, q, nchunks, true);
             zero_row<CH>(g);
-            score_samples<CH, ATOMIC, DET>(a, a.contextual, u, g, s_rows, s_lab, n_samples, lrc,
+            score_samples<CH, WM, DET>(a, a.contextual, u, g, s_rows, s_lab, n_samples, lrc,
                                            grp, q);
             if constexpr (!DET) reduce_groups<CH>(g);
-            if (grp == 0) scatter_add<CH, ATOMIC && !DET>(crow, q, nchunks, 1.0f, g, u);
+            if (grp == 0) scatter_add<CH, DET ? kWriteBack : WM>(crow, q, nchunks, 1.0f, g, u);
             if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             pairs += n_ctx;
             ++centres;
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
 // CBOW with negative sampling: h = mean of the window's *contextual* rows (input side), scored
 // against the centre and k negatives in the *central* table (output side); the input gradient / C
 // goes back to every context row.
-template <int CH, bool ATOMIC, bool DET>
+template <int CH, int WM, bool DET>
 __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                 h.c[cc].w *= invC;
             }
 
-            score_samples<CH, ATOMIC, DET>(a, a.central, h, g, s_rows, s_lab, k + 1, lrc, grp, q);
+            score_samples<CH, WM, DET>(a, a.central, h, g, s_rows, s_lab, k + 1, lrc, grp, q);
             if constexpr (!DET) reduce_groups<CH>(g);
 
             // every context row += g / C
@@ -400,7 +420,7 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                     float *base = a.contextual + (uint64_t)s_walk[j] * a.ld;
                     Row<CH> v;
                     load_row<CH>(v, base, q, nchunks, true);
-                    if (grp == 0) scatter_add<CH, false>(base, q, nchunks, invC, g, v);
+                    if (grp == 0) scatter_add<CH, kWriteBack>(base, q, nchunks, invC, g, v);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                 }
             } else {
@@ -411,8 +431,8 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                         if (j >= i) ++j;
                         float *base = a.contextual + (uint64_t)s_walk[j] * a.ld;
                         Row<CH> v;
-                        if constexpr (!ATOMIC) load_row<CH>(v, base, q, nchunks, true);
-                        scatter_add<CH, ATOMIC>(base, q, nchunks, invC, g, v);
+                        if constexpr (WM != kAtomic) load_row<CH>(v, base, q, nchunks, true);
+                        scatter_add<CH, WM>(base, q, nchunks, invC, g, v);
                     }
                 }
             }

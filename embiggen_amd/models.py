@@ -60,7 +60,7 @@ class _WalkBasedModel:
         verbose: bool = True,
         alpha: float = 0.75,
         deterministic: bool = False,
-        hogwild: bool = False,
+        update_mode: str = "write_through",
         device: int = 0,
     ):
         if not isinstance(embedding_size, int) or embedding_size < 1:
@@ -109,7 +109,9 @@ class _WalkBasedModel:
         self.verbose = bool(verbose)
         self.alpha = alpha
         self.deterministic = bool(deterministic)
-        self.hogwild = bool(hogwild)
+        if update_mode not in ("write_through", "write_back", "atomic"):
+            raise ValueError("update_mode must be 'write_through', 'write_back' or 'atomic'.")
+        self.update_mode = update_mode
         self.device = int(device)
         self.last_stats = None
         self.last_seconds = None
@@ -135,8 +137,10 @@ class _WalkBasedModel:
             flags |= _lib.TRAIN_NORM_LR
         if self.deterministic:
             flags |= _lib.TRAIN_DETERMINISTIC
-        if self.hogwild:
-            flags |= _lib.TRAIN_HOGWILD_STORES
+        if self.update_mode == "atomic":
+            flags |= _lib.TRAIN_ATOMIC
+        elif self.update_mode == "write_back":
+            flags |= _lib.TRAIN_WRITE_BACK
         return _lib.TrainParams(
             self.MODEL_ID, self.embedding_size, self.padded_size, self.epochs,
             self.number_of_negative_samples, self.window_size, self.learning_rate,

@@ -39,7 +39,7 @@ SCHEMA: Dict[str, Tuple[str, ...]] = {
     "alpha": ("float",),
     # engine-specific extensions (not in the reference)
     "deterministic": ("bool",),
-    "hogwild": ("bool",),
+    "update_mode": ("str",),
     "device": ("int",),
 }
 

@@ -40,7 +40,10 @@ extern "C" {
 #define GN2V_TRAIN_DOWNSAMPLE 2u     /* stochastic_downsample_by_degree (:97-98)                */
 #define GN2V_TRAIN_NORM_LR 4u        /* normalize_learning_rate_by_degree (:99-100)             */
 #define GN2V_TRAIN_DETERMINISTIC 8u  /* one wavefront, strict walk order: oracle-exact, slow    */
-#define GN2V_TRAIN_HOGWILD_STORES 16u /* racy read-modify-write stores instead of HBM atomics   */
+/* Row updates default to Hogwild read-modify-write with write-through 16 B stores (the CPU
+ * reference is racy by design as well).  Alternatives: */
+#define GN2V_TRAIN_ATOMIC 16u        /* hardware f32 atomics on every element: no lost update   */
+#define GN2V_TRAIN_WRITE_BACK 32u    /* plain (L2 write-back) stores: fastest, per-XCD staleness */
 
 #define GN2V_MODEL_SKIPGRAM 0u
 #define GN2V_MODEL_CBOW 1u

@@ -1,0 +1,28 @@
+"""Freezes a few outputs of the CPU oracle into ``oracle_karate.npz`` (self-golden: a regression
+pin between rounds, NOT a reference-derived vector -- the reference has none).
+
+    python tests/golden/make_oracle_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import embiggen_amd as E  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+if __name__ == "__main__":
+    g = E.karate_club()
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    wp = O.WalkParams(16, 2, 0.25, 4.0, 100, 0)
+    out = {"walks": O.walks(og, wp, 42, 0, 0, 68)}
+    for model, key in ((0, "sgns"), (1, "cbow")):
+        tp = O.TrainParams(model, 8, 8, 2, 4, 3, 0.01, 0.9, 6.0, 1, 8 ** -0.5)
+        c, x, pairs = O.fit(og, wp, tp, 42)
+        out[f"{key}_central"], out[f"{key}_contextual"], out[f"{key}_pairs"] = c, x, pairs
+    out["ba_dst"] = O.ba_edges(500, 3, 42)[1]
+    np.savez_compressed(os.path.join(HERE, "oracle_karate.npz"), **out)
+    print("written", {k: np.shape(v) for k, v in out.items()})

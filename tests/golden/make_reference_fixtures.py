@@ -1,0 +1,113 @@
+"""Generates the reference-derived fixtures in this directory.  Run in the build container only
+(needs /root/reference; the GPU box never runs this):
+
+    python tests/golden/make_reference_fixtures.py
+
+1. ``embedding_result_cases.json`` -- outcomes of the reference's own ``EmbeddingResult``
+   (embiggen/utils/abstract_models/embedding_result.py, the only reference module importable
+   without ensmallen) on the scenarios of the reference's tests/test_embedding_result.py:12-90
+   plus a few more; our ``EmbeddingResult`` must reproduce every outcome.
+2. ``api_defaults.json`` -- constructor signatures/defaults of the walk-based wrappers,
+   ``smoke_test_parameters`` and the "removed" parameter lists, read from the reference sources
+   with ``ast`` (no import), and the declared types of those kwargs from
+   ``embiggen/utils/normalization_schemas.json``.
+
+Only data (inputs -> expected outcomes, names -> default values) is written; no reference source
+text is stored.
+"""
+import ast
+import importlib.util
+import json
+import os
+import sys
+
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from helpers import probe, scenarios  # noqa: E402
+
+
+def embedding_result_cases():
+    spec = importlib.util.spec_from_file_location(
+        "ref_embedding_result",
+        os.path.join(REF, "embiggen/utils/abstract_models/embedding_result.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return {name: probe(mod.EmbeddingResult, kw) for name, kw in scenarios().items()}
+
+
+def _literal(node):
+    try:
+        return ast.literal_eval(node)
+    except Exception:  # noqa: BLE001
+        return ast.unparse(node)
+
+
+def class_defaults(path, class_name):
+    tree = ast.parse(open(path).read())
+    out = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == class_name:
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name == "__init__":
+                    args = fn.args.args[1:]
+                    defaults = fn.args.defaults
+                    names = [a.arg for a in args]
+                    out["init"] = {
+                        n: _literal(d) for n, d in zip(names[len(names) - len(defaults):], defaults)
+                    }
+                    out["init_order"] = names
+                if isinstance(fn, ast.FunctionDef) and fn.name == "model_name":
+                    out["model_name"] = [
+                        _literal(n.value) for n in ast.walk(fn) if isinstance(n, ast.Return)][0]
+                if isinstance(fn, ast.FunctionDef) and fn.name == "parameters":
+                    for n in ast.walk(fn):
+                        if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "removed":
+                            out["removed"] = _literal(n.value)
+                if isinstance(fn, ast.FunctionDef) and fn.name == "smoke_test_parameters":
+                    for n in ast.walk(fn):
+                        if isinstance(n, ast.Return) and isinstance(n.value, ast.Call):
+                            out["smoke_test_parameters"] = {
+                                kw.arg: _literal(kw.value) for kw in n.value.keywords}
+                if isinstance(fn, ast.FunctionDef) and fn.name in (
+                        "task_name", "library_name", "is_topological", "is_stocastic",
+                        "requires_nodes_sorted_by_decreasing_node_degree", "requires_edge_weights",
+                        "requires_positive_edge_weights", "can_use_edge_weights",
+                        "can_use_node_types", "can_use_edge_types", "requires_node_types",
+                        "requires_edge_types"):
+                    rets = [n for n in ast.walk(fn) if isinstance(n, ast.Return)]
+                    if len(rets) == 1:
+                        out.setdefault("flags", {})[fn.name] = _literal(rets[0].value)
+    return out
+
+
+def api_defaults():
+    base = os.path.join(REF, "embiggen/embedders/ensmallen_embedders")
+    classes = {
+        "Node2VecSkipGramEnsmallen": "node2vec_skipgram.py",
+        "Node2VecCBOWEnsmallen": "node2vec_cbow.py",
+        "DeepWalkSkipGramEnsmallen": "deepwalk_skipgram.py",
+        "DeepWalkCBOWEnsmallen": "deepwalk_cbow.py",
+        "Node2VecEnsmallen": "node2vec.py",
+        "EnsmallenEmbedder": "ensmallen_embedder.py",
+    }
+    out = {name: class_defaults(os.path.join(base, f), name) for name, f in classes.items()}
+    schema = json.load(open(os.path.join(REF, "embiggen/utils/normalization_schemas.json")))
+    keys = set()
+    for name in classes:
+        keys.update(out[name].get("init", {}).keys())
+    keys.update(["embedding_size", "random_state", "alpha"])
+    out["schema_types"] = {k: schema[k] for k in sorted(keys) if k in schema}
+    out["sequence_defaults"] = class_defaults(
+        os.path.join(REF, "embiggen/sequences/tensorflow_sequences/node2vec_sequence.py"),
+        "Node2VecSequence").get("init", {})
+    return out
+
+
+if __name__ == "__main__":
+    with open(os.path.join(HERE, "embedding_result_cases.json"), "w") as f:
+        json.dump(embedding_result_cases(), f, indent=1, sort_keys=True)
+    with open(os.path.join(HERE, "api_defaults.json"), "w") as f:
+        json.dump(api_defaults(), f, indent=1, sort_keys=True)
+    print("written")

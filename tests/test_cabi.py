@@ -1,0 +1,66 @@
+"""The C-ABI library loads and exports every symbol include/gn2v.h declares (no compute calls:
+this runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from embiggen_amd import _lib
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include",
+                      "gn2v.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gn2v_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(_lib.build())
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    assert _lib.lib().gn2v_version() == 100
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.WalkParams) == 24
+    assert C.sizeof(_lib.TrainParams) == 44
+    assert C.sizeof(_lib.Stats) == 48
+    text = open(HEADER).read()
+    for name, value in (("GN2V_TRAIN_SCALE_FREE", _lib.TRAIN_SCALE_FREE),
+                        ("GN2V_TRAIN_DOWNSAMPLE", _lib.TRAIN_DOWNSAMPLE),
+                        ("GN2V_TRAIN_NORM_LR", _lib.TRAIN_NORM_LR),
+                        ("GN2V_TRAIN_DETERMINISTIC", _lib.TRAIN_DETERMINISTIC),
+                        ("GN2V_TRAIN_ATOMIC", _lib.TRAIN_ATOMIC),
+                        ("GN2V_TRAIN_WRITE_BACK", _lib.TRAIN_WRITE_BACK),
+                        ("GN2V_GRAPH_DEVICE_PTRS", _lib.GRAPH_DEVICE_PTRS)):
+        assert re.search(rf"#define {name} {value}u", text), name
+
+
+def test_errors_are_reported_not_thrown():
+    L = _lib.lib()
+    handle = C.c_void_p()
+    rp = np.array([0, 1, 2], dtype=np.uint64)
+    ci = np.array([1, 0], dtype=np.uint32)
+    assert L.gn2v_graph_create(None, None, None, None, 2, 2, 2, 0, 0, C.byref(handle)) != 0
+    assert b"NULL" in L.gn2v_last_error()
+    assert L.gn2v_graph_create(rp.ctypes.data, ci.ctypes.data, None, None, 0, 2, 0, 0, 0,
+                               C.byref(handle)) != 0
+    assert b"no nodes" in L.gn2v_last_error()
+    if _lib.device_count() == 0:
+        assert L.gn2v_graph_create(rp.ctypes.data, ci.ctypes.data, None, None, 2, 2, 2, 0, 0,
+                                   C.byref(handle)) != 0
+        assert b"no CPU fallback" in L.gn2v_last_error()
+        with pytest.raises(RuntimeError):
+            _lib.require_device()
+    assert L.gn2v_walks(None, None, 0, 0, 0, 0, None, None) != 0
+    assert L.gn2v_train(None, None, None, 0, 0, None, None, None, None) != 0
+    assert L.gn2v_graph_destroy(None) == 0

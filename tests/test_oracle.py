@@ -1,0 +1,251 @@
+"""CPU tests that pin the oracle (oracle/gn2v_oracle.c).
+
+The reference holds no golden vectors for this path (parity unpinned), so the
+oracle is pinned by (a) the published known-answer vector of its RNG, (b) independent
+re-derivations -- exact node2vec transition probabilities, torch-autograd gradients of the
+negative-sampling loss, the closed-form pair count -- and (c) committed self-goldens that freeze
+its outputs between rounds (tests/golden/oracle_karate.npz, made by tests/golden/make_oracle_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import stats
+
+import embiggen_amd as E
+from helpers import GOLDEN, exact_second_order_probs, link_auc, ring_of_cliques
+from oracle import oracle as O
+
+
+def test_splitmix64_known_answers():
+    """First three outputs of splitmix64 seeded with 0 (Vigna's published test vector)."""
+    L = O.lib()
+    assert L.o_draw(0, 0) == 0xE220A8397B1DCDAF
+    assert L.o_draw(0, 1) == 0x6E789E6AA1B965F4
+    assert L.o_draw(0, 2) == 0x06C45D188009454F
+
+
+def test_walks_follow_edges_and_are_reproducible(karate, karate_oracle):
+    wp = O.WalkParams(32, 10, 0.25, 4.0, 100, 0)
+    w = O.walks(karate_oracle, wp, 42, 0, 0, 340)
+    assert w.shape == (340, 32) and w.dtype == np.uint32
+    rp, ci = karate.row_ptr.astype(np.int64), karate.col_idx
+    for b in range(340):
+        assert w[b, 0] == b % 34  # walk_id = iteration * n_sources + source
+        for t in range(31):
+            assert w[b, t + 1] in ci[rp[w[b, t]]:rp[w[b, t] + 1]]
+    # same (seed, epoch) -> same walks, whatever the batch split
+    again = np.concatenate([O.walks(karate_oracle, wp, 42, 0, 0, 100),
+                            O.walks(karate_oracle, wp, 42, 0, 100, 240)])
+    assert np.array_equal(w, again)
+    assert not np.array_equal(w, O.walks(karate_oracle, wp, 42, 1, 0, 340))
+    assert not np.array_equal(w, O.walks(karate_oracle, wp, 43, 0, 0, 340))
+
+
+@pytest.mark.parametrize("rw,ew", [(1.0, 1.0), (0.25, 4.0), (2.0, 0.5), (4.0, 0.25)])
+def test_second_order_transition_distribution(karate, karate_oracle, rw, ew):
+    """Empirical (prev, cur) -> next frequencies match the exact node2vec distribution."""
+    wp = O.WalkParams(12, 1, rw, ew, 100, 0)
+    w = O.walks(karate_oracle, wp, 7, 0, 0, 34 * 3000).astype(np.int64)
+    prev = w[:, :-2].ravel()
+    cur = w[:, 1:-1].ravel()
+    nxt = w[:, 2:].ravel()
+    key = prev * 34 + cur
+    checked, pvals = 0, []
+    for k in np.unique(key):
+        sel = key == k
+        if sel.sum() < 2000:
+            continue
+        p, c = divmod(int(k), 34)
+        neigh, probs = exact_second_order_probs(karate, p, c, rw, ew)
+        counts = np.array([(nxt[sel] == x).sum() for x in neigh], dtype=np.float64)
+        assert counts.sum() == sel.sum()
+        expected = probs * counts.sum()
+        if (expected < 5).any():
+            continue
+        pvals.append(stats.chisquare(counts, expected).pvalue)
+        checked += 1
+    assert checked >= 20
+    assert min(pvals) > 1e-3 / checked, (min(pvals), checked)
+
+
+def test_extreme_weights_use_exact_fallback(karate, karate_oracle):
+    """return_weight >> 1 with explore tiny: acceptance ~1e-4, the rejection loop gives up after
+    32 trials and the exact scan must still sample the right distribution."""
+    rw, ew = 1.0, 1e-4
+    wp = O.WalkParams(3, 1, rw, ew, 100, 0)
+    w = O.walks(karate_oracle, wp, 3, 0, 0, 34 * 4000).astype(np.int64)
+    sel = (w[:, 0] == 0) & (w[:, 1] == 1)
+    neigh, probs = exact_second_order_probs(karate, 0, 1, rw, ew)
+    counts = np.array([(w[sel, 2] == x).sum() for x in neigh], dtype=np.float64)
+    big = probs * counts.sum() >= 5
+    chi = stats.chisquare(counts[big], probs[big] / probs[big].sum() * counts[big].sum())
+    assert chi.pvalue > 1e-4
+
+
+def test_weighted_first_order_distribution():
+    src = np.array([0, 0, 0, 1, 2])
+    dst = np.array([1, 2, 3, 2, 3])
+    wts = np.array([1.0, 2.0, 5.0, 1.0, 1.0])
+    g = E.CSRGraph.from_edge_list(src, dst, wts, number_of_nodes=4)
+    og = O.OracleGraph(g.row_ptr, g.col_idx, g.cumw)
+    w = O.walks(og, O.WalkParams(2, 1, 1.0, 1.0, 100, 0), 1, 0, 0, 4 * 20000)
+    from0 = w[w[:, 0] == 0, 1]
+    counts = np.array([(from0 == x).sum() for x in (1, 2, 3)], dtype=np.float64)
+    assert stats.chisquare(counts, np.array([1, 2, 5]) / 8 * counts.sum()).pvalue > 1e-4
+
+
+def test_trap_nodes_end_walks_with_sentinel():
+    # directed path 0 -> 1 -> 2, node 2 is a trap; node 3 isolated (never a source)
+    g = E.CSRGraph.from_edge_list([0, 1], [1, 2], number_of_nodes=4, directed=True)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    assert list(g.sources) == [0, 1]
+    w = O.walks(og, O.WalkParams(5, 1, 1.0, 1.0, 100, 0), 1, 0, 0, 2, sources=g.sources)
+    S = O.SENTINEL
+    assert w.tolist() == [[0, 1, 2, S, S], [1, 2, S, S, S]]
+
+
+def test_ba_generator_shape():
+    n, m = 20000, 5
+    s, d = O.ba_edges(n, m, 42)
+    assert len(s) == (n - 1) * m and (s > d).all()
+    assert np.array_equal(s, np.repeat(np.arange(1, n), m).astype(np.uint32))
+    s2, d2 = O.ba_edges(n, m, 42)
+    assert np.array_equal(d, d2) and not np.array_equal(d, O.ba_edges(n, m, 43)[1])
+    g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=n)
+    deg = g.get_node_degrees()
+    assert abs(deg.mean() - 2 * m) < 0.2 and deg.min() >= 1
+    # preferential attachment: heavy tail, early nodes are the hubs
+    assert deg.max() > 40 * m / 2 and deg[:100].mean() > 10 * deg[-1000:].mean()
+    tail = np.sort(deg)[::-1]
+    assert tail[10] > 5 * np.median(deg)
+
+
+def _loss_sgns(u, rows, labels, clip):
+    dots = torch.clamp(rows @ u, -clip, clip)
+    return -(labels * torch.nn.functional.logsigmoid(dots)
+             + (1 - labels) * torch.nn.functional.logsigmoid(-dots)).sum()
+
+
+def test_sgns_update_is_the_loss_gradient(karate_oracle):
+    """One centre with distinct sample rows: the oracle's update == -lr * autograd gradient of
+    -log s(u.v+) - sum log s(-u.v-)  (NCE/negative-sampling loss of skipgram.py:45-50)."""
+    d, k, w, lr = 8, 3, 1, 0.05
+    tp = O.TrainParams(0, d, d, 1, k, w, lr, 1.0, 6.0, 0, 0.5)
+    central = O.init_table(34, d, d, 1, 0, 0.5)
+    contextual = O.init_table(34, d, d, 1, 1, 0.5)
+    c0, x0 = central.copy(), contextual.copy()
+    walk = np.array([[5, 9]], dtype=np.uint32)  # centre 5 -> ctx 9 and centre 9 -> ctx 5
+    neg = np.zeros((1, 2, 2 * w, k), dtype=np.uint32)
+    neg[0, 0, 1] = [11, 12, 13]  # centre 0 only has the right-hand slot (slot index w)
+    neg[0, 1, 0] = [20, 21, 22]
+    O.train_walks(karate_oracle, tp, walk, 0, 0, 0, lr, central, contextual, neg_override=neg)
+
+    u = torch.tensor(c0[5], requires_grad=True)
+    rows = torch.tensor(x0[[9, 11, 12, 13]], requires_grad=True)
+    labels = torch.tensor([1.0, 0, 0, 0])
+    _loss_sgns(u, rows, labels, 6.0).backward()
+    assert np.allclose(central[5], c0[5] - lr * u.grad.numpy(), atol=1e-6)
+    assert np.allclose(contextual[[9, 11, 12, 13]], x0[[9, 11, 12, 13]] - lr * rows.grad.numpy(),
+                       atol=1e-6)
+    u = torch.tensor(c0[9], requires_grad=True)
+    rows = torch.tensor(x0[[5, 20, 21, 22]], requires_grad=True)
+    _loss_sgns(u, rows, labels, 6.0).backward()
+    assert np.allclose(central[9], c0[9] - lr * u.grad.numpy(), atol=1e-6)
+    untouched = np.setdiff1d(np.arange(34), [5, 9, 11, 12, 13, 20, 21, 22])
+    assert np.array_equal(contextual[untouched], x0[untouched])
+
+
+def test_cbow_update_is_the_loss_gradient(karate_oracle):
+    d, k, w, lr = 8, 3, 2, 0.05
+    tp = O.TrainParams(1, d, d, 1, k, w, lr, 1.0, 6.0, 0, 0.5)
+    central = O.init_table(34, d, d, 2, 0, 0.5)
+    contextual = O.init_table(34, d, d, 2, 1, 0.5)
+    c0, x0 = central.copy(), contextual.copy()
+    walk = np.array([[1, 2, 3, O.SENTINEL, O.SENTINEL]], dtype=np.uint32)
+    neg = np.zeros((1, 5, k), dtype=np.uint32)
+    neg[0, 0] = [10, 11, 12]
+    neg[0, 1] = [13, 14, 15]
+    neg[0, 2] = [16, 17, 18]
+    O.train_walks(karate_oracle, tp, walk, 0, 0, 0, lr, central, contextual, neg_override=neg)
+    # first centre (node 1): contexts {2, 3}, targets {1, 10, 11, 12}; later centres touch
+    # other target rows, so these four rows only saw the first centre
+    ctx = torch.tensor(x0[[2, 3]], requires_grad=True)
+    tg = torch.tensor(c0[[1, 10, 11, 12]], requires_grad=True)
+    labels = torch.tensor([1.0, 0, 0, 0])
+    _loss_sgns(ctx.mean(0), tg, labels, 6.0).backward()
+    assert np.allclose(central[[10, 11, 12]], c0[[10, 11, 12]] - lr * tg.grad.numpy()[1:],
+                       atol=1e-6)
+
+
+def test_pair_count_and_window_trimming(karate_oracle):
+    L, w = 16, 3
+    wp = O.WalkParams(L, 2, 1.0, 1.0, 100, 0)
+    tp = O.TrainParams(0, 4, 4, 1, 2, w, 0.01, 0.9, 6.0, 1, 0.5)
+    _, _, pairs = O.fit(karate_oracle, wp, tp, 5)
+    assert pairs == 34 * 2 * (2 * w * L - w * (w + 1))
+
+
+def test_learning_rate_decay_and_epochs(karate_oracle):
+    wp = O.WalkParams(8, 1, 1.0, 1.0, 100, 0)
+    base = O.TrainParams(0, 4, 4, 2, 2, 2, 0.05, 0.5, 6.0, 1, 0.5)
+    c2, x2, _ = O.fit(karate_oracle, wp, base, 9)
+    # replay by hand: epoch 0 at lr, epoch 1 at lr * decay
+    c = O.init_table(34, 4, 4, 9, 0, 0.5)
+    x = O.init_table(34, 4, 4, 9, 1, 0.5)
+    for e, lr in ((0, 0.05), (1, np.float32(0.05) * np.float32(0.5))):
+        w = O.walks(karate_oracle, wp, 9, e, 0, 34)
+        O.train_walks(karate_oracle, base, w, 9, e, 0, float(lr), c, x)
+    assert np.array_equal(c, c2) and np.array_equal(x, x2)
+
+
+def test_window_batch_matches_sequence_contract(karate_oracle):
+    """contexts [n, 2w], words [n], n = walks * (walk_length - 2w)
+    (node2vec_sequence.py:115-128)."""
+    w = O.walks(karate_oracle, O.WalkParams(10, 1, 1.0, 1.0, 100, 0), 3, 0, 0, 34)
+    contexts, words = O.window_batch(w, 2)
+    assert contexts.shape == (34 * 6, 4) and words.shape == (34 * 6,)
+    assert contexts.dtype == np.int32 and words.dtype == np.int32
+    assert words[0] == w[0, 2] and contexts[0].tolist() == [w[0, 0], w[0, 1], w[0, 3], w[0, 4]]
+    assert words[7] == w[1, 3]
+
+
+def test_training_learns_communities():
+    """Quality sanity: embeddings of a ring of cliques separate edges from non-edges."""
+    src, dst, n = ring_of_cliques(8, 8)
+    g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=n)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    wp = O.WalkParams(32, 4, 1.0, 1.0, 100, 0)
+    tp = O.TrainParams(0, 16, 16, 5, 5, 4, 0.025, 0.9, 6.0, 1, 16 ** -0.5)
+    c, x, _ = O.fit(og, wp, tp, 42)
+    assert link_auc(g, c, x) > 0.9
+    tp.model = 1
+    c, x, _ = O.fit(og, wp, tp, 42)
+    assert np.isfinite(c).all() and link_auc(g, x, c) > 0.85
+
+
+def test_hogwild_threads_are_statistically_equivalent(karate, karate_oracle):
+    """The OpenMP Hogwild variant (the CPU baseline) races by design: same work, same quality,
+    different trajectory."""
+    wp = O.WalkParams(16, 4, 0.25, 4.0, 100, 0)
+    tp = O.TrainParams(0, 8, 8, 4, 5, 3, 0.025, 0.9, 6.0, 1, 8 ** -0.5)
+    c1, x1, p1 = O.fit(karate_oracle, wp, tp, 42, threads=1)
+    c4, x4, p4 = O.fit(karate_oracle, wp, tp, 42, threads=4)
+    assert p1 == p4 and np.isfinite(c4).all() and np.isfinite(x4).all()
+    assert abs(link_auc(karate, c1, x1) - link_auc(karate, c4, x4)) < 0.05
+
+
+def test_self_golden(karate_oracle):
+    """Freeze the oracle's own outputs (regression pin, not reference-derived)."""
+    gold = np.load(os.path.join(GOLDEN, "oracle_karate.npz"))
+    wp = O.WalkParams(16, 2, 0.25, 4.0, 100, 0)
+    assert np.array_equal(O.walks(karate_oracle, wp, 42, 0, 0, 68), gold["walks"])
+    for model, key in ((0, "sgns"), (1, "cbow")):
+        tp = O.TrainParams(model, 8, 8, 2, 4, 3, 0.01, 0.9, 6.0, 1, 8 ** -0.5)
+        c, x, pairs = O.fit(karate_oracle, wp, tp, 42)
+        assert pairs == int(gold[f"{key}_pairs"])
+        assert np.allclose(c, gold[f"{key}_central"], atol=1e-6)
+        assert np.allclose(x, gold[f"{key}_contextual"], atol=1e-6)
+    s, d = O.ba_edges(500, 3, 42)
+    assert np.array_equal(d, gold["ba_dst"])
