@@ -1,0 +1,216 @@
+"""Headline benchmark: SkipGram training-pairs/sec (+ walk-steps/sec), d = 128, on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (the graph BASELINE.json's target is quoted on): seeded
+Barabasi-Albert graph, 10 M nodes / 100 M edges, Node2Vec SkipGram with the reference's default
+hyper-parameters (walk_length 128, window 5, 10 negatives, return_weight 0.25, explore_weight 4;
+embiggen/embedders/ensmallen_embedders/node2vec_skipgram.py:11-24) at d = 128, f32.
+One step = one pass of the hot path over one batch of synthetic input: generate `--walks`
+second-order walks on the GPU and train on all of them (1 250 pairs per walk).  Graph and both
+tables are resident in HBM before the timed region.
+
+N > 1: one process per GPU, CSR replicated, every rank trains on its own slice of the walk ids
+(weak scaling: per-GPU work fixed) against a full replica of both tables; replicas are averaged
+with one RCCL all-reduce per table per step (inside the timed region).  See DESIGN.md
+"Multi-GPU" for why this is the round-1 form and what the row-sharded form changes.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_PAIR = 12288  # 2 * (k + 2) * d * 4 with k = 10, d = 128
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--walks", type=int, default=1 << 19, help="walks per step per GPU")
+    ap.add_argument("--batch", type=int, default=1 << 16, help="walks per kernel launch")
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--mode", default="auto",
+                    choices=["auto", "write_through", "write_back", "atomic"])
+    ap.add_argument("--return-weight", type=float, default=0.25)
+    ap.add_argument("--explore-weight", type=float, default=4.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(graph, args, central, contextual, seconds):
+    """The oracle's OpenMP Hogwild restatement timed on this box's host cores, on a bounded
+    sample of the same workload (same graph, same parameters, walk ids past the GPU's)."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    cores = os.cpu_count() or 1
+    og = O.OracleGraph(graph.row_ptr, graph.col_idx)
+    d = args.d
+    c = central[:, :d].contiguous().cpu().numpy()
+    x = contextual[:, :d].contiguous().cpu().numpy()
+    wp = O.WalkParams(128, 10, args.return_weight, args.explore_weight, 100, 0)
+    tp = O.TrainParams(0, d, d, 1, 10, 5, 0.01, 0.9, 6.0, O.FLAG_SCALE_FREE, d ** -0.5)
+
+    def run(first, n):
+        t0 = time.perf_counter()
+        w = O.walks(og, wp, 42, 0, first, n)
+        t1 = time.perf_counter()
+        O.train_walks(og, tp, w, 42, 0, first, 0.01, c, x, threads=cores)
+        t2 = time.perf_counter()
+        pairs = int(n) * (2 * 5 * 128 - 5 * 6)
+        return pairs, n * 127, t1 - t0, t2 - t1
+
+    first = 1 << 40  # walk ids the GPU run never uses
+    probe_n = 64 * cores
+    pairs, _, _, tt = run(first, probe_n)
+    rate = pairs / max(tt, 1e-6)
+    n = int(max(probe_n, min(seconds * rate / 1250, 1 << 20)))
+    pairs, steps, tw, tt = run(first + probe_n, n)
+    return {
+        "value": pairs / (tw + tt),
+        "unit": "pairs/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n} walks ({pairs} pairs) of the same BA graph and parameters, walks+training "
+                  f"{tw + tt:.1f}s, OpenMP Hogwild oracle on {cores} threads",
+        "train_only_pairs_per_s": pairs / tt,
+        "walk_steps_per_s": steps / max(tw, 1e-9),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    import embiggen_amd as E
+    from embiggen_amd import _lib, ops
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    _lib.require_device()
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    graph = E.barabasi_albert(args.nodes, args.m, 42, device=local)
+    n, d = graph.get_number_of_nodes(), args.d
+    central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local)
+    contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local)
+    flags = _lib.TRAIN_SCALE_FREE | {
+        "auto": 0, "write_through": _lib.TRAIN_WRITE_THROUGH,
+        "write_back": _lib.TRAIN_WRITE_BACK, "atomic": _lib.TRAIN_ATOMIC}[args.mode]
+    tp = ops.train_params(_lib.MODEL_SKIPGRAM, d, 10, 5, lr=0.01, flags=flags)
+    wp = ops.walk_params(128, 10, args.return_weight, args.explore_weight)
+    walk_buf = [None]
+
+    def step(index):
+        """walks [first, first + args.walks) of this rank, in launches of args.batch walks"""
+        first = (index * world + rank) * args.walks
+        for off in range(0, args.walks, args.batch):
+            nb = min(args.batch, args.walks - off)
+            wk = ops.walks(graph, wp, 42, 0, first + off, nb, device=local)
+            ops.sgns_step(graph, tp, wk, 42, 0, first + off, 0.01, central, contextual)
+            walk_buf[0] = wk
+        if world > 1:
+            for t in (central, contextual):
+                dist.all_reduce(t)
+                t.mul_(1.0 / world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ops.stats_reset(graph, local)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = ops.stats_read(graph, local)
+
+    times = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    counts = torch.tensor([st["pairs"], st["walk_steps"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    elapsed = float(times[0])
+    total_pairs, total_steps = float(counts[0]), float(counts[1])
+
+    if rank == 0:
+        ok = bool(torch.isfinite(central).all()) and bool(torch.isfinite(contextual).all())
+        launch_ms = st["train_ms"] / max(st["train_launches"], 1)
+        achieved = st["pairs"] * BYTES_PER_PAIR / (st["train_ms"] * 1e-3) / 1e9
+        line = {
+            "metric": "SkipGram training-pairs/sec (walk generation included), d=128",
+            "value": total_pairs / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Barabasi-Albert {n} nodes / {graph.get_number_of_directed_edges() // 2}"
+                            f" edges (seed 42), Node2Vec SkipGram d={d}, walk_length 128, window 5,"
+                            f" 10 negatives, return_weight {args.return_weight}, explore_weight "
+                            f"{args.explore_weight}, {args.walks} walks per step per GPU",
+                "update_mode": args.mode,
+                "walks_per_launch": args.batch,
+                "parallelism": "1 GPU" if world == 1 else
+                               f"{world} table replicas, walks partitioned, all-reduce average per step",
+            },
+            "walk_steps_per_s": total_steps / elapsed,
+            "walk_kernel_steps_per_s": st["walk_steps"] / max(st["walk_ms"] * 1e-3, 1e-12),
+            "finite": ok,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "gn2v::sgns_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": args.batch * 1250 * BYTES_PER_PAIR,
+                "avg_launch_ms": launch_ms,
+                "launches": st["train_launches"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(graph, args, central, contextual, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

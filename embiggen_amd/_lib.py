@@ -22,6 +22,7 @@ TRAIN_NORM_LR = 4
 TRAIN_DETERMINISTIC = 8
 TRAIN_ATOMIC = 16
 TRAIN_WRITE_BACK = 32
+TRAIN_WRITE_THROUGH = 64
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 

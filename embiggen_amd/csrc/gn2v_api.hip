@@ -195,11 +195,14 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const ui
     a.clip = tp->clip;
 
     const bool det = tp->flags & GN2V_TRAIN_DETERMINISTIC;
-    const int wm = (tp->flags & GN2V_TRAIN_ATOMIC)       ? gn2v::kAtomic
-                   : (tp->flags & GN2V_TRAIN_WRITE_BACK) ? gn2v::kWriteBack
-                                                         : gn2v::kWriteThrough;
+    const int wm = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
+                   : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
+                   : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
+                   : g->view.n_nodes < (1ULL << 20)         ? gn2v::kAtomic
+                                                            : gn2v::kWriteThrough;
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
-    const size_t lds = (size_t)waves_per_block * (L + 2 * (size_t)a.max_samples) * 4;
+    const size_t lds =
+        (size_t)waves_per_block * (L + 2 * (size_t)a.max_samples + (cbow ? 2 * tp->window : 0)) * 4;
     if (lds > 64 * 1024) return fail("walk_length / window / negatives too large for the LDS plan");
     uint64_t blocks = det ? 1 : (n_walks + waves_per_block - 1) / waves_per_block;
     const uint64_t cap = (uint64_t)g->n_cus * 8;

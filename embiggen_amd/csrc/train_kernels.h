@@ -202,6 +202,28 @@ __device__ __forceinline__ uint32_t stage_walk(const TrainArgs &a, uint64_t b, u
     return first_bad;
 }
 
+// The four row ids a wave handles in one round (one per 16-lane group).  Rows repeated inside a
+// round are serialised into passes in group order, so a single wave applies its updates in
+// exactly the oracle's sequential order even when a walk revisits a node inside the window
+// (a later round always sees an earlier round's stores: same wave, program order).
+struct RoundIds {
+    uint32_t r[4];
+    int last_pass;
+    __device__ __forceinline__ RoundIds(const uint32_t *ids, uint32_t t0, uint32_t n) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) r[g] = (t0 + g < n) ? ids[t0 + g] : kSentinel;
+        last_pass = max(max(pass_of(1), pass_of(2)), pass_of(3));
+    }
+    // number of earlier groups of this round holding the same (valid) row
+    __device__ __forceinline__ int pass_of(int g) const {
+        int p = 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (e < g && r[g] != kSentinel && r[e] == r[g]) ++p;
+        return p;
+    }
+};
+
 // Score the staged sample list against the register row `u` (replicated in every group):
 // for each sample row v: var = (label - sigmoid(clip(u.v))) * lr ; g += var * v ; v += var * u.
 // DET: one sample at a time, all groups redundantly, group 0 writes (strict sequential semantics).
@@ -227,17 +249,21 @@ __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, 
     } else {
         for (uint32_t t0 = 0; t0 < n_samples; t0 += 4) {
             const uint32_t t = t0 + grp;
-            const bool in = t < n_samples;
-            const uint32_t row = in ? s_rows[t] : kSentinel;
-            const float lab = in ? s_lab[t] : 0.f;
+            const RoundIds ids(s_rows, t0, n_samples);
+            const uint32_t row = ids.r[grp];
+            const float lab = t < n_samples ? s_lab[t] : 0.f;
             const bool valid = row != kSentinel;
+            const int my_pass = ids.pass_of(grp);
             float *base = table + (uint64_t)(valid ? row : 0) * a.ld;
-            Row<CH> v;
-            load_row<CH>(v, base, q, nchunks, valid);
-            const float dot = dot_rows<CH>(u, v);
-            const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
-            axpy<CH>(g, var, v);
-            if (valid) scatter_add<CH, WM>(base, q, nchunks, var, u, v);
+            for (int pass = 0; pass <= ids.last_pass; ++pass) {
+                const bool mine = valid && my_pass == pass;
+                Row<CH> v;
+                load_row<CH>(v, base, q, nchunks, mine);
+                const float dot = dot_rows<CH>(u, v);
+                const float var = mine ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+                axpy<CH>(g, var, v);
+                if (mine) scatter_add<CH, WM>(base, q, nchunks, var, u, v);
+            }
         }
     }
 }
@@ -335,10 +361,11 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
-    const uint32_t per_wave = a.L + 2 * a.max_samples;
+    const uint32_t per_wave = a.L + 2 * a.max_samples + 2 * a.window;
     uint32_t *s_walk = smem + wave * per_wave;
     uint32_t *s_rows = s_walk + a.L;
     float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
+    uint32_t *s_ctx = s_rows + 2 * a.max_samples;  // 2w context ids of the current centre
     const uint32_t nchunks = a.ld >> 2;
     const uint32_t w = a.window, k = a.k;
     const uint64_t per_walk_neg = (uint64_t)a.L * k;
@@ -375,6 +402,11 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                 }
                 s_rows[t] = row;
                 s_lab[t] = lab;
+            }
+            for (uint32_t t = lane; t < n_ctx; t += 64) {
+                uint32_t j = lo + t;
+                if (j >= i) ++j;
+                s_ctx[t] = s_walk[j];
             }
             wave_sync();
 
@@ -424,15 +456,18 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                 }
             } else {
+                // context node ids of this centre were staged behind the sample list
                 for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
-                    const uint32_t rank = r0 + grp;
-                    if (rank < n_ctx) {
-                        uint32_t j = lo + rank;
-                        if (j >= i) ++j;
-                        float *base = a.contextual + (uint64_t)s_walk[j] * a.ld;
+                    const RoundIds ids(s_ctx, r0, n_ctx);
+                    const uint32_t row = ids.r[grp];
+                    const bool valid = row != kSentinel;
+                    const int my_pass = ids.pass_of(grp);
+                    float *base = a.contextual + (uint64_t)(valid ? row : 0) * a.ld;
+                    for (int pass = 0; pass <= ids.last_pass; ++pass) {
+                        const bool mine = valid && my_pass == pass;
                         Row<CH> v;
-                        if constexpr (WM != kAtomic) load_row<CH>(v, base, q, nchunks, true);
-                        scatter_add<CH, WM>(base, q, nchunks, invC, g, v);
+                        if constexpr (WM != kAtomic) load_row<CH>(v, base, q, nchunks, mine);
+                        if (mine) scatter_add<CH, WM>(base, q, nchunks, invC, g, v);
                     }
                 }
             }

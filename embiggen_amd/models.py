@@ -60,7 +60,7 @@ class _WalkBasedModel:
         verbose: bool = True,
         alpha: float = 0.75,
         deterministic: bool = False,
-        update_mode: str = "write_through",
+        update_mode: str = "auto",
         device: int = 0,
     ):
         if not isinstance(embedding_size, int) or embedding_size < 1:
@@ -109,8 +109,9 @@ class _WalkBasedModel:
         self.verbose = bool(verbose)
         self.alpha = alpha
         self.deterministic = bool(deterministic)
-        if update_mode not in ("write_through", "write_back", "atomic"):
-            raise ValueError("update_mode must be 'write_through', 'write_back' or 'atomic'.")
+        if update_mode not in ("auto", "write_through", "write_back", "atomic"):
+            raise ValueError(
+                "update_mode must be 'auto', 'write_through', 'write_back' or 'atomic'.")
         self.update_mode = update_mode
         self.device = int(device)
         self.last_stats = None
@@ -141,6 +142,8 @@ class _WalkBasedModel:
             flags |= _lib.TRAIN_ATOMIC
         elif self.update_mode == "write_back":
             flags |= _lib.TRAIN_WRITE_BACK
+        elif self.update_mode == "write_through":
+            flags |= _lib.TRAIN_WRITE_THROUGH
         return _lib.TrainParams(
             self.MODEL_ID, self.embedding_size, self.padded_size, self.epochs,
             self.number_of_negative_samples, self.window_size, self.learning_rate,

@@ -40,10 +40,13 @@ extern "C" {
 #define GN2V_TRAIN_DOWNSAMPLE 2u     /* stochastic_downsample_by_degree (:97-98)                */
 #define GN2V_TRAIN_NORM_LR 4u        /* normalize_learning_rate_by_degree (:99-100)             */
 #define GN2V_TRAIN_DETERMINISTIC 8u  /* one wavefront, strict walk order: oracle-exact, slow    */
-/* Row updates default to Hogwild read-modify-write with write-through 16 B stores (the CPU
- * reference is racy by design as well).  Alternatives: */
+/* How row updates reach memory.  With none of the three bits set the engine picks: graphs below
+ * 2^20 nodes (where thousands of concurrent wavefronts would collide on the same rows all the
+ * time) use atomics, larger ones Hogwild write-through stores (the CPU reference is racy by
+ * design as well; measured ~10x faster than atomics, DESIGN.md "Update modes"). */
 #define GN2V_TRAIN_ATOMIC 16u        /* hardware f32 atomics on every element: no lost update   */
-#define GN2V_TRAIN_WRITE_BACK 32u    /* plain (L2 write-back) stores: fastest, per-XCD staleness */
+#define GN2V_TRAIN_WRITE_BACK 32u    /* read-modify-write, plain L2 write-back stores            */
+#define GN2V_TRAIN_WRITE_THROUGH 64u /* read-modify-write, 16 B write-through (sc1) stores       */
 
 #define GN2V_MODEL_SKIPGRAM 0u
 #define GN2V_MODEL_CBOW 1u

@@ -1,0 +1,88 @@
+"""Quality of the update modes at scale: train Node2Vec SkipGram on a BA graph with each mode on
+identical walks and compare link-prediction AUROC (edges vs random pairs) computed on the GPU.
+    python scripts/quality_probe.py --nodes 1000000 --walks 1000000
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import embiggen_amd as E  # noqa: E402
+from embiggen_amd import _lib, ops  # noqa: E402
+
+
+def auc(pos, neg):
+    s = torch.cat([pos, neg])
+    ranks = torch.empty_like(s)
+    order = torch.argsort(s)
+    ranks[order] = torch.arange(1, s.numel() + 1, device=s.device, dtype=s.dtype)
+    n1, n0 = pos.numel(), neg.numel()
+    return float((ranks[:n1].sum() - n1 * (n1 + 1) / 2) / (n1 * n0))
+
+
+def evaluate(g, c, x, n_eval, gen):
+    t = g._device_tensors
+    n = g.get_number_of_nodes()
+    e = torch.randint(0, t["col_idx"].numel(), (n_eval,), device="cuda", generator=gen)
+    dst = t["col_idx"][e].long()
+    src = torch.searchsorted(t["row_ptr"], e, right=True) - 1
+    ru = torch.randint(0, n, (n_eval,), device="cuda", generator=gen)
+    rv = torch.randint(0, n, (n_eval,), device="cuda", generator=gen)
+
+    def score(u, v):
+        return (c[u] * x[v]).sum(1) + (c[v] * x[u]).sum(1)
+
+    def cos(u, v):
+        a, b = c[u], c[v]
+        return (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1)).clamp_min(1e-6)
+
+    return auc(score(src, dst), score(ru, rv)), auc(cos(src, dst), cos(ru, rv))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=1_000_000)
+    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--walks", type=int, default=1_000_000)
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--modes", default="write_through,write_back,atomic")
+    a = ap.parse_args()
+    g = E.barabasi_albert(a.nodes, a.m, 42)
+    n, d = g.get_number_of_nodes(), a.d
+    wp = ops.walk_params(128, 10, 0.25, 4.0)
+    flagmap = {"write_through": _lib.TRAIN_WRITE_THROUGH, "write_back": _lib.TRAIN_WRITE_BACK,
+               "atomic": _lib.TRAIN_ATOMIC}
+    gen = torch.Generator(device="cuda")
+    results = {}
+    for mode in a.modes.split(","):
+        c = ops.init_table(n, d, 42, 0, d ** -0.5)
+        x = ops.init_table(n, d, 42, 1, d ** -0.5)
+        tp = ops.train_params(0, d, 10, 5, flags=1 | flagmap[mode])
+        gen.manual_seed(1)
+        base = evaluate(g, c, x, 200000, gen)
+        ops.stats_reset(g)
+        t0 = time.time()
+        lr = a.lr
+        for e in range(a.epochs):
+            for first in range(0, a.walks, 1 << 16):
+                nb = min(1 << 16, a.walks - first)
+                wk = ops.walks(g, wp, 42, e, first, nb)
+                ops.sgns_step(g, tp, wk, 42, e, first, lr, c, x)
+            lr *= 0.9
+        st = ops.stats_read(g)
+        gen.manual_seed(1)
+        res = evaluate(g, c, x, 200000, gen)
+        results[mode] = res
+        print(f"{mode:14s} pairs={st['pairs']:.3e} train_ms={st['train_ms']:.0f} "
+              f"({st['pairs'] / st['train_ms'] * 1e3:.3e} pairs/s) wall={time.time() - t0:.1f}s "
+              f"AUC(c.x)={res[0]:.4f} AUC(cos central)={res[1]:.4f}  [init: {base[0]:.4f} {base[1]:.4f}] "
+              f"finite={bool(torch.isfinite(c).all() and torch.isfinite(x).all())} "
+              f"|c|max={float(c.abs().max()):.3f} |x|max={float(x.abs().max()):.3f}", flush=True)
+        del c, x

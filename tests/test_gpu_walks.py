@@ -1,0 +1,123 @@
+"""GPU parity: the HIP walk sampler is bit-identical to the oracle (integer work => exact)."""
+import numpy as np
+import pytest
+import torch
+
+import embiggen_amd as E
+from embiggen_amd import _lib, ops
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("rw,ew", [(1.0, 1.0), (0.25, 4.0), (2.0, 0.5), (4.0, 0.25),
+                                   (1e-3, 1e-3), (1.0, 1e-4)])
+@pytest.mark.parametrize("walk_length", [2, 5, 16, 33, 128])
+def test_walks_bit_exact_on_karate(karate, karate_oracle, rw, ew, walk_length):
+    wp = ops.walk_params(walk_length, 10, rw, ew)
+    got = _u32(ops.walks(karate, wp, 42, 3, 0, 340))
+    ref = O.walks(karate_oracle, O.WalkParams(walk_length, 10, rw, ew, 100, 0), 42, 3, 0, 340)
+    assert np.array_equal(got, ref)
+
+
+def test_walks_batch_offsets_and_epochs(karate, karate_oracle):
+    wp = ops.walk_params(20, 3, 0.5, 2.0)
+    owp = O.WalkParams(20, 3, 0.5, 2.0, 100, 0)
+    whole = _u32(ops.walks(karate, wp, 1, 2, 0, 102))
+    parts = np.concatenate([_u32(ops.walks(karate, wp, 1, 2, 0, 37)),
+                            _u32(ops.walks(karate, wp, 1, 2, 37, 65))])
+    assert np.array_equal(whole, parts)
+    assert np.array_equal(whole, O.walks(karate_oracle, owp, 1, 2, 0, 102))
+    # ragged wave: 1 walk, 63, 65 walks
+    for n in (1, 63, 65):
+        assert np.array_equal(_u32(ops.walks(karate, wp, 9, 0, 5, n)),
+                              O.walks(karate_oracle, owp, 9, 0, 5, n))
+
+
+def test_walks_bit_exact_on_ba_graph():
+    """Scale-free graph with hubs (binary search over long adjacency lists)."""
+    s, d = O.ba_edges(5000, 4, 11)
+    g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=5000)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    for rw, ew in ((0.25, 4.0), (2.0, 0.5)):
+        got = _u32(ops.walks(g, ops.walk_params(64, 2, rw, ew), 5, 1, 0, 10000))
+        assert np.array_equal(got, O.walks(og, O.WalkParams(64, 2, rw, ew, 100, 0), 5, 1, 0, 10000))
+
+
+def test_weighted_walks_bit_exact():
+    rng = np.random.RandomState(3)
+    s, d = O.ba_edges(800, 3, 5)
+    w = rng.uniform(0.1, 5.0, size=len(s))
+    g = E.CSRGraph.from_edge_list(s, d, w, number_of_nodes=800)
+    og = O.OracleGraph(g.row_ptr, g.col_idx, g.cumw)
+    for rw, ew in ((1.0, 1.0), (0.25, 4.0), (1.0, 1e-4)):
+        got = _u32(ops.walks(g, ops.walk_params(24, 2, rw, ew), 8, 0, 0, 1600))
+        assert np.array_equal(got, O.walks(og, O.WalkParams(24, 2, rw, ew, 100, 0), 8, 0, 0, 1600))
+
+
+def test_directed_graph_with_traps_and_isolated_nodes():
+    rng = np.random.RandomState(0)
+    src = rng.randint(0, 300, size=900)
+    dst = rng.randint(0, 300, size=900)
+    g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=320, directed=True)
+    assert g.sources is not None and g.has_disconnected_nodes()
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    n = 2 * g.get_number_of_unique_source_nodes()
+    got = _u32(ops.walks(g, ops.walk_params(40, 2, 0.5, 2.0), 4, 0, 0, n))
+    ref = O.walks(og, O.WalkParams(40, 2, 0.5, 2.0, 100, 0), 4, 0, 0, n, sources=g.sources)
+    assert np.array_equal(got, ref)
+    assert (got == _lib.SENTINEL).any()  # some walks did hit a trap
+
+
+def test_ba_edges_and_init_table_bit_exact():
+    n, m = 3000, 7
+    src = torch.empty((n - 1) * m, dtype=torch.int32, device="cuda")
+    dst = torch.empty_like(src)
+    _lib.check(_lib.lib().gn2v_ba_edges(n, m, 42, src.data_ptr(), dst.data_ptr(), None))
+    torch.cuda.synchronize()
+    rs, rd = O.ba_edges(n, m, 42)
+    assert np.array_equal(_u32(src), rs) and np.array_equal(_u32(dst), rd)
+    for d, tid, scale in ((5, 0, 0.4), (128, 1, 128 ** -0.5), (100, 1, 0.1)):
+        ld = (d + 3) // 4 * 4
+        got = ops.init_table(77, d, 9, tid, scale).cpu().numpy()
+        assert np.array_equal(got, O.init_table(77, d, ld, 9, tid, scale))
+        assert (got[:, d:] == 0).all()
+
+
+def test_device_built_ba_graph_equals_host_build():
+    g = E.barabasi_albert(4000, 5, 42)
+    s, d = O.ba_edges(4000, 5, 42)
+    h = E.CSRGraph.from_edge_list(s, d, number_of_nodes=4000)
+    assert np.array_equal(g.row_ptr, h.row_ptr) and np.array_equal(g.col_idx, h.col_idx)
+    assert g.get_number_of_nodes() == 4000 and g.sources is None
+
+
+def test_window_batch_matches_oracle(karate, karate_oracle):
+    """Node2VecSequence batch form (node2vec_sequence.py:115-128,190-203)."""
+    wk = ops.walks(karate, ops.walk_params(128, 16, 1.0, 1.0), 42, 0, 0, 34 * 16)
+    contexts, words = ops.window_batch(wk, 4)
+    rc, rw = O.window_batch(_u32(wk), 4)
+    assert contexts.shape == (34 * 16 * 120, 8) and words.shape == (34 * 16 * 120,)
+    assert np.array_equal(contexts.cpu().numpy(), rc) and np.array_equal(words.cpu().numpy(), rw)
+
+
+def test_full_size_walk_properties():
+    """At benchmark scale (no oracle run): every step follows an edge, starts are the sources,
+    and a re-run is identical."""
+    g = E.barabasi_albert(1_000_000, 10, 42)
+    wp = ops.walk_params(128, 10, 0.25, 4.0)
+    wk = ops.walks(g, wp, 42, 0, 0, 1 << 15)
+    again = ops.walks(g, wp, 42, 0, 0, 1 << 15)
+    assert torch.equal(wk, again)
+    t = g._device_tensors
+    a, b = wk[:, :-1].long().flatten(), wk[:, 1:].long().flatten()
+    n = g.get_number_of_nodes()
+    edge_keys = (torch.arange(n, device="cuda").repeat_interleave(
+        t["row_ptr"][1:] - t["row_ptr"][:-1]) * n + t["col_idx"].long())
+    pos = torch.searchsorted(edge_keys, a * n + b).clamp_(max=edge_keys.numel() - 1)
+    assert bool((edge_keys[pos] == a * n + b).all())
+    assert torch.equal(wk[:, 0].long(), torch.arange(1 << 15, device="cuda") % n)
