@@ -46,8 +46,27 @@ def parse():
     ap.add_argument("--return-weight", type=float, default=0.25)
     ap.add_argument("--explore-weight", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="run the traffic-calibration kernel instead of training (for rocprofv3 "
+                         "--pmc passes): every table row touched exactly once per launch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(logical CPUs, affinity mask, cgroup quota)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
 
 
 def cpu_baseline(graph, args, central, contextual, seconds):
@@ -57,7 +76,7 @@ def cpu_baseline(graph, args, central, contextual, seconds):
 
     from oracle import oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     og = O.OracleGraph(graph.row_ptr, graph.col_idx)
     d = args.d
     c = central[:, :d].contiguous().cpu().numpy()
@@ -119,6 +138,23 @@ def main():
     flags = _lib.TRAIN_SCALE_FREE | {
         "auto": 0, "write_through": _lib.TRAIN_WRITE_THROUGH,
         "write_back": _lib.TRAIN_WRITE_BACK, "atomic": _lib.TRAIN_ATOMIC}[args.mode]
+    if args.calibrate:
+        perm = torch.randperm(n, device="cuda", dtype=torch.int64).to(torch.int32)
+        mode_flags = flags & ~_lib.TRAIN_SCALE_FREE
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = args.warmup + args.steps
+        for _ in range(reps):
+            ops.touch_rows(central, perm, mode_flags)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        row_bytes = central.shape[1] * 4
+        print(json.dumps({"calibration": "gn2v::touch_rows_kernel", "rows_per_launch": n,
+                          "read_bytes_per_launch": n * row_bytes + n * 4,
+                          "write_bytes_per_launch": n * row_bytes, "update_mode": args.mode,
+                          "ms_per_launch": dt * 1e3,
+                          "GBps": (2 * n * row_bytes + 4 * n) / dt / 1e9}), flush=True)
+        return
     tp = ops.train_params(_lib.MODEL_SKIPGRAM, d, 10, 5, lr=0.01, flags=flags)
     wp = ops.walk_params(128, 10, args.return_weight, args.explore_weight)
     walk_buf = [None]
@@ -191,6 +227,7 @@ def main():
             "walk_steps_per_s": total_steps / elapsed,
             "walk_kernel_steps_per_s": st["walk_steps"] / max(st["walk_ms"] * 1e-3, 1e-12),
             "finite": ok,
+            "argv": sys.argv[1:],
             "roofline": {
                 "bound": "hbm",
                 "kernel": "gn2v::sgns_kernel",

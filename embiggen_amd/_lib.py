@@ -30,7 +30,8 @@ MODEL_CBOW = 1
 EXPORTS = [
     "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
     "gn2v_graph_destroy", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_init_table",
-    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_train", "gn2v_stats_reset", "gn2v_stats_read",
+    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_train", "gn2v_touch_rows", "gn2v_stats_reset",
+    "gn2v_stats_read",
 ]
 
 
@@ -130,6 +131,7 @@ def lib():
     L.gn2v_cbow_step.argtypes = step
     L.gn2v_train.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64, vp, vp,
                              C.POINTER(Stats), vp]
+    L.gn2v_touch_rows.argtypes = [vp, u32, vp, u64, u32, vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]
     L.gn2v_stats_read.argtypes = [vp, C.POINTER(Stats), vp]
     for name in EXPORTS:

@@ -390,6 +390,42 @@ int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d
                         d_central, d_contextual, d_neg_override, (hipStream_t)stream);
 }
 
+int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t n, uint32_t flags,
+                    void *stream) {
+    if (!d_table || !d_ids) return fail("NULL pointer");
+    if (ld == 0 || (ld & 3) || ld > 512) return fail("ld must be a multiple of 4 in [4, 512]");
+    if (n == 0) return 0;
+    const int wm = (flags & GN2V_TRAIN_ATOMIC)       ? gn2v::kAtomic
+                   : (flags & GN2V_TRAIN_WRITE_BACK) ? gn2v::kWriteBack
+                                                     : gn2v::kWriteThrough;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 15) / 16, 256 * 8);
+    hipStream_t s = (hipStream_t)stream;
+#define GN2V_TOUCH(CH)                                                                          \
+    do {                                                                                        \
+        if (wm == gn2v::kAtomic)                                                                \
+            hipLaunchKernelGGL((gn2v::touch_rows_kernel<CH, gn2v::kAtomic>), dim3(blocks),      \
+                               dim3(gn2v::kTrainBlock), 0, s, d_table, ld, d_ids, n);           \
+        else if (wm == gn2v::kWriteBack)                                                        \
+            hipLaunchKernelGGL((gn2v::touch_rows_kernel<CH, gn2v::kWriteBack>), dim3(blocks),   \
+                               dim3(gn2v::kTrainBlock), 0, s, d_table, ld, d_ids, n);           \
+        else                                                                                    \
+            hipLaunchKernelGGL((gn2v::touch_rows_kernel<CH, gn2v::kWriteThrough>), dim3(blocks), \
+                               dim3(gn2v::kTrainBlock), 0, s, d_table, ld, d_ids, n);           \
+    } while (0)
+    const uint32_t nchunks = ld / 4;
+    if (nchunks <= 16)
+        GN2V_TOUCH(1);
+    else if (nchunks <= 32)
+        GN2V_TOUCH(2);
+    else if (nchunks <= 64)
+        GN2V_TOUCH(4);
+    else
+        GN2V_TOUCH(8);
+#undef GN2V_TOUCH
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int gn2v_stats_reset(gn2v_graph *g, void *stream) {
     if (!g) return fail("graph handle is NULL");
     HIP_TRY(hipSetDevice(g->device));

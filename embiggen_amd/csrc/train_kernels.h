@@ -207,20 +207,28 @@ __device__ __forceinline__ uint32_t stage_walk(const TrainArgs &a, uint64_t b, u
 // exactly the oracle's sequential order even when a walk revisits a node inside the window
 // (a later round always sees an earlier round's stores: same wave, program order).
 struct RoundIds {
-    uint32_t r[4];
+    uint32_t r0, r1, r2, r3;  // named scalars: a runtime-indexed array would live in scratch
     int last_pass;
     __device__ __forceinline__ RoundIds(const uint32_t *ids, uint32_t t0, uint32_t n) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) r[g] = (t0 + g < n) ? ids[t0 + g] : kSentinel;
-        last_pass = max(max(pass_of(1), pass_of(2)), pass_of(3));
+        r0 = (t0 + 0 < n) ? ids[t0 + 0] : kSentinel;
+        r1 = (t0 + 1 < n) ? ids[t0 + 1] : kSentinel;
+        r2 = (t0 + 2 < n) ? ids[t0 + 2] : kSentinel;
+        r3 = (t0 + 3 < n) ? ids[t0 + 3] : kSentinel;
+        last_pass = max(max(pass1(), pass2()), pass3());
+    }
+    __device__ __forceinline__ uint32_t row_of(int g) const {
+        return g == 0 ? r0 : g == 1 ? r1 : g == 2 ? r2 : r3;
     }
     // number of earlier groups of this round holding the same (valid) row
+    __device__ __forceinline__ int pass1() const { return (r1 != kSentinel && r1 == r0) ? 1 : 0; }
+    __device__ __forceinline__ int pass2() const {
+        return r2 == kSentinel ? 0 : (int)(r2 == r0) + (int)(r2 == r1);
+    }
+    __device__ __forceinline__ int pass3() const {
+        return r3 == kSentinel ? 0 : (int)(r3 == r0) + (int)(r3 == r1) + (int)(r3 == r2);
+    }
     __device__ __forceinline__ int pass_of(int g) const {
-        int p = 0;
-#pragma unroll
-        for (int e = 0; e < 3; ++e)
-            if (e < g && r[g] != kSentinel && r[e] == r[g]) ++p;
-        return p;
+        return g == 0 ? 0 : g == 1 ? pass1() : g == 2 ? pass2() : pass3();
     }
 };
 
@@ -250,7 +258,7 @@ __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, 
         for (uint32_t t0 = 0; t0 < n_samples; t0 += 4) {
             const uint32_t t = t0 + grp;
             const RoundIds ids(s_rows, t0, n_samples);
-            const uint32_t row = ids.r[grp];
+            const uint32_t row = ids.row_of(grp);
             const float lab = t < n_samples ? s_lab[t] : 0.f;
             const bool valid = row != kSentinel;
             const int my_pass = ids.pass_of(grp);
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                 // context node ids of this centre were staged behind the sample list
                 for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
                     const RoundIds ids(s_ctx, r0, n_ctx);
-                    const uint32_t row = ids.r[grp];
+                    const uint32_t row = ids.row_of(grp);
                     const bool valid = row != kSentinel;
                     const int my_pass = ids.pass_of(grp);
                     float *base = a.contextual + (uint64_t)(valid ? row : 0) * a.ld;
@@ -479,6 +487,29 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
             atomicAdd(&a.counters[2], (unsigned long long)centres);
         }
         wave_sync();
+    }
+}
+
+// Traffic calibration: every listed row is read and written exactly once with the same access
+// shape as the training kernels (16 lanes x float4 per row, same store flavour), so the HBM
+// bytes of a launch are known exactly (n * ld * 4 read + written, + 4 B of id per row).  Used to
+// calibrate the FETCH_SIZE / WRITE_SIZE counters for this access pattern (profiles/README.md).
+template <int CH, int WM>
+__global__ __launch_bounds__(kTrainBlock) void touch_rows_kernel(float *table, uint32_t ld,
+                                                                 const uint32_t *ids, uint64_t n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint32_t nchunks = ld >> 2;
+    const uint64_t stride = (uint64_t)gridDim.x * (kTrainBlock / 64) * 4;
+    Row<CH> ones;
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) ones.c[cc] = make_float4(1.f, 1.f, 1.f, 1.f);
+    for (uint64_t i = ((uint64_t)blockIdx.x * (kTrainBlock / 64) + wave) * 4 + grp; i < n;
+         i += stride) {
+        float *base = table + (uint64_t)ids[i] * ld;
+        Row<CH> v;
+        load_row<CH>(v, base, q, nchunks, true);
+        scatter_add<CH, WM>(base, q, nchunks, 1.0f, ones, v);
     }
 }
 

@@ -99,6 +99,14 @@ def cbow_step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, con
           contextual, neg_override)
 
 
+def touch_rows(table, ids, flags: int = 0):
+    """table[ids] += 1 with the training kernels' access shape (traffic calibration)."""
+    dev = table.device
+    assert table.is_contiguous() and ids.is_contiguous()
+    _lib.check(_lib.lib().gn2v_touch_rows(table.data_ptr(), table.shape[1], ids.data_ptr(),
+                                          ids.numel(), flags, _stream(dev)))
+
+
 def stats_reset(graph: CSRGraph, device: int = 0):
     dg = graph.device_graph(device)
     _lib.check(_lib.lib().gn2v_stats_reset(dg.handle, _stream(_torch().device("cuda", device))))

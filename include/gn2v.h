@@ -145,6 +145,13 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
                uint64_t seed, uint64_t max_walks_per_epoch, float *d_central,
                float *d_contextual, gn2v_stats *stats, void *stream);
 
+/* Traffic-calibration utility: table[ids[i]][:] += 1 for i < n with the access shape and store
+ * flavour (flags: GN2V_TRAIN_ATOMIC / _WRITE_BACK / _WRITE_THROUGH, default write-through) of the
+ * training kernels.  With distinct ids the HBM bytes of the launch are exactly n * ld * 8 + n * 4,
+ * which calibrates the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (profiles/README.md). */
+int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t n, uint32_t flags,
+                    void *stream);
+
 /* counters accumulated on the handle by the step / walk entry points since the last reset */
 int gn2v_stats_reset(gn2v_graph *g, void *stream);
 int gn2v_stats_read(gn2v_graph *g, gn2v_stats *stats, void *stream); /* synchronises */

@@ -1,0 +1,126 @@
+"""Turn the raw rocprofv3 CSVs of scripts/profile_bench.sh into the committed evidence:
+    python scripts/summarize_profiles.py r01
+reads gpurun_out/prof_<tag>/ and writes profiles/<tag>_kernel_stats.csv (the --stats table, top
+rows), profiles/<tag>_pmc.json (per-launch FETCH_SIZE / WRITE_SIZE of the dominant kernel, the
+calibration factors and the corrected HBM traffic) and profiles/<tag>_summary.md.
+
+Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are
+KiB, collected in separate --pmc passes; on gfx950 FETCH_SIZE under-reports wide coalesced reads
+(128 B requests tallied as 64 B) and WRITE_SIZE is uncalibrated, so both are calibrated on
+gn2v::touch_rows_kernel, which moves an exactly known byte count with the same access shape.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BYTES_PER_PAIR = 12288
+
+
+def one(pattern):
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        raise SystemExit(f"missing {pattern}")
+    return files[0]
+
+
+def per_kernel_counter(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def pick(agg, needle):
+    for name, vals in agg.items():
+        if needle in name:
+            return name, vals
+    raise SystemExit(f"kernel {needle} not found")
+
+
+def main(tag):
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = list(csv.DictReader(open(one(f"{src}/stats/**/*kernel_stats.csv"))))
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in stats[:12]:
+            w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                        r["Percentage"], r["MinNs"], r["MaxNs"]])
+    sg = next(r for r in stats if "sgns_kernel" in r["Name"])
+    wk = next(r for r in stats if "walk_kernel" in r["Name"])
+    avg_ms = float(sg["AverageNs"]) / 1e6
+
+    fetch = per_kernel_counter(one(f"{src}/fetch/**/*counter_collection.csv"), "FETCH_SIZE")
+    write = per_kernel_counter(one(f"{src}/write/**/*counter_collection.csv"), "WRITE_SIZE")
+    _, f_vals = pick(fetch, "sgns_kernel")
+    _, w_vals = pick(write, "sgns_kernel")
+    cal_f = per_kernel_counter(one(f"{src}/cal_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
+    cal_w = per_kernel_counter(one(f"{src}/cal_write/**/*counter_collection.csv"), "WRITE_SIZE")
+    _, cf = pick(cal_f, "touch_rows_kernel")
+    _, cw = pick(cal_w, "touch_rows_kernel")
+    cal = json.loads([l for l in open(f"{src}/cal_fetch.log") if l.startswith("{")][-1])
+    bench = json.loads([l for l in open(f"{src}/stats.log") if l.startswith("{")][-1])
+
+    mean = lambda v: sum(v) / len(v)  # noqa: E731
+    fetch_factor = cal["read_bytes_per_launch"] / (mean(cf) * 1024)
+    write_factor = cal["write_bytes_per_launch"] / (mean(cw) * 1024)
+    raw_f, raw_w = mean(f_vals) * 1024, mean(w_vals) * 1024
+    read_b, write_b = raw_f * fetch_factor, raw_w * write_factor
+    pairs_per_launch = bench["roofline"]["algorithmic_bytes_per_launch"] / BYTES_PER_PAIR
+    alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+    out = {
+        "tag": tag,
+        "command": "bench.py " + " ".join(bench.get("argv", [])),
+        "kernel": sg["Name"],
+        "launches_profiled": int(sg["Calls"]),
+        "avg_launch_ms_rocprof": avg_ms,
+        "avg_launch_ms_bench_hip_events": bench["roofline"]["avg_launch_ms"],
+        "pairs_per_launch": pairs_per_launch,
+        "algorithmic_bytes_per_launch": alg,
+        "algorithmic_GBps": alg / (avg_ms * 1e-3) / 1e9,
+        "frac_of_8TBps": alg / (avg_ms * 1e-3) / 8e12,
+        "FETCH_SIZE_KiB_per_launch": mean(f_vals),
+        "WRITE_SIZE_KiB_per_launch": mean(w_vals),
+        "calibration": {
+            "kernel": "gn2v::touch_rows_kernel",
+            "known_read_bytes": cal["read_bytes_per_launch"],
+            "known_write_bytes": cal["write_bytes_per_launch"],
+            "FETCH_SIZE_KiB": mean(cf), "WRITE_SIZE_KiB": mean(cw),
+            "fetch_factor": fetch_factor, "write_factor": write_factor,
+            "touch_rows_GBps": cal["GBps"],
+        },
+        "hbm_read_bytes_per_launch": read_b,
+        "hbm_write_bytes_per_launch": write_b,
+        "hbm_traffic_bytes_per_launch": read_b + write_b,
+        "hbm_traffic_GBps": (read_b + write_b) / (avg_ms * 1e-3) / 1e9,
+        "traffic_over_algorithmic": (read_b + write_b) / alg,
+        "walk_kernel_avg_ms": float(wk["AverageNs"]) / 1e6,
+        "config": bench["config"],
+    }
+    with open(os.path.join(dst, f"{tag}_pmc.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
+        f.write(f"# rocprofv3 summary `{tag}`\n\n")
+        f.write(f"Workload: {bench['config']['workload']} (update mode {bench['config']['update_mode']}).\n\n")
+        f.write("| kernel | calls | avg ms | % of GPU time |\n|---|---|---|---|\n")
+        for r in stats[:6]:
+            f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {r['Percentage']} |\n")
+        f.write(f"\n`sgns_kernel`: {pairs_per_launch:.0f} pairs per launch, {avg_ms:.2f} ms (rocprof) vs "
+                f"{bench['roofline']['avg_launch_ms']:.2f} ms (HIP events in bench.py) -> "
+                f"{out['algorithmic_GBps']:.0f} GB/s algorithmic = {out['frac_of_8TBps']:.3f} of 8 TB/s.\n\n")
+        f.write(f"PMC (separate passes): FETCH_SIZE {mean(f_vals):.0f} KiB, WRITE_SIZE {mean(w_vals):.0f} KiB per launch; "
+                f"calibration on `touch_rows_kernel` (known bytes): fetch x{fetch_factor:.3f}, write x{write_factor:.3f} -> "
+                f"HBM traffic {out['hbm_traffic_bytes_per_launch'] / 1e9:.1f} GB per launch = {out['hbm_traffic_GBps']:.0f} GB/s "
+                f"({out['traffic_over_algorithmic']:.3f} x the algorithmic bytes).\n")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
