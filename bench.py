@@ -69,6 +69,26 @@ def usable_cores() -> int:
     return cores
 
 
+def committed_traffic(config, update_mode):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/*_pmc.json, made by scripts/profile_bench.sh + summarize_profiles.py) when they were
+    taken on this very workload; None otherwise (counters cannot be read from inside the run)."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        same = (rec.get("config", {}).get("workload") == config["workload"]
+                and rec.get("config", {}).get("walks_per_launch") == config["walks_per_launch"]
+                and rec.get("config", {}).get("update_mode") == update_mode)
+        if same:
+            best = (rec["hbm_traffic_bytes_per_launch"], os.path.basename(path))
+    return best
+
+
 def cpu_baseline(graph, args, central, contextual, seconds):
     """The oracle's OpenMP Hogwild restatement timed on this box's host cores, on a bounded
     sample of the same workload (same graph, same parameters, walk ids past the GPU's)."""
@@ -241,6 +261,13 @@ def main():
                 "launches": st["train_launches"],
             },
         }
+        pmc = committed_traffic(line["config"], args.mode)
+        if pmc is not None:
+            bytes_per_launch, source = pmc
+            line["roofline"]["traffic"] = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+            line["roofline"]["traffic_bytes_per_launch"] = bytes_per_launch
+            line["roofline"]["traffic_source"] = f"profiles/{source} (rocprofv3 --pmc FETCH_SIZE / " \
+                                                 "WRITE_SIZE, calibrated; same workload)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(graph, args, central, contextual, args.cpu_seconds)
         print(json.dumps(line), flush=True)
