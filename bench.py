@@ -12,8 +12,8 @@ second-order walks on the GPU and train on all of them (1 250 pairs per walk).  
 tables are resident in HBM before the timed region.
 
 N > 1: one process per GPU, CSR replicated, every rank trains on its own slice of the walk ids
-(weak scaling: per-GPU work fixed) against a full replica of both tables; replicas are averaged
-with one RCCL all-reduce per table per step (inside the timed region).  See DESIGN.md
+(weak scaling: per-GPU work fixed) against a full replica of both tables; after every step the
+replicas sum their deltas with one RCCL all-reduce per table (inside the timed region).  See DESIGN.md
 "Multi-GPU" for why this is the round-1 form and what the row-sharded form changes.
 
 Prints ONE JSON line on rank 0.
@@ -50,6 +50,9 @@ def parse():
                     help="run the traffic-calibration kernel instead of training (for rocprofv3 "
                          "--pmc passes): every table row touched exactly once per launch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="testing only: all ranks use GPU 0 (use with --backend gloo)")
     return ap.parse_args()
 
 
@@ -144,12 +147,17 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     _lib.require_device()
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     graph = E.barabasi_albert(args.nodes, args.m, 42, device=local)
     n, d = graph.get_number_of_nodes(), args.d
@@ -177,20 +185,19 @@ def main():
         return
     tp = ops.train_params(_lib.MODEL_SKIPGRAM, d, 10, 5, lr=0.01, flags=flags)
     wp = ops.walk_params(128, 10, args.return_weight, args.explore_weight)
-    walk_buf = [None]
+    from embiggen_amd.distributed import ReplicaSync, walk_slice
+
+    replicas = ReplicaSync(central, contextual)
 
     def step(index):
-        """walks [first, first + args.walks) of this rank, in launches of args.batch walks"""
-        first = (index * world + rank) * args.walks
-        for off in range(0, args.walks, args.batch):
-            nb = min(args.batch, args.walks - off)
+        """this rank's slice of the step's walk ids, in launches of args.batch walks; then the
+        replicas exchange their deltas (one RCCL all-reduce per table)"""
+        first, count = walk_slice(index, rank, world, args.walks)
+        for off in range(0, count, args.batch):
+            nb = min(args.batch, count - off)
             wk = ops.walks(graph, wp, 42, 0, first + off, nb, device=local)
             ops.sgns_step(graph, tp, wk, 42, 0, first + off, 0.01, central, contextual)
-            walk_buf[0] = wk
-        if world > 1:
-            for t in (central, contextual):
-                dist.all_reduce(t)
-                t.mul_(1.0 / world)
+        replicas.sync()
 
     def fence():
         torch.cuda.synchronize()
@@ -242,7 +249,7 @@ def main():
                 "update_mode": args.mode,
                 "walks_per_launch": args.batch,
                 "parallelism": "1 GPU" if world == 1 else
-                               f"{world} table replicas, walks partitioned, all-reduce average per step",
+                               f"{world} table replicas, walks partitioned by id, delta-sum all-reduce per table per step",
             },
             "walk_steps_per_s": total_steps / elapsed,
             "walk_kernel_steps_per_s": st["walk_steps"] / max(st["walk_ms"] * 1e-3, 1e-12),
