@@ -39,7 +39,10 @@ def parse():
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--walks", type=int, default=1 << 19, help="walks per step per GPU")
-    ap.add_argument("--batch", type=int, default=1 << 16, help="walks per kernel launch")
+    ap.add_argument("--batch", type=int, default=1 << 16, help="walks per training launch")
+    ap.add_argument("--walk-batch", type=int, default=1 << 19,
+                    help="walks per walk-kernel launch (the sampler is latency bound: it needs "
+                         "many more walkers in flight than one training launch consumes)")
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--mode", default="auto",
                     choices=["auto", "write_through", "write_back", "atomic"])
@@ -193,10 +196,13 @@ def main():
         """this rank's slice of the step's walk ids, in launches of args.batch walks; then the
         replicas exchange their deltas (one RCCL all-reduce per table)"""
         first, count = walk_slice(index, rank, world, args.walks)
-        for off in range(0, count, args.batch):
-            nb = min(args.batch, count - off)
-            wk = ops.walks(graph, wp, 42, 0, first + off, nb, device=local)
-            ops.sgns_step(graph, tp, wk, 42, 0, first + off, 0.01, central, contextual)
+        for woff in range(0, count, args.walk_batch):
+            nw = min(args.walk_batch, count - woff)
+            wk = ops.walks(graph, wp, 42, 0, first + woff, nw, device=local)
+            for off in range(0, nw, args.batch):
+                nb = min(args.batch, nw - off)
+                ops.sgns_step(graph, tp, wk[off:off + nb], 42, 0, first + woff + off, 0.01,
+                              central, contextual)
         replicas.sync()
 
     def fence():

@@ -9,6 +9,7 @@ from . import _lib
 from .embedders import (DeepWalkCBOWEnsmallen, DeepWalkSkipGramEnsmallen, Node2VecCBOWEnsmallen,
                         Node2VecSkipGramEnsmallen, embed_graph)
 from .graph import CSRGraph, barabasi_albert, karate_club
+from .sequences import Node2VecSequence
 from .utils import (AbstractEmbeddingModel, AbstractModel, EmbeddingResult,
                     get_available_models_for_node_embedding, get_models_dataframe,
                     normalize_kwargs)
@@ -20,4 +21,5 @@ __all__ = [
     "AbstractEmbeddingModel", "embed_graph", "Node2VecSkipGramEnsmallen",
     "Node2VecCBOWEnsmallen", "DeepWalkSkipGramEnsmallen", "DeepWalkCBOWEnsmallen",
     "get_models_dataframe", "get_available_models_for_node_embedding", "normalize_kwargs",
+    "Node2VecSequence",
 ]

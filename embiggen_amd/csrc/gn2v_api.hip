@@ -475,19 +475,27 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
     uint64_t walks_per_epoch = g->view.n_sources * (uint64_t)wp->iterations;
     if (max_walks_per_epoch && max_walks_per_epoch < walks_per_epoch)
         walks_per_epoch = max_walks_per_epoch;
-    // walk batches: large enough to fill the chip several times, small enough to stay cheap
-    const uint64_t batch = std::min<uint64_t>(walks_per_epoch, (uint64_t)1 << 16);
+    // The walk sampler is latency bound (one walker per lane, dependent loads), so it wants many
+    // more walkers in flight than one training launch consumes: walks are generated 2^19 at a
+    // time (256 MiB at walk_length 128) and trained in launches of 2^16.
+    const uint64_t walk_batch = std::min<uint64_t>(walks_per_epoch, (uint64_t)1 << 19);
+    const uint64_t train_batch = (uint64_t)1 << 16;
     uint32_t *d_walks = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_walks, batch * L * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&d_walks, walk_batch * L * sizeof(uint32_t)));
     float lr = tp->lr;
     int rc = 0;
     for (uint32_t e = 0; e < tp->epochs && !rc; ++e) {
-        for (uint64_t first = 0; first < walks_per_epoch && !rc; first += batch) {
-            const uint64_t n = std::min(batch, walks_per_epoch - first);
-            rc = launch_walks(g, wp, seed, e, first, n, d_walks, s);
-            if (!rc)
-                rc = launch_train(g, cbow, tp, d_walks, n, L, seed, e, first, lr, d_central,
-                                  d_contextual, nullptr, s);
+        for (uint64_t first = 0; first < walks_per_epoch && !rc; first += walk_batch) {
+            const uint64_t nw = std::min(walk_batch, walks_per_epoch - first);
+            rc = launch_walks(g, wp, seed, e, first, nw, d_walks, s);
+            for (uint64_t off = 0; off < nw && !rc; off += train_batch) {
+                const uint64_t n = std::min(train_batch, nw - off);
+                rc = launch_train(g, cbow, tp, d_walks + off * L, n, L, seed, e, first + off, lr,
+                                  d_central, d_contextual, nullptr, s);
+            }
+            if (!rc && g->train_events.size() > 2048) {  // bound the event pool on long fits
+                if (hipStreamSynchronize(s) != hipSuccess || fold_events(g)) rc = 1;
+            }
         }
         lr *= tp->lr_decay;
     }

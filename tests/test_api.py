@@ -200,3 +200,17 @@ def test_missing_library_is_a_module_not_found(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libgn2v.so"))
     with pytest.raises(ModuleNotFoundError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_node2vec_sequence_signature_and_shape_contract(karate):
+    """Constructor defaults of the reference sequence (node2vec_sequence.py:14-27) and the batch
+    geometry (:115-128); the batch content itself needs the GPU (tests/test_gpu_api.py)."""
+    sig = inspect.signature(E.Node2VecSequence.__init__)
+    ours = {p.name: p.default for p in sig.parameters.values()
+            if p.name not in ("self", "graph", "device", "return_device_tensors")}
+    assert ours == API["sequence_defaults"]
+    seq = E.Node2VecSequence(karate, walk_length=20, batch_size=8, iterations=3, window_size=2)
+    assert seq.sample_number == 34 and len(seq) == 5 and seq.steps_per_epoch == 5
+    assert seq.number_of_skipgrams == 8 * 3 * 16
+    with pytest.raises(ValueError):
+        E.Node2VecSequence(karate, walk_length=8, window_size=4)

@@ -71,3 +71,27 @@ def test_weighted_graph_and_disconnected_warning():
         res = E.Node2VecSkipGramEnsmallen(embedding_size=4, epochs=1, walk_length=6,
                                           verbose=False).fit_transform(g)
     assert res.get_node_embedding_from_index(0).shape == (5, 4)
+
+
+def test_node2vec_sequence_batches_match_oracle(karate, karate_oracle):
+    """(contexts, words) batches of the sequence == the oracle's windows over the oracle's walks
+    with the reference's seeding rule random_state + idx + elapsed_epochs
+    (node2vec_sequence.py:190-203)."""
+    from oracle import oracle as O
+
+    seq = E.Node2VecSequence(karate, walk_length=20, batch_size=8, iterations=3, window_size=2,
+                             return_weight=0.5, explore_weight=2.0, random_state=5)
+    owp = O.WalkParams(20, 3, 0.5, 2.0, 100, 0)
+    for idx, epochs in ((0, 0), (3, 0), (4, 1)):  # idx 4 wraps around the 34 sources
+        seq.elapsed_epochs = epochs
+        (((contexts, words),),) = seq[idx]
+        assert contexts.shape == (8 * 3 * 16, 4) and contexts.dtype == np.int32
+        assert words.shape == (8 * 3 * 16,) and words.dtype == np.int32
+        seed, first = 5 + idx + epochs, (idx * 8) % 34
+        ref = np.concatenate([O.walks(karate_oracle, owp, seed, 0, 2 * it * 34 + first, 8)
+                              for it in range(3)])
+        rc, rw = O.window_batch(ref, 2)
+        assert np.array_equal(contexts, rc) and np.array_equal(words, rw)
+        assert set(ref[:, 0].tolist()) == {(first + b) % 34 for b in range(8)}
+    a = seq()
+    assert a[0][0][0].shape == (384, 4)

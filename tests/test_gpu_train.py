@@ -230,3 +230,50 @@ def test_full_size_training_properties():
     assert torch.equal(c[~visited], c0[~visited])  # central rows change only for walk nodes
     moved = (c[visited] - c0[visited]).abs().amax(1)
     assert float((moved > 0).float().mean()) > 0.99
+
+
+def test_config2_cora_shaped_graph_parity():
+    """BASELINE config 2: Cora-shaped BA graph (2 708 nodes / ~5.4 k edges), SkipGram d = 128,
+    p = q = 1.  Deterministic schedule vs oracle on a reduced walk budget (the single-wavefront
+    schedule is slow by construction), then the production schedule's quality vs the oracle's."""
+    s, d_ = O.ba_edges(2708, 2, 42)
+    g = E.CSRGraph.from_edge_list(s, d_, number_of_nodes=2708, name="BA-shaped-like-Cora")
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    kw = dict(embedding_size=128, epochs=1, walk_length=16, iterations=1, window_size=5,
+              return_weight=1.0, explore_weight=1.0, verbose=False)
+    m = E.Node2VecSkipGramEnsmallen(**kw)
+    m._model.deterministic = True
+    res = m.fit_transform(g, return_dataframe=False).get_all_node_embedding()
+    rc, rx, pairs = O.fit(og, O.WalkParams(16, 1, 1.0, 1.0, 100, 0),
+                          O.TrainParams(0, 128, 128, 1, 10, 5, 0.01, 0.9, 6.0, 1, 128 ** -0.5), 42)
+    assert m.get_last_stats()["pairs"] == pairs
+    assert np.abs(res[0] - rc).max() < 1e-5 and np.abs(res[1] - rx).max() < 1e-5
+
+    kw.update(epochs=3, walk_length=64, iterations=4, learning_rate=0.025)
+    m = E.Node2VecSkipGramEnsmallen(**kw)
+    res = m.fit_transform(g, return_dataframe=False).get_all_node_embedding()
+    rc, rx, pairs = O.fit(og, O.WalkParams(64, 4, 1.0, 1.0, 100, 0),
+                          O.TrainParams(0, 128, 128, 3, 10, 5, 0.025, 0.9, 6.0, 1, 128 ** -0.5), 42,
+                          threads=8)
+    assert m.get_last_stats()["pairs"] == pairs
+    auc_gpu, auc_ref = link_auc(g, res[0], res[1]), link_auc(g, rc, rx)
+    assert auc_gpu > auc_ref - 0.03, (auc_gpu, auc_ref)
+
+
+def test_config3_arxiv_shaped_graph_walks_and_training():
+    """BASELINE config 3: ogbn-arxiv-shaped BA graph (169 343 nodes / ~1.17 M edges), Node2Vec
+    p = 0.5, q = 2 (return_weight 2, explore_weight 0.5), d = 128: one full iteration of walks is
+    bit-identical to the oracle; a training pass stays finite and counts the closed-form pairs."""
+    g = E.barabasi_albert(169_343, 7, 42, name="BA-shaped-like-ogbn-arxiv")
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    n = g.get_number_of_nodes()
+    wp = ops.walk_params(128, 1, 2.0, 0.5)
+    wk = ops.walks(g, wp, 42, 0, 0, n)
+    ref = O.walks(og, O.WalkParams(128, 1, 2.0, 0.5, 100, 0), 42, 0, 0, n)
+    assert np.array_equal(wk.cpu().numpy().view(np.uint32), ref)
+    c, x = _tables(n, 128, 42)
+    ops.stats_reset(g)
+    ops.sgns_step(g, ops.train_params(0, 128, 10, 5), wk, 42, 0, 0, 0.01, c, x)
+    st = ops.stats_read(g)
+    assert st["pairs"] == n * 1250
+    assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
