@@ -201,8 +201,9 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const ui
                    : g->view.n_nodes < (1ULL << 20)         ? gn2v::kAtomic
                                                             : gn2v::kWriteThrough;
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
-    const size_t lds =
-        (size_t)waves_per_block * (L + 2 * (size_t)a.max_samples + (cbow ? 2 * tp->window : 0)) * 4;
+    const size_t per_wave_words =
+        ((size_t)tp->ld + L + 2 * (size_t)a.max_samples + (cbow ? 2 * tp->window : 0) + 3) & ~(size_t)3;
+    const size_t lds = (size_t)waves_per_block * per_wave_words * 4;
     if (lds > 64 * 1024) return fail("walk_length / window / negatives too large for the LDS plan");
     uint64_t blocks = det ? 1 : (n_walks + waves_per_block - 1) / waves_per_block;
     const uint64_t cap = (uint64_t)g->n_cus * 8;
@@ -390,6 +391,8 @@ int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d
                         d_central, d_contextual, d_neg_override, (hipStream_t)stream);
 }
 
+static bool nchunks_is_32(uint32_t ld) { return ld / 4 > 16 && ld / 4 <= 32; }
+
 int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t n, uint32_t flags,
                     void *stream) {
     if (!d_table || !d_ids) return fail("NULL pointer");
@@ -400,6 +403,22 @@ int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t
                                                      : gn2v::kWriteThrough;
     const unsigned blocks = (unsigned)std::min<uint64_t>((n + 15) / 16, 256 * 8);
     hipStream_t s = (hipStream_t)stream;
+    if ((flags & 512u) && nchunks_is_32(ld)) {  // experiment: lane-contiguous atomics
+        hipLaunchKernelGGL((gn2v::touch_rows_atomic_contig_kernel<2>), dim3(blocks),
+                           dim3(gn2v::kTrainBlock), 0, s, d_table, ld, d_ids, n);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if ((flags & 256u) && nchunks_is_32(ld)) {  // experiment: 2 rounds in flight (d = 128 only)
+        if (wm == gn2v::kWriteBack)
+            hipLaunchKernelGGL((gn2v::touch_rows2_kernel<2, gn2v::kWriteBack>), dim3(blocks),
+                               dim3(gn2v::kTrainBlock), 0, s, d_table, ld, d_ids, n);
+        else
+            hipLaunchKernelGGL((gn2v::touch_rows2_kernel<2, gn2v::kWriteThrough>), dim3(blocks),
+                               dim3(gn2v::kTrainBlock), 0, s, d_table, ld, d_ids, n);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #define GN2V_TOUCH(CH)                                                                          \
     do {                                                                                        \
         if (wm == gn2v::kAtomic)                                                                \

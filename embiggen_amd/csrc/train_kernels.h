@@ -103,7 +103,8 @@ __device__ __forceinline__ void axpy(Row<CH> &acc, float s, const Row<CH> &x) {
 //                  XCD's L2) -- Hogwild like the CPU reference, visible to every XCD at once.
 //   kWriteBack:    read-modify-write, plain stores (dirty lines stay private to an XCD's L2
 //                  until evicted: hot rows diverge per XCD inside a launch).
-//   kAtomic:       hardware f32 atomics, one per element (no lost update, ~10x the store cost).
+//   kAtomic:       hardware f32 atomics, one per element, lane-contiguous addresses (no lost
+//                  update; ~2-3x the store cost).
 enum WriteMode : int { kWriteThrough = 0, kWriteBack = 1, kAtomic = 2 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -114,21 +115,26 @@ __device__ __forceinline__ void store_sc1(float *p, float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
 }
 
-// table row += s * x
+// table row += s * x   (x: float4 shape for the store modes, lane-contiguous shape for kAtomic)
 template <int CH, int WM>
 __device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks, float s,
                                             const Row<CH> &x, const Row<CH> &old) {
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
-        const uint32_t ci = cc * 16 + q;
-        if (ci < nchunks) {
-            float *p = base + ci * 4;
-            if constexpr (WM == kAtomic) {
-                unsafeAtomicAdd(p + 0, s * x.c[cc].x);
-                unsafeAtomicAdd(p + 1, s * x.c[cc].y);
-                unsafeAtomicAdd(p + 2, s * x.c[cc].z);
-                unsafeAtomicAdd(p + 3, s * x.c[cc].w);
-            } else {
+        if constexpr (WM == kAtomic) {
+            // slot (cc, e) of lane q is element 64*cc + 16*e + q (to_contig_layout), so each
+            // atomic instruction covers 64 contiguous bytes per group -- measured 4x the
+            // throughput of float4-shaped (16 B strided) atomics.
+            float *pc = base + cc * 64 + q;
+            const uint32_t f = cc * 64 + q, ldf = nchunks * 4;
+            if (f < ldf) unsafeAtomicAdd(pc + 0, s * x.c[cc].x);
+            if (f + 16 < ldf) unsafeAtomicAdd(pc + 16, s * x.c[cc].y);
+            if (f + 32 < ldf) unsafeAtomicAdd(pc + 32, s * x.c[cc].z);
+            if (f + 48 < ldf) unsafeAtomicAdd(pc + 48, s * x.c[cc].w);
+        } else {
+            const uint32_t ci = cc * 16 + q;
+            if (ci < nchunks) {
+                float *p = base + ci * 4;
                 float4 o = old.c[cc];
                 o.x += s * x.c[cc].x;
                 o.y += s * x.c[cc].y;
@@ -156,6 +162,31 @@ __device__ __forceinline__ void reduce_groups(Row<CH> &r) {
             v += __shfl_xor(v, 32);
             f[e] = v;
         }
+    }
+}
+
+// Re-layout a register row from the float4 shape (slot (cc, e) of lane q = element 64cc + 4q + e)
+// to the lane-contiguous shape (element 64cc + 16e + q) through a per-wave LDS row.  `in` must be
+// identical in all four groups (group 0 writes).  Used once per centre in atomic mode.
+template <int CH>
+__device__ __forceinline__ void to_contig_layout(Row<CH> &out, const Row<CH> &in, float *s_tr,
+                                                 int grp, int q, uint32_t ld) {
+    wave_sync();
+    if (grp == 0) {
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) {
+            const uint32_t ci = cc * 16 + q;
+            if (ci * 4 < ld) *reinterpret_cast<float4 *>(s_tr + ci * 4) = in.c[cc];
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        const uint32_t f = cc * 64 + q;
+        out.c[cc].x = f < ld ? s_tr[f] : 0.f;
+        out.c[cc].y = f + 16 < ld ? s_tr[f + 16] : 0.f;
+        out.c[cc].z = f + 32 < ld ? s_tr[f + 32] : 0.f;
+        out.c[cc].w = f + 48 < ld ? s_tr[f + 48] : 0.f;
     }
 }
 
@@ -234,10 +265,12 @@ struct RoundIds {
 
 // Score the staged sample list against the register row `u` (replicated in every group):
 // for each sample row v: var = (label - sigmoid(clip(u.v))) * lr ; g += var * v ; v += var * u.
+// u_upd is the copy of u the row update consumes (lane-contiguous shape in atomic mode).
 // DET: one sample at a time, all groups redundantly, group 0 writes (strict sequential semantics).
 template <int CH, int WM, bool DET>
 __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, const Row<CH> &u,
-                                              Row<CH> &g, const uint32_t *s_rows,
+                                              const Row<CH> &u_upd, Row<CH> &g,
+                                              const uint32_t *s_rows,
                                               const float *s_lab, uint32_t n_samples, float lrc,
                                               int grp, int q) {
     const uint32_t nchunks = a.ld >> 2;
@@ -270,7 +303,7 @@ __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, 
                 const float dot = dot_rows<CH>(u, v);
                 const float var = mine ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
                 axpy<CH>(g, var, v);
-                if (mine) scatter_add<CH, WM>(base, q, nchunks, var, u, v);
+                if (mine) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
             }
         }
     }
@@ -285,14 +318,15 @@ __device__ __forceinline__ void zero_row(Row<CH> &r) {
 constexpr int kTrainBlock = 256;
 
 // SkipGram with negative sampling over a batch of walks.
-// LDS per wave: walk[L] | rows[max_samples] | labels[max_samples].
+// LDS per wave: transpose row[ld] | walk[L] | rows[max_samples] | labels[max_samples].
 template <int CH, int WM, bool DET>
 __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
-    const uint32_t per_wave = a.L + 2 * a.max_samples;
-    uint32_t *s_walk = smem + wave * per_wave;
+    const uint32_t per_wave = (a.ld + a.L + 2 * a.max_samples + 3) & ~3u;
+    float *s_tr = reinterpret_cast<float *>(smem + wave * per_wave);
+    uint32_t *s_walk = smem + wave * per_wave + a.ld;
     uint32_t *s_rows = s_walk + a.L;
     float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
     const uint32_t nchunks = a.ld >> 2;
@@ -345,9 +379,12 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
             Row<CH> u, g;
             load_row<CH>(u, crow, q, nchunks, true);
             zero_row<CH>(g);
-            score_samples<CH, WM, DET>(a, a.contextual, u, g, s_rows, s_lab, n_samples, lrc,
-                                           grp, q);
+            Row<CH> u_upd = u;
+            if constexpr (!DET && WM == kAtomic) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
+            score_samples<CH, WM, DET>(a, a.contextual, u, u_upd, g, s_rows, s_lab, n_samples,
+                                       lrc, grp, q);
             if constexpr (!DET) reduce_groups<CH>(g);
+            if constexpr (!DET && WM == kAtomic) to_contig_layout<CH>(g, g, s_tr, grp, q, a.ld);
             if (grp == 0) scatter_add<CH, DET ? kWriteBack : WM>(crow, q, nchunks, 1.0f, g, u);
             if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             pairs += n_ctx;
@@ -369,8 +406,9 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
-    const uint32_t per_wave = a.L + 2 * a.max_samples + 2 * a.window;
-    uint32_t *s_walk = smem + wave * per_wave;
+    const uint32_t per_wave = (a.ld + a.L + 2 * a.max_samples + 2 * a.window + 3) & ~3u;
+    float *s_tr = reinterpret_cast<float *>(smem + wave * per_wave);
+    uint32_t *s_walk = smem + wave * per_wave + a.ld;
     uint32_t *s_rows = s_walk + a.L;
     float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
     uint32_t *s_ctx = s_rows + 2 * a.max_samples;  // 2w context ids of the current centre
@@ -450,8 +488,12 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                 h.c[cc].w *= invC;
             }
 
-            score_samples<CH, WM, DET>(a, a.central, h, g, s_rows, s_lab, k + 1, lrc, grp, q);
+            Row<CH> h_upd = h;
+            if constexpr (!DET && WM == kAtomic) to_contig_layout<CH>(h_upd, h, s_tr, grp, q, a.ld);
+            score_samples<CH, WM, DET>(a, a.central, h, h_upd, g, s_rows, s_lab, k + 1, lrc, grp,
+                                       q);
             if constexpr (!DET) reduce_groups<CH>(g);
+            if constexpr (!DET && WM == kAtomic) to_contig_layout<CH>(g, g, s_tr, grp, q, a.ld);
 
             // every context row += g / C
             if constexpr (DET) {
@@ -494,6 +536,52 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
 // shape as the training kernels (16 lanes x float4 per row, same store flavour), so the HBM
 // bytes of a launch are known exactly (n * ld * 4 read + written, + 4 B of id per row).  Used to
 // calibrate the FETCH_SIZE / WRITE_SIZE counters for this access pattern (profiles/README.md).
+// experiment: f32 atomics with lane-contiguous addresses (lane q -> float 64*cc + 16*e + q)
+// instead of the float4-shaped stride (float 64*cc + 4*q + e)
+template <int CH>
+__global__ __launch_bounds__(kTrainBlock) void touch_rows_atomic_contig_kernel(
+    float *table, uint32_t ld, const uint32_t *ids, uint64_t n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint64_t stride = (uint64_t)gridDim.x * (kTrainBlock / 64) * 4;
+    for (uint64_t i = ((uint64_t)blockIdx.x * (kTrainBlock / 64) + wave) * 4 + grp; i < n;
+         i += stride) {
+        float *base = table + (uint64_t)ids[i] * ld;
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t f = cc * 64 + e * 16 + q;
+                if (f < ld) unsafeAtomicAdd(base + f, 1.0f);
+            }
+    }
+}
+
+// experiment: two rounds of rows in flight per wave (does more memory-level parallelism raise the
+// random-row read-modify-write bandwidth?)
+template <int CH, int WM>
+__global__ __launch_bounds__(kTrainBlock) void touch_rows2_kernel(float *table, uint32_t ld,
+                                                                  const uint32_t *ids, uint64_t n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint32_t nchunks = ld >> 2;
+    const uint64_t stride = (uint64_t)gridDim.x * (kTrainBlock / 64) * 8;
+    Row<CH> ones;
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) ones.c[cc] = make_float4(1.f, 1.f, 1.f, 1.f);
+    for (uint64_t i = ((uint64_t)blockIdx.x * (kTrainBlock / 64) + wave) * 8 + grp; i < n;
+         i += stride) {
+        const bool two = i + 4 < n;
+        float *base0 = table + (uint64_t)ids[i] * ld;
+        float *base1 = table + (uint64_t)ids[two ? i + 4 : i] * ld;
+        Row<CH> v0, v1;
+        load_row<CH>(v0, base0, q, nchunks, true);
+        load_row<CH>(v1, base1, q, nchunks, two);
+        scatter_add<CH, WM>(base0, q, nchunks, 1.0f, ones, v0);
+        if (two) scatter_add<CH, WM>(base1, q, nchunks, 1.0f, ones, v1);
+    }
+}
+
 template <int CH, int WM>
 __global__ __launch_bounds__(kTrainBlock) void touch_rows_kernel(float *table, uint32_t ld,
                                                                  const uint32_t *ids, uint64_t n) {
