@@ -7,7 +7,8 @@ gfx950 reached through the C ABI in ``include/gn2v.h``; there is no CPU executio
 """
 from . import _lib
 from .embedders import (DeepWalkCBOWEnsmallen, DeepWalkSkipGramEnsmallen, Node2VecCBOWEnsmallen,
-                        Node2VecSkipGramEnsmallen, embed_graph)
+                        Node2VecSkipGramEnsmallen, WalkletsCBOWEnsmallen,
+                        WalkletsSkipGramEnsmallen, embed_graph)
 from .graph import CSRGraph, barabasi_albert, karate_club
 from .sequences import Node2VecSequence
 from .utils import (AbstractEmbeddingModel, AbstractModel, EmbeddingResult,
@@ -20,6 +21,7 @@ __all__ = [
     "CSRGraph", "karate_club", "barabasi_albert", "EmbeddingResult", "AbstractModel",
     "AbstractEmbeddingModel", "embed_graph", "Node2VecSkipGramEnsmallen",
     "Node2VecCBOWEnsmallen", "DeepWalkSkipGramEnsmallen", "DeepWalkCBOWEnsmallen",
+    "WalkletsSkipGramEnsmallen", "WalkletsCBOWEnsmallen",
     "get_models_dataframe", "get_available_models_for_node_embedding", "normalize_kwargs",
     "Node2VecSequence",
 ]

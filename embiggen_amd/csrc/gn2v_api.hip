@@ -134,6 +134,7 @@ int check_train_params(const gn2v_train_params *tp, uint32_t L) {
     if (tp->ld < tp->d || (tp->ld & 3)) return fail("ld must be a multiple of 4 and >= d");
     if (tp->ld > 512) return fail("embedding sizes above 512 are not supported yet");
     if (tp->window < 1) return fail("window_size must be >= 1");
+    if (tp->min_dist > tp->window) return fail("min_dist must not exceed window_size");
     if (L < 2) return fail("walk_length must be >= 2");
     if (!std::isfinite(tp->lr) || !std::isfinite(tp->clip) || tp->clip <= 0.f)
         return fail("learning rate / clipping value must be finite, clipping value positive");
@@ -190,6 +191,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const ui
     a.k = tp->k;
     a.ld = tp->ld;
     a.flags = tp->flags & 7u;
+    a.min_dist = tp->min_dist ? tp->min_dist : 1;
     a.max_samples = cbow ? (tp->k + 1) : 2 * tp->window * (tp->k + 1);
     a.lr = lr;
     a.clip = tp->clip;

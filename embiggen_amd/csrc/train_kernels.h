@@ -32,6 +32,7 @@ struct TrainArgs {
     uint64_t first_walk;
     uint64_t ekey;
     uint32_t L, window, k, ld, flags;
+    uint32_t min_dist;  // contexts at walk distance [min_dist, window] (Walklets: == window)
     uint32_t max_samples;  // LDS list capacity per wave
     float lr, clip;
 };
@@ -219,6 +220,24 @@ __device__ __forceinline__ float centre_lr(const TrainArgs &a, uint32_t c) {
     return deg ? a.lr / (float)deg : a.lr;
 }
 
+// Context positions of centre i: [lo, lo + n_left) and [right0, right0 + n_right), i.e. every j
+// with min_dist <= |j - i| <= window inside the walk (window trimmed at the borders,
+// node2vec_skipgram.py:55-57).
+struct Window {
+    uint32_t lo, right0, n_left, n_ctx;
+    __device__ __forceinline__ Window(uint32_t i, uint32_t Le, uint32_t w, uint32_t md) {
+        lo = i > w ? i - w : 0;
+        const uint32_t hi = min(i + w, Le - 1);
+        n_left = (i >= md && i - md >= lo) ? (i - md - lo + 1) : 0;
+        right0 = i + md;
+        const uint32_t n_right = right0 <= hi ? hi - right0 + 1 : 0;
+        n_ctx = n_left + n_right;
+    }
+    __device__ __forceinline__ uint32_t position(uint32_t rank) const {
+        return rank < n_left ? lo + rank : right0 + (rank - n_left);
+    }
+};
+
 // Load walk b into LDS and return its effective length (first sentinel).
 __device__ __forceinline__ uint32_t stage_walk(const TrainArgs &a, uint64_t b, uint32_t *s_walk,
                                                int lane) {
@@ -347,9 +366,8 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
             const uint32_t c = s_walk[i];
             if (!keep_centre(a, wkey, i, c)) continue;
             const float lrc = centre_lr(a, c);
-            const uint32_t lo = i > w ? i - w : 0;
-            const uint32_t hi = min(i + w, Le - 1);
-            const uint32_t n_ctx = hi - lo;
+            const Window win(i, Le, w, a.min_dist);
+            const uint32_t n_ctx = win.n_ctx;
             const uint32_t n_samples = n_ctx * (k + 1);
             if (n_ctx == 0) continue;
 
@@ -358,8 +376,7 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
             for (uint32_t t = lane; t < n_samples; t += 64) {
                 const uint32_t rank = t / (k + 1);
                 const uint32_t s = t - rank * (k + 1);
-                uint32_t j = lo + rank;
-                if (j >= i) ++j;
+                const uint32_t j = win.position(rank);
                 const uint32_t slot = j < i ? (j + w - i) : (j + w - i - 1);
                 const uint32_t ctx = s_walk[j];
                 uint32_t row = ctx;
@@ -430,9 +447,8 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
             const uint32_t c = s_walk[i];
             if (!keep_centre(a, wkey, i, c)) continue;
             const float lrc = centre_lr(a, c);
-            const uint32_t lo = i > w ? i - w : 0;
-            const uint32_t hi = min(i + w, Le - 1);
-            const uint32_t n_ctx = hi - lo;
+            const Window win(i, Le, w, a.min_dist);
+            const uint32_t n_ctx = win.n_ctx;
             if (n_ctx == 0) continue;
             const float invC = 1.0f / (float)n_ctx;
 
@@ -449,11 +465,7 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                 s_rows[t] = row;
                 s_lab[t] = lab;
             }
-            for (uint32_t t = lane; t < n_ctx; t += 64) {
-                uint32_t j = lo + t;
-                if (j >= i) ++j;
-                s_ctx[t] = s_walk[j];
-            }
+            for (uint32_t t = lane; t < n_ctx; t += 64) s_ctx[t] = s_walk[win.position(t)];
             wave_sync();
 
             // h = mean of context rows; in DET mode every group sums all rows in walk order
@@ -461,20 +473,17 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
             zero_row<CH>(h);
             zero_row<CH>(g);
             if constexpr (DET) {
-                for (uint32_t j = lo; j <= hi; ++j) {
-                    if (j == i) continue;
+                for (uint32_t t = 0; t < n_ctx; ++t) {
                     Row<CH> v;
-                    load_row<CH>(v, a.contextual + (uint64_t)s_walk[j] * a.ld, q, nchunks, true);
+                    load_row<CH>(v, a.contextual + (uint64_t)s_ctx[t] * a.ld, q, nchunks, true);
                     axpy<CH>(h, 1.0f, v);
                 }
             } else {
                 for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
                     const uint32_t rank = r0 + grp;
                     const bool in = rank < n_ctx;
-                    uint32_t j = lo + rank;
-                    if (j >= i) ++j;
                     Row<CH> v;
-                    load_row<CH>(v, a.contextual + (uint64_t)(in ? s_walk[j] : 0) * a.ld, q,
+                    load_row<CH>(v, a.contextual + (uint64_t)(in ? s_ctx[rank] : 0) * a.ld, q,
                                  nchunks, in);
                     axpy<CH>(h, 1.0f, v);
                 }
@@ -497,9 +506,8 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
 
             // every context row += g / C
             if constexpr (DET) {
-                for (uint32_t j = lo; j <= hi; ++j) {
-                    if (j == i) continue;
-                    float *base = a.contextual + (uint64_t)s_walk[j] * a.ld;
+                for (uint32_t t = 0; t < n_ctx; ++t) {
+                    float *base = a.contextual + (uint64_t)s_ctx[t] * a.ld;
                     Row<CH> v;
                     load_row<CH>(v, base, q, nchunks, true);
                     if (grp == 0) scatter_add<CH, kWriteBack>(base, q, nchunks, invC, g, v);

@@ -54,6 +54,8 @@ class Node2VecEnsmallen(EnsmallenEmbedder):
         "DeepWalk SkipGram": models.SkipGram,
         "Node2Vec CBOW": models.CBOW,
         "Node2Vec SkipGram": models.SkipGram,
+        "Walklets CBOW": models.WalkletsCBOW,
+        "Walklets SkipGram": models.WalkletsSkipGram,
     }
 
     def __init__(self, embedding_size: int = 100, random_state: int = 42,
@@ -298,6 +300,120 @@ class DeepWalkCBOWEnsmallen(_DeepWalkMixin, Node2VecEnsmallen):
         return "DeepWalk CBOW"
 
 
+@abstract_class
+class WalkletsEnsmallen(Node2VecEnsmallen):
+    """Walklets on the MI355X engine (reference: walklets.py:7-150): one table pair per window
+    scale, each `embedding_size // window_size` wide (:113); ``parameters()`` reports the total
+    size again (:138-142)."""
+
+    _REMOVED_PARAMETERS = ("alpha",)
+
+    def __init__(
+        self,
+        embedding_size: int = 100,
+        epochs: int = 10,
+        clipping_value: float = 6.0,
+        number_of_negative_samples: int = 10,
+        walk_length: int = 128,
+        iterations: int = 10,
+        window_size: int = 4,
+        return_weight: float = 1.0,
+        explore_weight: float = 1.0,
+        max_neighbours: Optional[int] = 100,
+        learning_rate: float = 0.01,
+        learning_rate_decay: float = 0.9,
+        central_nodes_embedding_path: Optional[str] = None,
+        contextual_nodes_embedding_path: Optional[str] = None,
+        alpha: float = 0.75,
+        normalize_by_degree: bool = False,
+        stochastic_downsample_by_degree: Optional[bool] = False,
+        normalize_learning_rate_by_degree: Optional[bool] = False,
+        use_scale_free_distribution: Optional[bool] = True,
+        random_state: int = 42,
+        dtype: str = "f32",
+        ring_bell: bool = False,
+        enable_cache: bool = False,
+    ):
+        kwargs = _forward(locals())
+        kwargs["embedding_size"] = embedding_size // window_size
+        super().__init__(**kwargs)
+
+    def parameters(self) -> Dict[str, Any]:
+        parameters = super().parameters()
+        parameters["embedding_size"] = parameters["embedding_size"] * parameters["window_size"]
+        return parameters
+
+
+class WalkletsSkipGramEnsmallen(WalkletsEnsmallen):
+    """Walklets SkipGram on the MI355X engine (reference: walklets_skipgram.py:6-149)."""
+
+    def __init__(
+        self,
+        embedding_size: int = 100,
+        epochs: int = 30,
+        clipping_value: float = 6.0,
+        number_of_negative_samples: int = 10,
+        walk_length: int = 128,
+        iterations: int = 10,
+        window_size: int = 4,
+        return_weight: float = 1.0,
+        explore_weight: float = 1.0,
+        max_neighbours: Optional[int] = 100,
+        learning_rate: float = 0.01,
+        learning_rate_decay: float = 0.9,
+        central_nodes_embedding_path: Optional[str] = None,
+        contextual_nodes_embedding_path: Optional[str] = None,
+        normalize_by_degree: bool = False,
+        stochastic_downsample_by_degree: Optional[bool] = False,
+        normalize_learning_rate_by_degree: Optional[bool] = False,
+        use_scale_free_distribution: Optional[bool] = True,
+        random_state: int = 42,
+        dtype: str = "f32",
+        ring_bell: bool = False,
+        enable_cache: bool = False,
+    ):
+        super().__init__(**_forward(locals()))
+
+    @classmethod
+    def model_name(cls) -> str:
+        return "Walklets SkipGram"
+
+
+class WalkletsCBOWEnsmallen(WalkletsEnsmallen):
+    """Walklets CBOW on the MI355X engine (reference: walklets_cbow.py:6-149)."""
+
+    def __init__(
+        self,
+        embedding_size: int = 100,
+        epochs: int = 30,
+        clipping_value: float = 6.0,
+        number_of_negative_samples: int = 10,
+        walk_length: int = 128,
+        iterations: int = 10,
+        window_size: int = 4,
+        return_weight: float = 1.0,
+        explore_weight: float = 1.0,
+        max_neighbours: Optional[int] = 100,
+        learning_rate: float = 0.01,
+        learning_rate_decay: float = 0.9,
+        central_nodes_embedding_path: Optional[str] = None,
+        contextual_nodes_embedding_path: Optional[str] = None,
+        normalize_by_degree: bool = False,
+        stochastic_downsample_by_degree: Optional[bool] = False,
+        normalize_learning_rate_by_degree: Optional[bool] = False,
+        use_scale_free_distribution: Optional[bool] = True,
+        random_state: int = 42,
+        dtype: str = "f32",
+        ring_bell: bool = False,
+        enable_cache: bool = False,
+    ):
+        super().__init__(**_forward(locals()))
+
+    @classmethod
+    def model_name(cls) -> str:
+        return "Walklets CBOW"
+
+
 for _model in (Node2VecSkipGramEnsmallen, Node2VecCBOWEnsmallen, DeepWalkSkipGramEnsmallen,
-               DeepWalkCBOWEnsmallen):
+               DeepWalkCBOWEnsmallen, WalkletsSkipGramEnsmallen, WalkletsCBOWEnsmallen):
     AbstractEmbeddingModel.register(_model)

@@ -62,6 +62,7 @@ class _WalkBasedModel:
         deterministic: bool = False,
         update_mode: str = "auto",
         device: int = 0,
+        min_distance: int = 1,
     ):
         if not isinstance(embedding_size, int) or embedding_size < 1:
             raise ValueError("The embedding size must be a strictly positive integer.")
@@ -114,6 +115,9 @@ class _WalkBasedModel:
                 "update_mode must be 'auto', 'write_through', 'write_back' or 'atomic'.")
         self.update_mode = update_mode
         self.device = int(device)
+        if not 1 <= min_distance <= window_size:
+            raise ValueError("min_distance must be in [1, window_size].")
+        self.min_distance = int(min_distance)
         self.last_stats = None
         self.last_seconds = None
 
@@ -148,6 +152,7 @@ class _WalkBasedModel:
             self.MODEL_ID, self.embedding_size, self.padded_size, self.epochs,
             self.number_of_negative_samples, self.window_size, self.learning_rate,
             self.learning_rate_decay, self.clipping_value, flags, self.init_scale(),
+            self.min_distance,
         )
 
     def init_scale(self) -> float:
@@ -210,6 +215,60 @@ class _WalkBasedModel:
         return out
 
 
+class _WalkletsModel:
+    """Walklets: one independent table pair per scale s = 1..window_size, trained only on the
+    (centre, context) pairs exactly s steps apart in the walks, each of size `embedding_size`
+    (the wrapper passes embedding_size // window_size, embedders/ensmallen_embedders/walklets.py:113).
+    ``fit_transform`` returns ``[central_1, contextual_1, ..., central_w, contextual_w]``; path
+    arguments may contain ``{window_size}``, replaced by the scale (walklets.py:79-90)."""
+
+    BASE = None
+
+    def __init__(self, embedding_size: int = 100, random_state: int = 42, window_size: int = 4,
+                 central_nodes_embedding_path: Optional[str] = None,
+                 contextual_nodes_embedding_path: Optional[str] = None, **kwargs):
+        self.window_size = int(window_size)
+        self._paths = (central_nodes_embedding_path, contextual_nodes_embedding_path)
+        self._scales = []
+        kwargs.setdefault("verbose", False)  # the Walklets wrappers have no verbose argument
+        for s in range(1, self.window_size + 1):
+            paths = [None if p is None else p.replace("{window_size}", str(s))
+                     for p in self._paths]
+            self._scales.append(self.BASE(
+                embedding_size=embedding_size, random_state=random_state, window_size=s,
+                min_distance=s, central_nodes_embedding_path=paths[0],
+                contextual_nodes_embedding_path=paths[1], **kwargs))
+        self.last_stats = None
+
+    @property
+    def random_state(self):
+        return self._scales[0].random_state
+
+    @random_state.setter
+    def random_state(self, value):
+        for m in self._scales:
+            m.random_state = int(value)
+
+    @property
+    def deterministic(self):
+        return self._scales[0].deterministic
+
+    @deterministic.setter
+    def deterministic(self, value):
+        for m in self._scales:
+            m.deterministic = bool(value)
+
+    def fit_transform(self, graph) -> List[np.ndarray]:
+        out, stats = [], []
+        for m in self._scales:
+            out.extend(m.fit_transform(graph))
+            stats.append(m.last_stats)
+        self.last_stats = {
+            key: sum(st[key] for st in stats) for key in stats[0]
+        } if stats else None
+        return out
+
+
 class SkipGram(_WalkBasedModel):
     MODEL_ID = _lib.MODEL_SKIPGRAM
     NAME = "SkipGram"
@@ -218,3 +277,11 @@ class SkipGram(_WalkBasedModel):
 class CBOW(_WalkBasedModel):
     MODEL_ID = _lib.MODEL_CBOW
     NAME = "CBOW"
+
+
+class WalkletsSkipGram(_WalkletsModel):
+    BASE = SkipGram
+
+
+class WalkletsCBOW(_WalkletsModel):
+    BASE = CBOW

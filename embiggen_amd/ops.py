@@ -30,10 +30,11 @@ def walk_params(walk_length: int, iterations: int = 1, return_weight: float = 1.
 
 def train_params(model: int, d: int, k: int, window: int, lr: float = 0.01,
                  lr_decay: float = 0.9, clip: float = 6.0, epochs: int = 1, flags: int = 1,
-                 init_scale: Optional[float] = None, ld: Optional[int] = None):
+                 init_scale: Optional[float] = None, ld: Optional[int] = None, min_dist: int = 1):
     ld = (d + 3) // 4 * 4 if ld is None else ld
     scale = d ** -0.5 if init_scale is None else init_scale
-    return _lib.TrainParams(model, d, ld, epochs, k, window, lr, lr_decay, clip, flags, scale)
+    return _lib.TrainParams(model, d, ld, epochs, k, window, lr, lr_decay, clip, flags, scale,
+                            min_dist)
 
 
 def walks(graph: CSRGraph, wp, seed: int, epoch: int, first_walk: int, n_walks: int,

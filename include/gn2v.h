@@ -73,6 +73,8 @@ typedef struct {
     float clip;       /* clipping_value                                          */
     uint32_t flags;   /* GN2V_TRAIN_*                                            */
     float init_scale; /* tables start uniform(-init_scale, init_scale)           */
+    uint32_t min_dist; /* contexts at walk distance [min_dist, window]; 0 = 1 (Walklets scale s:
+                          window = min_dist = s, embedders/ensmallen_embedders/walklets.py)    */
 } gn2v_train_params;
 
 /* Filled by gn2v_train / gn2v_stats_read.  Times are HIP-event milliseconds measured on the

@@ -71,6 +71,7 @@ typedef struct {
     float clip;
     uint32_t flags;
     float init_scale;
+    uint32_t min_dist; /* contexts at distance [min_dist, window] from the centre; 0 = 1 */
 } o_train_params;
 
 typedef struct {
@@ -321,6 +322,21 @@ static inline uint32_t draw_negative(const o_graph *g, const o_train_params *tp,
 
 static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+static inline uint32_t min_dist_of(const o_train_params *tp) {
+    return tp->min_dist ? tp->min_dist : 1;
+}
+
+static inline int is_context(uint32_t i, uint32_t j, uint32_t md) {
+    return (j > i ? j - i : i - j) >= md;
+}
+
+/* number of context positions of centre i in a walk of effective length Le */
+static inline uint32_t context_count(uint32_t i, uint32_t Le, uint32_t w, uint32_t md) {
+    uint32_t lo = i > w ? i - w : 0, hi = i + w < Le - 1 ? i + w : Le - 1, n = 0;
+    for (uint32_t j = lo; j <= hi; ++j) n += is_context(i, j, md);
+    return n;
+}
+
 static inline uint32_t effective_len(const uint32_t *w, uint32_t L) {
     uint32_t n = 0;
     while (n < L && w[n] != O_SENTINEL) ++n;
@@ -353,12 +369,13 @@ static inline float centre_lr(const o_graph *g, const o_train_params *tp, float 
 void o_sgns_walk(const o_graph *g, const o_train_params *tp, const uint32_t *walk, uint32_t L,
                  uint64_t wkey, float lr, float *central, float *contextual,
                  const uint32_t *neg_override, float *u, float *gacc) {
-    uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k;
+    uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k, md = min_dist_of(tp);
     uint32_t Le = effective_len(walk, L);
     uint64_t nkey = wkey ^ O_TAG_NEG;
     for (uint32_t i = 0; i < Le; ++i) {
         uint32_t c = walk[i];
         if (!keep_centre(g, tp, wkey, i, c)) continue;
+        if (context_count(i, Le, w, md) == 0) continue;
         float lrc = centre_lr(g, tp, lr, c);
         float *crow = central + (uint64_t)c * ld;
         memcpy(u, crow, d * sizeof(float));
@@ -366,7 +383,7 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
         uint32_t lo = i > w ? i - w : 0;
         uint32_t hi = i + w < Le - 1 ? i + w : Le - 1;
         for (uint32_t j = lo; j <= hi; ++j) {
-            if (j == i) continue;
+            if (!is_context(i, j, md)) continue;
             uint32_t slot = j < i ? (j + w - i) : (j + w - i - 1); /* 0 .. 2w-1 */
             uint32_t ctx = walk[j];
             for (uint32_t s = 0; s <= k; ++s) {
@@ -403,7 +420,7 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
 void o_cbow_walk(const o_graph *g, const o_train_params *tp, const uint32_t *walk, uint32_t L,
                  uint64_t wkey, float lr, float *central, float *contextual,
                  const uint32_t *neg_override, float *h, float *gacc) {
-    uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k;
+    uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k, md = min_dist_of(tp);
     uint32_t Le = effective_len(walk, L);
     uint64_t nkey = wkey ^ O_TAG_NEG;
     for (uint32_t i = 0; i < Le; ++i) {
@@ -412,12 +429,12 @@ void o_cbow_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
         float lrc = centre_lr(g, tp, lr, c);
         uint32_t lo = i > w ? i - w : 0;
         uint32_t hi = i + w < Le - 1 ? i + w : Le - 1;
-        uint32_t C = hi - lo; /* window positions minus the centre */
+        uint32_t C = context_count(i, Le, w, md);
         if (C == 0) continue;
         memset(h, 0, d * sizeof(float));
         memset(gacc, 0, d * sizeof(float));
         for (uint32_t j = lo; j <= hi; ++j) {
-            if (j == i) continue;
+            if (!is_context(i, j, md)) continue;
             const float *row = contextual + (uint64_t)walk[j] * ld;
             for (uint32_t x = 0; x < d; ++x) h[x] += row[x];
         }
@@ -447,7 +464,7 @@ void o_cbow_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
             }
         }
         for (uint32_t j = lo; j <= hi; ++j) {
-            if (j == i) continue;
+            if (!is_context(i, j, md)) continue;
             float *row = contextual + (uint64_t)walk[j] * ld;
             for (uint32_t x = 0; x < d; ++x) row[x] += gacc[x] * invC;
         }
@@ -499,11 +516,9 @@ uint64_t o_fit(const o_graph *g, const o_walk_params *wp, const o_train_params *
         o_train_walks(g, tp, walks, n_walks, L, seed, e, 0, lr, central, contextual, NULL,
                       threads);
         for (uint64_t b = 0; b < n_walks; ++b) {
-            uint32_t Le = effective_len(walks + b * L, L), w = tp->window;
-            for (uint32_t i = 0; i < Le; ++i) {
-                uint32_t lo = i > w ? i - w : 0, hi = i + w < Le - 1 ? i + w : Le - 1;
-                pairs += hi - lo;
-            }
+            uint32_t Le = effective_len(walks + b * L, L);
+            for (uint32_t i = 0; i < Le; ++i)
+                pairs += context_count(i, Le, tp->window, min_dist_of(tp));
         }
         lr *= tp->lr_decay;
     }

@@ -45,6 +45,7 @@ class TrainParams(C.Structure):
         ("clip", C.c_float),
         ("flags", C.c_uint32),
         ("init_scale", C.c_float),
+        ("min_dist", C.c_uint32),
     ]
 
 

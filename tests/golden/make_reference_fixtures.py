@@ -89,6 +89,9 @@ def api_defaults():
         "Node2VecCBOWEnsmallen": "node2vec_cbow.py",
         "DeepWalkSkipGramEnsmallen": "deepwalk_skipgram.py",
         "DeepWalkCBOWEnsmallen": "deepwalk_cbow.py",
+        "WalkletsSkipGramEnsmallen": "walklets_skipgram.py",
+        "WalkletsCBOWEnsmallen": "walklets_cbow.py",
+        "WalkletsEnsmallen": "walklets.py",
         "Node2VecEnsmallen": "node2vec.py",
         "EnsmallenEmbedder": "ensmallen_embedder.py",
     }

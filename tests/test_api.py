@@ -25,6 +25,8 @@ CLASSES = {
     "Node2VecCBOWEnsmallen": E.Node2VecCBOWEnsmallen,
     "DeepWalkSkipGramEnsmallen": E.DeepWalkSkipGramEnsmallen,
     "DeepWalkCBOWEnsmallen": E.DeepWalkCBOWEnsmallen,
+    "WalkletsSkipGramEnsmallen": E.WalkletsSkipGramEnsmallen,
+    "WalkletsCBOWEnsmallen": E.WalkletsCBOWEnsmallen,
 }
 
 
@@ -102,6 +104,19 @@ def test_kwarg_coercion_and_errors():
             E.Node2VecSkipGramEnsmallen), random_state=None, embedding_size=4)
     with pytest.raises(ValueError):
         E.Node2VecSkipGramEnsmallen(dtype="f16")
+
+
+def test_walklets_split_the_embedding_size_per_scale():
+    """walklets.py:113 (embedding_size // window_size per scale) and :138-142 (parameters() reports
+    the total again)."""
+    m = E.WalkletsSkipGramEnsmallen(embedding_size=96, window_size=3)
+    assert m.parameters()["embedding_size"] == 96 and m.parameters()["window_size"] == 3
+    scales = m._model._scales
+    assert [s.embedding_size for s in scales] == [32, 32, 32]
+    assert [(s.window_size, s.min_distance) for s in scales] == [(1, 1), (2, 2), (3, 3)]
+    abstract = json.load(open(os.path.join(GOLDEN, "api_defaults.json")))["WalkletsEnsmallen"]
+    sig = inspect.signature(E.embedders.WalkletsEnsmallen.__init__)
+    assert {p.name: p.default for p in sig.parameters.values() if p.name != "self"} == abstract["init"]
 
 
 def test_set_random_state_reaches_the_engine_model():

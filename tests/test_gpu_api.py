@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 def test_embed_graph_smoke_for_every_registered_model(karate):
     df = E.get_available_models_for_node_embedding()
     for _, row in df.iterrows():
+        kwargs = {} if "Walklets" in row.model_name else {"verbose": False}
         res = E.embed_graph(karate, row.model_name, library_name=row.library_name,
-                            smoke_test=True, verbose=False)
+                            smoke_test=True, **kwargs)
         tables = res.get_all_node_embedding()
         assert len(tables) == 2 and res.embedding_method_name == row.model_name
         for t in tables:

@@ -277,3 +277,50 @@ def test_config3_arxiv_shaped_graph_walks_and_training():
     st = ops.stats_read(g)
     assert st["pairs"] == n * 1250
     assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("window,min_dist", [(3, 3), (4, 2), (5, 5), (1, 1)])
+def test_min_distance_windows_match_oracle(karate, karate_oracle, model, window, min_dist):
+    """Walklets-style windows (contexts at walk distance [min_dist, window]) in the deterministic
+    schedule and in the one-wave production schedule."""
+    d, k = 16, 4
+    wk = ops.walks(karate, ops.walk_params(20, 1, 0.5, 2.0), 6, 0, 0, 34)
+    wk_h = wk.cpu().numpy().view(np.uint32)
+    otp = O.TrainParams(model, d, d, 1, k, window, 0.01, 0.9, 6.0, 1, d ** -0.5, min_dist)
+    step = ops.sgns_step if model == 0 else ops.cbow_step
+    for flags, per_walk in ((1 | DET, False), (1 | _lib.TRAIN_WRITE_THROUGH, True),
+                            (1 | _lib.TRAIN_ATOMIC, True)):
+        c, x = _tables(34, d, 6)
+        c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+        tp = ops.train_params(model, d, k, window, flags=flags, min_dist=min_dist)
+        if per_walk:
+            for b in range(34):
+                step(karate, tp, wk[b:b + 1].contiguous(), 6, 0, b, 0.05, c, x)
+        else:
+            step(karate, tp, wk, 6, 0, 0, 0.05, c, x)
+        torch.cuda.synchronize()
+        O.train_walks(karate_oracle, otp, wk_h, 6, 0, 0, 0.05, c_h, x_h)
+        assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5
+        assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+
+
+@pytest.mark.parametrize("cls,model", [(E.WalkletsSkipGramEnsmallen, 0),
+                                       (E.WalkletsCBOWEnsmallen, 1)])
+def test_walklets_fit_matches_oracle_per_scale(karate, karate_oracle, cls, model):
+    m = cls(embedding_size=24, window_size=3, epochs=2, walk_length=16, iterations=2,
+            number_of_negative_samples=4)
+    m._model.deterministic = True
+    res = m.fit_transform(karate, return_dataframe=False).get_all_node_embedding()
+    assert len(res) == 6 and all(t.shape == (34, 8) for t in res)
+    if model == 1:
+        res = list(reversed(res))  # the wrapper reverses the whole list for CBOW (node2vec.py:101)
+    total = 0
+    for s in (1, 2, 3):
+        rc, rx, pairs = O.fit(karate_oracle, O.WalkParams(16, 2, 1.0, 1.0, 100, 0),
+                              O.TrainParams(model, 8, 8, 2, 4, s, 0.01, 0.9, 6.0, 1, 8 ** -0.5, s),
+                              42)
+        total += pairs
+        assert np.abs(res[2 * (s - 1)] - rc).max() < 1e-4
+        assert np.abs(res[2 * (s - 1) + 1] - rx).max() < 1e-4
+    assert m.get_last_stats()["pairs"] == total

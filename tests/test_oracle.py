@@ -187,6 +187,25 @@ def test_pair_count_and_window_trimming(karate_oracle):
     assert pairs == 34 * 2 * (2 * w * L - w * (w + 1))
 
 
+def test_min_distance_selects_walklets_pairs(karate_oracle):
+    """min_dist = window = s keeps only the (centre, context) pairs exactly s steps apart
+    (Walklets scale s): pair count 2 * (L - s) per walk, and only those rows move."""
+    L, s = 12, 3
+    wp = O.WalkParams(L, 1, 1.0, 1.0, 100, 0)
+    tp = O.TrainParams(0, 4, 4, 1, 2, s, 0.01, 0.9, 6.0, 1, 0.5, s)
+    _, _, pairs = O.fit(karate_oracle, wp, tp, 5)
+    assert pairs == 34 * 2 * (L - s)
+    # one walk, explicit check of which contextual rows are touched (no negatives)
+    tp0 = O.TrainParams(0, 4, 4, 1, 0, 2, 0.05, 1.0, 6.0, 0, 0.5, 2)
+    c = O.init_table(34, 4, 4, 1, 0, 0.5)
+    x = O.init_table(34, 4, 4, 1, 1, 0.5)
+    x0 = x.copy()
+    walk = np.array([[0, 1, 2, O.SENTINEL]], dtype=np.uint32)  # only pair at distance 2: (0, 2)
+    O.train_walks(karate_oracle, tp0, walk, 0, 0, 0, 0.05, c, x)
+    changed = np.flatnonzero(np.abs(x - x0).max(1) > 0)
+    assert changed.tolist() == [0, 2]
+
+
 def test_learning_rate_decay_and_epochs(karate_oracle):
     wp = O.WalkParams(8, 1, 1.0, 1.0, 100, 0)
     base = O.TrainParams(0, 4, 4, 2, 2, 2, 0.05, 0.5, 6.0, 1, 0.5)
