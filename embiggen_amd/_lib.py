@@ -110,6 +110,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch's ROCm wheel bundles its own HIP runtime.  It must be the first HIP runtime in
+        # the process: loading libgn2v.so first would bind the system libamdhip64 and leave torch
+        # unable to see the GPU (two runtimes in one process).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ModuleNotFoundError(
             f"The gn2v HIP engine `{LIB_PATH}` has not been built. Run "
