@@ -30,7 +30,8 @@ MODEL_CBOW = 1
 EXPORTS = [
     "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
     "gn2v_graph_destroy", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_init_table",
-    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_train", "gn2v_touch_rows", "gn2v_stats_reset",
+    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_touch_rows",
+    "gn2v_stats_reset",
     "gn2v_stats_read",
 ]
 
@@ -60,6 +61,21 @@ class TrainParams(C.Structure):
         ("flags", C.c_uint32),
         ("init_scale", C.c_float),
         ("min_dist", C.c_uint32),
+    ]
+
+
+class StepIO(C.Structure):
+    _fields_ = [
+        ("d_walks", C.c_void_p),
+        ("d_walk_rows", C.c_void_p),
+        ("d_central", C.c_void_p),
+        ("d_contextual", C.c_void_p),
+        ("d_negative", C.c_void_p),
+        ("d_neg_pool", C.c_void_p),
+        ("neg_pool_size", C.c_uint64),
+        ("neg_id_mul", C.c_uint32),
+        ("neg_id_add", C.c_uint32),
+        ("d_neg_override", C.c_void_p),
     ]
 
 
@@ -137,6 +153,8 @@ def lib():
     step = [vp, C.POINTER(TrainParams), vp, u64, u32, u64, u64, u64, f32, vp, vp, vp, vp]
     L.gn2v_sgns_step.argtypes = step
     L.gn2v_cbow_step.argtypes = step
+    L.gn2v_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(StepIO), u64, u32, u64, u64,
+                            u64, f32, vp]
     L.gn2v_train.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64, vp, vp,
                              C.POINTER(Stats), vp]
     L.gn2v_touch_rows.argtypes = [vp, u32, vp, u64, u32, vp]

@@ -169,19 +169,28 @@ int launch_train_ch(bool cbow, int wm, bool det, dim3 grid, dim3 block, size_t l
     return 0;
 }
 
-int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const uint32_t *d_walks,
+int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn2v_step_io *io,
                  uint64_t n_walks, uint32_t L, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                 float lr, float *d_central, float *d_contextual, const uint32_t *d_neg_override,
-                 hipStream_t s) {
+                 float lr, hipStream_t s) {
     if (check_train_params(tp, L)) return 1;
-    if (!d_walks || !d_central || !d_contextual) return fail("NULL walks / table pointer");
+    if (!io || !io->d_walks || !io->d_central || !io->d_contextual)
+        return fail("NULL walks / table pointer");
     if (n_walks == 0) return 0;
     gn2v::TrainArgs a{};
     a.g = g->view;
-    a.walks = d_walks;
-    a.neg_override = d_neg_override;
-    a.central = d_central;
-    a.contextual = d_contextual;
+    a.walks = io->d_walks;
+    a.walk_rows = io->d_walk_rows;
+    a.neg_override = io->d_neg_override;
+    a.central = io->d_central;
+    a.contextual = io->d_contextual;
+    float *positive_table = cbow ? io->d_central : io->d_contextual;
+    a.negative = io->d_negative ? io->d_negative : positive_table;
+    a.split = a.negative != positive_table;
+    a.neg_pool = io->d_neg_pool;
+    a.neg_pool_size = io->neg_pool_size;
+    if (a.neg_pool && a.neg_pool_size == 0) return fail("empty negative pool");
+    a.neg_id_mul = (io->neg_id_mul == 0 && io->neg_id_add == 0) ? 1u : io->neg_id_mul;
+    a.neg_id_add = io->neg_id_add;
     a.counters = g->counters;
     a.n_walks = n_walks;
     a.first_walk = first_walk;
@@ -204,7 +213,8 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const ui
                                                             : gn2v::kWriteThrough;
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
     const size_t per_wave_words =
-        ((size_t)tp->ld + L + 2 * (size_t)a.max_samples + (cbow ? 2 * tp->window : 0) + 3) & ~(size_t)3;
+        ((size_t)tp->ld + 2 * (size_t)L + 2 * (size_t)a.max_samples + (cbow ? 2 * tp->window : 0) + 3) &
+        ~(size_t)3;
     const size_t lds = (size_t)waves_per_block * per_wave_words * 4;
     if (lds > 64 * 1024) return fail("walk_length / window / negatives too large for the LDS plan");
     uint64_t blocks = det ? 1 : (n_walks + waves_per_block - 1) / waves_per_block;
@@ -373,24 +383,47 @@ int gn2v_init_table(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, ui
     return 0;
 }
 
+int gn2v_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_step_io *io,
+              uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
+              uint64_t first_walk, float lr, void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    if (!tp) return fail("train params are NULL");
+    if (tp->model > GN2V_MODEL_CBOW) return fail("unknown model id");
+    HIP_TRY(hipSetDevice(g->device));
+    return launch_train(g, tp->model == GN2V_MODEL_CBOW, tp, io, n_walks, walk_length, seed, epoch,
+                        first_walk, lr, (hipStream_t)stream);
+}
+
+static int simple_step(gn2v_graph *g, bool cbow, const gn2v_train_params *tp,
+                       const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
+                       uint64_t seed, uint64_t epoch, uint64_t first_walk, float lr,
+                       float *d_central, float *d_contextual, const uint32_t *d_neg_override,
+                       void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    HIP_TRY(hipSetDevice(g->device));
+    gn2v_step_io io{};
+    io.d_walks = d_walks;
+    io.d_central = d_central;
+    io.d_contextual = d_contextual;
+    io.d_neg_override = d_neg_override;
+    return launch_train(g, cbow, tp, &io, n_walks, walk_length, seed, epoch, first_walk, lr,
+                        (hipStream_t)stream);
+}
+
 int gn2v_sgns_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d_walks,
                    uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
                    uint64_t first_walk, float lr, float *d_central, float *d_contextual,
                    const uint32_t *d_neg_override, void *stream) {
-    if (!g) return fail("graph handle is NULL");
-    HIP_TRY(hipSetDevice(g->device));
-    return launch_train(g, false, tp, d_walks, n_walks, walk_length, seed, epoch, first_walk, lr,
-                        d_central, d_contextual, d_neg_override, (hipStream_t)stream);
+    return simple_step(g, false, tp, d_walks, n_walks, walk_length, seed, epoch, first_walk, lr,
+                       d_central, d_contextual, d_neg_override, stream);
 }
 
 int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d_walks,
                    uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
                    uint64_t first_walk, float lr, float *d_central, float *d_contextual,
                    const uint32_t *d_neg_override, void *stream) {
-    if (!g) return fail("graph handle is NULL");
-    HIP_TRY(hipSetDevice(g->device));
-    return launch_train(g, true, tp, d_walks, n_walks, walk_length, seed, epoch, first_walk, lr,
-                        d_central, d_contextual, d_neg_override, (hipStream_t)stream);
+    return simple_step(g, true, tp, d_walks, n_walks, walk_length, seed, epoch, first_walk, lr,
+                       d_central, d_contextual, d_neg_override, stream);
 }
 
 static bool nchunks_is_32(uint32_t ld) { return ld / 4 > 16 && ld / 4 <= 32; }
@@ -511,8 +544,11 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
             rc = launch_walks(g, wp, seed, e, first, nw, d_walks, s);
             for (uint64_t off = 0; off < nw && !rc; off += train_batch) {
                 const uint64_t n = std::min(train_batch, nw - off);
-                rc = launch_train(g, cbow, tp, d_walks + off * L, n, L, seed, e, first + off, lr,
-                                  d_central, d_contextual, nullptr, s);
+                gn2v_step_io io{};
+                io.d_walks = d_walks + off * L;
+                io.d_central = d_central;
+                io.d_contextual = d_contextual;
+                rc = launch_train(g, cbow, tp, &io, n, L, seed, e, first + off, lr, s);
             }
             if (!rc && g->train_events.size() > 2048) {  // bound the event pool on long fits
                 if (hipStreamSynchronize(s) != hipSuccess || fold_events(g)) rc = 1;

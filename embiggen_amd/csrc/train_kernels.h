@@ -20,13 +20,21 @@
 namespace gn2v {
 
 constexpr uint32_t kFlagScaleFree = 1u, kFlagDownsample = 2u, kFlagNormLr = 4u;
+constexpr uint32_t kNegBit = 0x80000000u;  // staged row id refers to the `negative` table
 
 struct TrainArgs {
     GraphView g;
-    const uint32_t *walks;
+    const uint32_t *walks;      // global node ids [n_walks][L]
+    const uint32_t *walk_rows;  // row of every walk node in central/contextual, or nullptr (= id)
     const uint32_t *neg_override;
     float *central;
     float *contextual;
+    float *negative;            // table the negative rows live in (== contextual / central when
+                                // the tables are whole; the local shard in row-sharded training)
+    const uint32_t *neg_pool;   // negatives = neg_pool[uniform] (rows of `negative`) or nullptr
+    uint64_t neg_pool_size;
+    uint32_t neg_id_mul, neg_id_add;  // global id of negative row r = r * mul + add (skip rule)
+    uint32_t split;             // 1 when `negative` is a different table than the positive one
     unsigned long long *counters;  // [0] pairs, [1] walk steps, [2] centres
     uint64_t n_walks;
     uint64_t first_walk;
@@ -196,8 +204,11 @@ __device__ __forceinline__ float sigmoid_clipped(float dot, float clip) {
     return 1.0f / (1.0f + __expf(-dot));
 }
 
+// row of the negative table for draw qi: a pool entry (shard-local sampling), the endpoint of a
+// uniform random edge (proportional to degree) or a uniform node
 __device__ __forceinline__ uint32_t draw_negative(const TrainArgs &a, uint64_t nkey, uint64_t qi) {
     const uint64_t r = draw(nkey, qi);
+    if (a.neg_pool) return a.neg_pool[mulhi64(r, a.neg_pool_size)];
     if (a.flags & kFlagScaleFree) return a.g.col_idx[mulhi64(r, a.g.n_edges)];
     return (uint32_t)mulhi64(r, a.g.n_nodes);
 }
@@ -240,11 +251,12 @@ struct Window {
 
 // Load walk b into LDS and return its effective length (first sentinel).
 __device__ __forceinline__ uint32_t stage_walk(const TrainArgs &a, uint64_t b, uint32_t *s_walk,
-                                               int lane) {
+                                               uint32_t *s_wrow, int lane) {
     uint32_t first_bad = a.L;
     for (uint32_t t = lane; t < a.L; t += 64) {
         const uint32_t v = a.walks[b * a.L + t];
         s_walk[t] = v;
+        s_wrow[t] = a.walk_rows ? a.walk_rows[b * a.L + t] : v;
         if (v == kSentinel) first_bad = min(first_bad, t);
     }
     for (int off = 32; off > 0; off >>= 1) first_bad = min(first_bad, (uint32_t)__shfl_xor(first_bad, off));
@@ -282,6 +294,12 @@ struct RoundIds {
     }
 };
 
+// staged row id -> address: ids carrying kNegBit index the `negative` table (split tables only)
+__device__ __forceinline__ float *sample_base(const TrainArgs &a, float *table, uint32_t row) {
+    if (a.split && (row & kNegBit)) return a.negative + (uint64_t)(row & ~kNegBit) * a.ld;
+    return table + (uint64_t)row * a.ld;
+}
+
 // Score the staged sample list against the register row `u` (replicated in every group):
 // for each sample row v: var = (label - sigmoid(clip(u.v))) * lr ; g += var * v ; v += var * u.
 // u_upd is the copy of u the row update consumes (lane-contiguous shape in atomic mode).
@@ -297,7 +315,7 @@ __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, 
         for (uint32_t t = 0; t < n_samples; ++t) {
             const uint32_t row = s_rows[t];
             if (row == kSentinel) continue;
-            float *base = table + (uint64_t)row * a.ld;
+            float *base = sample_base(a, table, row);
             Row<CH> v;
             load_row<CH>(v, base, q, nchunks, true);
             const float dot = dot_rows<CH>(u, v);
@@ -314,7 +332,7 @@ __device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, 
             const float lab = t < n_samples ? s_lab[t] : 0.f;
             const bool valid = row != kSentinel;
             const int my_pass = ids.pass_of(grp);
-            float *base = table + (uint64_t)(valid ? row : 0) * a.ld;
+            float *base = sample_base(a, table, valid ? row : 0);
             for (int pass = 0; pass <= ids.last_pass; ++pass) {
                 const bool mine = valid && my_pass == pass;
                 Row<CH> v;
@@ -337,16 +355,19 @@ __device__ __forceinline__ void zero_row(Row<CH> &r) {
 constexpr int kTrainBlock = 256;
 
 // SkipGram with negative sampling over a batch of walks.
-// LDS per wave: transpose row[ld] | walk[L] | rows[max_samples] | labels[max_samples].
+// LDS per wave: transpose row[ld] | walk ids[L] | walk rows[L] | rows[max_samples] |
+// labels[max_samples].
 template <int CH, int WM, bool DET>
 __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
-    const uint32_t per_wave = (a.ld + a.L + 2 * a.max_samples + 3) & ~3u;
+    const uint32_t per_wave = (a.ld + 2 * a.L + 2 * a.max_samples + 3) & ~3u;
     float *s_tr = reinterpret_cast<float *>(smem + wave * per_wave);
     uint32_t *s_walk = smem + wave * per_wave + a.ld;
-    uint32_t *s_rows = s_walk + a.L;
+    uint32_t *s_wrow = s_walk + a.L;
+    uint32_t *s_rows = s_wrow + a.L;
+    const uint32_t negbit = a.split ? kNegBit : 0u;
     float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
     const uint32_t nchunks = a.ld >> 2;
     const uint32_t w = a.window, k = a.k;
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
 
     for (uint64_t b = (uint64_t)blockIdx.x * waves_per_block + wave; b < a.n_walks;
          b += wave_stride) {
-        const uint32_t Le = stage_walk(a, b, s_walk, lane);
+        const uint32_t Le = stage_walk(a, b, s_walk, s_wrow, lane);
         const uint64_t wkey = draw(a.ekey, a.first_walk + b);
         const uint64_t nkey = wkey ^ kTagNeg;
         const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
@@ -379,20 +400,21 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
                 const uint32_t j = win.position(rank);
                 const uint32_t slot = j < i ? (j + w - i) : (j + w - i - 1);
                 const uint32_t ctx = s_walk[j];
-                uint32_t row = ctx;
+                uint32_t row = s_wrow[j];
                 float lab = 1.f;
                 if (s != 0) {
                     const uint64_t qi = ((uint64_t)i * 2 * w + slot) * k + (s - 1);
                     row = ov ? ov[qi] : draw_negative(a, nkey, qi);
                     lab = 0.f;
-                    if (row == c || row == ctx) row = kSentinel;
+                    const uint32_t gid = row * a.neg_id_mul + a.neg_id_add;
+                    row = (gid == c || gid == ctx) ? kSentinel : (row | negbit);
                 }
                 s_rows[t] = row;
                 s_lab[t] = lab;
             }
             wave_sync();
 
-            float *crow = a.central + (uint64_t)c * a.ld;
+            float *crow = a.central + (uint64_t)s_wrow[i] * a.ld;
             Row<CH> u, g;
             load_row<CH>(u, crow, q, nchunks, true);
             zero_row<CH>(g);
@@ -423,10 +445,12 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
-    const uint32_t per_wave = (a.ld + a.L + 2 * a.max_samples + 2 * a.window + 3) & ~3u;
+    const uint32_t per_wave = (a.ld + 2 * a.L + 2 * a.max_samples + 2 * a.window + 3) & ~3u;
     float *s_tr = reinterpret_cast<float *>(smem + wave * per_wave);
     uint32_t *s_walk = smem + wave * per_wave + a.ld;
-    uint32_t *s_rows = s_walk + a.L;
+    uint32_t *s_wrow = s_walk + a.L;
+    uint32_t *s_rows = s_wrow + a.L;
+    const uint32_t negbit = a.split ? kNegBit : 0u;
     float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
     uint32_t *s_ctx = s_rows + 2 * a.max_samples;  // 2w context ids of the current centre
     const uint32_t nchunks = a.ld >> 2;
@@ -437,7 +461,7 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
 
     for (uint64_t b = (uint64_t)blockIdx.x * waves_per_block + wave; b < a.n_walks;
          b += wave_stride) {
-        const uint32_t Le = stage_walk(a, b, s_walk, lane);
+        const uint32_t Le = stage_walk(a, b, s_walk, s_wrow, lane);
         const uint64_t wkey = draw(a.ekey, a.first_walk + b);
         const uint64_t nkey = wkey ^ kTagNeg;
         const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
@@ -454,18 +478,19 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
 
             wave_sync();
             for (uint32_t t = lane; t <= k; t += 64) {
-                uint32_t row = c;
+                uint32_t row = s_wrow[i];
                 float lab = 1.f;
                 if (t != 0) {
                     const uint64_t qi = (uint64_t)i * k + (t - 1);
                     row = ov ? ov[qi] : draw_negative(a, nkey, qi);
                     lab = 0.f;
-                    if (row == c) row = kSentinel;
+                    const uint32_t gid = row * a.neg_id_mul + a.neg_id_add;
+                    row = gid == c ? kSentinel : (row | negbit);
                 }
                 s_rows[t] = row;
                 s_lab[t] = lab;
             }
-            for (uint32_t t = lane; t < n_ctx; t += 64) s_ctx[t] = s_walk[win.position(t)];
+            for (uint32_t t = lane; t < n_ctx; t += 64) s_ctx[t] = s_wrow[win.position(t)];
             wave_sync();
 
             // h = mean of context rows; in DET mode every group sums all rows in walk order

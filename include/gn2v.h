@@ -139,6 +139,29 @@ int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d
                    uint64_t first_walk, float lr, float *d_central, float *d_contextual,
                    const uint32_t *d_neg_override, void *stream);
 
+/* General form of one training step, used by the row-sharded multi-GPU trainer (DESIGN.md
+ * section 7): the walk nodes may live in compact row caches (d_walk_rows gives the row of every
+ * walk position in d_central / d_contextual) while negatives are drawn from a caller-supplied pool
+ * of rows of a third table (the local shard).  With every optional field NULL / 0 this is exactly
+ * gn2v_sgns_step / gn2v_cbow_step. */
+typedef struct {
+    const uint32_t *d_walks;     /* global node ids u32[n_walks][walk_length]                    */
+    const uint32_t *d_walk_rows; /* optional u32[n_walks][walk_length]: row of each walk node    */
+    float *d_central;
+    float *d_contextual;
+    float *d_negative;           /* optional: table of the negative rows (default: d_contextual
+                                    for SkipGram, d_central for CBOW)                            */
+    const uint32_t *d_neg_pool;  /* optional: negatives = d_neg_pool[uniform draw]               */
+    uint64_t neg_pool_size;
+    uint32_t neg_id_mul;         /* global id of negative row r = r * mul + add (0, 0 = identity), */
+    uint32_t neg_id_add;         /*   used to skip negatives equal to the centre / context       */
+    const uint32_t *d_neg_override;
+} gn2v_step_io;
+
+int gn2v_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_step_io *io,
+              uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
+              uint64_t first_walk, float lr, void *stream);
+
 /* The whole of `models.SkipGram/CBOW(...).fit_transform(graph)` (node2vec.py:99): initialise both
  * caller-allocated tables f32[n_nodes][ld], then per epoch generate every walk and train on it.
  * max_walks_per_epoch = 0 trains on all iterations*n_sources walks; otherwise only that many

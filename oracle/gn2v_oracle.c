@@ -82,6 +82,20 @@ typedef struct {
     const float *cumw; /* per-row inclusive prefix sums of weights, or NULL */
 } o_graph;
 
+/* General step I/O (mirrors gn2v_step_io): walk nodes may live in row caches, negatives in a
+ * third table sampled through a pool (row-sharded multi-GPU training). */
+typedef struct {
+    const uint32_t *walks;
+    const uint32_t *walk_rows; /* optional */
+    float *central;
+    float *contextual;
+    float *negative;           /* optional */
+    const uint32_t *neg_pool;  /* optional */
+    uint64_t neg_pool_size;
+    uint32_t neg_id_mul, neg_id_add;
+    const uint32_t *neg_override;
+} o_step_io;
+
 /* ---------------------------------------------------------------- RNG */
 
 uint64_t o_mix64(uint64_t z) {
@@ -313,11 +327,17 @@ void o_init_table(float *t, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t s
 
 /* ---------------------------------------------------------------- training */
 
-static inline uint32_t draw_negative(const o_graph *g, const o_train_params *tp, uint64_t nkey,
-                                     uint64_t q) {
+static inline uint32_t draw_negative(const o_graph *g, const o_train_params *tp,
+                                     const o_step_io *io, uint64_t nkey, uint64_t q) {
     uint64_t r = o_draw(nkey, q);
+    if (io->neg_pool) return io->neg_pool[mulhi64(r, io->neg_pool_size)];
     if (tp->flags & O_FLAG_SCALE_FREE) return g->col_idx[mulhi64(r, g->n_edges)];
     return (uint32_t)mulhi64(r, g->n_nodes);
+}
+
+static inline uint32_t neg_global_id(const o_step_io *io, uint32_t row) {
+    if (io->neg_id_mul == 0 && io->neg_id_add == 0) return row;
+    return row * io->neg_id_mul + io->neg_id_add;
 }
 
 static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -366,9 +386,11 @@ static inline float centre_lr(const o_graph *g, const o_train_params *tp, float 
  * per centre the central row is copied to u, every (context, negatives...) sample updates the
  * contextual table immediately, the accumulated gradient is added to the central row at the end
  * of the centre.  neg_override (optional) = explicit negatives [L][2w][k] for this walk. */
-void o_sgns_walk(const o_graph *g, const o_train_params *tp, const uint32_t *walk, uint32_t L,
-                 uint64_t wkey, float lr, float *central, float *contextual,
+void o_sgns_walk(const o_graph *g, const o_train_params *tp, const o_step_io *io,
+                 const uint32_t *walk, const uint32_t *wrow, uint32_t L, uint64_t wkey, float lr,
                  const uint32_t *neg_override, float *u, float *gacc) {
+    float *central = io->central, *contextual = io->contextual;
+    float *negative = io->negative ? io->negative : contextual;
     uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k, md = min_dist_of(tp);
     uint32_t Le = effective_len(walk, L);
     uint64_t nkey = wkey ^ O_TAG_NEG;
@@ -377,7 +399,7 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
         if (!keep_centre(g, tp, wkey, i, c)) continue;
         if (context_count(i, Le, w, md) == 0) continue;
         float lrc = centre_lr(g, tp, lr, c);
-        float *crow = central + (uint64_t)c * ld;
+        float *crow = central + (uint64_t)wrow[i] * ld;
         memcpy(u, crow, d * sizeof(float));
         memset(gacc, 0, d * sizeof(float));
         uint32_t lo = i > w ? i - w : 0;
@@ -387,18 +409,19 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
             uint32_t slot = j < i ? (j + w - i) : (j + w - i - 1); /* 0 .. 2w-1 */
             uint32_t ctx = walk[j];
             for (uint32_t s = 0; s <= k; ++s) {
-                uint32_t row;
+                float *v;
                 float label;
                 if (s == 0) {
-                    row = ctx;
+                    v = contextual + (uint64_t)wrow[j] * ld;
                     label = 1.0f;
                 } else {
                     uint64_t q = ((uint64_t)i * 2 * w + slot) * k + (s - 1);
-                    row = neg_override ? neg_override[q] : draw_negative(g, tp, nkey, q);
+                    uint32_t row = neg_override ? neg_override[q] : draw_negative(g, tp, io, nkey, q);
+                    uint32_t gid = neg_global_id(io, row);
                     label = 0.0f;
-                    if (row == c || row == ctx) continue;
+                    if (gid == c || gid == ctx) continue;
+                    v = negative + (uint64_t)row * ld;
                 }
-                float *v = contextual + (uint64_t)row * ld;
                 float dot = 0.0f;
                 for (uint32_t x = 0; x < d; ++x) dot += u[x] * v[x];
                 if (dot > tp->clip) dot = tp->clip;
@@ -417,9 +440,11 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
 /* One walk, CBOW with negative sampling.  h = mean of the *contextual* rows of the window (the
  * input side, cbow.py:37-42); the centre and k negatives are scored against the *central* table
  * (the output side); the input gradient / C is added to every context row at the end. */
-void o_cbow_walk(const o_graph *g, const o_train_params *tp, const uint32_t *walk, uint32_t L,
-                 uint64_t wkey, float lr, float *central, float *contextual,
+void o_cbow_walk(const o_graph *g, const o_train_params *tp, const o_step_io *io,
+                 const uint32_t *walk, const uint32_t *wrow, uint32_t L, uint64_t wkey, float lr,
                  const uint32_t *neg_override, float *h, float *gacc) {
+    float *central = io->central, *contextual = io->contextual;
+    float *negative = io->negative ? io->negative : central;
     uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k, md = min_dist_of(tp);
     uint32_t Le = effective_len(walk, L);
     uint64_t nkey = wkey ^ O_TAG_NEG;
@@ -435,24 +460,24 @@ void o_cbow_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
         memset(gacc, 0, d * sizeof(float));
         for (uint32_t j = lo; j <= hi; ++j) {
             if (!is_context(i, j, md)) continue;
-            const float *row = contextual + (uint64_t)walk[j] * ld;
+            const float *row = contextual + (uint64_t)wrow[j] * ld;
             for (uint32_t x = 0; x < d; ++x) h[x] += row[x];
         }
         float invC = 1.0f / (float)C;
         for (uint32_t x = 0; x < d; ++x) h[x] *= invC;
         for (uint32_t s = 0; s <= k; ++s) {
-            uint32_t row;
+            float *v;
             float label;
             if (s == 0) {
-                row = c;
+                v = central + (uint64_t)wrow[i] * ld;
                 label = 1.0f;
             } else {
                 uint64_t q = (uint64_t)i * k + (s - 1);
-                row = neg_override ? neg_override[q] : draw_negative(g, tp, nkey, q);
+                uint32_t row = neg_override ? neg_override[q] : draw_negative(g, tp, io, nkey, q);
                 label = 0.0f;
-                if (row == c) continue;
+                if (neg_global_id(io, row) == c) continue;
+                v = negative + (uint64_t)row * ld;
             }
-            float *v = central + (uint64_t)row * ld;
             float dot = 0.0f;
             for (uint32_t x = 0; x < d; ++x) dot += h[x] * v[x];
             if (dot > tp->clip) dot = tp->clip;
@@ -465,7 +490,7 @@ void o_cbow_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
         }
         for (uint32_t j = lo; j <= hi; ++j) {
             if (!is_context(i, j, md)) continue;
-            float *row = contextual + (uint64_t)walk[j] * ld;
+            float *row = contextual + (uint64_t)wrow[j] * ld;
             for (uint32_t x = 0; x < d; ++x) row[x] += gacc[x] * invC;
         }
     }
@@ -474,10 +499,9 @@ void o_cbow_walk(const o_graph *g, const o_train_params *tp, const uint32_t *wal
 /* Train on explicit walks [n_walks][L]; walk b has id first_walk + b in (seed, epoch).
  * threads <= 1: strictly sequential in walk order (the parity oracle).
  * threads  > 1: OpenMP over walks, unsynchronised updates (Hogwild) -- the CPU baseline. */
-void o_train_walks(const o_graph *g, const o_train_params *tp, const uint32_t *walks,
-                   uint64_t n_walks, uint32_t L, uint64_t seed, uint64_t epoch,
-                   uint64_t first_walk, float lr, float *central, float *contextual,
-                   const uint32_t *neg_override, int threads) {
+void o_train_walks_ex(const o_graph *g, const o_train_params *tp, const o_step_io *io,
+                      uint64_t n_walks, uint32_t L, uint64_t seed, uint64_t epoch,
+                      uint64_t first_walk, float lr, int threads) {
     uint64_t ekey = o_epoch_key(seed, epoch);
     uint64_t per_walk_neg =
         tp->model == 0 ? (uint64_t)L * 2 * tp->window * tp->k : (uint64_t)L * tp->k;
@@ -488,15 +512,30 @@ void o_train_walks(const o_graph *g, const o_train_params *tp, const uint32_t *w
 #pragma omp for schedule(dynamic, 16)
         for (uint64_t b = 0; b < n_walks; ++b) {
             uint64_t wkey = o_draw(ekey, first_walk + b);
-            const uint32_t *ov = neg_override ? neg_override + b * per_walk_neg : NULL;
+            const uint32_t *ov = io->neg_override ? io->neg_override + b * per_walk_neg : NULL;
+            const uint32_t *walk = io->walks + b * L;
+            const uint32_t *wrow = io->walk_rows ? io->walk_rows + b * L : walk;
             if (tp->model == 0)
-                o_sgns_walk(g, tp, walks + b * L, L, wkey, lr, central, contextual, ov, u, gacc);
+                o_sgns_walk(g, tp, io, walk, wrow, L, wkey, lr, ov, u, gacc);
             else
-                o_cbow_walk(g, tp, walks + b * L, L, wkey, lr, central, contextual, ov, u, gacc);
+                o_cbow_walk(g, tp, io, walk, wrow, L, wkey, lr, ov, u, gacc);
         }
         free(u);
         free(gacc);
     }
+}
+
+void o_train_walks(const o_graph *g, const o_train_params *tp, const uint32_t *walks,
+                   uint64_t n_walks, uint32_t L, uint64_t seed, uint64_t epoch,
+                   uint64_t first_walk, float lr, float *central, float *contextual,
+                   const uint32_t *neg_override, int threads) {
+    o_step_io io;
+    memset(&io, 0, sizeof(io));
+    io.walks = walks;
+    io.central = central;
+    io.contextual = contextual;
+    io.neg_override = neg_override;
+    o_train_walks_ex(g, tp, &io, n_walks, L, seed, epoch, first_walk, lr, threads);
 }
 
 /* Full fit: init both tables, then per epoch generate all walks and train on them in order.

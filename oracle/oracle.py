@@ -158,6 +158,49 @@ def train_walks(g: OracleGraph, tp: TrainParams, walks_arr, seed: int, epoch: in
                         _ptr(neg_override), C.c_int(threads))
 
 
+class StepIO(C.Structure):
+    _fields_ = [
+        ("walks", C.c_void_p),
+        ("walk_rows", C.c_void_p),
+        ("central", C.c_void_p),
+        ("contextual", C.c_void_p),
+        ("negative", C.c_void_p),
+        ("neg_pool", C.c_void_p),
+        ("neg_pool_size", C.c_uint64),
+        ("neg_id_mul", C.c_uint32),
+        ("neg_id_add", C.c_uint32),
+        ("neg_override", C.c_void_p),
+    ]
+
+
+def train_walks_ex(g: OracleGraph, tp: TrainParams, walks_arr, seed: int, epoch: int,
+                   first_walk: int, lr: float, central, contextual, walk_rows=None,
+                   negative=None, neg_pool=None, neg_id_mul: int = 0, neg_id_add: int = 0,
+                   neg_override=None, threads: int = 1):
+    """General step (mirrors gn2v_step): walk nodes addressed through ``walk_rows``, negatives
+    drawn from ``neg_pool`` as rows of ``negative``.  All arrays are updated in place."""
+    walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
+    keep = [walks_arr]
+    io = StepIO()
+    io.walks = walks_arr.ctypes.data
+    for name, arr, dtype in (("walk_rows", walk_rows, np.uint32), ("neg_pool", neg_pool, np.uint32),
+                             ("neg_override", neg_override, np.uint32)):
+        if arr is not None:
+            arr = np.ascontiguousarray(arr, dtype=dtype)
+            keep.append(arr)
+            setattr(io, name, arr.ctypes.data)
+    for name, arr in (("central", central), ("contextual", contextual), ("negative", negative)):
+        if arr is not None:
+            assert arr.flags.c_contiguous and arr.dtype == np.float32
+            setattr(io, name, arr.ctypes.data)
+    io.neg_pool_size = 0 if neg_pool is None else int(np.asarray(neg_pool).size)
+    io.neg_id_mul, io.neg_id_add = neg_id_mul, neg_id_add
+    n_walks, L = walks_arr.shape
+    lib().o_train_walks_ex(C.byref(g.c), C.byref(tp), C.byref(io), C.c_uint64(n_walks),
+                           C.c_uint32(L), C.c_uint64(seed), C.c_uint64(epoch),
+                           C.c_uint64(first_walk), C.c_float(lr), C.c_int(threads))
+
+
 def fit(g: OracleGraph, wp: WalkParams, tp: TrainParams, seed: int, sources=None,
         threads: int = 1):
     """Full fit_transform restatement -> (central, contextual, n_pairs)."""

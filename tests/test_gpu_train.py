@@ -324,3 +324,52 @@ def test_walklets_fit_matches_oracle_per_scale(karate, karate_oracle, cls, model
         assert np.abs(res[2 * (s - 1)] - rc).max() < 1e-4
         assert np.abs(res[2 * (s - 1) + 1] - rx).max() < 1e-4
     assert m.get_last_stats()["pairs"] == total
+
+
+@pytest.mark.parametrize("d,ld", [(20, 32), (100, 128), (12, 12)])
+def test_padded_row_stride_through_the_public_api(karate, karate_oracle, d, ld):
+    """Rows wider than 64 B are stored at a 128 B-aligned stride on the device; the caller still
+    receives exact [N, d] tables equal to the oracle's."""
+    m = E.Node2VecSkipGramEnsmallen(embedding_size=d, epochs=1, walk_length=12, iterations=1,
+                                    window_size=3, number_of_negative_samples=3, verbose=False)
+    assert m._model.padded_size == ld
+    m._model.deterministic = True
+    res = m.fit_transform(karate, return_dataframe=False).get_all_node_embedding()
+    rc, rx, _ = O.fit(karate_oracle, O.WalkParams(12, 1, 0.25, 4.0, 100, 0),
+                      O.TrainParams(0, d, ld, 1, 3, 3, 0.01, 0.9, 6.0, 1, d ** -0.5), 42)
+    assert res[0].shape == (34, d) and res[0].flags.c_contiguous
+    assert np.abs(res[0] - rc[:, :d]).max() < 1e-5 and np.abs(res[1] - rx[:, :d]).max() < 1e-5
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("flags", [DET, _lib.TRAIN_WRITE_THROUGH, _lib.TRAIN_ATOMIC])
+def test_general_step_with_row_caches_and_negative_pool(karate, karate_oracle, model, flags):
+    """gn2v_step: walk nodes addressed through compact row caches, negatives drawn from a pool of
+    rows of a third table with a global-id mapping (the row-sharded trainer's step).  Checked
+    against the oracle's general step; parallel flavours one walk per launch."""
+    rng = np.random.RandomState(1)
+    d, k, w, n_cache, n_shard = 16, 5, 3, 40, 17
+    wk = ops.walks(karate, ops.walk_params(20, 1, 0.5, 2.0), 9, 0, 0, 34)
+    wk_h = wk.cpu().numpy().view(np.uint32)
+    perm = rng.permutation(n_cache)[:34].astype(np.uint32)  # node id -> cache row
+    rows_h = perm[wk_h]
+    pool_h = rng.randint(0, n_shard, size=500).astype(np.uint32)  # shard rows, with repeats
+    tabs = [ops.init_table(n, d, 9, t, d ** -0.5) for t, n in ((0, n_cache), (1, n_cache), (2, n_shard))]
+    host = [t.cpu().numpy().copy() for t in tabs]
+    tp = ops.train_params(model, d, k, w, flags=1 | flags)
+    otp = O.TrainParams(model, d, d, 1, k, w, 0.01, 0.9, 6.0, 1, d ** -0.5)
+    rows_t = torch.from_numpy(rows_h.view(np.int32)).cuda()
+    pool_t = torch.from_numpy(pool_h.view(np.int32)).cuda()
+    kw = dict(negative=tabs[2], neg_pool=pool_t, neg_id_mul=2, neg_id_add=1)
+    if flags == DET:
+        ops.step(karate, tp, wk, 9, 0, 0, 0.05, tabs[0], tabs[1], walk_rows=rows_t, **kw)
+    else:
+        for b in range(34):
+            ops.step(karate, tp, wk[b:b + 1].contiguous(), 9, 0, b, 0.05, tabs[0], tabs[1],
+                     walk_rows=rows_t[b:b + 1].contiguous(), **kw)
+    torch.cuda.synchronize()
+    O.train_walks_ex(karate_oracle, otp, wk_h, 9, 0, 0, 0.05, host[0], host[1], walk_rows=rows_h,
+                     negative=host[2], neg_pool=pool_h, neg_id_mul=2, neg_id_add=1)
+    for t, h in zip(tabs, host):
+        assert np.abs(t.cpu().numpy() - h).max() < 1e-5
+    assert np.abs(host[2] - ops.init_table(n_shard, d, 9, 2, d ** -0.5).cpu().numpy()).max() > 1e-4
