@@ -29,7 +29,8 @@ MODEL_CBOW = 1
 # every symbol include/gn2v.h declares (checked by tests/test_cabi.py)
 EXPORTS = [
     "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
-    "gn2v_graph_destroy", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_init_table",
+    "gn2v_graph_destroy", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_walk_pairs",
+    "gn2v_init_table",
     "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_touch_rows",
     "gn2v_stats_reset",
     "gn2v_stats_read",
@@ -76,6 +77,7 @@ class StepIO(C.Structure):
         ("neg_id_mul", C.c_uint32),
         ("neg_id_add", C.c_uint32),
         ("d_neg_override", C.c_void_p),
+        ("pair_mode", C.c_uint32),
     ]
 
 
@@ -149,6 +151,7 @@ def lib():
     L.gn2v_ba_edges.argtypes = [u64, u32, u64, vp, vp, vp]
     L.gn2v_walks.argtypes = [vp, C.POINTER(WalkParams), u64, u64, u64, u64, vp, vp]
     L.gn2v_window_batch.argtypes = [vp, u64, u32, u32, vp, vp, vp]
+    L.gn2v_walk_pairs.argtypes = [vp, u64, u32, u32, u32, vp, vp]
     L.gn2v_init_table.argtypes = [vp, u64, u32, u32, u64, u32, f32, vp]
     step = [vp, C.POINTER(TrainParams), vp, u64, u32, u64, u64, u64, f32, vp, vp, vp, vp]
     L.gn2v_sgns_step.argtypes = step

@@ -186,6 +186,9 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     float *positive_table = cbow ? io->d_central : io->d_contextual;
     a.negative = io->d_negative ? io->d_negative : positive_table;
     a.split = a.negative != positive_table;
+    a.pair_mode = io->pair_mode ? 1u : 0u;
+    if (a.pair_mode && (cbow || L != 2 || tp->window != 1))
+        return fail("pair mode needs SkipGram, walk_length 2 and window_size 1");
     a.neg_pool = io->d_neg_pool;
     a.neg_pool_size = io->neg_pool_size;
     if (a.neg_pool && a.neg_pool_size == 0) return fail("empty negative pool");
@@ -366,6 +369,19 @@ int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_l
     const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(gn2v::window_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        d_walks, n_walks, walk_length, window, d_contexts, d_words);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_walk_pairs(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
+                    uint32_t window, uint32_t min_dist, uint32_t *d_pairs, void *stream) {
+    if (!d_walks || !d_pairs) return fail("NULL pointer");
+    if (window < 1 || walk_length < 2) return fail("need window_size >= 1 and walk_length >= 2");
+    const uint64_t n = n_walks * walk_length * 2 * window;
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(gn2v::pairs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_walks,
+                       n_walks, walk_length, window, min_dist ? min_dist : 1u, d_pairs);
     HIP_TRY(hipGetLastError());
     return 0;
 }

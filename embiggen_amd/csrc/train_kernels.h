@@ -35,6 +35,7 @@ struct TrainArgs {
     uint64_t neg_pool_size;
     uint32_t neg_id_mul, neg_id_add;  // global id of negative row r = r * mul + add (skip rule)
     uint32_t split;             // 1 when `negative` is a different table than the positive one
+    uint32_t pair_mode;         // walks are (centre, context) records: only position 0 is a centre
     unsigned long long *counters;  // [0] pairs, [1] walk steps, [2] centres
     uint64_t n_walks;
     uint64_t first_walk;
@@ -383,7 +384,8 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
         const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
         uint32_t pairs = 0, centres = 0;
 
-        for (uint32_t i = 0; i < Le; ++i) {
+        const uint32_t n_centres = a.pair_mode ? min(Le, 1u) : Le;
+        for (uint32_t i = 0; i < n_centres; ++i) {
             const uint32_t c = s_walk[i];
             if (!keep_centre(a, wkey, i, c)) continue;
             const float lrc = centre_lr(a, c);

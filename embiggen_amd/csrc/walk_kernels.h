@@ -228,4 +228,32 @@ __global__ void window_kernel(const uint32_t *__restrict__ walks, uint64_t n_wal
     }
 }
 
+// (centre, context) pairs of every walk position, window trimmed at the walk borders: slot
+// [walk][position][2w] holds the pair or (sentinel, sentinel).  Feeds the block-partitioned
+// multi-GPU trainer, which buckets pairs by (centre partition, context partition).
+__global__ void pairs_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L,
+                             uint32_t w, uint32_t min_dist, uint32_t *__restrict__ pairs) {
+    const uint64_t n = n_walks * L * 2 * w;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t slot = (uint32_t)(t % (2 * w));
+        const uint64_t pos = t / (2 * w);
+        const uint32_t i = (uint32_t)(pos % L);
+        const uint64_t b = pos / L;
+        const int64_t j = slot < w ? (int64_t)i - w + slot : (int64_t)i + 1 + (slot - w);
+        uint32_t c = kSentinel, x = kSentinel;
+        if (j >= 0 && j < (int64_t)L) {
+            const uint32_t dist = (uint32_t)(j > (int64_t)i ? j - i : i - j);
+            const uint32_t ci = walks[b * L + i], xj = walks[b * L + j];
+            // a sentinel at j means the walk ended before j (sentinels are a suffix)
+            if (dist >= min_dist && ci != kSentinel && xj != kSentinel) {
+                c = ci;
+                x = xj;
+            }
+        }
+        pairs[2 * t] = c;
+        pairs[2 * t + 1] = x;
+    }
+}
+
 }  // namespace gn2v

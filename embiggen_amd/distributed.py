@@ -211,3 +211,145 @@ class ShardedTrainer:
         t.contextual.index_add_(0, requested, back[:, ld:])
         self.last_exchange = {"unique_nodes": int(uniq.numel()), "rows_sent": int(sum(send_l)),
                               "rows_served": int(sum(recv_l))}
+
+
+# ---------------------------------------------------------------------------------------------
+# Block-partitioned trainer: conflict-free multi-GPU SkipGram.
+#
+# Measured on one GPU with simulated ranks (scripts/replica_quality.py, sharded_quality2.py):
+# merging the displacements of replicas / row caches that several ranks moved at once is unstable
+# on scale-free graphs (8 replicas: link AUROC 0.02-0.27 where one trainer reaches 0.98), because
+# hub rows move far within one exchange interval.  The robust form shares no row between GPUs at
+# any time (GraphVite's orthogonal blocks): nodes are partitioned p(v) = v % world; GPU i owns
+# central partition i for good and holds ONE context partition at a time, which rotates around a
+# ring.  A (centre, context) pair is trained on the GPU that owns its centre, in the episode in
+# which that GPU holds the pair's context partition; negatives come from the resident context
+# partition (degree-proportional within it).  After `world` episodes every block (i, j) of the
+# round's pairs has been trained exactly once and every partition is home again.  Traffic per
+# round and GPU: its share of the pair list (8 B/pair) + world rotations of N/world context rows.
+# ---------------------------------------------------------------------------------------------
+
+
+def partition_rows(n_nodes: int, part: int, world: int) -> int:
+    return (n_nodes - part + world - 1) // world
+
+
+class BlockPartitionedTrainer:
+    def __init__(self, graph, train_params, d: int, ld: int, seed: int, init_scale: float, comm,
+                 device, scale_free: bool = True, init_fn=None, compute=None):
+        import torch
+
+        self.graph, self.tp, self.comm = graph, train_params, comm
+        self.device, self.ld, self.d = torch.device(device), ld, d
+        self.n_nodes = graph.get_number_of_nodes()
+        rank, world = comm.rank, comm.world
+        if init_fn is None:
+            from . import ops
+
+            def init_fn(table_id):
+                return ops.init_table(self.n_nodes, d, seed, table_id, init_scale,
+                                      device=self.device.index or 0, ld=ld)
+        self.central = init_fn(0)[rank::world].contiguous()   # partition `rank`, never moves
+        self.context = init_fn(1)[rank::world].contiguous()   # resident context partition
+        self.resident = rank
+        if getattr(graph, "_device_tensors", None) is not None:
+            col = graph._device_tensors["col_idx"].to(torch.int64) & 0xFFFFFFFF
+        else:
+            col = torch.from_numpy(graph.col_idx.astype("int64")).to(self.device)
+        self.pools = []
+        for p in range(world):
+            if scale_free:
+                rows = torch.div(col[col % world == p], world, rounding_mode="floor")
+            else:
+                rows = torch.arange(partition_rows(self.n_nodes, p, world), device=self.device)
+            if rows.numel() == 0:
+                raise ValueError("A partition owns no edge endpoint: graph too small to split.")
+            self.pools.append(rows.to(torch.int32).contiguous())
+        self.compute = compute or self._gpu_compute
+        self.pairs_seen = 0  # rounds completed (keys the pair ids)
+        self.last_round = None
+
+    def _gpu_compute(self, pairs, rows, part, seed, epoch, first_pair, lr):
+        from . import ops
+
+        ops.step(self.graph, self.tp, pairs, seed, epoch, first_pair, lr, self.central,
+                 self.context, walk_rows=rows, neg_pool=self.pools[part],
+                 neg_id_mul=self.comm.world, neg_id_add=part, pair_mode=True)
+
+    def _rotate(self):
+        """Send the resident context partition to the previous rank, receive the next one's."""
+        comm = self.comm
+        world = comm.world
+        nxt = (self.resident + 1) % world
+        send = [0] * world
+        recv = [0] * world
+        send[(comm.rank - 1) % world] = self.context.shape[0]
+        recv[(comm.rank + 1) % world] = partition_rows(self.n_nodes, nxt, world)
+        self.context = comm.exchange_rows(self.context, send, recv)
+        self.resident = nxt
+
+    def train_round(self, walks, window: int, min_dist: int, seed: int, epoch: int, lr: float,
+                    pairs=None):
+        """One round = every (centre, context) pair of this rank's walks (or the explicit
+        ``pairs`` int32 [n, 2]), plus the pairs the other ranks route here, trained block by
+        block while the context partitions go round the ring."""
+        import torch
+
+        comm = self.comm
+        world = comm.world
+        if pairs is None:
+            from . import ops
+
+            pairs = ops.walk_pairs(walks, window, min_dist)
+        centre = pairs[:, 0].to(torch.int64) & 0xFFFFFFFF
+        owner = centre % world
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=world)
+        recv_counts = comm.exchange_counts(counts)
+        mine = comm.exchange_rows(pairs[order], counts.tolist(), recv_counts.tolist())
+
+        ctx = mine[:, 1].to(torch.int64) & 0xFFFFFFFF
+        part = ctx % world
+        by_block = torch.argsort(part, stable=True)
+        blocks = mine[by_block].contiguous()
+        sizes = torch.bincount(part, minlength=world).tolist()
+        starts = [0]
+        for s in sizes:
+            starts.append(starts[-1] + s)
+        rows = torch.div(blocks.to(torch.int64) & 0xFFFFFFFF, world,
+                         rounding_mode="floor").to(torch.int32).contiguous()
+        # distinct RNG keys for every pair ever trained on any rank
+        base = (self.pairs_seen * world + comm.rank) << 32
+        for _ in range(world):
+            j = self.resident
+            lo, hi = starts[j], starts[j + 1]
+            if hi > lo:
+                self.compute(blocks[lo:hi], rows[lo:hi], j, seed, epoch, base + lo, lr)
+            if world > 1:
+                self._rotate()
+        self.pairs_seen += 1
+        self.last_round = {"pairs_generated": int(pairs.shape[0]), "pairs_trained": int(mine.shape[0]),
+                           "block_sizes": sizes}
+
+    def gather_full(self):
+        """(central, contextual) as full [N, ld] tables on every rank."""
+        import torch
+
+        comm, world = self.comm, self.comm.world
+        out = []
+        for shard, part in ((self.central, comm.rank), (self.context, self.resident)):
+            if world == 1:
+                out.append(shard.clone())
+                continue
+            n_max = partition_rows(self.n_nodes, 0, world)
+            padded = torch.zeros((n_max, self.ld), dtype=shard.dtype, device=shard.device)
+            padded[: shard.shape[0]] = shard
+            blocks = comm.exchange_rows(padded.repeat(world, 1), [n_max] * world, [n_max] * world)
+            parts = comm.exchange_counts(torch.full((world,), part, dtype=torch.int64,
+                                                    device=shard.device)).tolist()
+            full = torch.empty((self.n_nodes, self.ld), dtype=shard.dtype, device=shard.device)
+            for r in range(world):
+                p = parts[r]
+                full[p::world] = blocks[r * n_max: r * n_max + partition_rows(self.n_nodes, p, world)]
+            out.append(full)
+        return out

@@ -62,6 +62,18 @@ def window_batch(walks_tensor, window: int):
     return contexts, words
 
 
+def walk_pairs(walks_tensor, window: int, min_dist: int = 1):
+    """All (centre, context) pairs of the walks as an int32 [n_pairs, 2] tensor (uint32 bits),
+    in walk / position / slot order (``gn2v_walk_pairs`` + compaction of the unused slots)."""
+    torch = _torch()
+    n_walks, L = walks_tensor.shape
+    dev = walks_tensor.device
+    slots = torch.empty((n_walks * L * 2 * window, 2), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().gn2v_walk_pairs(walks_tensor.data_ptr(), n_walks, L, window, min_dist,
+                                          slots.data_ptr(), _stream(dev)))
+    return slots[slots[:, 0] != -1]
+
+
 def init_table(n_rows: int, d: int, seed: int, table_id: int, scale: float, device: int = 0,
                ld: Optional[int] = None):
     torch = _torch()
@@ -102,7 +114,7 @@ def cbow_step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, con
 
 def step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, contextual,
          walk_rows=None, negative=None, neg_pool=None, neg_id_mul: int = 0, neg_id_add: int = 0,
-         neg_override=None):
+         neg_override=None, pair_mode: bool = False):
     """General training step (``gn2v_step``): ``walk_rows`` gives the row of every walk node in
     ``central`` / ``contextual`` (compact row caches), negatives are rows of ``negative`` drawn
     from ``neg_pool``.  ``tp.model`` selects SkipGram / CBOW."""
@@ -115,7 +127,7 @@ def step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, contextu
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     io = _lib.StepIO(ptr(walks_tensor), ptr(walk_rows), ptr(central), ptr(contextual),
                      ptr(negative), ptr(neg_pool), 0 if neg_pool is None else neg_pool.numel(),
-                     neg_id_mul, neg_id_add, ptr(neg_override))
+                     neg_id_mul, neg_id_add, ptr(neg_override), 1 if pair_mode else 0)
     _lib.check(_lib.lib().gn2v_step(dg.handle, C.byref(tp), C.byref(io), n_walks, L, seed, epoch,
                                     first_walk, lr, _stream(dev)))
 

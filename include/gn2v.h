@@ -122,6 +122,12 @@ int gn2v_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_
 int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
                       uint32_t window, int32_t *d_contexts, int32_t *d_words, void *stream);
 
+/* Every (centre, context) pair of the walks, window trimmed at the borders, contexts at distance
+ * [min_dist, window]: d_pairs u32[n_walks][walk_length][2*window][2], unused slots hold
+ * (GN2V_SENTINEL, GN2V_SENTINEL).  Input of the block-partitioned multi-GPU trainer. */
+int gn2v_walk_pairs(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
+                    uint32_t window, uint32_t min_dist, uint32_t *d_pairs, void *stream);
+
 /* table[r][c] = uniform(-scale, scale) from a hash of (seed, table_id, r, c); padding = 0 */
 int gn2v_init_table(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
                     uint32_t table_id, float scale, void *stream);
@@ -156,6 +162,8 @@ typedef struct {
     uint32_t neg_id_mul;         /* global id of negative row r = r * mul + add (0, 0 = identity), */
     uint32_t neg_id_add;         /*   used to skip negatives equal to the centre / context       */
     const uint32_t *d_neg_override;
+    uint32_t pair_mode;          /* 1: d_walks holds (centre, context) records (walk_length 2,
+                                    window 1) and only position 0 acts as a centre (SkipGram)    */
 } gn2v_step_io;
 
 int gn2v_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_step_io *io,

@@ -94,6 +94,7 @@ typedef struct {
     uint64_t neg_pool_size;
     uint32_t neg_id_mul, neg_id_add;
     const uint32_t *neg_override;
+    uint32_t pair_mode; /* walks are (centre, context) records: only position 0 is a centre */
 } o_step_io;
 
 /* ---------------------------------------------------------------- RNG */
@@ -394,7 +395,8 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const o_step_io *io
     uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k, md = min_dist_of(tp);
     uint32_t Le = effective_len(walk, L);
     uint64_t nkey = wkey ^ O_TAG_NEG;
-    for (uint32_t i = 0; i < Le; ++i) {
+    uint32_t n_centres = io->pair_mode ? (Le ? 1 : 0) : Le;
+    for (uint32_t i = 0; i < n_centres; ++i) {
         uint32_t c = walk[i];
         if (!keep_centre(g, tp, wkey, i, c)) continue;
         if (context_count(i, Le, w, md) == 0) continue;
@@ -579,6 +581,28 @@ uint64_t o_window_batch(const uint32_t *walks, uint64_t n_walks, uint32_t L, uin
                 if (j != i) contexts[n * 2 * w + s++] = (int32_t)wk[j];
             ++n;
         }
+    }
+    return n;
+}
+
+/* All (centre, context) pairs of the walks in walk / position / slot order (window trimmed at the
+ * borders, contexts at distance [min_dist, w]); returns the number of pairs written. */
+uint64_t o_walk_pairs(const uint32_t *walks, uint64_t n_walks, uint32_t L, uint32_t w,
+                      uint32_t min_dist, uint32_t *pairs) {
+    uint64_t n = 0;
+    uint32_t md = min_dist ? min_dist : 1;
+    for (uint64_t b = 0; b < n_walks; ++b) {
+        const uint32_t *wk = walks + b * L;
+        uint32_t Le = effective_len(wk, L);
+        for (uint32_t i = 0; i < Le; ++i)
+            for (uint32_t slot = 0; slot < 2 * w; ++slot) {
+                int64_t j = slot < w ? (int64_t)i - w + slot : (int64_t)i + 1 + (slot - w);
+                if (j < 0 || j >= (int64_t)Le) continue;
+                if (!is_context(i, (uint32_t)j, md)) continue;
+                pairs[2 * n] = wk[i];
+                pairs[2 * n + 1] = wk[j];
+                ++n;
+            }
     }
     return n;
 }

@@ -84,6 +84,7 @@ def lib():
         _lib.o_walk_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         _lib.o_fit.restype = C.c_uint64
         _lib.o_window_batch.restype = C.c_uint64
+        _lib.o_walk_pairs.restype = C.c_uint64
     return _lib
 
 
@@ -170,13 +171,14 @@ class StepIO(C.Structure):
         ("neg_id_mul", C.c_uint32),
         ("neg_id_add", C.c_uint32),
         ("neg_override", C.c_void_p),
+        ("pair_mode", C.c_uint32),
     ]
 
 
 def train_walks_ex(g: OracleGraph, tp: TrainParams, walks_arr, seed: int, epoch: int,
                    first_walk: int, lr: float, central, contextual, walk_rows=None,
                    negative=None, neg_pool=None, neg_id_mul: int = 0, neg_id_add: int = 0,
-                   neg_override=None, threads: int = 1):
+                   neg_override=None, threads: int = 1, pair_mode: bool = False):
     """General step (mirrors gn2v_step): walk nodes addressed through ``walk_rows``, negatives
     drawn from ``neg_pool`` as rows of ``negative``.  All arrays are updated in place."""
     walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
@@ -195,6 +197,7 @@ def train_walks_ex(g: OracleGraph, tp: TrainParams, walks_arr, seed: int, epoch:
             setattr(io, name, arr.ctypes.data)
     io.neg_pool_size = 0 if neg_pool is None else int(np.asarray(neg_pool).size)
     io.neg_id_mul, io.neg_id_add = neg_id_mul, neg_id_add
+    io.pair_mode = 1 if pair_mode else 0
     n_walks, L = walks_arr.shape
     lib().o_train_walks_ex(C.byref(g.c), C.byref(tp), C.byref(io), C.c_uint64(n_walks),
                            C.c_uint32(L), C.c_uint64(seed), C.c_uint64(epoch),
@@ -227,3 +230,13 @@ def window_batch(walks_arr, window: int):
                                C.c_uint32(window), _ptr(contexts), _ptr(words))
     assert got == n
     return contexts, words
+
+
+def walk_pairs(walks_arr, window: int, min_dist: int = 1):
+    """(centre, context) pairs uint32 [n, 2] in walk / position / slot order."""
+    walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
+    n_walks, L = walks_arr.shape
+    out = np.empty((n_walks * L * 2 * window, 2), dtype=np.uint32)
+    n = lib().o_walk_pairs(_ptr(walks_arr), C.c_uint64(n_walks), C.c_uint32(L),
+                           C.c_uint32(window), C.c_uint32(min_dist), _ptr(out))
+    return out[:n].copy()

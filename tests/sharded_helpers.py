@@ -89,3 +89,20 @@ def host_init_fn(n_nodes, d, ld, seed, scale):
         return torch.from_numpy(O.init_table(n_nodes, d, ld, seed, table_id, scale))
 
     return init_fn
+
+
+def oracle_block_compute(oracle_graph, otp, trainer):
+    """compute callable for BlockPartitionedTrainer backed by the oracle's pair-mode step."""
+
+    def compute(pairs, rows, part, seed, epoch, first_pair, lr):
+        host = [np.ascontiguousarray(t.detach().cpu().numpy())
+                for t in (trainer.central, trainer.context)]
+        O.train_walks_ex(
+            oracle_graph, otp, pairs.cpu().numpy().view(np.uint32), seed, epoch, first_pair, lr,
+            host[0], host[1], walk_rows=rows.cpu().numpy().view(np.uint32),
+            neg_pool=trainer.pools[part].cpu().numpy().view(np.uint32),
+            neg_id_mul=trainer.comm.world, neg_id_add=part, pair_mode=True)
+        trainer.central.copy_(torch.from_numpy(host[0]))
+        trainer.context.copy_(torch.from_numpy(host[1]))
+
+    return compute

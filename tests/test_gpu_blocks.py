@@ -1,0 +1,118 @@
+"""GPU: pair extraction, the pair-mode kernel and the block-partitioned multi-GPU trainer with
+ranks simulated on one GPU (exact: ranks never share a row, so a sequential simulation computes
+precisely what W GPUs compute; only the transport differs)."""
+import numpy as np
+import pytest
+import torch
+
+import embiggen_amd as E
+from embiggen_amd import _lib, ops
+from embiggen_amd.distributed import BlockPartitionedTrainer
+from oracle import oracle as O
+from sharded_helpers import host_init_fn, oracle_block_compute, run_ranks
+from test_gpu_sharded import _auc
+
+pytestmark = pytest.mark.gpu
+D, K, W, L = 16, 4, 3, 14
+
+
+def test_walk_pairs_match_oracle(karate, karate_oracle):
+    wk = ops.walks(karate, ops.walk_params(20, 2, 0.5, 2.0), 3, 0, 0, 68)
+    wk_h = wk.cpu().numpy().view(np.uint32)
+    for window, md in ((3, 1), (5, 1), (4, 4), (4, 2)):
+        got = ops.walk_pairs(wk, window, md).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, O.walk_pairs(wk_h, window, md))
+    # trap nodes: sentinel suffixes produce no pairs
+    cut = wk.clone()
+    cut[:, 7:] = -1
+    got = ops.walk_pairs(cut, 3).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, O.walk_pairs(cut.cpu().numpy().view(np.uint32), 3))
+
+
+@pytest.mark.parametrize("flags", [_lib.TRAIN_DETERMINISTIC, _lib.TRAIN_ATOMIC,
+                                   _lib.TRAIN_WRITE_THROUGH])
+def test_pair_mode_step_matches_oracle(karate, karate_oracle, flags):
+    wk = ops.walks(karate, ops.walk_params(10, 1, 1.0, 1.0), 4, 0, 0, 34)
+    pairs = ops.walk_pairs(wk, 2)
+    pairs_h = pairs.cpu().numpy().view(np.uint32)
+    c, x = ops.init_table(34, D, 4, 0, D ** -0.5), ops.init_table(34, D, 4, 1, D ** -0.5)
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    tp = ops.train_params(0, D, K, 1, flags=1 | flags)
+    otp = O.TrainParams(0, D, D, 1, K, 1, 0.01, 0.9, 6.0, 1, D ** -0.5)
+    if flags == _lib.TRAIN_DETERMINISTIC:
+        ops.step(karate, tp, pairs, 4, 0, 100, 0.05, c, x, pair_mode=True)
+    else:  # production flavours one pair per launch (pairs of a batch share rows)
+        for b in range(0, 200):
+            ops.step(karate, tp, pairs[b:b + 1].contiguous(), 4, 0, 100 + b, 0.05, c, x,
+                     pair_mode=True)
+        pairs_h = pairs_h[:200]
+    torch.cuda.synchronize()
+    O.train_walks_ex(karate_oracle, otp, pairs_h, 4, 0, 100, 0.05, c_h, x_h, pair_mode=True)
+    assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+
+
+def _run(comm, device, use_oracle):
+    g = E.karate_club()
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    otp = O.TrainParams(0, D, D, 1, K, 1, 0.02, 0.9, 6.0, 1, D ** -0.5)
+    tp = ops.train_params(0, D, K, 1, flags=1 | _lib.TRAIN_DETERMINISTIC)
+    if use_oracle:
+        tr = BlockPartitionedTrainer(g, otp, D, D, 42, D ** -0.5, comm, "cpu",
+                                     init_fn=host_init_fn(34, D, D, 42, D ** -0.5))
+        tr.compute = oracle_block_compute(og, otp, tr)
+    else:
+        tr = BlockPartitionedTrainer(g, tp, D, D, 42, D ** -0.5, comm, device)
+    wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
+    for r in range(2):
+        first = (r * comm.world + comm.rank) * 9
+        walks = torch.from_numpy(O.walks(og, wp, 42, 0, first, 9).view(np.int32)).to(device)
+        if use_oracle:
+            pairs = torch.from_numpy(O.walk_pairs(walks.numpy().view(np.uint32), W).view(np.int32))
+            tr.train_round(None, W, 1, 42, 0, 0.02, pairs=pairs)
+        else:
+            tr.train_round(walks, W, 1, 42, 0, 0.02)
+    return [t.cpu().numpy() for t in tr.gather_full()]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_block_trainer_kernel_equals_oracle(world):
+    gpu = run_ranks(world, lambda comm: _run(comm, "cuda:0", use_oracle=False))
+    ref = run_ranks(world, lambda comm: _run(comm, "cpu", use_oracle=True))
+    for r in range(world):
+        assert np.abs(gpu[r][0] - ref[r][0]).max() < 1e-5
+        assert np.abs(gpu[r][1] - ref[r][1]).max() < 1e-5
+
+
+def test_eight_simulated_gpus_reach_single_gpu_quality():
+    """BA 200 k nodes: 8 block-partitioned ranks vs one walk-mode trainer on the same walks
+    (10 per node).  Merging replica deltas collapses here (AUROC 0.02-0.27);
+    orthogonal blocks must stay at the single-GPU quality."""
+    g = E.barabasi_albert(200_000, 8, 42)
+    n, d, w = g.get_number_of_nodes(), 64, 4
+    wp = ops.walk_params(64, 1, 1.0, 1.0)
+    total, per_round = 1 << 21, 1 << 15
+    c = ops.init_table(n, d, 42, 0, d ** -0.5)
+    x = ops.init_table(n, d, 42, 1, d ** -0.5)
+    tp_walk = ops.train_params(0, d, 5, w, flags=1)
+    for first in range(0, total, per_round):
+        ops.sgns_step(g, tp_walk, ops.walks(g, wp, 42, 0, first, per_round), 42, 0, first, 0.025,
+                      c, x)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1)
+    auc_single = _auc(g, c, x, gen)
+
+    world = 8
+    tp_pair = ops.train_params(0, d, 5, 1, flags=1)
+
+    def rank_fn(comm):
+        tr = BlockPartitionedTrainer(g, tp_pair, d, d, 42, d ** -0.5, comm, "cuda:0")
+        for r in range(total // per_round // world):
+            first = (r * world + comm.rank) * per_round
+            tr.train_round(ops.walks(g, wp, 42, 0, first, per_round), w, 1, 42, 0, 0.025)
+        return tr.gather_full(), tr.last_round
+
+    (bc, bx), info = run_ranks(world, rank_fn)[0]
+    gen.manual_seed(1)
+    auc_blocks = _auc(g, bc, bx, gen)
+    assert bool(torch.isfinite(bc).all()) and min(info["block_sizes"]) > 0
+    assert auc_single > 0.9 and auc_blocks > auc_single - 0.03, (auc_blocks, auc_single)
