@@ -11,10 +11,13 @@ One step = one pass of the hot path over one batch of synthetic input: generate 
 second-order walks on the GPU and train on all of them (1 250 pairs per walk).  Graph and both
 tables are resident in HBM before the timed region.
 
-N > 1: one process per GPU, CSR replicated, every rank trains on its own slice of the walk ids
-(weak scaling: per-GPU work fixed) against a full replica of both tables; after every step the
-replicas sum their deltas with one RCCL all-reduce per table (inside the timed region).  See DESIGN.md
-"Multi-GPU" for why this is the round-1 form and what the row-sharded form changes.
+N > 1: one process per GPU, CSR replicated, every rank generates its own slice of the walk ids
+(weak scaling: per-GPU work fixed).  Both tables are partitioned by node id % N: GPU i owns central
+partition i and holds one context partition at a time; every (centre, context) pair is routed to
+the owner of its centre (RCCL all-to-all of 8 B per pair) and trained in the episode in which the
+context partition is resident; partitions rotate around the ring once per round (RCCL, N/N-th of a
+table per hop).  No row is ever shared, so N GPUs compute exactly what the single-process
+simulation of the tests computes.  See DESIGN.md "Multi-GPU".
 
 Prints ONE JSON line on rank 0.
 """
@@ -53,6 +56,11 @@ def parse():
                     help="run the traffic-calibration kernel instead of training (for rocprofv3 "
                          "--pmc passes): every table row touched exactly once per launch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "single", "blocks"],
+                    help="auto: single on 1 GPU, block-partitioned tables on N > 1 GPUs")
+    ap.add_argument("--round-walks", type=int, default=1 << 18,
+                    help="blocks: walks per rank per round (one ring rotation of the context "
+                         "partitions per round)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: all ranks use GPU 0 (use with --backend gloo)")
@@ -188,11 +196,34 @@ def main():
         return
     tp = ops.train_params(_lib.MODEL_SKIPGRAM, d, 10, 5, lr=0.01, flags=flags)
     wp = ops.walk_params(128, 10, args.return_weight, args.explore_weight)
-    from embiggen_amd.distributed import ReplicaSync, walk_slice
+    from embiggen_amd.distributed import (BlockPartitionedTrainer, LoopbackComm, TorchComm,
+                                          walk_slice)
 
-    replicas = ReplicaSync(central, contextual)
+    mode = args.parallelism
+    if mode == "auto":
+        mode = "single" if world == 1 else "blocks"
+    if mode == "single" and world > 1:
+        raise SystemExit("--parallelism single needs --gpus 1")
+    blocks = None
+    if mode == "blocks":
+        # tables partitioned by node id % world; no row is ever held by two GPUs
+        del central, contextual
+        comm = TorchComm() if world > 1 else LoopbackComm()
+        tp_pair = ops.train_params(_lib.MODEL_SKIPGRAM, d, 10, 1, lr=0.01, flags=flags)
+        blocks = BlockPartitionedTrainer(graph, tp_pair, d, (d + 31) // 32 * 32, 42, d ** -0.5,
+                                         comm, f"cuda:{local}")
+        central, contextual = blocks.central, blocks.context
+
+    def step_blocks(index):
+        first, count = walk_slice(index, rank, world, args.walks)
+        for woff in range(0, count, args.round_walks):
+            nw = min(args.round_walks, count - woff)
+            wk = ops.walks(graph, wp, 42, 0, first + woff, nw, device=local)
+            blocks.train_round(wk, 5, 1, 42, 0, 0.01)
 
     def step(index):
+        if blocks is not None:
+            return step_blocks(index)
         """this rank's slice of the step's walk ids, in launches of args.batch walks; then the
         replicas exchange their deltas (one RCCL all-reduce per table)"""
         first, count = walk_slice(index, rank, world, args.walks)
@@ -203,7 +234,6 @@ def main():
                 nb = min(args.batch, nw - off)
                 ops.sgns_step(graph, tp, wk[off:off + nb], 42, 0, first + woff + off, 0.01,
                               central, contextual)
-        replicas.sync()
 
     def fence():
         torch.cuda.synchronize()
@@ -231,6 +261,8 @@ def main():
     total_pairs, total_steps = float(counts[0]), float(counts[1])
 
     if rank == 0:
+        if blocks is not None:
+            central, contextual = blocks.central, blocks.context
         ok = bool(torch.isfinite(central).all()) and bool(torch.isfinite(contextual).all())
         launch_ms = st["train_ms"] / max(st["train_launches"], 1)
         achieved = st["pairs"] * BYTES_PER_PAIR / (st["train_ms"] * 1e-3) / 1e9
@@ -254,8 +286,12 @@ def main():
                             f"{args.explore_weight}, {args.walks} walks per step per GPU",
                 "update_mode": args.mode,
                 "walks_per_launch": args.batch,
-                "parallelism": "1 GPU" if world == 1 else
-                               f"{world} table replicas, walks partitioned by id, delta-sum all-reduce per table per step",
+                "parallelism": {
+                    "single": "1 GPU, walk-ordered kernel",
+                    "blocks": f"{world} GPU(s), tables partitioned by node id % {world} (no shared "
+                              f"rows), pair-list kernel, context partitions rotate once per round of "
+                              f"{args.round_walks} walks per GPU",
+                }[mode],
             },
             "walk_steps_per_s": total_steps / elapsed,
             "walk_kernel_steps_per_s": st["walk_steps"] / max(st["walk_ms"] * 1e-3, 1e-12),
@@ -269,7 +305,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "algorithmic_bytes_per_launch": args.batch * 1250 * BYTES_PER_PAIR,
+                "algorithmic_bytes_per_launch": (st["pairs"] // max(st["train_launches"], 1))
+                                                * BYTES_PER_PAIR,
                 "avg_launch_ms": launch_ms,
                 "launches": st["train_launches"],
             },

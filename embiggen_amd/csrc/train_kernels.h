@@ -376,13 +376,14 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
 
+    unsigned long long pairs = 0, centres = 0;  // per wave, flushed with one atomic each at exit
+
     for (uint64_t b = (uint64_t)blockIdx.x * waves_per_block + wave; b < a.n_walks;
          b += wave_stride) {
         const uint32_t Le = stage_walk(a, b, s_walk, s_wrow, lane);
         const uint64_t wkey = draw(a.ekey, a.first_walk + b);
         const uint64_t nkey = wkey ^ kTagNeg;
         const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
-        uint32_t pairs = 0, centres = 0;
 
         const uint32_t n_centres = a.pair_mode ? min(Le, 1u) : Le;
         for (uint32_t i = 0; i < n_centres; ++i) {
@@ -431,11 +432,13 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
             pairs += n_ctx;
             ++centres;
         }
-        if (a.counters && lane == 0) {
-            atomicAdd(&a.counters[0], (unsigned long long)pairs);
-            atomicAdd(&a.counters[2], (unsigned long long)centres);
-        }
         wave_sync();
+    }
+    // one atomic per wave: a per-walk atomic on a single counter serialises at ~12 ns each and
+    // dominated the pair-list mode (328 M one-pair "walks" -> 7.9 s of counter traffic)
+    if (a.counters && lane == 0 && pairs) {
+        atomicAdd(&a.counters[0], pairs);
+        atomicAdd(&a.counters[2], centres);
     }
 }
 
@@ -461,13 +464,14 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
 
+    unsigned long long pairs = 0, centres = 0;  // per wave, flushed with one atomic each at exit
+
     for (uint64_t b = (uint64_t)blockIdx.x * waves_per_block + wave; b < a.n_walks;
          b += wave_stride) {
         const uint32_t Le = stage_walk(a, b, s_walk, s_wrow, lane);
         const uint64_t wkey = draw(a.ekey, a.first_walk + b);
         const uint64_t nkey = wkey ^ kTagNeg;
         const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
-        uint32_t pairs = 0, centres = 0;
 
         for (uint32_t i = 0; i < Le; ++i) {
             const uint32_t c = s_walk[i];
@@ -559,11 +563,13 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
             pairs += n_ctx;
             ++centres;
         }
-        if (a.counters && lane == 0) {
-            atomicAdd(&a.counters[0], (unsigned long long)pairs);
-            atomicAdd(&a.counters[2], (unsigned long long)centres);
-        }
         wave_sync();
+    }
+    // one atomic per wave: a per-walk atomic on a single counter serialises at ~12 ns each and
+    // dominated the pair-list mode (328 M one-pair "walks" -> 7.9 s of counter traffic)
+    if (a.counters && lane == 0 && pairs) {
+        atomicAdd(&a.counters[0], pairs);
+        atomicAdd(&a.counters[2], centres);
     }
 }
 

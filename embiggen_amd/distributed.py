@@ -1,14 +1,11 @@
-"""One-process-per-GPU data parallelism for the training path (torch.distributed; backend
+"""One-process-per-GPU data parallelism for the SkipGram training path (torch.distributed; backend
 "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 
-Round-1 form: the CSR and both tables are replicated, walks are partitioned
-by walk id, and after every step the replicas exchange what they learned.  Because every rank only
-touches the rows its walks visit, replicas are combined by **summing deltas**
-    new = base + sum_r (table_r - base)  =  all_reduce_sum(table_r) - (world - 1) * base
-rather than by averaging (averaging would divide the update of a row only one rank touched by the
-world size).  One all-reduce per table per step: 2 x 4*N*ld bytes per 1250 * walks_per_step pairs.
 The reference has no counterpart: ensmallen parallelises with rayon threads inside one process
-(SURVEY.md section 2a).
+(SURVEY.md section 2a).  Units (walks) are partitioned by walk id; the exchange step is the
+block-partitioned scheme below, chosen after measuring that schemes which let several GPUs move
+the same row between exchanges (replica delta-sum, row caches with delta scatter) lose or destroy
+embedding quality on scale-free graphs.
 """
 from typing import Tuple
 
@@ -17,38 +14,6 @@ def walk_slice(step: int, rank: int, world: int, walks_per_step: int) -> Tuple[i
     """(first_walk_id, n_walks) trained by `rank` in global step `step`: slices are disjoint
     across ranks and steps and cover the walk ids contiguously."""
     return (step * world + rank) * walks_per_step, walks_per_step
-
-
-class ReplicaSync:
-    """Keeps the last agreed copy of each table and folds every rank's delta into it."""
-
-    def __init__(self, *tables):
-        import torch.distributed as dist
-
-        self._dist = dist
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.tables = tables
-        self.bases = [t.clone() for t in tables] if self.world > 1 else []
-
-    def sync(self):
-        """Blocking on the current stream: after it every rank holds base + sum of all deltas."""
-        if self.world == 1:
-            return
-        for table, base in zip(self.tables, self.bases):
-            self._dist.all_reduce(table, op=self._dist.ReduceOp.SUM)
-            table.add_(base, alpha=-(self.world - 1))
-            base.copy_(table)
-
-
-# ---------------------------------------------------------------------------------------------
-# Row-sharded tables: the north-star form.  owner(v) = v % world, local row = v // world.
-# Per batch of walks a rank (1) collects the distinct nodes its walks visit, (2) fetches their rows
-# of both tables from the owners into compact row caches (all-to-all), (3) runs the fused kernel on
-# the caches with negatives drawn from -- and updated in place in -- its own shard, and (4) sends
-# the cache deltas back to the owners, which add them (all-to-all).  Only the needed rows travel:
-# <= walk_length rows per 2wL - w(w+1) pairs, ~184 B/pair against 12 288 B/pair of HBM traffic
-# (SURVEY.md section 8e), so xGMI is never the limiter, and no ring over a whole table exists.
-# ---------------------------------------------------------------------------------------------
 
 
 class TorchComm:
@@ -91,126 +56,6 @@ class LoopbackComm:
 
     def exchange_rows(self, rows, send_counts, recv_counts):
         return rows
-
-
-class RowShardedTables:
-    """This rank's rows of both tables plus its pool of negative rows."""
-
-    def __init__(self, graph, d: int, ld: int, seed: int, init_scale: float, comm, device,
-                 scale_free: bool = True, init_fn=None):
-        import torch
-
-        self.comm, self.device, self.ld, self.d = comm, torch.device(device), ld, d
-        self.n_nodes = graph.get_number_of_nodes()
-        rank, world = comm.rank, comm.world
-        self.n_local = (self.n_nodes - rank + world - 1) // world
-        if init_fn is None:
-            from . import ops
-
-            def init_fn(table_id):
-                return ops.init_table(self.n_nodes, d, seed, table_id, init_scale,
-                                      device=self.device.index or 0, ld=ld)
-        self.central = init_fn(0)[rank::world].contiguous()
-        self.contextual = init_fn(1)[rank::world].contiguous()
-        assert self.central.shape == (self.n_local, ld)
-        if scale_free:
-            if getattr(graph, "_device_tensors", None) is not None:
-                col = graph._device_tensors["col_idx"].to(torch.int64) & 0xFFFFFFFF
-            else:
-                col = torch.from_numpy(graph.col_idx.astype("int64")).to(self.device)
-            mine = col[col % world == rank]
-            self.neg_pool = torch.div(mine, world, rounding_mode="floor").to(torch.int32)
-        else:
-            self.neg_pool = torch.arange(self.n_local, dtype=torch.int32, device=self.device)
-        if self.neg_pool.numel() == 0:
-            raise ValueError("This rank owns no edge endpoint: the graph is too small to shard.")
-
-    def gather_full(self):
-        """(central, contextual) as full [N, ld] tables on every rank (result extraction)."""
-        import torch
-
-        out = []
-        for shard in (self.central, self.contextual):
-            world = self.comm.world
-            if world == 1:
-                out.append(shard.clone())
-                continue
-            n_max = (self.n_nodes + world - 1) // world
-            padded = torch.zeros((n_max, self.ld), dtype=shard.dtype, device=shard.device)
-            padded[: shard.shape[0]] = shard
-            blocks = self.comm.exchange_rows(padded.repeat(world, 1), [n_max] * world,
-                                             [n_max] * world)
-            full = torch.empty((self.n_nodes, self.ld), dtype=shard.dtype, device=shard.device)
-            for r in range(world):
-                n_r = (self.n_nodes - r + world - 1) // world
-                full[r::world] = blocks[r * n_max: r * n_max + n_r]
-            out.append(full)
-        return out
-
-
-class ShardedTrainer:
-    """One rank of the row-sharded trainer.  ``compute(walks, rows, cache_central,
-    cache_contextual, tables)`` runs the fused kernel on the row caches (default: ``ops.step``)."""
-
-    def __init__(self, graph, tables: RowShardedTables, train_params, compute=None,
-                 merge: str = "mean"):
-        if merge not in ("mean", "sum"):
-            raise ValueError("merge must be 'mean' or 'sum'")
-        self.merge = merge
-        self.graph, self.tables, self.tp = graph, tables, train_params
-        self.compute = compute or self._gpu_compute
-        self.last_exchange = None
-
-    def _gpu_compute(self, walks, rows, cache_c, cache_x, seed, epoch, first_walk, lr):
-        from . import _lib, ops
-
-        t = self.tables
-        negative = t.central if self.tp.model == _lib.MODEL_CBOW else t.contextual
-        ops.step(self.graph, self.tp, walks, seed, epoch, first_walk, lr, cache_c, cache_x,
-                 walk_rows=rows, negative=negative, neg_pool=t.neg_pool,
-                 neg_id_mul=t.comm.world, neg_id_add=t.comm.rank)
-
-    def train_batch(self, walks, seed: int, epoch: int, first_walk: int, lr: float):
-        """walks: int32 [n_walks, walk_length] of global node ids (uint32 bits) on the device."""
-        import torch
-
-        t, comm = self.tables, self.tables.comm
-        world, ld = comm.world, t.ld
-        ids = walks.to(torch.int64).flatten() & 0xFFFFFFFF
-        uniq, inv = torch.unique(ids, return_inverse=True)
-        if uniq[-1] == 0xFFFFFFFF:  # walk padding after a trap node: never addressed
-            uniq = uniq[:-1]
-        rows = inv.to(torch.int32).reshape(walks.shape).contiguous()
-
-        owner = uniq % world
-        order = torch.argsort(owner, stable=True)
-        counts = torch.bincount(owner, minlength=world)
-        recv_counts = comm.exchange_counts(counts)
-        send_l, recv_l = counts.tolist(), recv_counts.tolist()
-        wanted = torch.div(uniq[order], world, rounding_mode="floor")
-        requested = comm.exchange_rows(wanted, send_l, recv_l)  # local rows others (and I) need
-
-        payload = torch.cat([t.central[requested], t.contextual[requested]], dim=1)
-        got = comm.exchange_rows(payload, recv_l, send_l)
-        cache = torch.empty_like(got)
-        cache[order] = got
-        cache_c, cache_x = cache[:, :ld].contiguous(), cache[:, ld:].contiguous()
-        old_c, old_x = cache_c.clone(), cache_x.clone()
-
-        self.compute(walks, rows, cache_c, cache_x, seed, epoch, first_walk, lr)
-
-        delta = torch.cat([cache_c - old_c, cache_x - old_x], dim=1)[order]
-        back = comm.exchange_rows(delta, send_l, recv_l)
-        if self.merge == "mean":
-            # a row cached by several ranks comes back as several displacements of the same base:
-            # average them (summing overshoots once a row moves appreciably within a batch, which
-            # hub rows always do); rows held by one rank keep their full update
-            holders = torch.bincount(requested, minlength=t.n_local).to(back.dtype)
-            back = back / holders[requested].unsqueeze(1)
-        t.central.index_add_(0, requested, back[:, :ld])
-        t.contextual.index_add_(0, requested, back[:, ld:])
-        self.last_exchange = {"unique_nodes": int(uniq.numel()), "rows_sent": int(sum(send_l)),
-                              "rows_served": int(sum(recv_l))}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -301,18 +146,45 @@ class BlockPartitionedTrainer:
             from . import ops
 
             pairs = ops.walk_pairs(walks, window, min_dist)
+        # One sort at the source: key = (owner of the centre, context partition, hashed salt).
+        # The salt shuffles pairs inside a block (integer ops only, so CPU and GPU agree): pairs
+        # leave the walks ~10 in a row with the same centre, and one wavefront per pair would
+        # otherwise make them hammer that row at the same time.
+        n = pairs.shape[0]
         centre = pairs[:, 0].to(torch.int64) & 0xFFFFFFFF
-        owner = centre % world
-        order = torch.argsort(owner, stable=True)
-        counts = torch.bincount(owner, minlength=world)
-        recv_counts = comm.exchange_counts(counts)
-        mine = comm.exchange_rows(pairs[order], counts.tolist(), recv_counts.tolist())
-
-        ctx = mine[:, 1].to(torch.int64) & 0xFFFFFFFF
-        part = ctx % world
-        by_block = torch.argsort(part, stable=True)
-        blocks = mine[by_block].contiguous()
-        sizes = torch.bincount(part, minlength=world).tolist()
+        ctx = pairs[:, 1].to(torch.int64) & 0xFFFFFFFF
+        block = (centre % world) * world + ctx % world
+        idx = torch.arange(n, dtype=torch.int64, device=pairs.device)
+        salt = (idx * 0x3C6EF35F + (seed * 0x19660D + self.pairs_seen * 0x2545F491 + 1)) & 0x7FFFFFFF
+        salt = ((salt ^ (salt >> 15)) * 0x2C1B3C6D) & 0x7FFFFFFF
+        salt = ((salt ^ (salt >> 12)) * 0x297A2D39) & 0x7FFFFFFF
+        salt = salt ^ (salt >> 15)
+        order = torch.argsort(block * (1 << 31) + salt)
+        del idx, salt, centre, ctx
+        sorted_pairs = pairs[order]
+        del order
+        # counts[o][p] = my pairs for owner o with context partition p; owner o receives row o
+        counts = torch.bincount(block, minlength=world * world).reshape(world, world)
+        del block
+        got_counts = comm.exchange_rows(counts, [1] * world, [1] * world)  # [source][partition]
+        send_l = counts.sum(1).tolist()
+        src_part = got_counts.tolist()
+        recv_l = [sum(row) for row in src_part]
+        mine = comm.exchange_rows(sorted_pairs, send_l, recv_l)
+        del sorted_pairs
+        # block j = the j-th sub-segment of every source's segment (no second sort needed)
+        seg_start, pieces, sizes = 0, [[] for _ in range(world)], [0] * world
+        for src in range(world):
+            off = seg_start
+            for j in range(world):
+                c = src_part[src][j]
+                if c:
+                    pieces[j].append(mine[off:off + c])
+                    sizes[j] += c
+                off += c
+            seg_start = off
+        flat = [piece for j in range(world) for piece in pieces[j]]
+        blocks = torch.cat(flat) if len(flat) > 1 else (flat[0] if flat else mine[:0])
         starts = [0]
         for s in sizes:
             starts.append(starts[-1] + s)

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import embiggen_amd as E
 from embiggen_amd import ops, _lib
-from test_gpu_sharded import _auc
+from sharded_helpers import link_auc_device as _auc
 nodes, total, per_step = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 lr = 0.025
 g = E.barabasi_albert(nodes, 8, 42); n = g.get_number_of_nodes(); d = 64

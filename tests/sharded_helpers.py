@@ -65,25 +65,6 @@ def run_ranks(world, fn):
     return results
 
 
-def oracle_compute(oracle_graph, otp, tables):
-    """compute callable for ShardedTrainer backed by the oracle's general step (works for CPU
-    tensors in place and for CUDA tensors through a host round trip)."""
-
-    def compute(walks, rows, cache_c, cache_x, seed, epoch, first_walk, lr):
-        neg_t = tables.central if otp.model == 1 else tables.contextual
-        host = [t.detach().cpu().numpy() for t in (cache_c, cache_x, neg_t)]
-        host = [np.ascontiguousarray(h) for h in host]
-        O.train_walks_ex(
-            oracle_graph, otp, walks.cpu().numpy().view(np.uint32), seed, epoch, first_walk, lr,
-            host[0], host[1], walk_rows=rows.cpu().numpy().view(np.uint32), negative=host[2],
-            neg_pool=tables.neg_pool.cpu().numpy().view(np.uint32),
-            neg_id_mul=tables.comm.world, neg_id_add=tables.comm.rank)
-        for t, h in zip((cache_c, cache_x, neg_t), host):
-            t.copy_(torch.from_numpy(h))
-
-    return compute
-
-
 def host_init_fn(n_nodes, d, ld, seed, scale):
     def init_fn(table_id):
         return torch.from_numpy(O.init_table(n_nodes, d, ld, seed, table_id, scale))
@@ -106,3 +87,20 @@ def oracle_block_compute(oracle_graph, otp, trainer):
         trainer.context.copy_(torch.from_numpy(host[1]))
 
     return compute
+
+
+def link_auc_device(g, c, x, gen, n_eval=100000):
+    """AUROC of the symmetrised SkipGram score for sampled edges vs random node pairs, on the GPU
+    (graph must be device resident)."""
+    t = g._device_tensors
+    n = g.get_number_of_nodes()
+    e = torch.randint(0, t["col_idx"].numel(), (n_eval,), device="cuda", generator=gen)
+    dst = t["col_idx"][e].long()
+    src = torch.searchsorted(t["row_ptr"], e, right=True) - 1
+    ru = torch.randint(0, n, (n_eval,), device="cuda", generator=gen)
+    rv = torch.randint(0, n, (n_eval,), device="cuda", generator=gen)
+    score = lambda u, v: (c[u] * x[v]).sum(1) + (c[v] * x[u]).sum(1)  # noqa: E731
+    s = torch.cat([score(src, dst), score(ru, rv)])
+    ranks = torch.empty_like(s)
+    ranks[torch.argsort(s)] = torch.arange(1, s.numel() + 1, device="cuda", dtype=s.dtype)
+    return float((ranks[:n_eval].sum() - n_eval * (n_eval + 1) / 2) / (n_eval * n_eval))

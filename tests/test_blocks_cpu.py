@@ -48,7 +48,16 @@ def test_pair_extraction_counts():
     assert O.walk_pairs(cut, W).shape[0] == 4 * (2 * W * L - W * (W + 1)) + (2 * 3 * 4 - 3 * 4)
 
 
-def test_world_one_is_the_pair_list_trained_in_order():
+def _salt(n, seed, rnd):
+    """The trainer's in-bucket shuffle key, restated with numpy."""
+    idx = np.arange(n, dtype=np.int64)
+    salt = (idx * 0x3C6EF35F + (seed * 0x19660D + rnd * 0x2545F491 + 1)) & 0x7FFFFFFF
+    salt = ((salt ^ (salt >> 15)) * 0x2C1B3C6D) & 0x7FFFFFFF
+    salt = ((salt ^ (salt >> 12)) * 0x297A2D39) & 0x7FFFFFFF
+    return salt ^ (salt >> 15)
+
+
+def test_world_one_is_the_shuffled_pair_list_trained_in_order():
     (c, x), info = _train(LoopbackComm())
     g = E.karate_club()
     og = O.OracleGraph(g.row_ptr, g.col_idx)
@@ -58,6 +67,9 @@ def test_world_one_is_the_pair_list_trained_in_order():
     wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
     for r in range(2):
         pairs = O.walk_pairs(O.walks(og, wp, 42, 0, r * 9, 9), W)
+        salt = _salt(len(pairs), 42, r)
+        assert len(np.unique(salt)) > 0.99 * len(pairs)
+        pairs = pairs[np.argsort(salt, kind="stable")]
         O.train_walks_ex(og, otp, pairs, 42, 0, r << 32, 0.02, rc, rx, neg_pool=g.col_idx,
                          neg_id_mul=1, neg_id_add=0, pair_mode=True)
     assert np.array_equal(c, rc) and np.array_equal(x, rx)

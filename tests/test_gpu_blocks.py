@@ -9,8 +9,7 @@ import embiggen_amd as E
 from embiggen_amd import _lib, ops
 from embiggen_amd.distributed import BlockPartitionedTrainer
 from oracle import oracle as O
-from sharded_helpers import host_init_fn, oracle_block_compute, run_ranks
-from test_gpu_sharded import _auc
+from sharded_helpers import host_init_fn, link_auc_device as _auc, oracle_block_compute, run_ranks
 
 pytestmark = pytest.mark.gpu
 D, K, W, L = 16, 4, 3, 14
