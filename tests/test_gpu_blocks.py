@@ -115,3 +115,31 @@ def test_eight_simulated_gpus_reach_single_gpu_quality():
     auc_blocks = _auc(g, bc, bx, gen)
     assert bool(torch.isfinite(bc).all()) and min(info["block_sizes"]) > 0
     assert auc_single > 0.9 and auc_blocks > auc_single - 0.03, (auc_blocks, auc_single)
+
+
+@pytest.mark.parametrize("flags", [_lib.TRAIN_ATOMIC, _lib.TRAIN_WRITE_THROUGH,
+                                   _lib.TRAIN_WRITE_BACK])
+@pytest.mark.parametrize("d", [8, 128])
+def test_pair_mode_on_a_collision_free_batch(karate, karate_oracle, flags, d):
+    """Thousands of (centre, context) records in one launch: with every record on its own rows
+    the parallel schedule must equal the sequential oracle."""
+    rng = np.random.RandomState(3)
+    n_rec, k, blk = 3000, 6, 16
+    pairs = np.zeros((n_rec, 2), dtype=np.uint32)
+    neg = np.zeros((n_rec, 2, 2, k), dtype=np.uint32)
+    for b in range(n_rec):
+        nodes = b * blk + rng.permutation(blk)
+        pairs[b] = nodes[:2]
+        neg[b, 0, 1] = nodes[2:2 + k]
+    n_rows = n_rec * blk
+    c, x = ops.init_table(n_rows, d, 5, 0, d ** -0.5), ops.init_table(n_rows, d, 5, 1, d ** -0.5)
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    tp = ops.train_params(0, d, k, 1, flags=1 | flags)
+    otp = O.TrainParams(0, d, (d + 3) // 4 * 4, 1, k, 1, 0.01, 0.9, 6.0, 1, d ** -0.5)
+    ops.step(karate, tp, torch.from_numpy(pairs.view(np.int32)).cuda(), 5, 0, 77, 0.05, c, x,
+             neg_override=torch.from_numpy(neg.view(np.int32)).cuda(), pair_mode=True)
+    torch.cuda.synchronize()
+    O.train_walks_ex(karate_oracle, otp, pairs, 5, 0, 77, 0.05, c_h, x_h, neg_override=neg,
+                     pair_mode=True)
+    assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+    assert np.abs(x_h - ops.init_table(n_rows, d, 5, 1, d ** -0.5).cpu().numpy()).max() > 1e-3
