@@ -11,7 +11,8 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libgn2v.so")
-_SOURCES = ["gn2v_api.hip", "rng.h", "walk_kernels.h", "train_kernels.h", "util_kernels.h"]
+_SOURCES = ["gn2v_api.hip", "rng.h", "walk_kernels.h", "train_kernels.h", "util_kernels.h",
+            "edge_kernels.h"]
 _HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v.h")
 
 SENTINEL = 0xFFFFFFFF
@@ -31,7 +32,8 @@ EXPORTS = [
     "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
     "gn2v_graph_destroy", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_walk_pairs",
     "gn2v_init_table",
-    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_touch_rows",
+    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_edge_embedding",
+    "gn2v_touch_rows",
     "gn2v_stats_reset",
     "gn2v_stats_read",
 ]
@@ -160,6 +162,7 @@ def lib():
                             u64, f32, vp]
     L.gn2v_train.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64, vp, vp,
                              C.POINTER(Stats), vp]
+    L.gn2v_edge_embedding.argtypes = [vp, vp, u32, u32, vp, vp, u64, u32, vp, u32, vp]
     L.gn2v_touch_rows.argtypes = [vp, u32, vp, u64, u32, vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]
     L.gn2v_stats_read.argtypes = [vp, C.POINTER(Stats), vp]

@@ -12,6 +12,7 @@
 
 #include "../../include/gn2v.h"
 #include "rng.h"
+#include "edge_kernels.h"
 #include "train_kernels.h"
 #include "util_kernels.h"
 #include "walk_kernels.h"
@@ -440,6 +441,39 @@ int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d
                    const uint32_t *d_neg_override, void *stream) {
     return simple_step(g, true, tp, d_walks, n_walks, walk_length, seed, epoch, first_walk, lr,
                        d_central, d_contextual, d_neg_override, stream);
+}
+
+int gn2v_edge_embedding(const float *d_src_table, const float *d_dst_table, uint32_t d, uint32_t ld,
+                        const uint32_t *d_src_ids, const uint32_t *d_dst_ids, uint64_t n_edges,
+                        uint32_t method, float *d_out, uint32_t out_ld, void *stream) {
+    if (d == 0 || ld < d || (ld & 3) || ld > 512) return fail("need 0 < d <= ld <= 512, ld % 4 == 0");
+    if (method >= gn2v::kEdgeMethodCount) return fail("unknown edge embedding method");
+    if (n_edges == 0) return 0;  // empty edge lists are legal (and carry NULL pointers)
+    if (!d_src_table || !d_dst_table || !d_src_ids || !d_dst_ids || !d_out)
+        return fail("NULL pointer");
+    const uint32_t need = method == gn2v::kConcatenate ? 2 * d
+                          : (method == gn2v::kL2Distance || method == gn2v::kCosineSimilarity) ? 1
+                                                                                               : d;
+    if (out_ld < need) return fail("out_ld is too small for this method");
+    if (n_edges == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_edges + 15) / 16, 256 * 16);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nchunks = ld / 4;
+#define GN2V_EDGE(CH)                                                                         \
+    hipLaunchKernelGGL((gn2v::edge_embedding_kernel<CH>), dim3(blocks), dim3(256), 0, s,       \
+                       d_src_table, d_dst_table, d, ld, d_src_ids, d_dst_ids, n_edges, method, \
+                       d_out, out_ld)
+    if (nchunks <= 16)
+        GN2V_EDGE(1);
+    else if (nchunks <= 32)
+        GN2V_EDGE(2);
+    else if (nchunks <= 64)
+        GN2V_EDGE(4);
+    else
+        GN2V_EDGE(8);
+#undef GN2V_EDGE
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 static bool nchunks_is_32(uint32_t ld) { return ld / 4 > 16 && ld / 4 <= 32; }

@@ -178,6 +178,16 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
                uint64_t seed, uint64_t max_walks_per_epoch, float *d_central,
                float *d_contextual, gn2v_stats *stats, void *stream);
 
+/* Edge embeddings fused with the row gather: out[e] = op(src_table[src_ids[e]], dst_table[dst_ids[e]]).
+ * Device form of the operators of embiggen/embedding_transformers/edge_transformer.py:12-343;
+ * method ids follow the reference's method table (:348-361):
+ * 0 Hadamard, 1 Sum, 2 Average, 3 L1, 4 AbsoluteL1, 5 SquaredL2, 6 L2, 7 Concatenate, 8 Min,
+ * 9 Max, 10 L2Distance, 11 CosineSimilarity.  out is f32[n_edges][out_ld] with d columns written
+ * (2d for Concatenate, 1 for L2Distance / CosineSimilarity). */
+int gn2v_edge_embedding(const float *d_src_table, const float *d_dst_table, uint32_t d, uint32_t ld,
+                        const uint32_t *d_src_ids, const uint32_t *d_dst_ids, uint64_t n_edges,
+                        uint32_t method, float *d_out, uint32_t out_ld, void *stream);
+
 /* Traffic-calibration utility: table[ids[i]][:] += 1 for i < n with the access shape and store
  * flavour (flags: GN2V_TRAIN_ATOMIC / _WRITE_BACK / _WRITE_THROUGH, default write-through) of the
  * training kernels.  With distinct ids the HBM bytes of the launch are exactly n * ld * 8 + n * 4,

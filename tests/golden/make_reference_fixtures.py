@@ -108,7 +108,54 @@ def api_defaults():
     return out
 
 
+def edge_embedding_cases():
+    """Outputs of the reference's own edge operators on seeded inputs.  The module imports
+    `ensmallen` and `userinput` at the top although the operators are plain numpy, so those two
+    imports (and the sibling NodeTransformer import) are satisfied with empty placeholder modules
+    for the duration of this call; no reference function that is executed touches them."""
+    import types
+
+    import numpy as np
+
+    placeholders = {}
+    for name in ("ensmallen", "ensmallen.express_measures", "userinput", "userinput.utils",
+                 "embiggen", "embiggen.embedding_transformers",
+                 "embiggen.embedding_transformers.node_transformer"):
+        if name not in sys.modules:
+            placeholders[name] = sys.modules[name] = types.ModuleType(name)
+    sys.modules["ensmallen"].express_measures = sys.modules["ensmallen.express_measures"]
+    sys.modules["userinput.utils"].must_be_in_set = lambda *a, **k: a[0]
+    sys.modules["embiggen.embedding_transformers.node_transformer"].NodeTransformer = object
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "ref_edge_transformer",
+            os.path.join(REF, "embiggen/embedding_transformers/edge_transformer.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        methods = dict(mod.EdgeTransformer.methods)
+    finally:
+        for name in placeholders:
+            del sys.modules[name]
+    rng = np.random.RandomState(7)
+    out = {}
+    for d in (5, 8, 100, 128):
+        table = rng.normal(size=(40, d)).astype(np.float32)
+        table[3] = 0.0  # zero rows exercise the cosine epsilon clamp
+        table[4] = 1e-5
+        src = rng.randint(0, 40, size=64).astype(np.int64)
+        dst = rng.randint(0, 40, size=64).astype(np.int64)
+        src[:4], dst[:4] = [3, 3, 4, 7], [3, 9, 4, 7]
+        out[f"table_{d}"], out[f"src_{d}"], out[f"dst_{d}"] = table, src, dst
+        for name, fn in methods.items():
+            out[f"{name}_{d}"] = fn(table[src], table[dst])
+    out["method_names"] = np.array(list(methods))
+    return out
+
+
 if __name__ == "__main__":
+    import numpy as np
+
+    np.savez_compressed(os.path.join(HERE, "edge_embedding_cases.npz"), **edge_embedding_cases())
     with open(os.path.join(HERE, "embedding_result_cases.json"), "w") as f:
         json.dump(embedding_result_cases(), f, indent=1, sort_keys=True)
     with open(os.path.join(HERE, "api_defaults.json"), "w") as f:
