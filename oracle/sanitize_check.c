@@ -1,0 +1,86 @@
+/* Drives every oracle entry point on a small synthetic graph; built with
+ * -fsanitize=address,undefined by `make sanitize` (GPU sanitizers are unavailable on the pool, so
+ * memory-safety checking happens on this CPU restatement).  TEST INFRASTRUCTURE ONLY. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gn2v_oracle.c"
+
+int main(void) {
+    /* ring of 6 cliques of 5 nodes, plus one isolated node and one directed trap */
+    enum { NC = 6, CS = 5, N = NC * CS + 2 };
+    uint32_t adj[N][N];
+    memset(adj, 0, sizeof(adj));
+    for (int c = 0; c < NC; ++c) {
+        for (int i = 0; i < CS; ++i)
+            for (int j = 0; j < CS; ++j)
+                if (i != j) adj[c * CS + i][c * CS + j] = 1;
+        int a = c * CS, b = ((c + 1) % NC) * CS + 1;
+        adj[a][b] = adj[b][a] = 1;
+    }
+    adj[0][N - 1] = 1; /* N-1 is a trap (no out edges); N-2 is isolated */
+    uint64_t row_ptr[N + 1];
+    uint32_t col[N * N];
+    float cumw[N * N];
+    uint32_t sources[N];
+    uint64_t e = 0, ns = 0;
+    for (int u = 0; u < N; ++u) {
+        row_ptr[u] = e;
+        float acc = 0.f;
+        for (int v = 0; v < N; ++v)
+            if (adj[u][v]) {
+                col[e] = (uint32_t)v;
+                acc += 1.0f + (float)((u + v) % 3);
+                cumw[e++] = acc;
+            }
+        if (e > row_ptr[u]) sources[ns++] = (uint32_t)u;
+    }
+    row_ptr[N] = e;
+    o_graph g = {N, e, row_ptr, col, NULL};
+    o_graph gw = {N, e, row_ptr, col, cumw};
+
+    const float weights[4][2] = {{1.f, 1.f}, {0.25f, 4.f}, {2.f, 0.5f}, {1.f, 1e-4f}};
+    uint32_t *walks = malloc(sizeof(uint32_t) * ns * 3 * 20);
+    for (int w = 0; w < 4; ++w) {
+        o_walk_params wp = {20, 3, weights[w][0], weights[w][1], 100, 0};
+        o_walks(&g, &wp, sources, ns, 7, w, 0, ns * 3, walks);
+        o_walks(&gw, &wp, sources, ns, 7, w, 0, ns * 3, walks);
+    }
+    int32_t *ctx = malloc(sizeof(int32_t) * ns * 3 * 20 * 6), *words = malloc(sizeof(int32_t) * ns * 3 * 20);
+    o_window_batch(walks, ns * 3, 20, 3, ctx, words);
+    uint32_t *pairs = malloc(sizeof(uint32_t) * ns * 3 * 20 * 6 * 2);
+    uint64_t np = o_walk_pairs(walks, ns * 3, 20, 3, 1, pairs);
+
+    float *c = malloc(sizeof(float) * N * 12), *x = malloc(sizeof(float) * N * 12);
+    for (uint32_t model = 0; model < 2; ++model)
+        for (uint32_t flags = 0; flags < 8; ++flags)
+            for (uint32_t md = 1; md <= 3; md += 2) {
+                o_walk_params wp = {20, 2, 0.5f, 2.0f, 100, 0};
+                o_train_params tp = {model, 10, 12, 2, 4, 3, 0.02f, 0.9f, 6.0f, flags, 0.3f, md};
+                o_fit(&g, &wp, &tp, sources, ns, 11, c, x, flags & 1 ? 2 : 1);
+            }
+    /* pair mode through the general step with a pool and row indirection */
+    o_train_params tp = {0, 10, 12, 1, 4, 1, 0.02f, 0.9f, 6.0f, 1, 0.3f, 1};
+    uint32_t *rows = malloc(sizeof(uint32_t) * np * 2);
+    for (uint64_t i = 0; i < np * 2; ++i) rows[i] = pairs[i];
+    o_step_io io;
+    memset(&io, 0, sizeof(io));
+    io.walks = pairs;
+    io.walk_rows = rows;
+    io.central = c;
+    io.contextual = x;
+    io.neg_pool = col;
+    io.neg_pool_size = e;
+    io.neg_id_mul = 1;
+    io.pair_mode = 1;
+    o_train_walks_ex(&g, &tp, &io, np, 2, 3, 0, 0, 0.02f, 1);
+
+    uint32_t *bs = malloc(sizeof(uint32_t) * 999 * 4), *bd = malloc(sizeof(uint32_t) * 999 * 4);
+    o_ba_edges(1000, 4, 42, bs, bd);
+    double acc = 0;
+    for (int i = 0; i < N * 12; ++i) acc += c[i] + x[i];
+    printf("ok %llu pairs, checksum %.6f\n", (unsigned long long)np, acc);
+    free(walks); free(ctx); free(words); free(pairs); free(c); free(x); free(rows); free(bs); free(bd);
+    return 0;
+}

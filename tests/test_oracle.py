@@ -268,3 +268,15 @@ def test_self_golden(karate_oracle):
         assert np.allclose(x, gold[f"{key}_contextual"], atol=1e-6)
     s, d = O.ba_edges(500, 3, 42)
     assert np.array_equal(d, gold["ba_dst"])
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers():
+    """GPU sanitizers are not available on the pool; the CPU restatement of every entry point
+    (walks incl. weighted / traps / fallback, window, pairs, SkipGram / CBOW fits with all flag
+    combinations, pair mode with pools) runs under ASan + UBSan instead."""
+    import subprocess
+
+    root = os.path.join(os.path.dirname(GOLDEN), "..", "oracle")
+    res = subprocess.run(["make", "-C", root, "sanitize"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "ok " in res.stdout
