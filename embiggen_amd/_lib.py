@@ -24,6 +24,8 @@ TRAIN_DETERMINISTIC = 8
 TRAIN_ATOMIC = 16
 TRAIN_WRITE_BACK = 32
 TRAIN_WRITE_THROUGH = 64
+TRAIN_NO_CTX_CACHE = 128
+TRAIN_CTX_CACHE_ALL = 256
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 

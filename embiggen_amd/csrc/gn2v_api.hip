@@ -226,11 +226,50 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kTrainBlock);
 
+    // context cache (store modes, walk-ordered SkipGram on whole tables only)
+    const uint32_t slots = 2 * tp->window + 1;
+    const size_t cache_words =
+        ((size_t)slots * tp->ld + L + 2 * (size_t)a.max_samples + 2 * slots + 3) & ~(size_t)3;
+    const size_t cache_lds = (size_t)waves_per_block * cache_words * 4;
+    const bool use_cache = !cbow && !det && wm != gn2v::kAtomic && !a.pair_mode && !a.split &&
+                           !a.walk_rows && !a.neg_pool && !(tp->flags & GN2V_TRAIN_NO_CTX_CACHE) &&
+                           cache_lds <= 40 * 1024 && L > 2 * tp->window;
+    if (use_cache) {
+        if (tp->flags & GN2V_TRAIN_CTX_CACHE_ALL) {
+            a.cache_max_degree = 0xFFFFFFFFu;
+        } else {
+            // a row is cached by ~(resident waves x window) positions at a time; keep the expected
+            // number of waves holding the same row at once below 0.1
+            const double holders = (double)g->n_cus * 24.0 * slots;
+            const double limit = 0.1 * (double)g->view.n_edges / holders;
+            a.cache_max_degree = limit < 1.0 ? 1u : (limit > 4e9 ? 0xFFFFFFFEu : (uint32_t)limit);
+        }
+    }
+
     EventPair ev;
     if (get_events(g, &ev)) return 1;
     HIP_TRY(hipEventRecord(ev.a, s));
     const uint32_t nchunks = tp->ld / 4;
-    if (nchunks <= 16)
+    if (use_cache) {
+#define GN2V_CACHED(CH)                                                                        \
+    do {                                                                                       \
+        if (wm == gn2v::kWriteBack)                                                            \
+            hipLaunchKernelGGL((gn2v::sgns_cached_kernel<CH, gn2v::kWriteBack>), grid, block,  \
+                               cache_lds, s, a);                                               \
+        else                                                                                   \
+            hipLaunchKernelGGL((gn2v::sgns_cached_kernel<CH, gn2v::kWriteThrough>), grid,      \
+                               block, cache_lds, s, a);                                        \
+    } while (0)
+        if (nchunks <= 16)
+            GN2V_CACHED(1);
+        else if (nchunks <= 32)
+            GN2V_CACHED(2);
+        else if (nchunks <= 64)
+            GN2V_CACHED(4);
+        else
+            GN2V_CACHED(8);
+#undef GN2V_CACHED
+    } else if (nchunks <= 16)
         launch_train_ch<1>(cbow, wm, det, grid, block, lds, s, a);
     else if (nchunks <= 32)
         launch_train_ch<2>(cbow, wm, det, grid, block, lds, s, a);

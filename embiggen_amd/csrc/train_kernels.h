@@ -36,6 +36,8 @@ struct TrainArgs {
     uint32_t neg_id_mul, neg_id_add;  // global id of negative row r = r * mul + add (skip rule)
     uint32_t split;             // 1 when `negative` is a different table than the positive one
     uint32_t pair_mode;         // walks are (centre, context) records: only position 0 is a centre
+    uint32_t cache_max_degree;  // context cache: rows of nodes with degree >= this stay in HBM
+                                // (0xFFFFFFFF = cache every row)
     unsigned long long *counters;  // [0] pairs, [1] walk steps, [2] centres
     uint64_t n_walks;
     uint64_t first_walk;
@@ -436,6 +438,224 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
     }
     // one atomic per wave: a per-walk atomic on a single counter serialises at ~12 ns each and
     // dominated the pair-list mode (328 M one-pair "walks" -> 7.9 s of counter traffic)
+    if (a.counters && lane == 0 && pairs) {
+        atomicAdd(&a.counters[0], pairs);
+        atomicAdd(&a.counters[2], centres);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Walk-ordered SkipGram with a per-wave LDS cache of the window's contextual rows.
+//
+// In the plain kernel the contextual row of walk position j is read and written once for each of
+// the <= 2w centres that see it as a context: 1 of the 11.1 rows a pair moves.  Here every wave
+// keeps the rows of positions [i-w, i+w] in LDS (2w+1 slots of ld floats, a small directory keyed
+// by row id with reference counts for nodes the walk revisits): a row enters when the window
+// reaches it (one HBM read), every positive AND every negative sample that names it is served from
+// LDS (so the wave stays sequentially consistent with the oracle: one live copy per row), and it
+// is written back once when the window leaves it.  Saves ~0.9 row read + write per pair (-7.7 %
+// HBM traffic).  Rows of high-degree nodes are not cached (cache_max_degree): many waves would hold
+// private copies of a hub row at once and the write-back of one would discard the others' updates.
+// Store modes only (atomic mode keeps the plain kernel: a cached row would need a delta).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kCacheBit = 0x40000000u;  // staged row id = kCacheBit | LDS slot
+
+struct CtxCache {
+    float *rows;       // [slots][ld]
+    uint32_t *node;    // [slots] row id held by the slot
+    uint32_t *ref;     // [slots] number of window positions naming it (0 = free)
+    uint32_t slots, ld;
+
+    __device__ __forceinline__ int find(uint32_t v) const {
+        int hit = -1;
+        for (uint32_t s = 0; s < slots; ++s)
+            if (ref[s] != 0 && node[s] == v) hit = (int)s;
+        return hit;
+    }
+};
+
+template <int WM>
+__device__ __forceinline__ void cache_insert(const TrainArgs &a, CtxCache &c, float *table,
+                                             uint32_t v, int lane) {
+    const int hit = c.find(v);
+    wave_sync();
+    if (hit >= 0) {
+        if (lane == 0) c.ref[hit] += 1;
+        wave_sync();
+        return;
+    }
+    if (a.cache_max_degree != 0xFFFFFFFFu) {
+        const uint64_t deg = a.g.row_ptr[v + 1] - a.g.row_ptr[v];
+        if (deg >= a.cache_max_degree) return;
+    }
+    int free_slot = -1;
+    for (uint32_t s = 0; s < c.slots; ++s)
+        if (c.ref[s] == 0 && free_slot < 0) free_slot = (int)s;
+    if (free_slot < 0) return;  // cannot happen: slots >= window positions
+    const float *src = table + (uint64_t)v * c.ld;
+    float *dst = c.rows + (uint32_t)free_slot * c.ld;
+    for (uint32_t ci = lane; ci < (c.ld >> 2); ci += 64)
+        *reinterpret_cast<float4 *>(dst + ci * 4) = *reinterpret_cast<const float4 *>(src + ci * 4);
+    if (lane == 0) {
+        c.node[free_slot] = v;
+        c.ref[free_slot] = 1;
+    }
+    wave_sync();
+}
+
+template <int WM>
+__device__ __forceinline__ void cache_write_back(CtxCache &c, float *table, uint32_t slot,
+                                                 int lane) {
+    float *dst = table + (uint64_t)c.node[slot] * c.ld;
+    const float *src = c.rows + slot * c.ld;
+    for (uint32_t ci = lane; ci < (c.ld >> 2); ci += 64) {
+        const float4 x = *reinterpret_cast<const float4 *>(src + ci * 4);
+        if constexpr (WM == kWriteThrough)
+            store_sc1(dst + ci * 4, x);
+        else
+            *reinterpret_cast<float4 *>(dst + ci * 4) = x;
+    }
+}
+
+template <int WM>
+__device__ __forceinline__ void cache_retire(CtxCache &c, float *table, uint32_t v, int lane) {
+    const int hit = c.find(v);
+    wave_sync();
+    if (hit < 0) return;
+    if (c.ref[hit] == 1) cache_write_back<WM>(c, table, (uint32_t)hit, lane);
+    wave_sync();
+    if (lane == 0) c.ref[hit] -= 1;
+    wave_sync();
+}
+
+template <int CH, int WM>
+__global__ __launch_bounds__(kTrainBlock) void sgns_cached_kernel(TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint32_t w = a.window, k = a.k;
+    const uint32_t slots = 2 * w + 1;
+    const uint32_t per_wave = (slots * a.ld + a.L + 2 * a.max_samples + 2 * slots + 3) & ~3u;
+    uint32_t *base_w = smem + wave * per_wave;
+    CtxCache cache;
+    cache.rows = reinterpret_cast<float *>(base_w);
+    uint32_t *s_walk = base_w + slots * a.ld;
+    uint32_t *s_rows = s_walk + a.L;
+    float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
+    cache.node = s_rows + 2 * a.max_samples;
+    cache.ref = cache.node + slots;
+    cache.slots = slots;
+    cache.ld = a.ld;
+    const uint32_t nchunks = a.ld >> 2;
+    const uint64_t per_walk_neg = (uint64_t)a.L * 2 * w * k;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
+    unsigned long long pairs = 0, centres = 0;
+
+    for (uint64_t b = (uint64_t)blockIdx.x * waves_per_block + wave; b < a.n_walks;
+         b += wave_stride) {
+        const uint32_t Le = stage_walk(a, b, s_walk, s_walk, lane);
+        const uint64_t wkey = draw(a.ekey, a.first_walk + b);
+        const uint64_t nkey = wkey ^ kTagNeg;
+        const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
+        if ((uint32_t)lane < slots) cache.ref[lane] = 0;
+        wave_sync();
+        for (uint32_t p = 0; p < Le && p <= w; ++p) cache_insert<WM>(a, cache, a.contextual, s_walk[p], lane);
+
+        for (uint32_t i = 0; i < Le; ++i) {
+            // slide the window: position i-w-1 leaves, position i+w enters
+            if (i >= w + 1) cache_retire<WM>(cache, a.contextual, s_walk[i - w - 1], lane);
+            if (i >= 1 && i + w < Le) cache_insert<WM>(a, cache, a.contextual, s_walk[i + w], lane);
+
+            const uint32_t c = s_walk[i];
+            if (!keep_centre(a, wkey, i, c)) continue;
+            const float lrc = centre_lr(a, c);
+            const Window win(i, Le, w, a.min_dist);
+            const uint32_t n_ctx = win.n_ctx;
+            const uint32_t n_samples = n_ctx * (k + 1);
+            if (n_ctx == 0) continue;
+
+            wave_sync();
+            for (uint32_t t = lane; t < n_samples; t += 64) {
+                const uint32_t rank = t / (k + 1);
+                const uint32_t s = t - rank * (k + 1);
+                const uint32_t j = win.position(rank);
+                const uint32_t slot = j < i ? (j + w - i) : (j + w - i - 1);
+                const uint32_t ctx = s_walk[j];
+                uint32_t row = ctx;
+                float lab = 1.f;
+                if (s != 0) {
+                    const uint64_t qi = ((uint64_t)i * 2 * w + slot) * k + (s - 1);
+                    row = ov ? ov[qi] : draw_negative(a, nkey, qi);
+                    lab = 0.f;
+                    if (row == c || row == ctx) row = kSentinel;
+                }
+                if (row != kSentinel) {
+                    const int hit = cache.find(row);
+                    if (hit >= 0) row = kCacheBit | (uint32_t)hit;
+                }
+                s_rows[t] = row;
+                s_lab[t] = lab;
+            }
+            wave_sync();
+
+            float *crow = a.central + (uint64_t)c * a.ld;
+            Row<CH> u, g;
+            load_row<CH>(u, crow, q, nchunks, true);
+            zero_row<CH>(g);
+            for (uint32_t t0 = 0; t0 < n_samples; t0 += 4) {
+                const uint32_t t = t0 + grp;
+                const RoundIds ids(s_rows, t0, n_samples);
+                const uint32_t row = ids.row_of(grp);
+                const float lab = t < n_samples ? s_lab[t] : 0.f;
+                const bool valid = row != kSentinel;
+                const bool cached = valid && (row & kCacheBit);
+                const int my_pass = ids.pass_of(grp);
+                float *gbase = a.contextual + (uint64_t)((valid && !cached) ? row : 0) * a.ld;
+                float *lbase = cache.rows + (cached ? (row & 0xFFFFu) : 0u) * a.ld;
+                for (int pass = 0; pass <= ids.last_pass; ++pass) {
+                    const bool mine = valid && my_pass == pass;
+                    Row<CH> v;
+                    load_row<CH>(v, gbase, q, nchunks, mine && !cached);
+                    if (mine && cached) {
+#pragma unroll
+                        for (int cc = 0; cc < CH; ++cc) {
+                            const uint32_t ci = cc * 16 + q;
+                            if (ci < nchunks) v.c[cc] = *reinterpret_cast<const float4 *>(lbase + ci * 4);
+                        }
+                    }
+                    const float dot = dot_rows<CH>(u, v);
+                    const float var = mine ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+                    axpy<CH>(g, var, v);
+                    if (mine && !cached) scatter_add<CH, WM>(gbase, q, nchunks, var, u, v);
+                    if (mine && cached) {
+#pragma unroll
+                        for (int cc = 0; cc < CH; ++cc) {
+                            const uint32_t ci = cc * 16 + q;
+                            if (ci < nchunks) {
+                                float4 o = v.c[cc];
+                                o.x += var * u.c[cc].x;
+                                o.y += var * u.c[cc].y;
+                                o.z += var * u.c[cc].z;
+                                o.w += var * u.c[cc].w;
+                                *reinterpret_cast<float4 *>(lbase + ci * 4) = o;
+                            }
+                        }
+                    }
+                }
+            }
+            reduce_groups<CH>(g);
+            // the centre's own contextual row may sit in the cache, but its CENTRAL row never does
+            if (grp == 0) scatter_add<CH, WM>(crow, q, nchunks, 1.0f, g, u);
+            pairs += n_ctx;
+            ++centres;
+        }
+        // the walk is over: write the remaining window back
+        wave_sync();
+        for (uint32_t s = 0; s < slots; ++s)
+            if (cache.ref[s] != 0) cache_write_back<WM>(cache, a.contextual, s, lane);
+        wave_sync();
+    }
     if (a.counters && lane == 0 && pairs) {
         atomicAdd(&a.counters[0], pairs);
         atomicAdd(&a.counters[2], centres);

@@ -47,6 +47,11 @@ extern "C" {
 #define GN2V_TRAIN_ATOMIC 16u        /* hardware f32 atomics on every element: no lost update   */
 #define GN2V_TRAIN_WRITE_BACK 32u    /* read-modify-write, plain L2 write-back stores            */
 #define GN2V_TRAIN_WRITE_THROUGH 64u /* read-modify-write, 16 B write-through (sc1) stores       */
+/* Walk-ordered SkipGram in the store modes keeps the window's contextual rows in LDS (one HBM
+ * read + one write-back per walk position instead of one per pair); rows of high-degree nodes are
+ * left in HBM.  Switches: */
+#define GN2V_TRAIN_NO_CTX_CACHE 128u  /* always use the plain kernel                             */
+#define GN2V_TRAIN_CTX_CACHE_ALL 256u /* cache every row regardless of degree (tests)            */
 
 #define GN2V_MODEL_SKIPGRAM 0u
 #define GN2V_MODEL_CBOW 1u

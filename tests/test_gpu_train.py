@@ -17,8 +17,14 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 DET = _lib.TRAIN_DETERMINISTIC
-MODES = {"write_through": _lib.TRAIN_WRITE_THROUGH, "write_back": _lib.TRAIN_WRITE_BACK,
-         "atomic": _lib.TRAIN_ATOMIC}
+MODES = {
+    "write_through": _lib.TRAIN_WRITE_THROUGH,  # cached kernel, degree rule (caches nothing here)
+    "write_through_cache_all": _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_ALL,
+    "write_through_plain": _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_NO_CTX_CACHE,
+    "write_back_cache_all": _lib.TRAIN_WRITE_BACK | _lib.TRAIN_CTX_CACHE_ALL,
+    "write_back": _lib.TRAIN_WRITE_BACK | _lib.TRAIN_NO_CTX_CACHE,
+    "atomic": _lib.TRAIN_ATOMIC,
+}
 
 
 def _tables(n, d, seed, scale=None):
@@ -290,6 +296,7 @@ def test_min_distance_windows_match_oracle(karate, karate_oracle, model, window,
     otp = O.TrainParams(model, d, d, 1, k, window, 0.01, 0.9, 6.0, 1, d ** -0.5, min_dist)
     step = ops.sgns_step if model == 0 else ops.cbow_step
     for flags, per_walk in ((1 | DET, False), (1 | _lib.TRAIN_WRITE_THROUGH, True),
+                            (1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_ALL, True),
                             (1 | _lib.TRAIN_ATOMIC, True)):
         c, x = _tables(34, d, 6)
         c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
@@ -373,3 +380,49 @@ def test_general_step_with_row_caches_and_negative_pool(karate, karate_oracle, m
     for t, h in zip(tabs, host):
         assert np.abs(t.cpu().numpy() - h).max() < 1e-5
     assert np.abs(host[2] - ops.init_table(n_shard, d, 9, 2, d ** -0.5).cpu().numpy()).max() > 1e-4
+
+
+@pytest.mark.parametrize("rw,ew", [(4.0, 0.25), (0.25, 4.0)])
+@pytest.mark.parametrize("d", [8, 100, 128])
+def test_context_cache_is_sequentially_exact_on_real_walks(karate, karate_oracle, rw, ew, d):
+    """The LDS context cache with every row cached: return-heavy Karate walks revisit nodes inside
+    the window (reference counts), negatives hit cached nodes (served from LDS), windows slide and
+    write back.  One walk per launch must equal the sequential oracle; so must a following
+    uncached launch that re-reads everything from HBM (write-back happened)."""
+    k, w, L = 6, 4, 40
+    ld = (d + 3) // 4 * 4
+    wk = ops.walks(karate, ops.walk_params(L, 1, rw, ew), 3, 0, 0, 34)
+    wk_h = wk.cpu().numpy().view(np.uint32)
+    c, x = _tables(34, d, 3)
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    cached = ops.train_params(0, d, k, w, flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_ALL)
+    plain = ops.train_params(0, d, k, w, flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_NO_CTX_CACHE)
+    otp = O.TrainParams(0, d, ld, 1, k, w, 0.01, 0.9, 6.0, 1, d ** -0.5)
+    for b in range(34):
+        tp = cached if b % 3 else plain
+        ops.sgns_step(karate, tp, wk[b:b + 1].contiguous(), 3, 0, b, 0.05, c, x)
+    torch.cuda.synchronize()
+    O.train_walks(karate_oracle, otp, wk_h, 3, 0, 0, 0.05, c_h, x_h)
+    assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+
+
+def test_context_cache_degree_rule_and_short_walks(karate, karate_oracle):
+    """Walks shorter than the window, walks cut by sentinels, and the default degree rule."""
+    d, k, w = 16, 3, 5
+    otp = O.TrainParams(0, d, d, 1, k, w, 0.01, 0.9, 6.0, 1, d ** -0.5)
+    flags = 1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_ALL
+    for L in (12, 16, 30):  # L > 2w required for the cached kernel, else the plain one runs
+        wk = ops.walks(karate, ops.walk_params(L, 1, 1.0, 1.0), 8, 0, 0, 34)
+        cut = wk.clone()
+        cut[::2, L // 2:] = -1
+        for walks in (wk, cut):
+            c, x = _tables(34, d, 8)
+            c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+            tp = ops.train_params(0, d, k, w, flags=flags)
+            for b in range(34):
+                ops.sgns_step(karate, tp, walks[b:b + 1].contiguous(), 8, 0, b, 0.05, c, x)
+            torch.cuda.synchronize()
+            O.train_walks(karate_oracle, otp, walks.cpu().numpy().view(np.uint32), 8, 0, 0, 0.05,
+                          c_h, x_h)
+            assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5
+            assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
