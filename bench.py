@@ -299,7 +299,9 @@ def main():
             "argv": sys.argv[1:],
             "roofline": {
                 "bound": "hbm",
-                "kernel": "gn2v::sgns_kernel",
+                "kernel": ("gn2v::sgns_cached_kernel" if mode == "single" and n >= (1 << 20)
+                           and args.mode in ("auto", "write_through", "write_back")
+                           else "gn2v::sgns_kernel"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

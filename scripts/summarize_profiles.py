@@ -53,14 +53,14 @@ def main(tag):
         for r in stats[:12]:
             w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                         r["Percentage"], r["MinNs"], r["MaxNs"]])
-    sg = next(r for r in stats if "sgns_kernel" in r["Name"])
+    sg = next(r for r in stats if "sgns_" in r["Name"])
     wk = next(r for r in stats if "walk_kernel" in r["Name"])
     avg_ms = float(sg["AverageNs"]) / 1e6
 
     fetch = per_kernel_counter(one(f"{src}/fetch/**/*counter_collection.csv"), "FETCH_SIZE")
     write = per_kernel_counter(one(f"{src}/write/**/*counter_collection.csv"), "WRITE_SIZE")
-    _, f_vals = pick(fetch, "sgns_kernel")
-    _, w_vals = pick(write, "sgns_kernel")
+    _, f_vals = pick(fetch, "sgns_")
+    _, w_vals = pick(write, "sgns_")
     cal_f = per_kernel_counter(one(f"{src}/cal_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
     cal_w = per_kernel_counter(one(f"{src}/cal_write/**/*counter_collection.csv"), "WRITE_SIZE")
     _, cf = pick(cal_f, "touch_rows_kernel")
@@ -112,7 +112,7 @@ def main(tag):
         f.write("| kernel | calls | avg ms | % of GPU time |\n|---|---|---|---|\n")
         for r in stats[:6]:
             f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {r['Percentage']} |\n")
-        f.write(f"\n`sgns_kernel`: {pairs_per_launch:.0f} pairs per launch, {avg_ms:.2f} ms (rocprof) vs "
+        f.write(f"\n`{sg['Name'].split('(')[0].replace('void ', '')}`: {pairs_per_launch:.0f} pairs per launch, {avg_ms:.2f} ms (rocprof) vs "
                 f"{bench['roofline']['avg_launch_ms']:.2f} ms (HIP events in bench.py) -> "
                 f"{out['algorithmic_GBps']:.0f} GB/s algorithmic = {out['frac_of_8TBps']:.3f} of 8 TB/s.\n\n")
         f.write(f"PMC (separate passes): FETCH_SIZE {mean(f_vals):.0f} KiB, WRITE_SIZE {mean(w_vals):.0f} KiB per launch; "
