@@ -228,10 +228,11 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
 
     // context cache (store modes, walk-ordered SkipGram on whole tables only)
     const uint32_t slots = 2 * tp->window + 1;
-    const size_t cache_words =
-        ((size_t)slots * tp->ld + L + 2 * (size_t)a.max_samples + 2 * slots + 3) & ~(size_t)3;
+    const size_t cache_words = ((size_t)slots * tp->ld + L + 2 * (size_t)a.max_samples +
+                                (cbow ? 2 * tp->window : 0) + 2 * slots + 3) &
+                               ~(size_t)3;
     const size_t cache_lds = (size_t)waves_per_block * cache_words * 4;
-    const bool use_cache = !cbow && !det && wm != gn2v::kAtomic && !a.pair_mode && !a.split &&
+    const bool use_cache = !det && wm != gn2v::kAtomic && !a.pair_mode && !a.split &&
                            !a.walk_rows && !a.neg_pool && !(tp->flags & GN2V_TRAIN_NO_CTX_CACHE) &&
                            cache_lds <= 40 * 1024 && L > 2 * tp->window;
     if (use_cache) {
@@ -253,7 +254,13 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     if (use_cache) {
 #define GN2V_CACHED(CH)                                                                        \
     do {                                                                                       \
-        if (wm == gn2v::kWriteBack)                                                            \
+        if (cbow && wm == gn2v::kWriteBack)                                                    \
+            hipLaunchKernelGGL((gn2v::cbow_cached_kernel<CH, gn2v::kWriteBack>), grid, block,  \
+                               cache_lds, s, a);                                               \
+        else if (cbow)                                                                         \
+            hipLaunchKernelGGL((gn2v::cbow_cached_kernel<CH, gn2v::kWriteThrough>), grid,      \
+                               block, cache_lds, s, a);                                        \
+        else if (wm == gn2v::kWriteBack)                                                       \
             hipLaunchKernelGGL((gn2v::sgns_cached_kernel<CH, gn2v::kWriteBack>), grid, block,  \
                                cache_lds, s, a);                                               \
         else                                                                                   \

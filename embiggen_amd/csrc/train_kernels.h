@@ -793,6 +793,157 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
     }
 }
 
+// CBOW with the same LDS context cache: the window's contextual rows are what CBOW reads for the
+// mean AND read-modify-writes for the gradient (30 of the 52 row transfers of a centre); with the
+// cache they cost one read and one write-back per walk position.  Centre + negatives live in the
+// central table, which the cache never holds, so only the context list needs directory lookups.
+template <int CH, int WM>
+__global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint32_t w = a.window, k = a.k;
+    const uint32_t slots = 2 * w + 1;
+    const uint32_t per_wave =
+        (slots * a.ld + a.L + 2 * a.max_samples + 2 * w + 2 * slots + 3) & ~3u;
+    uint32_t *base_w = smem + wave * per_wave;
+    CtxCache cache;
+    cache.rows = reinterpret_cast<float *>(base_w);
+    uint32_t *s_walk = base_w + slots * a.ld;
+    uint32_t *s_rows = s_walk + a.L;
+    float *s_lab = reinterpret_cast<float *>(s_rows + a.max_samples);
+    uint32_t *s_ctx = s_rows + 2 * a.max_samples;
+    cache.node = s_ctx + 2 * w;
+    cache.ref = cache.node + slots;
+    cache.slots = slots;
+    cache.ld = a.ld;
+    const uint32_t nchunks = a.ld >> 2;
+    const uint64_t per_walk_neg = (uint64_t)a.L * k;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
+    unsigned long long pairs = 0, centres = 0;
+
+    for (uint64_t b = (uint64_t)blockIdx.x * waves_per_block + wave; b < a.n_walks;
+         b += wave_stride) {
+        const uint32_t Le = stage_walk(a, b, s_walk, s_walk, lane);
+        const uint64_t wkey = draw(a.ekey, a.first_walk + b);
+        const uint64_t nkey = wkey ^ kTagNeg;
+        const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
+        if ((uint32_t)lane < slots) cache.ref[lane] = 0;
+        wave_sync();
+        for (uint32_t p = 0; p < Le && p <= w; ++p)
+            cache_insert<WM>(a, cache, a.contextual, s_walk[p], lane);
+
+        for (uint32_t i = 0; i < Le; ++i) {
+            if (i >= w + 1) cache_retire<WM>(cache, a.contextual, s_walk[i - w - 1], lane);
+            if (i >= 1 && i + w < Le) cache_insert<WM>(a, cache, a.contextual, s_walk[i + w], lane);
+
+            const uint32_t c = s_walk[i];
+            if (!keep_centre(a, wkey, i, c)) continue;
+            const float lrc = centre_lr(a, c);
+            const Window win(i, Le, w, a.min_dist);
+            const uint32_t n_ctx = win.n_ctx;
+            if (n_ctx == 0) continue;
+            const float invC = 1.0f / (float)n_ctx;
+
+            wave_sync();
+            for (uint32_t t = lane; t <= k; t += 64) {
+                uint32_t row = c;
+                float lab = 1.f;
+                if (t != 0) {
+                    const uint64_t qi = (uint64_t)i * k + (t - 1);
+                    row = ov ? ov[qi] : draw_negative(a, nkey, qi);
+                    lab = 0.f;
+                    if (row == c) row = kSentinel;
+                }
+                s_rows[t] = row;
+                s_lab[t] = lab;
+            }
+            for (uint32_t t = lane; t < n_ctx; t += 64) {
+                uint32_t row = s_walk[win.position(t)];
+                const int hit = cache.find(row);
+                if (hit >= 0) row = kCacheBit | (uint32_t)hit;
+                s_ctx[t] = row;
+            }
+            wave_sync();
+
+            Row<CH> h, g;
+            zero_row<CH>(h);
+            zero_row<CH>(g);
+            for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
+                const uint32_t rank = r0 + grp;
+                const bool in = rank < n_ctx;
+                const uint32_t row = in ? s_ctx[rank] : 0u;
+                const bool cached = in && (row & kCacheBit);
+                Row<CH> v;
+                load_row<CH>(v, a.contextual + (uint64_t)(cached ? 0u : row) * a.ld, q, nchunks,
+                             in && !cached);
+                if (cached) {
+                    const float *lbase = cache.rows + (row & 0xFFFFu) * a.ld;
+#pragma unroll
+                    for (int cc = 0; cc < CH; ++cc) {
+                        const uint32_t ci = cc * 16 + q;
+                        if (ci < nchunks) v.c[cc] = *reinterpret_cast<const float4 *>(lbase + ci * 4);
+                    }
+                }
+                axpy<CH>(h, 1.0f, v);
+            }
+            reduce_groups<CH>(h);
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc) {
+                h.c[cc].x *= invC;
+                h.c[cc].y *= invC;
+                h.c[cc].z *= invC;
+                h.c[cc].w *= invC;
+            }
+
+            score_samples<CH, WM, false>(a, a.central, h, h, g, s_rows, s_lab, k + 1, lrc, grp, q);
+            reduce_groups<CH>(g);
+
+            for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
+                const RoundIds ids(s_ctx, r0, n_ctx);
+                const uint32_t row = ids.row_of(grp);
+                const bool valid = row != kSentinel;
+                const bool cached = valid && (row & kCacheBit);
+                const int my_pass = ids.pass_of(grp);
+                float *gbase = a.contextual + (uint64_t)((valid && !cached) ? row : 0) * a.ld;
+                float *lbase = cache.rows + (cached ? (row & 0xFFFFu) : 0u) * a.ld;
+                for (int pass = 0; pass <= ids.last_pass; ++pass) {
+                    const bool mine = valid && my_pass == pass;
+                    if (mine && cached) {
+#pragma unroll
+                        for (int cc = 0; cc < CH; ++cc) {
+                            const uint32_t ci = cc * 16 + q;
+                            if (ci < nchunks) {
+                                float4 o = *reinterpret_cast<const float4 *>(lbase + ci * 4);
+                                o.x += invC * g.c[cc].x;
+                                o.y += invC * g.c[cc].y;
+                                o.z += invC * g.c[cc].z;
+                                o.w += invC * g.c[cc].w;
+                                *reinterpret_cast<float4 *>(lbase + ci * 4) = o;
+                            }
+                        }
+                    } else {
+                        Row<CH> v;
+                        load_row<CH>(v, gbase, q, nchunks, mine);
+                        if (mine) scatter_add<CH, WM>(gbase, q, nchunks, invC, g, v);
+                    }
+                }
+            }
+            pairs += n_ctx;
+            ++centres;
+        }
+        wave_sync();
+        for (uint32_t s = 0; s < slots; ++s)
+            if (cache.ref[s] != 0) cache_write_back<WM>(cache, a.contextual, s, lane);
+        wave_sync();
+    }
+    if (a.counters && lane == 0 && pairs) {
+        atomicAdd(&a.counters[0], pairs);
+        atomicAdd(&a.counters[2], centres);
+    }
+}
+
 // Traffic calibration: every listed row is read and written exactly once with the same access
 // shape as the training kernels (16 lanes x float4 per row, same store flavour), so the HBM
 // bytes of a launch are known exactly (n * ld * 4 read + written, + 4 B of id per row).  Used to

@@ -382,9 +382,11 @@ def test_general_step_with_row_caches_and_negative_pool(karate, karate_oracle, m
     assert np.abs(host[2] - ops.init_table(n_shard, d, 9, 2, d ** -0.5).cpu().numpy()).max() > 1e-4
 
 
+@pytest.mark.parametrize("model", [0, 1])
 @pytest.mark.parametrize("rw,ew", [(4.0, 0.25), (0.25, 4.0)])
 @pytest.mark.parametrize("d", [8, 100, 128])
-def test_context_cache_is_sequentially_exact_on_real_walks(karate, karate_oracle, rw, ew, d):
+def test_context_cache_is_sequentially_exact_on_real_walks(karate, karate_oracle, rw, ew, d,
+                                                           model):
     """The LDS context cache with every row cached: return-heavy Karate walks revisit nodes inside
     the window (reference counts), negatives hit cached nodes (served from LDS), windows slide and
     write back.  One walk per launch must equal the sequential oracle; so must a following
@@ -395,12 +397,15 @@ def test_context_cache_is_sequentially_exact_on_real_walks(karate, karate_oracle
     wk_h = wk.cpu().numpy().view(np.uint32)
     c, x = _tables(34, d, 3)
     c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
-    cached = ops.train_params(0, d, k, w, flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_ALL)
-    plain = ops.train_params(0, d, k, w, flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_NO_CTX_CACHE)
-    otp = O.TrainParams(0, d, ld, 1, k, w, 0.01, 0.9, 6.0, 1, d ** -0.5)
+    cached = ops.train_params(model, d, k, w,
+                              flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_ALL)
+    plain = ops.train_params(model, d, k, w,
+                             flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_NO_CTX_CACHE)
+    otp = O.TrainParams(model, d, ld, 1, k, w, 0.01, 0.9, 6.0, 1, d ** -0.5)
+    step = ops.sgns_step if model == 0 else ops.cbow_step
     for b in range(34):
         tp = cached if b % 3 else plain
-        ops.sgns_step(karate, tp, wk[b:b + 1].contiguous(), 3, 0, b, 0.05, c, x)
+        step(karate, tp, wk[b:b + 1].contiguous(), 3, 0, b, 0.05, c, x)
     torch.cuda.synchronize()
     O.train_walks(karate_oracle, otp, wk_h, 3, 0, 0, 0.05, c_h, x_h)
     assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
