@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct gn2v_graph {
     std::vector<EventPair> train_events, walk_events, free_events;
     double train_ms = 0.0, walk_ms = 0.0;
     uint32_t train_launches = 0, walk_launches = 0;
+    std::mutex mu;  // guards the event / timing bookkeeping (launches themselves are stream ordered)
 };
 
 namespace {
@@ -116,6 +118,7 @@ int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint6
     const gn2v::WalkConsts c = walk_consts(wp);
     const uint64_t blocks = (n_walks + gn2v::kWalkBlock - 1) / gn2v::kWalkBlock;
     if (blocks > 0x7FFFFFFFULL) return fail("too many walks in one launch");
+    std::lock_guard<std::mutex> lock(g->mu);
     EventPair ev;
     if (get_events(g, &ev)) return 1;
     HIP_TRY(hipEventRecord(ev.a, s));
@@ -247,6 +250,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
         }
     }
 
+    std::lock_guard<std::mutex> lock(g->mu);
     EventPair ev;
     if (get_events(g, &ev)) return 1;
     HIP_TRY(hipEventRecord(ev.a, s));
@@ -422,10 +426,10 @@ int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_l
 
 int gn2v_walk_pairs(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
                     uint32_t window, uint32_t min_dist, uint32_t *d_pairs, void *stream) {
-    if (!d_walks || !d_pairs) return fail("NULL pointer");
     if (window < 1 || walk_length < 2) return fail("need window_size >= 1 and walk_length >= 2");
     const uint64_t n = n_walks * walk_length * 2 * window;
     if (n == 0) return 0;
+    if (!d_walks || !d_pairs) return fail("NULL pointer");
     const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(gn2v::pairs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_walks,
                        n_walks, walk_length, window, min_dist ? min_dist : 1u, d_pairs);
@@ -580,6 +584,7 @@ int gn2v_stats_reset(gn2v_graph *g, void *stream) {
     if (!g) return fail("graph handle is NULL");
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::lock_guard<std::mutex> lock(g->mu);
     if (fold_events(g)) return 1;
     g->train_ms = g->walk_ms = 0.0;
     g->train_launches = g->walk_launches = 0;
@@ -592,6 +597,7 @@ int gn2v_stats_read(gn2v_graph *g, gn2v_stats *stats, void *stream) {
     if (!g || !stats) return fail("NULL handle / stats");
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::lock_guard<std::mutex> lock(g->mu);
     if (fold_events(g)) return 1;
     unsigned long long h[4];
     HIP_TRY(hipMemcpy(h, g->counters, sizeof(h), hipMemcpyDeviceToHost));
@@ -647,7 +653,9 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
                 rc = launch_train(g, cbow, tp, &io, n, L, seed, e, first + off, lr, s);
             }
             if (!rc && g->train_events.size() > 2048) {  // bound the event pool on long fits
-                if (hipStreamSynchronize(s) != hipSuccess || fold_events(g)) rc = 1;
+                if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
+                std::lock_guard<std::mutex> lock(g->mu);
+                if (!rc && fold_events(g)) rc = 1;
             }
         }
         lr *= tp->lr_decay;

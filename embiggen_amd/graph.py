@@ -14,6 +14,7 @@ large synthetic graphs, directly in HBM (torch tensors, never copied back).
 """
 import ctypes as C
 import os
+import threading
 from typing import List, Optional
 
 import numpy as np
@@ -21,6 +22,7 @@ import numpy as np
 from . import _lib
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+_HANDLE_LOCK = threading.Lock()
 
 
 class DeviceGraph:
@@ -281,6 +283,10 @@ class CSRGraph:
     # ------------------------------------------------------------------ device side
     def device_graph(self, device: int = 0) -> DeviceGraph:
         """Create (once per device) the engine-side handle; uploads host arrays to HBM."""
+        with _HANDLE_LOCK:
+            return self._device_graph_locked(device)
+
+    def _device_graph_locked(self, device: int) -> DeviceGraph:
         if device in self._handles:
             return self._handles[device]
         L = _lib.lib()

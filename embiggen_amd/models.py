@@ -199,10 +199,72 @@ class _WalkBasedModel:
             )
         return central, contextual, self.last_stats
 
+    def fit_transform_blocks(self, graph, comm, round_walks: int = 1 << 18):
+        """SkipGram over several GPUs, one process per GPU (``comm`` = ``distributed.TorchComm``
+        under ``torch.distributed.run``): tables partitioned by node id, no row shared between
+        GPUs (``distributed.BlockPartitionedTrainer``).  Every rank returns the full
+        ``(central, contextual)`` device tensors [N, padded_size]."""
+        import torch
+
+        from . import ops
+        from .distributed import BlockPartitionedTrainer
+
+        if self.MODEL_ID != _lib.MODEL_SKIPGRAM:
+            raise NotImplementedError(
+                "Multi-GPU training is available for SkipGram only: CBOW needs all the contexts "
+                "of a centre on one GPU."
+            )
+        csr = _as_csr(graph)
+        _lib.require_device()
+        device = torch.cuda.current_device() if comm.world > 1 else self.device
+        dev = torch.device("cuda", device)
+        tp = self.train_params()
+        tp.window, tp.min_dist, tp.epochs = 1, 1, 1  # pair records: (centre, context)
+        with torch.cuda.device(dev):
+            trainer = BlockPartitionedTrainer(
+                csr, tp, self.embedding_size, self.padded_size, self.random_state,
+                self.init_scale(), comm, dev, scale_free=self.use_scale_free_distribution)
+            wp = self.walk_params()
+            walks_per_epoch = csr.get_number_of_unique_source_nodes() * self.iterations
+            stride = comm.world * round_walks
+            rounds = (walks_per_epoch + stride - 1) // stride
+            lr = np.float32(self.learning_rate)
+            start = time.perf_counter()
+            for epoch in range(self.epochs):
+                for r in range(rounds):  # every rank joins every round (collectives inside)
+                    first = r * stride + comm.rank * round_walks
+                    n = max(0, min(round_walks, walks_per_epoch - first))
+                    if n:
+                        walks = ops.walks(csr, wp, self.random_state, epoch, first, n, device=device)
+                        pairs = None
+                    else:
+                        walks = None
+                        pairs = torch.empty((0, 2), dtype=torch.int32, device=dev)
+                    trainer.train_round(walks, self.window_size, self.min_distance,
+                                        self.random_state, epoch, float(lr), pairs=pairs)
+                lr = np.float32(lr * np.float32(self.learning_rate_decay))
+            central, contextual = trainer.gather_full()
+            torch.cuda.synchronize(dev)
+            self.last_seconds = time.perf_counter() - start
+        self.last_stats = ops.stats_read(csr, device)
+        return central, contextual
+
     def fit_transform(self, graph) -> List[np.ndarray]:
         """``[central, contextual]`` as freshly allocated C-contiguous float32 [N, d] arrays
-        (or ``np.memmap``s when the ``*_embedding_path`` arguments are given)."""
-        central, contextual, _ = self.fit_transform_device(graph)
+        (or ``np.memmap``s when the ``*_embedding_path`` arguments are given).  Inside an
+        initialised ``torch.distributed`` job with several ranks the fit runs on all their GPUs."""
+        central = contextual = None
+        try:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from .distributed import TorchComm
+
+                central, contextual = self.fit_transform_blocks(graph, TorchComm())
+        except ImportError:
+            pass
+        if central is None:
+            central, contextual, _ = self.fit_transform_device(graph)
         d = self.embedding_size
         out = []
         for tensor, path in ((central, self.central_nodes_embedding_path),

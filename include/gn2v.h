@@ -17,7 +17,8 @@
  *   - pointers named d_* are DEVICE pointers (HBM of the graph's device); the caller owns them.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
  *     asynchronous on it unless documented otherwise.
- *   - a handle may be used from one thread at a time.
+ *   - a handle may be shared by threads (its bookkeeping is locked); launches from different
+ *     threads on the same stream are ordered by the stream as usual.
  */
 #ifndef GN2V_H
 #define GN2V_H

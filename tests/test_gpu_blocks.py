@@ -143,3 +143,32 @@ def test_pair_mode_on_a_collision_free_batch(karate, karate_oracle, flags, d):
                      pair_mode=True)
     assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
     assert np.abs(x_h - ops.init_table(n_rows, d, 5, 1, d ** -0.5).cpu().numpy()).max() > 1e-3
+
+
+def test_model_level_multi_gpu_fit_with_simulated_ranks():
+    """``models.SkipGram.fit_transform_blocks``: whole fits (epochs, lr decay, rounds where some
+    rank has no walks left) on 1, 2 and 3 simulated ranks give every rank the same full tables and
+    the single-GPU quality on a graph with communities."""
+    from helpers import link_auc, ring_of_cliques
+
+    src, dst, n = ring_of_cliques(32, 8)
+    g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=n)
+    kw = dict(embedding_size=16, epochs=4, walk_length=32, iterations=4, window_size=4,
+              number_of_negative_samples=5, learning_rate=0.025, return_weight=1.0,
+              explore_weight=1.0, verbose=False)
+    single = E.models.SkipGram(**kw).fit_transform(g)
+    auc_single = link_auc(g, single[0], single[1])
+    assert auc_single > 0.9
+    for world in (1, 2, 3):
+        def rank_fn(comm):
+            m = E.models.SkipGram(**kw)
+            c, x = m.fit_transform_blocks(g, comm, round_walks=300)
+            return c[:, :16].cpu().numpy(), x[:, :16].cpu().numpy(), m.last_stats["pairs"]
+
+        res = run_ranks(world, rank_fn)
+        for r in res[1:]:
+            assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1])
+        assert np.isfinite(res[0][0]).all()
+        assert link_auc(g, res[0][0], res[0][1]) > auc_single - 0.05
+    with pytest.raises(NotImplementedError):
+        E.models.CBOW(**kw).fit_transform_blocks(g, None)
