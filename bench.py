@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--parallelism", default="auto", choices=["auto", "single", "blocks"],
                     help="auto: single on 1 GPU, block-partitioned tables on N > 1 GPUs")
-    ap.add_argument("--round-walks", type=int, default=1 << 18,
+    ap.add_argument("--round-walks", type=int, default=1 << 19,
                     help="blocks: walks per rank per round (one ring rotation of the context "
                          "partitions per round)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")

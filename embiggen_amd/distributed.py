@@ -143,29 +143,38 @@ class BlockPartitionedTrainer:
         comm = self.comm
         world = comm.world
         if pairs is None:
+            # fused path: the pair kernel also emits the sort key of every slot
             from . import ops
 
-            pairs = ops.walk_pairs(walks, window, min_dist)
-        # One sort at the source: key = (owner of the centre, context partition, hashed salt).
-        # The salt shuffles pairs inside a block (integer ops only, so CPU and GPU agree): pairs
-        # leave the walks ~10 in a row with the same centre, and one wavefront per pair would
-        # otherwise make them hammer that row at the same time.
-        n = pairs.shape[0]
-        centre = pairs[:, 0].to(torch.int64) & 0xFFFFFFFF
-        ctx = pairs[:, 1].to(torch.int64) & 0xFFFFFFFF
-        block = (centre % world) * world + ctx % world
-        idx = torch.arange(n, dtype=torch.int64, device=pairs.device)
-        salt = (idx * 0x3C6EF35F + (seed * 0x19660D + self.pairs_seen * 0x2545F491 + 1)) & 0x7FFFFFFF
-        salt = ((salt ^ (salt >> 15)) * 0x2C1B3C6D) & 0x7FFFFFFF
-        salt = ((salt ^ (salt >> 12)) * 0x297A2D39) & 0x7FFFFFFF
-        salt = salt ^ (salt >> 15)
-        order = torch.argsort(block * (1 << 31) + salt)
-        del idx, salt, centre, ctx
-        sorted_pairs = pairs[order]
-        del order
-        # counts[o][p] = my pairs for owner o with context partition p; owner o receives row o
-        counts = torch.bincount(block, minlength=world * world).reshape(world, world)
-        del block
+            slots, keys = ops.walk_pair_blocks(
+                walks, window, min_dist, world,
+                (seed * 0x9E3779B97F4A7C15 + self.pairs_seen * world + comm.rank) & (2 ** 63 - 1))
+            keys, order = torch.sort(keys)
+            bounds = torch.arange(world * world + 1, dtype=torch.int64, device=keys.device) << 31
+            edges = torch.searchsorted(keys, bounds)
+            n = int(edges[-1])  # unused slots carry INT64_MAX and sort behind every block
+            counts = (edges[1:] - edges[:-1]).reshape(world, world)
+            sorted_pairs = slots[order[:n]]
+            del slots, keys, order
+        else:
+            # explicit pairs (tests, CPU): same key built with integer tensor ops, so CPU and GPU
+            # tensors sort identically.  The salt shuffles pairs inside a block: pairs leave the
+            # walks ~10 in a row with the same centre, and one wavefront per pair would otherwise
+            # make them hammer that row at the same time.
+            n = pairs.shape[0]
+            centre = pairs[:, 0].to(torch.int64) & 0xFFFFFFFF
+            ctx = pairs[:, 1].to(torch.int64) & 0xFFFFFFFF
+            block = (centre % world) * world + ctx % world
+            idx = torch.arange(n, dtype=torch.int64, device=pairs.device)
+            salt = (idx * 0x3C6EF35F + (seed * 0x19660D + self.pairs_seen * 0x2545F491 + 1)) & 0x7FFFFFFF
+            salt = ((salt ^ (salt >> 15)) * 0x2C1B3C6D) & 0x7FFFFFFF
+            salt = ((salt ^ (salt >> 12)) * 0x297A2D39) & 0x7FFFFFFF
+            salt = salt ^ (salt >> 15)
+            order = torch.argsort(block * (1 << 31) + salt)
+            sorted_pairs = pairs[order]
+            # counts[o][p] = my pairs for owner o with context partition p; owner o gets row o
+            counts = torch.bincount(block, minlength=world * world).reshape(world, world)
+            del idx, salt, centre, ctx, order, block
         got_counts = comm.exchange_rows(counts, [1] * world, [1] * world)  # [source][partition]
         send_l = counts.sum(1).tolist()
         src_part = got_counts.tolist()
@@ -200,7 +209,7 @@ class BlockPartitionedTrainer:
             if world > 1:
                 self._rotate()
         self.pairs_seen += 1
-        self.last_round = {"pairs_generated": int(pairs.shape[0]), "pairs_trained": int(mine.shape[0]),
+        self.last_round = {"pairs_generated": int(n), "pairs_trained": int(mine.shape[0]),
                            "block_sizes": sizes}
 
     def gather_full(self):

@@ -65,11 +65,10 @@ def _run(comm, device, use_oracle):
     for r in range(2):
         first = (r * comm.world + comm.rank) * 9
         walks = torch.from_numpy(O.walks(og, wp, 42, 0, first, 9).view(np.int32)).to(device)
-        if use_oracle:
-            pairs = torch.from_numpy(O.walk_pairs(walks.numpy().view(np.uint32), W).view(np.int32))
-            tr.train_round(None, W, 1, 42, 0, 0.02, pairs=pairs)
-        else:
-            tr.train_round(walks, W, 1, 42, 0, 0.02)
+        # explicit pairs on both sides: the same (torch-built) shuffle keys, hence the same order
+        pairs = torch.from_numpy(
+            O.walk_pairs(walks.cpu().numpy().view(np.uint32), W).view(np.int32)).to(device)
+        tr.train_round(None, W, 1, 42, 0, 0.02, pairs=pairs)
     return [t.cpu().numpy() for t in tr.gather_full()]
 
 
@@ -172,3 +171,26 @@ def test_model_level_multi_gpu_fit_with_simulated_ranks():
         assert link_auc(g, res[0][0], res[0][1]) > auc_single - 0.05
     with pytest.raises(NotImplementedError):
         E.models.CBOW(**kw).fit_transform_blocks(g, None)
+
+
+def test_fused_pair_keys_group_and_shuffle(karate):
+    """gn2v_walk_pair_blocks: sorting by the emitted key yields exactly the pair multiset of
+    gn2v_walk_pairs, grouped by (centre % world, context % world), shuffled inside a block, with
+    the unused slots (trap-node suffixes, trimmed windows) at the end."""
+    wk = ops.walks(karate, ops.walk_params(24, 4, 0.5, 2.0), 5, 0, 0, 136)
+    wk[::5, 9:] = -1
+    world, window = 3, 4
+    want = ops.walk_pairs(wk, window, 1).cpu().numpy().view(np.uint32)
+    slots, keys = ops.walk_pair_blocks(wk, window, 1, world, 99)
+    keys_s, order = torch.sort(keys)
+    n = int((keys_s != 0x7FFFFFFFFFFFFFFF).sum())
+    assert n == len(want)
+    got = slots[order[:n]].cpu().numpy().view(np.uint32)
+    block = (got[:, 0] % world).astype(np.int64) * world + got[:, 1] % world
+    assert (np.diff(block) >= 0).all() and (keys_s[:n].cpu().numpy() >> 31 == block).all()
+    as_set = lambda p: np.sort(p[:, 0].astype(np.int64) * 64 + p[:, 1])  # noqa: E731
+    assert np.array_equal(as_set(got), as_set(want))
+    inside = got[block == 4]
+    assert not np.array_equal(inside, inside[np.lexsort((inside[:, 1], inside[:, 0]))])  # shuffled
+    _, keys2 = ops.walk_pair_blocks(wk, window, 1, world, 100)
+    assert not torch.equal(keys, keys2)  # the salt changes the shuffle
