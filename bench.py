@@ -97,6 +97,7 @@ def committed_traffic(config, update_mode):
             continue
         same = (rec.get("config", {}).get("workload") == config["workload"]
                 and rec.get("config", {}).get("walks_per_launch") == config["walks_per_launch"]
+                and rec.get("config", {}).get("parallelism") == config["parallelism"]
                 and rec.get("config", {}).get("update_mode") == update_mode)
         if same:
             best = (rec["hbm_traffic_bytes_per_launch"], os.path.basename(path))

@@ -58,7 +58,6 @@ class CSRGraph:
             self._n_nodes = int(_device_tensors["row_ptr"].numel()) - 1
             self._n_edges = int(_device_tensors["col_idx"].numel())
             self._n_sources = int(_device_tensors["n_sources"])
-            self._n_singletons = self._n_nodes - self._n_sources if not directed else None
             return
         self._row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
         self._col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
