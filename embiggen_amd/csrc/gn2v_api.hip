@@ -177,9 +177,10 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
                  uint64_t n_walks, uint32_t L, uint64_t seed, uint64_t epoch, uint64_t first_walk,
                  float lr, hipStream_t s) {
     if (check_train_params(tp, L)) return 1;
-    if (!io || !io->d_walks || !io->d_central || !io->d_contextual)
+    if (!io) return fail("step io is NULL");
+    if (n_walks == 0) return 0;  // empty batches are legal (and carry NULL walk pointers)
+    if (!io->d_walks || !io->d_central || !io->d_contextual)
         return fail("NULL walks / table pointer");
-    if (n_walks == 0) return 0;
     gn2v::TrainArgs a{};
     a.g = g->view;
     a.walks = io->d_walks;

@@ -431,3 +431,47 @@ def test_context_cache_degree_rule_and_short_walks(karate, karate_oracle):
                           c_h, x_h)
             assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5
             assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("L,w,k", [(4, 5, 3), (2, 1, 0), (3, 8, 17), (40, 20, 2)])
+def test_extreme_shapes(karate, karate_oracle, model, L, w, k):
+    """Windows wider than the walk, no negatives at all, more than 16 negatives, very wide
+    windows: deterministic schedule and one-wave production schedule vs oracle."""
+    d = 12
+    wk = ops.walks(karate, ops.walk_params(L, 1, 1.0, 1.0), 2, 0, 0, 34)
+    wk_h = wk.cpu().numpy().view(np.uint32)
+    otp = O.TrainParams(model, d, d, 1, k, w, 0.01, 0.9, 6.0, 1, d ** -0.5)
+    step = ops.sgns_step if model == 0 else ops.cbow_step
+    for flags, per_walk in ((1 | DET, False), (1 | _lib.TRAIN_WRITE_THROUGH, True),
+                            (1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_ALL, True),
+                            (1 | _lib.TRAIN_ATOMIC, True)):
+        c, x = _tables(34, d, 2)
+        c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+        tp = ops.train_params(model, d, k, w, flags=flags)
+        if per_walk:
+            for b in range(34):
+                step(karate, tp, wk[b:b + 1].contiguous(), 2, 0, b, 0.05, c, x)
+        else:
+            step(karate, tp, wk, 2, 0, 0, 0.05, c, x)
+        torch.cuda.synchronize()
+        O.train_walks(karate_oracle, otp, wk_h, 2, 0, 0, 0.05, c_h, x_h)
+        assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5
+        assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+
+
+def test_limits_are_reported_as_errors(karate):
+    """Shapes beyond the LDS plan / supported sizes fail with a message, never silently."""
+    wk = torch.zeros((2, 30000), dtype=torch.int32, device="cuda")
+    c, x = _tables(34, 8, 1)
+    with pytest.raises(_lib.Gn2vError, match="LDS"):
+        ops.sgns_step(karate, ops.train_params(0, 8, 5, 5), wk, 1, 0, 0, 0.01, c, x)
+    with pytest.raises(_lib.Gn2vError, match="512"):
+        ops.sgns_step(karate, ops.train_params(0, 600, 5, 5, ld=600), wk[:, :8].contiguous(), 1, 0,
+                      0, 0.01, ops.init_table(34, 600, 1, 0, 0.1, ld=600),
+                      ops.init_table(34, 600, 1, 1, 0.1, ld=600))
+    with pytest.raises(ValueError):
+        E.Node2VecSkipGramEnsmallen(embedding_size=1024)
+    # empty batches are legal no-ops
+    ops.sgns_step(karate, ops.train_params(0, 8, 5, 5), wk[:0, :8].contiguous(), 1, 0, 0, 0.01, c, x)
+    assert ops.walks(karate, ops.walk_params(8, 1), 1, 0, 0, 0).shape == (0, 8)
