@@ -406,6 +406,7 @@ int gn2v_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_
                uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, void *stream) {
     if (!g) return fail("graph handle is NULL");
     if (check_walk_params(wp)) return 1;
+    if (n_walks == 0) return 0;
     if (!d_out) return fail("NULL output pointer");
     HIP_TRY(hipSetDevice(g->device));
     return launch_walks(g, wp, seed, epoch, first_walk, n_walks, d_out, (hipStream_t)stream);
@@ -415,9 +416,9 @@ int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_l
                       uint32_t window, int32_t *d_contexts, int32_t *d_words, void *stream) {
     if (window < 1 || walk_length <= 2 * window)
         return fail("walk_length must exceed 2 * window_size");
-    if (!d_walks || !d_contexts || !d_words) return fail("NULL pointer");
     const uint64_t n = n_walks * (walk_length - 2 * window);
     if (n == 0) return 0;
+    if (!d_walks || !d_contexts || !d_words) return fail("NULL pointer");
     const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(gn2v::window_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        d_walks, n_walks, walk_length, window, d_contexts, d_words);
@@ -457,10 +458,10 @@ int gn2v_walk_pair_blocks(const uint32_t *d_walks, uint64_t n_walks, uint32_t wa
 
 int gn2v_init_table(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
                     uint32_t table_id, float scale, void *stream) {
-    if (!d_table) return fail("NULL table pointer");
     if (d == 0 || ld < d) return fail("need 0 < d <= ld");
     const uint64_t n = n_rows * ld;
     if (n == 0) return 0;
+    if (!d_table) return fail("NULL table pointer");
     const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(gn2v::init_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_table,
                        n_rows, d, ld, gn2v::mix64(seed ^ (gn2v::kTagInit + table_id)), scale);
