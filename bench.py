@@ -300,7 +300,7 @@ def main():
             "argv": sys.argv[1:],
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("gn2v::sgns_cached_kernel" if mode == "single" and n >= (1 << 20)
+                "kernel": ("gn2v::sgns_cached_kernel" if mode == "single" and n >= (1 << 16)
                            and args.mode in ("auto", "write_through", "write_back")
                            else "gn2v::sgns_kernel"),
                 "achieved": achieved,

@@ -217,7 +217,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     const int wm = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
                    : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
                    : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
-                   : g->view.n_nodes < (1ULL << 20)         ? gn2v::kAtomic
+                   : g->view.n_nodes < (1ULL << 16)         ? gn2v::kAtomic
                                                             : gn2v::kWriteThrough;
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
     const size_t per_wave_words =

@@ -195,7 +195,7 @@ def test_parallel_schedule_is_statistically_equivalent(cls, model, mode):
     """The many-wavefront schedule is not reproducible element-wise (neither is the CPU reference
     under rayon); it must reach the oracle's quality on a graph with communities.  On a graph
     this small (256 nodes under thousands of concurrent waves) the default picks atomics; the
-    racy store modes are meant for >= 2^20 nodes and are compared at that size below."""
+    racy store modes are the default from 2^16 nodes (scripts/threshold_probe.py)."""
     src, dst, n = ring_of_cliques(32, 8)
     g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=n)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
