@@ -191,6 +191,8 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     float *positive_table = cbow ? io->d_central : io->d_contextual;
     a.negative = io->d_negative ? io->d_negative : positive_table;
     a.split = a.negative != positive_table;
+    if (a.split && g->view.n_nodes >= (1ULL << 31))
+        return fail("separate negative tables need node ids below 2^31");
     a.pair_mode = io->pair_mode ? 1u : 0u;
     if (a.pair_mode && (cbow || L != 2 || tp->window != 1))
         return fail("pair mode needs SkipGram, walk_length 2 and window_size 1");
@@ -238,7 +240,8 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     const size_t cache_lds = (size_t)waves_per_block * cache_words * 4;
     const bool use_cache = !det && wm != gn2v::kAtomic && !a.pair_mode && !a.split &&
                            !a.walk_rows && !a.neg_pool && !(tp->flags & GN2V_TRAIN_NO_CTX_CACHE) &&
-                           cache_lds <= 40 * 1024 && L > 2 * tp->window;
+                           cache_lds <= 40 * 1024 && L > 2 * tp->window &&
+                           g->view.n_nodes < (1ULL << 30);  // row ids share a word with kCacheBit
     if (use_cache) {
         if (tp->flags & GN2V_TRAIN_CTX_CACHE_ALL) {
             a.cache_max_degree = 0xFFFFFFFFu;
