@@ -196,7 +196,8 @@ class CSRGraph:
         return False
 
     def has_edge_weights(self) -> bool:
-        return self._weights is not None
+        return self._weights is not None or (
+            self._device_tensors is not None and "cumw" in self._device_tensors)
 
     def has_negative_edge_weights(self) -> bool:
         return self._weights is not None and bool((self._weights <= 0).any())
@@ -253,6 +254,36 @@ class CSRGraph:
         g._directed = self._directed
         return g
 
+    def with_degree_normalized_weights(self) -> "CSRGraph":
+        """Same graph with every edge weight divided by the degree of its destination node: the
+        walk sampler then realises ``normalize_by_degree`` ("normalize the random walk by the node
+        degree of the destination node", node2vec_skipgram.py:94-96) through its ordinary
+        weight-proportional candidate draw.  The derived graph is cached on this object."""
+        cached = getattr(self, "_degree_normalized", None)
+        if cached is not None:
+            return cached
+        if self._device_tensors is not None:
+            import torch
+
+            t = self._device_tensors
+            rp, col = t["row_ptr"], t["col_idx"].to(torch.int64) & 0xFFFFFFFF
+            deg = (rp[1:] - rp[:-1])
+            w = 1.0 / deg[col].to(torch.float64)
+            cum = torch.cumsum(w, 0)
+            base = torch.cat([torch.zeros(1, dtype=cum.dtype, device=cum.device), cum])[rp[:-1]]
+            cumw = (cum - torch.repeat_interleave(base, deg)).to(torch.float32)
+            g = CSRGraph(None, None, name=self._name, directed=self._directed,
+                         _device_tensors=dict(t, cumw=cumw))
+            g._node_names = self._node_names
+        else:
+            deg = np.diff(self._row_ptr.astype(np.int64)).astype(np.float64)
+            base = np.ones(self._n_edges) if self._weights is None else self._weights.astype(np.float64)
+            w = base / np.maximum(deg[self._col_idx.astype(np.int64)], 1.0)
+            g = CSRGraph(self._row_ptr, self._col_idx, w, self._node_names, self._name,
+                         self._directed)
+        self._degree_normalized = g
+        return g
+
     # ------------------------------------------------------------------ raw arrays
     @property
     def row_ptr(self) -> np.ndarray:
@@ -268,6 +299,8 @@ class CSRGraph:
 
     @property
     def cumw(self) -> Optional[np.ndarray]:
+        if self._cumw is None and self._device_tensors is not None and "cumw" in self._device_tensors:
+            self._cumw = self._device_tensors["cumw"].cpu().numpy()
         return self._cumw
 
     @property
@@ -296,8 +329,10 @@ class CSRGraph:
             if t["row_ptr"].device.index != device:
                 raise ValueError("This graph lives on another device.")
             src = t.get("sources")
+            cumw = t.get("cumw")
             _lib.check(L.gn2v_graph_create(
-                t["row_ptr"].data_ptr(), t["col_idx"].data_ptr(), None,
+                t["row_ptr"].data_ptr(), t["col_idx"].data_ptr(),
+                None if cumw is None else cumw.data_ptr(),
                 None if src is None else src.data_ptr(), self._n_nodes, self._n_edges,
                 self._n_sources, _lib.GRAPH_DEVICE_PTRS, device, C.byref(handle)))
             dg = DeviceGraph(handle, device, keep_alive=(t,))

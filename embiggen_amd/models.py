@@ -18,7 +18,9 @@ from . import _lib
 from .graph import CSRGraph
 
 
-def _as_csr(graph) -> CSRGraph:
+def _as_csr(graph, normalize_by_degree: bool = False) -> CSRGraph:
+    if normalize_by_degree:
+        return _as_csr(graph).with_degree_normalized_weights()
     if isinstance(graph, CSRGraph):
         return graph
     if hasattr(graph, "get_cumulative_node_degrees"):
@@ -80,10 +82,6 @@ class _WalkBasedModel:
             raise ValueError("clipping_value must be strictly positive.")
         if dtype != "f32":
             raise ValueError(f"Only dtype 'f32' is supported by the gn2v engine, got {dtype!r}.")
-        if normalize_by_degree:
-            raise NotImplementedError(
-                "normalize_by_degree is not supported by the gn2v engine yet."
-            )
         if change_node_type_weight != 1.0 or change_edge_type_weight != 1.0:
             raise NotImplementedError(
                 "Node/edge type transition weights need typed graphs, which the gn2v engine "
@@ -104,6 +102,7 @@ class _WalkBasedModel:
         self.learning_rate_decay = float(learning_rate_decay)
         self.central_nodes_embedding_path = central_nodes_embedding_path
         self.contextual_nodes_embedding_path = contextual_nodes_embedding_path
+        self.normalize_by_degree = bool(normalize_by_degree)
         self.stochastic_downsample_by_degree = bool(stochastic_downsample_by_degree)
         self.normalize_learning_rate_by_degree = bool(normalize_learning_rate_by_degree)
         self.use_scale_free_distribution = bool(use_scale_free_distribution)
@@ -169,7 +168,7 @@ class _WalkBasedModel:
         of shape [N, padded_size] (columns >= embedding_size are zero padding) and the stats."""
         import torch
 
-        csr = _as_csr(graph)
+        csr = _as_csr(graph, self.normalize_by_degree)
         _lib.require_device()
         if not torch.cuda.is_available():
             raise RuntimeError("PyTorch does not see a ROCm device; cannot allocate the tables.")
@@ -214,7 +213,7 @@ class _WalkBasedModel:
                 "Multi-GPU training is available for SkipGram only: CBOW needs all the contexts "
                 "of a centre on one GPU."
             )
-        csr = _as_csr(graph)
+        csr = _as_csr(graph, self.normalize_by_degree)
         _lib.require_device()
         device = torch.cuda.current_device() if comm.world > 1 else self.device
         dev = torch.device("cuda", device)

@@ -121,3 +121,26 @@ def test_full_size_walk_properties():
     pos = torch.searchsorted(edge_keys, a * n + b).clamp_(max=edge_keys.numel() - 1)
     assert bool((edge_keys[pos] == a * n + b).all())
     assert torch.equal(wk[:, 0].long(), torch.arange(1 << 15, device="cuda") % n)
+
+
+def test_normalize_by_degree_walks_and_fit(karate):
+    """normalize_by_degree through the public API: host graph and device-resident graph, walks
+    bit-identical to the oracle fed with the same derived weights."""
+    h = karate.with_degree_normalized_weights()
+    og = O.OracleGraph(h.row_ptr, h.col_idx, h.cumw)
+    for rw, ew in ((1.0, 1.0), (0.25, 4.0)):
+        got = _u32(ops.walks(h, ops.walk_params(20, 3, rw, ew), 6, 0, 0, 102))
+        assert np.array_equal(got, O.walks(og, O.WalkParams(20, 3, rw, ew, 100, 0), 6, 0, 0, 102))
+    g = E.barabasi_albert(3000, 4, 9)
+    hd = g.with_degree_normalized_weights()
+    assert hd.has_edge_weights() and hd is g.with_degree_normalized_weights()
+    ogd = O.OracleGraph(hd.row_ptr, hd.col_idx, hd.cumw)
+    got = _u32(ops.walks(hd, ops.walk_params(16, 1, 0.5, 2.0), 6, 0, 0, 3000))
+    assert np.array_equal(got, O.walks(ogd, O.WalkParams(16, 1, 0.5, 2.0, 100, 0), 6, 0, 0, 3000))
+    m = E.Node2VecSkipGramEnsmallen(embedding_size=8, epochs=1, walk_length=8, iterations=1,
+                                    normalize_by_degree=True, verbose=False)
+    res = m.fit_transform(karate, return_dataframe=False).get_all_node_embedding()
+    plain = E.Node2VecSkipGramEnsmallen(embedding_size=8, epochs=1, walk_length=8, iterations=1,
+                                        verbose=False).fit_transform(karate, return_dataframe=False)
+    assert np.isfinite(res[0]).all()
+    assert not np.array_equal(res[0], plain.get_all_node_embedding()[0])

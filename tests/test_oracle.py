@@ -280,3 +280,20 @@ def test_oracle_is_clean_under_address_and_ub_sanitizers():
     res = subprocess.run(["make", "-C", root, "sanitize"], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "ok " in res.stdout
+
+
+def test_normalize_by_degree_is_a_destination_degree_weighting(karate):
+    """normalize_by_degree (node2vec_skipgram.py:94-96): transition weight divided by the degree of
+    the destination -> realised as edge weights 1/deg(dst); first-order frequencies follow it."""
+    h = karate.with_degree_normalized_weights()
+    deg = karate.get_node_degrees()
+    assert np.allclose(h.get_directed_edge_weights(), 1.0 / deg[karate.col_idx])
+    og = O.OracleGraph(h.row_ptr, h.col_idx, h.cumw)
+    w = O.walks(og, O.WalkParams(2, 1, 1.0, 1.0, 100, 0), 5, 0, 0, 34 * 6000)
+    rp = karate.row_ptr.astype(np.int64)
+    for u in (0, 33, 2):
+        nxt = w[w[:, 0] == u, 1]
+        neigh = karate.col_idx[rp[u]:rp[u + 1]]
+        counts = np.array([(nxt == x).sum() for x in neigh], dtype=np.float64)
+        p = 1.0 / deg[neigh]
+        assert stats.chisquare(counts, p / p.sum() * counts.sum()).pvalue > 1e-4
