@@ -268,7 +268,8 @@ def main():
         launch_ms = st["train_ms"] / max(st["train_launches"], 1)
         achieved = st["pairs"] * BYTES_PER_PAIR / (st["train_ms"] * 1e-3) / 1e9
         line = {
-            "metric": "SkipGram training-pairs/sec (walk generation included), d=128",
+            "metric": "SkipGram training-pairs/sec + walk-steps/sec, d=128 (value = pairs/s with walk "
+                      "generation inside the timed region; walk-steps/s in walk_kernel_steps_per_s)",
             "value": total_pairs / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
