@@ -32,7 +32,7 @@ MODEL_CBOW = 1
 # every symbol include/gn2v.h declares (checked by tests/test_cabi.py)
 EXPORTS = [
     "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
-    "gn2v_graph_destroy", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_walk_pairs",
+    "gn2v_graph_destroy", "gn2v_graph_set_types", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_walk_pairs",
     "gn2v_walk_pair_blocks",
     "gn2v_init_table",
     "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_edge_embedding",
@@ -50,6 +50,8 @@ class WalkParams(C.Structure):
         ("explore_weight", C.c_float),
         ("max_neighbours", C.c_uint32),
         ("flags", C.c_uint32),
+        ("change_node_type_weight", C.c_float),  # 0 = unset = 1.0
+        ("change_edge_type_weight", C.c_float),
     ]
 
 
@@ -153,6 +155,7 @@ def lib():
     L.gn2v_device_count.restype = i32
     L.gn2v_graph_create.argtypes = [vp, vp, vp, vp, u64, u64, u64, u32, i32, C.POINTER(vp)]
     L.gn2v_graph_destroy.argtypes = [vp]
+    L.gn2v_graph_set_types.argtypes = [vp, vp, vp]
     L.gn2v_ba_edges.argtypes = [u64, u32, u64, vp, vp, vp]
     L.gn2v_walks.argtypes = [vp, C.POINTER(WalkParams), u64, u64, u64, u64, vp, vp]
     L.gn2v_window_batch.argtypes = [vp, u64, u32, u32, vp, vp, vp]

@@ -48,7 +48,7 @@ struct gn2v_graph {
     int n_cus = 256;
     bool owns = false;
     void *own_row_ptr = nullptr, *own_col_idx = nullptr, *own_cumw = nullptr,
-         *own_sources = nullptr;
+         *own_sources = nullptr, *own_node_types = nullptr, *own_edge_types = nullptr;
     unsigned long long *counters = nullptr;  // device, 4 x u64
     std::vector<EventPair> train_events, walk_events, free_events;
     double train_ms = 0.0, walk_ms = 0.0;
@@ -95,11 +95,26 @@ int check_walk_params(const gn2v_walk_params *wp) {
     if (!(wp->return_weight > 0.f) || !(wp->explore_weight > 0.f) ||
         !std::isfinite(wp->return_weight) || !std::isfinite(wp->explore_weight))
         return fail("return_weight and explore_weight must be finite and strictly positive");
+    if (!(wp->change_node_type_weight >= 0.f) || !(wp->change_edge_type_weight >= 0.f) ||
+        !std::isfinite(wp->change_node_type_weight) || !std::isfinite(wp->change_edge_type_weight))
+        return fail("change_node_type_weight and change_edge_type_weight must be finite and "
+                    "strictly positive (0 = unset)");
     return 0;
 }
 
-gn2v::WalkConsts walk_consts(const gn2v_walk_params *wp) {
+void type_factors(float weight, uint64_t *same, uint64_t *diff) {
+    const double w = weight == 0.0f ? 1.0 : (double)weight;
+    const double mx = w > 1.0 ? w : 1.0;
+    *same = (uint64_t)std::floor(1.0 / mx * 4294967296.0);
+    *diff = (uint64_t)std::floor(w / mx * 4294967296.0);
+}
+
+gn2v::WalkConsts walk_consts(const gn2v_graph *g, const gn2v_walk_params *wp) {
     gn2v::WalkConsts c{};
+    type_factors(wp->change_node_type_weight, &c.fn_same, &c.fn_diff);
+    type_factors(wp->change_edge_type_weight, &c.fe_same, &c.fe_diff);
+    c.node_bias = g->view.node_types != nullptr && c.fn_same != c.fn_diff;
+    c.edge_bias = g->view.edge_types != nullptr && c.fe_same != c.fe_diff;
     c.walk_length = wp->walk_length;
     c.second_order = !(wp->return_weight == 1.0f && wp->explore_weight == 1.0f);
     const double rw = wp->return_weight, ew = wp->explore_weight;
@@ -115,7 +130,7 @@ gn2v::WalkConsts walk_consts(const gn2v_walk_params *wp) {
 int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
                  uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, hipStream_t s) {
     if (n_walks == 0) return 0;
-    const gn2v::WalkConsts c = walk_consts(wp);
+    const gn2v::WalkConsts c = walk_consts(g, wp);
     const uint64_t blocks = (n_walks + gn2v::kWalkBlock - 1) / gn2v::kWalkBlock;
     if (blocks > 0x7FFFFFFFULL) return fail("too many walks in one launch");
     std::lock_guard<std::mutex> lock(g->mu);
@@ -374,6 +389,42 @@ int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const fl
     return 0;
 }
 
+int gn2v_graph_set_types(gn2v_graph *g, const uint32_t *node_types,
+                         const uint32_t *edge_types) {
+    if (!g) return fail("graph handle is NULL");
+    HIP_TRY(hipSetDevice(g->device));
+    std::lock_guard<std::mutex> lock(g->mu);
+    // walks already queued may still read the old arrays
+    HIP_TRY(hipDeviceSynchronize());
+    if (!g->owns) {
+        g->view.node_types = node_types;
+        g->view.edge_types = edge_types;
+        return 0;
+    }
+    struct Kind {
+        const uint32_t *src;
+        void **own;
+        const uint32_t **view;
+        uint64_t count;
+    } kinds[2] = {{node_types, &g->own_node_types, &g->view.node_types, g->view.n_nodes},
+                  {edge_types, &g->own_edge_types, &g->view.edge_types, g->view.n_edges}};
+    for (auto &k : kinds) {
+        if (*k.own) (void)hipFree(*k.own);
+        *k.own = nullptr;
+        *k.view = nullptr;
+        if (!k.src) continue;
+        const size_t bytes = k.count * sizeof(uint32_t);
+        if (hipMalloc(k.own, bytes) != hipSuccess ||
+            hipMemcpy(*k.own, k.src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            if (*k.own) (void)hipFree(*k.own);
+            *k.own = nullptr;
+            return fail("uploading the type ids to the device failed (out of memory?)");
+        }
+        *k.view = (const uint32_t *)*k.own;
+    }
+    return 0;
+}
+
 int gn2v_graph_destroy(gn2v_graph *g) {
     if (!g) return 0;
     (void)hipSetDevice(g->device);
@@ -382,6 +433,8 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->own_col_idx) (void)hipFree(g->own_col_idx);
     if (g->own_cumw) (void)hipFree(g->own_cumw);
     if (g->own_sources) (void)hipFree(g->own_sources);
+    if (g->own_node_types) (void)hipFree(g->own_node_types);
+    if (g->own_edge_types) (void)hipFree(g->own_edge_types);
     if (g->counters) (void)hipFree(g->counters);
     for (auto *v : {&g->train_events, &g->walk_events, &g->free_events})
         for (auto &ev : *v) {

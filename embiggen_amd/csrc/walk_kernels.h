@@ -5,10 +5,13 @@
 //
 // Second-order (return_weight = 1/p, explore_weight = 1/q; node2vec_skipgram.py:58-71) bias is
 // sampled exactly by rejection: candidate ~ uniform (or weight-proportional) over N(cur), accepted
-// against an integer threshold chosen by the candidate's class {prev, common neighbour, other};
-// after kMaxTrials rejections the lane falls back to an exact integer-weighted scan of the row.
-// All arithmetic that decides a transition is integer (or single rounded f32/f64 ops), so the
-// walks are bit-identical to oracle/gn2v_oracle.c.
+// against an integer threshold = product of the normalised factors of the candidate edge
+//   {return, 1, explore} by class {prev, common neighbour, other}      (second order)
+//   change_node_type_weight when type(candidate) != type(cur)          (graphs with node types)
+//   change_edge_type_weight when type(edge) != type(previous edge)     (graphs with edge types)
+// (node2vec_sequence.py:57-66); after kMaxTrials rejections the lane falls back to an exact
+// integer-weighted scan of the row.  All arithmetic that decides a transition is integer (or
+// single rounded f32/f64 ops), so the walks are bit-identical to oracle/gn2v_oracle.c.
 #pragma once
 #include "rng.h"
 
@@ -21,6 +24,8 @@ struct GraphView {
     const uint32_t *col_idx;
     const float *cumw;        // nullptr for unweighted graphs
     const uint32_t *sources;  // nullptr when every node is a source
+    const uint32_t *node_types;  // one id per node, or nullptr
+    const uint32_t *edge_types;  // one id per directed edge (aligned with col_idx), or nullptr
     uint64_t n_nodes;
     uint64_t n_edges;
     uint64_t n_sources;
@@ -29,7 +34,9 @@ struct GraphView {
 struct WalkConsts {
     uint32_t walk_length;
     uint32_t second_order;
+    uint32_t node_bias, edge_bias;        // type factors active (types present and weight != 1)
     uint64_t t_ret, t_common, t_explore;  // acceptance thresholds on a 2^32 scale
+    uint64_t fn_same, fn_diff, fe_same, fe_diff;
 };
 
 __device__ __forceinline__ bool adj_contains(const uint32_t *__restrict__ col, uint64_t lo,
@@ -61,51 +68,68 @@ __device__ __forceinline__ uint64_t pick_index(const GraphView &g, uint64_t star
     return lo < deg ? lo : deg - 1;
 }
 
-__device__ __forceinline__ uint64_t class_threshold(const GraphView &g, const WalkConsts &c,
-                                                    uint32_t x, uint32_t prev, uint64_t pstart,
-                                                    uint64_t pend) {
-    return (x == prev) ? c.t_ret
-           : adj_contains(g.col_idx, pstart, pend, x) ? c.t_common
-                                                      : c.t_explore;
+// t * f / 2^32 with t, f <= 2^32 (f == 2^32 is the identity)
+__device__ __forceinline__ uint64_t scale32(uint64_t t, uint64_t f) {
+    return f >= (1ULL << 32) ? t : (t * f) >> 32;
 }
 
-// exact fallback after kMaxTrials rejections (rare: only for extreme p/q on low-weight rows)
-__device__ __noinline__ uint32_t exact_scan(const GraphView &g, const WalkConsts &c, uint64_t r,
-                                            uint64_t start, uint64_t deg, uint32_t prev,
-                                            uint64_t pstart, uint64_t pend) {
+// acceptance threshold of candidate edge e = cur -> x
+__device__ __forceinline__ uint64_t accept_threshold(const GraphView &g, const WalkConsts &c,
+                                                     uint32_t cur, uint32_t x, uint64_t e,
+                                                     uint32_t prev, uint64_t pstart,
+                                                     uint64_t pend, uint32_t ptype) {
+    uint64_t t = 1ULL << 32;
+    if (c.second_order && prev != kSentinel)
+        t = (x == prev) ? c.t_ret
+            : adj_contains(g.col_idx, pstart, pend, x) ? c.t_common
+                                                       : c.t_explore;
+    if (c.node_bias) t = scale32(t, g.node_types[cur] != g.node_types[x] ? c.fn_diff : c.fn_same);
+    if (c.edge_bias && prev != kSentinel)
+        t = scale32(t, g.edge_types[e] != ptype ? c.fe_diff : c.fe_same);
+    return t;
+}
+
+// exact fallback after kMaxTrials rejections (rare: only for extreme weights on low-weight rows);
+// returns the index of the chosen edge inside the row
+__device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts &c, uint64_t r,
+                                            uint32_t cur, uint64_t start, uint64_t deg,
+                                            uint32_t prev, uint64_t pstart, uint64_t pend,
+                                            uint32_t ptype) {
     if (g.cumw == nullptr) {
         uint64_t total = 0;
         for (uint64_t i = 0; i < deg; ++i)
-            total += class_threshold(g, c, g.col_idx[start + i], prev, pstart, pend);
-        if (total == 0) return g.col_idx[start + (((r >> 32) * deg) >> 32)];
+            total += accept_threshold(g, c, cur, g.col_idx[start + i], start + i, prev, pstart,
+                                      pend, ptype);
+        if (total == 0) return ((r >> 32) * deg) >> 32;
         const uint64_t target = mulhi64(r, total);
         uint64_t acc = 0;
         for (uint64_t i = 0; i < deg; ++i) {
-            const uint32_t x = g.col_idx[start + i];
-            acc += class_threshold(g, c, x, prev, pstart, pend);
-            if (acc > target) return x;
+            acc += accept_threshold(g, c, cur, g.col_idx[start + i], start + i, prev, pstart,
+                                    pend, ptype);
+            if (acc > target) return i;
         }
-        return g.col_idx[start + deg - 1];
+        return deg - 1;
     }
     double total = 0.0;
     for (uint64_t i = 0; i < deg; ++i) {
         const double w = __dsub_rn((double)g.cumw[start + i],
                                    i ? (double)g.cumw[start + i - 1] : 0.0);
-        const uint64_t thr = class_threshold(g, c, g.col_idx[start + i], prev, pstart, pend);
+        const uint64_t thr = accept_threshold(g, c, cur, g.col_idx[start + i], start + i, prev,
+                                              pstart, pend, ptype);
         total = __dadd_rn(total, __dmul_rn(w, (double)thr));
     }
     const double target =
         __dmul_rn(__dmul_rn((double)(r >> 11), 1.0 / 9007199254740992.0), total);
     double acc = 0.0;
     for (uint64_t i = 0; i < deg; ++i) {
-        const uint32_t x = g.col_idx[start + i];
         const double w = __dsub_rn((double)g.cumw[start + i],
                                    i ? (double)g.cumw[start + i - 1] : 0.0);
-        const uint64_t thr = class_threshold(g, c, x, prev, pstart, pend);
+        const uint64_t thr = accept_threshold(g, c, cur, g.col_idx[start + i], start + i, prev,
+                                              pstart, pend, ptype);
         acc = __dadd_rn(acc, __dmul_rn(w, (double)thr));
-        if (acc > target) return x;
+        if (acc > target) return i;
     }
-    return g.col_idx[start + deg - 1];
+    return deg - 1;
 }
 
 // One lane = one walker.  Output row-major u32[n_walks][walk_length]; every 16 steps a wave
@@ -127,7 +151,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
     const uint32_t L = c.walk_length;
 
     uint64_t wkey = 0, ctr = 0;
-    uint32_t cur = kSentinel, prev = kSentinel;
+    uint32_t cur = kSentinel, prev = kSentinel, ptype = 0;
     uint64_t pstart = 0, pend = 0;
     if (live) {
         const uint64_t wid = first_walk + b;
@@ -152,28 +176,33 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                 if (deg == 0) {
                     dead = true;
                 } else {
-                    uint32_t nxt;
-                    if (!c.second_order || prev == kSentinel || deg == 1) {
+                    uint64_t idx;
+                    const bool biased =
+                        c.node_bias || (prev != kSentinel && (c.second_order || c.edge_bias));
+                    if (!biased || deg == 1) {
                         const uint64_t r = draw(wkey, ctr++);
-                        nxt = g.col_idx[start + pick_index(g, start, deg, r)];
+                        idx = pick_index(g, start, deg, r);
                     } else {
                         bool accepted = false;
-                        nxt = 0;
+                        idx = 0;
                         for (int trial = 0; trial < kMaxTrials; ++trial) {
                             const uint64_t r = draw(wkey, ctr++);
-                            const uint32_t x = g.col_idx[start + pick_index(g, start, deg, r)];
-                            const uint64_t thr = class_threshold(g, c, x, prev, pstart, pend);
+                            const uint64_t i = pick_index(g, start, deg, r);
+                            const uint64_t thr = accept_threshold(
+                                g, c, cur, g.col_idx[start + i], start + i, prev, pstart, pend, ptype);
                             if ((r & 0xFFFFFFFFULL) < thr) {
-                                nxt = x;
+                                idx = i;
                                 accepted = true;
                                 break;
                             }
                         }
                         if (!accepted) {
                             const uint64_t r = draw(wkey, ctr++);
-                            nxt = exact_scan(g, c, r, start, deg, prev, pstart, pend);
+                            idx = exact_scan(g, c, r, cur, start, deg, prev, pstart, pend, ptype);
                         }
                     }
+                    const uint32_t nxt = g.col_idx[start + idx];
+                    if (c.edge_bias) ptype = g.edge_types[start + idx];
                     val = nxt;
                     prev = cur;
                     pstart = start;

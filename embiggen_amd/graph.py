@@ -8,9 +8,12 @@ back-ends (embedders/pecanpy_embedders/node2vec.py:139-163): ``row_ptr`` = zero-
 cumulative node degrees, ``col_idx`` = directed destination ids, optional positive edge weights.
 
 Layout: ``row_ptr`` u64[N+1], ``col_idx`` u32[E_directed] with neighbours ascending and unique
-per row, ``cumw`` f32[E] per-row inclusive prefix sums of the weights (weighted graphs only),
-``sources`` u32 = nodes with out-degree > 0.  Arrays live either on the host (numpy) or, for the
-large synthetic graphs, directly in HBM (torch tensors, never copied back).
+per row (typed multigraphs list a neighbour once per edge type), ``cumw`` f32[E] per-row inclusive
+prefix sums of the weights (weighted graphs only), ``sources`` u32 = nodes with out-degree > 0,
+optional ``node_type_ids`` u32[N] / ``edge_type_ids`` u32[E] (equal id = same type, 0xFFFFFFFF =
+unknown; they only feed ``change_node_type_weight`` / ``change_edge_type_weight`` of the walks).
+Arrays live either on the host (numpy) or, for the large synthetic graphs, directly in HBM (torch
+tensors, never copied back).
 """
 import ctypes as C
 import os
@@ -23,6 +26,34 @@ from . import _lib
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 _HANDLE_LOCK = threading.Lock()
+UNKNOWN_TYPE = 0xFFFFFFFF
+
+
+def _canonical_type_ids(labels, count: int, what: str):
+    """Labels (None = unknown, a hashable, or a list / tuple / set of hashables for multi-label
+    nodes) -> (u32 ids, names): one id per distinct label set, ids ordered by first appearance.
+    Walks only compare types for equality, so a label set is one type."""
+    if len(labels) != count:
+        raise ValueError(f"{what} must have one entry per {what.split('_')[0]}.")
+    ids = np.empty(count, dtype=np.uint32)
+    table, names = {}, []
+    for i, label in enumerate(labels):
+        if label is None:
+            ids[i] = UNKNOWN_TYPE
+            continue
+        if isinstance(label, (list, tuple, set, frozenset, np.ndarray)):
+            key = tuple(sorted(set(label.tolist() if isinstance(label, np.ndarray) else label),
+                               key=repr))
+            if not key:
+                ids[i] = UNKNOWN_TYPE
+                continue
+        else:
+            key = (label.item() if isinstance(label, np.generic) else label,)
+        if key not in table:
+            table[key] = len(names)
+            names.append(key[0] if len(key) == 1 else key)
+        ids[i] = table[key]
+    return ids, names
 
 
 class DeviceGraph:
@@ -47,12 +78,16 @@ class DeviceGraph:
 
 class CSRGraph:
     def __init__(self, row_ptr, col_idx, weights=None, node_names: Optional[List[str]] = None,
-                 name: str = "Graph", directed: bool = False, _device_tensors=None):
+                 name: str = "Graph", directed: bool = False, _device_tensors=None,
+                 node_type_ids=None, edge_type_ids=None, node_type_names=None,
+                 edge_type_names=None):
         self._name = name
         self._directed = directed
         self._node_names = node_names
         self._device_tensors = _device_tensors  # dict of torch cuda tensors or None
         self._handles = {}
+        self._node_type_ids = self._edge_type_ids = None
+        self._node_type_names, self._edge_type_names = node_type_names, edge_type_names
         if _device_tensors is not None:
             self._row_ptr = self._col_idx = self._weights = self._cumw = None
             self._n_nodes = int(_device_tensors["row_ptr"].numel()) - 1
@@ -85,13 +120,61 @@ class CSRGraph:
         self._n_sources = len(self._sources)
         if node_names is not None and len(node_names) != self._n_nodes:
             raise ValueError("node_names must have one entry per node.")
+        if node_type_ids is not None:
+            self._node_type_ids = np.ascontiguousarray(node_type_ids, dtype=np.uint32)
+            if len(self._node_type_ids) != self._n_nodes:
+                raise ValueError("node_type_ids must have one entry per node.")
+        if edge_type_ids is not None:
+            self._edge_type_ids = np.ascontiguousarray(edge_type_ids, dtype=np.uint32)
+            if len(self._edge_type_ids) != self._n_edges:
+                raise ValueError("edge_type_ids must have one entry per directed edge.")
 
     # ------------------------------------------------------------------ constructors
+    @staticmethod
+    def _assemble(src, dst, w, etype, n: int, directed: bool):
+        """Edge list -> (row_ptr, cols, weights, edge type ids): undirected edges are stored in
+        both directions, neighbour lists sorted, duplicate (src, dst[, type]) edges collapsed
+        (weights of duplicates summed)."""
+        if not directed:
+            loops = src == dst
+            src, dst = np.concatenate([src, dst[~loops]]), np.concatenate([dst, src[~loops]])
+            if w is not None:
+                w = np.concatenate([w, w[~loops]])
+            if etype is not None:
+                etype = np.concatenate([etype, etype[~loops]])
+        if etype is None:
+            key = src * n + dst
+        else:
+            order = np.lexsort((etype, dst, src))
+            src, dst, etype = src[order], dst[order], etype[order]
+            if w is not None:
+                w = w[order]
+            new = np.ones(len(src), dtype=bool)
+            new[1:] = (src[1:] != src[:-1]) | (dst[1:] != dst[:-1]) | (etype[1:] != etype[:-1])
+            key = np.cumsum(new) - 1  # already sorted: unique() keeps this order
+        if w is None:
+            key, first = np.unique(key, return_index=True)
+        else:
+            key, first, inv = np.unique(key, return_index=True, return_inverse=True)
+            w = np.bincount(inv, weights=w, minlength=len(key))
+        if etype is None:
+            rows = key // max(n, 1)
+            cols = key - rows * n
+        else:
+            rows, cols, etype = src[first], dst[first], etype[first].astype(np.uint32)
+        row_ptr = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.bincount(rows, minlength=n), out=row_ptr[1:])
+        return row_ptr, cols.astype(np.uint32), w, etype
+
     @classmethod
     def from_edge_list(cls, sources, destinations, weights=None, number_of_nodes=None,
-                       directed: bool = False, node_names=None, name: str = "Graph"):
+                       directed: bool = False, node_names=None, name: str = "Graph",
+                       node_types=None, edge_types=None):
         """Build from an edge list; undirected edges are stored in both directions, neighbour
-        lists are sorted and duplicate edges collapsed (weights of duplicates are summed)."""
+        lists are sorted and duplicate edges collapsed (weights of duplicates are summed).
+        ``node_types``: one label per node (None = unknown; a list of labels for multi-label
+        nodes).  ``edge_types``: one label per listed edge (None = unknown); parallel edges of
+        different types are kept (multigraph), as in ensmallen."""
         src = np.asarray(sources, dtype=np.int64).ravel()
         dst = np.asarray(destinations, dtype=np.int64).ravel()
         if src.shape != dst.shape:
@@ -105,30 +188,23 @@ class CSRGraph:
         if len(src) and (src.min() < 0 or dst.min() < 0 or max(src.max(), dst.max()) >= n):
             raise ValueError("Edge list contains node ids outside [0, number_of_nodes).")
         w = None if weights is None else np.asarray(weights, dtype=np.float64).ravel()
-        if not directed:
-            loops = src == dst
-            s2 = np.concatenate([src, dst[~loops]])
-            d2 = np.concatenate([dst, src[~loops]])
-            if w is not None:
-                w = np.concatenate([w, w[~loops]])
-            src, dst = s2, d2
-        key = src * n + dst
-        if w is None:
-            key = np.unique(key)
-        else:
-            key, inv = np.unique(key, return_inverse=True)
-            w = np.bincount(inv, weights=w, minlength=len(key))
-        rows = key // max(n, 1)
-        cols = key - rows * n
-        row_ptr = np.zeros(n + 1, dtype=np.uint64)
-        np.cumsum(np.bincount(rows, minlength=n), out=row_ptr[1:])
-        return cls(row_ptr, cols.astype(np.uint32), w, node_names, name, directed)
+        nt_ids = nt_names = et = et_names = None
+        if node_types is not None:
+            nt_ids, nt_names = _canonical_type_ids(list(node_types), n, "node_types")
+        if edge_types is not None:
+            et, et_names = _canonical_type_ids(list(edge_types), len(src), "edge_types")
+            et = et.astype(np.int64)
+        row_ptr, cols, w, et = cls._assemble(src, dst, w, et, n, directed)
+        return cls(row_ptr, cols, w, node_names, name, directed, node_type_ids=nt_ids,
+                   edge_type_ids=et, node_type_names=nt_names, edge_type_names=et_names)
 
     @classmethod
     def from_csr(cls, row_ptr, col_idx, weights=None, node_names=None, name: str = "Graph",
-                 directed: bool = False):
-        """Wrap existing CSR arrays (neighbours must be ascending and unique per row)."""
-        return cls(row_ptr, col_idx, weights, node_names, name, directed)
+                 directed: bool = False, node_type_ids=None, edge_type_ids=None):
+        """Wrap existing CSR arrays (neighbours must be ascending per row, and unique unless
+        parallel edges of different types are meant)."""
+        return cls(row_ptr, col_idx, weights, node_names, name, directed,
+                   node_type_ids=node_type_ids, edge_type_ids=edge_type_ids)
 
     @classmethod
     def from_networkx(cls, graph, weight: Optional[str] = None, name: Optional[str] = None):
@@ -155,8 +231,17 @@ class CSRGraph:
         row_ptr[1:] = graph.get_cumulative_node_degrees().astype(np.uint64)
         col_idx = graph.get_directed_destination_node_ids().astype(np.uint32)
         weights = graph.get_directed_edge_weights() if graph.has_edge_weights() else None
+        nt_ids = nt_names = et_ids = None
+        if getattr(graph, "has_node_types", lambda: False)():
+            # one entry per node: None or the array of its node type ids
+            nt_ids, nt_names = _canonical_type_ids(list(graph.get_node_type_ids()), n,
+                                                   "node_types")
+        if getattr(graph, "has_edge_types", lambda: False)():
+            raw = graph.get_directed_edge_type_ids()  # one entry per directed edge, None = unknown
+            et_ids = np.array([UNKNOWN_TYPE if t is None else int(t) for t in raw], dtype=np.uint32)
         return cls(row_ptr, col_idx, weights, list(graph.get_node_names()), graph.get_name(),
-                   graph.is_directed())
+                   graph.is_directed(), node_type_ids=nt_ids, edge_type_ids=et_ids,
+                   node_type_names=nt_names)
 
     # ------------------------------------------------------------------ ensmallen.Graph getters
     def get_name(self) -> str:
@@ -187,13 +272,60 @@ class CSRGraph:
         return self._node_names
 
     def has_node_types(self) -> bool:
-        return False
+        return self.node_type_ids is not None
 
     def get_number_of_node_types(self) -> int:
-        return 0
+        """Distinct known node types (a multi-label set counts as one type here)."""
+        return self._count_types(self.node_type_ids)
 
     def has_edge_types(self) -> bool:
-        return False
+        return self.edge_type_ids is not None
+
+    def get_number_of_edge_types(self) -> int:
+        return self._count_types(self.edge_type_ids)
+
+    @staticmethod
+    def _count_types(ids) -> int:
+        if ids is None:
+            return 0
+        known = ids[ids != UNKNOWN_TYPE]
+        return int(len(np.unique(known)))
+
+    def is_multigraph(self) -> bool:
+        """True when some row lists the same neighbour more than once (parallel typed edges)."""
+        col, rp = self.col_idx, self.row_ptr.astype(np.int64)
+        if len(col) < 2:
+            return False
+        same = col[1:] == col[:-1]
+        same[rp[1:-1][(rp[1:-1] > 0) & (rp[1:-1] < len(col))] - 1] = False  # row boundaries
+        return bool(same.any())
+
+    def get_node_type_names(self):
+        return self._node_type_names
+
+    def get_edge_type_names(self):
+        return self._edge_type_names
+
+    def with_types(self, node_type_ids=None, edge_type_ids=None) -> "CSRGraph":
+        """Same graph (arrays shared) with the given type ids attached: u32 arrays, or device
+        tensors (int32) for a device-resident graph."""
+        if self._device_tensors is not None:
+            t = dict(self._device_tensors)
+            for key, ids, count in (("node_types", node_type_ids, self._n_nodes),
+                                    ("edge_types", edge_type_ids, self._n_edges)):
+                if ids is not None:
+                    if ids.numel() != count or ids.device != t["row_ptr"].device:
+                        raise ValueError(f"{key} must be a device tensor with {count} entries.")
+                    t[key] = ids.contiguous()
+            g = CSRGraph(None, None, name=self._name, directed=self._directed, _device_tensors=t)
+            g._node_names = self._node_names
+            return g
+        return CSRGraph(self._row_ptr, self._col_idx, self._weights, self._node_names, self._name,
+                        self._directed,
+                        node_type_ids=self._node_type_ids if node_type_ids is None else node_type_ids,
+                        edge_type_ids=self._edge_type_ids if edge_type_ids is None else edge_type_ids,
+                        node_type_names=self._node_type_names if node_type_ids is None else None,
+                        edge_type_names=self._edge_type_names if edge_type_ids is None else None)
 
     def has_edge_weights(self) -> bool:
         return self._weights is not None or (
@@ -246,13 +378,17 @@ class CSRGraph:
         new_of_old[order] = np.arange(self._n_nodes)
         src_old = np.repeat(np.arange(self._n_nodes), deg)
         names = self._node_names
-        g = CSRGraph.from_edge_list(
-            new_of_old[src_old], new_of_old[self._col_idx.astype(np.int64)], self._weights,
-            number_of_nodes=self._n_nodes, directed=True,
-            node_names=None if names is None else [names[i] for i in order], name=self._name,
-        )
-        g._directed = self._directed
-        return g
+        w = None if self._weights is None else self._weights.astype(np.float64)
+        et = None if self._edge_type_ids is None else self._edge_type_ids.astype(np.int64)
+        row_ptr, cols, w, et = CSRGraph._assemble(
+            new_of_old[src_old], new_of_old[self._col_idx.astype(np.int64)], w, et,
+            self._n_nodes, True)
+        return CSRGraph(
+            row_ptr, cols, w, None if names is None else [names[i] for i in order], self._name,
+            self._directed,
+            node_type_ids=None if self._node_type_ids is None else self._node_type_ids[order],
+            edge_type_ids=et, node_type_names=self._node_type_names,
+            edge_type_names=self._edge_type_names)
 
     def with_degree_normalized_weights(self) -> "CSRGraph":
         """Same graph with every edge weight divided by the degree of its destination node: the
@@ -280,7 +416,10 @@ class CSRGraph:
             base = np.ones(self._n_edges) if self._weights is None else self._weights.astype(np.float64)
             w = base / np.maximum(deg[self._col_idx.astype(np.int64)], 1.0)
             g = CSRGraph(self._row_ptr, self._col_idx, w, self._node_names, self._name,
-                         self._directed)
+                         self._directed, node_type_ids=self._node_type_ids,
+                         edge_type_ids=self._edge_type_ids,
+                         node_type_names=self._node_type_names,
+                         edge_type_names=self._edge_type_names)
         self._degree_normalized = g
         return g
 
@@ -302,6 +441,20 @@ class CSRGraph:
         if self._cumw is None and self._device_tensors is not None and "cumw" in self._device_tensors:
             self._cumw = self._device_tensors["cumw"].cpu().numpy()
         return self._cumw
+
+    @property
+    def node_type_ids(self) -> Optional[np.ndarray]:
+        if (self._node_type_ids is None and self._device_tensors is not None
+                and "node_types" in self._device_tensors):
+            self._node_type_ids = self._device_tensors["node_types"].cpu().numpy().view(np.uint32)
+        return self._node_type_ids
+
+    @property
+    def edge_type_ids(self) -> Optional[np.ndarray]:
+        if (self._edge_type_ids is None and self._device_tensors is not None
+                and "edge_types" in self._device_tensors):
+            self._edge_type_ids = self._device_tensors["edge_types"].cpu().numpy().view(np.uint32)
+        return self._edge_type_ids
 
     @property
     def sources(self) -> Optional[np.ndarray]:
@@ -336,6 +489,10 @@ class CSRGraph:
                 None if src is None else src.data_ptr(), self._n_nodes, self._n_edges,
                 self._n_sources, _lib.GRAPH_DEVICE_PTRS, device, C.byref(handle)))
             dg = DeviceGraph(handle, device, keep_alive=(t,))
+            nt, et = t.get("node_types"), t.get("edge_types")
+            if nt is not None or et is not None:
+                _lib.check(L.gn2v_graph_set_types(handle, None if nt is None else nt.data_ptr(),
+                                                  None if et is None else et.data_ptr()))
         else:
             srcs = self.sources
             _lib.check(L.gn2v_graph_create(
@@ -344,6 +501,10 @@ class CSRGraph:
                 None if srcs is None else srcs.ctypes.data, self._n_nodes, self._n_edges,
                 self._n_sources, 0, device, C.byref(handle)))
             dg = DeviceGraph(handle, device)
+            nt, et = self._node_type_ids, self._edge_type_ids
+            if nt is not None or et is not None:
+                _lib.check(L.gn2v_graph_set_types(handle, None if nt is None else nt.ctypes.data,
+                                                  None if et is None else et.ctypes.data))
         self._handles[device] = dg
         return dg
 

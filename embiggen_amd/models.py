@@ -82,11 +82,9 @@ class _WalkBasedModel:
             raise ValueError("clipping_value must be strictly positive.")
         if dtype != "f32":
             raise ValueError(f"Only dtype 'f32' is supported by the gn2v engine, got {dtype!r}.")
-        if change_node_type_weight != 1.0 or change_edge_type_weight != 1.0:
-            raise NotImplementedError(
-                "Node/edge type transition weights need typed graphs, which the gn2v engine "
-                "does not model yet."
-            )
+        if not (change_node_type_weight > 0 and change_edge_type_weight > 0):
+            raise ValueError(
+                "change_node_type_weight and change_edge_type_weight must be strictly positive.")
         self.embedding_size = embedding_size
         self.random_state = int(random_state)
         self.epochs = epochs
@@ -97,6 +95,10 @@ class _WalkBasedModel:
         self.window_size = window_size
         self.return_weight = float(return_weight)
         self.explore_weight = float(explore_weight)
+        # act on graphs that carry node / edge types, no impact otherwise
+        # (node2vec_sequence.py:57-66)
+        self.change_node_type_weight = float(change_node_type_weight)
+        self.change_edge_type_weight = float(change_edge_type_weight)
         self.max_neighbours = max_neighbours
         self.learning_rate = float(learning_rate)
         self.learning_rate_decay = float(learning_rate_decay)
@@ -133,6 +135,7 @@ class _WalkBasedModel:
         return _lib.WalkParams(
             self.walk_length, self.iterations, self.return_weight, self.explore_weight,
             0 if self.max_neighbours is None else int(self.max_neighbours), 0,
+            self.change_node_type_weight, self.change_edge_type_weight,
         )
 
     def train_params(self) -> _lib.TrainParams:

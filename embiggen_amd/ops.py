@@ -23,9 +23,15 @@ def _stream(device):
 
 
 def walk_params(walk_length: int, iterations: int = 1, return_weight: float = 1.0,
-                explore_weight: float = 1.0, max_neighbours: Optional[int] = 100):
+                explore_weight: float = 1.0, max_neighbours: Optional[int] = 100,
+                change_node_type_weight: float = 1.0, change_edge_type_weight: float = 1.0):
+    for name, value in (("change_node_type_weight", change_node_type_weight),
+                        ("change_edge_type_weight", change_edge_type_weight)):
+        if not value > 0.0:  # 0 means "unset" only at the C boundary
+            raise ValueError(f"{name} must be strictly positive, got {value}.")
     return _lib.WalkParams(walk_length, iterations, return_weight, explore_weight,
-                           0 if max_neighbours is None else max_neighbours, 0)
+                           0 if max_neighbours is None else max_neighbours, 0,
+                           change_node_type_weight, change_edge_type_weight)
 
 
 def train_params(model: int, d: int, k: int, window: int, lr: float = 0.01,

@@ -37,8 +37,9 @@ class Node2VecSequence:
     ):
         if walk_length <= 2 * window_size:
             raise ValueError("walk_length must exceed 2 * window_size.")
-        if change_node_type_weight != 1.0 or change_edge_type_weight != 1.0:
-            raise NotImplementedError("Typed graphs are not modelled by the gn2v engine yet.")
+        if not (change_node_type_weight > 0 and change_edge_type_weight > 0):
+            raise ValueError(
+                "change_node_type_weight and change_edge_type_weight must be strictly positive.")
         self._graph = graph
         self._walk_length = walk_length
         self._batch_size = batch_size
@@ -46,6 +47,8 @@ class Node2VecSequence:
         self._window_size = window_size
         self._return_weight = return_weight
         self._explore_weight = explore_weight
+        self._change_node_type_weight = change_node_type_weight
+        self._change_edge_type_weight = change_edge_type_weight
         self._max_neighbours = max_neighbours
         self._random_state = random_state
         self._device = device
@@ -90,7 +93,8 @@ class Node2VecSequence:
         import torch
 
         wp = ops.walk_params(self._walk_length, self._iterations, self._return_weight,
-                             self._explore_weight, self._max_neighbours)
+                             self._explore_weight, self._max_neighbours,
+                             self._change_node_type_weight, self._change_edge_type_weight)
         seed = self._random_state + idx + self.elapsed_epochs
         first_source = (idx * self._batch_size) % self._sample_number
         parts = [

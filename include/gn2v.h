@@ -66,6 +66,11 @@ typedef struct {
     float explore_weight;    /* 1/q                                                */
     uint32_t max_neighbours; /* accepted; walks are exact regardless   */
     uint32_t flags;          /* reserved                                           */
+    /* node2vec_skipgram.py:72-77, node2vec_sequence.py:57-66.  0 = unset = 1.0.  "Only applies
+     * to colored graphs / multigraphs, otherwise it has no impact": they act only when the
+     * matching type array was attached with gn2v_graph_set_types. */
+    float change_node_type_weight; /* x weight of an edge to a node of another type than the current */
+    float change_edge_type_weight; /* x weight of an edge of another type than the previous edge   */
 } gn2v_walk_params;
 
 typedef struct {
@@ -113,6 +118,14 @@ int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const fl
                       const uint32_t *sources, uint64_t n_nodes, uint64_t n_edges,
                       uint64_t n_sources, uint32_t flags, int device, gn2v_graph **out);
 int gn2v_graph_destroy(gn2v_graph *g);
+
+/* Attach node types u32[n_nodes] and / or edge types u32[n_edges] (aligned with col_idx; a row of
+ * a multigraph lists the same neighbour once per edge type).  Equal ids = same type; multi-label
+ * nodes get one id per distinct label set; unknown = 0xFFFFFFFF.  NULL leaves that kind untyped
+ * (detaches it).  Pointer kind (host: copied / device: borrowed) follows the flags given to
+ * gn2v_graph_create.  The ensmallen.Graph argument carries these (has_node_types /
+ * has_edge_types, abstract_model.py:329-350); used by change_*_type_weight only. */
+int gn2v_graph_set_types(gn2v_graph *g, const uint32_t *node_types, const uint32_t *edge_types);
 
 /* Seeded Barabasi-Albert edge list on the device: (n_nodes-1)*m edges (src > dst). */
 int gn2v_ba_edges(uint64_t n_nodes, uint32_t m, uint64_t seed, uint32_t *d_src, uint32_t *d_dst,

@@ -57,6 +57,8 @@ typedef struct {
     float explore_weight;
     uint32_t max_neighbours; /* accepted for API parity; walks are always exact */
     uint32_t flags;
+    float change_node_type_weight; /* 0 = unset = 1.0; only acts on graphs with node types */
+    float change_edge_type_weight; /* 0 = unset = 1.0; only acts on graphs with edge types */
 } o_walk_params;
 
 typedef struct {
@@ -80,6 +82,8 @@ typedef struct {
     const uint64_t *row_ptr;
     const uint32_t *col_idx;
     const float *cumw; /* per-row inclusive prefix sums of weights, or NULL */
+    const uint32_t *node_types; /* one id per node (0xFFFFFFFF = unknown), or NULL */
+    const uint32_t *edge_types; /* one id per directed edge, aligned with col_idx, or NULL */
 } o_graph;
 
 /* General step I/O (mirrors gn2v_step_io): walk nodes may live in row caches, negatives in a
@@ -163,16 +167,64 @@ static inline int adj_contains(const uint32_t *col, uint64_t lo, uint64_t hi, ui
     return lo < end && col[lo] == x;
 }
 
-/* integer acceptance thresholds on a 2^32 scale */
-static void thresholds(const o_walk_params *wp, uint64_t *t_ret, uint64_t *t_common,
-                       uint64_t *t_explore) {
+/* Integer acceptance thresholds on a 2^32 scale.  A candidate edge cur -> x carries the product
+ * of three factors, each normalised by its own maximum:
+ *   second order  {return_weight (x == prev), 1 (x adjacent to prev), explore_weight (else)}
+ *   node type     change_node_type_weight when type(x) != type(cur)          (typed nodes only)
+ *   edge type     change_edge_type_weight when type(cur->x) != type(prev->cur) (typed edges only)
+ * Semantics of the two type weights: node2vec_sequence.py:57-66 ("weight on the probability of
+ * visiting a neighbor node / edge of a different type than the previous node / edge; only applies
+ * to colored graphs / multigraphs, otherwise it has no impact"). */
+typedef struct {
+    int second, node_bias, edge_bias;
+    uint64_t t_ret, t_common, t_explore;
+    uint64_t fn_same, fn_diff, fe_same, fe_diff;
+} walk_consts;
+
+static void type_factors(float weight, uint64_t *same, uint64_t *diff) {
+    double w = weight == 0.0f ? 1.0 : (double)weight;
+    double mx = w > 1.0 ? w : 1.0;
+    double s = 4294967296.0;
+    *same = (uint64_t)floor(1.0 / mx * s);
+    *diff = (uint64_t)floor(w / mx * s);
+}
+
+static walk_consts make_walk_consts(const o_graph *g, const o_walk_params *wp) {
+    walk_consts c;
     double rw = wp->return_weight, ew = wp->explore_weight;
     double mx = rw > ew ? rw : ew;
     if (mx < 1.0) mx = 1.0;
     double s = 4294967296.0;
-    *t_ret = (uint64_t)floor(rw / mx * s);
-    *t_common = (uint64_t)floor(1.0 / mx * s);
-    *t_explore = (uint64_t)floor(ew / mx * s);
+    c.second = !(wp->return_weight == 1.0f && wp->explore_weight == 1.0f);
+    c.t_ret = (uint64_t)floor(rw / mx * s);
+    c.t_common = (uint64_t)floor(1.0 / mx * s);
+    c.t_explore = (uint64_t)floor(ew / mx * s);
+    type_factors(wp->change_node_type_weight, &c.fn_same, &c.fn_diff);
+    type_factors(wp->change_edge_type_weight, &c.fe_same, &c.fe_diff);
+    c.node_bias = g->node_types != NULL && c.fn_same != c.fn_diff;
+    c.edge_bias = g->edge_types != NULL && c.fe_same != c.fe_diff;
+    return c;
+}
+
+/* t * f / 2^32 with t <= 2^32 and f <= 2^32 (f == 2^32 is the identity) */
+static inline uint64_t scale32(uint64_t t, uint64_t f) {
+    return f >= (1ULL << 32) ? t : (t * f) >> 32;
+}
+
+/* acceptance threshold of candidate edge `e` = cur -> x */
+static inline uint64_t accept_threshold(const o_graph *g, const walk_consts *c, uint32_t cur,
+                                        uint32_t x, uint64_t e, uint32_t prev, uint64_t pstart,
+                                        uint64_t pend, uint32_t ptype) {
+    uint64_t t = 1ULL << 32;
+    if (c->second && prev != O_SENTINEL)
+        t = (x == prev) ? c->t_ret
+            : adj_contains(g->col_idx, pstart, pend, x) ? c->t_common
+                                                        : c->t_explore;
+    if (c->node_bias)
+        t = scale32(t, g->node_types[cur] != g->node_types[x] ? c->fn_diff : c->fn_same);
+    if (c->edge_bias && prev != O_SENTINEL)
+        t = scale32(t, g->edge_types[e] != ptype ? c->fe_diff : c->fe_same);
+    return t;
 }
 
 /* candidate index within the row of `cur` (uniform, or weight proportional via cumw) */
@@ -191,14 +243,51 @@ static inline uint64_t pick_index(const o_graph *g, uint64_t start, uint64_t deg
     return lo < deg ? lo : deg - 1;
 }
 
+/* exact fallback after O_MAX_TRIALS rejections: integer-weighted scan over the whole row
+ * (unweighted graphs); weighted graphs scale each threshold by the edge weight in double.
+ * Returns the index of the chosen edge inside the row. */
+static uint64_t exact_scan(const o_graph *g, const walk_consts *c, uint64_t r, uint32_t cur,
+                           uint64_t start, uint64_t deg, uint32_t prev, uint64_t pstart,
+                           uint64_t pend, uint32_t ptype) {
+    if (g->cumw == NULL) {
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < deg; ++i)
+            total += accept_threshold(g, c, cur, g->col_idx[start + i], start + i, prev, pstart,
+                                      pend, ptype);
+        if (total == 0) return ((r >> 32) * deg) >> 32;
+        uint64_t target = mulhi64(r, total), acc = 0;
+        for (uint64_t i = 0; i < deg; ++i) {
+            acc += accept_threshold(g, c, cur, g->col_idx[start + i], start + i, prev, pstart,
+                                    pend, ptype);
+            if (acc > target) return i;
+        }
+        return deg - 1;
+    }
+    double total = 0.0;
+    for (uint64_t i = 0; i < deg; ++i) {
+        double w = (double)g->cumw[start + i] - (i ? (double)g->cumw[start + i - 1] : 0.0);
+        uint64_t thr = accept_threshold(g, c, cur, g->col_idx[start + i], start + i, prev,
+                                        pstart, pend, ptype);
+        total += w * (double)thr;
+    }
+    double target = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
+    double acc = 0.0;
+    for (uint64_t i = 0; i < deg; ++i) {
+        double w = (double)g->cumw[start + i] - (i ? (double)g->cumw[start + i - 1] : 0.0);
+        uint64_t thr = accept_threshold(g, c, cur, g->col_idx[start + i], start + i, prev,
+                                        pstart, pend, ptype);
+        acc += w * (double)thr;
+        if (acc > target) return i;
+    }
+    return deg - 1;
+}
+
 void o_walk_one(const o_graph *g, const o_walk_params *wp, uint64_t wkey, uint32_t start_node,
                 uint32_t *out) {
     uint32_t L = wp->walk_length;
-    int second = !(wp->return_weight == 1.0f && wp->explore_weight == 1.0f);
-    uint64_t t_ret, t_common, t_explore;
-    thresholds(wp, &t_ret, &t_common, &t_explore);
+    walk_consts c = make_walk_consts(g, wp);
     uint64_t ctr = 0;
-    uint32_t cur = start_node, prev = O_SENTINEL;
+    uint32_t cur = start_node, prev = O_SENTINEL, ptype = 0;
     uint64_t pstart = 0, pend = 0;
     out[0] = cur;
     uint32_t t = 1;
@@ -206,83 +295,32 @@ void o_walk_one(const o_graph *g, const o_walk_params *wp, uint64_t wkey, uint32
         uint64_t start = g->row_ptr[cur], end = g->row_ptr[cur + 1];
         uint64_t deg = end - start;
         if (deg == 0) break;
-        uint32_t nxt;
-        if (!second || prev == O_SENTINEL || deg == 1) {
+        uint64_t idx;
+        int biased = c.node_bias || (prev != O_SENTINEL && (c.second || c.edge_bias));
+        if (!biased || deg == 1) {
             uint64_t r = o_draw(wkey, ctr++);
-            nxt = g->col_idx[start + pick_index(g, start, deg, r)];
+            idx = pick_index(g, start, deg, r);
         } else {
             int accepted = 0;
-            nxt = 0;
+            idx = 0;
             for (int trial = 0; trial < O_MAX_TRIALS; ++trial) {
                 uint64_t r = o_draw(wkey, ctr++);
-                uint32_t x = g->col_idx[start + pick_index(g, start, deg, r)];
-                uint64_t thr = (x == prev) ? t_ret
-                               : adj_contains(g->col_idx, pstart, pend, x) ? t_common
-                                                                           : t_explore;
+                uint64_t i = pick_index(g, start, deg, r);
+                uint64_t thr = accept_threshold(g, &c, cur, g->col_idx[start + i], start + i,
+                                                prev, pstart, pend, ptype);
                 if ((r & 0xFFFFFFFFULL) < thr) {
-                    nxt = x;
+                    idx = i;
                     accepted = 1;
                     break;
                 }
             }
             if (!accepted) {
-                /* exact fallback: integer-weighted scan over the whole row (unweighted graphs);
-                 * weighted graphs scale each class threshold by the edge weight in double. */
                 uint64_t r = o_draw(wkey, ctr++);
-                if (g->cumw == NULL) {
-                    uint64_t total = 0;
-                    for (uint64_t i = 0; i < deg; ++i) {
-                        uint32_t x = g->col_idx[start + i];
-                        total += (x == prev) ? t_ret
-                                 : adj_contains(g->col_idx, pstart, pend, x) ? t_common
-                                                                             : t_explore;
-                    }
-                    if (total == 0) {
-                        nxt = g->col_idx[start + (((r >> 32) * deg) >> 32)];
-                    } else {
-                        uint64_t target = mulhi64(r, total), acc = 0;
-                        nxt = g->col_idx[start + deg - 1];
-                        for (uint64_t i = 0; i < deg; ++i) {
-                            uint32_t x = g->col_idx[start + i];
-                            acc += (x == prev) ? t_ret
-                                   : adj_contains(g->col_idx, pstart, pend, x) ? t_common
-                                                                               : t_explore;
-                            if (acc > target) {
-                                nxt = x;
-                                break;
-                            }
-                        }
-                    }
-                } else {
-                    double total = 0.0;
-                    for (uint64_t i = 0; i < deg; ++i) {
-                        uint32_t x = g->col_idx[start + i];
-                        double w = (double)g->cumw[start + i] -
-                                   (i ? (double)g->cumw[start + i - 1] : 0.0);
-                        uint64_t thr = (x == prev) ? t_ret
-                                       : adj_contains(g->col_idx, pstart, pend, x) ? t_common
-                                                                                   : t_explore;
-                        total += w * (double)thr;
-                    }
-                    double target = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
-                    double acc = 0.0;
-                    nxt = g->col_idx[start + deg - 1];
-                    for (uint64_t i = 0; i < deg; ++i) {
-                        uint32_t x = g->col_idx[start + i];
-                        double w = (double)g->cumw[start + i] -
-                                   (i ? (double)g->cumw[start + i - 1] : 0.0);
-                        uint64_t thr = (x == prev) ? t_ret
-                                       : adj_contains(g->col_idx, pstart, pend, x) ? t_common
-                                                                                   : t_explore;
-                        acc += w * (double)thr;
-                        if (acc > target) {
-                            nxt = x;
-                            break;
-                        }
-                    }
-                }
+                idx = exact_scan(g, &c, r, cur, start, deg, prev, pstart, pend, ptype);
             }
         }
+        uint32_t nxt = g->col_idx[start + idx];
+        if (c.edge_bias) ptype = g->edge_types[start + idx];
         out[t] = nxt;
         prev = cur;
         pstart = start;

@@ -29,6 +29,8 @@ class WalkParams(C.Structure):
         ("explore_weight", C.c_float),
         ("max_neighbours", C.c_uint32),
         ("flags", C.c_uint32),
+        ("change_node_type_weight", C.c_float),  # 0 = unset = 1.0
+        ("change_edge_type_weight", C.c_float),
     ]
 
 
@@ -56,6 +58,8 @@ class Graph(C.Structure):
         ("row_ptr", C.c_void_p),
         ("col_idx", C.c_void_p),
         ("cumw", C.c_void_p),
+        ("node_types", C.c_void_p),
+        ("edge_types", C.c_void_p),
     ]
 
 
@@ -95,10 +99,14 @@ def _ptr(a):
 class OracleGraph:
     """Holds CSR arrays (kept alive) and the C struct that points at them."""
 
-    def __init__(self, row_ptr, col_idx, cumw=None):
+    def __init__(self, row_ptr, col_idx, cumw=None, node_types=None, edge_types=None):
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
         self.col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
         self.cumw = None if cumw is None else np.ascontiguousarray(cumw, dtype=np.float32)
+        self.node_types = (None if node_types is None
+                           else np.ascontiguousarray(node_types, dtype=np.uint32))
+        self.edge_types = (None if edge_types is None
+                           else np.ascontiguousarray(edge_types, dtype=np.uint32))
         self.n_nodes = len(self.row_ptr) - 1
         self.n_edges = len(self.col_idx)
         self.c = Graph(
@@ -107,6 +115,8 @@ class OracleGraph:
             self.row_ptr.ctypes.data,
             self.col_idx.ctypes.data,
             None if self.cumw is None else self.cumw.ctypes.data,
+            None if self.node_types is None else self.node_types.ctypes.data,
+            None if self.edge_types is None else self.edge_types.ctypes.data,
         )
 
 

@@ -47,6 +47,22 @@ int main(void) {
         o_walks(&g, &wp, sources, ns, 7, w, 0, ns * 3, walks);
         o_walks(&gw, &wp, sources, ns, 7, w, 0, ns * 3, walks);
     }
+    /* typed transitions, including weights small enough to reach the exact scan */
+    uint32_t ntype[N], etype[N * N];
+    for (int u = 0; u < N; ++u) ntype[u] = u % 5 == 4 ? 0xFFFFFFFFu : (uint32_t)(u % 3);
+    for (uint64_t i = 0; i < e; ++i) etype[i] = (uint32_t)((i * 7) % 4);
+    o_graph gt = {N, e, row_ptr, col, NULL, ntype, etype};
+    o_graph gtw = {N, e, row_ptr, col, cumw, ntype, etype};
+    const float tweights[3][2] = {{3.f, 0.25f}, {1e-5f, 1.f}, {1.f, 1e-5f}};
+    for (int w = 0; w < 3; ++w) {
+        o_walk_params wp = {20, 3, 0.5f, 2.f, 100, 0, tweights[w][0], tweights[w][1]};
+        o_walks(&gt, &wp, sources, ns, 9, w, 0, ns * 3, walks);
+        o_walks(&gtw, &wp, sources, ns, 9, w, 0, ns * 3, walks);
+    }
+    {
+        o_walk_params wp = {20, 3, 0.25f, 4.f, 100, 0};
+        o_walks(&g, &wp, sources, ns, 7, 1, 0, ns * 3, walks); /* walks used below */
+    }
     int32_t *ctx = malloc(sizeof(int32_t) * ns * 3 * 20 * 6), *words = malloc(sizeof(int32_t) * ns * 3 * 20);
     o_window_batch(walks, ns * 3, 20, 3, ctx, words);
     uint32_t *pairs = malloc(sizeof(uint32_t) * ns * 3 * 20 * 6 * 2);

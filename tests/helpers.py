@@ -135,3 +135,44 @@ def exact_second_order_probs(graph, prev: int, cur: int, return_weight: float,
         ew = graph.get_directed_edge_weights()[rp[cur]:rp[cur + 1]].astype(np.float64)
         w = w * ew
     return neigh, w / w.sum()
+
+
+def typed_karate():
+    """Karate Club with two node types (one multi-label, a few unknown) and three edge types
+    (symmetric: both directions of an edge carry the same type; some unknown)."""
+    import embiggen_amd as E
+
+    edges = np.loadtxt(os.path.join(ROOT, "embiggen_amd", "data", "karate.edges"), dtype=np.int64)
+    node_types = [None if v % 11 == 5 else (["club", "officer"] if v in (0, 33) else
+                                            ("mr_hi" if v < 17 else "club")) for v in range(34)]
+    edge_types = [None if (a * 7 + b) % 13 == 0 else ("abc"[(a * 5 + b * 3) % 3])
+                  for a, b in edges]
+    return E.CSRGraph.from_edge_list(edges[:, 0], edges[:, 1], number_of_nodes=34,
+                                     name="TypedKarate", node_types=node_types,
+                                     edge_types=edge_types)
+
+
+def exact_typed_probs(graph, prev, cur: int, return_weight: float, explore_weight: float,
+                      change_node_type_weight: float = 1.0, change_edge_type_weight: float = 1.0):
+    """Exact transition distribution out of `cur` (previous node `prev`, or None at the first
+    step) on a simple graph with optional node / edge types: product of the second-order factor,
+    change_node_type_weight when the neighbour's type differs from cur's, change_edge_type_weight
+    when the edge's type differs from the type of the edge prev -> cur, and the edge weight."""
+    rp = graph.row_ptr.astype(np.int64)
+    lo, hi = rp[cur], rp[cur + 1]
+    neigh = graph.col_idx[lo:hi]
+    w = np.ones(len(neigh), dtype=np.float64)
+    if prev is not None:
+        prow = graph.col_idx[rp[prev]:rp[prev + 1]]
+        prev_neigh = set(prow.tolist())
+        w *= np.array([return_weight if x == prev else
+                       (1.0 if int(x) in prev_neigh else explore_weight) for x in neigh])
+        if graph.edge_type_ids is not None:
+            ptype = graph.edge_type_ids[rp[prev] + int(np.flatnonzero(prow == cur)[0])]
+            w *= np.where(graph.edge_type_ids[lo:hi] != ptype, change_edge_type_weight, 1.0)
+    if graph.node_type_ids is not None:
+        nt = graph.node_type_ids
+        w *= np.where(nt[neigh.astype(np.int64)] != nt[cur], change_node_type_weight, 1.0)
+    if graph.cumw is not None:
+        w = w * graph.get_directed_edge_weights()[lo:hi].astype(np.float64)
+    return neigh, w / w.sum()

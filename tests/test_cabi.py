@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.WalkParams) == 24
+    assert C.sizeof(_lib.WalkParams) == 32
     assert C.sizeof(_lib.TrainParams) == 48
     assert C.sizeof(_lib.Stats) == 48
     text = open(HEADER).read()

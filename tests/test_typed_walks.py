@@ -1,0 +1,180 @@
+"""Typed-graph transition weights of the walk sampler (CPU, oracle side).
+
+change_node_type_weight / change_edge_type_weight are documented at the reference's call sites
+(embedders/ensmallen_embedders/node2vec_skipgram.py:72-77; sequences/tensorflow_sequences/
+node2vec_sequence.py:57-66: "weight on the probability of visiting a neighbor node / edge of a
+different type than the previous node / edge.  This only applies to colored graphs / multigraphs,
+otherwise it has no impact").  The reference holds no vectors for them (parity unpinned, see
+oracle/gn2v_oracle.c); these tests pin the restatement to the exact distribution it claims."""
+import numpy as np
+import pytest
+from scipy import stats
+
+import embiggen_amd as E
+from helpers import exact_typed_probs, typed_karate
+from oracle import oracle as O
+
+
+def oracle_graph(g):
+    return O.OracleGraph(g.row_ptr, g.col_idx, g.cumw, g.node_type_ids, g.edge_type_ids)
+
+
+def wparams(L, rw, ew, cn, ce):
+    return O.WalkParams(L, 1, rw, ew, 100, 0, cn, ce)
+
+
+def test_type_weights_have_no_impact_without_types(karate, karate_oracle):
+    base = O.walks(karate_oracle, wparams(20, 0.25, 4.0, 1.0, 1.0), 5, 0, 0, 340)
+    assert np.array_equal(base, O.walks(karate_oracle, wparams(20, 0.25, 4.0, 3.0, 0.2), 5, 0, 0, 340))
+    assert np.array_equal(base, O.walks(karate_oracle, O.WalkParams(20, 1, 0.25, 4.0, 100, 0), 5, 0, 0, 340))
+
+
+def test_unit_type_weights_leave_typed_graphs_alone(karate_oracle):
+    og = oracle_graph(typed_karate())
+    for rw, ew in ((1.0, 1.0), (0.25, 4.0)):
+        assert np.array_equal(O.walks(karate_oracle, wparams(20, rw, ew, 1.0, 1.0), 5, 0, 0, 340),
+                              O.walks(og, wparams(20, rw, ew, 1.0, 1.0), 5, 0, 0, 340))
+
+
+def test_only_the_attached_kind_of_type_acts():
+    g = typed_karate()
+    nodes_only = O.OracleGraph(g.row_ptr, g.col_idx, None, g.node_type_ids, None)
+    edges_only = O.OracleGraph(g.row_ptr, g.col_idx, None, None, g.edge_type_ids)
+    plain = O.OracleGraph(g.row_ptr, g.col_idx)
+    both = wparams(16, 1.0, 1.0, 4.0, 0.25)
+    assert np.array_equal(O.walks(nodes_only, both, 1, 0, 0, 340),
+                          O.walks(nodes_only, wparams(16, 1.0, 1.0, 4.0, 1.0), 1, 0, 0, 340))
+    assert np.array_equal(O.walks(edges_only, both, 1, 0, 0, 340),
+                          O.walks(edges_only, wparams(16, 1.0, 1.0, 1.0, 0.25), 1, 0, 0, 340))
+    assert not np.array_equal(O.walks(nodes_only, both, 1, 0, 0, 340), O.walks(plain, both, 1, 0, 0, 340))
+    assert not np.array_equal(O.walks(edges_only, both, 1, 0, 0, 340), O.walks(plain, both, 1, 0, 0, 340))
+
+
+@pytest.mark.parametrize("rw,ew,cn,ce", [(1.0, 1.0, 4.0, 1.0), (1.0, 1.0, 1.0, 0.2),
+                                         (0.25, 4.0, 0.3, 3.0), (2.0, 0.5, 5.0, 5.0)])
+def test_typed_transition_distribution(rw, ew, cn, ce):
+    g = typed_karate()
+    og = oracle_graph(g)
+    w = O.walks(og, wparams(10, rw, ew, cn, ce), 11, 0, 0, 34 * 3000).astype(np.int64)
+    # first step: node-type factor only
+    first_checked = 0
+    for c in range(34):
+        sel = w[:, 0] == c
+        neigh, probs = exact_typed_probs(g, None, c, rw, ew, cn, ce)
+        counts = np.array([(w[sel, 1] == x).sum() for x in neigh], dtype=np.float64)
+        assert counts.sum() == sel.sum()
+        if len(neigh) > 1 and (probs * counts.sum() >= 5).all():
+            assert stats.chisquare(counts, probs * counts.sum()).pvalue > 1e-5
+            first_checked += 1
+    assert first_checked >= 15
+    # later steps: all three factors
+    prev, cur, nxt = w[:, :-2].ravel(), w[:, 1:-1].ravel(), w[:, 2:].ravel()
+    key = prev * 34 + cur
+    pvals = []
+    for k in np.unique(key):
+        sel = key == k
+        if sel.sum() < 2000:
+            continue
+        p, c = divmod(int(k), 34)
+        neigh, probs = exact_typed_probs(g, p, c, rw, ew, cn, ce)
+        counts = np.array([(nxt[sel] == x).sum() for x in neigh], dtype=np.float64)
+        assert counts.sum() == sel.sum()
+        if (probs * counts.sum() < 5).any():
+            continue
+        pvals.append(stats.chisquare(counts, probs * counts.sum()).pvalue)
+    assert len(pvals) >= 20
+    assert min(pvals) > 1e-3 / len(pvals), (min(pvals), len(pvals))
+
+
+def test_tiny_type_weight_uses_exact_fallback():
+    """change_node_type_weight = 1e-5: a row whose neighbours all have another type than the
+    current node rejects every candidate 32 times and goes through the exact scan (which must
+    still be uniform over them); rows with same-type neighbours (almost) never leave the type."""
+    g = typed_karate()
+    og = oracle_graph(g)
+    cn = 1e-5
+    w = O.walks(og, wparams(2, 1.0, 1.0, cn, 1.0), 3, 0, 0, 34 * 2000).astype(np.int64)
+    checked = 0
+    for c in range(34):
+        neigh, probs = exact_typed_probs(g, None, c, 1.0, 1.0, cn, 1.0)
+        sel = w[:, 0] == c
+        counts = np.array([(w[sel, 1] == x).sum() for x in neigh], dtype=np.float64)
+        big = probs * counts.sum() >= 5
+        # neighbours of the other type are (almost) never taken when a same-type one exists
+        assert counts[~big].sum() <= 3
+        if big.sum() > 1:
+            chi = stats.chisquare(counts[big], probs[big] / probs[big].sum() * counts[big].sum())
+            assert chi.pvalue > 1e-5
+            checked += 1
+    assert checked >= 10
+
+
+def test_weighted_typed_graph_distribution():
+    src = np.array([0, 0, 0, 0, 1, 2, 3])
+    dst = np.array([1, 2, 3, 4, 2, 3, 4])
+    wts = np.array([1.0, 2.0, 5.0, 2.0, 1.0, 1.0, 1.0])
+    g = E.CSRGraph.from_edge_list(src, dst, wts, number_of_nodes=5,
+                                  node_types=["a", "a", "b", "b", "a"])
+    w = O.walks(oracle_graph(g), wparams(2, 1.0, 1.0, 3.0, 1.0), 1, 0, 0, 5 * 20000)
+    from0 = w[w[:, 0] == 0, 1]
+    counts = np.array([(from0 == x).sum() for x in (1, 2, 3, 4)], dtype=np.float64)
+    expect = np.array([1.0, 2.0 * 3, 5.0 * 3, 2.0])
+    assert stats.chisquare(counts, expect / expect.sum() * counts.sum()).pvalue > 1e-4
+
+
+def test_multigraph_parallel_edges_count_once_per_type():
+    # 0 -(a)- 1, 0 -(b)- 1, 0 -(a)- 2: node 1 is reached through two of node 0's three edges
+    g = E.CSRGraph.from_edge_list([0, 0, 0, 0], [1, 1, 2, 1], number_of_nodes=3,
+                                  edge_types=["a", "b", "a", "a"])
+    assert g.is_multigraph() and g.get_number_of_directed_edges() == 6
+    assert g.col_idx.tolist() == [1, 1, 2, 0, 0, 0] and g.get_number_of_edge_types() == 2
+    og = oracle_graph(g)
+    w = O.walks(og, wparams(2, 1.0, 1.0, 1.0, 1.0), 2, 0, 0, 3 * 20000)
+    from0 = w[w[:, 0] == 0, 1]
+    counts = np.array([(from0 == 1).sum(), (from0 == 2).sum()], dtype=np.float64)
+    assert stats.chisquare(counts, np.array([2, 1]) / 3 * counts.sum()).pvalue > 1e-4
+    # 1 -> 0 -> ?: arriving over an "a" edge with change_edge_type_weight 0.1 favours a-typed
+    # continuations {0->1 (a), 0->2 (a)} over {0->1 (b)}; arriving over "b" the opposite.
+    w = O.walks(og, wparams(3, 1.0, 1.0, 1.0, 0.1), 2, 0, 0, 3 * 40000)
+    sel = (w[:, 0] == 2) & (w[:, 1] == 0)  # the only edge 2 -> 0 has type a
+    counts = np.array([(w[sel, 2] == 1).sum(), (w[sel, 2] == 2).sum()], dtype=np.float64)
+    expect = np.array([1.0 + 0.1, 1.0])
+    assert stats.chisquare(counts, expect / expect.sum() * counts.sum()).pvalue > 1e-4
+
+
+def test_graph_type_bookkeeping():
+    g = typed_karate()
+    assert g.has_node_types() and g.has_edge_types() and not g.is_multigraph()
+    assert g.get_number_of_node_types() == 3 and g.get_number_of_edge_types() == 3
+    assert set(g.get_edge_type_names()) == {"a", "b", "c"}
+    # both directions of an undirected edge carry the same type
+    rp = g.row_ptr.astype(np.int64)
+    src = np.repeat(np.arange(34), np.diff(rp))
+    table = {(int(s), int(d)): int(t) for s, d, t in zip(src, g.col_idx, g.edge_type_ids)}
+    assert all(table[(d, s)] == t for (s, d), t in table.items())
+    s = g.sort_by_decreasing_outbound_node_degree()
+    assert s.has_nodes_sorted_by_decreasing_outbound_node_degree()
+    assert sorted(s.node_type_ids.tolist()) == sorted(g.node_type_ids.tolist())
+    assert sorted(s.edge_type_ids.tolist()) == sorted(g.edge_type_ids.tolist())
+    n = g.with_degree_normalized_weights()
+    assert np.array_equal(n.node_type_ids, g.node_type_ids)
+    assert np.array_equal(n.edge_type_ids, g.edge_type_ids)
+    with pytest.raises(ValueError):
+        E.CSRGraph.from_edge_list([0], [1], number_of_nodes=2, node_types=["a"])
+    with pytest.raises(ValueError):
+        E.CSRGraph.from_edge_list([0], [1], number_of_nodes=2, edge_types=["a", "b"])
+    with pytest.raises(ValueError):
+        E.CSRGraph.from_csr([0, 1, 2], [1, 0], node_type_ids=[0])
+
+
+def test_type_weights_are_validated():
+    from embiggen_amd import models, ops
+
+    for bad in (0.0, -1.0, float("nan")):
+        with pytest.raises(ValueError):
+            ops.walk_params(10, change_node_type_weight=bad)
+        with pytest.raises(ValueError):
+            models.SkipGram(change_edge_type_weight=bad)
+    with pytest.raises(ValueError):
+        E.Node2VecSequence(E.karate_club(), change_node_type_weight=0.0)
+    assert models.SkipGram(change_node_type_weight=2.0).walk_params().change_node_type_weight == 2.0
