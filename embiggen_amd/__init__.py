@@ -6,6 +6,7 @@ window batch generator of ``embiggen.sequences``.  Compute runs in hand-written 
 gfx950 reached through the C ABI in ``include/gn2v.h``; there is no CPU execution path.
 """
 from . import _lib
+from .embedding_transformers import EdgeTransformer, GraphTransformer, NodeTransformer
 from .embedders import (DeepWalkCBOWEnsmallen, DeepWalkSkipGramEnsmallen, Node2VecCBOWEnsmallen,
                         Node2VecSkipGramEnsmallen, WalkletsCBOWEnsmallen,
                         WalkletsSkipGramEnsmallen, embed_graph)
@@ -23,5 +24,5 @@ __all__ = [
     "Node2VecCBOWEnsmallen", "DeepWalkSkipGramEnsmallen", "DeepWalkCBOWEnsmallen",
     "WalkletsSkipGramEnsmallen", "WalkletsCBOWEnsmallen",
     "get_models_dataframe", "get_available_models_for_node_embedding", "normalize_kwargs",
-    "Node2VecSequence",
+    "Node2VecSequence", "EdgeTransformer", "NodeTransformer", "GraphTransformer",
 ]

@@ -31,29 +31,36 @@ UNKNOWN_TYPE = 0xFFFFFFFF
 
 def _canonical_type_ids(labels, count: int, what: str):
     """Labels (None = unknown, a hashable, or a list / tuple / set of hashables for multi-label
-    nodes) -> (u32 ids, names): one id per distinct label set, ids ordered by first appearance.
-    Walks only compare types for equality, so a label set is one type."""
+    nodes) -> (u32 ids, vocabulary, lists).  ``ids``: one id per distinct label *set* (walks only
+    compare types for equality, so a label set is one type), ordered by first appearance, unknown
+    = 0xFFFFFFFF.  ``vocabulary``: the individual labels by first appearance.  ``lists``: per item
+    None or the u32 array of its individual label ids (what ensmallen's get_node_type_ids
+    returns)."""
     if len(labels) != count:
         raise ValueError(f"{what} must have one entry per {what.split('_')[0]}.")
     ids = np.empty(count, dtype=np.uint32)
-    table, names = {}, []
+    sets, vocabulary, index, lists = {}, [], {}, []
     for i, label in enumerate(labels):
-        if label is None:
-            ids[i] = UNKNOWN_TYPE
-            continue
-        if isinstance(label, (list, tuple, set, frozenset, np.ndarray)):
-            key = tuple(sorted(set(label.tolist() if isinstance(label, np.ndarray) else label),
-                               key=repr))
-            if not key:
-                ids[i] = UNKNOWN_TYPE
-                continue
+        if isinstance(label, np.ndarray):
+            label = label.tolist()
+        if isinstance(label, (list, tuple, set, frozenset)):
+            members = list(dict.fromkeys(label))  # ordered, unique
+        elif label is None:
+            members = []
         else:
-            key = (label.item() if isinstance(label, np.generic) else label,)
-        if key not in table:
-            table[key] = len(names)
-            names.append(key[0] if len(key) == 1 else key)
-        ids[i] = table[key]
-    return ids, names
+            members = [label.item() if isinstance(label, np.generic) else label]
+        if not members:
+            ids[i] = UNKNOWN_TYPE
+            lists.append(None)
+            continue
+        for m in members:
+            if m not in index:
+                index[m] = len(vocabulary)
+                vocabulary.append(m)
+        own = np.array(sorted(index[m] for m in members), dtype=np.uint32)
+        lists.append(own)
+        ids[i] = sets.setdefault(tuple(own.tolist()), len(sets))
+    return ids, vocabulary, lists
 
 
 class DeviceGraph:
@@ -80,14 +87,16 @@ class CSRGraph:
     def __init__(self, row_ptr, col_idx, weights=None, node_names: Optional[List[str]] = None,
                  name: str = "Graph", directed: bool = False, _device_tensors=None,
                  node_type_ids=None, edge_type_ids=None, node_type_names=None,
-                 edge_type_names=None):
+                 edge_type_names=None, node_type_lists=None):
         self._name = name
         self._directed = directed
         self._node_names = node_names
         self._device_tensors = _device_tensors  # dict of torch cuda tensors or None
         self._handles = {}
         self._node_type_ids = self._edge_type_ids = None
+        # vocabularies (individual labels) and, for multi-label nodes, the per-node label ids
         self._node_type_names, self._edge_type_names = node_type_names, edge_type_names
+        self._node_type_lists = node_type_lists
         if _device_tensors is not None:
             self._row_ptr = self._col_idx = self._weights = self._cumw = None
             self._n_nodes = int(_device_tensors["row_ptr"].numel()) - 1
@@ -188,15 +197,19 @@ class CSRGraph:
         if len(src) and (src.min() < 0 or dst.min() < 0 or max(src.max(), dst.max()) >= n):
             raise ValueError("Edge list contains node ids outside [0, number_of_nodes).")
         w = None if weights is None else np.asarray(weights, dtype=np.float64).ravel()
-        nt_ids = nt_names = et = et_names = None
+        nt_ids = nt_names = nt_lists = et = et_names = None
         if node_types is not None:
-            nt_ids, nt_names = _canonical_type_ids(list(node_types), n, "node_types")
+            nt_ids, nt_names, nt_lists = _canonical_type_ids(list(node_types), n, "node_types")
         if edge_types is not None:
-            et, et_names = _canonical_type_ids(list(edge_types), len(src), "edge_types")
+            labels = list(edge_types)
+            if any(isinstance(t, (list, tuple, set, frozenset, np.ndarray)) for t in labels):
+                raise ValueError("An edge has exactly one type (or None).")
+            et, et_names, _ = _canonical_type_ids(labels, len(src), "edge_types")
             et = et.astype(np.int64)
         row_ptr, cols, w, et = cls._assemble(src, dst, w, et, n, directed)
         return cls(row_ptr, cols, w, node_names, name, directed, node_type_ids=nt_ids,
-                   edge_type_ids=et, node_type_names=nt_names, edge_type_names=et_names)
+                   edge_type_ids=et, node_type_names=nt_names, edge_type_names=et_names,
+                   node_type_lists=nt_lists)
 
     @classmethod
     def from_csr(cls, row_ptr, col_idx, weights=None, node_names=None, name: str = "Graph",
@@ -231,17 +244,17 @@ class CSRGraph:
         row_ptr[1:] = graph.get_cumulative_node_degrees().astype(np.uint64)
         col_idx = graph.get_directed_destination_node_ids().astype(np.uint32)
         weights = graph.get_directed_edge_weights() if graph.has_edge_weights() else None
-        nt_ids = nt_names = et_ids = None
+        nt_ids = nt_names = nt_lists = et_ids = None
         if getattr(graph, "has_node_types", lambda: False)():
             # one entry per node: None or the array of its node type ids
-            nt_ids, nt_names = _canonical_type_ids(list(graph.get_node_type_ids()), n,
-                                                   "node_types")
+            nt_ids, nt_names, nt_lists = _canonical_type_ids(list(graph.get_node_type_ids()), n,
+                                                             "node_types")
         if getattr(graph, "has_edge_types", lambda: False)():
             raw = graph.get_directed_edge_type_ids()  # one entry per directed edge, None = unknown
             et_ids = np.array([UNKNOWN_TYPE if t is None else int(t) for t in raw], dtype=np.uint32)
         return cls(row_ptr, col_idx, weights, list(graph.get_node_names()), graph.get_name(),
                    graph.is_directed(), node_type_ids=nt_ids, edge_type_ids=et_ids,
-                   node_type_names=nt_names)
+                   node_type_names=nt_names, node_type_lists=nt_lists)
 
     # ------------------------------------------------------------------ ensmallen.Graph getters
     def get_name(self) -> str:
@@ -300,11 +313,109 @@ class CSRGraph:
         same[rp[1:-1][(rp[1:-1] > 0) & (rp[1:-1] < len(col))] - 1] = False  # row boundaries
         return bool(same.any())
 
-    def get_node_type_names(self):
+    # --- typed-graph getters under ensmallen's names (used by embedding_transformers/
+    #     graph_transformer.py:196-243 and node_transformer.py:186-190)
+    def get_unique_node_type_names(self) -> List[str]:
+        if self._node_type_names is None:
+            n = 0 if self.node_type_ids is None else self._count_all(self.node_type_ids)
+            self._node_type_names = [str(i) for i in range(n)]
         return self._node_type_names
 
-    def get_edge_type_names(self):
+    def get_unique_edge_type_names(self) -> List[str]:
+        if self._edge_type_names is None:
+            n = 0 if self.edge_type_ids is None else self._count_all(self.edge_type_ids)
+            self._edge_type_names = [str(i) for i in range(n)]
         return self._edge_type_names
+
+    @staticmethod
+    def _count_all(ids) -> int:
+        known = ids[ids != UNKNOWN_TYPE]
+        return int(known.max()) + 1 if len(known) else 0
+
+    def get_node_type_ids(self):
+        """Per node: None (unknown) or the u32 array of its node type ids."""
+        if not self.has_node_types():
+            raise ValueError("The graph does not have node types.")
+        if self._node_type_lists is None:
+            self._node_type_lists = [None if t == UNKNOWN_TYPE else np.array([t], dtype=np.uint32)
+                                     for t in self.node_type_ids]
+        return self._node_type_lists
+
+    def get_node_type_ids_from_node_id(self, node_id: int):
+        return self.get_node_type_ids()[int(node_id)]
+
+    def get_node_type_names(self):
+        """Per node: None or the list of its node type names."""
+        vocabulary = self.get_unique_node_type_names()
+        return [None if ids is None else [vocabulary[i] for i in ids]
+                for ids in self.get_node_type_ids()]
+
+    def get_node_id_from_node_name(self, node_name: str) -> int:
+        index = getattr(self, "_node_index", None)
+        if index is None:
+            index = self._node_index = {n: i for i, n in enumerate(self.get_node_names())}
+        if node_name not in index:
+            raise ValueError(f"The node name {node_name!r} does not exist in the graph.")
+        return index[node_name]
+
+    def get_node_type_names_from_node_name(self, node_name: str):
+        ids = self.get_node_type_ids_from_node_id(self.get_node_id_from_node_name(node_name))
+        vocabulary = self.get_unique_node_type_names()
+        return None if ids is None else [vocabulary[i] for i in ids]
+
+    def get_directed_source_node_ids(self) -> np.ndarray:
+        deg = np.diff(self.row_ptr.astype(np.int64))
+        return np.repeat(np.arange(self._n_nodes, dtype=np.uint32), deg)
+
+    def _upper_triangular(self) -> np.ndarray:
+        return self.get_directed_source_node_ids() <= self.col_idx
+
+    def get_source_node_ids(self, directed: bool = True) -> np.ndarray:
+        src = self.get_directed_source_node_ids()
+        return src if directed or self._directed else src[self._upper_triangular()]
+
+    def get_destination_node_ids(self, directed: bool = True) -> np.ndarray:
+        return self.col_idx if directed or self._directed else self.col_idx[self._upper_triangular()]
+
+    def get_directed_edge_node_names(self):
+        names = self.get_node_names()
+        return [(names[s], names[d]) for s, d in zip(self.get_directed_source_node_ids(),
+                                                     self.col_idx)]
+
+    def _edge_types_or_raise(self) -> np.ndarray:
+        if not self.has_edge_types():
+            raise ValueError("The graph does not have edge types.")
+        return self.edge_type_ids
+
+    def get_directed_edge_type_ids(self):
+        return [None if t == UNKNOWN_TYPE else int(t) for t in self._edge_types_or_raise()]
+
+    def get_imputed_directed_edge_type_ids(self, imputation_edge_type_id: int = 0) -> np.ndarray:
+        ids = self._edge_types_or_raise()
+        return np.where(ids == UNKNOWN_TYPE, np.uint32(imputation_edge_type_id), ids)
+
+    def get_imputed_upper_triangular_edge_type_ids(self, imputation_edge_type_id: int = 0):
+        return self.get_imputed_directed_edge_type_ids(imputation_edge_type_id)[
+            self._upper_triangular()]
+
+    def get_directed_edge_type_names(self):
+        vocabulary = self.get_unique_edge_type_names()
+        return [None if t == UNKNOWN_TYPE else vocabulary[t] for t in self._edge_types_or_raise()]
+
+    def get_upper_triangular_edge_type_names(self):
+        keep = self._upper_triangular()
+        return [t for t, k in zip(self.get_directed_edge_type_names(), keep) if k]
+
+    def has_unknown_edge_types(self) -> bool:
+        return self.has_edge_types() and bool((self.edge_type_ids == UNKNOWN_TYPE).any())
+
+    def must_not_contain_unknown_edge_types(self):
+        if self.has_unknown_edge_types():
+            raise ValueError("The graph contains edges with unknown edge type.")
+
+    def must_not_be_multigraph(self):
+        if self.is_multigraph():
+            raise ValueError("The graph is a multigraph.")
 
     def with_types(self, node_type_ids=None, edge_type_ids=None) -> "CSRGraph":
         """Same graph (arrays shared) with the given type ids attached: u32 arrays, or device
@@ -325,7 +436,8 @@ class CSRGraph:
                         node_type_ids=self._node_type_ids if node_type_ids is None else node_type_ids,
                         edge_type_ids=self._edge_type_ids if edge_type_ids is None else edge_type_ids,
                         node_type_names=self._node_type_names if node_type_ids is None else None,
-                        edge_type_names=self._edge_type_names if edge_type_ids is None else None)
+                        edge_type_names=self._edge_type_names if edge_type_ids is None else None,
+                        node_type_lists=self._node_type_lists if node_type_ids is None else None)
 
     def has_edge_weights(self) -> bool:
         return self._weights is not None or (
@@ -388,7 +500,9 @@ class CSRGraph:
             self._directed,
             node_type_ids=None if self._node_type_ids is None else self._node_type_ids[order],
             edge_type_ids=et, node_type_names=self._node_type_names,
-            edge_type_names=self._edge_type_names)
+            edge_type_names=self._edge_type_names,
+            node_type_lists=(None if self._node_type_lists is None
+                             else [self._node_type_lists[i] for i in order]))
 
     def with_degree_normalized_weights(self) -> "CSRGraph":
         """Same graph with every edge weight divided by the degree of its destination node: the
@@ -419,7 +533,8 @@ class CSRGraph:
                          self._directed, node_type_ids=self._node_type_ids,
                          edge_type_ids=self._edge_type_ids,
                          node_type_names=self._node_type_names,
-                         edge_type_names=self._edge_type_names)
+                         edge_type_names=self._edge_type_names,
+                         node_type_lists=self._node_type_lists)
         self._degree_normalized = g
         return g
 

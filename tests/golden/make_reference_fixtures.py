@@ -12,6 +12,12 @@
    with ``ast`` (no import), and the declared types of those kwargs from
    ``embiggen/utils/normalization_schemas.json``.
 
+3. ``edge_embedding_cases.npz`` -- outputs of the reference's 12 edge operators on seeded inputs.
+4. ``transformer_cases.npz`` / ``transformer_cases.json`` -- outcomes (arrays / exception type
+   names) of the reference's NodeTransformer, EdgeTransformer and GraphTransformer on the scenario
+   table ``helpers.transformer_cases``; the graph argument is a small pure-Python stand-in for
+   ``ensmallen.Graph`` defined below (the reference only calls getters on it).
+
 Only data (inputs -> expected outcomes, names -> default values) is written; no reference source
 text is stored.
 """
@@ -25,7 +31,7 @@ import sys
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from helpers import probe, scenarios  # noqa: E402
+from helpers import probe, scenarios, transformer_cases, transformer_graph_spec  # noqa: E402
 
 
 def embedding_result_cases():
@@ -152,8 +158,100 @@ def edge_embedding_cases():
     return out
 
 
+class StandInGraph:
+    """The getters embedding_transformers/graph_transformer.py:150-243 and
+    node_transformer.py:186-190 call on an ensmallen.Graph, over transformer_graph_spec():
+    undirected, CSR edge order, type vocabularies in order of first appearance."""
+
+    def __init__(self):
+        import numpy as np
+
+        names, edges, edge_types, node_types = transformer_graph_spec()
+        self.names = names
+        directed = {}
+        for (a, b), t in zip(edges, edge_types):
+            directed[(a, b)] = t
+            directed[(b, a)] = t
+        keys = sorted(directed)
+        self.src = np.array([k[0] for k in keys], dtype=np.uint32)
+        self.dst = np.array([k[1] for k in keys], dtype=np.uint32)
+        self.edge_vocab = list(dict.fromkeys(edge_types))
+        self.etype = np.array([self.edge_vocab.index(directed[k]) for k in keys], dtype=np.uint32)
+        self.node_vocab = list(dict.fromkeys(t for ts in node_types if ts for t in ts))
+        self.ntype = [None if ts is None else
+                      np.array(sorted(self.node_vocab.index(t) for t in ts), dtype=np.uint32)
+                      for ts in node_types]
+        self.upper = self.src <= self.dst
+
+    def is_directed(self): return False
+    def get_node_names(self): return self.names
+    def get_directed_source_node_ids(self): return self.src
+    def get_directed_destination_node_ids(self): return self.dst
+    def get_source_node_ids(self, directed=True): return self.src if directed else self.src[self.upper]
+    def get_destination_node_ids(self, directed=True): return self.dst if directed else self.dst[self.upper]
+    def get_directed_edge_node_names(self):
+        return [(self.names[s], self.names[d]) for s, d in zip(self.src, self.dst)]
+    def get_node_type_ids(self): return self.ntype
+    def get_node_type_ids_from_node_id(self, i): return self.ntype[int(i)]
+    def get_node_type_names_from_node_name(self, name):
+        ids = self.ntype[self.names.index(name)]
+        return None if ids is None else [self.node_vocab[i] for i in ids]
+    def must_not_contain_unknown_edge_types(self): pass
+    def must_not_be_multigraph(self): pass
+    def get_imputed_directed_edge_type_ids(self, imputation_edge_type_id=0): return self.etype
+    def get_imputed_upper_triangular_edge_type_ids(self, imputation_edge_type_id=0):
+        return self.etype[self.upper]
+    def get_directed_edge_type_names(self): return [self.edge_vocab[t] for t in self.etype]
+    def get_upper_triangular_edge_type_names(self):
+        return [self.edge_vocab[t] for t in self.etype[self.upper]]
+
+
+def transformer_fixture():
+    """Runs helpers.transformer_cases against the reference's three transformer classes.  Their
+    modules import `ensmallen` (for isinstance checks against Graph) and `userinput`; both are
+    satisfied with placeholder modules whose Graph is StandInGraph for the duration of the call."""
+    import types
+
+    added = {}
+
+    def put(name, module):
+        if name not in sys.modules:
+            added[name] = sys.modules[name] = module
+        return sys.modules[name]
+
+    ens = put("ensmallen", types.ModuleType("ensmallen"))
+    ens.Graph = StandInGraph
+    ens.express_measures = put("ensmallen.express_measures", types.ModuleType("ensmallen.express_measures"))
+    put("userinput", types.ModuleType("userinput"))
+    put("userinput.utils", types.ModuleType("userinput.utils")).must_be_in_set = lambda *a, **k: a[0]
+    put("embiggen", types.ModuleType("embiggen"))
+    put("embiggen.embedding_transformers", types.ModuleType("embiggen.embedding_transformers"))
+    base = os.path.join(REF, "embiggen/embedding_transformers")
+    try:
+        loaded = {}
+        for stem in ("node_transformer", "edge_transformer", "graph_transformer"):
+            full = f"embiggen.embedding_transformers.{stem}"
+            spec = importlib.util.spec_from_file_location(full, os.path.join(base, stem + ".py"))
+            loaded[stem] = put(full, importlib.util.module_from_spec(spec))
+            spec.loader.exec_module(loaded[stem])
+        T = types.SimpleNamespace(NodeTransformer=loaded["node_transformer"].NodeTransformer,
+                                  EdgeTransformer=loaded["edge_transformer"].EdgeTransformer,
+                                  GraphTransformer=loaded["graph_transformer"].GraphTransformer)
+        return transformer_cases(T, StandInGraph())
+    finally:
+        for name in added:
+            del sys.modules[name]
+
+
 if __name__ == "__main__":
     import numpy as np
+
+    cases = transformer_fixture()
+    np.savez_compressed(os.path.join(HERE, "transformer_cases.npz"),
+                        **{k: v for k, v in cases.items() if not isinstance(v, str)})
+    with open(os.path.join(HERE, "transformer_cases.json"), "w") as f:
+        json.dump({k: v for k, v in cases.items() if isinstance(v, str)}, f, indent=1,
+                  sort_keys=True)
 
     np.savez_compressed(os.path.join(HERE, "edge_embedding_cases.npz"), **edge_embedding_cases())
     with open(os.path.join(HERE, "embedding_result_cases.json"), "w") as f:

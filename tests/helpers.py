@@ -176,3 +176,213 @@ def exact_typed_probs(graph, prev, cur: int, return_weight: float, explore_weigh
     if graph.cumw is not None:
         w = w * graph.get_directed_edge_weights()[lo:hi].astype(np.float64)
     return neigh, w / w.sum()
+
+
+# ------------------------------------------------------------------------------------------------
+# embedding_transformers scenarios, shared by tests/golden/make_reference_fixtures.py (run against
+# the reference's classes) and tests/test_transformers.py (run against ours).
+# ------------------------------------------------------------------------------------------------
+
+def transformer_graph_spec():
+    """Small undirected typed simple graph: (names, edges, edge type labels, node type labels)."""
+    names = [f"n{i}" for i in range(12)]
+    edges = [(0, 1), (0, 2), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9),
+             (9, 10), (10, 11), (0, 11), (3, 9), (5, 5)]
+    edge_types = ["binds" if (a + b) % 3 == 0 else ("inhibits" if (a + b) % 3 == 1 else "is_a")
+                  for a, b in edges]
+    node_types = [["gene"], ["gene", "drug"], None, ["drug"], ["disease"], ["gene"], None,
+                  ["disease", "gene"], ["drug"], ["gene"], ["disease"], ["drug"]]
+    return names, edges, edge_types, node_types
+
+
+def transformer_inputs():
+    """Seeded inputs of the transformer scenarios."""
+    rng = np.random.RandomState(11)
+    names = transformer_graph_spec()[0]
+    n = len(names)
+    X = rng.normal(size=(n, 6)).astype(np.float32)
+    X[3] = 0.0
+    Y = rng.normal(size=(n, 3)).astype(np.float32)
+    TF = rng.normal(size=(3, 4)).astype(np.float32)      # node type features (gene, drug, disease)
+    EF = rng.normal(size=(3, 2)).astype(np.float32)      # edge type features
+    dfX, dfY = pd.DataFrame(X, index=names), pd.DataFrame(Y, index=names)
+    type_names = ["gene", "drug", "disease"]
+    dfTF = pd.DataFrame(TF, index=type_names)
+    dfEF = pd.DataFrame(EF, index=["binds", "inhibits", "is_a"])
+    src = np.array([0, 3, 3, 7, 11, 5, 2], dtype=np.int64)
+    dst = np.array([1, 3, 9, 0, 11, 6, 2], dtype=np.int64)
+    src_names, dst_names = [names[i] for i in src], [names[i] for i in dst]
+    etypes = np.array([0, 1, 2, 2, 1, 0, 0], dtype=np.int64)
+    etype_names = [["binds", "inhibits", "is_a"][i] for i in etypes]
+    extra = rng.normal(size=(len(src), 3))
+    ntypes = [np.array([0]), None, np.array([0, 2]), np.array([1]), None, np.array([2, 1, 0]),
+              np.array([1])]
+    ntypes2 = list(reversed(ntypes))
+    return dict(names=names, X=X, Y=Y, TF=TF, EF=EF, dfX=dfX, dfY=dfY, dfTF=dfTF, dfEF=dfEF,
+                src=src, dst=dst, src_names=src_names, dst_names=dst_names, etypes=etypes,
+                etype_names=etype_names, extra=extra, ntypes=ntypes, ntypes2=ntypes2)
+
+
+def transformer_cases(T, graph, only=None):
+    """Outcome (ndarray, or the exception type name) of every scenario (whose name satisfies
+    `only`) for the implementation `T` (namespace with NodeTransformer / EdgeTransformer /
+    GraphTransformer) on `graph` (that implementation's graph object built from
+    transformer_graph_spec())."""
+    i = transformer_inputs()
+    names, X, Y, TF, EF, dfX, dfY, dfEF = (i[k] for k in ("names", "X", "Y", "TF", "EF", "dfX", "dfY", "dfEF"))
+    src, dst, src_names, dst_names = i["src"], i["dst"], i["src_names"], i["dst_names"]
+    etypes, etype_names, extra, ntypes, ntypes2 = (
+        i[k] for k in ("etypes", "etype_names", "extra", "ntypes", "ntypes2"))
+    methods = ["Hadamard", "Sum", "Average", "L1", "AbsoluteL1", "SquaredL2", "L2", "Concatenate",
+               "Min", "Max", "L2Distance", "CosineSimilarity"]
+    nan = X.copy()
+    nan[2, 1] = np.nan
+
+    def node(aligned, *fit_args, **fit_kwargs):
+        t = T.NodeTransformer(aligned_mapping=aligned)
+        t.fit(*fit_args, **fit_kwargs)
+        return t
+
+    def edge(methods_, aligned, *fit_args, **fit_kwargs):
+        t = T.EdgeTransformer(methods=methods_, aligned_mapping=aligned)
+        t.fit(*fit_args, **fit_kwargs)
+        return t
+
+    def gt(methods_, aligned, both, *fit_args, **fit_kwargs):
+        t = T.GraphTransformer(methods=methods_, aligned_mapping=aligned,
+                               include_both_undirected_edges=both)
+        t.fit(*fit_args, **fit_kwargs)
+        return t
+
+    cases = {
+        # ---- NodeTransformer
+        "nt_aligned_numpy": lambda: node(True, X).transform(src),
+        "nt_aligned_two": lambda: node(True, [X, dfY]).transform(dst),
+        "nt_aligned_graph": lambda: node(True, X).transform(graph),
+        "nt_unaligned_df": lambda: node(False, dfX).transform(src_names),
+        "nt_unaligned_two_df": lambda: node(False, [dfX, dfY]).transform(dst_names),
+        "nt_unaligned_graph": lambda: node(False, dfX).transform(graph),
+        "nt_numpy_unaligned_error": lambda: node(False, X),
+        "nt_nan_error": lambda: node(True, nan),
+        "nt_nan_df_error": lambda: node(False, pd.DataFrame(nan, index=names)),
+        "nt_bad_type_error": lambda: node(True, [X, "hu"]),
+        "nt_not_fit_error": lambda: T.NodeTransformer(aligned_mapping=True).transform(src),
+        "nt_aligned_list_ids_error": lambda: node(True, X).transform([0, 1]),
+        "nt_unaligned_missing_name_error": lambda: node(False, dfX).transform(["n1", "nope"]),
+        "nt_types_aligned": lambda: node(True, X, node_type_feature=TF).transform(src, node_types=ntypes),
+        "nt_types_only": lambda: node(True, node_type_feature=TF).transform(node_types=ntypes),
+        "nt_types_two": lambda: node(True, X, node_type_feature=[TF, TF * 2]).transform(
+            src, node_types=ntypes),
+        "nt_types_from_graph": lambda: node(True, X, node_type_feature=TF).transform(src, node_types=graph),
+        "nt_types_from_graph_all": lambda: node(True, X, node_type_feature=TF).transform(
+            graph, node_types=graph),
+        "nt_is_fit_flags": lambda: np.array([
+            node(True, X).is_fit(), node(True, X).has_node_features(),
+            node(True, X).has_node_type_features(), T.NodeTransformer().is_fit(),
+            node(True, node_type_feature=TF).has_node_type_features(),
+            node(True, X).is_aligned_mapping(), T.NodeTransformer().is_aligned_mapping()]),
+        # ---- EdgeTransformer
+        "et_multi": lambda: edge(["Hadamard", "L2Distance", "Concatenate"], True, X).transform(src, dst),
+        "et_two_features": lambda: edge("L1", True, [X, Y]).transform(src, dst),
+        "et_two_features_cosine": lambda: edge("CosineSimilarity", True, [X, dfY]).transform(src, dst),
+        "et_unaligned_names": lambda: edge("Average", False, dfX).transform(src_names, dst_names),
+        "et_unaligned_two": lambda: edge(["Min", "Max"], False, [dfX, dfY]).transform(src_names, dst_names),
+        "et_method_not_str_error": lambda: T.EdgeTransformer(methods=[3]),
+        "et_len_mismatch_error": lambda: edge("Sum", True, X).transform(src, dst[:-1]),
+        "et_edge_type_numpy": lambda: edge("Sum", True, X, edge_type_features=EF).transform(
+            src, dst, edge_types=etypes),
+        "et_edge_type_two": lambda: edge("Sum", True, X, edge_type_features=[EF, dfEF]).transform(
+            src, dst, edge_types=etypes),
+        "et_edge_type_df_str": lambda: edge("Sum", True, X, edge_type_features=dfEF).transform(
+            src, dst, edge_types=etype_names),
+        "et_edge_type_df_int": lambda: edge("Sum", True, X, edge_type_features=dfEF).transform(
+            src, dst, edge_types=etypes),
+        "et_edge_type_missing_error": lambda: edge("Sum", True, X, edge_type_features=EF).transform(src, dst),
+        "et_edge_type_numpy_str_error": lambda: edge("Sum", True, X, edge_type_features=EF).transform(
+            src, dst, edge_types=etype_names),
+        "et_edge_type_float_error": lambda: edge("Sum", True, X, edge_type_features=EF).transform(
+            src, dst, edge_types=[0.5] * len(src)),
+        "et_edge_type_len_error": lambda: edge("Sum", True, X, edge_type_features=EF).transform(
+            src, dst, edge_types=etypes[:-1]),
+        "et_edge_type_nan_error": lambda: edge("Sum", True, X, edge_type_features=EF * np.nan),
+        "et_edge_type_bad_kind_error": lambda: edge("Sum", True, X, edge_type_features="hu"),
+        "et_edge_type_dup_index_error": lambda: edge(
+            "Sum", True, X, edge_type_features=pd.DataFrame(EF, index=["a", "a", "b"])),
+        "et_edge_features": lambda: edge("Hadamard", True, X).transform(src, dst, edge_features=extra),
+        "et_edge_features_list": lambda: edge("L2Distance", True, X).transform(
+            src, dst, edge_features=[extra, extra[:, 0]]),
+        "et_edge_features_bad_shape_error": lambda: edge("Hadamard", True, X).transform(
+            src, dst, edge_features=extra[:-1]),
+        "et_edge_features_not_numpy_error": lambda: edge("Hadamard", True, X).transform(
+            src, dst, edge_features=[[1.0] * len(src)]),
+        "et_not_fit_error": lambda: T.EdgeTransformer().transform(src, dst),
+        "et_only_edge_type": lambda: edge("Sum", True, [], edge_type_features=EF).transform(
+            src, dst, edge_types=etypes),
+        "et_only_edge_features": lambda: edge("Sum", True, []).transform(src, dst, edge_features=extra),
+        "et_everything": lambda: edge(["Hadamard", "CosineSimilarity"], True, [X, Y], node_type_feature=TF,
+                                      edge_type_features=EF).transform(
+            src, dst, source_node_types=ntypes, destination_node_types=ntypes2, edge_types=etypes,
+            edge_features=extra),
+        "et_node_types": lambda: edge("L2", True, X, node_type_feature=TF).transform(
+            src, dst, source_node_types=ntypes, destination_node_types=ntypes2),
+        "et_node_types_missing_error": lambda: edge("L2", True, X, node_type_feature=TF).transform(src, dst),
+        "et_flags": lambda: np.array([
+            edge("Sum", True, X).has_edge_type_features(),
+            edge("Sum", True, X, edge_type_features=EF).has_edge_type_features(),
+            edge("Sum", True, X, node_type_feature=TF).has_node_type_features(),
+            edge("Sum", True, X).is_aligned_mapping(),
+            edge("Sum", True, X, edge_type_features=[EF, EF]).has_numpy_edge_type_features(),
+            edge("Sum", True, X).has_numpy_edge_type_features()]),
+        "et_flags_df": lambda: np.array([
+            edge("Sum", True, X, edge_type_features=[dfEF, EF]).has_numpy_edge_type_features(),
+            edge("Sum", True, X, edge_type_features=dfEF).has_numpy_edge_type_features()]),
+        # ---- GraphTransformer
+        "gt_array": lambda: gt("Hadamard", True, True, X).transform(np.stack([src, dst], axis=1)),
+        "gt_tuple": lambda: gt("Hadamard", True, True, X).transform((src, dst)),
+        "gt_list": lambda: gt("Sum", True, True, X).transform([[0, 1], [2, 3], [5, 5]]),
+        "gt_names_array": lambda: gt("Sum", False, True, dfX).transform(
+            np.array([src_names, dst_names]).T),
+        "gt_bad_width_error": lambda: gt("Sum", True, True, X).transform(np.zeros((4, 3), dtype=np.int64)),
+        "gt_empty_error": lambda: gt("Sum", True, True, X).transform(np.zeros((0, 2), dtype=np.int64)),
+        "gt_tuple_mismatch_error": lambda: gt("Sum", True, True, X).transform((src, dst[:-1])),
+        "gt_tuple_2d_error": lambda: gt("Sum", True, True, X).transform((src[None], dst[None])),
+        "gt_graph_aligned_both": lambda: gt("Hadamard", True, True, X).transform(graph),
+        "gt_graph_aligned_upper": lambda: gt("Hadamard", True, False, X).transform(graph),
+        "gt_graph_unaligned": lambda: gt("Concatenate", False, True, dfX).transform(graph),
+        "gt_graph_edge_types_aligned": lambda: gt("Sum", True, True, X, edge_type_features=EF).transform(
+            graph, edge_types=graph),
+        "gt_graph_edge_types_upper": lambda: gt("Sum", True, False, X, edge_type_features=EF).transform(
+            graph, edge_types=graph),
+        "gt_graph_edge_types_names": lambda: gt("Sum", False, True, dfX, edge_type_features=dfEF).transform(
+            graph, edge_types=graph),
+        "gt_graph_edge_types_names_upper_aligned": lambda: gt(
+            "Sum", True, False, X, edge_type_features=dfEF).transform(graph, edge_types=graph),
+        "gt_graph_edge_types_no_features_error": lambda: gt("Sum", True, True, X).transform(
+            graph, edge_types=graph),
+        "gt_graph_node_types_aligned": lambda: gt("L1", True, True, X, node_type_feature=TF).transform(
+            graph, node_types=graph),
+        "gt_node_types_tuple": lambda: gt("L1", True, True, X, node_type_feature=TF).transform(
+            (src, dst), node_types=(ntypes, ntypes2)),
+        "gt_graph_everything": lambda: gt(["Average", "CosineSimilarity"], True, True, [X, Y],
+                                          node_type_feature=TF, edge_type_features=EF).transform(
+            graph, node_types=graph, edge_types=graph),
+        "gt_flags": lambda: np.array([
+            gt("Sum", True, True, X).has_node_type_features(),
+            gt("Sum", True, True, X, node_type_feature=TF).has_node_type_features(),
+            gt("Sum", True, True, X, edge_type_features=EF).has_edge_type_features(),
+            gt("Sum", True, True, X).is_aligned_mapping()]),
+    }
+    for m in methods:
+        cases[f"et_{m}"] = (lambda m=m: edge(m, True, X).transform(src, dst))
+        cases[f"gt_graph_{m}"] = (lambda m=m: gt(m, True, True, [X, Y]).transform(graph))
+    out = {}
+    for name, fn in cases.items():
+        if only is not None and not only(name):
+            continue
+        try:
+            out[name] = np.asarray(fn())
+        except AssertionError:
+            out[name] = "AssertionError"
+        except Exception as e:  # noqa: BLE001
+            out[name] = type(e).__name__
+    return out

@@ -146,7 +146,17 @@ def test_graph_type_bookkeeping():
     g = typed_karate()
     assert g.has_node_types() and g.has_edge_types() and not g.is_multigraph()
     assert g.get_number_of_node_types() == 3 and g.get_number_of_edge_types() == 3
-    assert set(g.get_edge_type_names()) == {"a", "b", "c"}
+    assert set(g.get_unique_edge_type_names()) == {"a", "b", "c"}
+    assert set(g.get_unique_node_type_names()) == {"mr_hi", "club", "officer"}
+    assert g.get_node_type_names()[0] == ["club", "officer"] and g.get_node_type_names()[5] is None
+    assert g.get_node_type_names_from_node_name("1") == ["mr_hi"]
+    assert g.has_unknown_edge_types()
+    with pytest.raises(ValueError):
+        g.must_not_contain_unknown_edge_types()
+    g.must_not_be_multigraph()
+    assert len(g.get_source_node_ids(directed=False)) == 78
+    assert len(g.get_upper_triangular_edge_type_names()) == 78
+    assert (g.get_imputed_directed_edge_type_ids(0) != 0xFFFFFFFF).all()
     # both directions of an undirected edge carry the same type
     rp = g.row_ptr.astype(np.int64)
     src = np.repeat(np.arange(34), np.diff(rp))
