@@ -324,10 +324,15 @@ def main():
                                                  "WRITE_SIZE, calibrated; same workload)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(graph, args, central, contextual, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL logs its banner through C stdio on stdout; flush it so the JSON line comes last
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

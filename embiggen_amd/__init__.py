@@ -7,8 +7,9 @@ gfx950 reached through the C ABI in ``include/gn2v.h``; there is no CPU executio
 """
 from . import _lib
 from .embedding_transformers import EdgeTransformer, GraphTransformer, NodeTransformer
-from .embedders import (DeepWalkCBOWEnsmallen, DeepWalkSkipGramEnsmallen, Node2VecCBOWEnsmallen,
-                        Node2VecSkipGramEnsmallen, WalkletsCBOWEnsmallen,
+from .embedders import (DeepWalkCBOWEnsmallen, DeepWalkGloVeEnsmallen, DeepWalkSkipGramEnsmallen,
+                        Node2VecCBOWEnsmallen, Node2VecGloVeEnsmallen, Node2VecSkipGramEnsmallen,
+                        WalkletsCBOWEnsmallen, WalkletsGloVeEnsmallen,
                         WalkletsSkipGramEnsmallen, embed_graph)
 from .graph import CSRGraph, barabasi_albert, karate_club
 from .sequences import Node2VecSequence
@@ -22,7 +23,8 @@ __all__ = [
     "CSRGraph", "karate_club", "barabasi_albert", "EmbeddingResult", "AbstractModel",
     "AbstractEmbeddingModel", "embed_graph", "Node2VecSkipGramEnsmallen",
     "Node2VecCBOWEnsmallen", "DeepWalkSkipGramEnsmallen", "DeepWalkCBOWEnsmallen",
-    "WalkletsSkipGramEnsmallen", "WalkletsCBOWEnsmallen",
+    "WalkletsSkipGramEnsmallen", "WalkletsCBOWEnsmallen", "Node2VecGloVeEnsmallen",
+    "DeepWalkGloVeEnsmallen", "WalkletsGloVeEnsmallen",
     "get_models_dataframe", "get_available_models_for_node_embedding", "normalize_kwargs",
     "Node2VecSequence", "EdgeTransformer", "NodeTransformer", "GraphTransformer",
 ]

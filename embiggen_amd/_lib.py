@@ -36,6 +36,7 @@ EXPORTS = [
     "gn2v_walk_pair_blocks",
     "gn2v_init_table",
     "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_edge_embedding",
+    "gn2v_cooc_slots", "gn2v_glove_step",
     "gn2v_touch_rows",
     "gn2v_stats_reset",
     "gn2v_stats_read",
@@ -53,6 +54,12 @@ class WalkParams(C.Structure):
         ("change_node_type_weight", C.c_float),  # 0 = unset = 1.0
         ("change_edge_type_weight", C.c_float),
     ]
+
+
+class GloveIO(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in (
+        "d_rows", "d_cols", "d_logx", "d_fx", "d_central", "d_contextual", "d_bias_central",
+        "d_bias_contextual")]
 
 
 class TrainParams(C.Structure):
@@ -162,6 +169,8 @@ def lib():
     L.gn2v_walk_pairs.argtypes = [vp, u64, u32, u32, u32, vp, vp]
     L.gn2v_walk_pair_blocks.argtypes = [vp, u64, u32, u32, u32, u32, u64, vp, vp, vp]
     L.gn2v_init_table.argtypes = [vp, u64, u32, u32, u64, u32, f32, vp]
+    L.gn2v_cooc_slots.argtypes = [vp, u64, u32, u32, u32, vp, vp, vp]
+    L.gn2v_glove_step.argtypes = [vp, C.POINTER(GloveIO), u64, u32, u32, f32, u32, vp]
     step = [vp, C.POINTER(TrainParams), vp, u64, u32, u64, u64, u64, f32, vp, vp, vp, vp]
     L.gn2v_sgns_step.argtypes = step
     L.gn2v_cbow_step.argtypes = step

@@ -1,0 +1,82 @@
+"""Co-occurrence counts of random walks for the GloVe model, kept in HBM.
+
+The slots come from the ``gn2v_cooc_slots`` kernel; summing them by key (sort + segmented integer
+sum), merging batches and ordering the training entries is torch tensor plumbing on the device.
+Counts are fixed point (2^20 / distance per co-occurrence), so every sum is exact and independent
+of the order of accumulation; the oracle (oracle/gn2v_oracle.c, "GloVe") produces the same
+integers.  Reference call site: models.GloVe in embedders/ensmallen_embedders/node2vec.py:16-26.
+"""
+from typing import Optional, Tuple
+
+UNUSED = 0x7FFFFFFFFFFFFFFF
+_TAG_GLOVE = 0x610FE00000C00C01
+_M64 = (1 << 64) - 1
+
+
+def _signed(x: int) -> int:
+    x &= _M64
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def mix64_int(z: int) -> int:
+    z &= _M64
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & _M64
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def _lsr(z, s: int):
+    return (z >> s) & ((1 << (64 - s)) - 1)
+
+
+def mix64_tensor(z):
+    """splitmix64 finaliser on an int64 tensor (two's complement wrap-around = u64 arithmetic)."""
+    z = z ^ _lsr(z, 30)
+    z = z * _signed(0xBF58476D1CE4E5B9)
+    z = z ^ _lsr(z, 27)
+    z = z * _signed(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def reduce_slots(keys, weights) -> Tuple["torch.Tensor", "torch.Tensor"]:
+    """(distinct keys, summed weights) of the used slots; keys ascending as int64."""
+    import torch
+
+    keys, order = torch.sort(keys.view(torch.int64).flatten())
+    weights = weights.view(torch.int64).flatten()[order]
+    del order
+    uniq, inverse = torch.unique_consecutive(keys, return_inverse=True)
+    sums = torch.zeros(uniq.numel(), dtype=torch.int64, device=keys.device)
+    sums.index_add_(0, inverse, weights)
+    if uniq.numel() and int(uniq[-1]) == UNUSED:
+        uniq, sums = uniq[:-1], sums[:-1]
+    return uniq, sums
+
+
+def merge(a: Optional[tuple], b: tuple) -> tuple:
+    """Sum of two reduced (keys, counts) sets."""
+    import torch
+
+    if a is None:
+        return b
+    return reduce_slots(torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]]))
+
+
+def entries(keys, counts, seed: int, alpha: float):
+    """Training entries (rows i32, cols i32, log X f32, f(X) f32) in the fixed shuffled order:
+    ascending mix64(key ^ mix64(seed ^ tag)) as u64; X = count / max count."""
+    import torch
+
+    salt = _signed(mix64_int(seed ^ _TAG_GLOVE))
+    h = mix64_tensor(keys ^ salt) ^ _signed(1 << 63)  # flip the sign bit: signed sort = u64 order
+    order = torch.argsort(h, stable=True)
+    keys, counts = keys[order], counts[order]
+    top = counts.max().to(torch.float64) if counts.numel() else torch.tensor(1.0)
+    x = (counts.to(torch.float64) / top).to(torch.float32)
+    logx = torch.log(x.to(torch.float64)).to(torch.float32)
+    fx = torch.pow(x.to(torch.float64), float(alpha)).to(torch.float32)
+    rows = _lsr(keys, 32).to(torch.int32)  # values >= 2^31 wrap to the same 32 bits
+    cols = (keys & 0xFFFFFFFF).to(torch.int32)
+    return rows.contiguous(), cols.contiguous(), logx.contiguous(), fx.contiguous()

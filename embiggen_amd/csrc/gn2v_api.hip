@@ -14,6 +14,7 @@
 #include "../../include/gn2v.h"
 #include "rng.h"
 #include "edge_kernels.h"
+#include "glove_kernels.h"
 #include "train_kernels.h"
 #include "util_kernels.h"
 #include "walk_kernels.h"
@@ -510,6 +511,94 @@ int gn2v_walk_pair_blocks(const uint32_t *d_walks, uint64_t n_walks, uint32_t wa
                           uint32_t *d_pairs, uint64_t *d_keys, void *stream) {
     return launch_pairs(d_walks, n_walks, walk_length, window, min_dist, world, salt, d_pairs,
                         d_keys, true, stream);
+}
+
+int gn2v_cooc_slots(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
+                    uint32_t window, uint32_t min_dist, uint64_t *d_keys, uint64_t *d_weights,
+                    void *stream) {
+    if (window < 1 || walk_length < 2) return fail("need window_size >= 1 and walk_length >= 2");
+    const uint64_t n = n_walks * walk_length * 2 * window;
+    if (n == 0) return 0;
+    if (!d_walks || !d_keys || !d_weights) return fail("NULL pointer");
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(gn2v::cooc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_walks,
+                       n_walks, walk_length, window, min_dist ? min_dist : 1u,
+                       (unsigned long long *)d_keys, (unsigned long long *)d_weights);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C++" {
+template <int CH>
+static void launch_glove_ch(int wm, bool det, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                            const gn2v::GloveArgs &a) {
+    if (det)
+        hipLaunchKernelGGL((gn2v::glove_kernel<CH, gn2v::kWriteBack, true>), grid, block, 0, s, a);
+    else if (wm == gn2v::kAtomic)
+        hipLaunchKernelGGL((gn2v::glove_kernel<CH, gn2v::kAtomic, false>), grid, block, lds, s, a);
+    else if (wm == gn2v::kWriteBack)
+        hipLaunchKernelGGL((gn2v::glove_kernel<CH, gn2v::kWriteBack, false>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((gn2v::glove_kernel<CH, gn2v::kWriteThrough, false>), grid, block, 0, s, a);
+}
+}  // extern "C++"
+
+int gn2v_glove_step(gn2v_graph *g, const gn2v_glove_io *io, uint64_t n_entries, uint32_t d,
+                    uint32_t ld, float lr, uint32_t flags, void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    if (!io) return fail("glove io is NULL");
+    if (d == 0) return fail("embedding size must be strictly positive");
+    if (ld < d || (ld & 3)) return fail("ld must be a multiple of 4 and >= d");
+    if (ld > 512) return fail("embedding sizes above 512 are not supported yet");
+    if (!std::isfinite(lr)) return fail("learning rate must be finite");
+    if (n_entries == 0) return 0;
+    if (!io->d_rows || !io->d_cols || !io->d_logx || !io->d_fx || !io->d_central ||
+        !io->d_contextual || !io->d_bias_central || !io->d_bias_contextual)
+        return fail("NULL entry / table / bias pointer");
+    HIP_TRY(hipSetDevice(g->device));
+    gn2v::GloveArgs a{};
+    a.rows = io->d_rows;
+    a.cols = io->d_cols;
+    a.logx = io->d_logx;
+    a.fx = io->d_fx;
+    a.central = io->d_central;
+    a.contextual = io->d_contextual;
+    a.bias_c = io->d_bias_central;
+    a.bias_x = io->d_bias_contextual;
+    a.n_entries = n_entries;
+    a.ld = ld;
+    a.lr = lr;
+    const bool det = flags & GN2V_TRAIN_DETERMINISTIC;
+    const int wm = (flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
+                   : (flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
+                   : (flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
+                   : g->view.n_nodes < (1ULL << 16)     ? gn2v::kAtomic
+                                                        : gn2v::kWriteThrough;
+    const int waves_per_block = det ? 1 : gn2v::kGloveBlock / 64;
+    const size_t lds = (!det && wm == gn2v::kAtomic) ? (size_t)waves_per_block * 4 * ld * 4 : 0;
+    uint64_t blocks = det ? 1 : (n_entries + 4 * waves_per_block - 1) / (4 * waves_per_block);
+    const uint64_t cap = (uint64_t)g->n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kGloveBlock);
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g->mu);
+    EventPair ev;
+    if (get_events(g, &ev)) return 1;
+    HIP_TRY(hipEventRecord(ev.a, s));
+    const uint32_t nchunks = ld / 4;
+    if (nchunks <= 16)
+        launch_glove_ch<1>(wm, det, grid, block, lds, s, a);
+    else if (nchunks <= 32)
+        launch_glove_ch<2>(wm, det, grid, block, lds, s, a);
+    else if (nchunks <= 64)
+        launch_glove_ch<4>(wm, det, grid, block, lds, s, a);
+    else
+        launch_glove_ch<8>(wm, det, grid, block, lds, s, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.b, s));
+    g->train_events.push_back(ev);
+    g->train_launches++;
+    return 0;
 }
 
 int gn2v_init_table(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,

@@ -56,6 +56,9 @@ class Node2VecEnsmallen(EnsmallenEmbedder):
         "Node2Vec SkipGram": models.SkipGram,
         "Walklets CBOW": models.WalkletsCBOW,
         "Walklets SkipGram": models.WalkletsSkipGram,
+        "DeepWalk GloVe": models.GloVe,
+        "Node2Vec GloVe": models.GloVe,
+        "Walklets GloVe": models.WalkletsGloVe,
     }
 
     def __init__(self, embedding_size: int = 100, random_state: int = 42,
@@ -222,6 +225,77 @@ class Node2VecCBOWEnsmallen(Node2VecEnsmallen):
     @classmethod
     def model_name(cls) -> str:
         return "Node2Vec CBOW"
+
+
+class Node2VecGloVeEnsmallen(Node2VecEnsmallen):
+    """Node2Vec GloVe on the MI355X engine (reference: node2vec_glove.py:5-153): one walk of 512
+    nodes per source node, co-occurrence counts inside the window, 100 epochs of GloVe SGD."""
+
+    _REMOVED_PARAMETERS = ("change_node_type_weight", "change_edge_type_weight",
+                           "number_of_negative_samples", "iterations")
+
+    def __init__(
+        self,
+        embedding_size: int = 100,
+        alpha: float = 0.75,
+        epochs: int = 100,
+        walk_length: int = 512,
+        window_size: int = 5,
+        return_weight: float = 0.25,
+        explore_weight: float = 4.0,
+        change_node_type_weight: float = 1.0,
+        change_edge_type_weight: float = 1.0,
+        max_neighbours: Optional[int] = 100,
+        learning_rate: float = 0.05,
+        learning_rate_decay: float = 0.9,
+        central_nodes_embedding_path: Optional[str] = None,
+        contextual_nodes_embedding_path: Optional[str] = None,
+        normalize_by_degree: bool = False,
+        dtype: str = "f32",
+        random_state: int = 42,
+        ring_bell: bool = False,
+        enable_cache: bool = False,
+        verbose: bool = True,
+    ):
+        super().__init__(iterations=1, **_forward(locals()))
+
+    @classmethod
+    def model_name(cls) -> str:
+        return "Node2Vec GloVe"
+
+
+class DeepWalkGloVeEnsmallen(Node2VecEnsmallen):
+    """DeepWalk GloVe on the MI355X engine (reference: deepwalk_glove.py:5-123)."""
+
+    _REMOVED_PARAMETERS = ("return_weight", "explore_weight", "change_node_type_weight",
+                           "change_edge_type_weight", "number_of_negative_samples", "iterations")
+
+    def __init__(
+        self,
+        embedding_size: int = 100,
+        alpha: float = 0.75,
+        epochs: int = 100,
+        walk_length: int = 512,
+        window_size: int = 5,
+        max_neighbours: Optional[int] = 100,
+        learning_rate: float = 0.05,
+        learning_rate_decay: float = 0.99,
+        central_nodes_embedding_path: Optional[str] = None,
+        contextual_nodes_embedding_path: Optional[str] = None,
+        normalize_by_degree: bool = False,
+        dtype: str = "f32",
+        random_state: int = 42,
+        ring_bell: bool = False,
+        enable_cache: bool = False,
+        verbose: bool = True,
+    ):
+        # the reference leaves return / explore weight to the engine's defaults (first order)
+        super().__init__(iterations=1, return_weight=1.0, explore_weight=1.0,
+                         **_forward(locals()))
+
+    @classmethod
+    def model_name(cls) -> str:
+        return "DeepWalk GloVe"
 
 
 class _DeepWalkMixin:
@@ -413,6 +487,45 @@ class WalkletsCBOWEnsmallen(WalkletsEnsmallen):
     def model_name(cls) -> str:
         return "Walklets CBOW"
 
+
+class WalkletsGloVeEnsmallen(WalkletsEnsmallen):
+    """Walklets GloVe on the MI355X engine (reference: walklets_glove.py:6-143): one GloVe table
+    pair per window scale, on the co-occurrences exactly that many steps apart."""
+
+    _REMOVED_PARAMETERS = ("number_of_negative_samples", "clipping_value", "iterations")
+
+    def __init__(
+        self,
+        embedding_size: int = 100,
+        epochs: int = 100,
+        walk_length: int = 512,
+        window_size: int = 4,
+        return_weight: float = 1.0,
+        explore_weight: float = 1.0,
+        max_neighbours: Optional[int] = 100,
+        learning_rate: float = 0.05,
+        learning_rate_decay: float = 0.9,
+        central_nodes_embedding_path: Optional[str] = None,
+        contextual_nodes_embedding_path: Optional[str] = None,
+        alpha: float = 0.75,
+        normalize_by_degree: bool = False,
+        stochastic_downsample_by_degree: Optional[bool] = False,
+        normalize_learning_rate_by_degree: Optional[bool] = False,
+        use_scale_free_distribution: Optional[bool] = True,
+        random_state: int = 42,
+        dtype: str = "f32",
+        ring_bell: bool = False,
+        enable_cache: bool = False,
+    ):
+        super().__init__(iterations=1, **_forward(locals()))
+
+    @classmethod
+    def model_name(cls) -> str:
+        return "Walklets GloVe"
+
+
+for _model in (Node2VecGloVeEnsmallen, DeepWalkGloVeEnsmallen, WalkletsGloVeEnsmallen):
+    AbstractEmbeddingModel.register(_model)
 
 for _model in (Node2VecSkipGramEnsmallen, Node2VecCBOWEnsmallen, DeepWalkSkipGramEnsmallen,
                DeepWalkCBOWEnsmallen, WalkletsSkipGramEnsmallen, WalkletsCBOWEnsmallen):

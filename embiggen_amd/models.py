@@ -347,9 +347,90 @@ class CBOW(_WalkBasedModel):
     NAME = "CBOW"
 
 
+class GloVe(_WalkBasedModel):
+    """GloVe on the co-occurrences of the walks (``models.GloVe`` of the reference's table,
+    embedders/ensmallen_embedders/node2vec.py:16-26; kwargs node2vec_glove.py:8-30: ``alpha``,
+    100 epochs, walks of 512 nodes, one iteration, learning rate 0.05 x 0.9 per epoch).  Semantics
+    (published GloVe under these kwargs) are stated in oracle/gn2v_oracle.c; the co-occurrence
+    matrix is counted once from ``iterations`` walks per source node, then trained for ``epochs``
+    passes over its non-zero entries."""
+
+    MODEL_ID = 2
+    NAME = "GloVe"
+    SLOTS_PER_BATCH = 1 << 27  # co-occurrence slots generated and reduced at a time (2 x 1 GiB)
+
+    def update_flags(self) -> int:
+        if self.deterministic:
+            return _lib.TRAIN_DETERMINISTIC
+        return {"auto": 0, "atomic": _lib.TRAIN_ATOMIC, "write_back": _lib.TRAIN_WRITE_BACK,
+                "write_through": _lib.TRAIN_WRITE_THROUGH}[self.update_mode]
+
+    def cooccurrence_device(self, csr):
+        """Reduced co-occurrence counts of this model's walks: (keys int64, counts int64)."""
+        from . import cooccurrence, ops
+
+        wp = self.walk_params()
+        total = csr.get_number_of_unique_source_nodes() * self.iterations
+        per_walk = self.walk_length * 2 * self.window_size
+        batch = max(1, self.SLOTS_PER_BATCH // per_walk)
+        acc = None
+        for first in range(0, total, batch):
+            walks = ops.walks(csr, wp, self.random_state, 0, first, min(batch, total - first),
+                              device=self.device)
+            keys, weights = ops.cooc_slots(walks, self.window_size, self.min_distance)
+            acc = cooccurrence.merge(acc, cooccurrence.reduce_slots(keys, weights))
+            del walks, keys, weights
+        return acc
+
+    def fit_transform_device(self, graph, max_walks_per_epoch: int = 0):
+        import torch
+
+        from . import cooccurrence, ops
+
+        csr = _as_csr(graph, self.normalize_by_degree)
+        _lib.require_device()
+        if not torch.cuda.is_available():
+            raise RuntimeError("PyTorch does not see a ROCm device; cannot allocate the tables.")
+        dev = torch.device("cuda", self.device)
+        n, d, ld = csr.get_number_of_nodes(), self.embedding_size, self.padded_size
+        with torch.cuda.device(dev):
+            ops.stats_reset(csr, self.device)
+            start = time.perf_counter()
+            keys, counts = self.cooccurrence_device(csr)
+            rows, cols, logx, fx = cooccurrence.entries(keys, counts, self.random_state, self.alpha)
+            del keys, counts
+            central = ops.init_table(n, d, self.random_state, 0, self.init_scale(), self.device, ld)
+            contextual = ops.init_table(n, d, self.random_state, 1, self.init_scale(), self.device, ld)
+            bias_c = torch.zeros(n, dtype=torch.float32, device=dev)
+            bias_x = torch.zeros(n, dtype=torch.float32, device=dev)
+            lr, flags = np.float32(self.learning_rate), self.update_flags()
+            for _ in range(self.epochs):
+                ops.glove_step(csr, rows, cols, logx, fx, central, contextual, bias_c, bias_x, d,
+                               float(lr), flags)
+                lr = np.float32(lr * np.float32(self.learning_rate_decay))
+            torch.cuda.synchronize(dev)
+            self.last_seconds = time.perf_counter() - start
+        stats = ops.stats_read(csr, self.device)
+        stats["entries"] = int(rows.numel())
+        stats["pairs"] = int(rows.numel()) * self.epochs  # entry updates
+        self.last_stats = stats
+        if self.verbose:
+            print(f"[gn2v] GloVe: {stats['entries']} co-occurrence entries x {self.epochs} epochs in "
+                  f"{self.last_seconds:.3f}s (train kernels {stats['train_ms']:.1f} ms)",
+                  file=sys.stderr)
+        return central, contextual, stats
+
+    def fit_transform_blocks(self, graph, comm, round_walks: int = 1 << 18):
+        raise NotImplementedError("Multi-GPU training is available for SkipGram only.")
+
+
 class WalkletsSkipGram(_WalkletsModel):
     BASE = SkipGram
 
 
 class WalkletsCBOW(_WalkletsModel):
     BASE = CBOW
+
+
+class WalkletsGloVe(_WalkletsModel):
+    BASE = GloVe

@@ -96,6 +96,32 @@ def walk_pair_blocks(walks_tensor, window: int, min_dist: int, world: int, salt:
     return slots, keys
 
 
+def cooc_slots(walks_t, window: int, min_dist: int = 1):
+    """Co-occurrence slots of the walks: (keys int64, weights int64), each [n_walks * L * 2w];
+    unused slots hold (INT64_MAX, 0)."""
+    torch = _torch()
+    n_walks, L = walks_t.shape
+    n = n_walks * L * 2 * window
+    keys = torch.empty(n, dtype=torch.int64, device=walks_t.device)
+    weights = torch.empty(n, dtype=torch.int64, device=walks_t.device)
+    _lib.check(_lib.lib().gn2v_cooc_slots(walks_t.data_ptr(), n_walks, L, window, min_dist,
+                                          keys.data_ptr(), weights.data_ptr(),
+                                          _stream(walks_t.device)))
+    return keys, weights
+
+
+def glove_step(graph: CSRGraph, rows, cols, logx, fx, central, contextual, bias_central,
+               bias_contextual, d: int, lr: float, flags: int = 0):
+    """One SGD pass over the co-occurrence entries (in place on the tables and biases)."""
+    dev = central.device
+    dg = graph.device_graph(dev.index or 0)
+    io = _lib.GloveIO(rows.data_ptr(), cols.data_ptr(), logx.data_ptr(), fx.data_ptr(),
+                      central.data_ptr(), contextual.data_ptr(), bias_central.data_ptr(),
+                      bias_contextual.data_ptr())
+    _lib.check(_lib.lib().gn2v_glove_step(dg.handle, C.byref(io), rows.numel(), d,
+                                          central.shape[1], lr, flags, _stream(dev)))
+
+
 def init_table(n_rows: int, d: int, seed: int, table_id: int, scale: float, device: int = 0,
                ld: Optional[int] = None):
     torch = _torch()

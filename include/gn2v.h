@@ -204,6 +204,37 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
                uint64_t seed, uint64_t max_walks_per_epoch, float *d_central,
                float *d_contextual, gn2v_stats *stats, void *stream);
 
+/* ---- GloVe: the third model of the reference's walk-based table (embedders/ensmallen_embedders/
+ * node2vec.py:16-26 "Node2Vec GloVe" / "DeepWalk GloVe": models.GloVe; wrapper kwargs
+ * node2vec_glove.py:8-30).  The fit = gn2v_walks -> gn2v_cooc_slots -> (sort + sum by key) ->
+ * gn2v_glove_step over the non-zero entries for `epochs` epochs. */
+
+/* Co-occurrence slots of the walks: d_keys / d_weights u64[n_walks][walk_length][2*window]; a used
+ * slot holds centre << 32 | context and the fixed-point weight round(2^20 / distance), an unused
+ * one (INT64_MAX, 0).  Contexts at walk distance [min_dist, window], window trimmed at the
+ * borders.  Summing the weights of equal keys gives X_ij * 2^20 exactly, in any order. */
+int gn2v_cooc_slots(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
+                    uint32_t window, uint32_t min_dist, uint64_t *d_keys, uint64_t *d_weights,
+                    void *stream);
+
+typedef struct {
+    const uint32_t *d_rows; /* entry e couples central row d_rows[e] ...                     */
+    const uint32_t *d_cols; /* ... with contextual row d_cols[e]                            */
+    const float *d_logx;    /* log X_ij (X normalised by its largest entry)                  */
+    const float *d_fx;      /* f(X_ij) = X_ij ^ alpha                                        */
+    float *d_central;       /* f32[n_nodes][ld]                                              */
+    float *d_contextual;    /* f32[n_nodes][ld]                                              */
+    float *d_bias_central;  /* f32[n_nodes]                                                  */
+    float *d_bias_contextual;
+} gn2v_glove_io;
+
+/* One pass of SGD over n_entries non-zero co-occurrence entries: g = f (u.v + b_i + b~_j - log X),
+ * u -= lr g v, v -= lr g u, b_i -= lr g, b~_j -= lr g.  flags: GN2V_TRAIN_DETERMINISTIC (entry
+ * order, one wavefront: equals the oracle) or one of the update-mode bits (default as for
+ * gn2v_sgns_step).  `g` provides the device and the launch-time bookkeeping (gn2v_stats_read). */
+int gn2v_glove_step(gn2v_graph *g, const gn2v_glove_io *io, uint64_t n_entries, uint32_t d,
+                    uint32_t ld, float lr, uint32_t flags, void *stream);
+
 /* Edge embeddings fused with the row gather: out[e] = op(src_table[src_ids[e]], dst_table[dst_ids[e]]).
  * Device form of the operators of embiggen/embedding_transformers/edge_transformer.py:12-343;
  * method ids follow the reference's method table (:348-361):

@@ -644,3 +644,148 @@ uint64_t o_walk_pairs(const uint32_t *walks, uint64_t n_walks, uint32_t L, uint3
     }
     return n;
 }
+
+/* ---------------------------------------------------------------- GloVe
+ * The third model of the reference's walk-based table (embedders/ensmallen_embedders/node2vec.py
+ * :16-26 "Node2Vec GloVe": models.GloVe; wrapper kwargs node2vec_glove.py:8-30: alpha = 0.75,
+ * epochs = 100, walk_length = 512, iterations = 1, window_size = 5, learning_rate = 0.05,
+ * learning_rate_decay = 0.9).  PARITY UNPINNED like the rest of this file: the arithmetic lives in
+ * the ensmallen wheel, so this restates the published algorithm (Pennington, Socher, Manning,
+ * "GloVe: Global Vectors for Word Representation", EMNLP 2014) under the wrapper's kwargs:
+ *   X_ij   = sum over co-occurrences of centre i and context j inside the window of 1 / distance
+ *            (symmetric window, trimmed at the walk borders), normalised by the largest entry
+ *            (the wrapper has no x_max: the weighting function saturates at the maximum);
+ *   loss   = sum_ij f(X_ij) (w_i . w~_j + b_i + b~_j - log X_ij)^2 / 2,  f(x) = x^alpha;
+ *   update = plain SGD (learning_rate, multiplied by learning_rate_decay per epoch) over the
+ *            non-zero entries in a fixed shuffled order; biases are internal (two tables out).
+ * 1 / distance is accumulated in fixed point (2^20 / distance, rounded) so the sums are exact and
+ * independent of the order in which co-occurrences are counted. */
+
+#define O_TAG_GLOVE 0x610FE00000C00C01ULL
+#define O_COOC_ONE (1u << 20)
+#define O_COOC_UNUSED 0x7FFFFFFFFFFFFFFFULL
+
+static inline uint64_t cooc_weight(uint32_t dist) { return (O_COOC_ONE + dist / 2) / dist; }
+
+/* per slot [walk][position][2w]: key = centre << 32 | context and the fixed-point weight, or
+ * (O_COOC_UNUSED, 0) */
+void o_cooc_slots(const uint32_t *walks, uint64_t n_walks, uint32_t L, uint32_t w,
+                  uint32_t min_dist, uint64_t *keys, uint64_t *weights) {
+    uint32_t md = min_dist ? min_dist : 1;
+    for (uint64_t b = 0; b < n_walks; ++b) {
+        const uint32_t *wk = walks + b * L;
+        uint32_t Le = effective_len(wk, L);
+        for (uint32_t i = 0; i < L; ++i)
+            for (uint32_t slot = 0; slot < 2 * w; ++slot) {
+                uint64_t t = (b * L + i) * 2 * w + slot;
+                int64_t j = slot < w ? (int64_t)i - w + slot : (int64_t)i + 1 + (slot - w);
+                keys[t] = O_COOC_UNUSED;
+                weights[t] = 0;
+                if (i >= Le || j < 0 || j >= (int64_t)Le) continue;
+                if (!is_context(i, (uint32_t)j, md)) continue;
+                uint32_t dist = (uint32_t)(j > (int64_t)i ? j - i : i - j);
+                keys[t] = ((uint64_t)wk[i] << 32) | wk[j];
+                weights[t] = cooc_weight(dist);
+            }
+    }
+}
+
+typedef struct {
+    uint64_t key, val;
+} kv64;
+
+static int cmp_kv_key(const void *a, const void *b) {
+    uint64_t x = ((const kv64 *)a)->key, y = ((const kv64 *)b)->key;
+    return x < y ? -1 : x > y;
+}
+
+/* sum the weights of equal keys: keys ascending (unsigned), unused slots dropped; returns the
+ * number of distinct keys written to the front of keys / weights */
+uint64_t o_cooc_reduce(uint64_t *keys, uint64_t *weights, uint64_t n_slots) {
+    kv64 *kv = malloc(sizeof(kv64) * (n_slots ? n_slots : 1));
+    uint64_t m = 0;
+    for (uint64_t t = 0; t < n_slots; ++t)
+        if (keys[t] != O_COOC_UNUSED) {
+            kv[m].key = keys[t];
+            kv[m++].val = weights[t];
+        }
+    qsort(kv, m, sizeof(kv64), cmp_kv_key);
+    uint64_t n = 0;
+    for (uint64_t t = 0; t < m; ++t) {
+        if (n && keys[n - 1] == kv[t].key) {
+            weights[n - 1] += kv[t].val;
+        } else {
+            keys[n] = kv[t].key;
+            weights[n++] = kv[t].val;
+        }
+    }
+    free(kv);
+    return n;
+}
+
+static int cmp_kv_val_key(const void *a, const void *b) {
+    const kv64 *x = a, *y = b;
+    if (x->val != y->val) return x->val < y->val ? -1 : 1;
+    return x->key < y->key ? -1 : x->key > y->key;
+}
+
+/* training entries of the reduced co-occurrence counts, in the fixed shuffled order (ascending
+ * mix64(key ^ mix64(seed ^ TAG))): rows / cols, log X and f(X) with X = count / max count */
+void o_glove_entries(const uint64_t *keys, const uint64_t *counts, uint64_t n, uint64_t seed,
+                     float alpha, uint32_t *rows, uint32_t *cols, float *logx, float *fx) {
+    uint64_t salt = o_mix64(seed ^ O_TAG_GLOVE), mx = 1;
+    kv64 *kv = malloc(sizeof(kv64) * (n ? n : 1));
+    for (uint64_t t = 0; t < n; ++t) {
+        kv[t].key = t;
+        kv[t].val = o_mix64(keys[t] ^ salt);
+        if (counts[t] > mx) mx = counts[t];
+    }
+    qsort(kv, n, sizeof(kv64), cmp_kv_val_key); /* ties (practically none) by input position */
+    for (uint64_t t = 0; t < n; ++t) {
+        uint64_t s = kv[t].key;
+        float x = (float)((double)counts[s] / (double)mx);
+        rows[t] = (uint32_t)(keys[s] >> 32);
+        cols[t] = (uint32_t)(keys[s] & 0xFFFFFFFFu);
+        logx[t] = (float)log((double)x);
+        fx[t] = (float)pow((double)x, (double)alpha);
+    }
+    free(kv);
+}
+
+/* sequential SGD over entries [0, n): for each entry the gradient scale g = f * (u.v + b_i + b~_j
+ * - log X); u -= lr g v, v -= lr g u(old), both biases -= lr g; non-finite g skips the entry */
+void o_glove_step(const uint32_t *rows, const uint32_t *cols, const float *logx, const float *fx,
+                  uint64_t n, float *central, float *contextual, float *bias_c, float *bias_x,
+                  uint32_t d, uint32_t ld, float lr) {
+    for (uint64_t e = 0; e < n; ++e) {
+        float *u = central + (uint64_t)rows[e] * ld, *v = contextual + (uint64_t)cols[e] * ld;
+        float dot = 0.0f;
+        for (uint32_t c = 0; c < d; ++c) dot += u[c] * v[c];
+        float diff = dot + bias_c[rows[e]] + bias_x[cols[e]] - logx[e];
+        float g = fx[e] * diff;
+        if (!isfinite(g)) continue;
+        float s = -lr * g;
+        for (uint32_t c = 0; c < d; ++c) {
+            float uo = u[c];
+            u[c] = uo + s * v[c];
+            v[c] = v[c] + s * uo;
+        }
+        bias_c[rows[e]] += s;
+        bias_x[cols[e]] += s;
+    }
+}
+
+/* GloVe loss of the entries (double accumulation; tests) */
+double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *logx, const float *fx,
+                    uint64_t n, const float *central, const float *contextual,
+                    const float *bias_c, const float *bias_x, uint32_t d, uint32_t ld) {
+    double loss = 0.0;
+    for (uint64_t e = 0; e < n; ++e) {
+        const float *u = central + (uint64_t)rows[e] * ld, *v = contextual + (uint64_t)cols[e] * ld;
+        double dot = 0.0;
+        for (uint32_t c = 0; c < d; ++c) dot += (double)u[c] * v[c];
+        double diff = dot + bias_c[rows[e]] + bias_x[cols[e]] - logx[e];
+        loss += 0.5 * fx[e] * diff * diff;
+    }
+    return loss;
+}

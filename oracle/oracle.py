@@ -250,3 +250,56 @@ def walk_pairs(walks_arr, window: int, min_dist: int = 1):
     n = lib().o_walk_pairs(_ptr(walks_arr), C.c_uint64(n_walks), C.c_uint32(L),
                            C.c_uint32(window), C.c_uint32(min_dist), _ptr(out))
     return out[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------ GloVe
+COOC_UNUSED = 0x7FFFFFFFFFFFFFFF
+
+
+def cooc_slots(walks_arr, window: int, min_dist: int = 1):
+    """(keys u64, weights u64) per slot [n_walks * L * 2w]; unused slots hold COOC_UNUSED / 0."""
+    walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
+    n_walks, L = walks_arr.shape
+    n = n_walks * L * 2 * window
+    keys, weights = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint64)
+    lib().o_cooc_slots(_ptr(walks_arr), C.c_uint64(n_walks), C.c_uint32(L), C.c_uint32(window),
+                       C.c_uint32(min_dist), _ptr(keys), _ptr(weights))
+    return keys, weights
+
+
+def cooc_reduce(keys, weights):
+    """Distinct keys ascending and their summed fixed-point counts."""
+    keys = np.array(keys, dtype=np.uint64)
+    weights = np.array(weights, dtype=np.uint64)
+    lib().o_cooc_reduce.restype = C.c_uint64
+    n = lib().o_cooc_reduce(_ptr(keys), _ptr(weights), C.c_uint64(len(keys)))
+    return keys[:n].copy(), weights[:n].copy()
+
+
+def glove_entries(keys, counts, seed: int, alpha: float):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    n = len(keys)
+    rows, cols = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+    logx, fx = np.empty(n, dtype=np.float32), np.empty(n, dtype=np.float32)
+    lib().o_glove_entries(_ptr(keys), _ptr(counts), C.c_uint64(n), C.c_uint64(seed),
+                          C.c_float(alpha), _ptr(rows), _ptr(cols), _ptr(logx), _ptr(fx))
+    return rows, cols, logx, fx
+
+
+def glove_step(rows, cols, logx, fx, central, contextual, bias_c, bias_x, d: int, lr: float):
+    """In-place sequential SGD over the entries."""
+    for a, t in ((rows, np.uint32), (cols, np.uint32), (logx, np.float32), (fx, np.float32),
+                 (central, np.float32), (contextual, np.float32), (bias_c, np.float32),
+                 (bias_x, np.float32)):
+        assert a.dtype == t and a.flags.c_contiguous
+    lib().o_glove_step(_ptr(rows), _ptr(cols), _ptr(logx), _ptr(fx), C.c_uint64(len(rows)),
+                       _ptr(central), _ptr(contextual), _ptr(bias_c), _ptr(bias_x),
+                       C.c_uint32(d), C.c_uint32(central.shape[1]), C.c_float(lr))
+
+
+def glove_loss(rows, cols, logx, fx, central, contextual, bias_c, bias_x, d: int) -> float:
+    lib().o_glove_loss.restype = C.c_double
+    return lib().o_glove_loss(_ptr(rows), _ptr(cols), _ptr(logx), _ptr(fx), C.c_uint64(len(rows)),
+                              _ptr(central), _ptr(contextual), _ptr(bias_c), _ptr(bias_x),
+                              C.c_uint32(d), C.c_uint32(central.shape[1]))

@@ -98,6 +98,9 @@ def api_defaults():
         "WalkletsSkipGramEnsmallen": "walklets_skipgram.py",
         "WalkletsCBOWEnsmallen": "walklets_cbow.py",
         "WalkletsEnsmallen": "walklets.py",
+        "Node2VecGloVeEnsmallen": "node2vec_glove.py",
+        "DeepWalkGloVeEnsmallen": "deepwalk_glove.py",
+        "WalkletsGloVeEnsmallen": "walklets_glove.py",
         "Node2VecEnsmallen": "node2vec.py",
         "EnsmallenEmbedder": "ensmallen_embedder.py",
     }

@@ -27,6 +27,9 @@ CLASSES = {
     "DeepWalkCBOWEnsmallen": E.DeepWalkCBOWEnsmallen,
     "WalkletsSkipGramEnsmallen": E.WalkletsSkipGramEnsmallen,
     "WalkletsCBOWEnsmallen": E.WalkletsCBOWEnsmallen,
+    "Node2VecGloVeEnsmallen": E.Node2VecGloVeEnsmallen,
+    "DeepWalkGloVeEnsmallen": E.DeepWalkGloVeEnsmallen,
+    "WalkletsGloVeEnsmallen": E.WalkletsGloVeEnsmallen,
 }
 
 

@@ -194,3 +194,18 @@ def test_fused_pair_keys_group_and_shuffle(karate):
     assert not np.array_equal(inside, inside[np.lexsort((inside[:, 1], inside[:, 0]))])  # shuffled
     _, keys2 = ops.walk_pair_blocks(wk, window, 1, world, 100)
     assert not torch.equal(keys, keys2)  # the salt changes the shuffle
+
+
+def test_one_rank_rccl_group_equals_loopback():
+    """The trainer's collectives on the real backend ("nccl" = RCCL) with device tensors; a one-GPU
+    box can only host a one-rank group, the 2-rank exchange logic is covered on gloo
+    (tests/test_blocks_cpu.py)."""
+    import os
+    import subprocess
+    import sys
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_single_rank_check.py")
+    res = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    ok = [l.split() for l in res.stdout.splitlines() if l.startswith("OK ")]  # RCCL logs to stdout too
+    assert len(ok) == 1 and float(ok[0][1]) == 0.0, res.stdout[-500:]
