@@ -82,53 +82,60 @@ __global__ __launch_bounds__(kGloveBlock) void glove_kernel(GloveArgs a) {
     const int lane = threadIdx.x & 63, grp = lane >> 4, q = lane & 15;
     const int wave = threadIdx.x >> 6;
     const uint32_t nchunks = a.ld >> 2;
-    const uint64_t per_round = DET ? 1 : 4;
     const uint64_t wave_id = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    for (uint64_t base = wave_id * per_round; base < a.n_entries; base += n_waves * per_round) {
-        const uint64_t e = DET ? base : base + grp;
-        const bool valid = e < a.n_entries;
-        uint32_t i = 0, j = 0;
-        float lx = 0.f, f = 0.f;
-        if (valid) {
-            i = a.rows[e];
-            j = a.cols[e];
-            lx = a.logx[e];
-            f = a.fx[e];
+    // A wave takes 16 consecutive entries at a time: lane q of every group loads entry q (64 B
+    // contiguous per array and instruction), the groups then pick theirs with a 16-wide shuffle.
+    for (uint64_t base = wave_id * 16; base < a.n_entries; base += n_waves * 16) {
+        const uint64_t el = base + q;
+        uint32_t li = 0, lj = 0;
+        float llx = 0.f, lf = 0.f;
+        if (el < a.n_entries) {
+            li = a.rows[el];
+            lj = a.cols[el];
+            llx = a.logx[el];
+            lf = a.fx[el];
         }
-        float *ub = a.central + (uint64_t)i * a.ld, *vb = a.contextual + (uint64_t)j * a.ld;
-        Row<CH> u, v;
-        load_row<CH>(u, ub, q, nchunks, valid);
-        load_row<CH>(v, vb, q, nchunks, valid);
-        const float dot = dot_rows<CH>(u, v);
-        const float bi = valid ? a.bias_c[i] : 0.f, bj = valid ? a.bias_x[j] : 0.f;
-        const float g = f * (((dot + bi) + bj) - lx);
-        const float s = -a.lr * g;
-        const bool apply = valid && isfinite(g) && (!DET || grp == 0);
-        if constexpr (WM == kAtomic) {
-            float *s_grp = s_glove + ((size_t)wave * 4 + grp) * a.ld;
-            Row<CH> uc, vc;
-            group_to_contig<CH>(uc, u, s_grp, q, a.ld);
-            group_to_contig<CH>(vc, v, s_grp, q, a.ld);
-            if (apply) {
-                scatter_add<CH, kAtomic>(ub, q, nchunks, s, vc, u);
-                scatter_add<CH, kAtomic>(vb, q, nchunks, s, uc, v);
-                if (q == 0) {
-                    unsafeAtomicAdd(a.bias_c + i, s);
-                    unsafeAtomicAdd(a.bias_x + j, s);
+        constexpr int kRounds = DET ? 16 : 4;
+        for (int r = 0; r < kRounds; ++r) {
+            const int slot = DET ? r : r * 4 + grp;
+            const bool valid = base + slot < a.n_entries;
+            const uint32_t i = __shfl(li, slot, 16), j = __shfl(lj, slot, 16);
+            const float lx = __shfl(llx, slot, 16), f = __shfl(lf, slot, 16);
+            float *ub = a.central + (uint64_t)i * a.ld, *vb = a.contextual + (uint64_t)j * a.ld;
+            Row<CH> u, v;
+            load_row<CH>(u, ub, q, nchunks, valid);
+            load_row<CH>(v, vb, q, nchunks, valid);
+            const float dot = dot_rows<CH>(u, v);
+            const float bi = valid ? a.bias_c[i] : 0.f, bj = valid ? a.bias_x[j] : 0.f;
+            const float g = f * (((dot + bi) + bj) - lx);
+            const float s = -a.lr * g;
+            const bool apply = valid && isfinite(g) && (!DET || grp == 0);
+            if constexpr (WM == kAtomic) {
+                float *s_grp = s_glove + ((size_t)wave * 4 + grp) * a.ld;
+                Row<CH> uc, vc;
+                group_to_contig<CH>(uc, u, s_grp, q, a.ld);
+                group_to_contig<CH>(vc, v, s_grp, q, a.ld);
+                if (apply) {
+                    scatter_add<CH, kAtomic>(ub, q, nchunks, s, vc, u);
+                    scatter_add<CH, kAtomic>(vb, q, nchunks, s, uc, v);
+                    if (q == 0) {
+                        unsafeAtomicAdd(a.bias_c + i, s);
+                        unsafeAtomicAdd(a.bias_x + j, s);
+                    }
+                }
+            } else {
+                if (apply) {
+                    scatter_add<CH, WM>(ub, q, nchunks, s, v, u);
+                    scatter_add<CH, WM>(vb, q, nchunks, s, u, v);
+                    if (q == 0) {
+                        a.bias_c[i] = bi + s;
+                        a.bias_x[j] = bj + s;
+                    }
                 }
             }
-        } else {
-            if (apply) {
-                scatter_add<CH, WM>(ub, q, nchunks, s, v, u);
-                scatter_add<CH, WM>(vb, q, nchunks, s, u, v);
-                if (q == 0) {
-                    a.bias_c[i] = bi + s;
-                    a.bias_x[j] = bj + s;
-                }
-            }
+            if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         }
-        if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     }
 }
 

@@ -576,7 +576,7 @@ int gn2v_glove_step(gn2v_graph *g, const gn2v_glove_io *io, uint64_t n_entries, 
                                                         : gn2v::kWriteThrough;
     const int waves_per_block = det ? 1 : gn2v::kGloveBlock / 64;
     const size_t lds = (!det && wm == gn2v::kAtomic) ? (size_t)waves_per_block * 4 * ld * 4 : 0;
-    uint64_t blocks = det ? 1 : (n_entries + 4 * waves_per_block - 1) / (4 * waves_per_block);
+    uint64_t blocks = det ? 1 : (n_entries + 16 * waves_per_block - 1) / (16 * waves_per_block);
     const uint64_t cap = (uint64_t)g->n_cus * 8;
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kGloveBlock);
