@@ -64,6 +64,29 @@ def merge(a: Optional[tuple], b: tuple) -> tuple:
     return reduce_slots(torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]]))
 
 
+class Accumulator:
+    """Running sum of reduced batches.  Batches are kept as sorted runs and merged like a binary
+    counter (two runs merge when the older is at most twice the newer), so every entry takes part
+    in O(log batches) merges instead of one merge per batch."""
+
+    def __init__(self):
+        self.runs = []
+
+    def add(self, run: tuple):
+        self.runs.append(run)
+        while len(self.runs) > 1 and self.runs[-2][0].numel() <= 2 * self.runs[-1][0].numel():
+            b = self.runs.pop()
+            a = self.runs.pop()
+            self.runs.append(merge(a, b))
+
+    def result(self) -> tuple:
+        while len(self.runs) > 1:
+            b = self.runs.pop()
+            a = self.runs.pop()
+            self.runs.append(merge(a, b))
+        return self.runs[0] if self.runs else None
+
+
 def entries(keys, counts, seed: int, alpha: float):
     """Training entries (rows i32, cols i32, log X f32, f(X) f32) in the fixed shuffled order:
     ascending mix64(key ^ mix64(seed ^ tag)) as u64; X = count / max count."""

@@ -373,14 +373,14 @@ class GloVe(_WalkBasedModel):
         total = csr.get_number_of_unique_source_nodes() * self.iterations
         per_walk = self.walk_length * 2 * self.window_size
         batch = max(1, self.SLOTS_PER_BATCH // per_walk)
-        acc = None
+        acc = cooccurrence.Accumulator()
         for first in range(0, total, batch):
             walks = ops.walks(csr, wp, self.random_state, 0, first, min(batch, total - first),
                               device=self.device)
             keys, weights = ops.cooc_slots(walks, self.window_size, self.min_distance)
-            acc = cooccurrence.merge(acc, cooccurrence.reduce_slots(keys, weights))
+            acc.add(cooccurrence.reduce_slots(keys, weights))
             del walks, keys, weights
-        return acc
+        return acc.result()
 
     def fit_transform_device(self, graph, max_walks_per_epoch: int = 0):
         import torch

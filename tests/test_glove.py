@@ -147,6 +147,12 @@ def test_tensor_plumbing_equals_the_oracle(karate_oracle):
     merged = cooccurrence.merge(cooccurrence.merge(None, cooccurrence.reduce_slots(tk[:half], tw[:half])),
                                 cooccurrence.reduce_slots(tk[half:], tw[half:]))
     assert torch.equal(merged[0], got_keys) and torch.equal(merged[1], got_counts)
+    acc = cooccurrence.Accumulator()
+    for lo in range(0, len(keys), len(keys) // 7):
+        acc.add(cooccurrence.reduce_slots(tk[lo:lo + len(keys) // 7], tw[lo:lo + len(keys) // 7]))
+    total = acc.result()
+    assert torch.equal(total[0], got_keys) and torch.equal(total[1], got_counts)
+    assert cooccurrence.Accumulator().result() is None
     for seed in (0, 42, 2 ** 40 + 3):
         rows, cols, logx, fx = cooccurrence.entries(got_keys, got_counts, seed, 0.75)
         orows, ocols, ologx, ofx = O.glove_entries(want_keys, want_counts, seed, 0.75)
