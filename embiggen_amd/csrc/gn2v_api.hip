@@ -125,6 +125,8 @@ gn2v::WalkConsts walk_consts(const gn2v_graph *g, const gn2v_walk_params *wp) {
     c.t_ret = (uint64_t)std::floor(rw / mx * s);
     c.t_common = (uint64_t)std::floor(1.0 / mx * s);
     c.t_explore = (uint64_t)std::floor(ew / mx * s);
+    c.t_min = std::min(c.t_common, c.t_explore);
+    c.t_max = std::max(c.t_common, c.t_explore);
     return c;
 }
 
@@ -138,9 +140,14 @@ int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint6
     EventPair ev;
     if (get_events(g, &ev)) return 1;
     HIP_TRY(hipEventRecord(ev.a, s));
-    hipLaunchKernelGGL(gn2v::walk_kernel, dim3((unsigned)blocks), dim3(gn2v::kWalkBlock), 0, s,
-                       g->view, c, gn2v::epoch_key(seed, epoch), first_walk, n_walks, d_out,
-                       g->counters);
+    if (c.node_bias || c.edge_bias)
+        hipLaunchKernelGGL(gn2v::walk_kernel<true>, dim3((unsigned)blocks),
+                           dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
+                           first_walk, n_walks, d_out, g->counters);
+    else
+        hipLaunchKernelGGL(gn2v::walk_kernel<false>, dim3((unsigned)blocks),
+                           dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
+                           first_walk, n_walks, d_out, g->counters);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, s));
     g->walk_events.push_back(ev);

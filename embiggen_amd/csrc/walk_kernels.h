@@ -36,6 +36,7 @@ struct WalkConsts {
     uint32_t second_order;
     uint32_t node_bias, edge_bias;        // type factors active (types present and weight != 1)
     uint64_t t_ret, t_common, t_explore;  // acceptance thresholds on a 2^32 scale
+    uint64_t t_min, t_max;                // min / max of (t_common, t_explore)
     uint64_t fn_same, fn_diff, fe_same, fe_diff;
 };
 
@@ -73,7 +74,9 @@ __device__ __forceinline__ uint64_t scale32(uint64_t t, uint64_t f) {
     return f >= (1ULL << 32) ? t : (t * f) >> 32;
 }
 
-// acceptance threshold of candidate edge e = cur -> x
+// acceptance threshold of candidate edge e = cur -> x (TYPED = false compiles the type factors
+// out: the untyped instantiation of the walk kernel needs a third fewer registers)
+template <bool TYPED>
 __device__ __forceinline__ uint64_t accept_threshold(const GraphView &g, const WalkConsts &c,
                                                      uint32_t cur, uint32_t x, uint64_t e,
                                                      uint32_t prev, uint64_t pstart,
@@ -83,14 +86,55 @@ __device__ __forceinline__ uint64_t accept_threshold(const GraphView &g, const W
         t = (x == prev) ? c.t_ret
             : adj_contains(g.col_idx, pstart, pend, x) ? c.t_common
                                                        : c.t_explore;
-    if (c.node_bias) t = scale32(t, g.node_types[cur] != g.node_types[x] ? c.fn_diff : c.fn_same);
-    if (c.edge_bias && prev != kSentinel)
-        t = scale32(t, g.edge_types[e] != ptype ? c.fe_diff : c.fe_same);
+    if constexpr (TYPED) {
+        if (c.node_bias)
+            t = scale32(t, g.node_types[cur] != g.node_types[x] ? c.fn_diff : c.fn_same);
+        if (c.edge_bias && prev != kSentinel)
+            t = scale32(t, g.edge_types[e] != ptype ? c.fe_diff : c.fe_same);
+    }
     return t;
+}
+
+// Bounds of the acceptance threshold that need no adjacency search: the class of a candidate other
+// than `prev` is either "common neighbour" or "other", so its threshold lies in [lo, hi]; a draw
+// below lo is accepted and a draw at or above hi rejected whatever the class turns out to be
+// (lo == hi when the class does not matter or is known).  Same decision as accept_threshold.
+struct ThresholdBounds {
+    uint64_t lo, hi;
+};
+
+template <bool TYPED>
+__device__ __forceinline__ ThresholdBounds threshold_bounds(const GraphView &g,
+                                                            const WalkConsts &c, uint32_t cur,
+                                                            uint32_t x, uint64_t e, uint32_t prev,
+                                                            uint32_t ptype) {
+    ThresholdBounds b{1ULL << 32, 1ULL << 32};
+    if (c.second_order && prev != kSentinel) {
+        if (x == prev) {
+            b.lo = b.hi = c.t_ret;
+        } else {
+            b.lo = c.t_min;
+            b.hi = c.t_max;
+        }
+    }
+    if constexpr (TYPED) {
+        if (c.node_bias) {
+            const uint64_t f = g.node_types[cur] != g.node_types[x] ? c.fn_diff : c.fn_same;
+            b.lo = scale32(b.lo, f);
+            b.hi = scale32(b.hi, f);
+        }
+        if (c.edge_bias && prev != kSentinel) {
+            const uint64_t f = g.edge_types[e] != ptype ? c.fe_diff : c.fe_same;
+            b.lo = scale32(b.lo, f);
+            b.hi = scale32(b.hi, f);
+        }
+    }
+    return b;
 }
 
 // exact fallback after kMaxTrials rejections (rare: only for extreme weights on low-weight rows);
 // returns the index of the chosen edge inside the row
+template <bool TYPED>
 __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts &c, uint64_t r,
                                             uint32_t cur, uint64_t start, uint64_t deg,
                                             uint32_t prev, uint64_t pstart, uint64_t pend,
@@ -98,13 +142,13 @@ __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts
     if (g.cumw == nullptr) {
         uint64_t total = 0;
         for (uint64_t i = 0; i < deg; ++i)
-            total += accept_threshold(g, c, cur, g.col_idx[start + i], start + i, prev, pstart,
+            total += accept_threshold<TYPED>(g, c, cur, g.col_idx[start + i], start + i, prev, pstart,
                                       pend, ptype);
         if (total == 0) return ((r >> 32) * deg) >> 32;
         const uint64_t target = mulhi64(r, total);
         uint64_t acc = 0;
         for (uint64_t i = 0; i < deg; ++i) {
-            acc += accept_threshold(g, c, cur, g.col_idx[start + i], start + i, prev, pstart,
+            acc += accept_threshold<TYPED>(g, c, cur, g.col_idx[start + i], start + i, prev, pstart,
                                     pend, ptype);
             if (acc > target) return i;
         }
@@ -114,7 +158,7 @@ __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts
     for (uint64_t i = 0; i < deg; ++i) {
         const double w = __dsub_rn((double)g.cumw[start + i],
                                    i ? (double)g.cumw[start + i - 1] : 0.0);
-        const uint64_t thr = accept_threshold(g, c, cur, g.col_idx[start + i], start + i, prev,
+        const uint64_t thr = accept_threshold<TYPED>(g, c, cur, g.col_idx[start + i], start + i, prev,
                                               pstart, pend, ptype);
         total = __dadd_rn(total, __dmul_rn(w, (double)thr));
     }
@@ -124,7 +168,7 @@ __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts
     for (uint64_t i = 0; i < deg; ++i) {
         const double w = __dsub_rn((double)g.cumw[start + i],
                                    i ? (double)g.cumw[start + i - 1] : 0.0);
-        const uint64_t thr = accept_threshold(g, c, cur, g.col_idx[start + i], start + i, prev,
+        const uint64_t thr = accept_threshold<TYPED>(g, c, cur, g.col_idx[start + i], start + i, prev,
                                               pstart, pend, ptype);
         acc = __dadd_rn(acc, __dmul_rn(w, (double)thr));
         if (acc > target) return i;
@@ -137,6 +181,7 @@ __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts
 constexpr int kWalkBlock = 256;
 constexpr int kTileSteps = 16;
 
+template <bool TYPED>
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConsts c, uint64_t ekey,
                                                           uint64_t first_walk, uint64_t n_walks,
                                                           uint32_t *__restrict__ out,
@@ -178,31 +223,58 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                 } else {
                     uint64_t idx;
                     const bool biased =
-                        c.node_bias || (prev != kSentinel && (c.second_order || c.edge_bias));
+                        (TYPED && c.node_bias) ||
+                        (prev != kSentinel && (c.second_order || (TYPED && c.edge_bias)));
                     if (!biased || deg == 1) {
                         const uint64_t r = draw(wkey, ctr++);
                         idx = pick_index(g, start, deg, r);
                     } else {
+                        // Trials in two phases so that the wave pays for an adjacency search
+                        // only when some lane's draw falls between the class thresholds: phase A
+                        // runs trials until one is decided without the search (accept) or needs
+                        // it; phase B searches for the lanes that need it, in lock step.
                         bool accepted = false;
                         idx = 0;
-                        for (int trial = 0; trial < kMaxTrials; ++trial) {
-                            const uint64_t r = draw(wkey, ctr++);
-                            const uint64_t i = pick_index(g, start, deg, r);
-                            const uint64_t thr = accept_threshold(
-                                g, c, cur, g.col_idx[start + i], start + i, prev, pstart, pend, ptype);
-                            if ((r & 0xFFFFFFFFULL) < thr) {
+                        int trial = 0;
+                        while (trial < kMaxTrials) {
+                            uint64_t r = 0, i = 0;
+                            bool pending = false;
+                            while (trial < kMaxTrials) {
+                                r = draw(wkey, ctr++);
+                                i = pick_index(g, start, deg, r);
+                                ++trial;
+                                const ThresholdBounds b = threshold_bounds<TYPED>(
+                                    g, c, cur, g.col_idx[start + i], start + i, prev, ptype);
+                                const uint64_t r32 = r & 0xFFFFFFFFULL;
+                                if (r32 < b.lo) {
+                                    accepted = true;
+                                    break;
+                                }
+                                if (r32 < b.hi) {
+                                    pending = true;
+                                    break;
+                                }
+                            }
+                            if (pending) {
+                                const uint64_t thr = accept_threshold<TYPED>(
+                                    g, c, cur, g.col_idx[start + i], start + i, prev, pstart, pend, ptype);
+                                accepted = (r & 0xFFFFFFFFULL) < thr;
+                            }
+                            if (accepted) {
                                 idx = i;
-                                accepted = true;
                                 break;
                             }
+                            if (!pending) break;  // trials exhausted
                         }
                         if (!accepted) {
                             const uint64_t r = draw(wkey, ctr++);
-                            idx = exact_scan(g, c, r, cur, start, deg, prev, pstart, pend, ptype);
+                            idx = exact_scan<TYPED>(g, c, r, cur, start, deg, prev, pstart, pend,
+                                                    ptype);
                         }
                     }
                     const uint32_t nxt = g.col_idx[start + idx];
-                    if (c.edge_bias) ptype = g.edge_types[start + idx];
+                    if constexpr (TYPED)
+                        if (c.edge_bias) ptype = g.edge_types[start + idx];
                     val = nxt;
                     prev = cur;
                     pstart = start;
