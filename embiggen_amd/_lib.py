@@ -17,6 +17,7 @@ _HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v.h")
 
 SENTINEL = 0xFFFFFFFF
 GRAPH_DEVICE_PTRS = 1
+GRAPH_SYMMETRIC = 2
 TRAIN_SCALE_FREE = 1
 TRAIN_DOWNSAMPLE = 2
 TRAIN_NORM_LR = 4

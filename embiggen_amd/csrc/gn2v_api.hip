@@ -127,6 +127,18 @@ gn2v::WalkConsts walk_consts(const gn2v_graph *g, const gn2v_walk_params *wp) {
     c.t_explore = (uint64_t)std::floor(ew / mx * s);
     c.t_min = std::min(c.t_common, c.t_explore);
     c.t_max = std::max(c.t_common, c.t_explore);
+    // trial budget: 37 / (smallest acceptance probability) rejections leave a chance below e^-37
+    // of reaching the exact scan; clamped to [32, 1024] (same formula as the oracle)
+    double a = 1.0;
+    if (c.second_order) a *= (double)std::min(c.t_ret, c.t_min) / s;
+    if (c.node_bias) a *= (double)std::min(c.fn_same, c.fn_diff) / s;
+    if (c.edge_bias) a *= (double)std::min(c.fe_same, c.fe_diff) / s;
+    if (!(a > 37.0 / 1024.0)) {
+        c.max_trials = 1024;
+    } else {
+        const double n = std::ceil(37.0 / a);
+        c.max_trials = n < 32.0 ? 32u : (uint32_t)n;
+    }
     return c;
 }
 
@@ -388,6 +400,7 @@ int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const fl
     g->view.n_nodes = n_nodes;
     g->view.n_edges = n_edges;
     g->view.n_sources = n_sources;
+    g->view.symmetric = (flags & GN2V_GRAPH_SYMMETRIC) ? 1u : 0u;
     if (hipMalloc(&g->counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(g->counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
         cleanup();

@@ -9,7 +9,7 @@
 //   {return, 1, explore} by class {prev, common neighbour, other}      (second order)
 //   change_node_type_weight when type(candidate) != type(cur)          (graphs with node types)
 //   change_edge_type_weight when type(edge) != type(previous edge)     (graphs with edge types)
-// (node2vec_sequence.py:57-66); after kMaxTrials rejections the lane falls back to an exact
+// (node2vec_sequence.py:57-66); after max_trials rejections the lane falls back to an exact
 // integer-weighted scan of the row.  All arithmetic that decides a transition is integer (or
 // single rounded f32/f64 ops), so the walks are bit-identical to oracle/gn2v_oracle.c.
 #pragma once
@@ -17,7 +17,6 @@
 
 namespace gn2v {
 
-constexpr int kMaxTrials = 32;
 
 struct GraphView {
     const uint64_t *row_ptr;
@@ -29,12 +28,14 @@ struct GraphView {
     uint64_t n_nodes;
     uint64_t n_edges;
     uint64_t n_sources;
+    uint32_t symmetric;  // every edge is stored in both directions (undirected graph)
 };
 
 struct WalkConsts {
     uint32_t walk_length;
     uint32_t second_order;
     uint32_t node_bias, edge_bias;        // type factors active (types present and weight != 1)
+    uint32_t max_trials;                  // rejections before the exact scan (host: trial_budget)
     uint64_t t_ret, t_common, t_explore;  // acceptance thresholds on a 2^32 scale
     uint64_t t_min, t_max;                // min / max of (t_common, t_explore)
     uint64_t fn_same, fn_diff, fe_same, fe_diff;
@@ -51,6 +52,20 @@ __device__ __forceinline__ bool adj_contains(const uint32_t *__restrict__ col, u
             hi = mid;
     }
     return lo < end && col[lo] == x;
+}
+
+// Is x adjacent to prev?  On a symmetric graph the question can be asked from either side, so a
+// long adjacency list of prev (a hub: up to 17 dependent loads) is replaced by the list of x when
+// that one is shorter -- in lock step the deepest search of the wave sets the pace.
+constexpr uint64_t kLongRow = 64;
+
+__device__ __forceinline__ bool is_common_neighbour(const GraphView &g, uint32_t x, uint32_t prev,
+                                                    uint64_t pstart, uint64_t pend) {
+    if (g.symmetric && pend - pstart > kLongRow) {
+        const uint64_t xs = g.row_ptr[x], xe = g.row_ptr[x + 1];
+        if (xe - xs < pend - pstart) return adj_contains(g.col_idx, xs, xe, prev);
+    }
+    return adj_contains(g.col_idx, pstart, pend, x);
 }
 
 __device__ __forceinline__ uint64_t pick_index(const GraphView &g, uint64_t start, uint64_t deg,
@@ -84,8 +99,8 @@ __device__ __forceinline__ uint64_t accept_threshold(const GraphView &g, const W
     uint64_t t = 1ULL << 32;
     if (c.second_order && prev != kSentinel)
         t = (x == prev) ? c.t_ret
-            : adj_contains(g.col_idx, pstart, pend, x) ? c.t_common
-                                                       : c.t_explore;
+            : is_common_neighbour(g, x, prev, pstart, pend) ? c.t_common
+                                                            : c.t_explore;
     if constexpr (TYPED) {
         if (c.node_bias)
             t = scale32(t, g.node_types[cur] != g.node_types[x] ? c.fn_diff : c.fn_same);
@@ -132,7 +147,7 @@ __device__ __forceinline__ ThresholdBounds threshold_bounds(const GraphView &g,
     return b;
 }
 
-// exact fallback after kMaxTrials rejections (rare: only for extreme weights on low-weight rows);
+// exact fallback after max_trials rejections (rare: only for extreme weights on low-weight rows);
 // returns the index of the chosen edge inside the row
 template <bool TYPED>
 __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts &c, uint64_t r,
@@ -235,11 +250,11 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                         // it; phase B searches for the lanes that need it, in lock step.
                         bool accepted = false;
                         idx = 0;
-                        int trial = 0;
-                        while (trial < kMaxTrials) {
+                        uint32_t trial = 0;
+                        while (trial < c.max_trials) {
                             uint64_t r = 0, i = 0;
                             bool pending = false;
-                            while (trial < kMaxTrials) {
+                            while (trial < c.max_trials) {
                                 r = draw(wkey, ctr++);
                                 i = pick_index(g, start, deg, r);
                                 ++trial;

@@ -215,7 +215,8 @@ class CSRGraph:
     def from_csr(cls, row_ptr, col_idx, weights=None, node_names=None, name: str = "Graph",
                  directed: bool = False, node_type_ids=None, edge_type_ids=None):
         """Wrap existing CSR arrays (neighbours must be ascending per row, and unique unless
-        parallel edges of different types are meant)."""
+        parallel edges of different types are meant).  ``directed=False`` declares that every edge
+        is present in both directions; the walk sampler relies on it."""
         return cls(row_ptr, col_idx, weights, node_names, name, directed,
                    node_type_ids=node_type_ids, edge_type_ids=edge_type_ids)
 
@@ -586,6 +587,9 @@ class CSRGraph:
         with _HANDLE_LOCK:
             return self._device_graph_locked(device)
 
+    def _symmetry_flag(self) -> int:
+        return 0 if self._directed else _lib.GRAPH_SYMMETRIC
+
     def _device_graph_locked(self, device: int) -> DeviceGraph:
         if device in self._handles:
             return self._handles[device]
@@ -602,7 +606,8 @@ class CSRGraph:
                 t["row_ptr"].data_ptr(), t["col_idx"].data_ptr(),
                 None if cumw is None else cumw.data_ptr(),
                 None if src is None else src.data_ptr(), self._n_nodes, self._n_edges,
-                self._n_sources, _lib.GRAPH_DEVICE_PTRS, device, C.byref(handle)))
+                self._n_sources, _lib.GRAPH_DEVICE_PTRS | self._symmetry_flag(), device,
+                C.byref(handle)))
             dg = DeviceGraph(handle, device, keep_alive=(t,))
             nt, et = t.get("node_types"), t.get("edge_types")
             if nt is not None or et is not None:
@@ -614,7 +619,7 @@ class CSRGraph:
                 self._row_ptr.ctypes.data, self._col_idx.ctypes.data,
                 None if self._cumw is None else self._cumw.ctypes.data,
                 None if srcs is None else srcs.ctypes.data, self._n_nodes, self._n_edges,
-                self._n_sources, 0, device, C.byref(handle)))
+                self._n_sources, self._symmetry_flag(), device, C.byref(handle)))
             dg = DeviceGraph(handle, device)
             nt, et = self._node_type_ids, self._edge_type_ids
             if nt is not None or et is not None:

@@ -35,6 +35,8 @@ extern "C" {
 
 /* gn2v_graph_create flags */
 #define GN2V_GRAPH_DEVICE_PTRS 1u /* arrays are device pointers, borrowed (not copied) */
+#define GN2V_GRAPH_SYMMETRIC 2u   /* undirected: every edge is stored in both directions (lets the
+                                     sampler test adjacency from the shorter of two rows)       */
 
 /* gn2v_train_params.flags */
 #define GN2V_TRAIN_SCALE_FREE 1u     /* use_scale_free_distribution (node2vec_skipgram.py:101) */

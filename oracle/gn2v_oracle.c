@@ -44,7 +44,6 @@
 #define O_TAG_BA 0xBA5EBA11BA5EBA11ULL
 #define O_TAG_INIT 0x1417AB1E00000000ULL
 #define O_SENTINEL 0xFFFFFFFFu
-#define O_MAX_TRIALS 32
 
 #define O_FLAG_SCALE_FREE 1u
 #define O_FLAG_DOWNSAMPLE 2u
@@ -179,7 +178,23 @@ typedef struct {
     int second, node_bias, edge_bias;
     uint64_t t_ret, t_common, t_explore;
     uint64_t fn_same, fn_diff, fe_same, fe_diff;
+    uint32_t max_trials; /* rejections before the exact scan */
 } walk_consts;
+
+static inline uint64_t min_u64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
+/* Trial budget: with a_min the smallest acceptance probability any candidate can have, 37 / a_min
+ * trials leave a chance below e^-37 of reaching the (possibly very long) exact scan; clamped to
+ * [32, 1024] so that pathological weights still terminate through the scan. */
+static uint32_t trial_budget(const walk_consts *c) {
+    double a = 1.0, s = 4294967296.0;
+    if (c->second) a *= (double)min_u64(c->t_ret, min_u64(c->t_common, c->t_explore)) / s;
+    if (c->node_bias) a *= (double)min_u64(c->fn_same, c->fn_diff) / s;
+    if (c->edge_bias) a *= (double)min_u64(c->fe_same, c->fe_diff) / s;
+    if (!(a > 37.0 / 1024.0)) return 1024;
+    double n = ceil(37.0 / a);
+    return n < 32.0 ? 32u : (uint32_t)n;
+}
 
 static void type_factors(float weight, uint64_t *same, uint64_t *diff) {
     double w = weight == 0.0f ? 1.0 : (double)weight;
@@ -203,6 +218,7 @@ static walk_consts make_walk_consts(const o_graph *g, const o_walk_params *wp) {
     type_factors(wp->change_edge_type_weight, &c.fe_same, &c.fe_diff);
     c.node_bias = g->node_types != NULL && c.fn_same != c.fn_diff;
     c.edge_bias = g->edge_types != NULL && c.fe_same != c.fe_diff;
+    c.max_trials = trial_budget(&c);
     return c;
 }
 
@@ -243,7 +259,7 @@ static inline uint64_t pick_index(const o_graph *g, uint64_t start, uint64_t deg
     return lo < deg ? lo : deg - 1;
 }
 
-/* exact fallback after O_MAX_TRIALS rejections: integer-weighted scan over the whole row
+/* exact fallback after max_trials rejections: integer-weighted scan over the whole row
  * (unweighted graphs); weighted graphs scale each threshold by the edge weight in double.
  * Returns the index of the chosen edge inside the row. */
 static uint64_t exact_scan(const o_graph *g, const walk_consts *c, uint64_t r, uint32_t cur,
@@ -303,7 +319,7 @@ void o_walk_one(const o_graph *g, const o_walk_params *wp, uint64_t wkey, uint32
         } else {
             int accepted = 0;
             idx = 0;
-            for (int trial = 0; trial < O_MAX_TRIALS; ++trial) {
+            for (uint32_t trial = 0; trial < c.max_trials; ++trial) {
                 uint64_t r = o_draw(wkey, ctr++);
                 uint64_t i = pick_index(g, start, deg, r);
                 uint64_t thr = accept_threshold(g, &c, cur, g->col_idx[start + i], start + i,

@@ -44,3 +44,5 @@ rate(typed, ops.walk_params(128, 10, 1.0, 1.0, 100, 1.0, 0.5), "first order + ed
 rate(typed, ops.walk_params(128, 10, 0.25, 4.0, 100, 2.0, 0.5), "rw.25/ew4 + node x2 + edge x0.5")
 rate(g, ops.walk_params(128, 10, 2.0, 0.5), "untyped rw2/ew.5")
 rate(typed, ops.walk_params(128, 10, 2.0, 0.5, 100, 2.0, 0.5), "rw2/ew.5 + node x2 + edge x0.5")
+rate(g, ops.walk_params(128, 10, 4.0, 0.25), "untyped rw4/ew.25")
+rate(g, ops.walk_params(128, 10, 0.5, 2.0), "untyped rw.5/ew2")

@@ -42,8 +42,9 @@ def test_struct_layouts_match_header():
                         ("GN2V_TRAIN_ATOMIC", _lib.TRAIN_ATOMIC),
                         ("GN2V_TRAIN_WRITE_BACK", _lib.TRAIN_WRITE_BACK),
                         ("GN2V_TRAIN_WRITE_THROUGH", _lib.TRAIN_WRITE_THROUGH),
-                        ("GN2V_GRAPH_DEVICE_PTRS", _lib.GRAPH_DEVICE_PTRS)):
-        assert re.search(rf"#define {name} {value}u", text), name
+                        ("GN2V_GRAPH_DEVICE_PTRS", _lib.GRAPH_DEVICE_PTRS),
+                        ("GN2V_GRAPH_SYMMETRIC", _lib.GRAPH_SYMMETRIC)):
+        assert re.search(rf"#define {name} +{value}u", text), name
 
 
 def test_errors_are_reported_not_thrown():

@@ -72,7 +72,7 @@ def test_second_order_transition_distribution(karate, karate_oracle, rw, ew):
 
 def test_extreme_weights_use_exact_fallback(karate, karate_oracle):
     """return_weight >> 1 with explore tiny: acceptance ~1e-4, the rejection loop gives up after
-    32 trials and the exact scan must still sample the right distribution."""
+    128 trials and the exact scan must still sample the right distribution."""
     rw, ew = 1.0, 1e-4
     wp = O.WalkParams(3, 1, rw, ew, 100, 0)
     w = O.walks(karate_oracle, wp, 3, 0, 0, 34 * 4000).astype(np.int64)
