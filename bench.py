@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=10)
-    ap.add_argument("--walks", type=int, default=1 << 19, help="walks per step per GPU")
+    ap.add_argument("--walks", type=int, default=1 << 20, help="walks per step per GPU")
     ap.add_argument("--batch", type=int, default=1 << 16, help="walks per training launch")
     ap.add_argument("--walk-batch", type=int, default=1 << 19,
                     help="walks per walk-kernel launch (the sampler is latency bound: it needs "
@@ -58,9 +58,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--parallelism", default="auto", choices=["auto", "single", "blocks"],
                     help="auto: single on 1 GPU, block-partitioned tables on N > 1 GPUs")
-    ap.add_argument("--round-walks", type=int, default=1 << 19,
+    ap.add_argument("--round-walks", type=int, default=1 << 20,
                     help="blocks: walks per rank per round (one ring rotation of the context "
-                         "partitions per round)")
+                         "partitions per round; larger rounds amortise it: 2^20 measured 5 %% "
+                         "faster than 2^19 already on one GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: all ranks use GPU 0 (use with --backend gloo)")
