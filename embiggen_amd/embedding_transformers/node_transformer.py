@@ -12,7 +12,7 @@ Deliberate difference: with ``aligned_mapping=False`` the reference looks node t
 *node* feature frame (node_transformer.py:222, a slip: the node type frame is meant); this class
 uses the node type feature frame.
 """
-from typing import List, Optional, Union
+from typing import Optional
 
 import numpy as np
 import pandas as pd

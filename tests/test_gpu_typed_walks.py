@@ -6,7 +6,7 @@ import torch
 
 import embiggen_amd as E
 from embiggen_amd import _lib, ops
-from helpers import link_auc, typed_karate
+from helpers import typed_karate
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
