@@ -169,6 +169,33 @@ def test_embedders_learn_communities_and_keep_the_contract():
     assert out.get_all_node_embedding()[0].shape == (34, 8)
 
 
+def test_parallel_schedules_reach_the_sequential_loss():
+    """Racy schedules vs the deterministic one on the same entries: same loss level (BA 5 k nodes:
+    collisions are real but not dominant, as in the SGNS equivalence test)."""
+    n = 5000
+    g = E.barabasi_albert(n, 5, seed=3)
+    kw = dict(embedding_size=32, random_state=11, epochs=8, walk_length=30, iterations=1,
+              window_size=4, return_weight=1.0, explore_weight=1.0, learning_rate=0.05,
+              learning_rate_decay=0.95, verbose=False)
+    ref = models.GloVe(deterministic=True, **kw)
+    keys, counts = ref.cooccurrence_device(g)
+    rows, cols, logx, fx = cooccurrence.entries(keys, counts, 11, 0.75)
+    host = [t.cpu().numpy() for t in (rows, cols, logx, fx)]
+    host[0], host[1] = host[0].view(np.uint32), host[1].view(np.uint32)
+    zero = np.zeros(n, np.float32)  # biases are internal; compare the bias-free loss level
+
+    def loss_of(model):
+        c, x, _ = model.fit_transform_device(g)
+        assert torch.isfinite(c).all() and torch.isfinite(x).all()
+        return O.glove_loss(*host, np.ascontiguousarray(c.cpu().numpy()),
+                            np.ascontiguousarray(x.cpu().numpy()), zero, zero, 32)
+
+    want = loss_of(ref)
+    for mode in ("atomic", "write_through", "write_back"):
+        got = loss_of(models.GloVe(update_mode=mode, **kw))
+        assert abs(got - want) < 0.05 * want, (mode, got, want)
+
+
 def test_glove_step_argument_errors(karate):
     import ctypes as C
 
