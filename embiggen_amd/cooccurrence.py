@@ -41,18 +41,28 @@ def mix64_tensor(z):
 
 
 def reduce_slots(keys, weights) -> Tuple["torch.Tensor", "torch.Tensor"]:
-    """(distinct keys, summed weights) of the used slots; keys ascending as int64."""
+    """(distinct keys, summed weights) of the used slots; keys ascending as int64.  One radix sort,
+    then segment sums as differences of an exact int64 running sum (no atomics, no inverse map)."""
     import torch
 
     keys, order = torch.sort(keys.view(torch.int64).flatten())
     weights = weights.view(torch.int64).flatten()[order]
     del order
-    uniq, inverse = torch.unique_consecutive(keys, return_inverse=True)
-    sums = torch.zeros(uniq.numel(), dtype=torch.int64, device=keys.device)
-    sums.index_add_(0, inverse, weights)
-    if uniq.numel() and int(uniq[-1]) == UNUSED:
-        uniq, sums = uniq[:-1], sums[:-1]
-    return uniq, sums
+    unused = torch.tensor([UNUSED], dtype=torch.int64, device=keys.device)
+    used = int(torch.searchsorted(keys, unused)[0])  # unused slots sort behind every key
+    keys, weights = keys[:used], weights[:used]
+    if used == 0:
+        return keys.clone(), weights.clone()
+    last = torch.ones(used, dtype=torch.bool, device=keys.device)
+    torch.ne(keys[1:], keys[:-1], out=last[:-1])
+    ends = torch.nonzero(last).flatten()
+    del last
+    running = torch.cumsum(weights, 0)
+    del weights
+    sums = running[ends]
+    del running
+    sums[1:] -= sums[:-1].clone()
+    return keys[ends], sums
 
 
 def merge(a: Optional[tuple], b: tuple) -> tuple:
@@ -72,19 +82,23 @@ class Accumulator:
     def __init__(self):
         self.runs = []
 
+    def _merge_last_two(self):
+        import torch
+
+        b, a = self.runs.pop(), self.runs.pop()
+        keys, counts = torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])
+        del a, b  # the inputs are dead before the sort allocates its buffers
+        self.runs.append(reduce_slots(keys, counts))
+
     def add(self, run: tuple):
         self.runs.append(run)
         while len(self.runs) > 1 and self.runs[-2][0].numel() <= 2 * self.runs[-1][0].numel():
-            b = self.runs.pop()
-            a = self.runs.pop()
-            self.runs.append(merge(a, b))
+            self._merge_last_two()
 
     def result(self) -> tuple:
         while len(self.runs) > 1:
-            b = self.runs.pop()
-            a = self.runs.pop()
-            self.runs.append(merge(a, b))
-        return self.runs[0] if self.runs else None
+            self._merge_last_two()
+        return self.runs.pop() if self.runs else None
 
 
 def entries(keys, counts, seed: int, alpha: float):
@@ -95,11 +109,18 @@ def entries(keys, counts, seed: int, alpha: float):
     salt = _signed(mix64_int(seed ^ _TAG_GLOVE))
     h = mix64_tensor(keys ^ salt) ^ _signed(1 << 63)  # flip the sign bit: signed sort = u64 order
     order = torch.argsort(h, stable=True)
+    del h
     keys, counts = keys[order], counts[order]
+    del order
+    rows = _lsr(keys, 32).to(torch.int32).contiguous()  # values >= 2^31 wrap to the same 32 bits
+    cols = (keys & 0xFFFFFFFF).to(torch.int32).contiguous()
+    del keys
     top = counts.max().to(torch.float64) if counts.numel() else torch.tensor(1.0)
-    x = (counts.to(torch.float64) / top).to(torch.float32)
-    logx = torch.log(x.to(torch.float64)).to(torch.float32)
-    fx = torch.pow(x.to(torch.float64), float(alpha)).to(torch.float32)
-    rows = _lsr(keys, 32).to(torch.int32)  # values >= 2^31 wrap to the same 32 bits
-    cols = (keys & 0xFFFFFFFF).to(torch.int32)
-    return rows.contiguous(), cols.contiguous(), logx.contiguous(), fx.contiguous()
+    logx = torch.empty(counts.numel(), dtype=torch.float32, device=counts.device)
+    fx = torch.empty_like(logx)
+    step = 1 << 26  # float64 temporaries of a slice at a time
+    for lo in range(0, counts.numel(), step):
+        x = (counts[lo:lo + step].to(torch.float64) / top).to(torch.float32).to(torch.float64)
+        logx[lo:lo + step] = torch.log(x).to(torch.float32)
+        fx[lo:lo + step] = torch.pow(x, float(alpha)).to(torch.float32)
+    return rows, cols, logx, fx

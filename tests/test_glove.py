@@ -153,6 +153,12 @@ def test_tensor_plumbing_equals_the_oracle(karate_oracle):
     total = acc.result()
     assert torch.equal(total[0], got_keys) and torch.equal(total[1], got_counts)
     assert cooccurrence.Accumulator().result() is None
+    none = cooccurrence.reduce_slots(torch.full((6,), cooccurrence.UNUSED, dtype=torch.int64),
+                                     torch.zeros(6, dtype=torch.int64))
+    assert none[0].numel() == 0 and none[1].numel() == 0
+    assert cooccurrence.reduce_slots(tk[:0], tw[:0])[0].numel() == 0
+    one = cooccurrence.reduce_slots(torch.tensor([5, 5, 5]), torch.tensor([1, 2, 3]))
+    assert one[0].tolist() == [5] and one[1].tolist() == [6]
     for seed in (0, 42, 2 ** 40 + 3):
         rows, cols, logx, fx = cooccurrence.entries(got_keys, got_counts, seed, 0.75)
         orows, ocols, ologx, ofx = O.glove_entries(want_keys, want_counts, seed, 0.75)
