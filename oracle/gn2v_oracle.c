@@ -610,10 +610,13 @@ uint64_t o_fit(const o_graph *g, const o_walk_params *wp, const o_train_params *
         o_walks(g, wp, sources, n_sources, seed, e, 0, n_walks, walks);
         o_train_walks(g, tp, walks, n_walks, L, seed, e, 0, lr, central, contextual, NULL,
                       threads);
-        for (uint64_t b = 0; b < n_walks; ++b) {
+        uint64_t ekey = o_epoch_key(seed, e);
+        for (uint64_t b = 0; b < n_walks; ++b) { /* pairs of the centres that were trained */
             uint32_t Le = effective_len(walks + b * L, L);
+            uint64_t wkey = o_draw(ekey, b);
             for (uint32_t i = 0; i < Le; ++i)
-                pairs += context_count(i, Le, tp->window, min_dist_of(tp));
+                if (keep_centre(g, tp, wkey, i, walks[b * L + i]))
+                    pairs += context_count(i, Le, tp->window, min_dist_of(tp));
         }
         lr *= tp->lr_decay;
     }

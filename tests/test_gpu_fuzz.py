@@ -1,0 +1,103 @@
+"""Seeded differential fuzzing of the whole deterministic path (walks -> fit) against the oracle
+over random graphs (directed / undirected, weighted, typed, trap nodes) and random parameters,
+through the public model classes.  Walks must be bit-exact, fits equal to float tolerance."""
+import numpy as np
+import pytest
+
+import embiggen_amd as E
+from embiggen_amd import _lib, models, ops
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def random_graph(rng):
+    n = int(rng.randint(5, 160))
+    e = int(rng.randint(n, 6 * n))
+    src, dst = rng.randint(0, n, e), rng.randint(0, n, e)
+    directed = bool(rng.rand() < 0.3)
+    weights = rng.uniform(0.05, 4.0, e) if rng.rand() < 0.4 else None
+    node_types = rng.randint(0, 3, n).tolist() if rng.rand() < 0.4 else None
+    edge_types = rng.randint(0, 3, e).tolist() if rng.rand() < 0.4 else None
+    return E.CSRGraph.from_edge_list(src, dst, weights, number_of_nodes=n, directed=directed,
+                                     node_types=node_types, edge_types=edge_types)
+
+
+def oracle_graph(g):
+    return O.OracleGraph(g.row_ptr, g.col_idx, g.cumw, g.node_type_ids, g.edge_type_ids)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_fit_matches_oracle(case):
+    rng = np.random.RandomState(1000 + case)
+    g = random_graph(rng)
+    og = oracle_graph(g)
+    L = int(rng.randint(2, 40))
+    w = int(rng.randint(1, 7))
+    md = int(rng.randint(1, w + 1))
+    k = int(rng.randint(0, 7))
+    d = int(rng.choice([1, 3, 4, 7, 8, 16, 33, 64, 100, 130]))
+    iters = int(rng.randint(1, 4))
+    epochs = int(rng.randint(1, 4))
+    rw, ew = float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0])), float(rng.choice([0.25, 0.5, 1.0, 2.0, 4.0]))
+    cn, ce = float(rng.choice([0.2, 1.0, 3.0])), float(rng.choice([0.2, 1.0, 3.0]))
+    model_id = int(rng.randint(0, 2))
+    kw = dict(embedding_size=d, random_state=int(rng.randint(0, 2 ** 31)), epochs=epochs,
+              walk_length=L, iterations=iters, window_size=w, min_distance=md,
+              number_of_negative_samples=k, return_weight=rw, explore_weight=ew,
+              change_node_type_weight=cn, change_edge_type_weight=ce,
+              learning_rate=float(rng.choice([0.01, 0.05])), learning_rate_decay=0.9,
+              clipping_value=float(rng.choice([2.0, 6.0])),
+              use_scale_free_distribution=bool(rng.rand() < 0.7),
+              stochastic_downsample_by_degree=bool(rng.rand() < 0.3),
+              normalize_learning_rate_by_degree=bool(rng.rand() < 0.3),
+              deterministic=True, verbose=False)
+    cls = models.SkipGram if model_id == 0 else models.CBOW
+    m = cls(**kw)
+    seed = kw["random_state"]
+    n_src = g.get_number_of_unique_source_nodes()
+    owp = O.WalkParams(L, iters, rw, ew, 100, 0, cn, ce)
+    walks = ops.walks(g, m.walk_params(), seed, 0, 0, n_src * iters).cpu().numpy().view(np.uint32)
+    assert np.array_equal(walks, O.walks(og, owp, seed, 0, 0, n_src * iters, sources=g.sources))
+    central, contextual = m.fit_transform(g)
+    flags = ((1 if kw["use_scale_free_distribution"] else 0)
+             | (2 if kw["stochastic_downsample_by_degree"] else 0)
+             | (4 if kw["normalize_learning_rate_by_degree"] else 0))
+    ld = m.padded_size
+    otp = O.TrainParams(model_id, d, ld, epochs, k, w, kw["learning_rate"], 0.9,
+                        kw["clipping_value"], flags, d ** -0.5, md)
+    ref_c, ref_x, pairs = O.fit(og, owp, otp, seed, sources=g.sources)
+    assert m.last_stats["pairs"] == pairs
+    assert np.abs(central - ref_c[:, :d]).max() < 1e-4 and np.abs(contextual - ref_x[:, :d]).max() < 1e-4
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_glove_fit_matches_oracle(case):
+    rng = np.random.RandomState(2000 + case)
+    g = random_graph(rng)
+    og = oracle_graph(g)
+    L, w = int(rng.randint(3, 60)), int(rng.randint(1, 6))
+    md = int(rng.randint(1, w + 1))
+    d = int(rng.choice([2, 8, 20, 64, 100]))
+    iters, epochs = int(rng.randint(1, 3)), int(rng.randint(1, 5))
+    seed = int(rng.randint(0, 2 ** 31))
+    alpha = float(rng.choice([0.5, 0.75, 1.0]))
+    m = models.GloVe(embedding_size=d, random_state=seed, epochs=epochs, walk_length=L,
+                     iterations=iters, window_size=w, min_distance=md, return_weight=0.5,
+                     explore_weight=2.0, learning_rate=0.05, learning_rate_decay=0.9, alpha=alpha,
+                     deterministic=True, verbose=False)
+    central, contextual = m.fit_transform(g)
+    n_src = g.get_number_of_unique_source_nodes()
+    walks = O.walks(og, O.WalkParams(L, iters, 0.5, 2.0, 100, 0), seed, 0, 0, n_src * iters,
+                    sources=g.sources)
+    entries = O.glove_entries(*O.cooc_reduce(*O.cooc_slots(walks, w, md)), seed, alpha)
+    n, ld = g.get_number_of_nodes(), m.padded_size
+    state = [O.init_table(n, d, ld, seed, 0, d ** -0.5), O.init_table(n, d, ld, seed, 1, d ** -0.5),
+             np.zeros(n, np.float32), np.zeros(n, np.float32)]
+    lr = np.float32(0.05)
+    for _ in range(epochs):
+        O.glove_step(*entries, *state, d, float(lr))
+        lr = np.float32(lr * np.float32(0.9))
+    assert m.last_stats["entries"] == len(entries[0])
+    assert np.abs(central - state[0][:, :d]).max() < 1e-4
+    assert np.abs(contextual - state[1][:, :d]).max() < 1e-4
