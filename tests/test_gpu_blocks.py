@@ -50,14 +50,15 @@ def test_pair_mode_step_matches_oracle(karate, karate_oracle, flags):
     assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
 
 
-def _run(comm, device, use_oracle):
-    g = E.karate_club()
+def _run(comm, device, use_oracle, graph=None):
+    g = E.karate_club() if graph is None else graph
     og = O.OracleGraph(g.row_ptr, g.col_idx)
+    n_nodes = g.get_number_of_nodes()
     otp = O.TrainParams(0, D, D, 1, K, 1, 0.02, 0.9, 6.0, 1, D ** -0.5)
     tp = ops.train_params(0, D, K, 1, flags=1 | _lib.TRAIN_DETERMINISTIC)
     if use_oracle:
         tr = BlockPartitionedTrainer(g, otp, D, D, 42, D ** -0.5, comm, "cpu",
-                                     init_fn=host_init_fn(34, D, D, 42, D ** -0.5))
+                                     init_fn=host_init_fn(n_nodes, D, D, 42, D ** -0.5))
         tr.compute = oracle_block_compute(og, otp, tr)
     else:
         tr = BlockPartitionedTrainer(g, tp, D, D, 42, D ** -0.5, comm, device)
@@ -79,6 +80,20 @@ def test_block_trainer_kernel_equals_oracle(world):
     for r in range(world):
         assert np.abs(gpu[r][0] - ref[r][0]).max() < 1e-5
         assert np.abs(gpu[r][1] - ref[r][1]).max() < 1e-5
+
+
+@pytest.mark.parametrize("world,nodes", [(4, 203), (5, 97), (8, 64)])
+def test_block_trainer_on_scale_free_graphs_with_ragged_partitions(world, nodes):
+    """Partitions of unequal size (nodes % world != 0), hubs in one partition, more ranks."""
+    s, d = O.ba_edges(nodes, 3, 9)
+    g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=nodes)
+    gpu = run_ranks(world, lambda comm: _run(comm, "cuda:0", use_oracle=False, graph=g))
+    ref = run_ranks(world, lambda comm: _run(comm, "cpu", use_oracle=True, graph=g))
+    for r in range(world):
+        assert gpu[r][0].shape == (nodes, D)
+        assert np.abs(gpu[r][0] - ref[r][0]).max() < 1e-5
+        assert np.abs(gpu[r][1] - ref[r][1]).max() < 1e-5
+    assert all(np.array_equal(gpu[0][0], gpu[r][0]) for r in range(world))  # gather_full agrees
 
 
 def test_eight_simulated_gpus_reach_single_gpu_quality():
