@@ -109,9 +109,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_gloo_ranks_equal_the_in_process_simulation(tmp_path):
-    """No row is ever shared between ranks, so the distributed run is exactly the simulation."""
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_equal_the_in_process_simulation(tmp_path, world):
+    """No row is ever shared between ranks, so the distributed run is exactly the simulation
+    (world 3: ragged partitions of 12 / 11 / 11 rows go round the ring)."""
     mp.spawn(_gloo_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     sim = run_ranks(world, lambda comm: _train(comm))
     for r in range(world):
