@@ -7,7 +7,8 @@ import embiggen_amd as E
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 g = E.barabasi_albert(n, 7, 42)
 for cls, kw in ((E.Node2VecSkipGramEnsmallen, {}), (E.Node2VecCBOWEnsmallen, {}),
-                (E.WalkletsSkipGramEnsmallen, {"epochs": 3})):
+                (E.WalkletsSkipGramEnsmallen, {"epochs": 3}), (E.Node2VecGloVeEnsmallen, {}),
+                (E.DeepWalkGloVeEnsmallen, {"epochs": 20})):
     m = cls(**kw)
     t0 = time.time()
     res = m.fit_transform(g, return_dataframe=False)
