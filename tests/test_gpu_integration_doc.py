@@ -1,0 +1,45 @@
+"""The binding example in INTEGRATION.md is executed as written (against libgn2v.so and a stand-in
+for the ensmallen.Graph getters it calls), so the document cannot drift from the ABI."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import embiggen_amd as E
+from embiggen_amd import _lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class EnsmallenLikeGraph:
+    def __init__(self, g):
+        self.g = g
+
+    def get_number_of_nodes(self): return self.g.get_number_of_nodes()
+    def get_cumulative_node_degrees(self): return self.g.row_ptr[1:]
+    def get_directed_destination_node_ids(self): return self.g.col_idx
+    def is_directed(self): return self.g.is_directed()
+
+
+def test_the_documented_binding_runs_and_matches_the_package():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# embiggen/embedders/amd_embedders/gn2v_models.py.*?)```", text, re.S).group(1)
+    block = block.replace('C.CDLL("libgn2v.so")', f'C.CDLL({_lib.build()!r})')
+    _lib.lib()  # torch's HIP runtime first, as the package does
+    scope = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), scope)
+    graph = E.karate_club()
+    kw = dict(epochs=2, walk_length=16, iterations=2, window_size=3, number_of_negative_samples=4)
+    central, contextual = scope["SkipGram"](8, 42, **kw).fit_transform(EnsmallenLikeGraph(graph))
+    assert central.shape == (34, 8) and central.dtype == np.float32 and np.isfinite(central).all()
+    # same engine, same seed, same (atomic) schedule family: statistically the package's result
+    ours = E.models.SkipGram(embedding_size=8, random_state=42, verbose=False, **kw).fit_transform(graph)
+    assert np.abs(central - ours[0]).max() < 0.05 and np.abs(contextual - ours[1]).max() < 0.05
+    # struct layouts of the document == the package's
+    import ctypes as C
+    assert C.sizeof(scope["WalkParams"]) == C.sizeof(_lib.WalkParams)
+    assert C.sizeof(scope["TrainParams"]) == C.sizeof(_lib.TrainParams)
+    assert [f[0] for f in scope["WalkParams"]._fields_] == [f[0] for f in _lib.WalkParams._fields_]
+    assert [f[0] for f in scope["TrainParams"]._fields_] == [f[0] for f in _lib.TrainParams._fields_]
