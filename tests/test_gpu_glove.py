@@ -169,6 +169,32 @@ def test_embedders_learn_communities_and_keep_the_contract():
     assert out.get_all_node_embedding()[0].shape == (34, 8)
 
 
+def test_full_size_cooccurrence_properties():
+    """BA 1 M nodes, walks of 128, window 5 (1.3 x 10^8 slots): the matrix is symmetric, its total
+    is the closed form for full-length walks, keys are unique and ascending, and two halves merged
+    equal the whole."""
+    g = E.barabasi_albert(1_000_000, 10, 42)
+    L, w, nw = 128, 5, 100_000
+    walks = ops.walks(g, ops.walk_params(L, 1, 0.25, 4.0), 42, 0, 0, nw)
+    assert bool((walks != -1).all())  # no traps in a BA graph: every walk is full length
+    keys, counts = cooccurrence.reduce_slots(*ops.cooc_slots(walks, w))
+    assert bool((keys[1:] > keys[:-1]).all())
+    per_walk = sum(2 * (L - dist) * (((1 << 20) + dist // 2) // dist) for dist in range(1, w + 1))
+    assert int(counts.sum()) == nw * per_walk
+    swapped = ((keys & 0xFFFFFFFF) << 32) | ((keys >> 32) & 0xFFFFFFFF)
+    order = torch.argsort(swapped)
+    assert torch.equal(swapped[order], keys) and torch.equal(counts[order], counts)
+    half = nw // 2
+    acc = cooccurrence.Accumulator()
+    acc.add(cooccurrence.reduce_slots(*ops.cooc_slots(walks[:half], w)))
+    acc.add(cooccurrence.reduce_slots(*ops.cooc_slots(walks[half:], w)))
+    merged = acc.result()
+    assert torch.equal(merged[0], keys) and torch.equal(merged[1], counts)
+    rows, cols, logx, fx = cooccurrence.entries(keys, counts, 42, 0.75)
+    assert float(logx.max()) == 0.0 and bool((fx > 0).all()) and bool((fx <= 1).all())
+    assert rows.numel() == keys.numel()
+
+
 def test_parallel_schedules_reach_the_sequential_loss():
     """Racy schedules vs the deterministic one on the same entries: same loss level (BA 5 k nodes:
     collisions are real but not dominant, as in the SGNS equivalence test)."""
