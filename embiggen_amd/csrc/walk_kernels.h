@@ -350,7 +350,8 @@ __global__ void window_kernel(const uint32_t *__restrict__ walks, uint64_t n_wal
 // With keys != nullptr every slot also gets the sort key of the block-partitioned trainer:
 // ((centre % world) * world + context % world) << 31 | 31-bit hashed salt, or INT64_MAX for an
 // unused slot -- one radix sort then groups the pairs by block, shuffles them inside a block and
-// pushes the unused slots to the end.
+// pushes the unused slots to the end.  With salt == ~0 the key is block << 32 | centre: the sort
+// then also groups the pairs of a block by centre node (for packing them into centre records).
 __global__ void pairs_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L,
                              uint32_t w, uint32_t min_dist, uint32_t *__restrict__ pairs,
                              unsigned long long *__restrict__ keys, uint32_t world,
@@ -377,9 +378,12 @@ __global__ void pairs_kernel(const uint32_t *__restrict__ walks, uint64_t n_walk
         pairs[2 * t + 1] = x;
         if (keys) {
             unsigned long long key = 0x7FFFFFFFFFFFFFFFULL;
-            if (c != kSentinel)
-                key = ((unsigned long long)((c % world) * world + x % world) << 31) |
-                      (mix64(t + salt) >> 33);
+            if (c != kSentinel) {
+                const unsigned long long block = (c % world) * world + x % world;
+                // salt == ~0: group by centre inside the block (centre-record packing) instead of
+                // shuffling the pairs
+                key = salt == ~0ULL ? (block << 32) | c : (block << 31) | (mix64(t + salt) >> 33);
+            }
             keys[t] = key;
         }
     }

@@ -238,12 +238,10 @@ class _WalkBasedModel:
                     n = max(0, min(round_walks, walks_per_epoch - first))
                     if n:
                         walks = ops.walks(csr, wp, self.random_state, epoch, first, n, device=device)
-                        pairs = None
-                    else:
-                        walks = None
-                        pairs = torch.empty((0, 2), dtype=torch.int32, device=dev)
+                    else:  # nothing left for this rank: it still takes part in the exchange
+                        walks = torch.empty((0, self.walk_length), dtype=torch.int32, device=dev)
                     trainer.train_round(walks, self.window_size, self.min_distance,
-                                        self.random_state, epoch, float(lr), pairs=pairs)
+                                        self.random_state, epoch, float(lr))
                 lr = np.float32(lr * np.float32(self.learning_rate_decay))
             central, contextual = trainer.gather_full()
             torch.cuda.synchronize(dev)

@@ -151,7 +151,9 @@ int gn2v_walk_pairs(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_len
                     uint32_t window, uint32_t min_dist, uint32_t *d_pairs, void *stream);
 /* Same, plus d_keys u64[n_walks][walk_length][2*window]: the block-partitioned trainer's sort key
  * ((centre % world) * world + context % world) << 31 | hashed 31-bit salt, INT64_MAX for unused
- * slots (so that one sort groups by block, shuffles inside a block and drops the unused slots). */
+ * slots (so that one sort groups by block, shuffles inside a block and drops the unused slots).
+ * salt = UINT64_MAX selects the grouping key block << 32 | centre instead: the sort then also
+ * brings the pairs of one centre node together (packed into centre records by the trainer). */
 int gn2v_walk_pair_blocks(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
                           uint32_t window, uint32_t min_dist, uint32_t world, uint64_t salt,
                           uint32_t *d_pairs, uint64_t *d_keys, void *stream);
@@ -190,8 +192,10 @@ typedef struct {
     uint32_t neg_id_mul;         /* global id of negative row r = r * mul + add (0, 0 = identity), */
     uint32_t neg_id_add;         /*   used to skip negatives equal to the centre / context       */
     const uint32_t *d_neg_override;
-    uint32_t pair_mode;          /* 1: d_walks holds (centre, context) records (walk_length 2,
-                                    window 1) and only position 0 acts as a centre (SkipGram)    */
+    uint32_t pair_mode;          /* 1: d_walks holds centre records [centre, context_1 .. context_C]
+                                    (walk_length 1 + C, window C, unused tail = GN2V_SENTINEL;
+                                    C = 1: plain pairs) and only position 0 acts as a centre
+                                    (SkipGram)                                                   */
 } gn2v_step_io;
 
 int gn2v_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_step_io *io,

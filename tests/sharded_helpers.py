@@ -78,8 +78,10 @@ def oracle_block_compute(oracle_graph, otp, trainer):
     def compute(pairs, rows, part, seed, epoch, first_pair, lr):
         host = [np.ascontiguousarray(t.detach().cpu().numpy())
                 for t in (trainer.central, trainer.context)]
+        tp = type(otp).from_buffer_copy(otp)
+        tp.window = pairs.shape[1] - 1  # (centre, context) pairs or centre records
         O.train_walks_ex(
-            oracle_graph, otp, pairs.cpu().numpy().view(np.uint32), seed, epoch, first_pair, lr,
+            oracle_graph, tp, pairs.cpu().numpy().view(np.uint32), seed, epoch, first_pair, lr,
             host[0], host[1], walk_rows=rows.cpu().numpy().view(np.uint32),
             neg_pool=trainer.pools[part].cpu().numpy().view(np.uint32),
             neg_id_mul=trainer.comm.world, neg_id_add=part, pair_mode=True)
@@ -104,3 +106,20 @@ def link_auc_device(g, c, x, gen, n_eval=100000):
     ranks = torch.empty_like(s)
     ranks[torch.argsort(s)] = torch.arange(1, s.numel() + 1, device="cuda", dtype=s.dtype)
     return float((ranks[:n_eval].sum() - n_eval * (n_eval + 1) / 2) / (n_eval * n_eval))
+
+
+def host_walk_pair_blocks(walks_tensor, window, min_dist, world, salt):
+    """CPU stand-in for ops.walk_pair_blocks in its grouping mode (salt = 2^64 - 1): the same
+    slots and keys (block << 32 | centre, INT64_MAX for unused slots), built from the oracle's
+    co-occurrence slots (tests only)."""
+    assert salt == 2 ** 64 - 1
+    walks = walks_tensor.cpu().numpy().view(np.uint32)
+    keys, _ = O.cooc_slots(walks, window, min_dist)
+    used = keys != O.COOC_UNUSED
+    c, x = (keys >> np.uint64(32)).astype(np.int64), (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    slots = np.full((len(keys), 2), -1, dtype=np.int32)
+    slots[used, 0] = c[used].astype(np.uint32).view(np.int32)
+    slots[used, 1] = x[used].astype(np.uint32).view(np.int32)
+    out = np.full(len(keys), 0x7FFFFFFFFFFFFFFF, dtype=np.int64)
+    out[used] = (((c[used] % world) * world + x[used] % world) << 32) | c[used]
+    return torch.from_numpy(slots), torch.from_numpy(out)

@@ -9,7 +9,8 @@ import embiggen_amd as E
 from embiggen_amd import _lib, ops
 from embiggen_amd.distributed import BlockPartitionedTrainer
 from oracle import oracle as O
-from sharded_helpers import host_init_fn, link_auc_device as _auc, oracle_block_compute, run_ranks
+from sharded_helpers import (host_init_fn, host_walk_pair_blocks, link_auc_device as _auc,
+                             oracle_block_compute, run_ranks)
 
 pytestmark = pytest.mark.gpu
 D, K, W, L = 16, 4, 3, 14
@@ -94,6 +95,48 @@ def test_block_trainer_on_scale_free_graphs_with_ragged_partitions(world, nodes)
         assert np.abs(gpu[r][0] - ref[r][0]).max() < 1e-5
         assert np.abs(gpu[r][1] - ref[r][1]).max() < 1e-5
     assert all(np.array_equal(gpu[0][0], gpu[r][0]) for r in range(world))  # gather_full agrees
+
+
+def _run_fused(comm, device, use_oracle, graph, contexts):
+    """The production route: walks in, pairs grouped by (block, centre) and packed into centre
+    records, records routed and trained."""
+    og = O.OracleGraph(graph.row_ptr, graph.col_idx)
+    n_nodes = graph.get_number_of_nodes()
+    otp = O.TrainParams(0, D, D, 1, K, 1, 0.02, 0.9, 6.0, 1, D ** -0.5)
+    tp = ops.train_params(0, D, K, 1, flags=1 | _lib.TRAIN_DETERMINISTIC)
+    if use_oracle:
+        tr = BlockPartitionedTrainer(graph, otp, D, D, 42, D ** -0.5, comm, "cpu",
+                                     init_fn=host_init_fn(n_nodes, D, D, 42, D ** -0.5),
+                                     record_contexts=contexts)
+        tr.compute = oracle_block_compute(og, otp, tr)
+    else:
+        tr = BlockPartitionedTrainer(graph, tp, D, D, 42, D ** -0.5, comm, device,
+                                     record_contexts=contexts)
+    wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
+    infos = []
+    for r in range(2):
+        first = (r * comm.world + comm.rank) * 11
+        walks = torch.from_numpy(O.walks(og, wp, 42, 0, first, 11).view(np.int32)).to(device)
+        tr.train_round(walks, W, 1, 42, 0, 0.02)
+        infos.append(tr.last_round)
+    return [t.cpu().numpy() for t in tr.gather_full()], infos
+
+
+@pytest.mark.parametrize("world,contexts", [(1, 10), (2, 10), (3, 4), (4, 1)])
+def test_fused_centre_record_route_equals_oracle(world, contexts, monkeypatch):
+    s, d = O.ba_edges(150, 3, 4)
+    g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=150)
+    gpu = run_ranks(world, lambda comm: _run_fused(comm, "cuda:0", False, g, contexts))
+    monkeypatch.setattr(ops, "walk_pair_blocks", host_walk_pair_blocks)
+    ref = run_ranks(world, lambda comm: _run_fused(comm, "cpu", True, g, contexts))
+    per_walk = 2 * W * L - W * (W + 1)
+    for r in range(world):
+        assert np.abs(gpu[r][0][0] - ref[r][0][0]).max() < 1e-5
+        assert np.abs(gpu[r][0][1] - ref[r][0][1]).max() < 1e-5
+        assert gpu[r][1] == ref[r][1]
+    for rnd in range(2):  # every pair of the round is trained exactly once, somewhere
+        assert sum(gpu[r][1][rnd]["pairs_trained"] for r in range(world)) == world * 11 * per_walk
+        assert all(gpu[r][1][rnd]["pairs_generated"] == 11 * per_walk for r in range(world))
 
 
 def test_eight_simulated_gpus_reach_single_gpu_quality():
