@@ -250,8 +250,11 @@ class BlockPartitionedTrainer:
         starts = [0]
         for s in sizes:
             starts.append(starts[-1] + s)
-        rows = torch.div(blocks.to(torch.int64) & 0xFFFFFFFF, world,
-                         rounding_mode="floor").to(torch.int32).contiguous()
+        if self.n_nodes < 2 ** 31:  # ids are non-negative as int32 (sentinels stay negative)
+            rows = torch.div(blocks, world, rounding_mode="trunc")
+        else:
+            rows = torch.div(blocks.to(torch.int64) & 0xFFFFFFFF, world,
+                             rounding_mode="floor").to(torch.int32).contiguous()
         # distinct RNG keys for every pair ever trained on any rank
         base = (self.pairs_seen * world + comm.rank) << 32
         for _ in range(world):
