@@ -101,26 +101,67 @@ class Accumulator:
         return self.runs.pop() if self.runs else None
 
 
+RECORD = 16
+_GOLDEN = 0x9E3779B97F4A7C15
+_SIGN = -(1 << 63)
+
+
 def entries(keys, counts, seed: int, alpha: float):
-    """Training entries (rows i32, cols i32, log X f32, f(X) f32) in the fixed shuffled order:
-    ascending mix64(key ^ mix64(seed ^ tag)) as u64; X = count / max count."""
+    """Training slots (rows i32, cols i32, log X f32, f(X) f32) laid out as records of RECORD
+    consecutive slots that share their central row (the engine trains a record per wavefront with
+    that row in registers): every row's entries in ascending mix64(key ^ salt) are cut into records,
+    the records are shuffled (ascending draw(mix64(row ^ salt), record index in the row)); unused
+    slots of a row's last record hold col = -1.  X = count / max count.  Same order as the oracle
+    (o_glove_entries)."""
     import torch
 
+    dev = keys.device
+    n = keys.numel()
+    if n == 0:
+        empty_i = torch.empty(0, dtype=torch.int32, device=dev)
+        empty_f = torch.empty(0, dtype=torch.float32, device=dev)
+        return empty_i, empty_i.clone(), empty_f, empty_f.clone()
     salt = _signed(mix64_int(seed ^ _TAG_GLOVE))
-    h = mix64_tensor(keys ^ salt) ^ _signed(1 << 63)  # flip the sign bit: signed sort = u64 order
-    order = torch.argsort(h, stable=True)
-    del h
+    # order by (row, hash of key): stable sort by the hash, then stable sort by the row
+    order = torch.argsort(mix64_tensor(keys ^ salt) ^ _SIGN, stable=True)
+    order = order[torch.argsort(_lsr(keys[order], 32), stable=True)]
     keys, counts = keys[order], counts[order]
     del order
-    rows = _lsr(keys, 32).to(torch.int32).contiguous()  # values >= 2^31 wrap to the same 32 bits
-    cols = (keys & 0xFFFFFFFF).to(torch.int32).contiguous()
-    del keys
-    top = counts.max().to(torch.float64) if counts.numel() else torch.tensor(1.0)
-    logx = torch.empty(counts.numel(), dtype=torch.float32, device=counts.device)
-    fx = torch.empty_like(logx)
+    row = _lsr(keys, 32)
+    start = torch.ones(n, dtype=torch.bool, device=dev)
+    torch.ne(row[1:], row[:-1], out=start[1:])
+    run_pos = torch.nonzero(start).flatten()
+    run_id = torch.cumsum(start, 0) - 1
+    del start
+    rank = torch.arange(n, dtype=torch.int64, device=dev) - run_pos[run_id]
+    run_len = torch.diff(run_pos, append=torch.tensor([n], dtype=torch.int64, device=dev))
+    recs = torch.div(run_len + (RECORD - 1), RECORD, rounding_mode="floor")
+    first_rec = torch.cumsum(recs, 0) - recs
+    rec_id = first_rec[run_id] + torch.div(rank, RECORD, rounding_mode="floor")
+    del run_id, run_len
+    n_rec = int(recs.sum())
+    rec_run = torch.repeat_interleave(torch.arange(recs.numel(), device=dev), recs)
+    rec_row = row[run_pos][rec_run]
+    rec_q = torch.arange(n_rec, dtype=torch.int64, device=dev) - first_rec[rec_run]
+    del rec_run, first_rec, recs, run_pos
+    h = mix64_tensor(mix64_tensor(rec_row ^ salt) + (rec_q + 1) * _signed(_GOLDEN)) ^ _SIGN
+    rec_order = torch.argsort(h, stable=True)  # ties keep the (row, index) order
+    del h, rec_q
+    new_pos = torch.empty(n_rec, dtype=torch.int64, device=dev)
+    new_pos[rec_order] = torch.arange(n_rec, dtype=torch.int64, device=dev)
+    slot = new_pos[rec_id] * RECORD + rank % RECORD
+    del rec_id, rank, new_pos
+    rows = rec_row[rec_order].to(torch.int32).repeat_interleave(RECORD).contiguous()
+    del rec_row, rec_order
+    cols = torch.full((n_rec * RECORD,), -1, dtype=torch.int32, device=dev)
+    cols[slot] = (keys & 0xFFFFFFFF).to(torch.int32)
+    del keys, row
+    top = counts.max().to(torch.float64)
+    logx = torch.zeros(n_rec * RECORD, dtype=torch.float32, device=dev)
+    fx = torch.zeros_like(logx)
     step = 1 << 26  # float64 temporaries of a slice at a time
-    for lo in range(0, counts.numel(), step):
+    for lo in range(0, n, step):
         x = (counts[lo:lo + step].to(torch.float64) / top).to(torch.float32).to(torch.float64)
-        logx[lo:lo + step] = torch.log(x).to(torch.float32)
-        fx[lo:lo + step] = torch.pow(x, float(alpha)).to(torch.float32)
+        logx[slot[lo:lo + step]] = torch.log(x).to(torch.float32)
+        fx[slot[lo:lo + step]] = torch.pow(x, float(alpha)).to(torch.float32)
     return rows, cols, logx, fx

@@ -75,7 +75,8 @@ __device__ __forceinline__ void group_to_contig(Row<CH> &out, const Row<CH> &in,
 constexpr int kGloveBlock = 256;
 
 // DET: one wavefront, one entry at a time in entry order (all groups compute it, group 0 writes):
-// equals the oracle's sequential loop.  Otherwise Hogwild over entries, one per 16-lane group.
+// equals the oracle's sequential loop.  Otherwise Hogwild over entries, one per 16-lane group,
+// with the record fast path when the 16 slots of a chunk share their central row.
 template <int CH, int WM, bool DET>
 __global__ __launch_bounds__(kGloveBlock) void glove_kernel(GloveArgs a) {
     extern __shared__ float s_glove[];  // atomic mode: [waves][4 groups][ld]
@@ -96,13 +97,80 @@ __global__ __launch_bounds__(kGloveBlock) void glove_kernel(GloveArgs a) {
             llx = a.logx[el];
             lf = a.fx[el];
         }
+        const bool lvalid = el < a.n_entries && lj != kSentinel;  // col = sentinel: padding slot
+        const unsigned long long vmask = __ballot(lvalid);
+        if (vmask == 0) continue;
+        if constexpr (!DET) {
+            // Record fast path: the slots of this chunk share their central row (the order
+            // cooccurrence.entries / o_glove_entries produce).  The row is read once, kept in
+            // registers, refreshed after every round of four entries with the four groups' summed
+            // contributions, and written once: 1 KiB + 64 B instead of 2 KiB of HBM traffic per
+            // entry.
+            const uint32_t i0 = __shfl(li, __ffsll((long long)vmask) - 1, 16);
+            if (__ballot(lvalid && li != i0) == 0) {
+                float *ub = a.central + (uint64_t)i0 * a.ld;
+                Row<CH> u, acc;
+                load_row<CH>(u, ub, q, nchunks, true);
+                zero_row<CH>(acc);
+                float bi = a.bias_c[i0], accb = 0.f;
+                float *s_grp = s_glove + ((size_t)wave * 4 + grp) * a.ld;  // atomic mode only
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = r * 4 + grp;
+                    const uint32_t j = __shfl(lj, slot, 16);
+                    const float lx = __shfl(llx, slot, 16), f = __shfl(lf, slot, 16);
+                    const bool valid = base + slot < a.n_entries && j != kSentinel;
+                    float *vb = a.contextual + (uint64_t)(valid ? j : 0) * a.ld;
+                    Row<CH> v, c;
+                    load_row<CH>(v, vb, q, nchunks, valid);
+                    const float dot = dot_rows<CH>(u, v);
+                    const float bj = valid ? a.bias_x[j] : 0.f;
+                    const float g = f * (((dot + bi) + bj) - lx);
+                    const bool apply = valid && isfinite(g);
+                    const float s = apply ? -a.lr * g : 0.f;
+                    zero_row<CH>(c);
+                    axpy<CH>(c, s, v);  // this entry's contribution to the central row
+                    if constexpr (WM == kAtomic) {
+                        Row<CH> uc;
+                        group_to_contig<CH>(uc, u, s_grp, q, a.ld);
+                        if (apply) {
+                            scatter_add<CH, kAtomic>(vb, q, nchunks, s, uc, v);
+                            if (q == 0) unsafeAtomicAdd(a.bias_x + j, s);
+                        }
+                    } else if (apply) {
+                        scatter_add<CH, WM>(vb, q, nchunks, s, u, v);
+                        if (q == 0) a.bias_x[j] = bj + s;
+                    }
+                    reduce_groups<CH>(c);
+                    float ds = s;
+                    ds += __shfl_xor(ds, 16);
+                    ds += __shfl_xor(ds, 32);
+                    axpy<CH>(u, 1.0f, c);
+                    axpy<CH>(acc, 1.0f, c);
+                    bi += ds;
+                    accb += ds;
+                }
+                if constexpr (WM == kAtomic) {
+                    Row<CH> accc;
+                    group_to_contig<CH>(accc, acc, s_grp, q, a.ld);
+                    if (grp == 0) {
+                        scatter_add<CH, kAtomic>(ub, q, nchunks, 1.0f, accc, u);
+                        if (q == 0) unsafeAtomicAdd(a.bias_c + i0, accb);
+                    }
+                } else if (grp == 0) {
+                    scatter_add<CH, WM>(ub, q, nchunks, 0.0f, u, u);  // stores u
+                    if (q == 0) a.bias_c[i0] = bi;
+                }
+                continue;
+            }
+        }
         constexpr int kRounds = DET ? 16 : 4;
         for (int r = 0; r < kRounds; ++r) {
             const int slot = DET ? r : r * 4 + grp;
-            const bool valid = base + slot < a.n_entries;
             const uint32_t i = __shfl(li, slot, 16), j = __shfl(lj, slot, 16);
+            const bool valid = base + slot < a.n_entries && j != kSentinel;
             const float lx = __shfl(llx, slot, 16), f = __shfl(lf, slot, 16);
-            float *ub = a.central + (uint64_t)i * a.ld, *vb = a.contextual + (uint64_t)j * a.ld;
+            float *ub = a.central + (uint64_t)(valid ? i : 0) * a.ld;
+            float *vb = a.contextual + (uint64_t)(valid ? j : 0) * a.ld;
             Row<CH> u, v;
             load_row<CH>(u, ub, q, nchunks, valid);
             load_row<CH>(v, vb, q, nchunks, valid);

@@ -607,7 +607,11 @@ int gn2v_glove_step(gn2v_graph *g, const gn2v_glove_io *io, uint64_t n_entries, 
     const int waves_per_block = det ? 1 : gn2v::kGloveBlock / 64;
     const size_t lds = (!det && wm == gn2v::kAtomic) ? (size_t)waves_per_block * 4 * ld * 4 : 0;
     uint64_t blocks = det ? 1 : (n_entries + 16 * waves_per_block - 1) / (16 * waves_per_block);
-    const uint64_t cap = (uint64_t)g->n_cus * 8;
+    uint64_t cap = (uint64_t)g->n_cus * 8;
+    // records of one row are trained from the same stale copy of it by concurrent waves: at most
+    // one wave per table row on average (binds on tiny graphs only, as for the SkipGram records)
+    const uint64_t max_blocks = std::max<uint64_t>(1, g->view.n_nodes / waves_per_block);
+    if (!det && cap > max_blocks) cap = max_blocks;
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kGloveBlock);
     hipStream_t s = (hipStream_t)stream;

@@ -409,8 +409,8 @@ class GloVe(_WalkBasedModel):
             torch.cuda.synchronize(dev)
             self.last_seconds = time.perf_counter() - start
         stats = ops.stats_read(csr, self.device)
-        stats["entries"] = int(rows.numel())
-        stats["pairs"] = int(rows.numel()) * self.epochs  # entry updates
+        stats["entries"] = int((cols != -1).sum())  # record slots minus padding
+        stats["pairs"] = stats["entries"] * self.epochs  # entry updates
         self.last_stats = stats
         if self.verbose:
             print(f"[gn2v] GloVe: {stats['entries']} co-occurrence entries x {self.epochs} epochs in "

@@ -676,7 +676,8 @@ uint64_t o_walk_pairs(const uint32_t *walks, uint64_t n_walks, uint32_t L, uint3
  *            (the wrapper has no x_max: the weighting function saturates at the maximum);
  *   loss   = sum_ij f(X_ij) (w_i . w~_j + b_i + b~_j - log X_ij)^2 / 2,  f(x) = x^alpha;
  *   update = plain SGD (learning_rate, multiplied by learning_rate_decay per epoch) over the
- *            non-zero entries in a fixed shuffled order; biases are internal (two tables out).
+ *            non-zero entries in a fixed shuffled order (see o_glove_entries); biases are
+ *            internal (two tables out).
  * 1 / distance is accumulated in fixed point (2^20 / distance, rounded) so the sums are exact and
  * independent of the order in which co-occurrences are counted. */
 
@@ -742,33 +743,97 @@ uint64_t o_cooc_reduce(uint64_t *keys, uint64_t *weights, uint64_t n_slots) {
     return n;
 }
 
-static int cmp_kv_val_key(const void *a, const void *b) {
-    const kv64 *x = a, *y = b;
-    if (x->val != y->val) return x->val < y->val ? -1 : 1;
-    return x->key < y->key ? -1 : x->key > y->key;
+/* Training order of the non-zero entries.  Entries are grouped by their central row, every row's
+ * entries (in ascending mix64(key ^ salt)) are cut into records of O_GLOVE_RECORD, and the records
+ * are shuffled (ascending draw(mix64(row ^ salt), record index in the row)).  A record occupies
+ * O_GLOVE_RECORD consecutive slots of the output arrays; the unused slots of a row's last record
+ * hold col = O_SENTINEL (skipped by the step).  The engine trains a record per wavefront with the
+ * central row in registers; the arithmetic per entry does not depend on this layout. */
+#define O_GLOVE_RECORD 16u
+
+typedef struct {
+    uint64_t row, h, src;
+} glove_ent;
+
+static int cmp_ent(const void *a, const void *b) {
+    const glove_ent *x = a, *y = b;
+    if (x->row != y->row) return x->row < y->row ? -1 : 1;
+    if (x->h != y->h) return x->h < y->h ? -1 : 1;
+    return x->src < y->src ? -1 : x->src > y->src;
 }
 
-/* training entries of the reduced co-occurrence counts, in the fixed shuffled order (ascending
- * mix64(key ^ mix64(seed ^ TAG))): rows / cols, log X and f(X) with X = count / max count */
+/* number of records the entries need (keys ascending, i.e. grouped by row) */
+uint64_t o_glove_record_count(const uint64_t *keys, uint64_t n) {
+    uint64_t records = 0, run = 0;
+    for (uint64_t t = 0; t < n; ++t) {
+        ++run;
+        if (t + 1 == n || (keys[t + 1] >> 32) != (keys[t] >> 32)) {
+            records += (run + O_GLOVE_RECORD - 1) / O_GLOVE_RECORD;
+            run = 0;
+        }
+    }
+    return records;
+}
+
+/* rows / cols / log X / f(X) of every slot, X = count / max count; arrays of
+ * o_glove_record_count(keys, n) * O_GLOVE_RECORD slots */
 void o_glove_entries(const uint64_t *keys, const uint64_t *counts, uint64_t n, uint64_t seed,
                      float alpha, uint32_t *rows, uint32_t *cols, float *logx, float *fx) {
     uint64_t salt = o_mix64(seed ^ O_TAG_GLOVE), mx = 1;
-    kv64 *kv = malloc(sizeof(kv64) * (n ? n : 1));
+    glove_ent *ent = malloc(sizeof(glove_ent) * (n ? n : 1));
     for (uint64_t t = 0; t < n; ++t) {
-        kv[t].key = t;
-        kv[t].val = o_mix64(keys[t] ^ salt);
+        ent[t].row = keys[t] >> 32;
+        ent[t].h = o_mix64(keys[t] ^ salt);
+        ent[t].src = t;
         if (counts[t] > mx) mx = counts[t];
     }
-    qsort(kv, n, sizeof(kv64), cmp_kv_val_key); /* ties (practically none) by input position */
-    for (uint64_t t = 0; t < n; ++t) {
-        uint64_t s = kv[t].key;
-        float x = (float)((double)counts[s] / (double)mx);
-        rows[t] = (uint32_t)(keys[s] >> 32);
-        cols[t] = (uint32_t)(keys[s] & 0xFFFFFFFFu);
-        logx[t] = (float)log((double)x);
-        fx[t] = (float)pow((double)x, (double)alpha);
+    qsort(ent, n, sizeof(glove_ent), cmp_ent);
+    /* records: (shuffle hash, row, index in row, first entry, length) */
+    uint64_t n_rec = o_glove_record_count(keys, n);
+    glove_ent *rec = malloc(sizeof(glove_ent) * (n_rec ? n_rec : 1));
+    uint64_t *first = malloc(sizeof(uint64_t) * (n_rec ? n_rec : 1));
+    uint64_t r = 0;
+    for (uint64_t t = 0; t < n;) {
+        uint64_t e = t;
+        while (e < n && ent[e].row == ent[t].row) ++e;
+        uint64_t rkey = o_mix64(ent[t].row ^ salt);
+        for (uint64_t q = 0; t + q * O_GLOVE_RECORD < e; ++q) {
+            rec[r].h = o_draw(rkey, q);
+            rec[r].row = ent[t].row;
+            rec[r].src = r; /* = (row, q) order: the tie break */
+            first[r] = t + q * O_GLOVE_RECORD;
+            ++r;
+        }
+        t = e;
     }
-    free(kv);
+    /* cmp_ent orders by (row, h, src); the shuffle wants (h, row, q): swap the roles */
+    for (uint64_t i = 0; i < n_rec; ++i) {
+        uint64_t row = rec[i].row;
+        rec[i].row = rec[i].h;
+        rec[i].h = row;
+    }
+    qsort(rec, n_rec, sizeof(glove_ent), cmp_ent);
+    for (uint64_t i = 0; i < n_rec; ++i) {
+        uint64_t t0 = first[rec[i].src];
+        for (uint32_t q = 0; q < O_GLOVE_RECORD; ++q) {
+            uint64_t slot = i * O_GLOVE_RECORD + q, t = t0 + q;
+            rows[slot] = (uint32_t)rec[i].h;
+            if (t < n && ent[t].row == rec[i].h) {
+                uint64_t src = ent[t].src;
+                float x = (float)((double)counts[src] / (double)mx);
+                cols[slot] = (uint32_t)(keys[src] & 0xFFFFFFFFu);
+                logx[slot] = (float)log((double)x);
+                fx[slot] = (float)pow((double)x, (double)alpha);
+            } else {
+                cols[slot] = O_SENTINEL;
+                logx[slot] = 0.0f;
+                fx[slot] = 0.0f;
+            }
+        }
+    }
+    free(ent);
+    free(rec);
+    free(first);
 }
 
 /* sequential SGD over entries [0, n): for each entry the gradient scale g = f * (u.v + b_i + b~_j
@@ -777,6 +842,7 @@ void o_glove_step(const uint32_t *rows, const uint32_t *cols, const float *logx,
                   uint64_t n, float *central, float *contextual, float *bias_c, float *bias_x,
                   uint32_t d, uint32_t ld, float lr) {
     for (uint64_t e = 0; e < n; ++e) {
+        if (cols[e] == O_SENTINEL) continue; /* padding slot of a record */
         float *u = central + (uint64_t)rows[e] * ld, *v = contextual + (uint64_t)cols[e] * ld;
         float dot = 0.0f;
         for (uint32_t c = 0; c < d; ++c) dot += u[c] * v[c];
@@ -794,12 +860,47 @@ void o_glove_step(const uint32_t *rows, const uint32_t *cols, const float *logx,
     }
 }
 
+/* The engine's record schedule, restated for the tests of its parallel kernel: the slots come in
+ * records of O_GLOVE_RECORD with a common row; the four entries of a round (slots 4r .. 4r+3) all
+ * see the row and its bias as they were at the start of the round, then their summed
+ * contributions are applied (o_glove_step is the limit of one entry per round). */
+void o_glove_step_rounds(const uint32_t *rows, const uint32_t *cols, const float *logx,
+                         const float *fx, uint64_t n, float *central, float *contextual,
+                         float *bias_c, float *bias_x, uint32_t d, uint32_t ld, float lr) {
+    float *du = (float *)malloc(sizeof(float) * (d ? d : 1));
+    for (uint64_t base = 0; base < n; base += 4) {
+        uint32_t i = rows[base];
+        float *u = central + (uint64_t)i * ld;
+        float db = 0.0f;
+        memset(du, 0, sizeof(float) * d);
+        for (uint64_t e = base; e < base + 4 && e < n; ++e) {
+            if (cols[e] == O_SENTINEL) continue;
+            float *v = contextual + (uint64_t)cols[e] * ld;
+            float dot = 0.0f;
+            for (uint32_t c = 0; c < d; ++c) dot += u[c] * v[c];
+            float g = fx[e] * (((dot + bias_c[i]) + bias_x[cols[e]]) - logx[e]);
+            if (!isfinite(g)) continue;
+            float s = -lr * g;
+            for (uint32_t c = 0; c < d; ++c) {
+                du[c] += s * v[c];
+                v[c] += s * u[c];
+            }
+            bias_x[cols[e]] += s;
+            db += s;
+        }
+        for (uint32_t c = 0; c < d; ++c) u[c] += du[c];
+        bias_c[i] += db;
+    }
+    free(du);
+}
+
 /* GloVe loss of the entries (double accumulation; tests) */
 double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *logx, const float *fx,
                     uint64_t n, const float *central, const float *contextual,
                     const float *bias_c, const float *bias_x, uint32_t d, uint32_t ld) {
     double loss = 0.0;
     for (uint64_t e = 0; e < n; ++e) {
+        if (cols[e] == O_SENTINEL) continue;
         const float *u = central + (uint64_t)rows[e] * ld, *v = contextual + (uint64_t)cols[e] * ld;
         double dot = 0.0;
         for (uint32_t c = 0; c < d; ++c) dot += (double)u[c] * v[c];

@@ -276,13 +276,19 @@ def cooc_reduce(keys, weights):
     return keys[:n].copy(), weights[:n].copy()
 
 
+GLOVE_RECORD = 16
+
+
 def glove_entries(keys, counts, seed: int, alpha: float):
+    """Slots of the training records (rows, cols, log X, f(X)): GLOVE_RECORD consecutive slots
+    share their row; padding slots have col == SENTINEL."""
     keys = np.ascontiguousarray(keys, dtype=np.uint64)
     counts = np.ascontiguousarray(counts, dtype=np.uint64)
-    n = len(keys)
+    lib().o_glove_record_count.restype = C.c_uint64
+    n = int(lib().o_glove_record_count(_ptr(keys), C.c_uint64(len(keys)))) * GLOVE_RECORD
     rows, cols = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
     logx, fx = np.empty(n, dtype=np.float32), np.empty(n, dtype=np.float32)
-    lib().o_glove_entries(_ptr(keys), _ptr(counts), C.c_uint64(n), C.c_uint64(seed),
+    lib().o_glove_entries(_ptr(keys), _ptr(counts), C.c_uint64(len(keys)), C.c_uint64(seed),
                           C.c_float(alpha), _ptr(rows), _ptr(cols), _ptr(logx), _ptr(fx))
     return rows, cols, logx, fx
 
@@ -296,6 +302,13 @@ def glove_step(rows, cols, logx, fx, central, contextual, bias_c, bias_x, d: int
     lib().o_glove_step(_ptr(rows), _ptr(cols), _ptr(logx), _ptr(fx), C.c_uint64(len(rows)),
                        _ptr(central), _ptr(contextual), _ptr(bias_c), _ptr(bias_x),
                        C.c_uint32(d), C.c_uint32(central.shape[1]), C.c_float(lr))
+
+
+def glove_step_rounds(rows, cols, logx, fx, central, contextual, bias_c, bias_x, d: int, lr: float):
+    """In-place SGD in the engine's record schedule (four entries of a record per round)."""
+    lib().o_glove_step_rounds(_ptr(rows), _ptr(cols), _ptr(logx), _ptr(fx), C.c_uint64(len(rows)),
+                              _ptr(central), _ptr(contextual), _ptr(bias_c), _ptr(bias_x),
+                              C.c_uint32(d), C.c_uint32(central.shape[1]), C.c_float(lr))
 
 
 def glove_loss(rows, cols, logx, fx, central, contextual, bias_c, bias_x, d: int) -> float:

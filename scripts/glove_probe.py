@@ -1,5 +1,6 @@
 """GloVe path on a scale-free graph: co-occurrence build time and the SGD kernel's rate against
-its HBM roofline (algorithmic bytes per entry = 4 * d * 4: two rows read, two rows written).
+its HBM roofline (algorithmic bytes per entry = (2 + 2 / 16) * d * 4: the contextual row read and
+written per entry, the central row once per record of 16 entries).
 Usage: python scripts/glove_probe.py [--nodes N] [--walk-length L] [--d D]"""
 import argparse
 import os
@@ -32,7 +33,8 @@ rows, cols, logx, fx = cooccurrence.entries(keys, counts, 42, 0.75)
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 slots = a.nodes * a.walk_length * 2 * a.window
-print(f"co-occurrence: {slots:.3e} slots -> {rows.numel():.3e} entries in {t1 - t0:.2f}s "
+n_entries = int((cols != -1).sum())
+print(f"co-occurrence: {slots:.3e} slots -> {n_entries:.3e} entries in {rows.numel() // 16} records, {t1 - t0:.2f}s "
       f"(+ {t2 - t1:.2f}s ordering)", flush=True)
 del keys, counts
 n, d, ld = a.nodes, a.d, m.padded_size
@@ -52,8 +54,8 @@ for label, flags in (("write-through", _lib.TRAIN_WRITE_THROUGH), ("write-back",
     dt = (time.perf_counter() - t0) / a.epochs
     st = ops.stats_read(g, 0)
     kernel = st["train_ms"] / max(st["train_launches"], 1) * 1e-3
-    bytes_per = 4 * d * 4
-    print(f"{label:14s} {rows.numel() / dt:.3e} entries/s wall, kernel {kernel * 1e3:.1f} ms -> "
-          f"{rows.numel() * bytes_per / kernel / 1e9:.0f} GB/s algorithmic "
-          f"({rows.numel() * bytes_per / kernel / 8e12:.2f} of 8 TB/s), finite "
+    bytes_per = (2 + 2 / 16) * d * 4
+    print(f"{label:14s} {n_entries / dt:.3e} entries/s wall, kernel {kernel * 1e3:.1f} ms -> "
+          f"{n_entries * bytes_per / kernel / 1e9:.0f} GB/s algorithmic "
+          f"({n_entries * bytes_per / kernel / 8e12:.2f} of 8 TB/s), finite "
           f"{bool(torch.isfinite(central).all())}", flush=True)

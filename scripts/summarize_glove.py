@@ -29,7 +29,7 @@ def main(tag, cal_tag="r01"):
     fetch = per_kernel_counter(one(f"{src}/fetch/**/*counter_collection.csv"), "FETCH_SIZE")
     write = per_kernel_counter(one(f"{src}/write/**/*counter_collection.csv"), "WRITE_SIZE")
     out = {"tag": tag, "command": "scripts/glove_probe.py --nodes 1000000 --epochs 2",
-           "entries_per_launch": entries, "algorithmic_bytes_per_entry": 2048,
+           "entries_per_launch": entries, "algorithmic_bytes_per_entry": 1088,
            "fetch_calibration_factor": ff, "write_calibration_factor": wf, "kernels": {}}
     lines = []
     for mode, needle in (("write-through", "<2, 0, false>"), ("write-back", "<2, 1, false>"),
@@ -42,7 +42,7 @@ def main(tag, cal_tag="r01"):
         ms = float(st["AverageNs"]) / 1e6
         rd = sum(fv) / len(fv) * 1024 * ff
         wr = sum(wv) / len(wv) * 1024 * wf
-        alg = entries * 2048
+        alg = entries * 1088
         out["kernels"][mode] = {
             "avg_ms": ms, "calls": int(st["Calls"]), "algorithmic_GBps": alg / ms / 1e6,
             "frac_of_8TBps": alg / ms / 1e6 / 8000, "hbm_read_bytes_per_launch": rd,
@@ -54,7 +54,8 @@ def main(tag, cal_tag="r01"):
         f.write(f"# {tag}: `gn2v::glove_kernel` (BA 1 M nodes / 10 M edges, walks of 128, window 5, d = 128)\n\n"
                 f"`rocprofv3 --kernel-trace --stats` and separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of\n"
                 f"`python3 scripts/glove_probe.py --nodes 1000000 --epochs 2`; {entries:.3e} co-occurrence entries\n"
-                f"per launch, algorithmic 2 048 B per entry (two 512 B rows read, two written); counters corrected\n"
+                f"per launch, algorithmic 1 088 B per entry (the 512 B contextual row read and written per entry, the\n"
+                f"central row once per record of 16 entries); counters corrected\n"
                 f"with the `{cal_tag}` calibration (fetch x{ff:.3f}, write x{wf:.3f}).\n\n"
                 "| update mode | avg ms / launch | algorithmic GB/s | of 8 TB/s | HBM read B / entry | HBM written B / entry | traffic / algorithmic |\n"
                 "|---|---|---|---|---|---|---|\n" + "\n".join(lines) + "\n")

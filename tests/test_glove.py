@@ -58,21 +58,52 @@ def test_trapped_walks_only_count_their_valid_prefix():
     assert dict(zip(ukeys.tolist(), counts.tolist())) == naive_counts(walks, 2)
 
 
-def test_entries_are_a_shuffled_normalised_view(karate_oracle):
+def test_entries_are_shuffled_row_records(karate_oracle):
     ukeys, counts = O.cooc_reduce(*O.cooc_slots(karate_walks(karate_oracle), 5))
     rows, cols, logx, fx = O.glove_entries(ukeys, counts, 42, 0.75)
-    got = (rows.astype(np.uint64) << np.uint64(32)) | cols.astype(np.uint64)
-    assert sorted(got.tolist()) == ukeys.tolist() and not np.array_equal(got, ukeys)
-    x = np.exp(logx.astype(np.float64))
+    R = O.GLOVE_RECORD
+    assert len(rows) % R == 0 and (rows.reshape(-1, R) == rows.reshape(-1, R)[:, :1]).all()
+    used = cols != O.SENTINEL
+    # padding only at the end of a record, and only in the last record of a row
+    pad = (~used).reshape(-1, R)
+    assert (pad[:, 1:] >= pad[:, :-1]).all() and not pad[:, 0].any()
+    assert pad.any(axis=1).sum() <= len(np.unique(rows))
+    got = (rows[used].astype(np.uint64) << np.uint64(32)) | cols[used].astype(np.uint64)
+    assert sorted(got.tolist()) == ukeys.tolist()
+    x = np.exp(logx[used].astype(np.float64))
     assert x.max() == pytest.approx(1.0) and (logx <= 0).all() and (x > 0).all()
-    assert np.allclose(fx, x ** 0.75, rtol=1e-6)
+    assert np.allclose(fx[used], x ** 0.75, rtol=1e-6) and (fx[~used] == 0).all()
     order = np.argsort(got)
     assert np.allclose(x[order], counts / counts.max(), rtol=1e-6)
-    # the order depends on the seed only through the hash
+    # records of one row are scattered, not adjacent
+    first = rows.reshape(-1, R)[:, 0]
+    assert (first[1:] != first[:-1]).mean() > 0.8
     rows2 = O.glove_entries(ukeys, counts, 43, 0.75)[0]
     assert not np.array_equal(rows, rows2)
     again = O.glove_entries(ukeys, counts, 42, 0.75)
     assert np.array_equal(rows, again[0]) and np.array_equal(cols, again[1])
+
+
+def test_round_schedule_is_sgd_with_a_row_refreshed_every_four_entries(karate_oracle):
+    """The engine's record schedule (o_glove_step_rounds) equals the per-entry loop when every
+    round holds one entry, and stays close to it otherwise."""
+    ukeys, counts = O.cooc_reduce(*O.cooc_slots(karate_walks(karate_oracle), 3))
+    rows, cols, logx, fx = O.glove_entries(ukeys, counts, 1, 0.75)
+    d = 8
+    make = lambda: [O.init_table(34, d, d, 5, 0, 0.3), O.init_table(34, d, d, 5, 1, 0.3),  # noqa: E731
+                    np.zeros(34, np.float32), np.zeros(34, np.float32)]
+    # one entry per round: spread every entry to the first slot of its own round of four
+    n = len(rows)
+    sr, sc = np.repeat(rows, 4), np.full(4 * n, O.SENTINEL, np.uint32)
+    sl, sf = np.zeros(4 * n, np.float32), np.zeros(4 * n, np.float32)
+    sc[::4], sl[::4], sf[::4] = cols, logx, fx
+    a, b = make(), make()
+    O.glove_step(rows, cols, logx, fx, *a, d, 0.05)
+    O.glove_step_rounds(sr, sc, sl, sf, *b, d, 0.05)
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    c = make()
+    O.glove_step_rounds(rows, cols, logx, fx, *c, d, 0.05)
+    assert not np.array_equal(a[0], c[0]) and np.abs(a[0] - c[0]).max() < 0.05
 
 
 def test_glove_update_is_the_loss_gradient():

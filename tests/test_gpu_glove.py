@@ -107,6 +107,33 @@ def test_update_modes_on_collision_free_entries(flags, d, ld):
         assert np.abs(a - b).max() < 1e-5
 
 
+@pytest.mark.parametrize("flags", [_lib.TRAIN_ATOMIC, _lib.TRAIN_WRITE_THROUGH, _lib.TRAIN_WRITE_BACK])
+@pytest.mark.parametrize("d,ld", [(8, 8), (128, 128), (100, 128)])
+def test_record_fast_path_equals_the_round_schedule(flags, d, ld):
+    """Records of 16 slots with a common row (some padded), every row and every column used once:
+    the parallel kernel's record path must equal o_glove_step_rounds exactly."""
+    n_rec, R = 700, O.GLOVE_RECORD
+    rng = np.random.RandomState(2)
+    n = n_rec * R
+    g = E.CSRGraph.from_edge_list(np.arange(n - 1), np.arange(1, n), number_of_nodes=n)
+    rows = np.repeat(rng.permutation(n)[:n_rec].astype(np.uint32), R)
+    cols = rng.permutation(n).astype(np.uint32)
+    logx = -rng.uniform(0.1, 8.0, size=n).astype(np.float32)
+    fx = rng.uniform(0.01, 1.0, size=n).astype(np.float32)
+    fill = rng.randint(1, R + 1, size=n_rec)  # valid slots per record
+    pad = np.arange(R)[None, :] >= fill[:, None]
+    cols[pad.ravel()] = O.SENTINEL
+    logx[pad.ravel()] = 0
+    fx[pad.ravel()] = 0
+    state = _state(n, d, ld, 8)
+    got = _run_gpu(g, (rows, cols, logx, fx), state, d, 0.05, flags)
+    want = [a.copy() for a in state]
+    O.glove_step_rounds(rows, cols, logx, fx, *want, d, 0.05)
+    for a, b in zip(got, want):
+        assert np.abs(a - b).max() < 1e-5
+    assert np.abs(want[0] - state[0]).max() > 1e-3
+
+
 def test_non_finite_entries_are_skipped(karate):
     rows, cols = np.array([1, 2, 3], np.uint32), np.array([4, 5, 6], np.uint32)
     logx = np.array([-1.0, -np.inf, -2.0], np.float32)
@@ -134,7 +161,8 @@ def test_model_fit_equals_the_oracle_pipeline(karate, karate_oracle):
     for _ in range(5):
         O.glove_step(*entries, *state, 12, float(lr))
         lr = np.float32(lr * np.float32(0.9))
-    assert central.shape == (34, 12) and m.last_stats["entries"] == len(entries[0])
+    assert central.shape == (34, 12)
+    assert m.last_stats["entries"] == int((entries[1] != O.SENTINEL).sum())
     assert np.abs(central - state[0][:, :12]).max() < 2e-5
     assert np.abs(contextual - state[1][:, :12]).max() < 2e-5
 
@@ -191,8 +219,10 @@ def test_full_size_cooccurrence_properties():
     merged = acc.result()
     assert torch.equal(merged[0], keys) and torch.equal(merged[1], counts)
     rows, cols, logx, fx = cooccurrence.entries(keys, counts, 42, 0.75)
-    assert float(logx.max()) == 0.0 and bool((fx > 0).all()) and bool((fx <= 1).all())
-    assert rows.numel() == keys.numel()
+    used = cols != -1
+    assert float(logx.max()) == 0.0 and bool((fx[used] > 0).all()) and bool((fx <= 1).all())
+    assert int(used.sum()) == keys.numel() and rows.numel() % cooccurrence.RECORD == 0
+    assert rows.numel() < 1.15 * keys.numel()  # ~110 entries per row here: little padding
 
 
 def test_parallel_schedules_reach_the_sequential_loss():
