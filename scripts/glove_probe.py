@@ -38,6 +38,21 @@ print(f"co-occurrence: {slots:.3e} slots -> {n_entries:.3e} entries in {rows.num
       f"(+ {t2 - t1:.2f}s ordering)", flush=True)
 del keys, counts
 n, d, ld = a.nodes, a.d, m.padded_size
+
+
+def loss_of(central, contextual, bc, bx):
+    """GloVe loss of the entries, in slices (torch on the device; measurement only)."""
+    total = 0.0
+    step = 1 << 24
+    for lo in range(0, rows.numel(), step):
+        r, c = rows[lo:lo + step].long(), cols[lo:lo + step].long()
+        ok = c >= 0
+        r, c = r[ok], c[ok]
+        diff = (central[r] * contextual[c]).sum(1) + bc[r] + bx[c] - logx[lo:lo + step][ok]
+        total += float((0.5 * fx[lo:lo + step][ok] * diff * diff).sum())
+    return total
+
+
 for label, flags in (("write-through", _lib.TRAIN_WRITE_THROUGH), ("write-back", _lib.TRAIN_WRITE_BACK),
                      ("atomic", _lib.TRAIN_ATOMIC)):
     central = ops.init_table(n, d, 42, 0, d ** -0.5, 0, ld)
@@ -58,4 +73,5 @@ for label, flags in (("write-through", _lib.TRAIN_WRITE_THROUGH), ("write-back",
     print(f"{label:14s} {n_entries / dt:.3e} entries/s wall, kernel {kernel * 1e3:.1f} ms -> "
           f"{n_entries * bytes_per / kernel / 1e9:.0f} GB/s algorithmic "
           f"({n_entries * bytes_per / kernel / 8e12:.2f} of 8 TB/s), finite "
-          f"{bool(torch.isfinite(central).all())}", flush=True)
+          f"{bool(torch.isfinite(central).all())}, loss after {a.epochs + 1} epochs "
+          f"{loss_of(central, contextual, bc, bx):.4e}", flush=True)
