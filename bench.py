@@ -292,7 +292,7 @@ def main():
                 "parallelism": {
                     "single": "1 GPU, walk-ordered kernel",
                     "blocks": f"{world} GPU(s), tables partitioned by node id % {world} (no shared "
-                              f"rows), pair-list kernel, context partitions rotate once per round of "
+                              f"rows), centre-record kernel, context partitions rotate once per round of "
                               f"{args.round_walks} walks per GPU",
                 }[mode],
             },
