@@ -44,3 +44,28 @@ def test_blocks_mode_line_on_one_gpu():
     d = _run("--parallelism", "blocks", "--no-cpu-baseline", "--round-walks", "8192")
     assert "partitioned" in d["config"]["parallelism"] and d["finite"] is True
     assert "cpu_baseline" not in d and d["value"] > 0
+
+
+def test_two_rank_line_through_torch_distributed_run():
+    """The N > 1 launch line of the contract (python -m torch.distributed.run ... bench.py --gpus 2)
+    on a one-GPU box: both ranks share GPU 0 and exchange over gloo (testing flags of bench.py);
+    the collectives, barriers, max-over-ranks timing and the single JSON line are the real code."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--nodes", "200000", "--walks", "8192", "--round-walks", "8192", "--backend", "gloo",
+           "--share-device"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and res.stdout.strip().splitlines()[-1] == lines[0]  # JSON comes last
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite"] is True
+    assert "2 GPU(s)" in d["config"]["parallelism"] and "cpu_baseline" not in d
+    pairs = 2 * 2 * 8192 * 1250  # steps x ranks x walks x pairs per walk: the whole-job aggregate
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - pairs) < 1e-3 * pairs
