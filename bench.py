@@ -12,12 +12,15 @@ second-order walks on the GPU and train on all of them (1 250 pairs per walk).  
 tables are resident in HBM before the timed region.
 
 N > 1: one process per GPU, CSR replicated, every rank generates its own slice of the walk ids
-(weak scaling: per-GPU work fixed).  Both tables are partitioned by node id % N: GPU i owns central
-partition i and holds one context partition at a time; every (centre, context) pair is routed to
-the owner of its centre (RCCL all-to-all of 8 B per pair) and trained in the episode in which the
-context partition is resident; partitions rotate around the ring once per round (RCCL, N/N-th of a
-table per hop).  No row is ever shared, so N GPUs compute exactly what the single-process
-simulation of the tests computes.  See DESIGN.md "Multi-GPU".
+(weak scaling: per-GPU work fixed).  The central table is striped over the ranks (node id % N), the
+contextual table over 2 N parts that travel round the ranks: in every episode a GPU trains the
+pairs (centre it owns, context in the resident part) with negatives from that part while the part
+it just finished and the part it needs next are in flight (RCCL send / receive).  The round's walks
+are all-gathered (512 B per walk) and every rank extracts and sorts its own pairs on the device,
+on a second stream while the previous round trains.  No row is ever shared, so N GPUs compute
+exactly what the single-process simulation of the tests computes.  See DESIGN.md "Multi-GPU".
+
+`--model cbow` times the CBOW kernel on the same workload (unit: centres/s).
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,8 +40,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--walks", type=int, default=1 << 20, help="walks per step per GPU")
@@ -59,9 +62,16 @@ def parse():
     ap.add_argument("--parallelism", default="auto", choices=["auto", "single", "blocks"],
                     help="auto: single on 1 GPU, block-partitioned tables on N > 1 GPUs")
     ap.add_argument("--round-walks", type=int, default=1 << 20,
-                    help="blocks: walks per rank per round (one ring rotation of the context "
-                         "partitions per round; larger rounds amortise it: 2^20 measured 5 %% "
-                         "faster than 2^19 already on one GPU)")
+                    help="blocks: walks per rank per round (every context part visits every rank "
+                         "once per round)")
+    ap.add_argument("--parts", type=int, default=None,
+                    help="blocks: context parts (default 1 on one GPU, 2 x world otherwise)")
+    ap.add_argument("--slices", type=int, default=1,
+                    help="blocks: XCD slices inside a part (8 = every XCD owns its rows)")
+    ap.add_argument("--record", type=int, default=16, help="blocks: pairs per record")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="blocks: prepare every round in line instead of on a second stream")
+    ap.add_argument("--model", default="skipgram", choices=["skipgram", "cbow"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: all ranks use GPU 0 (use with --backend gloo)")
@@ -118,7 +128,9 @@ def cpu_baseline(graph, args, central, contextual, seconds):
     c = central[:, :d].contiguous().cpu().numpy()
     x = contextual[:, :d].contiguous().cpu().numpy()
     wp = O.WalkParams(128, 10, args.return_weight, args.explore_weight, 100, 0)
-    tp = O.TrainParams(0, d, d, 1, 10, 5, 0.01, 0.9, 6.0, O.FLAG_SCALE_FREE, d ** -0.5)
+    cbow = args.model == "cbow"
+    tp = O.TrainParams(1 if cbow else 0, d, d, 1, 10, 5, 0.01, 0.9, 6.0, O.FLAG_SCALE_FREE,
+                       d ** -0.5)
 
     def run(first, n):
         t0 = time.perf_counter()
@@ -126,23 +138,24 @@ def cpu_baseline(graph, args, central, contextual, seconds):
         t1 = time.perf_counter()
         O.train_walks(og, tp, w, 42, 0, first, 0.01, c, x, threads=cores)
         t2 = time.perf_counter()
-        pairs = int(n) * (2 * 5 * 128 - 5 * 6)
+        # the metric's unit: (centre, context) pairs for SkipGram, centres for CBOW
+        pairs = int(n) * (128 if cbow else 2 * 5 * 128 - 5 * 6)
         return pairs, n * 127, t1 - t0, t2 - t1
 
     first = 1 << 40  # walk ids the GPU run never uses
     probe_n = 64 * cores
     pairs, _, _, tt = run(first, probe_n)
     rate = pairs / max(tt, 1e-6)
-    n = int(max(probe_n, min(seconds * rate / 1250, 1 << 20)))
+    n = int(max(probe_n, min(seconds * rate / (128 if cbow else 1250), 1 << 20)))
     pairs, steps, tw, tt = run(first + probe_n, n)
     return {
         "value": pairs / (tw + tt),
-        "unit": "pairs/s",
+        "unit": "centres/s" if cbow else "pairs/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n} walks ({pairs} pairs) of the same BA graph and parameters, walks+training "
+        "sample": f"{n} walks ({pairs} {'centres' if cbow else 'pairs'}) of the same BA graph and parameters, walks+training "
                   f"{tw + tt:.1f}s, OpenMP Hogwild oracle on {cores} threads",
-        "train_only_pairs_per_s": pairs / tt,
+        "train_only_per_s": pairs / tt,
         "walk_steps_per_s": steps / max(tw, 1e-9),
     }
 
@@ -172,14 +185,15 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
+    cbow = args.model == "cbow"
     graph = E.barabasi_albert(args.nodes, args.m, 42, device=local)
     n, d = graph.get_number_of_nodes(), args.d
-    central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local)
-    contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local)
+    ld = (d + 3) // 4 * 4 if d <= 16 else (d + 31) // 32 * 32  # the engine's padded row stride
     flags = _lib.TRAIN_SCALE_FREE | {
         "auto": 0, "write_through": _lib.TRAIN_WRITE_THROUGH,
         "write_back": _lib.TRAIN_WRITE_BACK, "atomic": _lib.TRAIN_ATOMIC}[args.mode]
     if args.calibrate:
+        central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         perm = torch.randperm(n, device="cuda", dtype=torch.int64).to(torch.int32)
         mode_flags = flags & ~_lib.TRAIN_SCALE_FREE
         torch.cuda.synchronize()
@@ -196,7 +210,8 @@ def main():
                           "ms_per_launch": dt * 1e3,
                           "GBps": (2 * n * row_bytes + 4 * n) / dt / 1e9}), flush=True)
         return
-    tp = ops.train_params(_lib.MODEL_SKIPGRAM, d, 10, 5, lr=0.01, flags=flags)
+    model_id = _lib.MODEL_CBOW if cbow else _lib.MODEL_SKIPGRAM
+    tp = ops.train_params(model_id, d, 10, 5, lr=0.01, flags=flags, ld=ld)
     wp = ops.walk_params(128, 10, args.return_weight, args.explore_weight)
     from embiggen_amd.distributed import (BlockPartitionedTrainer, LoopbackComm, TorchComm,
                                           walk_slice)
@@ -206,36 +221,50 @@ def main():
         mode = "single" if world == 1 else "blocks"
     if mode == "single" and world > 1:
         raise SystemExit("--parallelism single needs --gpus 1")
-    blocks = None
+    if mode == "blocks" and cbow:
+        raise SystemExit("the block-partitioned trainer is SkipGram only")
+    blocks = comm = None
     if mode == "blocks":
-        # tables partitioned by node id % world; no row is ever held by two GPUs
-        del central, contextual
+        # tables partitioned by node id; no row is ever held by two GPUs
         comm = TorchComm() if world > 1 else LoopbackComm()
-        tp_pair = ops.train_params(_lib.MODEL_SKIPGRAM, d, 10, 1, lr=0.01, flags=flags)
-        blocks = BlockPartitionedTrainer(graph, tp_pair, d, (d + 31) // 32 * 32, 42, d ** -0.5,
-                                         comm, f"cuda:{local}")
-        central, contextual = blocks.central, blocks.context
+        blocks = BlockPartitionedTrainer(graph, tp, d, ld, 42, d ** -0.5, comm, f"cuda:{local}",
+                                         walk_length=128, window=5, parts=args.parts,
+                                         slices=args.slices, record=args.record)
+    else:
+        central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
+        contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local, ld=ld)
 
-    def step_blocks(index):
-        first, count = walk_slice(index, rank, world, args.walks)
-        for woff in range(0, count, args.round_walks):
-            nw = min(args.round_walks, count - woff)
-            wk = ops.walks(graph, wp, 42, 0, first + woff, nw, device=local)
-            blocks.train_round(wk, 5, 1, 42, 0, 0.01)
+    def block_rounds(first_step, n_steps):
+        """(make_walks, seed, epoch, lr, first_walk) of every round of the given steps"""
+        per_rank = min(args.round_walks, args.walks)
+        out = []
+        for index in range(first_step, first_step + n_steps):
+            base = index * world * args.walks  # ids of the step: [base, base + world * walks)
+            for woff in range(0, args.walks, per_rank):
+                nw = min(per_rank, args.walks - woff)
+                first = base + woff * world
 
-    def step(index):
+                def make(first=first, nw=nw):
+                    return ops.walks(graph, wp, 42, 0, first + rank * nw, nw, device=local)
+
+                out.append((make, 42, 0, 0.01, first))
+        return out
+
+    def run_steps(first_step, n_steps):
         if blocks is not None:
-            return step_blocks(index)
-        """this rank's slice of the step's walk ids, in launches of args.batch walks; then the
-        replicas exchange their deltas (one RCCL all-reduce per table)"""
-        first, count = walk_slice(index, rank, world, args.walks)
-        for woff in range(0, count, args.walk_batch):
-            nw = min(args.walk_batch, count - woff)
-            wk = ops.walks(graph, wp, 42, 0, first + woff, nw, device=local)
-            for off in range(0, nw, args.batch):
-                nb = min(args.batch, nw - off)
-                ops.sgns_step(graph, tp, wk[off:off + nb], 42, 0, first + woff + off, 0.01,
-                              central, contextual)
+            blocks.run(block_rounds(first_step, n_steps), overlap=not args.no_overlap)
+            return
+        train = ops.cbow_step if cbow else ops.sgns_step
+        for index in range(first_step, first_step + n_steps):
+            # this rank's slice of the step's walk ids, trained in launches of args.batch walks
+            first, count = walk_slice(index, rank, world, args.walks)
+            for woff in range(0, count, args.walk_batch):
+                nw = min(args.walk_batch, count - woff)
+                wk = ops.walks(graph, wp, 42, 0, first + woff, nw, device=local)
+                for off in range(0, nw, args.batch):
+                    nb = min(args.batch, nw - off)
+                    train(graph, tp, wk[off:off + nb], 42, 0, first + woff + off, 0.01, central,
+                          contextual)
 
     def fence():
         torch.cuda.synchronize()
@@ -243,36 +272,86 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(0, args.warmup)
     fence()
     ops.stats_reset(graph, local)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run_steps(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     st = ops.stats_read(graph, local)
 
     times = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    counts = torch.tensor([st["pairs"], st["walk_steps"]], dtype=torch.float64, device="cuda")
+    counts = torch.tensor([st["pairs"], st["walk_steps"], st["centres"]], dtype=torch.float64,
+                          device="cuda")
+    per_rank_pairs = [st["pairs"]]
+    comm_info = None
     if world > 1:
+        mine = counts[:1].clone()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank_pairs = [int(t[0]) for t in gathered]
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        # the two exchanges of a round, timed alone after the measured region (they overlap with
+        # training inside it): the all-gather of one round's walks and one half-partition hop
+        wk = torch.zeros((min(args.round_walks, args.walks), 128), dtype=torch.int32, device="cuda")
+        half = next(iter(blocks.held.values()))
+        recv = torch.empty_like(half)
+        reps = 4
+        ms = []
+        for fn in (lambda: comm.all_gather(wk),
+                   lambda: comm.sendrecv_start(half, (rank - 1) % world, recv,
+                                               (rank + 1) % world).wait()):
+            fn()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            fence()
+            ms.append((time.perf_counter() - t1) / reps * 1e3)
+        comm_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "per_rank_pairs": per_rank_pairs,
+                     "rounds_per_step": -(-args.walks // min(args.round_walks, args.walks)),
+                     "walk_allgather_ms_alone": ms[0],
+                     "walk_allgather_bytes_per_rank": wk.numel() * 4,
+                     "half_partition_hop_ms_alone": ms[1],
+                     "half_partition_bytes": half.numel() * 4,
+                     "hops_per_round": blocks.parts}
     elapsed = float(times[0])
-    total_pairs, total_steps = float(counts[0]), float(counts[1])
+    total_pairs, total_steps, total_centres = (float(x) for x in counts)
 
     if rank == 0:
         if blocks is not None:
-            central, contextual = blocks.central, blocks.context
-        ok = bool(torch.isfinite(central).all()) and bool(torch.isfinite(contextual).all())
-        launch_ms = st["train_ms"] / max(st["train_launches"], 1)
-        achieved = st["pairs"] * BYTES_PER_PAIR / (st["train_ms"] * 1e-3) / 1e9
+            ok = bool(torch.isfinite(blocks.central).all()) and all(
+                bool(torch.isfinite(t).all()) for t in blocks.held.values())
+        else:
+            ok = bool(torch.isfinite(central).all()) and bool(torch.isfinite(contextual).all())
+        launches = max(st["train_launches"], 1)
+        launch_ms = st["train_ms"] / launches
+        if cbow:
+            # per centre: c context rows + (1 + k) output rows, each read once and written once
+            algo_bytes = 2 * 4 * d * (st["pairs"] + st["centres"] * 11)
+            unit_name, value = "centres/s", total_centres / elapsed
+        else:
+            algo_bytes = st["pairs"] * (BYTES_PER_PAIR * d // 128)
+            unit_name, value = "pairs/s", total_pairs / elapsed
+        achieved = algo_bytes / (st["train_ms"] * 1e-3) / 1e9
+        if cbow:
+            kernel = "gn2v::cbow_cached_kernel" if n >= (1 << 16) else "gn2v::cbow_kernel"
+        elif blocks is not None:
+            kernel = "gn2v::sgns_block_kernel"
+        elif n >= (1 << 16) and args.mode in ("auto", "write_through", "write_back"):
+            kernel = "gn2v::sgns_cached_kernel"
+        else:
+            kernel = "gn2v::sgns_kernel"
         line = {
-            "metric": "SkipGram training-pairs/sec + walk-steps/sec, d=128 (value = pairs/s with walk "
-                      "generation inside the timed region; walk-steps/s in walk_kernel_steps_per_s)",
-            "value": total_pairs / elapsed,
-            "unit": "pairs/s",
+            "metric": ("CBOW training-centres/sec (21 504 B per centre at 10 contexts), d=128"
+                       if cbow else
+                       "SkipGram training-pairs/sec + walk-steps/sec, d=128 (value = pairs/s with walk "
+                       "generation inside the timed region; walk-steps/s in walk_kernel_steps_per_s)"),
+            "value": value,
+            "unit": unit_name,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -284,38 +363,41 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"Barabasi-Albert {n} nodes / {graph.get_number_of_directed_edges() // 2}"
-                            f" edges (seed 42), Node2Vec SkipGram d={d}, walk_length 128, window 5,"
+                            f" edges (seed 42), Node2Vec {'CBOW' if cbow else 'SkipGram'} d={d}, "
+                            f"walk_length 128, window 5,"
                             f" 10 negatives, return_weight {args.return_weight}, explore_weight "
                             f"{args.explore_weight}, {args.walks} walks per step per GPU",
                 "update_mode": args.mode,
-                "walks_per_launch": args.batch,
+                "walks_per_launch": args.batch if blocks is None else None,
                 "parallelism": {
                     "single": "1 GPU, walk-ordered kernel",
-                    "blocks": f"{world} GPU(s), tables partitioned by node id % {world} (no shared "
-                              f"rows), centre-record kernel, context partitions rotate once per round of "
-                              f"{args.round_walks} walks per GPU",
+                    "blocks": f"{world} GPU(s), central table striped over the ranks, contextual "
+                              f"table in {blocks.parts if blocks else 0} travelling parts x "
+                              f"{args.slices} XCD slice(s) (no shared rows), rounds of "
+                              f"{min(args.round_walks, args.walks)} walks per GPU, preparation "
+                              f"{'overlapped' if not args.no_overlap else 'in line'}",
                 }[mode],
             },
+            "pairs_per_s": total_pairs / elapsed,
             "walk_steps_per_s": total_steps / elapsed,
             "walk_kernel_steps_per_s": st["walk_steps"] / max(st["walk_ms"] * 1e-3, 1e-12),
             "finite": ok,
             "argv": sys.argv[1:],
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("gn2v::sgns_cached_kernel" if mode == "single" and n >= (1 << 16)
-                           and args.mode in ("auto", "write_through", "write_back")
-                           else "gn2v::sgns_kernel"),
+                "kernel": kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "algorithmic_bytes_per_launch": (st["pairs"] // max(st["train_launches"], 1))
-                                                * BYTES_PER_PAIR,
+                "algorithmic_bytes_per_launch": algo_bytes // launches,
                 "avg_launch_ms": launch_ms,
                 "launches": st["train_launches"],
             },
         }
+        if comm_info is not None:
+            line["distributed"] = comm_info
         pmc = committed_traffic(line["config"], args.mode)
         if pmc is not None:
             bytes_per_launch, source = pmc
@@ -324,6 +406,8 @@ def main():
             line["roofline"]["traffic_source"] = f"profiles/{source} (rocprofv3 --pmc FETCH_SIZE / " \
                                                  "WRITE_SIZE, calibrated; same workload)"
         if world == 1 and not args.no_cpu_baseline:
+            if blocks is not None:
+                central, contextual = blocks.gather_full()
             line["cpu_baseline"] = cpu_baseline(graph, args, central, contextual, args.cpu_seconds)
     if world > 1:
         dist.barrier()

@@ -11,8 +11,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libgn2v.so")
-_SOURCES = ["gn2v_api.hip", "rng.h", "walk_kernels.h", "train_kernels.h", "util_kernels.h",
-            "edge_kernels.h"]
+_UNITS = ["gn2v_api.hip", "gn2v_block_api.hip"]  # translation units of libgn2v.so
 _HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v.h")
 
 SENTINEL = 0xFFFFFFFF
@@ -39,6 +38,9 @@ EXPORTS = [
     "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_edge_embedding",
     "gn2v_cooc_slots", "gn2v_glove_step",
     "gn2v_touch_rows",
+    "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_pool_temp_bytes",
+    "gn2v_block_pool", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
+    "gn2v_block_extract", "gn2v_block_step",
     "gn2v_stats_reset",
     "gn2v_stats_read",
 ]
@@ -96,6 +98,31 @@ class StepIO(C.Structure):
     ]
 
 
+class BlockPlan(C.Structure):
+    """gn2v_block_plan: how nodes are striped over ranks, context parts and XCD slices."""
+
+    _fields_ = [(name, C.c_uint32) for name in (
+        "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
+        "row_bits", "flags")]
+
+
+class BlockIO(C.Structure):
+    _fields_ = [
+        ("d_keys", C.c_void_p),
+        ("d_vals", C.c_void_p),
+        ("d_cell_offsets", C.c_void_p),
+        ("d_pool", C.c_void_p),
+        ("d_pool_offsets", C.c_void_p),
+        ("d_central", C.c_void_p),
+        ("d_context", C.c_void_p),
+        ("block_id", C.c_uint64),
+        ("part", C.c_uint32),
+    ]
+
+
+BLOCK_WORK_WORDS = 9216
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("pairs", C.c_uint64),
@@ -117,7 +144,11 @@ class Gn2vError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile ``libgn2v.so`` for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, s) for s in _SOURCES] + [_HEADER]
+    import glob
+
+    # every header and unit in csrc/ is a dependency: a stale library must never survive an edit
+    srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip")))
+    srcs.append(_HEADER)
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(s) for s in srcs)
         if os.path.getmtime(LIB_PATH) >= newest:
@@ -125,7 +156,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [
         hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared",
-        "-fPIC", os.path.join(_CSRC, "gn2v_api.hip"), "-o", LIB_PATH,
+        "-fPIC", "-parallel-jobs=2", *[os.path.join(_CSRC, u) for u in _UNITS], "-o", LIB_PATH,
     ]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
@@ -181,6 +212,16 @@ def lib():
                              C.POINTER(Stats), vp]
     L.gn2v_edge_embedding.argtypes = [vp, vp, u32, u32, vp, vp, u64, u32, vp, u32, vp]
     L.gn2v_touch_rows.argtypes = [vp, u32, vp, u64, u32, vp]
+    L.gn2v_block_plan_check.argtypes = [vp, C.POINTER(BlockPlan)]
+    L.gn2v_init_table_rows.argtypes = [vp, u64, u32, u32, u64, u32, f32, u64, u64, vp]
+    L.gn2v_block_pool_temp_bytes.argtypes = [u64, C.POINTER(u64)]
+    L.gn2v_block_pool.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, u64, vp]
+    L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, vp, vp]
+    L.gn2v_block_extract_temp_bytes.argtypes = [u64, C.POINTER(u64)]
+    L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, u64,
+                                     vp, vp, vp, u64, vp]
+    L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),
+                                  C.POINTER(BlockIO), u64, u64, f32, vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]
     L.gn2v_stats_read.argtypes = [vp, C.POINTER(Stats), vp]
     for name in EXPORTS:

@@ -1,0 +1,418 @@
+// Block-partitioned SkipGram: the multi-GPU form of the fused negative-sampling step.
+//
+// The reference has no counterpart (ensmallen trains in one process with rayon threads; the call
+// being replaced is embedders/ensmallen_embedders/node2vec.py:99).  Scheme:
+// nodes are striped over `world` ranks (centre c lives on rank c % world, row c / world) and over
+// `parts` context parts (context x lives in part x % parts, row x / parts; parts is a multiple of
+// world and the parts travel round the ranks).  Inside a part the rows are striped once more over
+// `slices` (slice = row % slices): on MI355X one slice per XCD, so that every contextual row is
+// only ever touched by the workgroups of ONE XCD during a launch -- its L2 is then coherent for
+// that row, plain write-back stores are safe and hub rows (degree-proportional negatives) stay L2
+// resident.  cell = part * slices + slice.
+//
+// Per round: every (centre, context) pair of the round's walks whose centre this rank owns is
+// emitted as key = cell << row_bits | centre_row, value = context row (two passes over the walks:
+// count, then write at scanned offsets -- the output is in walk / position / slot order, whatever
+// the launch geometry), one stable radix sort by key groups the pairs by cell and centre, and the
+// training kernel walks a cell in implicit records of `record` consecutive pairs: a wave keeps
+// the centre row in registers while the centre does not change, records are visited in a
+// golden-ratio stride order (a hub centre owns thousands of consecutive records; concurrent waves
+// must not all accumulate into the same row).  Nothing is packed, padded or moved after the sort.
+#pragma once
+#include "train_kernels.h"
+
+namespace gn2v {
+
+constexpr uint64_t kTagBlock = 0xB10C5EED0B10C5EDULL;
+constexpr int kPrepBlock = 256;
+constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
+constexpr uint32_t kMaxCells = 1024;
+constexpr uint32_t kMaxRecord = 32;
+
+struct BlockPlan {
+    uint32_t world, rank, parts, slices;
+    uint32_t L, window, min_dist, record;
+    uint32_t row_bits;
+    uint32_t flags;  // kFlagDownsample: centres are thinned at extraction (needs the graph)
+};
+
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xF;
+}
+
+// --------------------------------------------------------------------------------------------
+// Negative pools: pool[cell] = the rows (x / parts) of every directed-edge endpoint x in the cell,
+// so a uniform draw from it is degree proportional within the cell.  Built once per graph and
+// plan: keys = cell of col_idx[e], values = row; one stable radix sort; a histogram for the
+// offsets.
+// --------------------------------------------------------------------------------------------
+__global__ void pool_keys_kernel(const uint32_t *__restrict__ col, uint64_t n_edges, uint32_t parts,
+                                 uint32_t slices, uint32_t *__restrict__ keys,
+                                 uint32_t *__restrict__ rows,
+                                 unsigned long long *__restrict__ cell_counts) {
+    __shared__ unsigned int hist[kMaxCells];
+    const uint32_t cells = parts * slices;
+    for (uint32_t c = threadIdx.x; c < cells; c += blockDim.x) hist[c] = 0;
+    __syncthreads();
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = col[e];
+        const uint32_t row = x / parts;
+        const uint32_t cell = (x - row * parts) * slices + row % slices;
+        keys[e] = cell;
+        rows[e] = row;
+        atomicAdd(&hist[cell], 1u);
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < cells; c += blockDim.x)
+        if (hist[c]) atomicAdd(&cell_counts[c], (unsigned long long)hist[c]);
+}
+
+// offsets[0 .. n] = exclusive prefix sums of counts[0 .. n) (one small block)
+__global__ void offsets_kernel(const unsigned long long *__restrict__ counts, uint32_t n,
+                               unsigned long long *__restrict__ offsets) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long run = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            offsets[i] = run;
+            run += counts[i];
+        }
+        offsets[n] = run;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Pair extraction.  Wave w owns the contiguous chunk of walks [w * chunk, (w + 1) * chunk) and
+// emits their pairs in walk / position / slot order; WRITE = false counts (per wave and per cell),
+// WRITE = true writes at the wave's scanned offset.
+// --------------------------------------------------------------------------------------------
+struct ExtractArgs {
+    GraphView g;
+    BlockPlan p;
+    const uint32_t *walks;
+    uint64_t n_walks;
+    uint64_t ekey;        // for the centre down-sampling draws (same as the walk-ordered kernels)
+    uint64_t first_walk;  // id of walks[0]
+    unsigned long long *wave_counts;  // [kPrepWaves]: counts out (count pass), offsets in (write)
+    unsigned long long *cell_counts;  // [cells] (count pass)
+    uint32_t *keys, *vals;
+};
+
+__device__ __forceinline__ bool keep_centre_at(const GraphView &g, uint64_t wkey, uint32_t i,
+                                               uint32_t c) {
+    const uint64_t deg = g.row_ptr[c + 1] - g.row_ptr[c];
+    if (deg == 0) return true;
+    const uint64_t r32 = draw(wkey ^ kTagDown, i) >> 32;
+    const uint64_t x = r32 * deg;
+    const uint64_t lhs_lo = x * g.n_nodes, lhs_hi = mulhi64(x, g.n_nodes);
+    const uint64_t rhs_lo = g.n_edges << 32, rhs_hi = g.n_edges >> 32;
+    return lhs_hi < rhs_hi || (lhs_hi == rhs_hi && lhs_lo < rhs_lo);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t waves_per_block = kPrepBlock / 64;
+    const uint32_t cells = a.p.parts * a.p.slices;
+    const uint32_t L = a.p.L, w = a.p.window, w2 = 2 * a.p.window;
+    uint32_t *s_walk = smem + wave * L;
+    unsigned int *s_hist = smem + waves_per_block * L + wave * cells;
+    const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint64_t chunk = (a.n_walks + kPrepWaves - 1) / kPrepWaves;
+    const uint64_t b0 = gw * chunk;
+    const uint64_t b1 = b0 + chunk < a.n_walks ? b0 + chunk : a.n_walks;
+    if constexpr (!WRITE) {
+        for (uint32_t c = lane; c < cells; c += 64) s_hist[c] = 0;
+    }
+    unsigned long long base = 0;
+    if constexpr (WRITE) base = a.wave_counts[gw];
+    unsigned long long total = 0;
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    for (uint64_t b = b0; b < b1; ++b) {
+        wave_sync();
+        uint32_t Le = L;
+        for (uint32_t t = lane; t < L; t += 64) {
+            const uint32_t v = a.walks[b * L + t];
+            s_walk[t] = v;
+            if (v == kSentinel) Le = min(Le, t);
+        }
+        for (int off = 32; off > 0; off >>= 1) Le = min(Le, (uint32_t)__shfl_xor(Le, off));
+        wave_sync();
+        const uint64_t wkey = draw(a.ekey, a.first_walk + b);
+        const uint32_t n_slots = Le * w2;
+        for (uint32_t t0 = 0; t0 < n_slots; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            bool valid = false;
+            uint32_t key = 0, val = 0, cell = 0;
+            if (t < n_slots) {
+                const uint32_t i = t / w2, slot = t - i * w2;
+                const int64_t j = slot < w ? (int64_t)i - w + slot : (int64_t)i + 1 + (slot - w);
+                if (j >= 0 && j < (int64_t)Le) {
+                    const uint32_t dist = (uint32_t)(j > (int64_t)i ? j - i : i - j);
+                    const uint32_t c = s_walk[i];
+                    const uint32_t crow = c / a.p.world;
+                    if (dist >= a.p.min_dist && c - crow * a.p.world == a.p.rank &&
+                        (!(a.p.flags & kFlagDownsample) || keep_centre_at(a.g, wkey, i, c))) {
+                        const uint32_t x = s_walk[j];
+                        val = x / a.p.parts;
+                        cell = (x - val * a.p.parts) * a.p.slices + val % a.p.slices;
+                        key = (cell << a.p.row_bits) | crow;
+                        valid = true;
+                    }
+                }
+            }
+            const uint64_t mask = __ballot(valid);
+            if constexpr (WRITE) {
+                if (valid) {
+                    const unsigned long long pos = base + __popcll(mask & lt_mask);
+                    a.keys[pos] = key;
+                    a.vals[pos] = val;
+                }
+                base += __popcll(mask);
+            } else {
+                if (valid) atomicAdd(&s_hist[cell], 1u);
+                total += __popcll(mask);
+            }
+        }
+    }
+    if constexpr (!WRITE) {
+        wave_sync();
+        if (lane == 0) a.wave_counts[gw] = total;
+        for (uint32_t c = lane; c < cells; c += 64)
+            if (s_hist[c]) atomicAdd(&a.cell_counts[c], (unsigned long long)s_hist[c]);
+    }
+}
+
+// wave_counts -> exclusive offsets in place, total -> total_out[0]; cell_counts -> cell_offsets
+__global__ __launch_bounds__(1024) void block_scan_kernel(unsigned long long *wave_counts,
+                                                          const unsigned long long *cell_counts,
+                                                          uint32_t cells,
+                                                          unsigned long long *cell_offsets) {
+    __shared__ unsigned long long part[1024];
+    constexpr uint32_t per = kPrepWaves / 1024;
+    unsigned long long loc[per];
+    unsigned long long sum = 0;
+    for (uint32_t e = 0; e < per; ++e) {
+        loc[e] = sum;
+        sum += wave_counts[threadIdx.x * per + e];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (uint32_t i = 0; i < 1024; ++i) {
+            const unsigned long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        unsigned long long off = 0;
+        for (uint32_t c = 0; c < cells; ++c) {
+            cell_offsets[c] = off;
+            off += cell_counts[c];
+        }
+        cell_offsets[cells] = off;
+    }
+    __syncthreads();
+    for (uint32_t e = 0; e < per; ++e) wave_counts[threadIdx.x * per + e] = part[threadIdx.x] + loc[e];
+}
+
+// --------------------------------------------------------------------------------------------
+// Training kernel over the sorted pairs of one part.
+// --------------------------------------------------------------------------------------------
+struct BlockArgs {
+    GraphView g;
+    BlockPlan p;
+    const uint32_t *keys;   // sorted: cell << row_bits | centre row
+    const uint32_t *vals;   // context row inside its part
+    const unsigned long long *cell_offsets;  // [cells + 1] into keys / vals
+    const uint32_t *pool;                    // negative pool (rows), or nullptr: uniform rows
+    const unsigned long long *pool_offsets;  // [cells + 1] into pool
+    float *central;    // this rank's central partition  [rows][ld]
+    float *context;    // the resident context part      [rows][ld]
+    unsigned long long *cursors;  // [slices] record tickets of the part's cells (zeroed per launch)
+    unsigned long long *counters;
+    uint64_t n_nodes;
+    uint64_t ekey;
+    uint64_t block_id;
+    uint32_t part;
+    uint32_t sweep;  // 1: second launch -- every workgroup serves every cell's leftover records
+    uint32_t k, ld, flags;
+    float lr, clip;
+};
+
+__device__ __forceinline__ float *sample_base(const BlockArgs &a, float *table, uint32_t row) {
+    return table + (uint64_t)row * a.ld;
+}
+
+__device__ __forceinline__ uint64_t gcd64(uint64_t a, uint64_t b) {
+    while (b) {
+        const uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// stride of the record visiting order: close to R / golden ratio, coprime with R
+__device__ __forceinline__ uint64_t record_stride(uint64_t R) {
+    if (R < 3) return 1;
+    uint64_t s = (uint64_t)((double)R * 0.6180339887498949);
+    if (s < 1) s = 1;
+    while (gcd64(s, R) != 1) ++s;
+    return s % R;
+}
+
+// rows of part `part` striped by `parts`, and of its slice `slice`
+__device__ __forceinline__ uint64_t stripe_count(uint64_t n, uint64_t first, uint64_t stride) {
+    return n > first ? (n - first + stride - 1) / stride : 0;
+}
+
+template <int CH, int WMX, int WMC, bool DET>
+__device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, uint64_t lo,
+                                             uint64_t p0, uint32_t n, uint64_t ckey,
+                                             uint64_t pool_lo, uint64_t pool_n, uint32_t slice,
+                                             uint32_t *s_key, uint32_t *s_val, uint32_t *s_rows,
+                                             float *s_lab, float *s_tr, int lane, int grp, int q,
+                                             unsigned long long &pairs) {
+    const uint32_t k = a.k, nchunks = a.ld >> 2;
+    const uint32_t rowmask = a.p.row_bits >= 32 ? 0xFFFFFFFFu : ((1u << a.p.row_bits) - 1u);
+    wave_sync();
+    if ((uint32_t)lane < n) {
+        s_key[lane] = a.keys[p0 + lane] & rowmask;
+        s_val[lane] = a.vals[p0 + lane];
+    }
+    wave_sync();
+    const uint32_t n_samples = n * (k + 1);
+    for (uint32_t t = lane; t < n_samples; t += 64) {
+        const uint32_t pr = t / (k + 1), s = t - pr * (k + 1);
+        const uint32_t xrow = s_val[pr];
+        uint32_t row = xrow;
+        float lab = 1.f;
+        if (s != 0) {
+            const uint64_t r = draw(ckey, (p0 - lo + pr) * k + (s - 1));
+            row = a.pool ? a.pool[pool_lo + mulhi64(r, pool_n)]
+                         : slice + a.p.slices * (uint32_t)mulhi64(r, pool_n);
+            lab = 0.f;
+            const uint64_t ngid = (uint64_t)row * a.p.parts + a.part;
+            const uint64_t cgid = (uint64_t)s_key[pr] * a.p.world + a.p.rank;
+            if (row == xrow || ngid == cgid) row = kSentinel;
+        }
+        s_rows[t] = row;
+        s_lab[t] = lab;
+    }
+    wave_sync();
+    uint32_t r0 = 0;
+    while (r0 < n) {
+        const uint32_t crow_id = s_key[r0];
+        uint32_t r1 = r0 + 1;
+        while (r1 < n && s_key[r1] == crow_id) ++r1;
+        float lrc = a.lr;
+        if (a.flags & kFlagNormLr) {
+            const uint64_t c = (uint64_t)crow_id * a.p.world + a.p.rank;
+            const uint64_t deg = a.g.row_ptr[c + 1] - a.g.row_ptr[c];
+            if (deg) lrc = a.lr / (float)deg;
+        }
+        float *crow = a.central + (uint64_t)crow_id * a.ld;
+        Row<CH> u, g;
+        load_row<CH>(u, crow, q, nchunks, true);
+        zero_row<CH>(g);
+        Row<CH> u_upd = u;
+        if constexpr (!DET && WMX == kAtomic) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
+        score_samples<CH, WMX, DET>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
+                                    s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
+        if constexpr (!DET) reduce_groups<CH>(g);
+        if constexpr (!DET && WMC == kAtomic) to_contig_layout<CH>(g, g, s_tr, grp, q, a.ld);
+        if (grp == 0) scatter_add<CH, DET ? kWriteBack : WMC>(crow, q, nchunks, 1.0f, g, u);
+        if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        r0 = r1;
+    }
+    pairs += n;
+}
+
+// WMX: store flavour of the contextual rows (kWriteBack only when the cell is exclusive to the
+// XCD the workgroup runs on), WMC: of the central rows (shared between XCDs).
+template <int CH, int WMX, int WMC, bool DET>
+__global__ __launch_bounds__(kTrainBlock) void sgns_block_kernel(BlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint32_t C = a.p.record, k = a.k;
+    const uint32_t per_wave = (a.ld + 2 * C + 2 * C * (k + 1) + 3) & ~3u;
+    float *s_tr = reinterpret_cast<float *>(smem + wave * per_wave);
+    uint32_t *s_key = smem + wave * per_wave + a.ld;
+    uint32_t *s_val = s_key + C;
+    uint32_t *s_rows = s_val + C;
+    float *s_lab = reinterpret_cast<float *>(s_rows + C * (k + 1));
+    unsigned long long pairs = 0;
+    const uint64_t part_rows = stripe_count(a.n_nodes, a.part, a.p.parts);
+
+    uint32_t first_slice = 0, n_my_slices = a.p.slices;
+    if (!DET && !a.sweep && a.p.slices > 1) {
+        first_slice = xcc_id() % a.p.slices;  // this workgroup's XCD owns exactly one slice
+        n_my_slices = 1;
+    }
+    for (uint32_t si = 0; si < n_my_slices; ++si) {
+        const uint32_t slice = first_slice + si;
+        const uint32_t cell = a.part * a.p.slices + slice;
+        const uint64_t lo = a.cell_offsets[cell], hi = a.cell_offsets[cell + 1];
+        if (hi == lo) continue;
+        const uint64_t R = (hi - lo + C - 1) / C;
+        const uint64_t A = record_stride(R);
+        const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kMaxCells + cell);
+        uint64_t pool_lo = 0, pool_n = stripe_count(part_rows, slice, a.p.slices);
+        if (a.pool) {
+            pool_lo = a.pool_offsets[cell];
+            pool_n = a.pool_offsets[cell + 1] - pool_lo;
+        }
+        if (pool_n == 0) continue;  // cannot happen when the cell has pairs (their contexts)
+        if constexpr (DET) {
+            for (uint64_t t = 0; t < R; ++t) {
+                const uint64_t rec = (t * A) % R;
+                const uint64_t p0 = lo + rec * C;
+                const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
+                train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, pool_lo, pool_n, slice,
+                                                s_key, s_val, s_rows, s_lab, s_tr, lane, grp, q,
+                                                pairs);
+            }
+        } else {
+            for (;;) {
+                unsigned long long t = 0;
+                if (lane == 0) t = atomicAdd(&a.cursors[slice], 1ULL);
+                t = __shfl(t, 0);
+                if (t >= R) break;
+                const uint64_t rec = (t * A) % R;
+                const uint64_t p0 = lo + rec * C;
+                const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
+                train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, pool_lo, pool_n, slice,
+                                                s_key, s_val, s_rows, s_lab, s_tr, lane, grp, q,
+                                                pairs);
+            }
+        }
+    }
+    if (a.counters && lane == 0 && pairs) atomicAdd(&a.counters[0], pairs);
+}
+
+// table row r <- initial values of global row first_row + r * row_stride (shards of a table that
+// never exists as a whole on this device)
+__global__ void init_rows_kernel(float *__restrict__ t, uint64_t n_rows, uint32_t d, uint32_t ld,
+                                 uint64_t key, float scale, uint64_t first_row,
+                                 uint64_t row_stride) {
+    const uint64_t n = n_rows * ld;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ld;
+        const uint32_t c = (uint32_t)(i - r * ld);
+        float v = 0.f;
+        if (c < d) {
+            const uint64_t h = draw(key, (first_row + r * row_stride) * d + c);
+            const float u = __fmul_rn((float)(h >> 40), 1.0f / 16777216.0f);
+            v = __fmul_rn(__fsub_rn(__fmul_rn(2.0f, u), 1.0f), scale);
+        }
+        t[i] = v;
+    }
+}
+
+}  // namespace gn2v

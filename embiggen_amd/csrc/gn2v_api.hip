@@ -19,7 +19,9 @@
 #include "util_kernels.h"
 #include "walk_kernels.h"
 
-namespace {
+#include "handle.h"
+
+namespace gn2v_host {
 
 thread_local std::string g_err;
 
@@ -27,37 +29,6 @@ int fail(const std::string &msg) {
     g_err = msg;
     return 1;
 }
-
-#define HIP_TRY(expr)                                                                     \
-    do {                                                                                  \
-        hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess)                                                             \
-            return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ \
-                                                                           ":" +          \
-                        std::to_string(__LINE__) + ")");                                  \
-    } while (0)
-
-struct EventPair {
-    hipEvent_t a, b;
-};
-
-}  // namespace
-
-struct gn2v_graph {
-    gn2v::GraphView view{};
-    int device = 0;
-    int n_cus = 256;
-    bool owns = false;
-    void *own_row_ptr = nullptr, *own_col_idx = nullptr, *own_cumw = nullptr,
-         *own_sources = nullptr, *own_node_types = nullptr, *own_edge_types = nullptr;
-    unsigned long long *counters = nullptr;  // device, 4 x u64
-    std::vector<EventPair> train_events, walk_events, free_events;
-    double train_ms = 0.0, walk_ms = 0.0;
-    uint32_t train_launches = 0, walk_launches = 0;
-    std::mutex mu;  // guards the event / timing bookkeeping (launches themselves are stream ordered)
-};
-
-namespace {
 
 int get_events(gn2v_graph *g, EventPair *ev) {
     if (!g->free_events.empty()) {
@@ -69,6 +40,12 @@ int get_events(gn2v_graph *g, EventPair *ev) {
     HIP_TRY(hipEventCreate(&ev->b));
     return 0;
 }
+
+}  // namespace gn2v_host
+
+using namespace gn2v_host;
+
+namespace {
 
 // fold finished event pairs into the ms accumulators (caller has synchronised the stream)
 int fold_events(gn2v_graph *g) {
@@ -375,7 +352,8 @@ int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const fl
     if (gn2v_device_count() <= device || device < 0)
         return fail("no HIP device " + std::to_string(device) +
                     " is visible: the gn2v engine requires an AMD GPU (there is no CPU fallback)");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok()) return fail("cannot select HIP device " + std::to_string(device));
     gn2v_graph *g = new gn2v_graph();
     g->device = device;
     hipDeviceProp_t prop;
@@ -416,6 +394,11 @@ int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const fl
         cleanup();
         return fail("allocating device counters failed");
     }
+    if (hipMalloc(&g->cursors, kCursorRing * kCursorWords * sizeof(unsigned long long)) !=
+        hipSuccess) {
+        cleanup();
+        return fail("allocating device counters failed");
+    }
     *out = g;
     return 0;
 }
@@ -423,7 +406,8 @@ int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const fl
 int gn2v_graph_set_types(gn2v_graph *g, const uint32_t *node_types,
                          const uint32_t *edge_types) {
     if (!g) return fail("graph handle is NULL");
-    HIP_TRY(hipSetDevice(g->device));
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
     std::lock_guard<std::mutex> lock(g->mu);
     // walks already queued may still read the old arrays
     HIP_TRY(hipDeviceSynchronize());
@@ -458,7 +442,7 @@ int gn2v_graph_set_types(gn2v_graph *g, const uint32_t *node_types,
 
 int gn2v_graph_destroy(gn2v_graph *g) {
     if (!g) return 0;
-    (void)hipSetDevice(g->device);
+    DeviceGuard guard(g->device);
     (void)hipDeviceSynchronize();
     if (g->own_row_ptr) (void)hipFree(g->own_row_ptr);
     if (g->own_col_idx) (void)hipFree(g->own_col_idx);
@@ -467,6 +451,7 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->own_node_types) (void)hipFree(g->own_node_types);
     if (g->own_edge_types) (void)hipFree(g->own_edge_types);
     if (g->counters) (void)hipFree(g->counters);
+    if (g->cursors) (void)hipFree(g->cursors);
     for (auto *v : {&g->train_events, &g->walk_events, &g->free_events})
         for (auto &ev : *v) {
             (void)hipEventDestroy(ev.a);
@@ -478,6 +463,7 @@ int gn2v_graph_destroy(gn2v_graph *g) {
 
 int gn2v_ba_edges(uint64_t n_nodes, uint32_t m, uint64_t seed, uint32_t *d_src, uint32_t *d_dst,
                   void *stream) {
+    DeviceGuard guard(DeviceGuard::of_pointer(d_src));
     if (n_nodes < 2 || m < 1) return fail("need n_nodes >= 2 and m >= 1");
     if (n_nodes >= 0xFFFFFFFFULL) return fail("node ids must fit in 32 bits");
     if (!d_src || !d_dst) return fail("NULL output pointer");
@@ -495,12 +481,14 @@ int gn2v_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_
     if (check_walk_params(wp)) return 1;
     if (n_walks == 0) return 0;
     if (!d_out) return fail("NULL output pointer");
-    HIP_TRY(hipSetDevice(g->device));
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
     return launch_walks(g, wp, seed, epoch, first_walk, n_walks, d_out, (hipStream_t)stream);
 }
 
 int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
                       uint32_t window, int32_t *d_contexts, int32_t *d_words, void *stream) {
+    DeviceGuard guard(DeviceGuard::of_pointer(d_walks));
     if (window < 1 || walk_length <= 2 * window)
         return fail("walk_length must exceed 2 * window_size");
     const uint64_t n = n_walks * (walk_length - 2 * window);
@@ -516,6 +504,7 @@ int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_l
 static int launch_pairs(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
                         uint32_t window, uint32_t min_dist, uint32_t world, uint64_t salt,
                         uint32_t *d_pairs, uint64_t *d_keys, bool want_keys, void *stream) {
+    DeviceGuard guard(DeviceGuard::of_pointer(d_walks));
     if (window < 1 || walk_length < 2) return fail("need window_size >= 1 and walk_length >= 2");
     if (want_keys && (world < 1 || world > 32768)) return fail("world must be in [1, 32768]");
     const uint64_t n = n_walks * walk_length * 2 * window;
@@ -546,6 +535,7 @@ int gn2v_walk_pair_blocks(const uint32_t *d_walks, uint64_t n_walks, uint32_t wa
 int gn2v_cooc_slots(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
                     uint32_t window, uint32_t min_dist, uint64_t *d_keys, uint64_t *d_weights,
                     void *stream) {
+    DeviceGuard guard(DeviceGuard::of_pointer(d_walks));
     if (window < 1 || walk_length < 2) return fail("need window_size >= 1 and walk_length >= 2");
     const uint64_t n = n_walks * walk_length * 2 * window;
     if (n == 0) return 0;
@@ -585,7 +575,8 @@ int gn2v_glove_step(gn2v_graph *g, const gn2v_glove_io *io, uint64_t n_entries, 
     if (!io->d_rows || !io->d_cols || !io->d_logx || !io->d_fx || !io->d_central ||
         !io->d_contextual || !io->d_bias_central || !io->d_bias_contextual)
         return fail("NULL entry / table / bias pointer");
-    HIP_TRY(hipSetDevice(g->device));
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
     gn2v::GloveArgs a{};
     a.rows = io->d_rows;
     a.cols = io->d_cols;
@@ -637,6 +628,7 @@ int gn2v_glove_step(gn2v_graph *g, const gn2v_glove_io *io, uint64_t n_entries, 
 
 int gn2v_init_table(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
                     uint32_t table_id, float scale, void *stream) {
+    DeviceGuard guard(DeviceGuard::of_pointer(d_table));
     if (d == 0 || ld < d) return fail("need 0 < d <= ld");
     const uint64_t n = n_rows * ld;
     if (n == 0) return 0;
@@ -654,7 +646,8 @@ int gn2v_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_step_io *io
     if (!g) return fail("graph handle is NULL");
     if (!tp) return fail("train params are NULL");
     if (tp->model > GN2V_MODEL_CBOW) return fail("unknown model id");
-    HIP_TRY(hipSetDevice(g->device));
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
     return launch_train(g, tp->model == GN2V_MODEL_CBOW, tp, io, n_walks, walk_length, seed, epoch,
                         first_walk, lr, (hipStream_t)stream);
 }
@@ -665,7 +658,8 @@ static int simple_step(gn2v_graph *g, bool cbow, const gn2v_train_params *tp,
                        float *d_central, float *d_contextual, const uint32_t *d_neg_override,
                        void *stream) {
     if (!g) return fail("graph handle is NULL");
-    HIP_TRY(hipSetDevice(g->device));
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
     gn2v_step_io io{};
     io.d_walks = d_walks;
     io.d_central = d_central;
@@ -694,6 +688,7 @@ int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d
 int gn2v_edge_embedding(const float *d_src_table, const float *d_dst_table, uint32_t d, uint32_t ld,
                         const uint32_t *d_src_ids, const uint32_t *d_dst_ids, uint64_t n_edges,
                         uint32_t method, float *d_out, uint32_t out_ld, void *stream) {
+    DeviceGuard guard(DeviceGuard::of_pointer(d_out));
     if (d == 0 || ld < d || (ld & 3) || ld > 512) return fail("need 0 < d <= ld <= 512, ld % 4 == 0");
     if (method >= gn2v::kEdgeMethodCount) return fail("unknown edge embedding method");
     if (n_edges == 0) return 0;  // empty edge lists are legal (and carry NULL pointers)
@@ -728,6 +723,7 @@ static bool nchunks_is_32(uint32_t ld) { return ld / 4 > 16 && ld / 4 <= 32; }
 
 int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t n, uint32_t flags,
                     void *stream) {
+    DeviceGuard guard(DeviceGuard::of_pointer(d_table));
     if (!d_table || !d_ids) return fail("NULL pointer");
     if (ld == 0 || (ld & 3) || ld > 512) return fail("ld must be a multiple of 4 in [4, 512]");
     if (n == 0) return 0;
@@ -780,7 +776,8 @@ int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t
 
 int gn2v_stats_reset(gn2v_graph *g, void *stream) {
     if (!g) return fail("graph handle is NULL");
-    HIP_TRY(hipSetDevice(g->device));
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     std::lock_guard<std::mutex> lock(g->mu);
     if (fold_events(g)) return 1;
@@ -793,7 +790,8 @@ int gn2v_stats_reset(gn2v_graph *g, void *stream) {
 
 int gn2v_stats_read(gn2v_graph *g, gn2v_stats *stats, void *stream) {
     if (!g || !stats) return fail("NULL handle / stats");
-    HIP_TRY(hipSetDevice(g->device));
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     std::lock_guard<std::mutex> lock(g->mu);
     if (fold_events(g)) return 1;
@@ -817,7 +815,8 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
     if (check_train_params(tp, wp->walk_length)) return 1;
     if (tp->model > GN2V_MODEL_CBOW) return fail("unknown model id");
     if (!d_central || !d_contextual) return fail("NULL table pointer");
-    HIP_TRY(hipSetDevice(g->device));
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
     const bool cbow = tp->model == GN2V_MODEL_CBOW;
     const uint32_t L = wp->walk_length;

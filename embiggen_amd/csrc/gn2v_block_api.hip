@@ -1,0 +1,356 @@
+// libgn2v.so -- entry points of the block-partitioned (multi-GPU) SkipGram trainer
+// (include/gn2v.h "Block-partitioned training").  The reference has no counterpart: its one call,
+// self._model.fit_transform(graph) (embedders/ensmallen_embedders/node2vec.py:99), runs in one
+// process; this is how the same call is spread over the GPUs of a node.
+#include <hip/hip_runtime.h>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+#include "block_kernels.h"
+#include "handle.h"
+
+using namespace gn2v_host;
+
+namespace {
+
+uint32_t bits_for(uint64_t n) {  // smallest b with 2^b >= n
+    uint32_t b = 0;
+    while ((1ULL << b) < n) ++b;
+    return b;
+}
+
+int check_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
+    if (!g) return fail("graph handle is NULL");
+    if (!p) return fail("block plan is NULL");
+    if (p->world < 1 || p->rank >= p->world) return fail("need rank < world");
+    if (p->parts < p->world || p->parts % p->world)
+        return fail("parts must be a positive multiple of world");
+    if (p->slices < 1 || p->slices > gn2v_host::kCursorWords)
+        return fail("slices must be in [1, 16]");
+    if ((uint64_t)p->parts * p->slices > gn2v::kMaxCells) return fail("too many cells (parts x slices)");
+    if (p->walk_length < 2 || p->window < 1) return fail("need walk_length >= 2, window_size >= 1");
+    if (p->min_dist > p->window) return fail("min_dist must not exceed window_size");
+    if (p->record > gn2v::kMaxRecord) return fail("record must be at most 32 pairs");
+    return 0;
+}
+
+gn2v::BlockPlan device_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
+    gn2v::BlockPlan d{};
+    d.world = p->world;
+    d.rank = p->rank;
+    d.parts = p->parts;
+    d.slices = p->slices;
+    d.L = p->walk_length;
+    d.window = p->window;
+    d.min_dist = p->min_dist ? p->min_dist : 1;
+    d.record = p->record ? p->record : 16;
+    const uint64_t rows = (g->view.n_nodes + p->world - 1) / p->world;
+    d.row_bits = bits_for(rows);
+    d.flags = p->flags & gn2v::kFlagDownsample;
+    return d;
+}
+
+int check_key_width(const gn2v::BlockPlan &d) {
+    if (d.row_bits + bits_for((uint64_t)d.parts * d.slices) > 32)
+        return fail("block keys need more than 32 bits: use fewer parts / slices or more ranks");
+    return 0;
+}
+
+template <class K, class V>
+int sort_pairs(void *temp, size_t temp_bytes, const K *keys_in, K *keys_out, const V *vals_in,
+               V *vals_out, uint64_t n, uint32_t end_bit, hipStream_t s) {
+    size_t need = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, n, 0,
+                                      end_bit, s));
+    if (need > temp_bytes) return fail("temporary storage too small for the radix sort");
+    HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys_in, keys_out, vals_in, vals_out, n, 0,
+                                      end_bit, s));
+    return 0;
+}
+
+size_t sort_temp_bytes(uint64_t n) {
+    size_t need = 0;
+    const uint32_t *k = nullptr;
+    uint32_t *ko = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, need, k, ko, k, ko, n ? n : 1, 0, 32, (hipStream_t)0) !=
+        hipSuccess)
+        return 0;
+    return (need + 255) & ~(size_t)255;
+}
+
+constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+int gn2v_block_plan_check(gn2v_graph *g, gn2v_block_plan *plan) {
+    if (check_plan(g, plan)) return 1;
+    const gn2v::BlockPlan d = device_plan(g, plan);
+    if (check_key_width(d)) return 1;
+    plan->row_bits = d.row_bits;
+    plan->record = d.record;
+    plan->min_dist = d.min_dist;
+    return 0;
+}
+
+int gn2v_init_table_rows(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
+                         uint32_t table_id, float scale, uint64_t first_row, uint64_t row_stride,
+                         void *stream) {
+    if (d == 0 || ld < d) return fail("need 0 < d <= ld");
+    const uint64_t n = n_rows * ld;
+    if (n == 0) return 0;
+    if (!d_table) return fail("NULL table pointer");
+    DeviceGuard guard(DeviceGuard::of_pointer(d_table));
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(gn2v::init_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       d_table, n_rows, d, ld, gn2v::mix64(seed ^ (gn2v::kTagInit + table_id)), scale,
+                       first_row, row_stride ? row_stride : 1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_block_pool_temp_bytes(uint64_t n_edges, uint64_t *bytes) {
+    if (!bytes) return fail("bytes is NULL");
+    *bytes = 3 * align256(n_edges * 4) + align256(gn2v::kMaxCells * 8) + sort_temp_bytes(n_edges);
+    return 0;
+}
+
+int gn2v_block_pool(gn2v_graph *g, const gn2v_block_plan *plan, uint32_t *d_pool,
+                    uint64_t *d_pool_offsets, void *d_temp, uint64_t temp_bytes, void *stream) {
+    if (check_plan(g, plan)) return 1;
+    if (!d_pool || !d_pool_offsets || !d_temp) return fail("NULL pointer");
+    uint64_t need = 0;
+    gn2v_block_pool_temp_bytes(g->view.n_edges, &need);
+    if (temp_bytes < need) return fail("temporary storage too small for the pool build");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t E = g->view.n_edges;
+    const uint32_t cells = plan->parts * plan->slices;
+    char *t = (char *)d_temp;
+    uint32_t *keys = (uint32_t *)t;
+    uint32_t *rows = (uint32_t *)(t + align256(E * 4));
+    uint32_t *keys_out = (uint32_t *)(t + 2 * align256(E * 4));
+    unsigned long long *counts = (unsigned long long *)(t + 3 * align256(E * 4));
+    void *sort_temp = t + 3 * align256(E * 4) + align256(gn2v::kMaxCells * 8);
+    HIP_TRY(hipMemsetAsync(counts, 0, cells * sizeof(unsigned long long), s));
+    const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(gn2v::pool_keys_kernel, dim3(blocks), dim3(256), 0, s, g->view.col_idx, E,
+                       plan->parts, plan->slices, keys, rows, counts);
+    HIP_TRY(hipGetLastError());
+    if (sort_pairs(sort_temp, temp_bytes - (3 * align256(E * 4) + align256(gn2v::kMaxCells * 8)),
+                   keys, keys_out, rows, d_pool, E, std::max(1u, bits_for(cells)), s))
+        return 1;
+    hipLaunchKernelGGL(gn2v::offsets_kernel, dim3(1), dim3(64), 0, s, counts, cells,
+                       (unsigned long long *)d_pool_offsets);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
+                          const uint32_t *d_walks, uint64_t n_walks, uint64_t seed, uint64_t epoch,
+                          uint64_t first_walk, uint64_t *d_work, uint32_t *keys, uint32_t *vals,
+                          hipStream_t s) {
+    gn2v::ExtractArgs a{};
+    a.g = g->view;
+    a.p = d;
+    a.walks = d_walks;
+    a.n_walks = n_walks;
+    a.ekey = gn2v::epoch_key(seed, epoch);
+    a.first_walk = first_walk;
+    a.wave_counts = (unsigned long long *)d_work;
+    a.cell_counts = (unsigned long long *)d_work + gn2v::kPrepWaves;
+    a.keys = keys;
+    a.vals = vals;
+    const uint32_t cells = d.parts * d.slices;
+    const size_t lds = (size_t)(gn2v::kPrepBlock / 64) * (d.L + cells) * 4;
+    if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
+    const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
+    if (write)
+        hipLaunchKernelGGL(gn2v::block_extract_kernel<true>, grid, block, lds, s, a);
+    else
+        hipLaunchKernelGGL(gn2v::block_extract_kernel<false>, grid, block, lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
+                     uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                     uint64_t *d_work, uint64_t *d_cell_offsets, void *stream) {
+    if (check_plan(g, plan)) return 1;
+    const gn2v::BlockPlan d = device_plan(g, plan);
+    if (check_key_width(d)) return 1;
+    if (!d_work || !d_cell_offsets || (n_walks && !d_walks)) return fail("NULL pointer");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(d_work, 0, GN2V_BLOCK_WORK_WORDS * sizeof(uint64_t), s));
+    if (n_walks &&
+        launch_extract(g, d, false, d_walks, n_walks, seed, epoch, first_walk, d_work, nullptr,
+                       nullptr, s))
+        return 1;
+    hipLaunchKernelGGL(gn2v::block_scan_kernel, dim3(1), dim3(1024), 0, s,
+                       (unsigned long long *)d_work,
+                       (const unsigned long long *)d_work + gn2v::kPrepWaves, d.parts * d.slices,
+                       (unsigned long long *)d_cell_offsets);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes) {
+    if (!bytes) return fail("bytes is NULL");
+    *bytes = 2 * align256(n_pairs * 4) + sort_temp_bytes(n_pairs);
+    return 0;
+}
+
+int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
+                       uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                       const uint64_t *d_work, uint64_t n_pairs, uint32_t *d_keys, uint32_t *d_vals,
+                       void *d_temp, uint64_t temp_bytes, void *stream) {
+    if (check_plan(g, plan)) return 1;
+    const gn2v::BlockPlan d = device_plan(g, plan);
+    if (check_key_width(d)) return 1;
+    if (n_pairs == 0) return 0;
+    if (!d_work || !d_walks || !d_keys || !d_vals || !d_temp) return fail("NULL pointer");
+    uint64_t need = 0;
+    gn2v_block_extract_temp_bytes(n_pairs, &need);
+    if (temp_bytes < need) return fail("temporary storage too small for the extraction");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    hipStream_t s = (hipStream_t)stream;
+    char *t = (char *)d_temp;
+    uint32_t *keys_in = (uint32_t *)t;
+    uint32_t *vals_in = (uint32_t *)(t + align256(n_pairs * 4));
+    void *sort_temp = t + 2 * align256(n_pairs * 4);
+    if (launch_extract(g, d, true, d_walks, n_walks, seed, epoch, first_walk,
+                       const_cast<uint64_t *>(d_work), keys_in, vals_in, s))
+        return 1;
+    const uint32_t end_bit = d.row_bits + bits_for((uint64_t)d.parts * d.slices);
+    return sort_pairs(sort_temp, temp_bytes - 2 * align256(n_pairs * 4), keys_in, d_keys, vals_in,
+                      d_vals, n_pairs, std::max(1u, end_bit), s);
+}
+
+extern "C++" {
+template <int CH>
+static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, size_t lds,
+                            hipStream_t s, const gn2v::BlockArgs &a) {
+#define GN2V_BLOCK(WMX, WMC, DT) \
+    hipLaunchKernelGGL((gn2v::sgns_block_kernel<CH, WMX, WMC, DT>), grid, block, lds, s, a)
+    if (det)
+        GN2V_BLOCK(gn2v::kWriteBack, gn2v::kWriteBack, true);
+    else if (wmx == gn2v::kAtomic)
+        GN2V_BLOCK(gn2v::kAtomic, gn2v::kAtomic, false);
+    else if (wmx == gn2v::kWriteBack && wmc == gn2v::kWriteBack)
+        GN2V_BLOCK(gn2v::kWriteBack, gn2v::kWriteBack, false);
+    else if (wmx == gn2v::kWriteBack)
+        GN2V_BLOCK(gn2v::kWriteBack, gn2v::kWriteThrough, false);
+    else
+        GN2V_BLOCK(gn2v::kWriteThrough, gn2v::kWriteThrough, false);
+#undef GN2V_BLOCK
+}
+}  // extern "C++"
+
+int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
+                    const gn2v_block_io *io, uint64_t seed, uint64_t epoch, float lr,
+                    void *stream) {
+    if (check_plan(g, plan)) return 1;
+    const gn2v::BlockPlan d = device_plan(g, plan);
+    if (check_key_width(d)) return 1;
+    if (!tp || !io) return fail("NULL params / io");
+    if (tp->d == 0) return fail("embedding size must be strictly positive");
+    if (tp->ld < tp->d || (tp->ld & 3)) return fail("ld must be a multiple of 4 and >= d");
+    if (tp->ld > 512) return fail("embedding sizes above 512 are not supported yet");
+    if (!std::isfinite(lr) || !std::isfinite(tp->clip) || tp->clip <= 0.f)
+        return fail("learning rate / clipping value must be finite, clipping value positive");
+    if (io->part >= plan->parts) return fail("part out of range");
+    if (!io->d_keys || !io->d_vals || !io->d_cell_offsets || !io->d_central || !io->d_context)
+        return fail("NULL pointer");
+    if ((tp->flags & GN2V_TRAIN_SCALE_FREE) && (!io->d_pool || !io->d_pool_offsets))
+        return fail("degree-proportional negatives need the pool of gn2v_block_pool");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    hipStream_t s = (hipStream_t)stream;
+
+    gn2v::BlockArgs a{};
+    a.g = g->view;
+    a.p = d;
+    a.keys = io->d_keys;
+    a.vals = io->d_vals;
+    a.cell_offsets = (const unsigned long long *)io->d_cell_offsets;
+    const bool scale_free = tp->flags & GN2V_TRAIN_SCALE_FREE;
+    a.pool = scale_free ? io->d_pool : nullptr;
+    a.pool_offsets = scale_free ? (const unsigned long long *)io->d_pool_offsets : nullptr;
+    a.central = io->d_central;
+    a.context = io->d_context;
+    a.counters = g->counters;
+    a.n_nodes = g->view.n_nodes;
+    a.ekey = gn2v::epoch_key(seed, epoch);
+    a.block_id = io->block_id;
+    a.part = io->part;
+    a.k = tp->k;
+    a.ld = tp->ld;
+    a.flags = tp->flags & 7u;
+    a.lr = lr;
+    a.clip = tp->clip;
+
+    const bool det = tp->flags & GN2V_TRAIN_DETERMINISTIC;
+    // contextual rows: exclusive to one XCD when the part is sliced -> plain write-back stores;
+    // central rows are shared by the XCDs -> write-through.  Small graphs: atomics, as elsewhere.
+    int wmc = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
+              : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
+              : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
+              : g->view.n_nodes < (1ULL << 16)         ? gn2v::kAtomic
+                                                       : gn2v::kWriteThrough;
+    int wmx = wmc;
+    if (wmc == gn2v::kWriteThrough && d.slices > 1) wmx = gn2v::kWriteBack;
+
+    const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
+    const size_t per_wave_words =
+        ((size_t)tp->ld + 2 * d.record + 2 * (size_t)d.record * (tp->k + 1) + 3) & ~(size_t)3;
+    const size_t lds = (size_t)waves_per_block * per_wave_words * 4;
+    if (lds > 64 * 1024) return fail("record / negatives too large for the LDS plan");
+    uint64_t blocks = det ? 1 : (uint64_t)g->n_cus * 8;
+    if (!det) {
+        // at most one concurrent wave per table row on average (staleness of the records of one
+        // centre trained from the same copy of its row; binds on tiny graphs only)
+        const uint64_t rows = g->view.n_nodes / d.parts;
+        const uint64_t max_blocks = std::max<uint64_t>(d.slices, rows / waves_per_block);
+        if (blocks > max_blocks) blocks = max_blocks;
+    }
+    dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kTrainBlock);
+
+    std::lock_guard<std::mutex> lock(g->mu);
+    a.cursors = g->cursors + (size_t)(g->cursor_slot++ % kCursorRing) * kCursorWords;
+    HIP_TRY(hipMemsetAsync(a.cursors, 0, kCursorWords * sizeof(unsigned long long), s));
+    EventPair ev;
+    if (get_events(g, &ev)) return 1;
+    HIP_TRY(hipEventRecord(ev.a, s));
+    const uint32_t nchunks = tp->ld / 4;
+    for (int pass = 0; pass < ((!det && d.slices > 1) ? 2 : 1); ++pass) {
+        // pass 1 (sliced parts only): whatever the XCD placement left behind is finished by
+        // every workgroup with write-through stores (normally nothing: the kernel exits at once)
+        a.sweep = pass;
+        const int x = pass ? (wmc == gn2v::kAtomic ? gn2v::kAtomic : gn2v::kWriteThrough) : wmx;
+        if (nchunks <= 16)
+            launch_block_ch<1>(x, wmc, det, grid, block, lds, s, a);
+        else if (nchunks <= 32)
+            launch_block_ch<2>(x, wmc, det, grid, block, lds, s, a);
+        else if (nchunks <= 64)
+            launch_block_ch<4>(x, wmc, det, grid, block, lds, s, a);
+        else
+            launch_block_ch<8>(x, wmc, det, grid, block, lds, s, a);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ev.b, s));
+    g->train_events.push_back(ev);
+    g->train_launches++;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Host-side pieces shared by the translation units of libgn2v.so: the opaque graph handle of
+// include/gn2v.h, error reporting, the device guard and the launch-time bookkeeping.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gn2v.h"
+#include "walk_kernels.h"
+
+namespace gn2v_host {
+
+int fail(const std::string &msg);  // records the thread's last error, returns 1
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return gn2v_host::fail(std::string(#expr) + ": " + hipGetErrorString(e_) +    \
+                                   " (" __FILE__ ":" + std::to_string(__LINE__) + ")");   \
+    } while (0)
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+// record-ticket arrays of the block trainer: one per launch, reused round robin (a launch is long
+// over before its slot comes round again)
+constexpr unsigned kCursorWords = 16, kCursorRing = 256;
+
+// Every entry point runs on the device of its graph handle (or of the buffers it is given) and
+// leaves the calling thread's current HIP device as it found it: a one-process multi-device
+// program (PyTorch keeps its own notion of the current device) must not see it change.
+class DeviceGuard {
+  public:
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+        if (device >= 0 && device != prev_) {
+            ok_ = hipSetDevice(device) == hipSuccess;
+            switched_ = ok_;
+        }
+    }
+    // device that owns `ptr` (device memory); falls back to the current device
+    static int of_pointer(const void *ptr) {
+        hipPointerAttribute_t attr;
+        if (ptr && hipPointerGetAttributes(&attr, ptr) == hipSuccess) return attr.device;
+        (void)hipGetLastError();
+        return -1;
+    }
+    ~DeviceGuard() {
+        if (switched_ && prev_ >= 0) (void)hipSetDevice(prev_);
+    }
+    bool ok() const { return ok_; }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+
+  private:
+    int prev_ = -1;
+    bool ok_ = true, switched_ = false;
+};
+
+}  // namespace gn2v_host
+
+struct gn2v_graph {
+    gn2v::GraphView view{};
+    int device = 0;
+    int n_cus = 256;
+    bool owns = false;
+    void *own_row_ptr = nullptr, *own_col_idx = nullptr, *own_cumw = nullptr,
+         *own_sources = nullptr, *own_node_types = nullptr, *own_edge_types = nullptr;
+    unsigned long long *counters = nullptr;  // device, 4 x u64
+    unsigned long long *cursors = nullptr;   // device, ring of record-ticket arrays (block trainer)
+    uint32_t cursor_slot = 0;
+    std::vector<gn2v_host::EventPair> train_events, walk_events, free_events;
+    double train_ms = 0.0, walk_ms = 0.0;
+    uint32_t train_launches = 0, walk_launches = 0;
+    std::mutex mu;  // guards the event / timing bookkeeping (launches themselves are stream ordered)
+};
+
+namespace gn2v_host {
+int get_events(gn2v_graph *g, EventPair *ev);
+}

@@ -307,8 +307,8 @@ __device__ __forceinline__ float *sample_base(const TrainArgs &a, float *table, 
 // for each sample row v: var = (label - sigmoid(clip(u.v))) * lr ; g += var * v ; v += var * u.
 // u_upd is the copy of u the row update consumes (lane-contiguous shape in atomic mode).
 // DET: one sample at a time, all groups redundantly, group 0 writes (strict sequential semantics).
-template <int CH, int WM, bool DET>
-__device__ __forceinline__ void score_samples(const TrainArgs &a, float *table, const Row<CH> &u,
+template <int CH, int WM, bool DET, class Args>
+__device__ __forceinline__ void score_samples(const Args &a, float *table, const Row<CH> &u,
                                               const Row<CH> &u_upd, Row<CH> &g,
                                               const uint32_t *s_rows,
                                               const float *s_lab, uint32_t n_samples, float lrc,

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
 }
 
 // Node2VecSequence batch form: words / contexts of every full-window position.
-__global__ void window_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L,
+static __global__ void window_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L,
                               uint32_t w, int32_t *__restrict__ contexts,
                               int32_t *__restrict__ words) {
     const uint32_t per = L - 2 * w;
@@ -352,7 +352,7 @@ __global__ void window_kernel(const uint32_t *__restrict__ walks, uint64_t n_wal
 // unused slot -- one radix sort then groups the pairs by block, shuffles them inside a block and
 // pushes the unused slots to the end.  With salt == ~0 the key is block << 32 | centre: the sort
 // then also groups the pairs of a block by centre node (for packing them into centre records).
-__global__ void pairs_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L,
+static __global__ void pairs_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L,
                              uint32_t w, uint32_t min_dist, uint32_t *__restrict__ pairs,
                              unsigned long long *__restrict__ keys, uint32_t world,
                              uint64_t salt) {

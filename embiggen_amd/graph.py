@@ -91,6 +91,7 @@ class CSRGraph:
         self._name = name
         self._directed = directed
         self._node_names = node_names
+        self._named = node_names is not None  # False: names are the default str(id)
         self._device_tensors = _device_tensors  # dict of torch cuda tensors or None
         self._handles = {}
         self._node_type_ids = self._edge_type_ids = None
@@ -538,6 +539,26 @@ class CSRGraph:
                          node_type_lists=self._node_type_lists)
         self._degree_normalized = g
         return g
+
+    def content_digest(self) -> str:
+        """sha256 over the graph's content (CSR arrays, weights, type ids, node names): what the
+        reference's ``@Cache`` hashes when the graph argument takes part in the cache key
+        (utils/abstract_models/abstract_embedding_model.py:91-95).  Two graphs with the same name
+        but different edges never share a digest."""
+        import hashlib
+
+        if getattr(self, "_digest", None) is None:
+            h = hashlib.sha256()
+            h.update(f"{self._n_nodes},{self._n_edges},{int(self._directed)}".encode())
+            for arr in (self.row_ptr, self.col_idx, self.cumw, self.node_type_ids,
+                        self.edge_type_ids):
+                h.update(b"|")
+                if arr is not None:
+                    h.update(np.ascontiguousarray(arr).view(np.uint8).data)
+            if self._named:
+                h.update("\x00".join(map(str, self._node_names)).encode())
+            self._digest = h.hexdigest()
+        return self._digest
 
     # ------------------------------------------------------------------ raw arrays
     @property

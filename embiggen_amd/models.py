@@ -201,7 +201,8 @@ class _WalkBasedModel:
             )
         return central, contextual, self.last_stats
 
-    def fit_transform_blocks(self, graph, comm, round_walks: int = 1 << 18):
+    def fit_transform_blocks(self, graph, comm, round_walks: int = 1 << 20, slices: int = 1,
+                             overlap: bool = True):
         """SkipGram over several GPUs, one process per GPU (``comm`` = ``distributed.TorchComm``
         under ``torch.distributed.run``): tables partitioned by node id, no row shared between
         GPUs (``distributed.BlockPartitionedTrainer``).  Every rank returns the full
@@ -221,28 +222,39 @@ class _WalkBasedModel:
         device = torch.cuda.current_device() if comm.world > 1 else self.device
         dev = torch.device("cuda", device)
         tp = self.train_params()
-        tp.window, tp.min_dist, tp.epochs = 1, 1, 1  # pair records: (centre, context)
+        L = self.walk_length
         with torch.cuda.device(dev):
+            ops.stats_reset(csr, device)
             trainer = BlockPartitionedTrainer(
                 csr, tp, self.embedding_size, self.padded_size, self.random_state,
-                self.init_scale(), comm, dev, scale_free=self.use_scale_free_distribution)
+                self.init_scale(), comm, dev, walk_length=L, window=self.window_size,
+                min_dist=self.min_distance, scale_free=self.use_scale_free_distribution,
+                slices=slices)
             wp = self.walk_params()
             walks_per_epoch = csr.get_number_of_unique_source_nodes() * self.iterations
+            round_walks = max(1, min(round_walks, -(-walks_per_epoch // comm.world)))
             stride = comm.world * round_walks
-            rounds = (walks_per_epoch + stride - 1) // stride
+            n_rounds = (walks_per_epoch + stride - 1) // stride
             lr = np.float32(self.learning_rate)
             start = time.perf_counter()
+            rounds = []
             for epoch in range(self.epochs):
-                for r in range(rounds):  # every rank joins every round (collectives inside)
-                    first = r * stride + comm.rank * round_walks
-                    n = max(0, min(round_walks, walks_per_epoch - first))
-                    if n:
-                        walks = ops.walks(csr, wp, self.random_state, epoch, first, n, device=device)
-                    else:  # nothing left for this rank: it still takes part in the exchange
-                        walks = torch.empty((0, self.walk_length), dtype=torch.int32, device=dev)
-                    trainer.train_round(walks, self.window_size, self.min_distance,
-                                        self.random_state, epoch, float(lr))
+                for r in range(n_rounds):  # every rank joins every round (collectives inside)
+                    first = r * stride
+                    mine = first + comm.rank * round_walks
+                    n = max(0, min(round_walks, walks_per_epoch - mine))
+
+                    def make(epoch=epoch, mine=mine, n=n):
+                        # ranks with fewer walks left pad with ended (sentinel) walks
+                        walks = torch.full((round_walks, L), -1, dtype=torch.int32, device=dev)
+                        if n:
+                            walks[:n] = ops.walks(csr, wp, self.random_state, epoch, mine, n,
+                                                  device=device)
+                        return walks
+
+                    rounds.append((make, self.random_state, epoch, float(lr), first))
                 lr = np.float32(lr * np.float32(self.learning_rate_decay))
+            trainer.run(rounds, overlap=overlap)
             central, contextual = trainer.gather_full()
             torch.cuda.synchronize(dev)
             self.last_seconds = time.perf_counter() - start
@@ -251,18 +263,23 @@ class _WalkBasedModel:
 
     def fit_transform(self, graph) -> List[np.ndarray]:
         """``[central, contextual]`` as freshly allocated C-contiguous float32 [N, d] arrays
-        (or ``np.memmap``s when the ``*_embedding_path`` arguments are given).  Inside an
-        initialised ``torch.distributed`` job with several ranks the fit runs on all their GPUs."""
+        (or ``np.memmap``s when the ``*_embedding_path`` arguments are given).
+
+        Multi-GPU is an explicit opt-in: set ``model.comm`` to a ``distributed.TorchComm`` (or
+        export ``GN2V_DISTRIBUTED=1`` inside an initialised ``torch.distributed`` job: the default
+        process group is then used) and every rank must make the call.  Models without a
+        multi-GPU path (CBOW, GloVe) always run on their own ``device``."""
         central = contextual = None
-        try:
+        comm = getattr(self, "comm", None)
+        if comm is None and os.environ.get("GN2V_DISTRIBUTED", "0") not in ("", "0"):
             import torch.distributed as dist
 
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 from .distributed import TorchComm
 
-                central, contextual = self.fit_transform_blocks(graph, TorchComm())
-        except ImportError:
-            pass
+                comm = TorchComm()
+        if comm is not None and comm.world > 1 and self.MODEL_ID == _lib.MODEL_SKIPGRAM:
+            central, contextual = self.fit_transform_blocks(graph, comm)
         if central is None:
             central, contextual, _ = self.fit_transform_device(graph)
         d = self.embedding_size

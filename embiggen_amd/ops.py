@@ -133,6 +133,104 @@ def init_table(n_rows: int, d: int, seed: int, table_id: int, scale: float, devi
     return t
 
 
+def init_table_rows(n_rows: int, d: int, seed: int, table_id: int, scale: float, first_row: int,
+                    row_stride: int, device: int = 0, ld: Optional[int] = None, out=None):
+    """Rows first_row, first_row + row_stride, ... of the table ``init_table`` would produce."""
+    torch = _torch()
+    ld = (d + 3) // 4 * 4 if ld is None else ld
+    dev = torch.device("cuda", device)
+    t = torch.empty((n_rows, ld), dtype=torch.float32, device=dev) if out is None else out
+    assert t.is_contiguous() and t.shape == (n_rows, ld)
+    _lib.check(_lib.lib().gn2v_init_table_rows(t.data_ptr(), n_rows, d, ld, seed, table_id, scale,
+                                               first_row, row_stride, _stream(dev)))
+    return t
+
+
+# ------------------------------------------------------------- block-partitioned SkipGram
+def block_plan(graph: CSRGraph, world: int, rank: int, parts: int, slices: int, walk_length: int,
+               window: int, min_dist: int = 1, record: int = 16, flags: int = 0, device: int = 0):
+    """A validated ``gn2v_block_plan`` (row_bits filled in by the library)."""
+    plan = _lib.BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, 0,
+                          flags)
+    _lib.check(_lib.lib().gn2v_block_plan_check(graph.device_graph(device).handle, C.byref(plan)))
+    return plan
+
+
+def block_pool(graph: CSRGraph, plan, device: int = 0):
+    """(pool int32 [n_edges], offsets int64 [cells + 1]): degree-proportional negative pools."""
+    torch = _torch()
+    dg = graph.device_graph(device)
+    dev = torch.device("cuda", device)
+    n_edges = graph.get_number_of_directed_edges()
+    need = C.c_uint64()
+    _lib.check(_lib.lib().gn2v_block_pool_temp_bytes(n_edges, C.byref(need)))
+    temp = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    pool = torch.empty(n_edges, dtype=torch.int32, device=dev)
+    offsets = torch.empty(plan.parts * plan.slices + 1, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().gn2v_block_pool(dg.handle, C.byref(plan), pool.data_ptr(),
+                                          offsets.data_ptr(), temp.data_ptr(), need.value,
+                                          _stream(dev)))
+    return pool, offsets
+
+
+def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
+                work=None, cell_offsets=None):
+    """Pass 1 of the pair extraction: (work, cell_offsets int64 [cells + 1]); the last offset is
+    the number of pairs this rank trains in the round."""
+    torch = _torch()
+    dev = walks_tensor.device
+    dg = graph.device_graph(dev.index or 0)
+    if work is None:
+        work = torch.empty(_lib.BLOCK_WORK_WORDS, dtype=torch.int64, device=dev)
+    if cell_offsets is None:
+        cell_offsets = torch.empty(plan.parts * plan.slices + 1, dtype=torch.int64, device=dev)
+    assert walks_tensor.is_contiguous()
+    _lib.check(_lib.lib().gn2v_block_count(
+        dg.handle, C.byref(plan), walks_tensor.data_ptr(), walks_tensor.shape[0], seed, epoch,
+        first_walk, work.data_ptr(), cell_offsets.data_ptr(), _stream(dev)))
+    return work, cell_offsets
+
+
+def block_extract_temp_bytes(n_pairs: int) -> int:
+    need = C.c_uint64()
+    _lib.check(_lib.lib().gn2v_block_extract_temp_bytes(n_pairs, C.byref(need)))
+    return need.value
+
+
+def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
+                  work, n_pairs: int, keys=None, vals=None, temp=None):
+    """Pass 2 + sort: (keys int32 [n_pairs], vals int32 [n_pairs]) sorted by key."""
+    torch = _torch()
+    dev = walks_tensor.device
+    dg = graph.device_graph(dev.index or 0)
+    if keys is None:
+        keys = torch.empty(n_pairs, dtype=torch.int32, device=dev)
+        vals = torch.empty(n_pairs, dtype=torch.int32, device=dev)
+    need = block_extract_temp_bytes(n_pairs)
+    if temp is None:
+        temp = torch.empty(need, dtype=torch.uint8, device=dev)
+    assert keys.numel() >= n_pairs and vals.numel() >= n_pairs and temp.numel() >= need
+    _lib.check(_lib.lib().gn2v_block_extract(
+        dg.handle, C.byref(plan), walks_tensor.data_ptr(), walks_tensor.shape[0], seed, epoch,
+        first_walk, work.data_ptr(), n_pairs, keys.data_ptr(), vals.data_ptr(), temp.data_ptr(),
+        temp.numel(), _stream(dev)))
+    return keys, vals
+
+
+def block_step(graph: CSRGraph, tp, plan, keys, vals, cell_offsets, pool, pool_offsets, central,
+               context, block_id: int, part: int, seed: int, epoch: int, lr: float):
+    """Train the pairs of one context part (``gn2v_block_step``; tables updated in place)."""
+    dev = central.device
+    dg = graph.device_graph(dev.index or 0)
+    assert central.is_contiguous() and context.is_contiguous()
+    assert central.shape[1] == tp.ld and context.shape[1] == tp.ld
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    io = _lib.BlockIO(ptr(keys), ptr(vals), ptr(cell_offsets), ptr(pool), ptr(pool_offsets),
+                      ptr(central), ptr(context), block_id, part)
+    _lib.check(_lib.lib().gn2v_block_step(dg.handle, C.byref(tp), C.byref(plan), C.byref(io),
+                                          seed, epoch, lr, _stream(dev)))
+
+
 def _step(fn_name: str, graph: CSRGraph, tp, walks_tensor, seed, epoch, first_walk, lr, central,
           contextual, neg_override=None):
     dev = central.device

@@ -297,8 +297,13 @@ class AbstractEmbeddingModel(AbstractModel):
 
     # ------------------------------------------------------------------ cache
     def _cache_path(self, graph, return_dataframe: bool) -> str:
+        # the reference's `@Cache {_hash}` also hashes the graph argument: the key depends on the
+        # graph's content, not just on its name (abstract_embedding_model.py:91-95)
+        digest = graph.content_digest() if hasattr(graph, "content_digest") else (
+            f"{graph.get_number_of_nodes()}:{graph.get_number_of_directed_edges()}")
         key = hashlib.sha256(
-            json.dumps({"model": self.consistent_hash(), "df": return_dataframe}).encode()
+            json.dumps({"model": self.consistent_hash(), "df": return_dataframe,
+                        "graph": digest}).encode()
         ).hexdigest()
         return os.path.join("embedding", self.model_name(), self.library_name(),
                             graph.get_name(), f"{key}.pkl.gz")

@@ -210,6 +210,84 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
                uint64_t seed, uint64_t max_walks_per_epoch, float *d_central,
                float *d_contextual, gn2v_stats *stats, void *stream);
 
+/* ---- Block-partitioned training: how the one call of the reference (node2vec.py:99) is spread
+ * over the GPUs of a node, one process per GPU.  The reference has no
+ * counterpart (ensmallen trains inside one process).  Nodes are striped over `world` ranks
+ * (centre c: rank c % world, row c / world of that rank's central partition) and over `parts`
+ * context parts (context x: part x % parts, row x / parts); the parts travel round the ranks, a
+ * pair (c, x) is trained on the owner of c while part x % parts is resident there, with
+ * negatives drawn inside the resident part.  `slices` stripes the rows of a part once more
+ * (slice = row % slices): with 8 slices every XCD of an MI355X owns the rows it updates.
+ * cell = part * slices + slice.  No row is ever held by two ranks. */
+typedef struct {
+    uint32_t world;       /* ranks = central partitions                                      */
+    uint32_t rank;
+    uint32_t parts;       /* context parts, a multiple of world                               */
+    uint32_t slices;      /* 1 .. 16                                                          */
+    uint32_t walk_length;
+    uint32_t window;      /* window_size                                                      */
+    uint32_t min_dist;    /* 0 = 1 (Walklets: = window)                                       */
+    uint32_t record;      /* consecutive sorted pairs a wavefront takes at a time; 0 = 16     */
+    uint32_t row_bits;    /* out (gn2v_block_plan_check): bits of the centre row in a key     */
+    uint32_t flags;       /* GN2V_TRAIN_DOWNSAMPLE: centres thinned while pairs are extracted */
+} gn2v_block_plan;
+
+/* validates the plan against the graph, fills row_bits and the defaults */
+int gn2v_block_plan_check(gn2v_graph *g, gn2v_block_plan *plan);
+
+/* rows first_row, first_row + row_stride, ... of the table gn2v_init_table would produce: a
+ * rank initialises its partitions without ever holding the whole table */
+int gn2v_init_table_rows(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
+                         uint32_t table_id, float scale, uint64_t first_row, uint64_t row_stride,
+                         void *stream);
+
+/* Negative pools: d_pool u32[n_edges] = the rows (x / parts) of the endpoints x of all directed
+ * edges grouped by cell (edge order kept inside a cell), d_pool_offsets u64[cells + 1]; a uniform
+ * draw from a cell's segment is degree proportional inside the cell
+ * (use_scale_free_distribution, node2vec_skipgram.py:101-102). */
+int gn2v_block_pool_temp_bytes(uint64_t n_edges, uint64_t *bytes);
+int gn2v_block_pool(gn2v_graph *g, const gn2v_block_plan *plan, uint32_t *d_pool,
+                    uint64_t *d_pool_offsets, void *d_temp, uint64_t temp_bytes, void *stream);
+
+/* Pairs of a round.  d_walks holds the walks of ALL ranks for the round (ids first_walk,
+ * first_walk + 1, ...; all-gathered); this rank keeps the pairs whose centre it owns.
+ * gn2v_block_count: pass 1, fills d_work u64[GN2V_BLOCK_WORK_WORDS] (private to the two calls)
+ * and d_cell_offsets u64[cells + 1] = where each cell starts in the sorted pair arrays; the last
+ * entry is the number of pairs (the caller reads it to size the buffers).
+ * gn2v_block_extract: pass 2 + one stable radix sort: d_keys u32[n_pairs] = cell << row_bits |
+ * centre row, d_vals u32[n_pairs] = context row, sorted by key, ties in walk / position / slot
+ * order (independent of the launch geometry). */
+#define GN2V_BLOCK_WORK_WORDS 9216
+int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
+                     uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                     uint64_t *d_work, uint64_t *d_cell_offsets, void *stream);
+int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes);
+int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
+                       uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                       const uint64_t *d_work, uint64_t n_pairs, uint32_t *d_keys,
+                       uint32_t *d_vals, void *d_temp, uint64_t temp_bytes, void *stream);
+
+typedef struct {
+    const uint32_t *d_keys;          /* sorted pairs of the round (gn2v_block_extract)         */
+    const uint32_t *d_vals;
+    const uint64_t *d_cell_offsets;  /* [cells + 1] (gn2v_block_count)                         */
+    const uint32_t *d_pool;          /* gn2v_block_pool; unused without GN2V_TRAIN_SCALE_FREE  */
+    const uint64_t *d_pool_offsets;
+    float *d_central;                /* this rank's central partition f32[rows][ld]            */
+    float *d_context;                /* context part `part`, resident here, f32[rows][ld]      */
+    uint64_t block_id;               /* RNG stream of the negatives: unique per (round, rank)  */
+    uint32_t part;
+} gn2v_block_io;
+
+/* The fused gather -> dot -> sigmoid -> scatter-add step over the pairs of one part: a wavefront
+ * takes `record` consecutive sorted pairs at a time (records visited in a golden-ratio stride
+ * order), keeps the centre row in registers while the centre does not change and applies
+ * [context, k negatives] per pair.  tp: d, ld, k, clip, flags (update mode as gn2v_sgns_step;
+ * sliced parts use plain stores for the contextual rows: they are exclusive to one XCD). */
+int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
+                    const gn2v_block_io *io, uint64_t seed, uint64_t epoch, float lr,
+                    void *stream);
+
 /* ---- GloVe: the third model of the reference's walk-based table (embedders/ensmallen_embedders/
  * node2vec.py:16-26 "Node2Vec GloVe" / "DeepWalk GloVe": models.GloVe; wrapper kwargs
  * node2vec_glove.py:8-30).  The fit = gn2v_walks -> gn2v_cooc_slots -> (sort + sum by key) ->

@@ -909,3 +909,238 @@ double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *log
     }
     return loss;
 }
+
+/* ---------------------------------------------------------------- block-partitioned SkipGram
+ * Sequential restatement of the engine's multi-GPU schedule (embiggen_amd/csrc/block_kernels.h;
+ * the reference has no counterpart: its call, node2vec.py:99, runs inside one process).  Nodes
+ * are striped over `world` ranks (centre c: rank c % world, row c / world) and over `parts`
+ * context parts (x: part x % parts, row x / parts), the rows of a part once more over `slices`
+ * (row % slices); cell = part * slices + slice.  A rank extracts, from the walks of all ranks of
+ * a round, the pairs whose centre it owns as (key = cell << row_bits | centre row, value = context
+ * row) in walk / position / slot order, sorts them stably by key, and trains one part at a time:
+ * per cell, implicit records of `record` consecutive sorted pairs visited in the stride order
+ * rec(t) = t * A mod R (A ~ R / golden ratio, coprime with R); inside a record every run of equal
+ * centre is one "centre" of Semantic S (copy of the central row, samples [context, k negatives]
+ * applied one after the other, gradient added at the end of the run).  Negative n of the pair at
+ * position p of its cell: pool entry (or uniform row of the cell) picked by
+ * draw(cell_key, p * k + n), cell_key = draw(mix64(epoch_key ^ TAG_BLOCK), block_id * 1024 + cell);
+ * skipped when it is the context or the centre itself. */
+
+#define O_TAG_BLOCK 0xB10C5EED0B10C5EDULL
+
+typedef struct {
+    uint32_t world, rank, parts, slices;
+    uint32_t walk_length, window, min_dist, record;
+    uint32_t row_bits;
+    uint32_t flags;
+} o_block_plan;
+
+uint32_t o_block_row_bits(uint64_t n_nodes, uint32_t world) {
+    uint64_t rows = (n_nodes + world - 1) / world;
+    uint32_t b = 0;
+    while ((1ULL << b) < rows) ++b;
+    return b;
+}
+
+/* pairs of this rank in walk / position / slot order; keys / vals may be NULL (count only) */
+uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t *walks,
+                         uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                         uint32_t *keys, uint32_t *vals) {
+    uint64_t n = 0, ekey = o_epoch_key(seed, epoch);
+    uint32_t L = p->walk_length, w = p->window, md = p->min_dist ? p->min_dist : 1;
+    o_train_params tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.flags = p->flags & O_FLAG_DOWNSAMPLE;
+    for (uint64_t b = 0; b < n_walks; ++b) {
+        const uint32_t *wk = walks + b * L;
+        uint32_t Le = effective_len(wk, L);
+        uint64_t wkey = o_draw(ekey, first_walk + b);
+        for (uint32_t i = 0; i < Le; ++i) {
+            uint32_t c = wk[i];
+            if (c % p->world != p->rank) continue;
+            if (!keep_centre(g, &tp, wkey, i, c)) continue;
+            for (uint32_t slot = 0; slot < 2 * w; ++slot) {
+                int64_t j = slot < w ? (int64_t)i - w + slot : (int64_t)i + 1 + (slot - w);
+                if (j < 0 || j >= (int64_t)Le) continue;
+                if (!is_context(i, (uint32_t)j, md)) continue;
+                uint32_t x = wk[j];
+                uint32_t row = x / p->parts;
+                uint32_t cell = (x % p->parts) * p->slices + row % p->slices;
+                if (keys) {
+                    keys[n] = (cell << p->row_bits) | (c / p->world);
+                    vals[n] = row;
+                }
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
+typedef struct {
+    uint32_t key, val;
+    uint64_t idx;
+} block_kv;
+
+static int cmp_block_kv(const void *a, const void *b) {
+    const block_kv *x = (const block_kv *)a, *y = (const block_kv *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* stable sort by key */
+void o_block_sort(uint32_t *keys, uint32_t *vals, uint64_t n) {
+    block_kv *kv = (block_kv *)malloc(sizeof(block_kv) * (n ? n : 1));
+    for (uint64_t i = 0; i < n; ++i) {
+        kv[i].key = keys[i];
+        kv[i].val = vals[i];
+        kv[i].idx = i;
+    }
+    qsort(kv, n, sizeof(block_kv), cmp_block_kv);
+    for (uint64_t i = 0; i < n; ++i) {
+        keys[i] = kv[i].key;
+        vals[i] = kv[i].val;
+    }
+    free(kv);
+}
+
+/* cell_offsets[c] = first sorted position whose cell is >= c, c = 0 .. cells */
+void o_block_cell_offsets(const uint32_t *keys, uint64_t n, uint32_t row_bits, uint32_t cells,
+                          uint64_t *offsets) {
+    uint64_t p = 0;
+    for (uint32_t c = 0; c <= cells; ++c) {
+        while (p < n && (row_bits >= 32 ? 0u : (keys[p] >> row_bits)) < c) ++p;
+        offsets[c] = c == cells ? n : p;
+    }
+}
+
+/* negative pools: rows of the endpoints of all directed edges grouped by cell, edge order kept */
+void o_block_pool(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t *pool,
+                  uint64_t *offsets) {
+    uint32_t cells = parts * slices;
+    uint64_t *count = (uint64_t *)calloc(cells + 1, sizeof(uint64_t));
+    for (uint64_t e = 0; e < g->n_edges; ++e) {
+        uint32_t x = g->col_idx[e], row = x / parts;
+        count[(x % parts) * slices + row % slices]++;
+    }
+    uint64_t run = 0;
+    for (uint32_t c = 0; c < cells; ++c) {
+        offsets[c] = run;
+        run += count[c];
+        count[c] = offsets[c];
+    }
+    offsets[cells] = run;
+    for (uint64_t e = 0; e < g->n_edges; ++e) {
+        uint32_t x = g->col_idx[e], row = x / parts;
+        pool[count[(x % parts) * slices + row % slices]++] = row;
+    }
+    free(count);
+}
+
+static uint64_t gcd_u64(uint64_t a, uint64_t b) {
+    while (b) {
+        uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+uint64_t o_block_record_stride(uint64_t R) {
+    if (R < 3) return 1;
+    uint64_t s = (uint64_t)((double)R * 0.6180339887498949);
+    if (s < 1) s = 1;
+    while (gcd_u64(s, R) != 1) ++s;
+    return s % R;
+}
+
+static inline uint64_t stripe_count(uint64_t n, uint64_t first, uint64_t stride) {
+    return n > first ? (n - first + stride - 1) / stride : 0;
+}
+
+/* one part of one round, strictly sequential; returns the pairs trained */
+uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_plan *p,
+                      const uint32_t *keys, const uint32_t *vals, const uint64_t *cell_offsets,
+                      const uint32_t *pool, const uint64_t *pool_offsets, float *central,
+                      float *context, uint64_t block_id, uint32_t part, uint64_t seed,
+                      uint64_t epoch, float lr) {
+    uint32_t d = tp->d, ld = tp->ld, k = tp->k, C = p->record ? p->record : 16;
+    uint32_t rowmask = p->row_bits >= 32 ? 0xFFFFFFFFu : ((1u << p->row_bits) - 1u);
+    uint64_t ekey = o_epoch_key(seed, epoch), trained = 0;
+    uint64_t part_rows = stripe_count(g->n_nodes, part, p->parts);
+    float *u = (float *)malloc(sizeof(float) * d), *gacc = (float *)malloc(sizeof(float) * d);
+    for (uint32_t slice = 0; slice < p->slices; ++slice) {
+        uint32_t cell = part * p->slices + slice;
+        uint64_t lo = cell_offsets[cell], hi = cell_offsets[cell + 1];
+        if (hi == lo) continue;
+        uint64_t R = (hi - lo + C - 1) / C, A = o_block_record_stride(R);
+        uint64_t ckey = o_draw(o_mix64(ekey ^ O_TAG_BLOCK), block_id * 1024 + cell);
+        int use_pool = (tp->flags & O_FLAG_SCALE_FREE) && pool;
+        uint64_t pool_lo = use_pool ? pool_offsets[cell] : 0;
+        uint64_t pool_n = use_pool ? pool_offsets[cell + 1] - pool_lo
+                                   : stripe_count(part_rows, slice, p->slices);
+        if (pool_n == 0) continue;
+        for (uint64_t t = 0; t < R; ++t) {
+            uint64_t rec = (t * A) % R, p0 = lo + rec * C;
+            uint32_t n = (uint32_t)(hi - p0 < C ? hi - p0 : C);
+            uint32_t r0 = 0;
+            while (r0 < n) {
+                uint32_t crow = keys[p0 + r0] & rowmask, r1 = r0 + 1;
+                while (r1 < n && (keys[p0 + r1] & rowmask) == crow) ++r1;
+                uint64_t cgid = (uint64_t)crow * p->world + p->rank;
+                float lrc = centre_lr(g, tp, lr, (uint32_t)cgid);
+                float *cptr = central + (uint64_t)crow * ld;
+                memcpy(u, cptr, d * sizeof(float));
+                memset(gacc, 0, d * sizeof(float));
+                for (uint32_t pr = r0; pr < r1; ++pr) {
+                    uint32_t xrow = vals[p0 + pr];
+                    for (uint32_t s = 0; s <= k; ++s) {
+                        uint32_t row = xrow;
+                        float label = 1.0f;
+                        if (s) {
+                            uint64_t r = o_draw(ckey, (p0 - lo + pr) * k + (s - 1));
+                            row = use_pool ? pool[pool_lo + mulhi64(r, pool_n)]
+                                           : slice + p->slices * (uint32_t)mulhi64(r, pool_n);
+                            label = 0.0f;
+                            if (row == xrow || (uint64_t)row * p->parts + part == cgid) continue;
+                        }
+                        float *v = context + (uint64_t)row * ld;
+                        float dot = 0.0f;
+                        for (uint32_t x = 0; x < d; ++x) dot += u[x] * v[x];
+                        if (dot > tp->clip) dot = tp->clip;
+                        if (dot < -tp->clip) dot = -tp->clip;
+                        float var = (label - sigmoidf(dot)) * lrc;
+                        for (uint32_t x = 0; x < d; ++x) {
+                            gacc[x] += var * v[x];
+                            v[x] += var * u[x];
+                        }
+                    }
+                }
+                for (uint32_t x = 0; x < d; ++x) cptr[x] += gacc[x];
+                trained += r1 - r0;
+                r0 = r1;
+            }
+        }
+    }
+    free(u);
+    free(gacc);
+    return trained;
+}
+
+/* rows first_row, first_row + stride, ... of the table o_init_table would produce */
+void o_init_table_rows(float *t, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
+                       uint32_t table_id, float scale, uint64_t first_row, uint64_t row_stride) {
+    uint64_t key = o_mix64(seed ^ (O_TAG_INIT + table_id));
+    for (uint64_t r = 0; r < n_rows; ++r) {
+        uint64_t gr = first_row + r * row_stride;
+        for (uint32_t c = 0; c < ld; ++c) {
+            float v = 0.0f;
+            if (c < d) {
+                uint64_t h = o_draw(key, gr * d + c);
+                float uu = (float)(h >> 40) * (1.0f / 16777216.0f);
+                v = (2.0f * uu - 1.0f) * scale;
+            }
+            t[r * ld + c] = v;
+        }
+    }
+}

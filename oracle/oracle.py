@@ -316,3 +316,81 @@ def glove_loss(rows, cols, logx, fx, central, contextual, bias_c, bias_x, d: int
     return lib().o_glove_loss(_ptr(rows), _ptr(cols), _ptr(logx), _ptr(fx), C.c_uint64(len(rows)),
                               _ptr(central), _ptr(contextual), _ptr(bias_c), _ptr(bias_x),
                               C.c_uint32(d), C.c_uint32(central.shape[1]))
+
+
+# ------------------------------------------------------------- block-partitioned SkipGram
+class BlockPlan(C.Structure):
+    """Mirror of gn2v_block_plan (include/gn2v.h)."""
+
+    _fields_ = [(name, C.c_uint32) for name in (
+        "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
+        "row_bits", "flags")]
+
+
+def block_plan(n_nodes: int, world: int, rank: int, parts: int, slices: int, walk_length: int,
+               window: int, min_dist: int = 1, record: int = 16, flags: int = 0) -> BlockPlan:
+    lib().o_block_row_bits.restype = C.c_uint32
+    bits = lib().o_block_row_bits(C.c_uint64(n_nodes), C.c_uint32(world))
+    return BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, bits,
+                     flags)
+
+
+def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: int,
+                  first_walk: int, sort: bool = True):
+    """(keys, vals, cell_offsets): the pairs of the walks whose centre `plan.rank` owns, sorted
+    stably by key = cell << row_bits | centre row (``sort=False``: extraction order)."""
+    walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
+    n_walks = walks_arr.shape[0]
+    L = lib()
+    L.o_block_extract.restype = C.c_uint64
+    args = (C.byref(g.c), C.byref(plan), _ptr(walks_arr), C.c_uint64(n_walks), C.c_uint64(seed),
+            C.c_uint64(epoch), C.c_uint64(first_walk))
+    n = int(L.o_block_extract(*args, None, None))
+    keys, vals = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+    if n:
+        L.o_block_extract(*args, _ptr(keys), _ptr(vals))
+        if sort:
+            L.o_block_sort(_ptr(keys), _ptr(vals), C.c_uint64(n))
+    cells = plan.parts * plan.slices
+    offsets = np.zeros(cells + 1, dtype=np.uint64)
+    if sort:
+        L.o_block_cell_offsets(_ptr(keys), C.c_uint64(n), C.c_uint32(plan.row_bits),
+                               C.c_uint32(cells), _ptr(offsets))
+    return keys, vals, offsets
+
+
+def block_pool(g: OracleGraph, parts: int, slices: int):
+    """(pool rows u32[n_edges] grouped by cell, offsets u64[cells + 1])."""
+    pool = np.empty(g.n_edges, dtype=np.uint32)
+    offsets = np.empty(parts * slices + 1, dtype=np.uint64)
+    lib().o_block_pool(C.byref(g.c), C.c_uint32(parts), C.c_uint32(slices), _ptr(pool),
+                       _ptr(offsets))
+    return pool, offsets
+
+
+def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, keys, vals, cell_offsets, pool,
+               pool_offsets, central, context, block_id: int, part: int, seed: int, epoch: int,
+               lr: float) -> int:
+    """Sequential training of one part (in place on ``central`` / ``context``)."""
+    for a, t in ((keys, np.uint32), (vals, np.uint32), (cell_offsets, np.uint64),
+                 (central, np.float32), (context, np.float32)):
+        assert a.dtype == t and a.flags.c_contiguous
+    lib().o_block_step.restype = C.c_uint64
+    return int(lib().o_block_step(
+        C.byref(g.c), C.byref(tp), C.byref(plan), _ptr(keys), _ptr(vals), _ptr(cell_offsets),
+        _ptr(pool), _ptr(pool_offsets), _ptr(central), _ptr(context), C.c_uint64(block_id),
+        C.c_uint32(part), C.c_uint64(seed), C.c_uint64(epoch), C.c_float(lr)))
+
+
+def init_table_rows(n_rows: int, d: int, ld: int, seed: int, table_id: int, scale: float,
+                    first_row: int, row_stride: int):
+    t = np.empty((n_rows, ld), dtype=np.float32)
+    lib().o_init_table_rows(_ptr(t), C.c_uint64(n_rows), C.c_uint32(d), C.c_uint32(ld),
+                            C.c_uint64(seed), C.c_uint32(table_id), C.c_float(scale),
+                            C.c_uint64(first_row), C.c_uint64(row_stride))
+    return t
+
+
+def block_record_stride(n_records: int) -> int:
+    lib().o_block_record_stride.restype = C.c_uint64
+    return int(lib().o_block_record_stride(C.c_uint64(n_records)))

@@ -20,28 +20,31 @@ dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.de
 
 g = E.karate_club()
 D, K = 16, 4
-tp = ops.train_params(0, D, K, 1, flags=1 | _lib.TRAIN_DETERMINISTIC)
+tp = ops.train_params(0, D, K, 3, flags=1 | _lib.TRAIN_DETERMINISTIC)
 wp = ops.walk_params(20, 2, 0.25, 4.0)
 
 
 def run(comm):
-    tr = BlockPartitionedTrainer(g, tp, D, D, 42, D ** -0.5, comm, "cuda:0")
+    tr = BlockPartitionedTrainer(g, tp, D, D, 42, D ** -0.5, comm, "cuda:0", walk_length=20,
+                                 window=3, parts=2)
     for r in range(2):
         walks = ops.walks(g, wp, 42, 0, r * 34, 34)
-        tr.train_round(walks, 3, 1, 42, 0, 0.02)
+        tr.train_round(walks, 42, 0, 0.02, r * 34)
     return [t.cpu().numpy() for t in tr.gather_full()], tr.last_round
 
 
-(a0, a1), info = run(TorchComm())
+comm = TorchComm()
+assert comm.backend == "nccl" and comm.world == 1
+(a0, a1), info = run(comm)
 (b0, b1), _ = run(LoopbackComm())
 # raw collectives on device tensors, the shapes the trainer uses for world > 1
-comm = TorchComm()
+walks = torch.arange(40, dtype=torch.int32, device="cuda").reshape(2, 20)
+assert torch.equal(comm.all_gather(walks), walks)
 rows = torch.arange(12, dtype=torch.float32, device="cuda").reshape(4, 3)
-assert torch.equal(comm.exchange_rows(rows, [4], [4]), rows)
-pairs = torch.arange(10, dtype=torch.int32, device="cuda").reshape(5, 2)
-assert torch.equal(comm.exchange_rows(pairs, [5], [5]), pairs)
-counts = torch.tensor([7], dtype=torch.int64, device="cuda")
-assert torch.equal(comm.exchange_counts(counts), counts)
+back = torch.empty_like(rows)
+comm.sendrecv_start(rows, 0, back, 0).wait()
+torch.cuda.synchronize()
+assert torch.equal(back, rows)
 dist.barrier()
 dist.destroy_process_group()
 diff = max(np.abs(a0 - b0).max(), np.abs(a1 - b1).max())

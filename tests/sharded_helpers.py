@@ -11,36 +11,41 @@ from oracle import oracle as O
 class ThreadComm:
     """W ranks as W threads of one process; exchange through shared slots."""
 
+    backend = "threads"
+
     class Shared:
         def __init__(self, world):
             self.world = world
             self.barrier = threading.Barrier(world)
             self.slots = [None] * world
+            self.mail = {}
 
     def __init__(self, shared, rank):
         self.shared, self.rank, self.world = shared, rank, shared.world
 
-    def exchange_counts(self, counts):
+    def all_gather(self, tensor):
         s = self.shared
-        s.slots[self.rank] = counts
+        if tensor.is_cuda:  # the other "ranks" read it from their own streams
+            torch.cuda.current_stream(tensor.device).synchronize()
+        s.slots[self.rank] = tensor
         s.barrier.wait()
-        out = torch.stack([s.slots[r][self.rank] for r in range(self.world)])
+        out = torch.cat([s.slots[r] for r in range(self.world)]).clone()
         s.barrier.wait()
         return out
 
-    def exchange_rows(self, rows, send_counts, recv_counts):
-        s = self.shared
-        s.slots[self.rank] = (rows, list(send_counts))
-        s.barrier.wait()
-        pieces = []
-        for r in range(self.world):
-            src, counts = s.slots[r]
-            start = sum(counts[: self.rank])
-            pieces.append(src[start:start + counts[self.rank]])
-            assert counts[self.rank] == recv_counts[r]
-        out = torch.cat(pieces).clone()
-        s.barrier.wait()
-        return out
+    def sendrecv_start(self, send, dst, recv, src):
+        s, rank = self.shared, self.rank
+        s.mail[(rank, dst)] = send.clone()
+        if send.is_cuda:
+            torch.cuda.current_stream(send.device).synchronize()
+
+        class Handle:
+            def wait(self_inner):
+                s.barrier.wait()
+                recv.copy_(s.mail[(src, rank)])
+                s.barrier.wait()
+
+        return Handle()
 
 
 def run_ranks(world, fn):
@@ -65,30 +70,48 @@ def run_ranks(world, fn):
     return results
 
 
-def host_init_fn(n_nodes, d, ld, seed, scale):
-    def init_fn(table_id):
-        return torch.from_numpy(O.init_table(n_nodes, d, ld, seed, table_id, scale))
+class OracleBlockBackend:
+    """CPU stand-in for embiggen_amd.distributed.GpuBlockBackend: the same five operations done
+    by the oracle on numpy arrays behind CPU torch tensors (tests only)."""
 
-    return init_fn
+    def __init__(self, graph):
+        self.graph = graph
+        self.og = O.OracleGraph(graph.row_ptr, graph.col_idx)
 
+    def init_rows(self, n_rows, d, ld, seed, table_id, scale, first_row, stride, out=None):
+        t = torch.from_numpy(O.init_table_rows(n_rows, d, ld, seed, table_id, scale, first_row,
+                                               stride))
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
 
-def oracle_block_compute(oracle_graph, otp, trainer):
-    """compute callable for BlockPartitionedTrainer backed by the oracle's pair-mode step."""
+    def empty_rows(self, n_rows, ld):
+        return torch.zeros((n_rows, ld), dtype=torch.float32)
 
-    def compute(pairs, rows, part, seed, epoch, first_pair, lr):
-        host = [np.ascontiguousarray(t.detach().cpu().numpy())
-                for t in (trainer.central, trainer.context)]
-        tp = type(otp).from_buffer_copy(otp)
-        tp.window = pairs.shape[1] - 1  # (centre, context) pairs or centre records
-        O.train_walks_ex(
-            oracle_graph, tp, pairs.cpu().numpy().view(np.uint32), seed, epoch, first_pair, lr,
-            host[0], host[1], walk_rows=rows.cpu().numpy().view(np.uint32),
-            neg_pool=trainer.pools[part].cpu().numpy().view(np.uint32),
-            neg_id_mul=trainer.comm.world, neg_id_add=part, pair_mode=True)
-        trainer.central.copy_(torch.from_numpy(host[0]))
-        trainer.context.copy_(torch.from_numpy(host[1]))
+    def plan(self, world, rank, parts, slices, walk_length, window, min_dist, record, flags):
+        return O.block_plan(self.graph.get_number_of_nodes(), world, rank, parts, slices,
+                            walk_length, window, min_dist, record, flags)
 
-    return compute
+    def pools(self, plan):
+        return O.block_pool(self.og, plan.parts, plan.slices)
+
+    def prepare(self, plan, walks_all, seed, epoch, first_walk):
+        walks = walks_all.cpu().numpy().view(np.uint32)
+        keys, vals, offsets = O.block_extract(self.og, plan, walks, seed, epoch, first_walk)
+        return keys, vals, offsets, len(keys)
+
+    def step(self, tp, plan, prepared, pool, pool_offsets, central, context, block_id, part, seed,
+             epoch, lr):
+        keys, vals, offsets, n_pairs = prepared
+        if n_pairs == 0:
+            return
+        c = np.ascontiguousarray(central.numpy())
+        x = np.ascontiguousarray(context.numpy())
+        O.block_step(self.og, tp, plan, keys, vals, offsets, pool, pool_offsets, c, x, block_id,
+                     part, seed, epoch, lr)
+        central.copy_(torch.from_numpy(c))
+        context.copy_(torch.from_numpy(x))
 
 
 def link_auc_device(g, c, x, gen, n_eval=100000):
@@ -106,20 +129,3 @@ def link_auc_device(g, c, x, gen, n_eval=100000):
     ranks = torch.empty_like(s)
     ranks[torch.argsort(s)] = torch.arange(1, s.numel() + 1, device="cuda", dtype=s.dtype)
     return float((ranks[:n_eval].sum() - n_eval * (n_eval + 1) / 2) / (n_eval * n_eval))
-
-
-def host_walk_pair_blocks(walks_tensor, window, min_dist, world, salt):
-    """CPU stand-in for ops.walk_pair_blocks in its grouping mode (salt = 2^64 - 1): the same
-    slots and keys (block << 32 | centre, INT64_MAX for unused slots), built from the oracle's
-    co-occurrence slots (tests only)."""
-    assert salt == 2 ** 64 - 1
-    walks = walks_tensor.cpu().numpy().view(np.uint32)
-    keys, _ = O.cooc_slots(walks, window, min_dist)
-    used = keys != O.COOC_UNUSED
-    c, x = (keys >> np.uint64(32)).astype(np.int64), (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
-    slots = np.full((len(keys), 2), -1, dtype=np.int32)
-    slots[used, 0] = c[used].astype(np.uint32).view(np.int32)
-    slots[used, 1] = x[used].astype(np.uint32).view(np.int32)
-    out = np.full(len(keys), 0x7FFFFFFFFFFFFFFF, dtype=np.int64)
-    out[used] = (((c[used] % world) * world + x[used] % world) << 32) | c[used]
-    return torch.from_numpy(slots), torch.from_numpy(out)

@@ -1,6 +1,7 @@
-"""Block-partitioned multi-GPU trainer (embiggen_amd/distributed.py), host logic on CPU with the
-oracle's pair-mode step as compute stand-in (tests only): pair routing, block bucketing, ring
-rotation of the context partitions and their mapping onto torch.distributed (2 gloo ranks)."""
+"""Block-partitioned multi-GPU trainer (embiggen_amd/distributed.py) on CPU: the oracle's
+restatement of the schedule (oracle/gn2v_oracle.c, "block-partitioned SkipGram") as compute
+stand-in (tests only), the host logic -- walk all-gather, part ownership, half-partition rotation,
+final gather -- on threads and on torch.distributed (2 and 3 gloo ranks)."""
 import os
 import sys
 
@@ -11,81 +12,171 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import embiggen_amd as E
-from embiggen_amd.distributed import BlockPartitionedTrainer, LoopbackComm, TorchComm
+from embiggen_amd.distributed import (BlockPartitionedTrainer, LoopbackComm, TorchComm,
+                                      stripe_rows)
 from oracle import oracle as O
-from sharded_helpers import host_init_fn, oracle_block_compute, run_ranks
+from sharded_helpers import OracleBlockBackend, run_ranks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D, K, W, L = 8, 4, 3, 14
 
 
-def _train(comm, rounds=2, walks_per_round=9):
-    g = E.karate_club()
+def _graph(nodes=34):
+    if nodes == 34:
+        return E.karate_club()
+    s, d = O.ba_edges(nodes, 3, 9)
+    return E.CSRGraph.from_edge_list(s, d, number_of_nodes=nodes)
+
+
+def _otp(flags=1):
+    return O.TrainParams(0, D, D, 1, K, W, 0.02, 0.9, 6.0, flags, D ** -0.5)
+
+
+def _train(comm, rounds=2, walks_per_round=9, nodes=34, slices=1, parts=None, record=4):
+    g = _graph(nodes)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    otp = O.TrainParams(0, D, D, 1, K, 1, 0.02, 0.9, 6.0, 1, D ** -0.5)
-    tr = BlockPartitionedTrainer(g, otp, D, D, 42, D ** -0.5, comm, "cpu",
-                                 init_fn=host_init_fn(34, D, D, 42, D ** -0.5))
-    tr.compute = oracle_block_compute(og, otp, tr)
+    tr = BlockPartitionedTrainer(g, _otp(), D, D, 42, D ** -0.5, comm, "cpu", walk_length=L,
+                                 window=W, backend=OracleBlockBackend(g), slices=slices,
+                                 parts=parts, record=record)
     wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
+    trained = 0
     for r in range(rounds):
-        first = (r * comm.world + comm.rank) * walks_per_round
-        pairs = O.walk_pairs(O.walks(og, wp, 42, 0, first, walks_per_round), W)
-        tr.train_round(None, W, 1, 42, 0, 0.02, pairs=torch.from_numpy(pairs.view(np.int32)))
-        assert tr.resident == comm.rank  # every partition is home again after a round
-    return [t.numpy().copy() for t in tr.gather_full()], tr.last_round
+        first = r * comm.world * walks_per_round
+        mine = O.walks(og, wp, 42, 0, first + comm.rank * walks_per_round, walks_per_round)
+        tr.train_round(torch.from_numpy(mine.view(np.int32)), 42, 0, 0.02, first)
+        trained += tr.last_round["pairs_trained"]
+    return [t.numpy().copy() for t in tr.gather_full()], trained, sorted(tr.held)
 
 
-def test_pair_extraction_counts():
-    g = E.karate_club()
+# ------------------------------------------------------------------ the restated schedule itself
+@pytest.mark.parametrize("world,parts,slices", [(1, 1, 1), (2, 4, 1), (3, 6, 2), (4, 8, 8)])
+def test_extraction_partitions_the_pairs_of_the_walks(world, parts, slices):
+    g = _graph(97)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    walks = O.walks(og, O.WalkParams(L, 1, 1.0, 1.0, 100, 0), 1, 0, 0, 5)
-    pairs = O.walk_pairs(walks, W)
-    assert pairs.shape == (5 * (2 * W * L - W * (W + 1)), 2)
-    assert pairs[0].tolist() == [walks[0, 0], walks[0, 1]]
-    assert O.walk_pairs(walks, W, W).shape[0] == 5 * 2 * (L - W)
-    cut = walks.copy()
-    cut[0, 4:] = O.SENTINEL
-    assert O.walk_pairs(cut, W).shape[0] == 4 * (2 * W * L - W * (W + 1)) + (2 * 3 * 4 - 3 * 4)
+    walks = O.walks(og, O.WalkParams(L, 2, 0.5, 2.0, 100, 0), 3, 0, 0, 40)
+    walks[::7, 9:] = O.SENTINEL  # walks that ended early
+    want = O.walk_pairs(walks, W)
+    got = []
+    for rank in range(world):
+        plan = O.block_plan(97, world, rank, parts, slices, L, W, 1, 4)
+        keys, vals, offsets = O.block_extract(og, plan, walks, 3, 0, 0)
+        raw_k, raw_v, _ = O.block_extract(og, plan, walks, 3, 0, 0, sort=False)
+        assert (np.diff(keys.astype(np.int64)) >= 0).all()
+        # stable: pairs with equal keys keep the extraction (walk / position / slot) order
+        order = np.argsort(raw_k, kind="stable")
+        assert np.array_equal(keys, raw_k[order]) and np.array_equal(vals, raw_v[order])
+        cell = keys >> plan.row_bits if plan.row_bits < 32 else np.zeros_like(keys)
+        crow = keys & ((1 << plan.row_bits) - 1)
+        assert offsets[-1] == len(keys)
+        for c in range(parts * slices):
+            assert (cell[int(offsets[c]):int(offsets[c + 1])] == c).all()
+        part, slc = cell // slices, cell % slices
+        assert (vals % slices == slc).all()
+        centre = crow.astype(np.int64) * world + rank
+        context = vals.astype(np.int64) * parts + part
+        got.append(np.stack([centre, context], 1))
+    got = np.concatenate(got)
+    as_sorted = lambda p: np.sort(p[:, 0].astype(np.int64) * 1000 + p[:, 1])  # noqa: E731
+    assert np.array_equal(as_sorted(got), as_sorted(want))
 
 
-def _salt(n, seed, rnd):
-    """The trainer's in-bucket shuffle key, restated with numpy."""
-    idx = np.arange(n, dtype=np.int64)
-    salt = (idx * 0x3C6EF35F + (seed * 0x19660D + rnd * 0x2545F491 + 1)) & 0x7FFFFFFF
-    salt = ((salt ^ (salt >> 15)) * 0x2C1B3C6D) & 0x7FFFFFFF
-    salt = ((salt ^ (salt >> 12)) * 0x297A2D39) & 0x7FFFFFFF
-    return salt ^ (salt >> 15)
-
-
-def test_world_one_is_the_shuffled_pair_list_trained_in_order():
-    (c, x), info = _train(LoopbackComm())
-    g = E.karate_club()
+def test_pools_are_degree_proportional_inside_a_cell():
+    g = _graph(97)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    otp = O.TrainParams(0, D, D, 1, K, 1, 0.02, 0.9, 6.0, 1, D ** -0.5)
+    pool, offsets = O.block_pool(og, 4, 2)
+    assert offsets[-1] == og.n_edges
+    indeg = np.bincount(og.col_idx, minlength=97)
+    for cell in range(8):
+        part, slc = cell // 2, cell % 2
+        rows = pool[int(offsets[cell]):int(offsets[cell + 1])]
+        assert (rows % 2 == slc).all()
+        nodes = rows.astype(np.int64) * 4 + part
+        assert np.array_equal(np.bincount(nodes, minlength=97), np.where(
+            (np.arange(97) % 4 == part) & ((np.arange(97) // 4) % 2 == slc), indeg, 0))
+        # edge order is kept inside a cell
+        sel = og.col_idx[(og.col_idx % 4 == part) & ((og.col_idx // 4) % 2 == slc)]
+        assert np.array_equal(nodes, sel)
+
+
+def test_record_visiting_order_is_a_permutation():
+    for R in (1, 2, 3, 10, 97, 1000, 4096, 65537):
+        A = O.block_record_stride(R)
+        assert sorted((t * A) % R for t in range(R)) == list(range(R))
+        if R > 10:  # consecutive tickets land far apart
+            assert min(A, R - A) > R // 4
+
+
+def test_step_properties_zero_lr_counts_and_untouched_rows():
+    g = _graph(97)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    walks = O.walks(og, O.WalkParams(L, 1, 1.0, 1.0, 100, 0), 5, 0, 0, 30)
+    plan = O.block_plan(97, 1, 0, 2, 1, L, W, 1, 4)
+    keys, vals, offsets = O.block_extract(og, plan, walks, 5, 0, 0)
+    pool, pool_offsets = O.block_pool(og, 2, 1)
+    c = O.init_table_rows(97, D, D, 5, 0, 0.3, 0, 1)
+    assert np.array_equal(c, O.init_table(97, D, D, 5, 0, 0.3))
+    parts = [O.init_table_rows(stripe_rows(97, p, 2), D, D, 5, 1, 0.3, p, 2) for p in range(2)]
+    full = O.init_table(97, D, D, 5, 1, 0.3)
+    assert np.array_equal(parts[0], full[0::2]) and np.array_equal(parts[1], full[1::2])
+    c0, x0 = c.copy(), [p.copy() for p in parts]
+    n0 = O.block_step(og, _otp(), plan, keys, vals, offsets, pool, pool_offsets, c, parts[0], 0, 0,
+                      5, 0, 0.0)
+    assert np.array_equal(c, c0) and np.array_equal(parts[0], x0[0])  # lr = 0: identity
+    n1 = sum(O.block_step(og, _otp(), plan, keys, vals, offsets, pool, pool_offsets, c, parts[p],
+                          0, p, 5, 0, 0.05) for p in range(2))
+    assert n0 == offsets[1] and n1 == len(keys) == len(O.walk_pairs(walks, W))
+    centres = np.unique(keys & ((1 << plan.row_bits) - 1))
+    untouched = np.setdiff1d(np.arange(97), centres)
+    assert np.array_equal(c[untouched], c0[untouched]) and not np.array_equal(c, c0)
+    for p in range(2):  # contextual rows move only for contexts and pool (edge endpoint) rows
+        seg = slice(int(offsets[p]), int(offsets[p + 1]))
+        may = np.union1d(vals[seg], pool[int(pool_offsets[p]):int(pool_offsets[p + 1])])
+        rest = np.setdiff1d(np.arange(len(parts[p])), may)
+        assert np.array_equal(parts[p][rest], x0[p][rest])
+
+
+# ------------------------------------------------------------------ trainer host logic
+def test_world_one_trainer_is_the_plain_sequence_of_block_steps():
+    (c, x), trained, held = _train(LoopbackComm(), parts=2)
+    g = _graph()
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    plan = O.block_plan(34, 1, 0, 2, 1, L, W, 1, 4)
+    pool, pool_offsets = O.block_pool(og, 2, 1)
     rc = O.init_table(34, D, D, 42, 0, D ** -0.5)
     rx = O.init_table(34, D, D, 42, 1, D ** -0.5)
+    parts = [np.ascontiguousarray(rx[p::2]) for p in range(2)]
     wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
+    total = 0
     for r in range(2):
-        pairs = O.walk_pairs(O.walks(og, wp, 42, 0, r * 9, 9), W)
-        salt = _salt(len(pairs), 42, r)
-        assert len(np.unique(salt)) > 0.99 * len(pairs)
-        pairs = pairs[np.argsort(salt, kind="stable")]
-        O.train_walks_ex(og, otp, pairs, 42, 0, r << 32, 0.02, rc, rx, neg_pool=g.col_idx,
-                         neg_id_mul=1, neg_id_add=0, pair_mode=True)
+        walks = O.walks(og, wp, 42, 0, r * 9, 9)
+        keys, vals, offsets = O.block_extract(og, plan, walks, 42, 0, r * 9)
+        for p in range(2):
+            total += O.block_step(og, _otp(), plan, keys, vals, offsets, pool, pool_offsets, rc,
+                                  parts[p], r, p, 42, 0, 0.02)
+    rx[0::2], rx[1::2] = parts
     assert np.array_equal(c, rc) and np.array_equal(x, rx)
-    assert info["pairs_generated"] == info["pairs_trained"] == 9 * (2 * W * L - W * (W + 1))
+    assert trained == total == 2 * 9 * (2 * W * L - W * (W + 1)) and held == [0, 1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_blocks_cover_every_pair_once_and_rows_are_never_shared(world):
-    sims = run_ranks(world, lambda comm: _train(comm, rounds=1))
-    total = sum(s[1]["pairs_trained"] for s in sims)
-    assert total == sum(s[1]["pairs_generated"] for s in sims)
-    for r, ((c, x), info) in enumerate(sims):
-        assert sum(info["block_sizes"]) == info["pairs_trained"]
-    # all ranks assemble identical full tables
+@pytest.mark.parametrize("world,nodes", [(2, 34), (3, 34), (4, 97)])
+def test_ranks_cover_every_pair_once_and_assemble_identical_tables(world, nodes):
+    sims = run_ranks(world, lambda comm: _train(comm, rounds=1, nodes=nodes))
+    assert sum(s[1] for s in sims) == world * 9 * (2 * W * L - W * (W + 1))
     for s in sims[1:]:
         assert np.array_equal(s[0][0], sims[0][0][0]) and np.array_equal(s[0][1], sims[0][0][1])
+    # after `parts` episodes rank r holds parts 2r - 1 and 2r (one hop from home)
+    for r, s in enumerate(sims):
+        assert s[2] == sorted([(2 * r - 1) % (2 * world), (2 * r) % (2 * world)])
+    init = O.init_table(nodes, D, D, 42, 1, D ** -0.5)
+    assert np.abs(sims[0][0][1] - init).max() > 1e-3
+    assert np.isfinite(sims[0][0][0]).all() and np.isfinite(sims[0][0][1]).all()
+
+
+def test_slices_change_the_negative_cells_not_the_bookkeeping():
+    plain = run_ranks(2, lambda comm: _train(comm, rounds=1, nodes=97))
+    sliced = run_ranks(2, lambda comm: _train(comm, rounds=1, nodes=97, slices=2))
+    assert plain[0][1] + plain[1][1] == sliced[0][1] + sliced[1][1]
+    assert not np.array_equal(plain[0][0][1], sliced[0][0][1])
 
 
 def _gloo_worker(rank, world, port, out_dir):
@@ -94,7 +185,7 @@ def _gloo_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    (c, x), _ = _train(TorchComm())
+    (c, x), _, _ = _train(TorchComm())
     np.save(os.path.join(out_dir, f"c{rank}.npy"), c)
     np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
     dist.barrier()
@@ -112,7 +203,8 @@ def _free_port():
 @pytest.mark.parametrize("world", [2, 3])
 def test_gloo_ranks_equal_the_in_process_simulation(tmp_path, world):
     """No row is ever shared between ranks, so the distributed run is exactly the simulation
-    (world 3: ragged partitions of 12 / 11 / 11 rows go round the ring)."""
+    (world 3: ragged parts of 6 / 6 / 6 / 6 / 5 / 5 rows travel round the ring; two rounds, so
+    the rotation continues across the round boundary)."""
     mp.spawn(_gloo_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     sim = run_ranks(world, lambda comm: _train(comm))
     for r in range(world):

@@ -42,8 +42,21 @@ def test_single_gpu_line():
 
 def test_blocks_mode_line_on_one_gpu():
     d = _run("--parallelism", "blocks", "--no-cpu-baseline", "--round-walks", "8192")
-    assert "partitioned" in d["config"]["parallelism"] and d["finite"] is True
+    assert "travelling parts" in d["config"]["parallelism"] and d["finite"] is True
     assert "cpu_baseline" not in d and d["value"] > 0
+    assert d["roofline"]["kernel"] == "gn2v::sgns_block_kernel"
+    pairs = 2 * 16384 * 1250
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - pairs) < 1e-3 * pairs
+
+
+def test_cbow_line_on_one_gpu():
+    d = _run("--model", "cbow")
+    assert d["unit"] == "centres/s" and d["finite"] is True and "CBOW" in d["config"]["workload"]
+    centres = 2 * 16384 * 128
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - centres) < 1e-3 * centres
+    assert d["roofline"]["kernel"].startswith("gn2v::cbow") and d["roofline"]["achieved"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "centres/s" and c["value"] > 0
 
 
 def test_two_rank_line_through_torch_distributed_run():
@@ -67,5 +80,9 @@ def test_two_rank_line_through_torch_distributed_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite"] is True
     assert "2 GPU(s)" in d["config"]["parallelism"] and "cpu_baseline" not in d
+    dd = d["distributed"]
+    assert dd["backend"] == "gloo" and dd["world_size"] == 2 and len(dd["per_rank_pairs"]) == 2
+    assert sum(dd["per_rank_pairs"]) == 2 * 2 * 8192 * 1250 and min(dd["per_rank_pairs"]) > 0
+    assert dd["walk_allgather_ms_alone"] > 0 and dd["half_partition_hop_ms_alone"] > 0
     pairs = 2 * 2 * 8192 * 1250  # steps x ranks x walks x pairs per walk: the whole-job aggregate
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - pairs) < 1e-3 * pairs

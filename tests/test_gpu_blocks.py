@@ -1,19 +1,30 @@
-"""GPU: pair extraction, the pair-mode kernel and the block-partitioned multi-GPU trainer with
-ranks simulated on one GPU (exact: ranks never share a row, so a sequential simulation computes
-precisely what W GPUs compute; only the transport differs)."""
+"""GPU: the block-partitioned multi-GPU SkipGram path against the oracle's restatement of its
+schedule -- pair extraction + sort, negative pools and shard initialisation bit-exact, the
+training kernel within 1e-5 per element (f32 sums in another order, v_exp_f32 vs expf), and the
+trainer with ranks simulated on one GPU (exact: ranks never share a row, so a sequential
+simulation computes precisely what W GPUs compute; only the transport differs)."""
 import numpy as np
 import pytest
 import torch
 
 import embiggen_amd as E
 from embiggen_amd import _lib, ops
-from embiggen_amd.distributed import BlockPartitionedTrainer
+from embiggen_amd.distributed import BlockPartitionedTrainer, LoopbackComm, stripe_rows
 from oracle import oracle as O
-from sharded_helpers import (host_init_fn, host_walk_pair_blocks, link_auc_device as _auc,
-                             oracle_block_compute, run_ranks)
+from sharded_helpers import OracleBlockBackend, link_auc_device as _auc, run_ranks
 
 pytestmark = pytest.mark.gpu
 D, K, W, L = 16, 4, 3, 14
+DET = _lib.TRAIN_DETERMINISTIC
+
+
+def _ba(nodes, m=3, seed=9):
+    s, d = O.ba_edges(nodes, m, seed)
+    return E.CSRGraph.from_edge_list(s, d, number_of_nodes=nodes)
+
+
+def _u32(t):
+    return t.cpu().numpy().view(np.uint32)
 
 
 def test_walk_pairs_match_oracle(karate, karate_oracle):
@@ -22,127 +33,227 @@ def test_walk_pairs_match_oracle(karate, karate_oracle):
     for window, md in ((3, 1), (5, 1), (4, 4), (4, 2)):
         got = ops.walk_pairs(wk, window, md).cpu().numpy().view(np.uint32)
         assert np.array_equal(got, O.walk_pairs(wk_h, window, md))
-    # trap nodes: sentinel suffixes produce no pairs
     cut = wk.clone()
-    cut[:, 7:] = -1
+    cut[:, 7:] = -1  # trap nodes: sentinel suffixes produce no pairs
     got = ops.walk_pairs(cut, 3).cpu().numpy().view(np.uint32)
     assert np.array_equal(got, O.walk_pairs(cut.cpu().numpy().view(np.uint32), 3))
 
 
-@pytest.mark.parametrize("flags", [_lib.TRAIN_DETERMINISTIC, _lib.TRAIN_ATOMIC,
-                                   _lib.TRAIN_WRITE_THROUGH])
-def test_pair_mode_step_matches_oracle(karate, karate_oracle, flags):
-    wk = ops.walks(karate, ops.walk_params(10, 1, 1.0, 1.0), 4, 0, 0, 34)
-    pairs = ops.walk_pairs(wk, 2)
-    pairs_h = pairs.cpu().numpy().view(np.uint32)
-    c, x = ops.init_table(34, D, 4, 0, D ** -0.5), ops.init_table(34, D, 4, 1, D ** -0.5)
-    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
-    tp = ops.train_params(0, D, K, 1, flags=1 | flags)
-    otp = O.TrainParams(0, D, D, 1, K, 1, 0.01, 0.9, 6.0, 1, D ** -0.5)
-    if flags == _lib.TRAIN_DETERMINISTIC:
-        ops.step(karate, tp, pairs, 4, 0, 100, 0.05, c, x, pair_mode=True)
-    else:  # production flavours one pair per launch (pairs of a batch share rows)
-        for b in range(0, 200):
-            ops.step(karate, tp, pairs[b:b + 1].contiguous(), 4, 0, 100 + b, 0.05, c, x,
-                     pair_mode=True)
-        pairs_h = pairs_h[:200]
-    torch.cuda.synchronize()
-    O.train_walks_ex(karate_oracle, otp, pairs_h, 4, 0, 100, 0.05, c_h, x_h, pair_mode=True)
-    assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+def test_init_table_rows_are_the_rows_of_the_whole_table():
+    full = ops.init_table(1003, 20, 7, 1, 0.25)
+    for first, stride in ((0, 1), (2, 3), (5, 16)):
+        n = stripe_rows(1003, first, stride)
+        got = ops.init_table_rows(n, 20, 7, 1, 0.25, first, stride)
+        assert torch.equal(got, full[first::stride])
+        assert np.array_equal(got.cpu().numpy(), O.init_table_rows(n, 20, 20, 7, 1, 0.25, first, stride))
 
 
-def _run(comm, device, use_oracle, graph=None):
-    g = E.karate_club() if graph is None else graph
+@pytest.mark.parametrize("world,rank,parts,slices,md", [
+    (1, 0, 1, 1, 1), (1, 0, 4, 8, 1), (2, 1, 4, 1, 1), (3, 2, 6, 2, 2), (8, 5, 16, 8, 1)])
+def test_extraction_and_sort_are_bit_exact(world, rank, parts, slices, md):
+    g = _ba(203)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    n_nodes = g.get_number_of_nodes()
-    otp = O.TrainParams(0, D, D, 1, K, 1, 0.02, 0.9, 6.0, 1, D ** -0.5)
-    tp = ops.train_params(0, D, K, 1, flags=1 | _lib.TRAIN_DETERMINISTIC)
-    if use_oracle:
-        tr = BlockPartitionedTrainer(g, otp, D, D, 42, D ** -0.5, comm, "cpu",
-                                     init_fn=host_init_fn(n_nodes, D, D, 42, D ** -0.5))
-        tr.compute = oracle_block_compute(og, otp, tr)
-    else:
-        tr = BlockPartitionedTrainer(g, tp, D, D, 42, D ** -0.5, comm, device)
-    wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
-    for r in range(2):
-        first = (r * comm.world + comm.rank) * 9
-        walks = torch.from_numpy(O.walks(og, wp, 42, 0, first, 9).view(np.int32)).to(device)
-        # explicit pairs on both sides: the same (torch-built) shuffle keys, hence the same order
-        pairs = torch.from_numpy(
-            O.walk_pairs(walks.cpu().numpy().view(np.uint32), W).view(np.int32)).to(device)
-        tr.train_round(None, W, 1, 42, 0, 0.02, pairs=pairs)
-    return [t.cpu().numpy() for t in tr.gather_full()]
+    wk = ops.walks(g, ops.walk_params(24, 4, 0.5, 2.0), 5, 1, 100, 300)
+    wk[::5, 9:] = -1   # ended walks
+    wk[7] = -1         # a padding walk (rank with no walks left)
+    plan = ops.block_plan(g, world, rank, parts, slices, 24, 4, md, 4)
+    oplan = O.block_plan(203, world, rank, parts, slices, 24, 4, md, 4)
+    assert plan.row_bits == oplan.row_bits
+    work, offsets = ops.block_count(g, plan, wk, 5, 1, 100)
+    n = int(offsets[-1])
+    keys, vals = ops.block_extract(g, plan, wk, 5, 1, 100, work, n)
+    rk, rv, ro = O.block_extract(og, oplan, _u32(wk), 5, 1, 100)
+    assert n == len(rk) and n > 0
+    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
+    assert np.array_equal(_u32(keys), rk) and np.array_equal(_u32(vals), rv)
+    # empty input: no pairs, all offsets zero
+    empty = torch.full((4, 24), -1, dtype=torch.int32, device="cuda")
+    _, off0 = ops.block_count(g, plan, empty, 5, 1, 0)
+    assert int(off0.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_block_trainer_kernel_equals_oracle(world):
-    gpu = run_ranks(world, lambda comm: _run(comm, "cuda:0", use_oracle=False))
-    ref = run_ranks(world, lambda comm: _run(comm, "cpu", use_oracle=True))
-    for r in range(world):
-        assert np.abs(gpu[r][0] - ref[r][0]).max() < 1e-5
-        assert np.abs(gpu[r][1] - ref[r][1]).max() < 1e-5
+def test_extraction_honours_centre_downsampling(karate, karate_oracle):
+    wk = ops.walks(karate, ops.walk_params(16, 4, 1.0, 1.0), 3, 0, 0, 136)
+    plan = ops.block_plan(karate, 2, 0, 4, 1, 16, 3, 1, 4, flags=_lib.TRAIN_DOWNSAMPLE)
+    oplan = O.block_plan(34, 2, 0, 4, 1, 16, 3, 1, 4, flags=O.FLAG_DOWNSAMPLE)
+    work, offsets = ops.block_count(karate, plan, wk, 3, 0, 40)
+    n = int(offsets[-1])
+    keys, vals = ops.block_extract(karate, plan, wk, 3, 0, 40, work, n)
+    rk, rv, ro = O.block_extract(karate_oracle, oplan, _u32(wk), 3, 0, 40)
+    full = O.block_extract(karate_oracle, O.block_plan(34, 2, 0, 4, 1, 16, 3, 1, 4), _u32(wk), 3, 0, 40)
+    assert 0 < n < len(full[0])  # hubs are thinned
+    assert np.array_equal(_u32(keys), rk) and np.array_equal(_u32(vals), rv)
 
 
-@pytest.mark.parametrize("world,nodes", [(4, 203), (5, 97), (8, 64)])
-def test_block_trainer_on_scale_free_graphs_with_ragged_partitions(world, nodes):
-    """Partitions of unequal size (nodes % world != 0), hubs in one partition, more ranks."""
-    s, d = O.ba_edges(nodes, 3, 9)
-    g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=nodes)
-    gpu = run_ranks(world, lambda comm: _run(comm, "cuda:0", use_oracle=False, graph=g))
-    ref = run_ranks(world, lambda comm: _run(comm, "cpu", use_oracle=True, graph=g))
-    for r in range(world):
-        assert gpu[r][0].shape == (nodes, D)
-        assert np.abs(gpu[r][0] - ref[r][0]).max() < 1e-5
-        assert np.abs(gpu[r][1] - ref[r][1]).max() < 1e-5
-    assert all(np.array_equal(gpu[0][0], gpu[r][0]) for r in range(world))  # gather_full agrees
+@pytest.mark.parametrize("parts,slices", [(1, 1), (4, 1), (6, 8), (16, 8)])
+def test_negative_pools_are_bit_exact(parts, slices):
+    g = _ba(997, 4)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2)
+    pool, offsets = ops.block_pool(g, plan)
+    rp, ro = O.block_pool(og, parts, slices)
+    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
+    assert np.array_equal(_u32(pool), rp)
 
 
-def _run_fused(comm, device, use_oracle, graph, contexts):
-    """The production route: walks in, pairs grouped by (block, centre) and packed into centre
-    records, records routed and trained."""
+def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, n_walks=60,
+               wl=14, window=3, part_list=None, scale_free=True, extra=0):
+    """One round through gn2v_block_step and through the oracle; returns both table sets."""
+    n = g.get_number_of_nodes()
+    ld = (d + 3) // 4 * 4
+    wk = ops.walks(g, ops.walk_params(wl, 2, 0.5, 2.0), 11, 0, 0, n_walks)
+    plan = ops.block_plan(g, world, rank, parts, slices, wl, window, 1, record)
+    oplan = O.block_plan(n, world, rank, parts, slices, wl, window, 1, record)
+    work, offsets = ops.block_count(g, plan, wk, 11, 0, 0)
+    keys, vals = ops.block_extract(g, plan, wk, 11, 0, 0, work, int(offsets[-1]))
+    pool, pool_offsets = ops.block_pool(g, plan)
+    sf = (1 if scale_free else 0) | extra
+    tp = ops.train_params(0, d, k, window, flags=sf | flags, ld=ld)
+    otp = O.TrainParams(0, d, ld, 1, k, window, 0.01, 0.9, 6.0, sf, d ** -0.5)
+    c = ops.init_table_rows(stripe_rows(n, rank, world), d, 11, 0, d ** -0.5, rank, world, ld=ld)
+    c_h = c.cpu().numpy().copy()
+    rk, rv, ro = _u32(keys), _u32(vals), offsets.cpu().numpy().astype(np.uint64)
+    rp, rpo = _u32(pool), pool_offsets.cpu().numpy().astype(np.uint64)
+    got_x, ref_x = [], []
+    ops.stats_reset(g)
+    trained = 0
+    for part in (range(parts) if part_list is None else part_list):
+        x = ops.init_table_rows(stripe_rows(n, part, parts), d, 11, 1, d ** -0.5, part, parts, ld=ld)
+        x_h = x.cpu().numpy().copy()
+        ops.block_step(g, tp, plan, keys, vals, offsets, pool, pool_offsets, c, x, 3, part, 11, 0, lr)
+        trained += O.block_step(og, otp, oplan, rk, rv, ro, rp, rpo, c_h, x_h, 3, part, 11, 0, lr)
+        got_x.append(x.cpu().numpy())
+        ref_x.append(x_h)
+    torch.cuda.synchronize()
+    assert ops.stats_read(g)["pairs"] == trained
+    return c.cpu().numpy(), got_x, c_h, ref_x
+
+
+@pytest.mark.parametrize("d", [4, 16, 100, 128, 300])
+def test_deterministic_block_step_matches_oracle(karate, karate_oracle, d):
+    c, xs, c_h, xs_h = _step_both(karate, karate_oracle, d, 5, 1, 0, 2, 1, 4, DET)
+    assert np.abs(c - c_h).max() < 1e-5
+    for x, x_h in zip(xs, xs_h):
+        assert np.abs(x - x_h).max() < 1e-5
+    assert np.abs(c_h - O.init_table(34, d, (d + 3) // 4 * 4, 11, 0, d ** -0.5)).max() > 1e-3
+
+
+@pytest.mark.parametrize("world,rank,parts,slices,record", [
+    (1, 0, 1, 1, 16), (1, 0, 1, 8, 16), (2, 1, 4, 1, 1), (3, 0, 6, 2, 7), (4, 3, 8, 8, 32)])
+def test_deterministic_block_step_over_plans(world, rank, parts, slices, record):
+    g = _ba(203)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    c, xs, c_h, xs_h = _step_both(g, og, D, K, world, rank, parts, slices, record, DET)
+    assert np.abs(c - c_h).max() < 1e-5
+    for x, x_h in zip(xs, xs_h):
+        assert np.abs(x - x_h).max() < 1e-5
+
+
+def test_uniform_negatives_and_degree_normalised_learning_rate(karate, karate_oracle):
+    c, xs, c_h, xs_h = _step_both(karate, karate_oracle, D, K, 1, 0, 2, 2, 4,
+                                  DET, scale_free=False, extra=_lib.TRAIN_NORM_LR, lr=0.5)
+    assert np.abs(c - c_h).max() < 1e-5 and all(
+        np.abs(x - x_h).max() < 1e-5 for x, x_h in zip(xs, xs_h))
+    assert np.abs(c_h - O.init_table(34, D, D, 11, 0, D ** -0.5)).max() > 1e-3
+
+
+@pytest.mark.parametrize("flags", [_lib.TRAIN_ATOMIC, _lib.TRAIN_WRITE_THROUGH,
+                                   _lib.TRAIN_WRITE_BACK])
+@pytest.mark.parametrize("d,slices", [(8, 1), (128, 1), (128, 8)])
+def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
+    """Thousands of records in one launch with k = 0 and every row used once: with no row shared
+    between records the parallel schedule (dynamic record tickets, four rows per wave round, XCD
+    slices, every store flavour) must equal the sequential oracle."""
+    n_pairs, parts, record = 40_000, 2, 16
+    n_rows = 2 * n_pairs
+    # synthetic sorted pairs: centre row i (unique, ascending), context row perm[i] of the cell
+    g = _ba(2 * n_rows + 5)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, 1, record)
+    oplan = O.block_plan(2 * n_rows + 5, 1, 0, parts, slices, 8, 2, 1, record)
+    rng = np.random.RandomState(3)
+    rows_per_part = stripe_rows(2 * n_rows + 5, 0, parts)
+    keys_l, vals_l, offsets = [], [], [0]
+    next_centre = 0
+    for cell in range(parts * slices):
+        slc = cell % slices
+        cand = np.arange(slc, rows_per_part - 1, slices)
+        m = n_pairs // (parts * slices)
+        ctx = rng.permutation(cand)[:m]
+        centres = next_centre + np.arange(m)
+        next_centre += m
+        keys_l.append((cell << plan.row_bits) | centres)
+        vals_l.append(ctx)
+        offsets.append(offsets[-1] + m)
+    keys_h = np.concatenate(keys_l).astype(np.uint32)
+    vals_h = np.concatenate(vals_l).astype(np.uint32)
+    off_h = np.asarray(offsets, dtype=np.uint64)
+    keys = torch.from_numpy(keys_h.view(np.int32)).cuda()
+    vals = torch.from_numpy(vals_h.view(np.int32)).cuda()
+    offs = torch.from_numpy(off_h.astype(np.int64)).cuda()
+    ld = (d + 3) // 4 * 4
+    tp = ops.train_params(0, d, 0, 2, flags=flags, ld=ld)  # k = 0, no pool needed
+    otp = O.TrainParams(0, d, ld, 1, 0, 2, 0.01, 0.9, 6.0, 0, d ** -0.5)
+    c = ops.init_table(2 * n_rows + 5, d, 5, 0, 0.5, ld=ld)
+    c_h = c.cpu().numpy().copy()
+    for part in range(parts):
+        x = ops.init_table(rows_per_part, d, 5, 1 + part, 0.5, ld=ld)
+        x_h = x.cpu().numpy().copy()
+        ops.block_step(g, tp, plan, keys, vals, offs, None, None, c, x, 0, part, 5, 0, 0.05)
+        O.block_step(og, otp, oplan, keys_h, vals_h, off_h, None, None, c_h, x_h, 0, part, 5, 0, 0.05)
+        torch.cuda.synchronize()
+        assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+        assert np.abs(x_h - ops.init_table(rows_per_part, d, 5, 1 + part, 0.5, ld=ld).cpu().numpy()
+                      ).max() > 1e-3
+    assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5
+
+
+def _trainer_run(comm, graph, use_oracle, slices=1, rounds=2, walks_per_round=11, record=4):
     og = O.OracleGraph(graph.row_ptr, graph.col_idx)
-    n_nodes = graph.get_number_of_nodes()
-    otp = O.TrainParams(0, D, D, 1, K, 1, 0.02, 0.9, 6.0, 1, D ** -0.5)
-    tp = ops.train_params(0, D, K, 1, flags=1 | _lib.TRAIN_DETERMINISTIC)
     if use_oracle:
-        tr = BlockPartitionedTrainer(graph, otp, D, D, 42, D ** -0.5, comm, "cpu",
-                                     init_fn=host_init_fn(n_nodes, D, D, 42, D ** -0.5),
-                                     record_contexts=contexts)
-        tr.compute = oracle_block_compute(og, otp, tr)
+        tp = O.TrainParams(0, D, D, 1, K, W, 0.02, 0.9, 6.0, 1, D ** -0.5)
+        tr = BlockPartitionedTrainer(graph, tp, D, D, 42, D ** -0.5, comm, "cpu", walk_length=L,
+                                     window=W, backend=OracleBlockBackend(graph), slices=slices,
+                                     record=record)
+        dev = "cpu"
     else:
-        tr = BlockPartitionedTrainer(graph, tp, D, D, 42, D ** -0.5, comm, device,
-                                     record_contexts=contexts)
+        tp = ops.train_params(0, D, K, W, flags=1 | DET)
+        tr = BlockPartitionedTrainer(graph, tp, D, D, 42, D ** -0.5, comm, "cuda:0",
+                                     walk_length=L, window=W, slices=slices, record=record)
+        dev = "cuda:0"
     wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
-    infos = []
-    for r in range(2):
-        first = (r * comm.world + comm.rank) * 11
-        walks = torch.from_numpy(O.walks(og, wp, 42, 0, first, 11).view(np.int32)).to(device)
-        tr.train_round(walks, W, 1, 42, 0, 0.02)
-        infos.append(tr.last_round)
-    return [t.cpu().numpy() for t in tr.gather_full()], infos
+    trained = []
+    for r in range(rounds):
+        first = r * comm.world * walks_per_round
+        mine = O.walks(og, wp, 42, 0, first + comm.rank * walks_per_round, walks_per_round)
+        tr.train_round(torch.from_numpy(mine.view(np.int32)).to(dev), 42, 0, 0.02, first)
+        trained.append(tr.last_round["pairs_trained"])
+    return [t.cpu().numpy() for t in tr.gather_full()], trained
 
 
-@pytest.mark.parametrize("world,contexts", [(1, 10), (2, 10), (3, 4), (4, 1)])
-def test_fused_centre_record_route_equals_oracle(world, contexts, monkeypatch):
-    s, d = O.ba_edges(150, 3, 4)
-    g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=150)
-    gpu = run_ranks(world, lambda comm: _run_fused(comm, "cuda:0", False, g, contexts))
-    monkeypatch.setattr(ops, "walk_pair_blocks", host_walk_pair_blocks)
-    ref = run_ranks(world, lambda comm: _run_fused(comm, "cpu", True, g, contexts))
+@pytest.mark.parametrize("world,nodes,slices", [(1, 34, 1), (2, 34, 1), (3, 34, 1), (4, 203, 2),
+                                                (5, 97, 1), (8, 64, 8)])
+def test_block_trainer_with_simulated_ranks_equals_oracle(world, nodes, slices):
+    """1-8 simulated ranks, ragged partitions (nodes % parts != 0), hubs in one partition,
+    half-partition rotation continuing across the round boundary, XCD slices."""
+    g = E.karate_club() if nodes == 34 else _ba(nodes)
+    gpu = run_ranks(world, lambda comm: _trainer_run(comm, g, False, slices))
+    ref = run_ranks(world, lambda comm: _trainer_run(comm, g, True, slices))
     per_walk = 2 * W * L - W * (W + 1)
     for r in range(world):
+        assert gpu[r][0][0].shape == (nodes, D)
         assert np.abs(gpu[r][0][0] - ref[r][0][0]).max() < 1e-5
         assert np.abs(gpu[r][0][1] - ref[r][0][1]).max() < 1e-5
         assert gpu[r][1] == ref[r][1]
+    assert all(np.array_equal(gpu[0][0][0], gpu[r][0][0]) for r in range(world))
     for rnd in range(2):  # every pair of the round is trained exactly once, somewhere
-        assert sum(gpu[r][1][rnd]["pairs_trained"] for r in range(world)) == world * 11 * per_walk
-        assert all(gpu[r][1][rnd]["pairs_generated"] == 11 * per_walk for r in range(world))
+        assert sum(gpu[r][1][rnd] for r in range(world)) == world * 11 * per_walk
 
 
 def test_eight_simulated_gpus_reach_single_gpu_quality():
-    """BA 200 k nodes: 8 block-partitioned ranks vs one walk-mode trainer on the same walks
-    (10 per node).  Merging replica deltas collapses here (AUROC 0.02-0.27, DESIGN.md section 7);
-    orthogonal blocks must stay at the single-GPU quality."""
+    """BA 200 k nodes: 8 block-partitioned ranks (production update mode, pipelined rounds) vs
+    one walk-mode trainer on the same walks.  Merging replica deltas collapses here (AUROC
+    0.02-0.27); orthogonal blocks must stay at the single-GPU quality."""
     g = E.barabasi_albert(200_000, 8, 42)
     n, d, w = g.get_number_of_nodes(), 64, 4
     wp = ops.walk_params(64, 1, 1.0, 1.0)
@@ -158,48 +269,47 @@ def test_eight_simulated_gpus_reach_single_gpu_quality():
     auc_single = _auc(g, c, x, gen)
 
     world = 8
-    tp_pair = ops.train_params(0, d, 5, 1, flags=1)
 
     def rank_fn(comm):
-        tr = BlockPartitionedTrainer(g, tp_pair, d, d, 42, d ** -0.5, comm, "cuda:0")
+        tr = BlockPartitionedTrainer(g, tp_walk, d, d, 42, d ** -0.5, comm, "cuda:0",
+                                     walk_length=64, window=w)
         for r in range(total // per_round // world):
-            first = (r * world + comm.rank) * per_round
-            tr.train_round(ops.walks(g, wp, 42, 0, first, per_round), w, 1, 42, 0, 0.025)
+            first = r * world * per_round
+            tr.train_round(ops.walks(g, wp, 42, 0, first + comm.rank * per_round, per_round), 42,
+                           0, 0.025, first)
         return tr.gather_full(), tr.last_round
 
     (bc, bx), info = run_ranks(world, rank_fn)[0]
     gen.manual_seed(1)
     auc_blocks = _auc(g, bc, bx, gen)
-    assert bool(torch.isfinite(bc).all()) and min(info["block_sizes"]) > 0
+    assert bool(torch.isfinite(bc).all()) and info["pairs_trained"] > 0
     assert auc_single > 0.9 and auc_blocks > auc_single - 0.03, (auc_blocks, auc_single)
 
 
-@pytest.mark.parametrize("flags", [_lib.TRAIN_ATOMIC, _lib.TRAIN_WRITE_THROUGH,
-                                   _lib.TRAIN_WRITE_BACK])
-@pytest.mark.parametrize("d", [8, 128])
-def test_pair_mode_on_a_collision_free_batch(karate, karate_oracle, flags, d):
-    """Thousands of (centre, context) records in one launch: with every record on its own rows
-    the parallel schedule must equal the sequential oracle."""
-    rng = np.random.RandomState(3)
-    n_rec, k, blk = 3000, 6, 16
-    pairs = np.zeros((n_rec, 2), dtype=np.uint32)
-    neg = np.zeros((n_rec, 2, 2, k), dtype=np.uint32)
-    for b in range(n_rec):
-        nodes = b * blk + rng.permutation(blk)
-        pairs[b] = nodes[:2]
-        neg[b, 0, 1] = nodes[2:2 + k]
-    n_rows = n_rec * blk
-    c, x = ops.init_table(n_rows, d, 5, 0, d ** -0.5), ops.init_table(n_rows, d, 5, 1, d ** -0.5)
-    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
-    tp = ops.train_params(0, d, k, 1, flags=1 | flags)
-    otp = O.TrainParams(0, d, (d + 3) // 4 * 4, 1, k, 1, 0.01, 0.9, 6.0, 1, d ** -0.5)
-    ops.step(karate, tp, torch.from_numpy(pairs.view(np.int32)).cuda(), 5, 0, 77, 0.05, c, x,
-             neg_override=torch.from_numpy(neg.view(np.int32)).cuda(), pair_mode=True)
-    torch.cuda.synchronize()
-    O.train_walks_ex(karate_oracle, otp, pairs, 5, 0, 77, 0.05, c_h, x_h, neg_override=neg,
-                     pair_mode=True)
-    assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
-    assert np.abs(x_h - ops.init_table(n_rows, d, 5, 1, d ** -0.5).cpu().numpy()).max() > 1e-3
+def test_sliced_parts_and_pipelined_rounds_keep_the_quality():
+    """One GPU, XCD-sliced parts with write-back contextual rows, rounds prepared on a second
+    stream while the previous round trains: link quality of the plain walk-ordered trainer."""
+    g = E.barabasi_albert(200_000, 8, 42)
+    n, d, w = g.get_number_of_nodes(), 64, 4
+    wp = ops.walk_params(64, 1, 1.0, 1.0)
+    total, per_round = 1 << 21, 1 << 17
+    tp = ops.train_params(0, d, 5, w, flags=1)
+    gen = torch.Generator(device="cuda")
+    aucs = {}
+    for slices in (1, 8):
+        tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
+                                     walk_length=64, window=w, slices=slices)
+        rounds = [(lambda first=first: ops.walks(g, wp, 42, 0, first, per_round), 42, 0, 0.025, first)
+                  for first in range(0, total, per_round)]
+        ops.stats_reset(g)
+        tr.run(rounds, overlap=True)
+        torch.cuda.synchronize()
+        assert ops.stats_read(g)["pairs"] == total * (2 * w * 64 - w * (w + 1))
+        bc, bx = tr.gather_full()
+        gen.manual_seed(1)
+        aucs[slices] = _auc(g, bc, bx, gen)
+        assert bool(torch.isfinite(bc).all()) and bool(torch.isfinite(bx).all())
+    assert aucs[1] > 0.93 and aucs[8] > 0.93, aucs
 
 
 def test_model_level_multi_gpu_fit_with_simulated_ranks():
@@ -231,33 +341,20 @@ def test_model_level_multi_gpu_fit_with_simulated_ranks():
         E.models.CBOW(**kw).fit_transform_blocks(g, None)
 
 
-def test_fused_pair_keys_group_and_shuffle(karate):
-    """gn2v_walk_pair_blocks: sorting by the emitted key yields exactly the pair multiset of
-    gn2v_walk_pairs, grouped by (centre % world, context % world), shuffled inside a block, with
-    the unused slots (trap-node suffixes, trimmed windows) at the end."""
-    wk = ops.walks(karate, ops.walk_params(24, 4, 0.5, 2.0), 5, 0, 0, 136)
-    wk[::5, 9:] = -1
-    world, window = 3, 4
-    want = ops.walk_pairs(wk, window, 1).cpu().numpy().view(np.uint32)
-    slots, keys = ops.walk_pair_blocks(wk, window, 1, world, 99)
-    keys_s, order = torch.sort(keys)
-    n = int((keys_s != 0x7FFFFFFFFFFFFFFF).sum())
-    assert n == len(want)
-    got = slots[order[:n]].cpu().numpy().view(np.uint32)
-    block = (got[:, 0] % world).astype(np.int64) * world + got[:, 1] % world
-    assert (np.diff(block) >= 0).all() and (keys_s[:n].cpu().numpy() >> 31 == block).all()
-    as_set = lambda p: np.sort(p[:, 0].astype(np.int64) * 64 + p[:, 1])  # noqa: E731
-    assert np.array_equal(as_set(got), as_set(want))
-    inside = got[block == 4]
-    assert not np.array_equal(inside, inside[np.lexsort((inside[:, 1], inside[:, 0]))])  # shuffled
-    _, keys2 = ops.walk_pair_blocks(wk, window, 1, world, 100)
-    assert not torch.equal(keys, keys2)  # the salt changes the shuffle
+def test_multi_gpu_is_an_explicit_opt_in(karate):
+    """A model without ``comm`` never touches torch.distributed; CBOW with a ``comm`` falls back
+    to its own device instead of raising inside somebody else's job."""
+    kw = dict(embedding_size=8, epochs=1, walk_length=8, iterations=1, window_size=2, verbose=False)
+    m = E.models.CBOW(**kw)
+    m.comm = LoopbackComm()
+    out = m.fit_transform(karate)
+    assert out[0].shape == (34, 8) and np.isfinite(out[0]).all()
 
 
 def test_one_rank_rccl_group_equals_loopback():
     """The trainer's collectives on the real backend ("nccl" = RCCL) with device tensors; a one-GPU
-    box can only host a one-rank group, the 2-rank exchange logic is covered on gloo
-    (tests/test_blocks_cpu.py)."""
+    box can only host a one-rank group, the multi-rank exchange logic is covered on gloo
+    (tests/test_blocks_cpu.py, tests/test_gpu_bench_contract.py)."""
     import os
     import subprocess
     import sys

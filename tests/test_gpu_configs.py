@@ -1,0 +1,106 @@
+"""BASELINE.json configs 4 and 5 at their full sizes on one MI355X, through size-independent
+properties (the oracle cannot run these sizes in seconds):
+
+  * walks follow edges of the CSR (u64 ``row_ptr``: config 5 has 2 x 10^9 directed edges) and
+    re-run identically;
+  * the pair / centre counters of a training launch equal the closed form 2wL - w(w+1);
+  * a zero learning rate is the identity (bit for bit);
+  * central rows move only for nodes on the walks, contextual rows also for the negatives;
+  * everything stays finite.
+
+Tables are checked through exact per-row integer checksums so that the 2 x 51.2 GB tables of
+config 5 need no second copy.  Config 4 additionally runs the block-partitioned multi-GPU trainer
+with 8 simulated ranks at full size (tests/test_gpu_blocks.py holds the small exact cases).
+"""
+import pytest
+import torch
+
+import embiggen_amd as E
+from embiggen_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+PAIRS_PER_WALK = 2 * 5 * 128 - 5 * 6  # window 5, walk_length 128
+
+
+def row_checksums(t, chunk=1 << 21):
+    """Exact int64 checksum of every row (bit pattern sums), computed in row chunks."""
+    out = torch.empty(t.shape[0], dtype=torch.int64, device=t.device)
+    for lo in range(0, t.shape[0], chunk):
+        out[lo:lo + chunk] = t[lo:lo + chunk].view(torch.int32).sum(1, dtype=torch.int64)
+    return out
+
+
+def all_finite(t, chunk=1 << 23):
+    return all(bool(torch.isfinite(t[lo:lo + chunk]).all()) for lo in range(0, t.shape[0], chunk))
+
+
+def walks_follow_edges(g, wk, chunk=1 << 22):
+    """Every consecutive walk pair (a, b) has b in the sorted adjacency row of a."""
+    t = g._device_tensors
+    col, row_ptr = t["col_idx"], t["row_ptr"]
+    a_all, b_all = wk[:, :-1].reshape(-1), wk[:, 1:].reshape(-1)
+    for off in range(0, a_all.numel(), chunk):
+        a = a_all[off:off + chunk].long() & 0xFFFFFFFF
+        b = b_all[off:off + chunk].long() & 0xFFFFFFFF
+        lo, ends = row_ptr[a].clone(), row_ptr[a + 1]
+        hi = ends.clone()
+        for _ in range(32):
+            mid = (lo + hi) // 2
+            val = col[mid.clamp(max=col.numel() - 1)].long() & 0xFFFFFFFF
+            go_right = (mid < hi) & (val < b)
+            lo = torch.where(go_right, mid + 1, lo)
+            hi = torch.where(go_right, hi, mid)
+        hit = col[lo.clamp(max=col.numel() - 1)].long() & 0xFFFFFFFF
+        if not bool(((lo < ends) & (hit == b)).all()):
+            return False
+    return True
+
+
+def full_size_properties(g, n_walks, d=128):
+    n = g.get_number_of_nodes()
+    wp = ops.walk_params(128, 10, 0.25, 4.0)
+    wk = ops.walks(g, wp, 42, 0, 0, n_walks)
+    assert torch.equal(wk, ops.walks(g, wp, 42, 0, 0, n_walks))
+    assert int((wk == -1).sum()) == 0  # BA graphs have no trap nodes
+    assert walks_follow_edges(g, wk)
+
+    c = ops.init_table(n, d, 42, 0, d ** -0.5)
+    x = ops.init_table(n, d, 42, 1, d ** -0.5)
+    c0, x0 = row_checksums(c), row_checksums(x)
+    tp = ops.train_params(0, d, 10, 5)
+    ops.sgns_step(g, tp, wk, 42, 0, 0, 0.0, c, x)  # lr = 0: identity
+    assert torch.equal(row_checksums(c), c0) and torch.equal(row_checksums(x), x0)
+    ops.stats_reset(g)
+    ops.sgns_step(g, tp, wk, 42, 0, 0, 0.01, c, x)
+    st = ops.stats_read(g)
+    assert st["pairs"] == n_walks * PAIRS_PER_WALK and st["centres"] == n_walks * 128
+    assert all_finite(c) and all_finite(x)
+    visited = torch.zeros(n, dtype=torch.bool, device="cuda")
+    visited[wk.long().flatten() & 0xFFFFFFFF] = True
+    c1, x1 = row_checksums(c), row_checksums(x)
+    assert torch.equal(c1[~visited], c0[~visited])  # central rows move only for walk nodes
+    assert float((c1[visited] != c0[visited]).float().mean()) > 0.99
+    moved = int((x1 != x0).sum())
+    assert moved > int(visited.sum())  # negatives reach beyond the walk nodes
+    return st
+
+
+def test_config4_ogbn_products_shaped_full_size_properties():
+    """BASELINE config 4: ogbn-products-shaped BA graph, 2 449 029 nodes / ~61.2 M edges
+    (m = 25), d = 128, reference defaults; one launch of 2^16 walks on one GPU."""
+    g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
+    assert g.get_number_of_nodes() == 2_449_029
+    assert 2 * 60_000_000 < g.get_number_of_directed_edges() <= 2 * 61_225_700
+    full_size_properties(g, 1 << 16)
+
+
+def test_config5_ba_100m_nodes_1b_edges_full_size_properties():
+    """BASELINE config 5: Barabasi-Albert 100 M nodes / 1 B edges (2 x 10^9 directed: u64 row
+    pointers), d = 128: 2 x 51.2 GB tables + 8.8 GB CSR on one MI355X, one launch of 2^16 walks."""
+    g = E.barabasi_albert(100_000_000, 10, 42)
+    assert g.get_number_of_nodes() == 100_000_000
+    e = g.get_number_of_directed_edges()
+    assert 1.99e9 < e <= 2 * 999_999_990  # multi-edges collapse: a little under 2 x 10^9
+    assert int(g._device_tensors["row_ptr"][-1]) == e
+    full_size_properties(g, 1 << 16)
