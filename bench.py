@@ -60,15 +60,19 @@ def parse():
                          "--pmc passes): every table row touched exactly once per launch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--parallelism", default="auto", choices=["auto", "single", "blocks"],
-                    help="auto: single on 1 GPU, block-partitioned tables on N > 1 GPUs")
+                    help="blocks (= auto): the block trainer, on one GPU too (contextual rows in "
+                         "XCD-exclusive cells); single: the walk-ordered kernel, 1 GPU only")
     ap.add_argument("--round-walks", type=int, default=1 << 20,
                     help="blocks: walks per rank per round (every context part visits every rank "
                          "once per round)")
     ap.add_argument("--parts", type=int, default=None,
                     help="blocks: context parts (default 1 on one GPU, 2 x world otherwise)")
-    ap.add_argument("--slices", type=int, default=1,
-                    help="blocks: XCD slices inside a part (8 = every XCD owns its rows)")
+    ap.add_argument("--slices", type=int, default=None,
+                    help="blocks: XCD slices inside a part (8 = every XCD owns its rows; default: "
+                         "distributed.auto_plan)")
     ap.add_argument("--record", type=int, default=16, help="blocks: pairs per record")
+    ap.add_argument("--local-atomic", action="store_true",
+                    help="blocks with slices: contextual rows updated by L2-local f32 atomics")
     ap.add_argument("--no-overlap", action="store_true",
                     help="blocks: prepare every round in line instead of on a second stream")
     ap.add_argument("--model", default="skipgram", choices=["skipgram", "cbow"])
@@ -192,6 +196,8 @@ def main():
     flags = _lib.TRAIN_SCALE_FREE | {
         "auto": 0, "write_through": _lib.TRAIN_WRITE_THROUGH,
         "write_back": _lib.TRAIN_WRITE_BACK, "atomic": _lib.TRAIN_ATOMIC}[args.mode]
+    if args.local_atomic:
+        flags |= _lib.TRAIN_LOCAL_ATOMIC
     if args.calibrate:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         perm = torch.randperm(n, device="cuda", dtype=torch.int64).to(torch.int32)
@@ -218,7 +224,7 @@ def main():
 
     mode = args.parallelism
     if mode == "auto":
-        mode = "single" if world == 1 else "blocks"
+        mode = "single" if cbow else "blocks"
     if mode == "single" and world > 1:
         raise SystemExit("--parallelism single needs --gpus 1")
     if mode == "blocks" and cbow:
@@ -373,7 +379,7 @@ def main():
                     "single": "1 GPU, walk-ordered kernel",
                     "blocks": f"{world} GPU(s), central table striped over the ranks, contextual "
                               f"table in {blocks.parts if blocks else 0} travelling parts x "
-                              f"{args.slices} XCD slice(s) (no shared rows), rounds of "
+                              f"{blocks.slices if blocks else 0} XCD slice(s) (no shared rows), rounds of "
                               f"{min(args.round_walks, args.walks)} walks per GPU, preparation "
                               f"{'overlapped' if not args.no_overlap else 'in line'}",
                 }[mode],

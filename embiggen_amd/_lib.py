@@ -26,6 +26,7 @@ TRAIN_WRITE_BACK = 32
 TRAIN_WRITE_THROUGH = 64
 TRAIN_NO_CTX_CACHE = 128
 TRAIN_CTX_CACHE_ALL = 256
+TRAIN_LOCAL_ATOMIC = 512
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 

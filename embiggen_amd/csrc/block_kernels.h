@@ -320,7 +320,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         load_row<CH>(u, crow, q, nchunks, true);
         zero_row<CH>(g);
         Row<CH> u_upd = u;
-        if constexpr (!DET && WMX == kAtomic) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
+        if constexpr (!DET && is_atomic(WMX)) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
         score_samples<CH, WMX, DET>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
                                     s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
         if constexpr (!DET) reduce_groups<CH>(g);

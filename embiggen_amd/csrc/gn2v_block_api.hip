@@ -249,9 +249,11 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
     else if (wmx == gn2v::kWriteBack && wmc == gn2v::kWriteBack)
         GN2V_BLOCK(gn2v::kWriteBack, gn2v::kWriteBack, false);
     else if (wmx == gn2v::kWriteBack)
-        GN2V_BLOCK(gn2v::kWriteBack, gn2v::kWriteThrough, false);
+        GN2V_BLOCK(gn2v::kWriteBack, gn2v::kAtomic, false);
+    else if (wmx == gn2v::kLocalAtomic)
+        GN2V_BLOCK(gn2v::kLocalAtomic, gn2v::kAtomic, false);
     else
-        GN2V_BLOCK(gn2v::kWriteThrough, gn2v::kWriteThrough, false);
+        GN2V_BLOCK(gn2v::kWriteThrough, gn2v::kAtomic, false);
 #undef GN2V_BLOCK
 }
 }  // extern "C++"
@@ -300,15 +302,18 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     a.clip = tp->clip;
 
     const bool det = tp->flags & GN2V_TRAIN_DETERMINISTIC;
-    // contextual rows: exclusive to one XCD when the part is sliced -> plain write-back stores;
-    // central rows are shared by the XCDs -> write-through.  Small graphs: atomics, as elsewhere.
+    // contextual rows: exclusive to one XCD when the part is sliced -> plain write-back stores,
+    // else write-through.  Central rows: the gradient of a whole record is added with hardware
+    // f32 atomics (one row per ~record * (k + 1) sample rows: free, and the records of a hub centre
+    // that many waves train at once lose no update).  Small graphs: atomics everywhere.
     int wmc = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
               : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
               : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
               : g->view.n_nodes < (1ULL << 16)         ? gn2v::kAtomic
                                                        : gn2v::kWriteThrough;
     int wmx = wmc;
-    if (wmc == gn2v::kWriteThrough && d.slices > 1) wmx = gn2v::kWriteBack;
+    if (wmc == gn2v::kWriteThrough && d.slices > 1)
+        wmx = (tp->flags & GN2V_TRAIN_LOCAL_ATOMIC) ? gn2v::kLocalAtomic : gn2v::kWriteBack;
 
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
     const size_t per_wave_words =

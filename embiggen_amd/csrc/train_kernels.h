@@ -117,7 +117,20 @@ __device__ __forceinline__ void axpy(Row<CH> &acc, float s, const Row<CH> &x) {
 //                  until evicted: hot rows diverge per XCD inside a launch).
 //   kAtomic:       hardware f32 atomics, one per element, lane-contiguous addresses (no lost
 //                  update; ~2-3x the store cost).
-enum WriteMode : int { kWriteThrough = 0, kWriteBack = 1, kAtomic = 2 };
+//   kLocalAtomic:  f32 atomics at workgroup scope: executed by the XCD's L2 without leaving it.
+//                  Only valid for rows that a single XCD touches during the launch (the sliced
+//                  parts of the block trainer): exact accumulation at L2 speed.
+enum WriteMode : int { kWriteThrough = 0, kWriteBack = 1, kAtomic = 2, kLocalAtomic = 3 };
+
+__host__ __device__ constexpr bool is_atomic(int wm) { return wm == kAtomic || wm == kLocalAtomic; }
+
+template <int WM>
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) {
+    if constexpr (WM == kLocalAtomic)
+        (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+        unsafeAtomicAdd(p, v);
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -133,16 +146,16 @@ __device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks
                                             const Row<CH> &x, const Row<CH> &old) {
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
-        if constexpr (WM == kAtomic) {
+        if constexpr (is_atomic(WM)) {
             // slot (cc, e) of lane q is element 64*cc + 16*e + q (to_contig_layout), so each
             // atomic instruction covers 64 contiguous bytes per group -- measured 4x the
             // throughput of float4-shaped (16 B strided) atomics.
             float *pc = base + cc * 64 + q;
             const uint32_t f = cc * 64 + q, ldf = nchunks * 4;
-            if (f < ldf) unsafeAtomicAdd(pc + 0, s * x.c[cc].x);
-            if (f + 16 < ldf) unsafeAtomicAdd(pc + 16, s * x.c[cc].y);
-            if (f + 32 < ldf) unsafeAtomicAdd(pc + 32, s * x.c[cc].z);
-            if (f + 48 < ldf) unsafeAtomicAdd(pc + 48, s * x.c[cc].w);
+            if (f < ldf) atomic_add_f32<WM>(pc + 0, s * x.c[cc].x);
+            if (f + 16 < ldf) atomic_add_f32<WM>(pc + 16, s * x.c[cc].y);
+            if (f + 32 < ldf) atomic_add_f32<WM>(pc + 32, s * x.c[cc].z);
+            if (f + 48 < ldf) atomic_add_f32<WM>(pc + 48, s * x.c[cc].w);
         } else {
             const uint32_t ci = cc * 16 + q;
             if (ci < nchunks) {

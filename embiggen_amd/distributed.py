@@ -41,6 +41,32 @@ def stripe_rows(n: int, first: int, stride: int) -> int:
     return (n - first + stride - 1) // stride if n > first else 0
 
 
+MIN_ROWS_PER_CELL = 32768
+
+
+def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:
+    """(parts, slices) of the contextual table.  Measured (scripts/quality_probe.py, DESIGN.md
+    section 7): the smaller a cell, the more of it lives in the XCD's L2 (BA 10 M nodes: 0.67 of
+    the HBM roofline unsliced, 0.80 at 4 x 8 cells, 0.87 at 32 x 8) -- and the more often two
+    waves read-modify-write the same row at once; link quality stays at or above the walk-ordered
+    trainer's while a cell keeps >= 32 k rows.  With several ranks the number of parts is fixed by
+    the rotation (two per rank)."""
+    def pow2_floor(x):
+        return 1 << (max(1, int(x)).bit_length() - 1)
+
+    # a sort key is cell << row_bits | centre row, 32 bits in all
+    row_bits = max(0, (stripe_rows(n_nodes, 0, world) - 1).bit_length())
+    max_cells = 1 << max(0, 32 - row_bits)
+    if world > 1:
+        parts = 2 * world
+        slices = max(1, min(8, pow2_floor(n_nodes // (parts * MIN_ROWS_PER_CELL))))
+        return parts, max(1, min(slices, pow2_floor(max_cells // parts)))
+    slices = max(1, min(8, pow2_floor(n_nodes // MIN_ROWS_PER_CELL), max_cells))
+    parts = max(1, min(32, pow2_floor(n_nodes // (slices * MIN_ROWS_PER_CELL)),
+                       pow2_floor(max_cells // slices)))
+    return parts, slices
+
+
 class _Done:
     def wait(self):
         return None
@@ -177,17 +203,18 @@ class BlockPartitionedTrainer:
     def __init__(self, graph, train_params, d: int, ld: int, seed: int, init_scale: float, comm,
                  device, walk_length: int, window: int, min_dist: int = 1,
                  scale_free: bool = True, backend=None, parts: Optional[int] = None,
-                 slices: int = 1, record: int = 16):
+                 slices: Optional[int] = None, record: int = 16):
         self.graph, self.tp, self.comm = graph, train_params, comm
         self.d, self.ld, self.seed = d, ld, seed
         self.n_nodes = graph.get_number_of_nodes()
         rank, world = comm.rank, comm.world
         self.backend = backend if backend is not None else GpuBlockBackend(graph, device)
-        if parts is None:
-            parts = 1 if world == 1 else 2 * world
+        auto_parts, auto_slices = auto_plan(self.n_nodes, world)
+        parts = auto_parts if parts is None else parts
+        slices = auto_slices if slices is None else slices
         if world > 1 and parts != 2 * world:
             raise ValueError("With several ranks the contextual table is cut into 2 * world parts.")
-        self.parts = parts
+        self.parts, self.slices = parts, slices
         self.plan = self.backend.plan(world=world, rank=rank, parts=parts, slices=slices,
                                       walk_length=walk_length, window=window, min_dist=min_dist,
                                       record=record, flags=int(train_params.flags) & 2)
@@ -310,13 +337,16 @@ class BlockPartitionedTrainer:
         import torch
 
         comm, world, n, ld = self.comm, self.comm.world, self.n_nodes, self.ld
+        if world == 1:
+            # the central partition of the only rank IS the table; parts are released one by one
+            if self.parts == 1:
+                return self.central, self.held[0]
+            context = self.backend.empty_rows(n, ld)
+            for p in sorted(self.held):
+                context[p::self.parts] = self.held[p][: self.part_rows(p)]
+            return self.central, context
         central = self.backend.empty_rows(n, ld)
         context = self.backend.empty_rows(n, ld)
-        if world == 1:
-            central.copy_(self.central)
-            for p, buf in self.held.items():
-                context[p::self.parts] = buf[: self.part_rows(p)]
-            return central, context
         max_c = stripe_rows(n, 0, world)
         padded = self.backend.empty_rows(max_c, ld)
         padded.zero_()

@@ -56,6 +56,10 @@ extern "C" {
  * left in HBM.  Switches: */
 #define GN2V_TRAIN_NO_CTX_CACHE 128u  /* always use the plain kernel                             */
 #define GN2V_TRAIN_CTX_CACHE_ALL 256u /* cache every row regardless of degree (tests)            */
+/* Block trainer with sliced parts: the contextual rows of a slice are touched by one XCD only, so
+ * their updates can be f32 atomics executed inside that XCD's L2 (workgroup scope): no lost
+ * update, no trip to memory. */
+#define GN2V_TRAIN_LOCAL_ATOMIC 512u
 
 #define GN2V_MODEL_SKIPGRAM 0u
 #define GN2V_MODEL_CBOW 1u

@@ -62,6 +62,39 @@ if __name__ == "__main__":
     gen = torch.Generator(device="cuda")
     results = {}
     for mode in a.modes.split(","):
+        if mode.startswith("blocks"):
+            # blocks:<parts>:<slices>[:<record>] -- the block trainer on one GPU
+            from embiggen_amd.distributed import BlockPartitionedTrainer, LoopbackComm
+
+            f = mode.split(":")
+            parts, slices = int(f[1]), int(f[2])
+            record = int(f[3]) if len(f) > 3 and f[3] else 16
+            extra = _lib.TRAIN_LOCAL_ATOMIC if len(f) > 4 and f[4] == "la" else 0
+            tp = ops.train_params(0, d, 10, 5, flags=1 | extra, ld=d)
+            tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
+                                         walk_length=128, window=5, parts=parts, slices=slices,
+                                         record=record)
+            ops.stats_reset(g)
+            t0 = time.time()
+            lr, rounds = a.lr, []
+            for e in range(a.epochs):
+                for first in range(0, a.walks, 1 << 19):
+                    nb = min(1 << 19, a.walks - first)
+                    rounds.append((lambda e=e, first=first, nb=nb: ops.walks(g, wp, 42, e, first, nb),
+                                   42, e, lr, first))
+                lr *= 0.9
+            tr.run(rounds)
+            c, x = tr.gather_full()
+            st = ops.stats_read(g)
+            gen.manual_seed(1)
+            res = evaluate(g, c, x, 200000, gen)
+            print(f"{mode:14s} pairs={st['pairs']:.3e} train_ms={st['train_ms']:.0f} "
+                  f"({st['pairs'] / st['train_ms'] * 1e3:.3e} pairs/s) wall={time.time() - t0:.1f}s "
+                  f"AUC(c.x)={res[0]:.4f} AUC(cos central)={res[1]:.4f} "
+                  f"finite={bool(torch.isfinite(c).all() and torch.isfinite(x).all())} "
+                  f"|c|max={float(c.abs().max()):.3f} |x|max={float(x.abs().max()):.3f}", flush=True)
+            del c, x, tr
+            continue
         c = ops.init_table(n, d, 42, 0, d ** -0.5)
         x = ops.init_table(n, d, 42, 1, d ** -0.5)
         tp = ops.train_params(0, d, 10, 5, flags=1 | flagmap[mode])

@@ -12,6 +12,7 @@ Tables are checked through exact per-row integer checksums so that the 2 x 51.2 
 config 5 need no second copy.  Config 4 additionally runs the block-partitioned multi-GPU trainer
 with 8 simulated ranks at full size (tests/test_gpu_blocks.py holds the small exact cases).
 """
+import numpy as np
 import pytest
 import torch
 
@@ -104,3 +105,67 @@ def test_config5_ba_100m_nodes_1b_edges_full_size_properties():
     assert 1.99e9 < e <= 2 * 999_999_990  # multi-edges collapse: a little under 2 x 10^9
     assert int(g._device_tensors["row_ptr"][-1]) == e
     full_size_properties(g, 1 << 16)
+
+
+def test_config4_block_trainer_with_eight_simulated_ranks_at_full_size():
+    """BASELINE config 4 ("embedding table row-sharded across 8 x MI355X") at its full size with
+    the 8 ranks simulated on one GPU (exact: ranks never share a row): every pair of every round
+    is trained exactly once, the 16 context parts are each held by exactly one rank at the end,
+    tables stay finite and the link quality equals the single trainer's on the same walks."""
+    from embiggen_amd.distributed import BlockPartitionedTrainer, auto_plan
+    from sharded_helpers import link_auc_device, run_ranks
+
+    g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
+    n, d, w, world = g.get_number_of_nodes(), 128, 5, 8
+    wp = ops.walk_params(128, 10, 0.25, 4.0)
+    total, per_round = 1 << 21, 1 << 15
+    tp = ops.train_params(0, d, 10, w, flags=1, ld=d)
+    c = ops.init_table(n, d, 42, 0, d ** -0.5)
+    x = ops.init_table(n, d, 42, 1, d ** -0.5)
+    for first in range(0, total, 1 << 16):
+        ops.sgns_step(g, tp, ops.walks(g, wp, 42, 0, first, 1 << 16), 42, 0, first, 0.025, c, x)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1)
+    auc_single = link_auc_device(g, c, x, gen)
+    del c, x
+    assert auto_plan(n, world) == (16, 4)
+
+    def rank_fn(comm):
+        tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, comm, "cuda:0", walk_length=128,
+                                     window=w)
+        trained = 0
+        for r in range(total // per_round // world):
+            first = r * world * per_round
+            mine = ops.walks(g, wp, 42, 0, first + comm.rank * per_round, per_round)
+            tr.train_round(mine, 42, 0, 0.025, first)
+            trained += tr.last_round["pairs_trained"]
+        held = sorted(tr.held)
+        finite = all_finite(tr.central) and all(all_finite(t) for t in tr.held.values())
+        full = tr.gather_full() if comm.rank == 0 else (tr.gather_full(), None)[1]
+        return trained, held, finite, full
+
+    ops.stats_reset(g)
+    res = run_ranks(world, rank_fn)
+    torch.cuda.synchronize()
+    assert sum(r[0] for r in res) == total * PAIRS_PER_WALK == ops.stats_read(g)["pairs"]
+    assert sorted(p for r in res for p in r[1]) == list(range(2 * world))
+    assert all(r[2] for r in res)
+    bc, bx = res[0][3]
+    gen.manual_seed(1)
+    auc_blocks = link_auc_device(g, bc, bx, gen)
+    assert auc_single > 0.6 and auc_blocks > auc_single - 0.03, (auc_blocks, auc_single)
+
+
+def test_large_graphs_are_fitted_through_the_block_path_on_one_gpu():
+    """``fit_transform`` of the public class on a graph above ``BLOCK_PATH_MIN_NODES``: the block
+    path with the automatic plan; every pair is counted, the result has the API's shape."""
+    g = E.barabasi_albert(400_000, 5, 42)
+    m = E.Node2VecSkipGramEnsmallen(embedding_size=32, epochs=1, iterations=1, walk_length=32,
+                                    window_size=3, verbose=False)
+    res = m.fit_transform(g, return_dataframe=False).get_all_node_embedding()
+    assert res[0].shape == (400_000, 32) and res[1].shape == (400_000, 32)
+    assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
+    assert m._model.last_plan == {"world": 1, "parts": 1, "slices": 8}
+    assert m.get_last_stats()["pairs"] == 400_000 * (2 * 3 * 32 - 3 * 4)
+    init = ops.init_table(400_000, 32, 42, 0, 32 ** -0.5).cpu().numpy()
+    assert np.abs(res[0] - init).max() > 1e-3
