@@ -73,8 +73,10 @@ def parse():
     ap.add_argument("--record", type=int, default=16, help="blocks: pairs per record")
     ap.add_argument("--local-atomic", action="store_true",
                     help="blocks with slices: contextual rows updated by L2-local f32 atomics")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="blocks: prepare every round in line instead of on a second stream")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                    help="blocks: prepare round t + 1 on a second stream while round t trains "
+                         "(auto: with several GPUs, where it hides the walk all-gather; on one GPU "
+                         "preparation and training share the same HBM and nothing is gained)")
     ap.add_argument("--model", default="skipgram", choices=["skipgram", "cbow"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
@@ -230,6 +232,7 @@ def main():
     if mode == "blocks" and cbow:
         raise SystemExit("the block-partitioned trainer is SkipGram only")
     blocks = comm = None
+    overlap = args.overlap == "on" or (args.overlap == "auto" and world > 1)
     if mode == "blocks":
         # tables partitioned by node id; no row is ever held by two GPUs
         comm = TorchComm() if world > 1 else LoopbackComm()
@@ -258,7 +261,7 @@ def main():
 
     def run_steps(first_step, n_steps):
         if blocks is not None:
-            blocks.run(block_rounds(first_step, n_steps), overlap=not args.no_overlap)
+            blocks.run(block_rounds(first_step, n_steps), overlap=overlap)
             return
         train = ops.cbow_step if cbow else ops.sgns_step
         for index in range(first_step, first_step + n_steps):
@@ -381,7 +384,7 @@ def main():
                               f"table in {blocks.parts if blocks else 0} travelling parts x "
                               f"{blocks.slices if blocks else 0} XCD slice(s) (no shared rows), rounds of "
                               f"{min(args.round_walks, args.walks)} walks per GPU, preparation "
-                              f"{'overlapped' if not args.no_overlap else 'in line'}",
+                              f"{'overlapped' if overlap else 'in line'}",
                 }[mode],
             },
             "pairs_per_s": total_pairs / elapsed,

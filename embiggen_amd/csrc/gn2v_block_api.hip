@@ -342,6 +342,8 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
         // every workgroup with write-through stores (normally nothing: the kernel exits at once)
         a.sweep = pass;
         const int x = pass ? (wmc == gn2v::kAtomic ? gn2v::kAtomic : gn2v::kWriteThrough) : wmx;
+        // the sweep normally finds every cell finished: a small grid keeps its ticket reads cheap
+        if (pass) grid = dim3(std::min<unsigned>(grid.x, 8 * d.slices));
         if (nchunks <= 16)
             launch_block_ch<1>(x, wmc, det, grid, block, lds, s, a);
         else if (nchunks <= 32)

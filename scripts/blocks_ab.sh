@@ -6,7 +6,7 @@ out=${1:-gpurun_out/blocks_ab.log}
 run() { echo "### $*" >> $out; python bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" 2>>$out | tail -1 >> $out; }
 run --parallelism single
 run --parallelism blocks
-run --parallelism blocks --no-overlap
+run --parallelism blocks --overlap on
 run --parallelism blocks --parts 16
 run --parallelism blocks --parts 16 --slices 8
 run --parallelism blocks --slices 8
