@@ -502,34 +502,22 @@ int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_l
 }
 
 static int launch_pairs(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
-                        uint32_t window, uint32_t min_dist, uint32_t world, uint64_t salt,
-                        uint32_t *d_pairs, uint64_t *d_keys, bool want_keys, void *stream) {
+                        uint32_t window, uint32_t min_dist, uint32_t *d_pairs, void *stream) {
     DeviceGuard guard(DeviceGuard::of_pointer(d_walks));
     if (window < 1 || walk_length < 2) return fail("need window_size >= 1 and walk_length >= 2");
-    if (want_keys && (world < 1 || world > 32768)) return fail("world must be in [1, 32768]");
     const uint64_t n = n_walks * walk_length * 2 * window;
     if (n == 0) return 0;
-    if (!d_walks || !d_pairs || (want_keys && !d_keys)) return fail("NULL pointer");
+    if (!d_walks || !d_pairs) return fail("NULL pointer");
     const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(gn2v::pairs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_walks,
-                       n_walks, walk_length, window, min_dist ? min_dist : 1u, d_pairs,
-                       (unsigned long long *)(want_keys ? d_keys : nullptr), world ? world : 1u,
-                       salt);
+                       n_walks, walk_length, window, min_dist ? min_dist : 1u, d_pairs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int gn2v_walk_pairs(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
                     uint32_t window, uint32_t min_dist, uint32_t *d_pairs, void *stream) {
-    return launch_pairs(d_walks, n_walks, walk_length, window, min_dist, 1, 0, d_pairs, nullptr,
-                        false, stream);
-}
-
-int gn2v_walk_pair_blocks(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
-                          uint32_t window, uint32_t min_dist, uint32_t world, uint64_t salt,
-                          uint32_t *d_pairs, uint64_t *d_keys, void *stream) {
-    return launch_pairs(d_walks, n_walks, walk_length, window, min_dist, world, salt, d_pairs,
-                        d_keys, true, stream);
+    return launch_pairs(d_walks, n_walks, walk_length, window, min_dist, d_pairs, stream);
 }
 
 int gn2v_cooc_slots(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,

@@ -345,17 +345,10 @@ static __global__ void window_kernel(const uint32_t *__restrict__ walks, uint64_
 }
 
 // (centre, context) pairs of every walk position, window trimmed at the walk borders: slot
-// [walk][position][2w] holds the pair or (sentinel, sentinel).  Feeds the block-partitioned
-// multi-GPU trainer, which buckets pairs by (centre partition, context partition).
-// With keys != nullptr every slot also gets the sort key of the block-partitioned trainer:
-// ((centre % world) * world + context % world) << 31 | 31-bit hashed salt, or INT64_MAX for an
-// unused slot -- one radix sort then groups the pairs by block, shuffles them inside a block and
-// pushes the unused slots to the end.  With salt == ~0 the key is block << 32 | centre: the sort
-// then also groups the pairs of a block by centre node (for packing them into centre records).
-static __global__ void pairs_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks, uint32_t L,
-                             uint32_t w, uint32_t min_dist, uint32_t *__restrict__ pairs,
-                             unsigned long long *__restrict__ keys, uint32_t world,
-                             uint64_t salt) {
+// [walk][position][2w] holds the pair or (sentinel, sentinel).
+static __global__ void pairs_kernel(const uint32_t *__restrict__ walks, uint64_t n_walks,
+                                    uint32_t L, uint32_t w, uint32_t min_dist,
+                                    uint32_t *__restrict__ pairs) {
     const uint64_t n = n_walks * L * 2 * w;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
          t += (uint64_t)gridDim.x * blockDim.x) {
@@ -376,16 +369,6 @@ static __global__ void pairs_kernel(const uint32_t *__restrict__ walks, uint64_t
         }
         pairs[2 * t] = c;
         pairs[2 * t + 1] = x;
-        if (keys) {
-            unsigned long long key = 0x7FFFFFFFFFFFFFFFULL;
-            if (c != kSentinel) {
-                const unsigned long long block = (c % world) * world + x % world;
-                // salt == ~0: group by centre inside the block (centre-record packing) instead of
-                // shuffling the pairs
-                key = salt == ~0ULL ? (block << 32) | c : (block << 31) | (mix64(t + salt) >> 33);
-            }
-            keys[t] = key;
-        }
     }
 }
 

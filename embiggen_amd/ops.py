@@ -80,22 +80,6 @@ def walk_pairs(walks_tensor, window: int, min_dist: int = 1):
     return slots[slots[:, 0] != -1]
 
 
-def walk_pair_blocks(walks_tensor, window: int, min_dist: int, world: int, salt: int):
-    """(pair slots int32 [n_slots, 2], keys int64 [n_slots]) for the block-partitioned trainer:
-    sorting by key groups the pairs by (centre partition, context partition), shuffles them
-    inside a block and moves the unused slots (key INT64_MAX) to the end."""
-    torch = _torch()
-    n_walks, L = walks_tensor.shape
-    dev = walks_tensor.device
-    n_slots = n_walks * L * 2 * window
-    slots = torch.empty((n_slots, 2), dtype=torch.int32, device=dev)
-    keys = torch.empty((n_slots,), dtype=torch.int64, device=dev)
-    _lib.check(_lib.lib().gn2v_walk_pair_blocks(
-        walks_tensor.data_ptr(), n_walks, L, window, min_dist, world, salt & (2 ** 64 - 1),
-        slots.data_ptr(), keys.data_ptr(), _stream(dev)))
-    return slots, keys
-
-
 def cooc_slots(walks_t, window: int, min_dist: int = 1):
     """Co-occurrence slots of the walks: (keys int64, weights int64), each [n_walks * L * 2w];
     unused slots hold (INT64_MAX, 0)."""

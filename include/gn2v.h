@@ -150,18 +150,10 @@ int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_l
 
 /* Every (centre, context) pair of the walks, window trimmed at the borders, contexts at distance
  * [min_dist, window]: d_pairs u32[n_walks][walk_length][2*window][2], unused slots hold
- * (GN2V_SENTINEL, GN2V_SENTINEL).  Input of the block-partitioned multi-GPU trainer. */
+ * (GN2V_SENTINEL, GN2V_SENTINEL).  The flat pair list of a batch of walks (tests, tools); the
+ * block-partitioned trainer extracts its pairs with gn2v_block_count / gn2v_block_extract. */
 int gn2v_walk_pairs(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
                     uint32_t window, uint32_t min_dist, uint32_t *d_pairs, void *stream);
-/* Same, plus d_keys u64[n_walks][walk_length][2*window]: the block-partitioned trainer's sort key
- * ((centre % world) * world + context % world) << 31 | hashed 31-bit salt, INT64_MAX for unused
- * slots (so that one sort groups by block, shuffles inside a block and drops the unused slots).
- * salt = UINT64_MAX selects the grouping key block << 32 | centre instead: the sort then also
- * brings the pairs of one centre node together (packed into centre records by the trainer). */
-int gn2v_walk_pair_blocks(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,
-                          uint32_t window, uint32_t min_dist, uint32_t world, uint64_t salt,
-                          uint32_t *d_pairs, uint64_t *d_keys, void *stream);
-
 /* table[r][c] = uniform(-scale, scale) from a hash of (seed, table_id, r, c); padding = 0 */
 int gn2v_init_table(float *d_table, uint64_t n_rows, uint32_t d, uint32_t ld, uint64_t seed,
                     uint32_t table_id, float scale, void *stream);
