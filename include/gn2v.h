@@ -70,7 +70,8 @@ typedef struct {
     uint32_t iterations;     /* walks per source node per epoch                   */
     float return_weight;     /* 1/p                                                */
     float explore_weight;    /* 1/q                                                */
-    uint32_t max_neighbours; /* accepted; walks are exact regardless   */
+    uint32_t max_neighbours; /* accepted; walks are exact for every value: the law the
+                                reference's sub-sampled walks approximate */
     uint32_t flags;          /* reserved                                           */
     /* node2vec_skipgram.py:72-77, node2vec_sequence.py:57-66.  0 = unset = 1.0.  "Only applies
      * to colored graphs / multigraphs, otherwise it has no impact": they act only when the

@@ -144,3 +144,22 @@ def test_normalize_by_degree_walks_and_fit(karate):
                                         verbose=False).fit_transform(karate, return_dataframe=False)
     assert np.isfinite(res[0]).all()
     assert not np.array_equal(res[0], plain.get_all_node_embedding()[0])
+
+
+def test_max_neighbours_of_the_smoke_configuration_is_accepted_and_walks_stay_exact(karate,
+                                                                                    karate_oracle):
+    """The smoke configuration of the reference sets ``max_neighbours=10``
+    (embedders/ensmallen_embedders/node2vec.py:79-87; meaning: node2vec_skipgram.py:78-81).  The
+    engine's walks are exact for every value (tests/test_oracle.py::
+    test_max_neighbours_never_changes_the_walks states why that is the law the approximation
+    approximates): same walks on the GPU, through the C ABI, for 10, 100 and "unset"."""
+    import embiggen_amd as E
+
+    smoke = E.Node2VecSkipGramEnsmallen().into_smoke_test()
+    assert smoke.parameters()["max_neighbours"] == 10
+    res = smoke.fit_transform(karate, return_dataframe=False).get_all_node_embedding()
+    assert res[0].shape == (34, 5) and np.isfinite(res[0]).all()
+    ref = O.walks(karate_oracle, O.WalkParams(16, 2, 0.25, 4.0, 100, 0), 9, 0, 0, 68)
+    for mn in (10, 100, None, 3):
+        wk = ops.walks(karate, ops.walk_params(16, 2, 0.25, 4.0, max_neighbours=mn), 9, 0, 0, 68)
+        assert np.array_equal(wk.cpu().numpy().view(np.uint32), ref)

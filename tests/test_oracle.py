@@ -297,3 +297,42 @@ def test_normalize_by_degree_is_a_destination_degree_weighting(karate):
         counts = np.array([(nxt == x).sum() for x in neigh], dtype=np.float64)
         p = 1.0 / deg[neigh]
         assert stats.chisquare(counts, p / p.sum() * counts.sum()).pvalue > 1e-4
+
+
+@pytest.mark.parametrize("max_neighbours", [10, 3, 100, 0])
+def test_max_neighbours_never_changes_the_walks(karate, karate_oracle, max_neighbours):
+    """``max_neighbours`` (node2vec_skipgram.py:22,78-81: "Number of maximum neighbours to
+    consider when using approximated walks ... mainly useful for graphs containing nodes with high
+    degrees"; the smoke configuration sets it to 10, node2vec.py:79-87) is the reference's CPU-cost
+    approximation of the exact walk: candidates are drawn from a uniform sub-sample of the
+    neighbours of a hub.  The engine never needs the approximation (rejection sampling costs O(1)
+    per step whatever the degree), so the kwarg is accepted and walks are EXACT for every value:
+
+    * first-order walks on unweighted graphs: a uniform pick from a uniform sub-sample IS a
+      uniform pick from all neighbours, so exact and sub-sampled walks have the same law;
+    * second-order / weighted walks: the exact transition law is what the sub-sampled walk
+      approximates (its limit for max_neighbours -> infinity).
+
+    Karate's hubs have 16-17 neighbours (> 10): with max_neighbours = 10 the transition
+    frequencies still match the exact node2vec law, and the walks are identical for any value."""
+    rw, ew = 0.25, 4.0
+    assert max(np.diff(karate.row_ptr.astype(np.int64))) > 10
+    ref = O.walks(karate_oracle, O.WalkParams(12, 1, rw, ew, 100, 0), 7, 0, 0, 34 * 1500)
+    w = O.walks(karate_oracle, O.WalkParams(12, 1, rw, ew, max_neighbours, 0), 7, 0, 0, 34 * 1500)
+    assert np.array_equal(w, ref)
+    w = w.astype(np.int64)
+    prev, cur, nxt = w[:, :-2].ravel(), w[:, 1:-1].ravel(), w[:, 2:].ravel()
+    key = prev * 34 + cur
+    hubs = [v for v in range(34) if karate.row_ptr[v + 1] - karate.row_ptr[v] > 10]
+    pvals = []
+    for k in np.unique(key):
+        p, c = divmod(int(k), 34)
+        sel = key == k
+        if c not in hubs or sel.sum() < 1500:
+            continue
+        neigh, probs = exact_second_order_probs(karate, p, c, rw, ew)
+        counts = np.array([(nxt[sel] == x).sum() for x in neigh], dtype=np.float64)
+        if (probs * counts.sum() < 5).any():
+            continue
+        pvals.append(stats.chisquare(counts, probs * counts.sum()).pvalue)
+    assert len(pvals) >= 5 and min(pvals) > 1e-3 / len(pvals), (pvals,)
