@@ -212,7 +212,7 @@ class _WalkBasedModel:
     # graphs from this size on are trained through the block path on one GPU as well (contextual
     # rows in XCD-exclusive cells: 0.87 instead of 0.70 of the HBM roofline at 10 M nodes, link
     # quality at or above the walk-ordered schedule's)
-    BLOCK_PATH_MIN_NODES = 1 << 18
+    BLOCK_PATH_MIN_NODES = 1 << 16
 
     def fit_transform_blocks(self, graph, comm, round_walks: int = 1 << 20, slices=None,
                              parts=None, overlap: bool = True, max_walks_per_epoch: int = 0):
