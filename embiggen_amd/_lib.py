@@ -94,7 +94,6 @@ class StepIO(C.Structure):
         ("neg_id_mul", C.c_uint32),
         ("neg_id_add", C.c_uint32),
         ("d_neg_override", C.c_void_p),
-        ("pair_mode", C.c_uint32),
     ]
 
 

@@ -205,9 +205,6 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     a.split = a.negative != positive_table;
     if (a.split && g->view.n_nodes >= (1ULL << 31))
         return fail("separate negative tables need node ids below 2^31");
-    a.pair_mode = io->pair_mode ? 1u : 0u;
-    if (a.pair_mode && (cbow || tp->window != L - 1))
-        return fail("pair mode needs SkipGram and records of 1 + window_size ids");
     a.neg_pool = io->d_neg_pool;
     a.neg_pool_size = io->neg_pool_size;
     if (a.neg_pool && a.neg_pool_size == 0) return fail("empty negative pool");
@@ -241,16 +238,6 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     if (lds > 64 * 1024) return fail("walk_length / window / negatives too large for the LDS plan");
     uint64_t blocks = det ? 1 : (n_walks + waves_per_block - 1) / waves_per_block;
     uint64_t cap = (uint64_t)g->n_cus * 8;
-    if (a.pair_mode && !det) {
-        // Records of one centre node are trained by different waves from the same stale copy of
-        // its row; on tiny graphs thousands of concurrent waves would apply hundreds of such
-        // updates at once (measured: rows grow 5x on 256 nodes, divergence on smaller blocks).
-        // At most one concurrent wave per table row on average keeps the staleness of the
-        // walk-ordered schedule; graphs with more rows than resident waves are unaffected.
-        const uint64_t rows = g->view.n_nodes / (a.neg_id_mul ? a.neg_id_mul : 1u);
-        const uint64_t max_blocks = std::max<uint64_t>(1, rows / waves_per_block);
-        if (cap > max_blocks) cap = max_blocks;
-    }
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kTrainBlock);
 
@@ -260,7 +247,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
                                 (cbow ? 2 * tp->window : 0) + 2 * slots + 3) &
                                ~(size_t)3;
     const size_t cache_lds = (size_t)waves_per_block * cache_words * 4;
-    const bool use_cache = !det && wm != gn2v::kAtomic && !a.pair_mode && !a.split &&
+    const bool use_cache = !det && wm != gn2v::kAtomic && !a.split &&
                            !a.walk_rows && !a.neg_pool && !(tp->flags & GN2V_TRAIN_NO_CTX_CACHE) &&
                            cache_lds <= 40 * 1024 && L > 2 * tp->window &&
                            g->view.n_nodes < (1ULL << 30);  // row ids share a word with kCacheBit

@@ -35,7 +35,6 @@ struct TrainArgs {
     uint64_t neg_pool_size;
     uint32_t neg_id_mul, neg_id_add;  // global id of negative row r = r * mul + add (skip rule)
     uint32_t split;             // 1 when `negative` is a different table than the positive one
-    uint32_t pair_mode;         // walks are (centre, context) records: only position 0 is a centre
     uint32_t cache_max_degree;  // context cache: rows of nodes with degree >= this stay in HBM
                                 // (0xFFFFFFFF = cache every row)
     unsigned long long *counters;  // [0] pairs, [1] walk steps, [2] centres
@@ -400,8 +399,7 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
         const uint64_t nkey = wkey ^ kTagNeg;
         const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
 
-        const uint32_t n_centres = a.pair_mode ? min(Le, 1u) : Le;
-        for (uint32_t i = 0; i < n_centres; ++i) {
+        for (uint32_t i = 0; i < Le; ++i) {
             const uint32_t c = s_walk[i];
             if (!keep_centre(a, wkey, i, c)) continue;
             const float lrc = centre_lr(a, c);
@@ -449,8 +447,7 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_kernel(TrainArgs a) {
         }
         wave_sync();
     }
-    // one atomic per wave: a per-walk atomic on a single counter serialises at ~12 ns each and
-    // dominated the pair-list mode (328 M one-pair "walks" -> 7.9 s of counter traffic)
+    // one atomic per wave: a per-walk atomic on a single counter serialises at ~12 ns each
     if (a.counters && lane == 0 && pairs) {
         atomicAdd(&a.counters[0], pairs);
         atomicAdd(&a.counters[2], centres);
@@ -798,8 +795,7 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
         }
         wave_sync();
     }
-    // one atomic per wave: a per-walk atomic on a single counter serialises at ~12 ns each and
-    // dominated the pair-list mode (328 M one-pair "walks" -> 7.9 s of counter traffic)
+    // one atomic per wave: a per-walk atomic on a single counter serialises at ~12 ns each
     if (a.counters && lane == 0 && pairs) {
         atomicAdd(&a.counters[0], pairs);
         atomicAdd(&a.counters[2], centres);

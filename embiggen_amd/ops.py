@@ -244,7 +244,7 @@ def cbow_step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, con
 
 def step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, contextual,
          walk_rows=None, negative=None, neg_pool=None, neg_id_mul: int = 0, neg_id_add: int = 0,
-         neg_override=None, pair_mode: bool = False):
+         neg_override=None):
     """General training step (``gn2v_step``): ``walk_rows`` gives the row of every walk node in
     ``central`` / ``contextual`` (compact row caches), negatives are rows of ``negative`` drawn
     from ``neg_pool``.  ``tp.model`` selects SkipGram / CBOW."""
@@ -257,7 +257,7 @@ def step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, contextu
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     io = _lib.StepIO(ptr(walks_tensor), ptr(walk_rows), ptr(central), ptr(contextual),
                      ptr(negative), ptr(neg_pool), 0 if neg_pool is None else neg_pool.numel(),
-                     neg_id_mul, neg_id_add, ptr(neg_override), 1 if pair_mode else 0)
+                     neg_id_mul, neg_id_add, ptr(neg_override))
     _lib.check(_lib.lib().gn2v_step(dg.handle, C.byref(tp), C.byref(io), n_walks, L, seed, epoch,
                                     first_walk, lr, _stream(dev)))
 

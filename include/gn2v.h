@@ -172,8 +172,8 @@ int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d
                    uint64_t first_walk, float lr, float *d_central, float *d_contextual,
                    const uint32_t *d_neg_override, void *stream);
 
-/* General form of one training step, used by the row-sharded multi-GPU trainer (DESIGN.md
- * section 7): the walk nodes may live in compact row caches (d_walk_rows gives the row of every
+/* General form of one training step (the row-cache experiments of DESIGN.md section 7.1 run
+ * through it): the walk nodes may live in compact row caches (d_walk_rows gives the row of every
  * walk position in d_central / d_contextual) while negatives are drawn from a caller-supplied pool
  * of rows of a third table (the local shard).  With every optional field NULL / 0 this is exactly
  * gn2v_sgns_step / gn2v_cbow_step. */
@@ -189,10 +189,6 @@ typedef struct {
     uint32_t neg_id_mul;         /* global id of negative row r = r * mul + add (0, 0 = identity), */
     uint32_t neg_id_add;         /*   used to skip negatives equal to the centre / context       */
     const uint32_t *d_neg_override;
-    uint32_t pair_mode;          /* 1: d_walks holds centre records [centre, context_1 .. context_C]
-                                    (walk_length 1 + C, window C, unused tail = GN2V_SENTINEL;
-                                    C = 1: plain pairs) and only position 0 acts as a centre
-                                    (SkipGram)                                                   */
 } gn2v_step_io;
 
 int gn2v_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_step_io *io,

@@ -97,7 +97,6 @@ typedef struct {
     uint64_t neg_pool_size;
     uint32_t neg_id_mul, neg_id_add;
     const uint32_t *neg_override;
-    uint32_t pair_mode; /* walks are (centre, context) records: only position 0 is a centre */
 } o_step_io;
 
 /* ---------------------------------------------------------------- RNG */
@@ -449,8 +448,7 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const o_step_io *io
     uint32_t d = tp->d, ld = tp->ld, w = tp->window, k = tp->k, md = min_dist_of(tp);
     uint32_t Le = effective_len(walk, L);
     uint64_t nkey = wkey ^ O_TAG_NEG;
-    uint32_t n_centres = io->pair_mode ? (Le ? 1 : 0) : Le;
-    for (uint32_t i = 0; i < n_centres; ++i) {
+    for (uint32_t i = 0; i < Le; ++i) {
         uint32_t c = walk[i];
         if (!keep_centre(g, tp, wkey, i, c)) continue;
         if (context_count(i, Le, w, md) == 0) continue;

@@ -181,14 +181,13 @@ class StepIO(C.Structure):
         ("neg_id_mul", C.c_uint32),
         ("neg_id_add", C.c_uint32),
         ("neg_override", C.c_void_p),
-        ("pair_mode", C.c_uint32),
     ]
 
 
 def train_walks_ex(g: OracleGraph, tp: TrainParams, walks_arr, seed: int, epoch: int,
                    first_walk: int, lr: float, central, contextual, walk_rows=None,
                    negative=None, neg_pool=None, neg_id_mul: int = 0, neg_id_add: int = 0,
-                   neg_override=None, threads: int = 1, pair_mode: bool = False):
+                   neg_override=None, threads: int = 1):
     """General step (mirrors gn2v_step): walk nodes addressed through ``walk_rows``, negatives
     drawn from ``neg_pool`` as rows of ``negative``.  All arrays are updated in place."""
     walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
@@ -207,7 +206,6 @@ def train_walks_ex(g: OracleGraph, tp: TrainParams, walks_arr, seed: int, epoch:
             setattr(io, name, arr.ctypes.data)
     io.neg_pool_size = 0 if neg_pool is None else int(np.asarray(neg_pool).size)
     io.neg_id_mul, io.neg_id_add = neg_id_mul, neg_id_add
-    io.pair_mode = 1 if pair_mode else 0
     n_walks, L = walks_arr.shape
     lib().o_train_walks_ex(C.byref(g.c), C.byref(tp), C.byref(io), C.c_uint64(n_walks),
                            C.c_uint32(L), C.c_uint64(seed), C.c_uint64(epoch),

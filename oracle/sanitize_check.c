@@ -76,7 +76,7 @@ int main(void) {
                 o_train_params tp = {model, 10, 12, 2, 4, 3, 0.02f, 0.9f, 6.0f, flags, 0.3f, md};
                 o_fit(&g, &wp, &tp, sources, ns, 11, c, x, flags & 1 ? 2 : 1);
             }
-    /* pair mode through the general step with a pool and row indirection */
+    /* two-node walks through the general step with a pool and row indirection */
     o_train_params tp = {0, 10, 12, 1, 4, 1, 0.02f, 0.9f, 6.0f, 1, 0.3f, 1};
     uint32_t *rows = malloc(sizeof(uint32_t) * np * 2);
     for (uint64_t i = 0; i < np * 2; ++i) rows[i] = pairs[i];
@@ -89,8 +89,30 @@ int main(void) {
     io.neg_pool = col;
     io.neg_pool_size = e;
     io.neg_id_mul = 1;
-    io.pair_mode = 1;
     o_train_walks_ex(&g, &tp, &io, np, 2, 3, 0, 0, 0.02f, 1);
+
+    /* block-partitioned schedule: extraction, stable sort, pools, one round over every part */
+    {
+        o_block_plan bp = {3, 1, 6, 2, 20, 3, 1, 4, o_block_row_bits(N, 3), 0};
+        uint64_t nw = ns * 3, cap = nw * 20 * 6;
+        uint32_t *bk = malloc(sizeof(uint32_t) * cap), *bv = malloc(sizeof(uint32_t) * cap);
+        uint64_t nb = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, bk, bv);
+        o_block_sort(bk, bv, nb);
+        uint64_t off[13], poff[13];
+        o_block_cell_offsets(bk, nb, bp.row_bits, 12, off);
+        uint32_t *pool = malloc(sizeof(uint32_t) * e);
+        o_block_pool(&g, 6, 2, pool, poff);
+        uint64_t crows = (N + 3 - 1 - 1) / 3 + 1, xrows = N / 6 + 1, trained = 0;
+        float *bc = malloc(sizeof(float) * crows * 12), *bx = malloc(sizeof(float) * xrows * 12);
+        o_init_table_rows(bc, (N - 1 + 2) / 3, 10, 12, 5, 0, 0.3f, 1, 3);
+        for (uint32_t part = 0; part < 6; ++part) {
+            o_init_table_rows(bx, (N - part + 5) / 6, 10, 12, 5, 1, 0.3f, part, 6);
+            trained += o_block_step(&g, &tp, &bp, bk, bv, off, pool, poff, bc, bx, 2, part, 7, 1,
+                                    0.02f);
+        }
+        if (trained != nb) return 1;
+        free(bk); free(bv); free(pool); free(bc); free(bx);
+    }
 
     uint32_t *bs = malloc(sizeof(uint32_t) * 999 * 4), *bd = malloc(sizeof(uint32_t) * 999 * 4);
     o_ba_edges(1000, 4, 42, bs, bd);
