@@ -118,8 +118,9 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
     const uint32_t waves_per_block = kPrepBlock / 64;
     const uint32_t cells = a.p.parts * a.p.slices;
     const uint32_t L = a.p.L, w = a.p.window, w2 = 2 * a.p.window;
-    uint32_t *s_walk = smem + wave * L;
-    unsigned int *s_hist = smem + waves_per_block * L + wave * cells;
+    uint32_t *s_walk = smem + wave * 2 * L;
+    uint32_t *s_own = s_walk + L;
+    unsigned int *s_hist = smem + waves_per_block * 2 * L + wave * cells;
     const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;
     const uint64_t chunk = (a.n_walks + kPrepWaves - 1) / kPrepWaves;
     const uint64_t b0 = gw * chunk;
@@ -142,24 +143,37 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
         for (int off = 32; off > 0; off >>= 1) Le = min(Le, (uint32_t)__shfl_xor(Le, off));
         wave_sync();
         const uint64_t wkey = draw(a.ekey, a.first_walk + b);
-        const uint32_t n_slots = Le * w2;
+        // positions whose centre this rank owns (1 / world of them), compacted in walk order
+        uint32_t n_own = 0;
+        for (uint32_t i0 = 0; i0 < Le; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            bool own = false;
+            if (i < Le) {
+                const uint32_t c = s_walk[i];
+                own = c % a.p.world == a.p.rank &&
+                      (!(a.p.flags & kFlagDownsample) || keep_centre_at(a.g, wkey, i, c));
+            }
+            const uint64_t m = __ballot(own);
+            if (own) s_own[n_own + __popcll(m & lt_mask)] = i;
+            n_own += __popcll(m);
+        }
+        wave_sync();
+        const uint32_t n_slots = n_own * w2;
         for (uint32_t t0 = 0; t0 < n_slots; t0 += 64) {
             const uint32_t t = t0 + lane;
             bool valid = false;
             uint32_t key = 0, val = 0, cell = 0;
             if (t < n_slots) {
-                const uint32_t i = t / w2, slot = t - i * w2;
+                const uint32_t idx = t / w2, slot = t - idx * w2;
+                const uint32_t i = s_own[idx];
                 const int64_t j = slot < w ? (int64_t)i - w + slot : (int64_t)i + 1 + (slot - w);
                 if (j >= 0 && j < (int64_t)Le) {
                     const uint32_t dist = (uint32_t)(j > (int64_t)i ? j - i : i - j);
-                    const uint32_t c = s_walk[i];
-                    const uint32_t crow = c / a.p.world;
-                    if (dist >= a.p.min_dist && c - crow * a.p.world == a.p.rank &&
-                        (!(a.p.flags & kFlagDownsample) || keep_centre_at(a.g, wkey, i, c))) {
+                    if (dist >= a.p.min_dist) {
                         const uint32_t x = s_walk[j];
                         val = x / a.p.parts;
                         cell = (x - val * a.p.parts) * a.p.slices + val % a.p.slices;
-                        key = (cell << a.p.row_bits) | crow;
+                        key = (cell << a.p.row_bits) | (s_walk[i] / a.p.world);
                         valid = true;
                     }
                 }

@@ -169,7 +169,7 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     a.keys = keys;
     a.vals = vals;
     const uint32_t cells = d.parts * d.slices;
-    const size_t lds = (size_t)(gn2v::kPrepBlock / 64) * (d.L + cells) * 4;
+    const size_t lds = (size_t)(gn2v::kPrepBlock / 64) * (2 * d.L + cells) * 4;
     if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
     const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
     if (write)
