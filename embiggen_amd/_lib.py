@@ -38,8 +38,8 @@ EXPORTS = [
     "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_edge_embedding",
     "gn2v_cooc_slots", "gn2v_glove_step",
     "gn2v_touch_rows",
-    "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_pool_temp_bytes",
-    "gn2v_block_pool", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
+    "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
+    "gn2v_block_alias", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
     "gn2v_block_extract", "gn2v_block_step",
     "gn2v_stats_reset",
     "gn2v_stats_read",
@@ -110,8 +110,8 @@ class BlockIO(C.Structure):
         ("d_keys", C.c_void_p),
         ("d_vals", C.c_void_p),
         ("d_cell_offsets", C.c_void_p),
-        ("d_pool", C.c_void_p),
-        ("d_pool_offsets", C.c_void_p),
+        ("d_alias", C.c_void_p),
+        ("d_cell_rows", C.c_void_p),
         ("d_central", C.c_void_p),
         ("d_context", C.c_void_p),
         ("block_id", C.c_uint64),
@@ -155,7 +155,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [
         hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-shared",
-        "-fPIC", "-parallel-jobs=2", *[os.path.join(_CSRC, u) for u in _UNITS], "-o", LIB_PATH,
+        "-fPIC", "-parallel-jobs=2", *os.environ.get("GN2V_HIPCC_FLAGS", "").split(),
+        *[os.path.join(_CSRC, u) for u in _UNITS], "-o", LIB_PATH,
     ]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
@@ -212,8 +213,8 @@ def lib():
     L.gn2v_touch_rows.argtypes = [vp, u32, vp, u64, u32, vp]
     L.gn2v_block_plan_check.argtypes = [vp, C.POINTER(BlockPlan)]
     L.gn2v_init_table_rows.argtypes = [vp, u64, u32, u32, u64, u32, f32, u64, u64, vp]
-    L.gn2v_block_pool_temp_bytes.argtypes = [u64, C.POINTER(u64)]
-    L.gn2v_block_pool.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, u64, vp]
+    L.gn2v_block_alias_temp_bytes.argtypes = [u64, C.POINTER(u64)]
+    L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, u64, vp]
     L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, vp, vp]
     L.gn2v_block_extract_temp_bytes.argtypes = [u64, C.POINTER(u64)]
     L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, u64,

@@ -43,43 +43,93 @@ __device__ __forceinline__ uint32_t xcc_id() {
 }
 
 // --------------------------------------------------------------------------------------------
-// Negative pools: pool[cell] = the rows (x / parts) of every directed-edge endpoint x in the cell,
-// so a uniform draw from it is degree proportional within the cell.  Built once per graph and
-// plan: keys = cell of col_idx[e], values = row; one stable radix sort; a histogram for the
-// offsets.
+// Negative sampling inside a cell, proportional to the degree (use_scale_free_distribution,
+// node2vec_skipgram.py:101-102: a uniform random edge's endpoint): one Walker alias table per cell,
+// 8 B per row (threshold on a 2^32 scale | alias row << 32), built once per graph and plan.  A draw
+// costs one 8 B read from a table that stays L2 resident (39 k rows = 312 KB per cell on the bench
+// graph) -- a pool of edge endpoints, the first form of this sampler, was 4 B per directed edge:
+// 3 MB per cell of uniformly hit lines competing with the embedding rows for the 4 MB of L2.
+// All arithmetic is integer (weights = in-degrees), so the oracle builds identical tables.
 // --------------------------------------------------------------------------------------------
-__global__ void pool_keys_kernel(const uint32_t *__restrict__ col, uint64_t n_edges, uint32_t parts,
-                                 uint32_t slices, uint32_t *__restrict__ keys,
-                                 uint32_t *__restrict__ rows,
-                                 unsigned long long *__restrict__ cell_counts) {
-    __shared__ unsigned int hist[kMaxCells];
-    const uint32_t cells = parts * slices;
-    for (uint32_t c = threadIdx.x; c < cells; c += blockDim.x) hist[c] = 0;
-    __syncthreads();
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
-         e += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t x = col[e];
-        const uint32_t row = x / parts;
-        const uint32_t cell = (x - row * parts) * slices + row % slices;
-        keys[e] = cell;
-        rows[e] = row;
-        atomicAdd(&hist[cell], 1u);
-    }
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < cells; c += blockDim.x)
-        if (hist[c]) atomicAdd(&cell_counts[c], (unsigned long long)hist[c]);
+__device__ __host__ __forceinline__ uint64_t stripe_count(uint64_t n, uint64_t first,
+                                                          uint64_t stride) {
+    return n > first ? (n - first + stride - 1) / stride : 0;
 }
 
-// offsets[0 .. n] = exclusive prefix sums of counts[0 .. n) (one small block)
-__global__ void offsets_kernel(const unsigned long long *__restrict__ counts, uint32_t n,
-                               unsigned long long *__restrict__ offsets) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        unsigned long long run = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            offsets[i] = run;
-            run += counts[i];
+// floor(w * 2^32 / D) for w < D < 2^48, in two 16-bit steps (no 128-bit division on the device)
+__device__ __host__ __forceinline__ unsigned long long scaled_threshold(unsigned long long w,
+                                                                        unsigned long long D) {
+    const unsigned long long q1 = (w << 16) / D, r1 = (w << 16) % D;
+    return (q1 << 16) | ((r1 << 16) / D);
+}
+
+static __global__ void indegree_kernel(const uint32_t *__restrict__ col, uint64_t n_edges,
+                                       uint32_t *__restrict__ indeg) {
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
+         e += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&indeg[col[e]], 1u);
+}
+
+// cell_rows[c] = first table entry of cell c (cells in order, rows of a cell in order)
+static __global__ void cell_rows_kernel(uint64_t n_nodes, uint32_t parts, uint32_t slices,
+                                        unsigned long long *__restrict__ cell_rows) {
+    if (threadIdx.x || blockIdx.x) return;
+    unsigned long long run = 0;
+    for (uint32_t p = 0; p < parts; ++p) {
+        const uint64_t part_rows = stripe_count(n_nodes, p, parts);
+        for (uint32_t sl = 0; sl < slices; ++sl) {
+            cell_rows[p * slices + sl] = run;
+            run += stripe_count(part_rows, sl, slices);
         }
-        offsets[n] = run;
+    }
+    cell_rows[parts * slices] = run;
+}
+
+// Vose's construction, one thread per cell, integer arithmetic: row i of the cell has weight
+// p_i = indeg_i * n against the cell total D; "small" rows (p < D) keep threshold p * 2^32 / D and
+// borrow the rest from a "large" row.  work: u64 weight[n_nodes] | u32 stack[n_nodes].
+static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t n_nodes,
+                                    uint32_t parts, uint32_t slices,
+                                    const unsigned long long *__restrict__ cell_rows,
+                                    unsigned long long *__restrict__ table,
+                                    unsigned long long *__restrict__ weight,
+                                    uint32_t *__restrict__ stack) {
+    const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= parts * slices) return;
+    const uint32_t part = cell / slices, slice = cell - part * slices;
+    const uint64_t lo = cell_rows[cell], n = cell_rows[cell + 1] - lo;
+    if (n == 0) return;
+    unsigned long long *w = weight + lo, *t = table + lo;
+    uint32_t *st = stack + lo;
+    unsigned long long D = 0;
+    for (uint64_t i = 0; i < n; ++i) D += indeg[(slice + (uint64_t)slices * i) * parts + part];
+    uint64_t n_small = 0, n_large = 0;  // small stack grows from st[0], large from st[n - 1]
+    for (uint64_t i = 0; i < n; ++i) {
+        const unsigned long long p = (unsigned long long)indeg[(slice + (uint64_t)slices * i) * parts + part] * n;
+        w[i] = p;
+        if (D == 0 || p >= D)
+            st[n - 1 - n_large++] = (uint32_t)i;
+        else
+            st[n_small++] = (uint32_t)i;
+    }
+    while (n_small && n_large) {
+        const uint32_t sidx = st[--n_small];
+        const uint32_t lidx = st[n - n_large];  // top of the large stack
+        t[sidx] = ((unsigned long long)lidx << 32) | scaled_threshold(w[sidx], D);
+        const unsigned long long pl = w[lidx] + w[sidx] - D;
+        w[lidx] = pl;
+        if (pl < D) {  // the large row became small: move it over
+            --n_large;
+            st[n_small++] = lidx;
+        }
+    }
+    while (n_large) {
+        const uint32_t i = st[n - n_large--];
+        t[i] = ((unsigned long long)i << 32) | 0xFFFFFFFFull;
+    }
+    while (n_small) {  // only through rounding
+        const uint32_t i = st[--n_small];
+        t[i] = ((unsigned long long)i << 32) | 0xFFFFFFFFull;
     }
 }
 
@@ -242,8 +292,9 @@ struct BlockArgs {
     const uint32_t *keys;   // sorted: cell << row_bits | centre row
     const uint32_t *vals;   // context row inside its part
     const unsigned long long *cell_offsets;  // [cells + 1] into keys / vals
-    const uint32_t *pool;                    // negative pool (rows), or nullptr: uniform rows
-    const unsigned long long *pool_offsets;  // [cells + 1] into pool
+    const unsigned long long *alias;      // alias tables (threshold | alias << 32), or nullptr:
+                                          // negatives uniform over the rows of the cell
+    const unsigned long long *cell_rows;  // [cells + 1]: first table entry of every cell
     float *central;    // this rank's central partition  [rows][ld]
     float *context;    // the resident context part      [rows][ld]
     unsigned long long *cursors;  // [slices] record tickets of the part's cells (zeroed per launch)
@@ -279,15 +330,10 @@ __device__ __forceinline__ uint64_t record_stride(uint64_t R) {
     return s % R;
 }
 
-// rows of part `part` striped by `parts`, and of its slice `slice`
-__device__ __forceinline__ uint64_t stripe_count(uint64_t n, uint64_t first, uint64_t stride) {
-    return n > first ? (n - first + stride - 1) / stride : 0;
-}
-
 template <int CH, int WMX, int WMC, bool DET>
 __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, uint64_t lo,
                                              uint64_t p0, uint32_t n, uint64_t ckey,
-                                             uint64_t pool_lo, uint64_t pool_n, uint32_t slice,
+                                             uint64_t alias_lo, uint64_t cell_n, uint32_t slice,
                                              uint32_t *s_key, uint32_t *s_val, uint32_t *s_rows,
                                              float *s_lab, float *s_tr, int lane, int grp, int q,
                                              unsigned long long &pairs) {
@@ -307,8 +353,12 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         float lab = 1.f;
         if (s != 0) {
             const uint64_t r = draw(ckey, (p0 - lo + pr) * k + (s - 1));
-            row = a.pool ? a.pool[pool_lo + mulhi64(r, pool_n)]
-                         : slice + a.p.slices * (uint32_t)mulhi64(r, pool_n);
+            uint32_t local = (uint32_t)mulhi64(r, cell_n);
+            if (a.alias) {
+                const unsigned long long e = a.alias[alias_lo + local];
+                if ((uint32_t)r >= (uint32_t)e) local = (uint32_t)(e >> 32);
+            }
+            row = slice + a.p.slices * local;
             lab = 0.f;
             const uint64_t ngid = (uint64_t)row * a.p.parts + a.part;
             const uint64_t cgid = (uint64_t)s_key[pr] * a.p.world + a.p.rank;
@@ -348,8 +398,11 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
 
 // WMX: store flavour of the contextual rows (kWriteBack only when the cell is exclusive to the
 // XCD the workgroup runs on), WMC: of the central rows (shared between XCDs).
+#ifndef GN2V_BLOCK_MIN_BLOCKS
+#define GN2V_BLOCK_MIN_BLOCKS 1  // occupancy experiments: -DGN2V_BLOCK_MIN_BLOCKS=6 caps the VGPRs
+#endif
 template <int CH, int WMX, int WMC, bool DET>
-__global__ __launch_bounds__(kTrainBlock) void sgns_block_kernel(BlockArgs a) {
+__global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block_kernel(BlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
@@ -376,18 +429,15 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_block_kernel(BlockArgs a) {
         const uint64_t R = (hi - lo + C - 1) / C;
         const uint64_t A = record_stride(R);
         const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kMaxCells + cell);
-        uint64_t pool_lo = 0, pool_n = stripe_count(part_rows, slice, a.p.slices);
-        if (a.pool) {
-            pool_lo = a.pool_offsets[cell];
-            pool_n = a.pool_offsets[cell + 1] - pool_lo;
-        }
-        if (pool_n == 0) continue;  // cannot happen when the cell has pairs (their contexts)
+        const uint64_t cell_n = stripe_count(part_rows, slice, a.p.slices);
+        const uint64_t alias_lo = a.alias ? a.cell_rows[cell] : 0;
+        if (cell_n == 0) continue;  // cannot happen when the cell has pairs (their contexts)
         if constexpr (DET) {
             for (uint64_t t = 0; t < R; ++t) {
                 const uint64_t rec = (t * A) % R;
                 const uint64_t p0 = lo + rec * C;
                 const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
-                train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, pool_lo, pool_n, slice,
+                train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, alias_lo, cell_n, slice,
                                                 s_key, s_val, s_rows, s_lab, s_tr, lane, grp, q,
                                                 pairs);
             }
@@ -400,7 +450,7 @@ __global__ __launch_bounds__(kTrainBlock) void sgns_block_kernel(BlockArgs a) {
                 const uint64_t rec = (t * A) % R;
                 const uint64_t p0 = lo + rec * C;
                 const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
-                train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, pool_lo, pool_n, slice,
+                train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, alias_lo, cell_n, slice,
                                                 s_key, s_val, s_rows, s_lab, s_tr, lane, grp, q,
                                                 pairs);
             }

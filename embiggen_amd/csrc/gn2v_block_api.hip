@@ -115,40 +115,41 @@ int gn2v_init_table_rows(float *d_table, uint64_t n_rows, uint32_t d, uint32_t l
     return 0;
 }
 
-int gn2v_block_pool_temp_bytes(uint64_t n_edges, uint64_t *bytes) {
+int gn2v_block_alias_temp_bytes(uint64_t n_nodes, uint64_t *bytes) {
     if (!bytes) return fail("bytes is NULL");
-    *bytes = 3 * align256(n_edges * 4) + align256(gn2v::kMaxCells * 8) + sort_temp_bytes(n_edges);
+    *bytes = 2 * align256(n_nodes * 4) + align256(n_nodes * 8);
     return 0;
 }
 
-int gn2v_block_pool(gn2v_graph *g, const gn2v_block_plan *plan, uint32_t *d_pool,
-                    uint64_t *d_pool_offsets, void *d_temp, uint64_t temp_bytes, void *stream) {
+int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_alias,
+                     uint64_t *d_cell_rows, void *d_temp, uint64_t temp_bytes, void *stream) {
     if (check_plan(g, plan)) return 1;
-    if (!d_pool || !d_pool_offsets || !d_temp) return fail("NULL pointer");
+    if (!d_alias || !d_cell_rows || !d_temp) return fail("NULL pointer");
+    const uint64_t n = g->view.n_nodes;
     uint64_t need = 0;
-    gn2v_block_pool_temp_bytes(g->view.n_edges, &need);
-    if (temp_bytes < need) return fail("temporary storage too small for the pool build");
+    gn2v_block_alias_temp_bytes(n, &need);
+    if (temp_bytes < need) return fail("temporary storage too small for the alias tables");
+    if (g->view.n_edges >= (1ULL << 47)) return fail("too many edges for the alias tables");
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
-    const uint64_t E = g->view.n_edges;
-    const uint32_t cells = plan->parts * plan->slices;
     char *t = (char *)d_temp;
-    uint32_t *keys = (uint32_t *)t;
-    uint32_t *rows = (uint32_t *)(t + align256(E * 4));
-    uint32_t *keys_out = (uint32_t *)(t + 2 * align256(E * 4));
-    unsigned long long *counts = (unsigned long long *)(t + 3 * align256(E * 4));
-    void *sort_temp = t + 3 * align256(E * 4) + align256(gn2v::kMaxCells * 8);
-    HIP_TRY(hipMemsetAsync(counts, 0, cells * sizeof(unsigned long long), s));
+    uint32_t *indeg = (uint32_t *)t;
+    uint32_t *stack = (uint32_t *)(t + align256(n * 4));
+    unsigned long long *weight = (unsigned long long *)(t + 2 * align256(n * 4));
+    HIP_TRY(hipMemsetAsync(indeg, 0, n * sizeof(uint32_t), s));
+    const uint64_t E = g->view.n_edges;
     const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(gn2v::pool_keys_kernel, dim3(blocks), dim3(256), 0, s, g->view.col_idx, E,
-                       plan->parts, plan->slices, keys, rows, counts);
+    hipLaunchKernelGGL(gn2v::indegree_kernel, dim3(blocks), dim3(256), 0, s, g->view.col_idx, E,
+                       indeg);
     HIP_TRY(hipGetLastError());
-    if (sort_pairs(sort_temp, temp_bytes - (3 * align256(E * 4) + align256(gn2v::kMaxCells * 8)),
-                   keys, keys_out, rows, d_pool, E, std::max(1u, bits_for(cells)), s))
-        return 1;
-    hipLaunchKernelGGL(gn2v::offsets_kernel, dim3(1), dim3(64), 0, s, counts, cells,
-                       (unsigned long long *)d_pool_offsets);
+    hipLaunchKernelGGL(gn2v::cell_rows_kernel, dim3(1), dim3(64), 0, s, n, plan->parts,
+                       plan->slices, (unsigned long long *)d_cell_rows);
+    HIP_TRY(hipGetLastError());
+    const uint32_t cells = plan->parts * plan->slices;
+    hipLaunchKernelGGL(gn2v::alias_kernel, dim3((cells + 63) / 64), dim3(64), 0, s, indeg, n,
+                       plan->parts, plan->slices, (const unsigned long long *)d_cell_rows,
+                       (unsigned long long *)d_alias, weight, stack);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -273,8 +274,8 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     if (io->part >= plan->parts) return fail("part out of range");
     if (!io->d_keys || !io->d_vals || !io->d_cell_offsets || !io->d_central || !io->d_context)
         return fail("NULL pointer");
-    if ((tp->flags & GN2V_TRAIN_SCALE_FREE) && (!io->d_pool || !io->d_pool_offsets))
-        return fail("degree-proportional negatives need the pool of gn2v_block_pool");
+    if ((tp->flags & GN2V_TRAIN_SCALE_FREE) && (!io->d_alias || !io->d_cell_rows))
+        return fail("degree-proportional negatives need the tables of gn2v_block_alias");
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
@@ -286,8 +287,8 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     a.vals = io->d_vals;
     a.cell_offsets = (const unsigned long long *)io->d_cell_offsets;
     const bool scale_free = tp->flags & GN2V_TRAIN_SCALE_FREE;
-    a.pool = scale_free ? io->d_pool : nullptr;
-    a.pool_offsets = scale_free ? (const unsigned long long *)io->d_pool_offsets : nullptr;
+    a.alias = scale_free ? (const unsigned long long *)io->d_alias : nullptr;
+    a.cell_rows = scale_free ? (const unsigned long long *)io->d_cell_rows : nullptr;
     a.central = io->d_central;
     a.context = io->d_context;
     a.counters = g->counters;

@@ -22,7 +22,7 @@ ever held by two GPUs.
   centre it owns, sorted by (context part, centre) -- two passes over the walks and one radix sort
   in HIP (``gn2v_block_count`` / ``gn2v_block_extract``); nothing else crosses the fabric.
 * Training: ``gn2v_block_step`` per part, negatives drawn degree-proportionally inside the
-  resident part.
+  cell of the pair's context (one alias table per cell).
 
 Preparation of round ``t + 1`` (walk generation, all-gather, extraction, sort) runs on a second
 stream while round ``t`` trains.
@@ -170,10 +170,10 @@ class GpuBlockBackend:
 
         return ops.block_plan(self.graph, device=self.index, **kw)
 
-    def pools(self, plan):
+    def alias_tables(self, plan):
         from . import ops
 
-        return ops.block_pool(self.graph, plan, device=self.index)
+        return ops.block_alias(self.graph, plan, device=self.index)
 
     def prepare(self, plan, walks_all, seed, epoch, first_walk):
         """-> (keys, vals, cell_offsets, n_pairs); one host read (the pair count)."""
@@ -185,14 +185,14 @@ class GpuBlockBackend:
                                        n_pairs)
         return keys, vals, offsets, n_pairs
 
-    def step(self, tp, plan, prepared, pool, pool_offsets, central, context, block_id, part, seed,
+    def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
              epoch, lr):
         from . import ops
 
         keys, vals, offsets, n_pairs = prepared
         if n_pairs == 0:
             return
-        ops.block_step(self.graph, tp, plan, keys, vals, offsets, pool, pool_offsets, central,
+        ops.block_step(self.graph, tp, plan, keys, vals, offsets, alias, cell_rows, central,
                        context, block_id, part, seed, epoch, lr)
 
 
@@ -219,8 +219,8 @@ class BlockPartitionedTrainer:
                                       walk_length=walk_length, window=window, min_dist=min_dist,
                                       record=record, flags=int(train_params.flags) & 2)
         self.scale_free = bool(scale_free)
-        self.pool, self.pool_offsets = (self.backend.pools(self.plan) if scale_free
-                                        else (None, None))
+        self.alias, self.cell_rows = (self.backend.alias_tables(self.plan) if scale_free
+                                      else (None, None))
         for p in range(parts):
             if stripe_rows(self.n_nodes, p, parts) == 0:
                 raise ValueError("A context part owns no node: graph too small to split this far.")
@@ -276,7 +276,7 @@ class BlockPartitionedTrainer:
                                               recv_buf[: self.part_rows(nxt)],
                                               (comm.rank + 1) % world)
             ctx = self.held[part]
-            self.backend.step(self.tp, self.plan, prepared, self.pool, self.pool_offsets,
+            self.backend.step(self.tp, self.plan, prepared, self.alias, self.cell_rows,
                               self.central, ctx[: self.part_rows(part)], block_id, part, seed,
                               epoch, lr)
             if pending is not None:

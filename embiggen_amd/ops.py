@@ -140,21 +140,22 @@ def block_plan(graph: CSRGraph, world: int, rank: int, parts: int, slices: int, 
     return plan
 
 
-def block_pool(graph: CSRGraph, plan, device: int = 0):
-    """(pool int32 [n_edges], offsets int64 [cells + 1]): degree-proportional negative pools."""
+def block_alias(graph: CSRGraph, plan, device: int = 0):
+    """(alias int64 [n_nodes], cell_rows int64 [cells + 1]): per-cell alias tables for
+    degree-proportional negatives (``gn2v_block_alias``)."""
     torch = _torch()
     dg = graph.device_graph(device)
     dev = torch.device("cuda", device)
-    n_edges = graph.get_number_of_directed_edges()
+    n = graph.get_number_of_nodes()
     need = C.c_uint64()
-    _lib.check(_lib.lib().gn2v_block_pool_temp_bytes(n_edges, C.byref(need)))
+    _lib.check(_lib.lib().gn2v_block_alias_temp_bytes(n, C.byref(need)))
     temp = torch.empty(need.value, dtype=torch.uint8, device=dev)
-    pool = torch.empty(n_edges, dtype=torch.int32, device=dev)
-    offsets = torch.empty(plan.parts * plan.slices + 1, dtype=torch.int64, device=dev)
-    _lib.check(_lib.lib().gn2v_block_pool(dg.handle, C.byref(plan), pool.data_ptr(),
-                                          offsets.data_ptr(), temp.data_ptr(), need.value,
-                                          _stream(dev)))
-    return pool, offsets
+    alias = torch.empty(n, dtype=torch.int64, device=dev)
+    cell_rows = torch.empty(plan.parts * plan.slices + 1, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().gn2v_block_alias(dg.handle, C.byref(plan), alias.data_ptr(),
+                                           cell_rows.data_ptr(), temp.data_ptr(), need.value,
+                                           _stream(dev)))
+    return alias, cell_rows
 
 
 def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
@@ -201,7 +202,7 @@ def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, fi
     return keys, vals
 
 
-def block_step(graph: CSRGraph, tp, plan, keys, vals, cell_offsets, pool, pool_offsets, central,
+def block_step(graph: CSRGraph, tp, plan, keys, vals, cell_offsets, alias, cell_rows, central,
                context, block_id: int, part: int, seed: int, epoch: int, lr: float):
     """Train the pairs of one context part (``gn2v_block_step``; tables updated in place)."""
     dev = central.device
@@ -209,7 +210,7 @@ def block_step(graph: CSRGraph, tp, plan, keys, vals, cell_offsets, pool, pool_o
     assert central.is_contiguous() and context.is_contiguous()
     assert central.shape[1] == tp.ld and context.shape[1] == tp.ld
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-    io = _lib.BlockIO(ptr(keys), ptr(vals), ptr(cell_offsets), ptr(pool), ptr(pool_offsets),
+    io = _lib.BlockIO(ptr(keys), ptr(vals), ptr(cell_offsets), ptr(alias), ptr(cell_rows),
                       ptr(central), ptr(context), block_id, part)
     _lib.check(_lib.lib().gn2v_block_step(dg.handle, C.byref(tp), C.byref(plan), C.byref(io),
                                           seed, epoch, lr, _stream(dev)))

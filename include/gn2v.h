@@ -209,7 +209,7 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
  * (centre c: rank c % world, row c / world of that rank's central partition) and over `parts`
  * context parts (context x: part x % parts, row x / parts); the parts travel round the ranks, a
  * pair (c, x) is trained on the owner of c while part x % parts is resident there, with
- * negatives drawn inside the resident part.  `slices` stripes the rows of a part once more
+ * negatives drawn inside the cell of x.  `slices` stripes the rows of a part once more
  * (slice = row % slices): with 8 slices every XCD of an MI355X owns the rows it updates.
  * cell = part * slices + slice.  No row is ever held by two ranks. */
 typedef struct {
@@ -234,13 +234,14 @@ int gn2v_init_table_rows(float *d_table, uint64_t n_rows, uint32_t d, uint32_t l
                          uint32_t table_id, float scale, uint64_t first_row, uint64_t row_stride,
                          void *stream);
 
-/* Negative pools: d_pool u32[n_edges] = the rows (x / parts) of the endpoints x of all directed
- * edges grouped by cell (edge order kept inside a cell), d_pool_offsets u64[cells + 1]; a uniform
- * draw from a cell's segment is degree proportional inside the cell
- * (use_scale_free_distribution, node2vec_skipgram.py:101-102). */
-int gn2v_block_pool_temp_bytes(uint64_t n_edges, uint64_t *bytes);
-int gn2v_block_pool(gn2v_graph *g, const gn2v_block_plan *plan, uint32_t *d_pool,
-                    uint64_t *d_pool_offsets, void *d_temp, uint64_t temp_bytes, void *stream);
+/* Degree-proportional negatives inside a cell (use_scale_free_distribution,
+ * node2vec_skipgram.py:101-102): one Walker alias table per cell, d_alias u64[n_nodes] = threshold
+ * (2^32 scale) | alias row << 32, cells in order, rows of a cell in order; d_cell_rows
+ * u64[cells + 1] = first entry of every cell.  Weights are the in-degrees (a uniform random
+ * edge's endpoint); integer arithmetic throughout. */
+int gn2v_block_alias_temp_bytes(uint64_t n_nodes, uint64_t *bytes);
+int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_alias,
+                     uint64_t *d_cell_rows, void *d_temp, uint64_t temp_bytes, void *stream);
 
 /* Pairs of a round.  d_walks holds the walks of ALL ranks for the round (ids first_walk,
  * first_walk + 1, ...; all-gathered); this rank keeps the pairs whose centre it owns.
@@ -264,8 +265,8 @@ typedef struct {
     const uint32_t *d_keys;          /* sorted pairs of the round (gn2v_block_extract)         */
     const uint32_t *d_vals;
     const uint64_t *d_cell_offsets;  /* [cells + 1] (gn2v_block_count)                         */
-    const uint32_t *d_pool;          /* gn2v_block_pool; unused without GN2V_TRAIN_SCALE_FREE  */
-    const uint64_t *d_pool_offsets;
+    const uint64_t *d_alias;         /* gn2v_block_alias; unused without GN2V_TRAIN_SCALE_FREE */
+    const uint64_t *d_cell_rows;
     float *d_central;                /* this rank's central partition f32[rows][ld]            */
     float *d_context;                /* context part `part`, resident here, f32[rows][ld]      */
     uint64_t block_id;               /* RNG stream of the negatives: unique per (round, rank)  */

@@ -920,8 +920,8 @@ double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *log
  * rec(t) = t * A mod R (A ~ R / golden ratio, coprime with R); inside a record every run of equal
  * centre is one "centre" of Semantic S (copy of the central row, samples [context, k negatives]
  * applied one after the other, gradient added at the end of the run).  Negative n of the pair at
- * position p of its cell: pool entry (or uniform row of the cell) picked by
- * draw(cell_key, p * k + n), cell_key = draw(mix64(epoch_key ^ TAG_BLOCK), block_id * 1024 + cell);
+ * position p of its cell: a row of the cell, degree-proportional through the cell's alias table
+ * (or uniform), picked by draw(cell_key, p * k + n), cell_key = draw(mix64(epoch_key ^ TAG_BLOCK), block_id * 1024 + cell);
  * skipped when it is the context or the centre itself. */
 
 #define O_TAG_BLOCK 0xB10C5EED0B10C5EDULL
@@ -1012,27 +1012,73 @@ void o_block_cell_offsets(const uint32_t *keys, uint64_t n, uint32_t row_bits, u
     }
 }
 
-/* negative pools: rows of the endpoints of all directed edges grouped by cell, edge order kept */
-void o_block_pool(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t *pool,
-                  uint64_t *offsets) {
-    uint32_t cells = parts * slices;
-    uint64_t *count = (uint64_t *)calloc(cells + 1, sizeof(uint64_t));
-    for (uint64_t e = 0; e < g->n_edges; ++e) {
-        uint32_t x = g->col_idx[e], row = x / parts;
-        count[(x % parts) * slices + row % slices]++;
-    }
+static inline uint64_t stripe_count(uint64_t n, uint64_t first, uint64_t stride) {
+    return n > first ? (n - first + stride - 1) / stride : 0;
+}
+
+/* floor(w * 2^32 / D) for w < D < 2^48 */
+static inline uint64_t scaled_threshold(uint64_t w, uint64_t D) {
+    uint64_t q1 = (w << 16) / D, r1 = (w << 16) % D;
+    return (q1 << 16) | ((r1 << 16) / D);
+}
+
+/* Degree-proportional negatives inside a cell: one Walker alias table per cell (Vose's
+ * construction in integers; weights = in-degrees = how often a node is the endpoint of a uniform
+ * random directed edge, node2vec_skipgram.py:101-102).  table[cell_rows[c] + i] = threshold on a
+ * 2^32 scale | alias row << 32 for row i of cell c.  A draw r picks i = mulhi(r, n) and keeps it
+ * when (u32) r < threshold, else takes the alias. */
+void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint64_t *table,
+                   uint64_t *cell_rows) {
+    uint32_t *indeg = (uint32_t *)calloc(g->n_nodes, sizeof(uint32_t));
+    for (uint64_t e = 0; e < g->n_edges; ++e) indeg[g->col_idx[e]]++;
     uint64_t run = 0;
-    for (uint32_t c = 0; c < cells; ++c) {
-        offsets[c] = run;
-        run += count[c];
-        count[c] = offsets[c];
+    for (uint32_t p = 0; p < parts; ++p) {
+        uint64_t part_rows = stripe_count(g->n_nodes, p, parts);
+        for (uint32_t sl = 0; sl < slices; ++sl) {
+            cell_rows[p * slices + sl] = run;
+            run += stripe_count(part_rows, sl, slices);
+        }
     }
-    offsets[cells] = run;
-    for (uint64_t e = 0; e < g->n_edges; ++e) {
-        uint32_t x = g->col_idx[e], row = x / parts;
-        pool[count[(x % parts) * slices + row % slices]++] = row;
+    cell_rows[parts * slices] = run;
+    uint64_t *w = (uint64_t *)malloc(sizeof(uint64_t) * (g->n_nodes ? g->n_nodes : 1));
+    uint32_t *st = (uint32_t *)malloc(sizeof(uint32_t) * (g->n_nodes ? g->n_nodes : 1));
+    for (uint32_t cell = 0; cell < parts * slices; ++cell) {
+        uint32_t part = cell / slices, slice = cell % slices;
+        uint64_t lo = cell_rows[cell], n = cell_rows[cell + 1] - lo, D = 0;
+        uint64_t *t = table + lo;
+        if (n == 0) continue;
+        for (uint64_t i = 0; i < n; ++i) D += indeg[(slice + (uint64_t)slices * i) * parts + part];
+        uint64_t n_small = 0, n_large = 0; /* small stack from st[0], large from st[n - 1] */
+        for (uint64_t i = 0; i < n; ++i) {
+            uint64_t p = (uint64_t)indeg[(slice + (uint64_t)slices * i) * parts + part] * n;
+            w[i] = p;
+            if (D == 0 || p >= D)
+                st[n - 1 - n_large++] = (uint32_t)i;
+            else
+                st[n_small++] = (uint32_t)i;
+        }
+        while (n_small && n_large) {
+            uint32_t sidx = st[--n_small], lidx = st[n - n_large];
+            t[sidx] = ((uint64_t)lidx << 32) | scaled_threshold(w[sidx], D);
+            uint64_t pl = w[lidx] + w[sidx] - D;
+            w[lidx] = pl;
+            if (pl < D) {
+                --n_large;
+                st[n_small++] = lidx;
+            }
+        }
+        while (n_large) {
+            uint32_t i = st[n - n_large--];
+            t[i] = ((uint64_t)i << 32) | 0xFFFFFFFFull;
+        }
+        while (n_small) {
+            uint32_t i = st[--n_small];
+            t[i] = ((uint64_t)i << 32) | 0xFFFFFFFFull;
+        }
     }
-    free(count);
+    free(indeg);
+    free(w);
+    free(st);
 }
 
 static uint64_t gcd_u64(uint64_t a, uint64_t b) {
@@ -1052,14 +1098,10 @@ uint64_t o_block_record_stride(uint64_t R) {
     return s % R;
 }
 
-static inline uint64_t stripe_count(uint64_t n, uint64_t first, uint64_t stride) {
-    return n > first ? (n - first + stride - 1) / stride : 0;
-}
-
 /* one part of one round, strictly sequential; returns the pairs trained */
 uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_plan *p,
                       const uint32_t *keys, const uint32_t *vals, const uint64_t *cell_offsets,
-                      const uint32_t *pool, const uint64_t *pool_offsets, float *central,
+                      const uint64_t *alias, const uint64_t *cell_rows, float *central,
                       float *context, uint64_t block_id, uint32_t part, uint64_t seed,
                       uint64_t epoch, float lr) {
     uint32_t d = tp->d, ld = tp->ld, k = tp->k, C = p->record ? p->record : 16;
@@ -1073,11 +1115,10 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
         if (hi == lo) continue;
         uint64_t R = (hi - lo + C - 1) / C, A = o_block_record_stride(R);
         uint64_t ckey = o_draw(o_mix64(ekey ^ O_TAG_BLOCK), block_id * 1024 + cell);
-        int use_pool = (tp->flags & O_FLAG_SCALE_FREE) && pool;
-        uint64_t pool_lo = use_pool ? pool_offsets[cell] : 0;
-        uint64_t pool_n = use_pool ? pool_offsets[cell + 1] - pool_lo
-                                   : stripe_count(part_rows, slice, p->slices);
-        if (pool_n == 0) continue;
+        int use_alias = (tp->flags & O_FLAG_SCALE_FREE) && alias;
+        uint64_t alias_lo = use_alias ? cell_rows[cell] : 0;
+        uint64_t cell_n = stripe_count(part_rows, slice, p->slices);
+        if (cell_n == 0) continue;
         for (uint64_t t = 0; t < R; ++t) {
             uint64_t rec = (t * A) % R, p0 = lo + rec * C;
             uint32_t n = (uint32_t)(hi - p0 < C ? hi - p0 : C);
@@ -1097,8 +1138,12 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
                         float label = 1.0f;
                         if (s) {
                             uint64_t r = o_draw(ckey, (p0 - lo + pr) * k + (s - 1));
-                            row = use_pool ? pool[pool_lo + mulhi64(r, pool_n)]
-                                           : slice + p->slices * (uint32_t)mulhi64(r, pool_n);
+                            uint32_t local = (uint32_t)mulhi64(r, cell_n);
+                            if (use_alias) {
+                                uint64_t e = alias[alias_lo + local];
+                                if ((uint32_t)r >= (uint32_t)e) local = (uint32_t)(e >> 32);
+                            }
+                            row = slice + p->slices * local;
                             label = 0.0f;
                             if (row == xrow || (uint64_t)row * p->parts + part == cgid) continue;
                         }

@@ -357,17 +357,17 @@ def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: 
     return keys, vals, offsets
 
 
-def block_pool(g: OracleGraph, parts: int, slices: int):
-    """(pool rows u32[n_edges] grouped by cell, offsets u64[cells + 1])."""
-    pool = np.empty(g.n_edges, dtype=np.uint32)
-    offsets = np.empty(parts * slices + 1, dtype=np.uint64)
-    lib().o_block_pool(C.byref(g.c), C.c_uint32(parts), C.c_uint32(slices), _ptr(pool),
-                       _ptr(offsets))
-    return pool, offsets
+def block_alias(g: OracleGraph, parts: int, slices: int):
+    """(alias tables u64[n_nodes] = threshold | alias row << 32, cell_rows u64[cells + 1])."""
+    table = np.zeros(g.n_nodes, dtype=np.uint64)
+    cell_rows = np.empty(parts * slices + 1, dtype=np.uint64)
+    lib().o_block_alias(C.byref(g.c), C.c_uint32(parts), C.c_uint32(slices), _ptr(table),
+                        _ptr(cell_rows))
+    return table, cell_rows
 
 
-def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, keys, vals, cell_offsets, pool,
-               pool_offsets, central, context, block_id: int, part: int, seed: int, epoch: int,
+def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, keys, vals, cell_offsets, alias,
+               cell_rows, central, context, block_id: int, part: int, seed: int, epoch: int,
                lr: float) -> int:
     """Sequential training of one part (in place on ``central`` / ``context``)."""
     for a, t in ((keys, np.uint32), (vals, np.uint32), (cell_offsets, np.uint64),
@@ -376,7 +376,7 @@ def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, keys, vals, cel
     lib().o_block_step.restype = C.c_uint64
     return int(lib().o_block_step(
         C.byref(g.c), C.byref(tp), C.byref(plan), _ptr(keys), _ptr(vals), _ptr(cell_offsets),
-        _ptr(pool), _ptr(pool_offsets), _ptr(central), _ptr(context), C.c_uint64(block_id),
+        _ptr(alias), _ptr(cell_rows), _ptr(central), _ptr(context), C.c_uint64(block_id),
         C.c_uint32(part), C.c_uint64(seed), C.c_uint64(epoch), C.c_float(lr)))
 
 

@@ -91,7 +91,7 @@ int main(void) {
     io.neg_id_mul = 1;
     o_train_walks_ex(&g, &tp, &io, np, 2, 3, 0, 0, 0.02f, 1);
 
-    /* block-partitioned schedule: extraction, stable sort, pools, one round over every part */
+    /* block-partitioned schedule: extraction, stable sort, alias tables, one round over every part */
     {
         o_block_plan bp = {3, 1, 6, 2, 20, 3, 1, 4, o_block_row_bits(N, 3), 0};
         uint64_t nw = ns * 3, cap = nw * 20 * 6;
@@ -100,18 +100,18 @@ int main(void) {
         o_block_sort(bk, bv, nb);
         uint64_t off[13], poff[13];
         o_block_cell_offsets(bk, nb, bp.row_bits, 12, off);
-        uint32_t *pool = malloc(sizeof(uint32_t) * e);
-        o_block_pool(&g, 6, 2, pool, poff);
+        uint64_t *alias = malloc(sizeof(uint64_t) * N);
+        o_block_alias(&g, 6, 2, alias, poff);
         uint64_t crows = (N + 3 - 1 - 1) / 3 + 1, xrows = N / 6 + 1, trained = 0;
         float *bc = malloc(sizeof(float) * crows * 12), *bx = malloc(sizeof(float) * xrows * 12);
         o_init_table_rows(bc, (N - 1 + 2) / 3, 10, 12, 5, 0, 0.3f, 1, 3);
         for (uint32_t part = 0; part < 6; ++part) {
             o_init_table_rows(bx, (N - part + 5) / 6, 10, 12, 5, 1, 0.3f, part, 6);
-            trained += o_block_step(&g, &tp, &bp, bk, bv, off, pool, poff, bc, bx, 2, part, 7, 1,
+            trained += o_block_step(&g, &tp, &bp, bk, bv, off, alias, poff, bc, bx, 2, part, 7, 1,
                                     0.02f);
         }
         if (trained != nb) return 1;
-        free(bk); free(bv); free(pool); free(bc); free(bx);
+        free(bk); free(bv); free(alias); free(bc); free(bx);
     }
 
     uint32_t *bs = malloc(sizeof(uint32_t) * 999 * 4), *bd = malloc(sizeof(uint32_t) * 999 * 4);

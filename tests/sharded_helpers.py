@@ -93,22 +93,22 @@ class OracleBlockBackend:
         return O.block_plan(self.graph.get_number_of_nodes(), world, rank, parts, slices,
                             walk_length, window, min_dist, record, flags)
 
-    def pools(self, plan):
-        return O.block_pool(self.og, plan.parts, plan.slices)
+    def alias_tables(self, plan):
+        return O.block_alias(self.og, plan.parts, plan.slices)
 
     def prepare(self, plan, walks_all, seed, epoch, first_walk):
         walks = walks_all.cpu().numpy().view(np.uint32)
         keys, vals, offsets = O.block_extract(self.og, plan, walks, seed, epoch, first_walk)
         return keys, vals, offsets, len(keys)
 
-    def step(self, tp, plan, prepared, pool, pool_offsets, central, context, block_id, part, seed,
+    def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
              epoch, lr):
         keys, vals, offsets, n_pairs = prepared
         if n_pairs == 0:
             return
         c = np.ascontiguousarray(central.numpy())
         x = np.ascontiguousarray(context.numpy())
-        O.block_step(self.og, tp, plan, keys, vals, offsets, pool, pool_offsets, c, x, block_id,
+        O.block_step(self.og, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, block_id,
                      part, seed, epoch, lr)
         central.copy_(torch.from_numpy(c))
         context.copy_(torch.from_numpy(x))

@@ -5,6 +5,8 @@ final gather -- on threads and on torch.distributed (2 and 3 gloo ranks)."""
 import os
 import sys
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -19,6 +21,7 @@ from sharded_helpers import OracleBlockBackend, run_ranks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D, K, W, L = 8, 4, 3, 14
+C_u64 = ctypes.c_uint64
 
 
 def _graph(nodes=34):
@@ -80,22 +83,46 @@ def test_extraction_partitions_the_pairs_of_the_walks(world, parts, slices):
     assert np.array_equal(as_sorted(got), as_sorted(want))
 
 
-def test_pools_are_degree_proportional_inside_a_cell():
+def _alias_probabilities(table, n):
+    """Exact law of a draw from one cell's alias table (thresholds on a 2^32 scale)."""
+    thresh = (table & np.uint64(0xFFFFFFFF)).astype(np.float64)
+    alias = (table >> np.uint64(32)).astype(np.int64)
+    keep = np.where(thresh >= 0xFFFFFFFF, 1.0, thresh / 2.0 ** 32)
+    p = keep / n
+    np.add.at(p, alias, (1.0 - keep) / n)
+    return p
+
+
+def test_alias_tables_are_degree_proportional_inside_a_cell():
     g = _graph(97)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    pool, offsets = O.block_pool(og, 4, 2)
-    assert offsets[-1] == og.n_edges
-    indeg = np.bincount(og.col_idx, minlength=97)
+    table, cell_rows = O.block_alias(og, 4, 2)
+    assert cell_rows[-1] == 97 and cell_rows[0] == 0
+    indeg = np.bincount(og.col_idx, minlength=97).astype(np.float64)
     for cell in range(8):
         part, slc = cell // 2, cell % 2
-        rows = pool[int(offsets[cell]):int(offsets[cell + 1])]
-        assert (rows % 2 == slc).all()
-        nodes = rows.astype(np.int64) * 4 + part
-        assert np.array_equal(np.bincount(nodes, minlength=97), np.where(
-            (np.arange(97) % 4 == part) & ((np.arange(97) // 4) % 2 == slc), indeg, 0))
-        # edge order is kept inside a cell
-        sel = og.col_idx[(og.col_idx % 4 == part) & ((og.col_idx // 4) % 2 == slc)]
-        assert np.array_equal(nodes, sel)
+        lo, hi = int(cell_rows[cell]), int(cell_rows[cell + 1])
+        nodes = (slc + 2 * np.arange(hi - lo)) * 4 + part   # row i of the cell -> node id
+        assert nodes.max() < 97 and hi - lo == len([v for v in range(97) if v % 4 == part
+                                                      and (v // 4) % 2 == slc])
+        p = _alias_probabilities(table[lo:hi], hi - lo)
+        want = indeg[nodes] / indeg[nodes].sum()
+        assert np.abs(p - want).max() < 1e-8 and abs(p.sum() - 1) < 1e-9
+        assert ((table[lo:hi] >> np.uint64(32)) < hi - lo).all()
+    # empirical check of the sampler itself on one cell: chi-square against the degrees
+    from scipy import stats
+    lo, hi = int(cell_rows[3]), int(cell_rows[4])
+    n = hi - lo
+    r = np.array([O.lib().o_draw(C_u64(12345), C_u64(t)) for t in range(40000)], dtype=np.uint64)
+    local = ((r >> np.uint64(32)) * np.uint64(n) >> np.uint64(32)).astype(np.int64)  # ~ mulhi
+    e = table[lo:hi][local]
+    take_alias = (r & np.uint64(0xFFFFFFFF)) >= (e & np.uint64(0xFFFFFFFF))
+    local = np.where(take_alias, (e >> np.uint64(32)).astype(np.int64), local)
+    nodes = (1 + 2 * np.arange(n)) * 4 + 1
+    want = indeg[nodes] / indeg[nodes].sum()
+    counts = np.bincount(local, minlength=n).astype(np.float64)
+    sel = want * 40000 >= 5
+    assert stats.chisquare(counts[sel], want[sel] / want[sel].sum() * counts[sel].sum()).pvalue > 1e-4
 
 
 def test_record_visiting_order_is_a_permutation():
@@ -112,25 +139,26 @@ def test_step_properties_zero_lr_counts_and_untouched_rows():
     walks = O.walks(og, O.WalkParams(L, 1, 1.0, 1.0, 100, 0), 5, 0, 0, 30)
     plan = O.block_plan(97, 1, 0, 2, 1, L, W, 1, 4)
     keys, vals, offsets = O.block_extract(og, plan, walks, 5, 0, 0)
-    pool, pool_offsets = O.block_pool(og, 2, 1)
+    alias, cell_rows = O.block_alias(og, 2, 1)
     c = O.init_table_rows(97, D, D, 5, 0, 0.3, 0, 1)
     assert np.array_equal(c, O.init_table(97, D, D, 5, 0, 0.3))
     parts = [O.init_table_rows(stripe_rows(97, p, 2), D, D, 5, 1, 0.3, p, 2) for p in range(2)]
     full = O.init_table(97, D, D, 5, 1, 0.3)
     assert np.array_equal(parts[0], full[0::2]) and np.array_equal(parts[1], full[1::2])
     c0, x0 = c.copy(), [p.copy() for p in parts]
-    n0 = O.block_step(og, _otp(), plan, keys, vals, offsets, pool, pool_offsets, c, parts[0], 0, 0,
+    n0 = O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows, c, parts[0], 0, 0,
                       5, 0, 0.0)
     assert np.array_equal(c, c0) and np.array_equal(parts[0], x0[0])  # lr = 0: identity
-    n1 = sum(O.block_step(og, _otp(), plan, keys, vals, offsets, pool, pool_offsets, c, parts[p],
+    n1 = sum(O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows, c, parts[p],
                           0, p, 5, 0, 0.05) for p in range(2))
     assert n0 == offsets[1] and n1 == len(keys) == len(O.walk_pairs(walks, W))
     centres = np.unique(keys & ((1 << plan.row_bits) - 1))
     untouched = np.setdiff1d(np.arange(97), centres)
     assert np.array_equal(c[untouched], c0[untouched]) and not np.array_equal(c, c0)
-    for p in range(2):  # contextual rows move only for contexts and pool (edge endpoint) rows
+    indeg = np.bincount(og.col_idx, minlength=97)
+    for p in range(2):  # contextual rows move only for contexts and nodes an edge points to
         seg = slice(int(offsets[p]), int(offsets[p + 1]))
-        may = np.union1d(vals[seg], pool[int(pool_offsets[p]):int(pool_offsets[p + 1])])
+        may = np.union1d(vals[seg], np.nonzero(indeg[p::2])[0])
         rest = np.setdiff1d(np.arange(len(parts[p])), may)
         assert np.array_equal(parts[p][rest], x0[p][rest])
 
@@ -141,7 +169,7 @@ def test_world_one_trainer_is_the_plain_sequence_of_block_steps():
     g = _graph()
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     plan = O.block_plan(34, 1, 0, 2, 1, L, W, 1, 4)
-    pool, pool_offsets = O.block_pool(og, 2, 1)
+    alias, cell_rows = O.block_alias(og, 2, 1)
     rc = O.init_table(34, D, D, 42, 0, D ** -0.5)
     rx = O.init_table(34, D, D, 42, 1, D ** -0.5)
     parts = [np.ascontiguousarray(rx[p::2]) for p in range(2)]
@@ -151,7 +179,7 @@ def test_world_one_trainer_is_the_plain_sequence_of_block_steps():
         walks = O.walks(og, wp, 42, 0, r * 9, 9)
         keys, vals, offsets = O.block_extract(og, plan, walks, 42, 0, r * 9)
         for p in range(2):
-            total += O.block_step(og, _otp(), plan, keys, vals, offsets, pool, pool_offsets, rc,
+            total += O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows, rc,
                                   parts[p], r, p, 42, 0, 0.02)
     rx[0::2], rx[1::2] = parts
     assert np.array_equal(c, rc) and np.array_equal(x, rx)

@@ -1,5 +1,5 @@
 """GPU: the block-partitioned multi-GPU SkipGram path against the oracle's restatement of its
-schedule -- pair extraction + sort, negative pools and shard initialisation bit-exact, the
+schedule -- pair extraction + sort, alias tables and shard initialisation bit-exact, the
 training kernel within 1e-5 per element (f32 sums in another order, v_exp_f32 vs expf), and the
 trainer with ranks simulated on one GPU (exact: ranks never share a row, so a sequential
 simulation computes precisely what W GPUs compute; only the transport differs)."""
@@ -86,14 +86,14 @@ def test_extraction_honours_centre_downsampling(karate, karate_oracle):
 
 
 @pytest.mark.parametrize("parts,slices", [(1, 1), (4, 1), (6, 8), (16, 8)])
-def test_negative_pools_are_bit_exact(parts, slices):
+def test_alias_tables_are_bit_exact(parts, slices):
     g = _ba(997, 4)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2)
-    pool, offsets = ops.block_pool(g, plan)
-    rp, ro = O.block_pool(og, parts, slices)
-    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
-    assert np.array_equal(_u32(pool), rp)
+    alias, cell_rows = ops.block_alias(g, plan)
+    ra, rc = O.block_alias(og, parts, slices)
+    assert np.array_equal(cell_rows.cpu().numpy().astype(np.uint64), rc)
+    assert np.array_equal(alias.cpu().numpy().view(np.uint64), ra)
 
 
 def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, n_walks=60,
@@ -106,21 +106,21 @@ def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, 
     oplan = O.block_plan(n, world, rank, parts, slices, wl, window, 1, record)
     work, offsets = ops.block_count(g, plan, wk, 11, 0, 0)
     keys, vals = ops.block_extract(g, plan, wk, 11, 0, 0, work, int(offsets[-1]))
-    pool, pool_offsets = ops.block_pool(g, plan)
+    alias, cell_rows = ops.block_alias(g, plan)
     sf = (1 if scale_free else 0) | extra
     tp = ops.train_params(0, d, k, window, flags=sf | flags, ld=ld)
     otp = O.TrainParams(0, d, ld, 1, k, window, 0.01, 0.9, 6.0, sf, d ** -0.5)
     c = ops.init_table_rows(stripe_rows(n, rank, world), d, 11, 0, d ** -0.5, rank, world, ld=ld)
     c_h = c.cpu().numpy().copy()
     rk, rv, ro = _u32(keys), _u32(vals), offsets.cpu().numpy().astype(np.uint64)
-    rp, rpo = _u32(pool), pool_offsets.cpu().numpy().astype(np.uint64)
+    rp, rpo = alias.cpu().numpy().view(np.uint64), cell_rows.cpu().numpy().astype(np.uint64)
     got_x, ref_x = [], []
     ops.stats_reset(g)
     trained = 0
     for part in (range(parts) if part_list is None else part_list):
         x = ops.init_table_rows(stripe_rows(n, part, parts), d, 11, 1, d ** -0.5, part, parts, ld=ld)
         x_h = x.cpu().numpy().copy()
-        ops.block_step(g, tp, plan, keys, vals, offsets, pool, pool_offsets, c, x, 3, part, 11, 0, lr)
+        ops.block_step(g, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, 3, part, 11, 0, lr)
         trained += O.block_step(og, otp, oplan, rk, rv, ro, rp, rpo, c_h, x_h, 3, part, 11, 0, lr)
         got_x.append(x.cpu().numpy())
         ref_x.append(x_h)
@@ -192,7 +192,7 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
     vals = torch.from_numpy(vals_h.view(np.int32)).cuda()
     offs = torch.from_numpy(off_h.astype(np.int64)).cuda()
     ld = (d + 3) // 4 * 4
-    tp = ops.train_params(0, d, 0, 2, flags=flags, ld=ld)  # k = 0, no pool needed
+    tp = ops.train_params(0, d, 0, 2, flags=flags, ld=ld)  # k = 0, no alias tables needed
     otp = O.TrainParams(0, d, ld, 1, 0, 2, 0.01, 0.9, 6.0, 0, d ** -0.5)
     c = ops.init_table(2 * n_rows + 5, d, 5, 0, 0.5, ld=ld)
     c_h = c.cpu().numpy().copy()
