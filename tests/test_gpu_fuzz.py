@@ -101,3 +101,66 @@ def test_random_glove_fit_matches_oracle(case):
     assert m.last_stats["entries"] == int((entries[1] != O.SENTINEL).sum())
     assert np.abs(central - state[0][:, :d]).max() < 1e-4
     assert np.abs(contextual - state[1][:, :d]).max() < 1e-4
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_block_rounds_match_oracle(case):
+    """The block path on random graphs (directed, trap nodes, isolated nodes), random plans
+    (ranks, parts, XCD slices, record length) and random parameters: extraction + sort and the
+    alias tables bit-exact, one deterministic round over every part equal to float tolerance."""
+    import torch
+
+    from embiggen_amd.distributed import stripe_rows
+
+    rng = np.random.RandomState(5000 + case)
+    n = int(rng.randint(40, 400))
+    e = int(rng.randint(n, 5 * n))
+    src, dst = rng.randint(0, n, e), rng.randint(0, n, e)
+    g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=n, directed=bool(rng.rand() < 0.4))
+    og = oracle_graph(g)
+    world = int(rng.choice([1, 2, 3, 5, 8]))
+    rank = int(rng.randint(0, world))
+    parts = world * int(rng.choice([1, 2, 4]))
+    while stripe_rows(n, parts - 1, parts) == 0:
+        parts //= 2
+    parts = max(parts, world)
+    slices = int(rng.choice([1, 2, 8]))
+    record = int(rng.choice([1, 3, 16, 32]))
+    L, w = int(rng.randint(3, 30)), int(rng.randint(1, 6))
+    md = int(rng.randint(1, w + 1))
+    k, d = int(rng.randint(0, 7)), int(rng.choice([3, 8, 20, 64, 130]))
+    flags = (1 if rng.rand() < 0.7 else 0) | (4 if rng.rand() < 0.3 else 0)
+    down = 2 if rng.rand() < 0.3 else 0
+    seed, epoch, first = int(rng.randint(0, 2 ** 31)), int(rng.randint(0, 5)), int(rng.randint(0, 10 ** 6))
+    n_src = g.get_number_of_unique_source_nodes()
+    wk = ops.walks(g, ops.walk_params(L, 2, 0.5, 2.0), seed, epoch, first, 2 * n_src)
+    plan = ops.block_plan(g, world, rank, parts, slices, L, w, md, record, flags=down)
+    oplan = O.block_plan(n, world, rank, parts, slices, L, w, md, record, flags=down)
+    work, offsets = ops.block_count(g, plan, wk, seed, epoch, first)
+    n_pairs = int(offsets[-1])
+    keys, vals = ops.block_extract(g, plan, wk, seed, epoch, first, work, n_pairs)
+    rk, rv, ro = O.block_extract(og, oplan, wk.cpu().numpy().view(np.uint32), seed, epoch, first)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint32), rk)
+    assert np.array_equal(vals.cpu().numpy().view(np.uint32), rv)
+    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
+    alias, cell_rows = ops.block_alias(g, plan)
+    ra, rc = O.block_alias(og, parts, slices)
+    assert np.array_equal(alias.cpu().numpy().view(np.uint64), ra)
+    assert np.array_equal(cell_rows.cpu().numpy().astype(np.uint64), rc)
+    if n_pairs == 0:
+        return
+    ld = (d + 3) // 4 * 4
+    tp = ops.train_params(0, d, k, w, flags=flags | _lib.TRAIN_DETERMINISTIC, ld=ld)
+    otp = O.TrainParams(0, d, ld, 1, k, w, 0.01, 0.9, 6.0, flags, d ** -0.5)
+    c = ops.init_table_rows(stripe_rows(n, rank, world), d, seed, 0, d ** -0.5, rank, world, ld=ld)
+    c_h = c.cpu().numpy().copy()
+    for part in range(parts):
+        rows = stripe_rows(n, part, parts)
+        x = ops.init_table_rows(rows, d, seed, 1, d ** -0.5, part, parts, ld=ld)
+        x_h = x.cpu().numpy().copy()
+        ops.block_step(g, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, case, part, seed,
+                       epoch, 0.05)
+        O.block_step(og, otp, oplan, rk, rv, ro, ra, rc, c_h, x_h, case, part, seed, epoch, 0.05)
+        torch.cuda.synchronize()
+        assert np.abs(x.cpu().numpy() - x_h).max() < 2e-5, (part,)
+    assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5
