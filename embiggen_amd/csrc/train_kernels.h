@@ -361,6 +361,53 @@ __device__ __forceinline__ void score_samples(const Args &a, float *table, const
     }
 }
 
+// The same scoring with every sample row of the centre in flight at once (up to three rounds of
+// four rows): one memory round trip per centre instead of one per round.  Precondition: no row id
+// occurs twice in the list (the caller checks and otherwise takes score_samples, whose per-round
+// serialisation keeps repeated rows sequentially exact).  Same accumulation order per group, so
+// the result is bit-identical to score_samples on such lists.
+constexpr uint32_t kFlightSamples = 12;
+template <int CH, int WM, class Args>
+__device__ __forceinline__ void score_samples_flight(const Args &a, float *table,
+                                                     const Row<CH> &u, const Row<CH> &u_upd,
+                                                     Row<CH> &g, const uint32_t *s_rows,
+                                                     const float *s_lab, uint32_t n_samples,
+                                                     float lrc, int grp, int q) {
+    const uint32_t nchunks = a.ld >> 2;
+    Row<CH> v0, v1, v2;
+    const uint32_t t0 = grp, t1 = 4 + grp, t2 = 8 + grp;
+    const uint32_t r0 = t0 < n_samples ? s_rows[t0] : kSentinel;
+    const uint32_t r1 = t1 < n_samples ? s_rows[t1] : kSentinel;
+    const uint32_t r2 = t2 < n_samples ? s_rows[t2] : kSentinel;
+    const float l0 = t0 < n_samples ? s_lab[t0] : 0.f;
+    const float l1 = t1 < n_samples ? s_lab[t1] : 0.f;
+    const float l2 = t2 < n_samples ? s_lab[t2] : 0.f;
+    float *b0 = sample_base(a, table, r0 != kSentinel ? r0 : 0);
+    float *b1 = sample_base(a, table, r1 != kSentinel ? r1 : 0);
+    float *b2 = sample_base(a, table, r2 != kSentinel ? r2 : 0);
+    load_row<CH>(v0, b0, q, nchunks, r0 != kSentinel);
+    load_row<CH>(v1, b1, q, nchunks, r1 != kSentinel);
+    load_row<CH>(v2, b2, q, nchunks, r2 != kSentinel);
+    {
+        const float dot = dot_rows<CH>(u, v0);
+        const float var = r0 != kSentinel ? (l0 - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+        axpy<CH>(g, var, v0);
+        if (r0 != kSentinel) scatter_add<CH, WM>(b0, q, nchunks, var, u_upd, v0);
+    }
+    {
+        const float dot = dot_rows<CH>(u, v1);
+        const float var = r1 != kSentinel ? (l1 - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+        axpy<CH>(g, var, v1);
+        if (r1 != kSentinel) scatter_add<CH, WM>(b1, q, nchunks, var, u_upd, v1);
+    }
+    {
+        const float dot = dot_rows<CH>(u, v2);
+        const float var = r2 != kSentinel ? (l2 - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+        axpy<CH>(g, var, v2);
+        if (r2 != kSentinel) scatter_add<CH, WM>(b2, q, nchunks, var, u_upd, v2);
+    }
+}
+
 template <int CH>
 __device__ __forceinline__ void zero_row(Row<CH> &r) {
 #pragma unroll
@@ -506,6 +553,70 @@ __device__ __forceinline__ void cache_insert(const TrainArgs &a, CtxCache &c, fl
     float *dst = c.rows + (uint32_t)free_slot * c.ld;
     for (uint32_t ci = lane; ci < (c.ld >> 2); ci += 64)
         *reinterpret_cast<float4 *>(dst + ci * 4) = *reinterpret_cast<const float4 *>(src + ci * 4);
+    if (lane == 0) {
+        c.node[free_slot] = v;
+        c.ref[free_slot] = 1;
+    }
+    wave_sync();
+}
+
+// The row that enters the window at the NEXT centre, fetched one centre ahead into registers
+// (its degree too): the insert then costs no memory round trip.  Only issued for a node that is
+// not in the cache (a cached node is never re-read); it cannot become stale in between: this wave
+// changes contextual rows only through the cache or, for uncached hub rows, in place -- and a hub
+// row is discarded at commit by the same degree test.
+template <int NC>  // float4 chunks per lane: ld / 4 chunks over 64 lanes
+struct RowPrefetch {
+    uint32_t node;
+    bool valid;
+    uint64_t deg;
+    float4 chunk[NC];
+};
+
+template <int NC>
+__device__ __forceinline__ void prefetch_issue(const TrainArgs &a, const CtxCache &c,
+                                               const float *table, uint32_t v, int lane,
+                                               RowPrefetch<NC> &pf) {
+    pf.node = v;
+    pf.valid = c.find(v) < 0;
+    if (!pf.valid) return;
+    pf.deg = a.cache_max_degree != 0xFFFFFFFFu ? a.g.row_ptr[v + 1] - a.g.row_ptr[v] : 0;
+    const float *src = table + (uint64_t)v * c.ld;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+        const uint32_t ci = lane + 64 * cc;
+        pf.chunk[cc] = ci < (c.ld >> 2) ? *reinterpret_cast<const float4 *>(src + ci * 4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// cache_insert with the prefetched registers when they belong to this node (else the plain path)
+template <int WM, int NC>
+__device__ __forceinline__ void cache_insert_prefetched(const TrainArgs &a, CtxCache &c,
+                                                        float *table, uint32_t v, int lane,
+                                                        const RowPrefetch<NC> &pf) {
+    if (!pf.valid || pf.node != v) {
+        cache_insert<WM>(a, c, table, v, lane);
+        return;
+    }
+    const int hit = c.find(v);
+    wave_sync();
+    if (hit >= 0) {  // cannot happen (nothing is inserted between issue and commit); stay exact
+        if (lane == 0) c.ref[hit] += 1;
+        wave_sync();
+        return;
+    }
+    if (a.cache_max_degree != 0xFFFFFFFFu && pf.deg >= a.cache_max_degree) return;
+    int free_slot = -1;
+    for (uint32_t s = 0; s < c.slots; ++s)
+        if (c.ref[s] == 0 && free_slot < 0) free_slot = (int)s;
+    if (free_slot < 0) return;
+    float *dst = c.rows + (uint32_t)free_slot * c.ld;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+        const uint32_t ci = lane + 64 * cc;
+        if (ci < (c.ld >> 2)) *reinterpret_cast<float4 *>(dst + ci * 4) = pf.chunk[cc];
+    }
     if (lane == 0) {
         c.node[free_slot] = v;
         c.ref[free_slot] = 1;
@@ -842,10 +953,30 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
         wave_sync();
         for (uint32_t p = 0; p < Le && p <= w; ++p)
             cache_insert<WM>(a, cache, a.contextual, s_walk[p], lane);
+        // one centre ahead, in registers: the negatives (their ids cost a random col_idx read) and
+        // the contextual row that enters the window -- the centre's latency chain shrinks from
+        // ~6 dependent memory round trips to the one of its output rows
+        constexpr int kPfChunks = CH > 4 ? 2 : 1;  // CH <= 4: ld <= 256 floats = 64 chunks
+        RowPrefetch<kPfChunks> pf;
+        pf.valid = false;
+        pf.node = kSentinel;
+        pf.deg = 0;
+#pragma unroll
+        for (int cc = 0; cc < kPfChunks; ++cc) pf.chunk[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t pre_neg = kSentinel, pre_for = kSentinel;
+        const bool neg_in_lanes = k < 64;
+        auto fetch_negative = [&](uint32_t ii) -> uint32_t {
+            if (lane < 1 || (uint32_t)lane > k) return kSentinel;
+            const uint64_t qi = (uint64_t)ii * k + (uint32_t)(lane - 1);
+            return ov ? ov[qi] : draw_negative(a, nkey, qi);
+        };
 
         for (uint32_t i = 0; i < Le; ++i) {
             if (i >= w + 1) cache_retire<WM>(cache, a.contextual, s_walk[i - w - 1], lane);
-            if (i >= 1 && i + w < Le) cache_insert<WM>(a, cache, a.contextual, s_walk[i + w], lane);
+            if (i >= 1 && i + w < Le)
+                cache_insert_prefetched<WM>(a, cache, a.contextual, s_walk[i + w], lane, pf);
+            pf.valid = false;
+            if (i + 1 + w < Le) prefetch_issue(a, cache, a.contextual, s_walk[i + 1 + w], lane, pf);
 
             const uint32_t c = s_walk[i];
             if (!keep_centre(a, wkey, i, c)) continue;
@@ -856,17 +987,29 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
             const float invC = 1.0f / (float)n_ctx;
 
             wave_sync();
-            for (uint32_t t = lane; t <= k; t += 64) {
-                uint32_t row = c;
-                float lab = 1.f;
-                if (t != 0) {
-                    const uint64_t qi = (uint64_t)i * k + (t - 1);
-                    row = ov ? ov[qi] : draw_negative(a, nkey, qi);
-                    lab = 0.f;
-                    if (row == c) row = kSentinel;
+            if (neg_in_lanes) {
+                const uint32_t raw = pre_for == i ? pre_neg : fetch_negative(i);
+                if (i + 1 < Le) {
+                    pre_neg = fetch_negative(i + 1);
+                    pre_for = i + 1;
                 }
-                s_rows[t] = row;
-                s_lab[t] = lab;
+                if ((uint32_t)lane <= k) {
+                    s_rows[lane] = lane == 0 ? c : (raw == c ? kSentinel : raw);
+                    s_lab[lane] = lane == 0 ? 1.f : 0.f;
+                }
+            } else {
+                for (uint32_t t = lane; t <= k; t += 64) {
+                    uint32_t row = c;
+                    float lab = 1.f;
+                    if (t != 0) {
+                        const uint64_t qi = (uint64_t)i * k + (t - 1);
+                        row = ov ? ov[qi] : draw_negative(a, nkey, qi);
+                        lab = 0.f;
+                        if (row == c) row = kSentinel;
+                    }
+                    s_rows[t] = row;
+                    s_lab[t] = lab;
+                }
             }
             for (uint32_t t = lane; t < n_ctx; t += 64) {
                 uint32_t row = s_walk[win.position(t)];
@@ -906,7 +1049,19 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
                 h.c[cc].w *= invC;
             }
 
-            score_samples<CH, WM, false>(a, a.central, h, h, g, s_rows, s_lab, k + 1, lrc, grp, q);
+            // all output rows in flight at once unless a row is named twice (then the serialising
+            // path keeps the oracle's order)
+            bool repeated = false;
+            if (k + 1 <= kFlightSamples && (uint32_t)lane <= k) {
+                const uint32_t mine = s_rows[lane];
+                for (int j = 0; j < lane; ++j) repeated |= mine != kSentinel && s_rows[j] == mine;
+            }
+            if (k + 1 <= kFlightSamples && __ballot(repeated) == 0)
+                score_samples_flight<CH, WM>(a, a.central, h, h, g, s_rows, s_lab, k + 1, lrc, grp,
+                                             q);
+            else
+                score_samples<CH, WM, false>(a, a.central, h, h, g, s_rows, s_lab, k + 1, lrc, grp,
+                                             q);
             reduce_groups<CH>(g);
 
             for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
