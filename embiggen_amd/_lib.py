@@ -102,7 +102,7 @@ class BlockPlan(C.Structure):
 
     _fields_ = [(name, C.c_uint32) for name in (
         "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
-        "row_bits", "flags")]
+        "row_bits", "flags", "hot_lo", "hot_hi")]
 
 
 class BlockIO(C.Structure):
@@ -214,11 +214,11 @@ def lib():
     L.gn2v_block_plan_check.argtypes = [vp, C.POINTER(BlockPlan)]
     L.gn2v_init_table_rows.argtypes = [vp, u64, u32, u32, u64, u32, f32, u64, u64, vp]
     L.gn2v_block_alias_temp_bytes.argtypes = [u64, C.POINTER(u64)]
-    L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, u64, vp]
+    L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, vp, u64, vp]
     L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, vp, vp]
     L.gn2v_block_extract_temp_bytes.argtypes = [u64, C.POINTER(u64)]
-    L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, u64,
-                                     vp, vp, vp, u64, vp]
+    L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, vp,
+                                     u64, vp, vp, vp, u64, vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),
                                   C.POINTER(BlockIO), u64, u64, f32, vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]

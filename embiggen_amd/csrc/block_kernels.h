@@ -28,6 +28,10 @@ constexpr int kPrepBlock = 256;
 constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
 constexpr uint32_t kMaxCells = 1024;
 constexpr uint32_t kMaxRecord = 32;
+// "Hot" contextual rows (share of the cell's edge endpoints inside the plan's band; off by
+// default): so many waves read-modify-write them at once that plain stores lose updates.  They
+// carry this bit in the sorted pair values and in the alias tables and are updated with f32 atomics.
+constexpr uint32_t kHubBit = 0x80000000u;
 
 struct BlockPlan {
     uint32_t world, rank, parts, slices;
@@ -88,12 +92,16 @@ static __global__ void cell_rows_kernel(uint64_t n_nodes, uint32_t parts, uint32
 // Vose's construction, one thread per cell, integer arithmetic: row i of the cell has weight
 // p_i = indeg_i * n against the cell total D; "small" rows (p < D) keep threshold p * 2^32 / D and
 // borrow the rest from a "large" row.  work: u64 weight[n_nodes] | u32 stack[n_nodes].
+// Entry of row i: bit 0 = row i is hot, bits 1..31 = threshold (its lowest bit dropped), bits
+// 32..62 = alias row, bit 63 = the alias row is hot.  hub_bits: one bit per node id.
 static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t n_nodes,
                                     uint32_t parts, uint32_t slices,
                                     const unsigned long long *__restrict__ cell_rows,
                                     unsigned long long *__restrict__ table,
                                     unsigned long long *__restrict__ weight,
-                                    uint32_t *__restrict__ stack) {
+                                    uint32_t *__restrict__ stack,
+                                    uint32_t *__restrict__ hub_bits, uint32_t hub_lo_shift,
+                                    uint32_t hub_hi_shift) {
     const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= parts * slices) return;
     const uint32_t part = cell / slices, slice = cell - part * slices;
@@ -104,9 +112,22 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
     unsigned long long D = 0;
     for (uint64_t i = 0; i < n; ++i) D += indeg[(slice + (uint64_t)slices * i) * parts + part];
     uint64_t n_small = 0, n_large = 0;  // small stack grows from st[0], large from st[n - 1]
+    auto node_of = [&](uint64_t i) { return (slice + (uint64_t)slices * i) * parts + part; };
+    // hot: share of the cell's endpoints in [2^-lo, 2^-hi) (hi = 0: no upper bound)
+    auto hot = [&](uint64_t i) -> unsigned long long {
+        const unsigned long long d = indeg[node_of(i)];
+        return hub_lo_shift != 0 && D != 0 && (d << hub_lo_shift) >= D &&
+                       (hub_hi_shift == 0 || (d << hub_hi_shift) < D)
+                   ? 1ull
+                   : 0ull;
+    };
     for (uint64_t i = 0; i < n; ++i) {
-        const unsigned long long p = (unsigned long long)indeg[(slice + (uint64_t)slices * i) * parts + part] * n;
+        const unsigned long long p = (unsigned long long)indeg[node_of(i)] * n;
         w[i] = p;
+        if (hot(i)) {
+            const uint64_t x = node_of(i);
+            atomicOr(&hub_bits[x >> 5], 1u << (x & 31));
+        }
         if (D == 0 || p >= D)
             st[n - 1 - n_large++] = (uint32_t)i;
         else
@@ -115,7 +136,8 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
     while (n_small && n_large) {
         const uint32_t sidx = st[--n_small];
         const uint32_t lidx = st[n - n_large];  // top of the large stack
-        t[sidx] = ((unsigned long long)lidx << 32) | scaled_threshold(w[sidx], D);
+        t[sidx] = (hot(lidx) << 63) | ((unsigned long long)lidx << 32) |
+                  (scaled_threshold(w[sidx], D) & ~1ull) | hot(sidx);
         const unsigned long long pl = w[lidx] + w[sidx] - D;
         w[lidx] = pl;
         if (pl < D) {  // the large row became small: move it over
@@ -125,11 +147,11 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
     }
     while (n_large) {
         const uint32_t i = st[n - n_large--];
-        t[i] = ((unsigned long long)i << 32) | 0xFFFFFFFFull;
+        t[i] = (hot(i) << 63) | ((unsigned long long)i << 32) | 0xFFFFFFFEull | hot(i);
     }
     while (n_small) {  // only through rounding
         const uint32_t i = st[--n_small];
-        t[i] = ((unsigned long long)i << 32) | 0xFFFFFFFFull;
+        t[i] = (hot(i) << 63) | ((unsigned long long)i << 32) | 0xFFFFFFFEull | hot(i);
     }
 }
 
@@ -147,6 +169,7 @@ struct ExtractArgs {
     uint64_t first_walk;  // id of walks[0]
     unsigned long long *wave_counts;  // [kPrepWaves]: counts out (count pass), offsets in (write)
     unsigned long long *cell_counts;  // [cells] (count pass)
+    const uint32_t *hub_bits;         // one bit per node (gn2v_block_alias), or nullptr
     uint32_t *keys, *vals;
 };
 
@@ -224,6 +247,8 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
                         val = x / a.p.parts;
                         cell = (x - val * a.p.parts) * a.p.slices + val % a.p.slices;
                         key = (cell << a.p.row_bits) | (s_walk[i] / a.p.world);
+                        if (WRITE && a.hub_bits && ((a.hub_bits[x >> 5] >> (x & 31)) & 1u))
+                            val |= kHubBit;
                         valid = true;
                     }
                 }
@@ -309,7 +334,7 @@ struct BlockArgs {
 };
 
 __device__ __forceinline__ float *sample_base(const BlockArgs &a, float *table, uint32_t row) {
-    return table + (uint64_t)row * a.ld;
+    return table + (uint64_t)(row & ~kHubBit) * a.ld;
 }
 
 __device__ __forceinline__ uint64_t gcd64(uint64_t a, uint64_t b) {
@@ -348,21 +373,28 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
     const uint32_t n_samples = n * (k + 1);
     for (uint32_t t = lane; t < n_samples; t += 64) {
         const uint32_t pr = t / (k + 1), s = t - pr * (k + 1);
-        const uint32_t xrow = s_val[pr];
+        const uint32_t xrow = s_val[pr];  // may carry kHubBit
         uint32_t row = xrow;
         float lab = 1.f;
         if (s != 0) {
             const uint64_t r = draw(ckey, (p0 - lo + pr) * k + (s - 1));
-            uint32_t local = (uint32_t)mulhi64(r, cell_n);
+            uint32_t local = (uint32_t)mulhi64(r, cell_n), hub = 0;
             if (a.alias) {
                 const unsigned long long e = a.alias[alias_lo + local];
-                if ((uint32_t)r >= (uint32_t)e) local = (uint32_t)(e >> 32);
+                hub = (uint32_t)e & 1u;
+                if ((uint32_t)r >= ((uint32_t)e & ~1u)) {
+                    local = (uint32_t)(e >> 32) & ~kHubBit;
+                    hub = (uint32_t)(e >> 63);
+                }
             }
             row = slice + a.p.slices * local;
             lab = 0.f;
             const uint64_t ngid = (uint64_t)row * a.p.parts + a.part;
             const uint64_t cgid = (uint64_t)s_key[pr] * a.p.world + a.p.rank;
-            if (row == xrow || ngid == cgid) row = kSentinel;
+            if (row == (xrow & ~kHubBit) || ngid == cgid)
+                row = kSentinel;
+            else if (hub)
+                row |= kHubBit;
         }
         s_rows[t] = row;
         s_lab[t] = lab;
@@ -384,9 +416,14 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         load_row<CH>(u, crow, q, nchunks, true);
         zero_row<CH>(g);
         Row<CH> u_upd = u;
-        if constexpr (!DET && is_atomic(WMX)) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
-        score_samples<CH, WMX, DET>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
-                                    s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
+        if constexpr (!DET) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
+        if constexpr (!DET && !is_atomic(WMX))  // stores take u, the atomics of hot rows u_upd
+            score_samples<CH, WMX, DET, true>(a, a.context, u, u, g, s_rows + r0 * (k + 1),
+                                              s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp,
+                                              q, &u_upd);
+        else
+            score_samples<CH, WMX, DET>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
+                                        s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
         if constexpr (!DET) reduce_groups<CH>(g);
         if constexpr (!DET && WMC == kAtomic) to_contig_layout<CH>(g, g, s_tr, grp, q, a.ld);
         if (grp == 0) scatter_add<CH, DET ? kWriteBack : WMC>(crow, q, nchunks, 1.0f, g, u);

@@ -36,6 +36,7 @@ int check_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     if (p->walk_length < 2 || p->window < 1) return fail("need walk_length >= 2, window_size >= 1");
     if (p->min_dist > p->window) return fail("min_dist must not exceed window_size");
     if (p->record > gn2v::kMaxRecord) return fail("record must be at most 32 pairs");
+    if (p->hot_lo > 40 || p->hot_hi > p->hot_lo) return fail("need hot_hi <= hot_lo <= 40");
     return 0;
 }
 
@@ -122,9 +123,12 @@ int gn2v_block_alias_temp_bytes(uint64_t n_nodes, uint64_t *bytes) {
 }
 
 int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_alias,
-                     uint64_t *d_cell_rows, void *d_temp, uint64_t temp_bytes, void *stream) {
+                     uint64_t *d_cell_rows, uint32_t *d_hub_bits, void *d_temp,
+                     uint64_t temp_bytes, void *stream) {
     if (check_plan(g, plan)) return 1;
-    if (!d_alias || !d_cell_rows || !d_temp) return fail("NULL pointer");
+    if (!d_alias || !d_cell_rows || !d_hub_bits || !d_temp) return fail("NULL pointer");
+    if ((g->view.n_nodes + plan->parts - 1) / plan->parts >= (1ULL << 31))
+        return fail("a context part must have fewer than 2^31 rows");
     const uint64_t n = g->view.n_nodes;
     uint64_t need = 0;
     gn2v_block_alias_temp_bytes(n, &need);
@@ -138,6 +142,7 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
     uint32_t *stack = (uint32_t *)(t + align256(n * 4));
     unsigned long long *weight = (unsigned long long *)(t + 2 * align256(n * 4));
     HIP_TRY(hipMemsetAsync(indeg, 0, n * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(d_hub_bits, 0, ((n + 31) / 32) * sizeof(uint32_t), s));
     const uint64_t E = g->view.n_edges;
     const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(gn2v::indegree_kernel, dim3(blocks), dim3(256), 0, s, g->view.col_idx, E,
@@ -147,17 +152,18 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
                        plan->slices, (unsigned long long *)d_cell_rows);
     HIP_TRY(hipGetLastError());
     const uint32_t cells = plan->parts * plan->slices;
+    const uint32_t hub_lo = plan->hot_lo, hub_hi = plan->hot_hi;
     hipLaunchKernelGGL(gn2v::alias_kernel, dim3((cells + 63) / 64), dim3(64), 0, s, indeg, n,
                        plan->parts, plan->slices, (const unsigned long long *)d_cell_rows,
-                       (unsigned long long *)d_alias, weight, stack);
+                       (unsigned long long *)d_alias, weight, stack, d_hub_bits, hub_lo, hub_hi);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
                           const uint32_t *d_walks, uint64_t n_walks, uint64_t seed, uint64_t epoch,
-                          uint64_t first_walk, uint64_t *d_work, uint32_t *keys, uint32_t *vals,
-                          hipStream_t s) {
+                          uint64_t first_walk, uint64_t *d_work, const uint32_t *d_hub_bits,
+                          uint32_t *keys, uint32_t *vals, hipStream_t s) {
     gn2v::ExtractArgs a{};
     a.g = g->view;
     a.p = d;
@@ -167,6 +173,7 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     a.first_walk = first_walk;
     a.wave_counts = (unsigned long long *)d_work;
     a.cell_counts = (unsigned long long *)d_work + gn2v::kPrepWaves;
+    a.hub_bits = d_hub_bits;
     a.keys = keys;
     a.vals = vals;
     const uint32_t cells = d.parts * d.slices;
@@ -194,7 +201,7 @@ int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t 
     HIP_TRY(hipMemsetAsync(d_work, 0, GN2V_BLOCK_WORK_WORDS * sizeof(uint64_t), s));
     if (n_walks &&
         launch_extract(g, d, false, d_walks, n_walks, seed, epoch, first_walk, d_work, nullptr,
-                       nullptr, s))
+                       nullptr, nullptr, s))
         return 1;
     hipLaunchKernelGGL(gn2v::block_scan_kernel, dim3(1), dim3(1024), 0, s,
                        (unsigned long long *)d_work,
@@ -212,8 +219,9 @@ int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes) {
 
 int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                        uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                       const uint64_t *d_work, uint64_t n_pairs, uint32_t *d_keys, uint32_t *d_vals,
-                       void *d_temp, uint64_t temp_bytes, void *stream) {
+                       const uint64_t *d_work, const uint32_t *d_hub_bits, uint64_t n_pairs,
+                       uint32_t *d_keys, uint32_t *d_vals, void *d_temp, uint64_t temp_bytes,
+                       void *stream) {
     if (check_plan(g, plan)) return 1;
     const gn2v::BlockPlan d = device_plan(g, plan);
     if (check_key_width(d)) return 1;
@@ -230,7 +238,7 @@ int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_
     uint32_t *vals_in = (uint32_t *)(t + align256(n_pairs * 4));
     void *sort_temp = t + 2 * align256(n_pairs * 4);
     if (launch_extract(g, d, true, d_walks, n_walks, seed, epoch, first_walk,
-                       const_cast<uint64_t *>(d_work), keys_in, vals_in, s))
+                       const_cast<uint64_t *>(d_work), d_hub_bits, keys_in, vals_in, s))
         return 1;
     const uint32_t end_bit = d.row_bits + bits_for((uint64_t)d.parts * d.slices);
     return sort_pairs(sort_temp, temp_bytes - 2 * align256(n_pairs * 4), keys_in, d_keys, vals_in,

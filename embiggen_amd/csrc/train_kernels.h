@@ -319,12 +319,14 @@ __device__ __forceinline__ float *sample_base(const TrainArgs &a, float *table, 
 // for each sample row v: var = (label - sigmoid(clip(u.v))) * lr ; g += var * v ; v += var * u.
 // u_upd is the copy of u the row update consumes (lane-contiguous shape in atomic mode).
 // DET: one sample at a time, all groups redundantly, group 0 writes (strict sequential semantics).
-template <int CH, int WM, bool DET, class Args>
+// HUB: staged ids may carry bit 31 ("hot row", block trainer): such a row is updated with f32
+// atomics from *u_hub (u in the lane-contiguous layout) whatever WM says.
+template <int CH, int WM, bool DET, bool HUB = false, class Args>
 __device__ __forceinline__ void score_samples(const Args &a, float *table, const Row<CH> &u,
                                               const Row<CH> &u_upd, Row<CH> &g,
                                               const uint32_t *s_rows,
                                               const float *s_lab, uint32_t n_samples, float lrc,
-                                              int grp, int q) {
+                                              int grp, int q, const Row<CH> *u_hub = nullptr) {
     const uint32_t nchunks = a.ld >> 2;
     if constexpr (DET) {
         for (uint32_t t = 0; t < n_samples; ++t) {
@@ -355,7 +357,14 @@ __device__ __forceinline__ void score_samples(const Args &a, float *table, const
                 const float dot = dot_rows<CH>(u, v);
                 const float var = mine ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
                 axpy<CH>(g, var, v);
-                if (mine) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
+                if constexpr (HUB) {
+                    if (mine && (row & 0x80000000u))
+                        scatter_add<CH, kAtomic>(base, q, nchunks, var, *u_hub, v);
+                    else if (mine)
+                        scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
+                } else {
+                    if (mine) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
+                }
             }
         }
     }

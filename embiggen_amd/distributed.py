@@ -175,14 +175,14 @@ class GpuBlockBackend:
 
         return ops.block_alias(self.graph, plan, device=self.index)
 
-    def prepare(self, plan, walks_all, seed, epoch, first_walk):
+    def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None):
         """-> (keys, vals, cell_offsets, n_pairs); one host read (the pair count)."""
         from . import ops
 
         work, offsets = ops.block_count(self.graph, plan, walks_all, seed, epoch, first_walk)
         n_pairs = int(offsets[-1])
         keys, vals = ops.block_extract(self.graph, plan, walks_all, seed, epoch, first_walk, work,
-                                       n_pairs)
+                                       n_pairs, hub_bits=hub_bits)
         return keys, vals, offsets, n_pairs
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
@@ -203,7 +203,7 @@ class BlockPartitionedTrainer:
     def __init__(self, graph, train_params, d: int, ld: int, seed: int, init_scale: float, comm,
                  device, walk_length: int, window: int, min_dist: int = 1,
                  scale_free: bool = True, backend=None, parts: Optional[int] = None,
-                 slices: Optional[int] = None, record: int = 16):
+                 slices: Optional[int] = None, record: int = 16, hot_band=(0, 0)):
         self.graph, self.tp, self.comm = graph, train_params, comm
         self.d, self.ld, self.seed = d, ld, seed
         self.n_nodes = graph.get_number_of_nodes()
@@ -217,10 +217,12 @@ class BlockPartitionedTrainer:
         self.parts, self.slices = parts, slices
         self.plan = self.backend.plan(world=world, rank=rank, parts=parts, slices=slices,
                                       walk_length=walk_length, window=window, min_dist=min_dist,
-                                      record=record, flags=int(train_params.flags) & 2)
+                                      record=record, flags=int(train_params.flags) & 2,
+                                      hot_lo=int(hot_band[0]), hot_hi=int(hot_band[1]))
         self.scale_free = bool(scale_free)
-        self.alias, self.cell_rows = (self.backend.alias_tables(self.plan) if scale_free
-                                      else (None, None))
+        # per-cell alias tables for the negatives + the hot-row flags (rows updated by atomics)
+        self.alias, self.cell_rows, self.hub_bits = (
+            self.backend.alias_tables(self.plan) if scale_free else (None, None, None))
         for p in range(parts):
             if stripe_rows(self.n_nodes, p, parts) == 0:
                 raise ValueError("A context part owns no node: graph too small to split this far.")
@@ -254,7 +256,7 @@ class BlockPartitionedTrainer:
         ``walks``: this rank's int32 [n, L] slice (ids first_walk + rank * n + [0, n)); every rank
         passes the same n (ranks with fewer walks pad with sentinel rows)."""
         walks_all = self.comm.all_gather(walks)
-        return self.backend.prepare(self.plan, walks_all, seed, epoch, first_walk)
+        return self.backend.prepare(self.plan, walks_all, seed, epoch, first_walk, self.hub_bits)
 
     def train_prepared(self, prepared, seed: int, epoch: int, lr: float):
         """`parts` episodes over the prepared pairs of one round."""

@@ -132,17 +132,21 @@ def init_table_rows(n_rows: int, d: int, seed: int, table_id: int, scale: float,
 
 # ------------------------------------------------------------- block-partitioned SkipGram
 def block_plan(graph: CSRGraph, world: int, rank: int, parts: int, slices: int, walk_length: int,
-               window: int, min_dist: int = 1, record: int = 16, flags: int = 0, device: int = 0):
-    """A validated ``gn2v_block_plan`` (row_bits filled in by the library)."""
+               window: int, min_dist: int = 1, record: int = 16, flags: int = 0, device: int = 0,
+               hot_lo: int = 0, hot_hi: int = 0):
+    """A validated ``gn2v_block_plan`` (row_bits filled in by the library).  ``hot_lo`` /
+    ``hot_hi``: contextual rows whose share of their cell's edge endpoints lies in
+    [2^-hot_lo, 2^-hot_hi) are updated with atomics (off by default)."""
     plan = _lib.BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, 0,
-                          flags)
+                          flags, hot_lo, hot_hi)
     _lib.check(_lib.lib().gn2v_block_plan_check(graph.device_graph(device).handle, C.byref(plan)))
     return plan
 
 
 def block_alias(graph: CSRGraph, plan, device: int = 0):
-    """(alias int64 [n_nodes], cell_rows int64 [cells + 1]): per-cell alias tables for
-    degree-proportional negatives (``gn2v_block_alias``)."""
+    """(alias int64 [n_nodes], cell_rows int64 [cells + 1], hub_bits int32 [(n_nodes + 31) // 32]):
+    per-cell alias tables for degree-proportional negatives and the hot-row flags
+    (``gn2v_block_alias``)."""
     torch = _torch()
     dg = graph.device_graph(device)
     dev = torch.device("cuda", device)
@@ -152,10 +156,11 @@ def block_alias(graph: CSRGraph, plan, device: int = 0):
     temp = torch.empty(need.value, dtype=torch.uint8, device=dev)
     alias = torch.empty(n, dtype=torch.int64, device=dev)
     cell_rows = torch.empty(plan.parts * plan.slices + 1, dtype=torch.int64, device=dev)
+    hub_bits = torch.empty((n + 31) // 32, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().gn2v_block_alias(dg.handle, C.byref(plan), alias.data_ptr(),
-                                           cell_rows.data_ptr(), temp.data_ptr(), need.value,
-                                           _stream(dev)))
-    return alias, cell_rows
+                                           cell_rows.data_ptr(), hub_bits.data_ptr(),
+                                           temp.data_ptr(), need.value, _stream(dev)))
+    return alias, cell_rows, hub_bits
 
 
 def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
@@ -183,7 +188,7 @@ def block_extract_temp_bytes(n_pairs: int) -> int:
 
 
 def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
-                  work, n_pairs: int, keys=None, vals=None, temp=None):
+                  work, n_pairs: int, keys=None, vals=None, temp=None, hub_bits=None):
     """Pass 2 + sort: (keys int32 [n_pairs], vals int32 [n_pairs]) sorted by key."""
     torch = _torch()
     dev = walks_tensor.device
@@ -197,8 +202,8 @@ def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, fi
     assert keys.numel() >= n_pairs and vals.numel() >= n_pairs and temp.numel() >= need
     _lib.check(_lib.lib().gn2v_block_extract(
         dg.handle, C.byref(plan), walks_tensor.data_ptr(), walks_tensor.shape[0], seed, epoch,
-        first_walk, work.data_ptr(), n_pairs, keys.data_ptr(), vals.data_ptr(), temp.data_ptr(),
-        temp.numel(), _stream(dev)))
+        first_walk, work.data_ptr(), None if hub_bits is None else hub_bits.data_ptr(), n_pairs,
+        keys.data_ptr(), vals.data_ptr(), temp.data_ptr(), temp.numel(), _stream(dev)))
     return keys, vals
 
 

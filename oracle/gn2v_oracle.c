@@ -931,6 +931,7 @@ typedef struct {
     uint32_t walk_length, window, min_dist, record;
     uint32_t row_bits;
     uint32_t flags;
+    uint32_t hot_lo, hot_hi; /* band of "hot" rows, 0 / 0 = off (see o_block_alias) */
 } o_block_plan;
 
 uint32_t o_block_row_bits(uint64_t n_nodes, uint32_t world) {
@@ -943,7 +944,7 @@ uint32_t o_block_row_bits(uint64_t n_nodes, uint32_t world) {
 /* pairs of this rank in walk / position / slot order; keys / vals may be NULL (count only) */
 uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t *walks,
                          uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                         uint32_t *keys, uint32_t *vals) {
+                         const uint32_t *hub_bits, uint32_t *keys, uint32_t *vals) {
     uint64_t n = 0, ekey = o_epoch_key(seed, epoch);
     uint32_t L = p->walk_length, w = p->window, md = p->min_dist ? p->min_dist : 1;
     o_train_params tp;
@@ -966,7 +967,8 @@ uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t
                 uint32_t cell = (x % p->parts) * p->slices + row % p->slices;
                 if (keys) {
                     keys[n] = (cell << p->row_bits) | (c / p->world);
-                    vals[n] = row;
+                    /* hot context rows carry bit 31 (updated with atomics on the device) */
+                    vals[n] = row | ((hub_bits && ((hub_bits[x >> 5] >> (x & 31)) & 1u)) ? 0x80000000u : 0u);
                 }
                 ++n;
             }
@@ -1027,10 +1029,15 @@ static inline uint64_t scaled_threshold(uint64_t w, uint64_t D) {
  * random directed edge, node2vec_skipgram.py:101-102).  table[cell_rows[c] + i] = threshold on a
  * 2^32 scale | alias row << 32 for row i of cell c.  A draw r picks i = mulhi(r, n) and keeps it
  * when (u32) r < threshold, else takes the alias. */
-void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint64_t *table,
-                   uint64_t *cell_rows) {
+/* Hot rows (in-degree share of the cell's total in [2^-hot_lo, 2^-hot_hi); 0 / 0 = none) are
+ * flagged: bit 0 of an entry = the row itself (the threshold keeps its upper 31 bits), bit 63 =
+ * its alias row, hub_bits = one bit per node id.  The flags steer the device's store flavour
+ * only; this file's arithmetic ignores them. */
+void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t hot_lo,
+                   uint32_t hot_hi, uint64_t *table, uint64_t *cell_rows, uint32_t *hub_bits) {
     uint32_t *indeg = (uint32_t *)calloc(g->n_nodes, sizeof(uint32_t));
     for (uint64_t e = 0; e < g->n_edges; ++e) indeg[g->col_idx[e]]++;
+    memset(hub_bits, 0, sizeof(uint32_t) * ((g->n_nodes + 31) / 32));
     uint64_t run = 0;
     for (uint32_t p = 0; p < parts; ++p) {
         uint64_t part_rows = stripe_count(g->n_nodes, p, parts);
@@ -1049,9 +1056,14 @@ void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint64_t *
         if (n == 0) continue;
         for (uint64_t i = 0; i < n; ++i) D += indeg[(slice + (uint64_t)slices * i) * parts + part];
         uint64_t n_small = 0, n_large = 0; /* small stack from st[0], large from st[n - 1] */
+#define O_NODE_OF(i) ((slice + (uint64_t)slices * (i)) * parts + part)
+#define O_HOT(i)                                                                  \
+    ((uint64_t)(hot_lo != 0 && D != 0 && ((uint64_t)indeg[O_NODE_OF(i)] << hot_lo) >= D && \
+                (hot_hi == 0 || ((uint64_t)indeg[O_NODE_OF(i)] << hot_hi) < D)))
         for (uint64_t i = 0; i < n; ++i) {
-            uint64_t p = (uint64_t)indeg[(slice + (uint64_t)slices * i) * parts + part] * n;
+            uint64_t p = (uint64_t)indeg[O_NODE_OF(i)] * n;
             w[i] = p;
+            if (O_HOT(i)) hub_bits[O_NODE_OF(i) >> 5] |= 1u << (O_NODE_OF(i) & 31);
             if (D == 0 || p >= D)
                 st[n - 1 - n_large++] = (uint32_t)i;
             else
@@ -1059,7 +1071,8 @@ void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint64_t *
         }
         while (n_small && n_large) {
             uint32_t sidx = st[--n_small], lidx = st[n - n_large];
-            t[sidx] = ((uint64_t)lidx << 32) | scaled_threshold(w[sidx], D);
+            t[sidx] = (O_HOT(lidx) << 63) | ((uint64_t)lidx << 32) |
+                      (scaled_threshold(w[sidx], D) & ~1ull) | O_HOT(sidx);
             uint64_t pl = w[lidx] + w[sidx] - D;
             w[lidx] = pl;
             if (pl < D) {
@@ -1069,12 +1082,14 @@ void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint64_t *
         }
         while (n_large) {
             uint32_t i = st[n - n_large--];
-            t[i] = ((uint64_t)i << 32) | 0xFFFFFFFFull;
+            t[i] = (O_HOT(i) << 63) | ((uint64_t)i << 32) | 0xFFFFFFFEull | O_HOT(i);
         }
         while (n_small) {
             uint32_t i = st[--n_small];
-            t[i] = ((uint64_t)i << 32) | 0xFFFFFFFFull;
+            t[i] = (O_HOT(i) << 63) | ((uint64_t)i << 32) | 0xFFFFFFFEull | O_HOT(i);
         }
+#undef O_NODE_OF
+#undef O_HOT
     }
     free(indeg);
     free(w);
@@ -1132,7 +1147,7 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
                 memcpy(u, cptr, d * sizeof(float));
                 memset(gacc, 0, d * sizeof(float));
                 for (uint32_t pr = r0; pr < r1; ++pr) {
-                    uint32_t xrow = vals[p0 + pr];
+                    uint32_t xrow = vals[p0 + pr] & 0x7FFFFFFFu; /* bit 31: hot-row flag */
                     for (uint32_t s = 0; s <= k; ++s) {
                         uint32_t row = xrow;
                         float label = 1.0f;
@@ -1141,7 +1156,8 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
                             uint32_t local = (uint32_t)mulhi64(r, cell_n);
                             if (use_alias) {
                                 uint64_t e = alias[alias_lo + local];
-                                if ((uint32_t)r >= (uint32_t)e) local = (uint32_t)(e >> 32);
+                                if ((uint32_t)r >= ((uint32_t)e & ~1u))
+                                    local = (uint32_t)(e >> 32) & 0x7FFFFFFFu;
                             }
                             row = slice + p->slices * local;
                             label = 0.0f;

@@ -322,19 +322,20 @@ class BlockPlan(C.Structure):
 
     _fields_ = [(name, C.c_uint32) for name in (
         "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
-        "row_bits", "flags")]
+        "row_bits", "flags", "hot_lo", "hot_hi")]
 
 
 def block_plan(n_nodes: int, world: int, rank: int, parts: int, slices: int, walk_length: int,
-               window: int, min_dist: int = 1, record: int = 16, flags: int = 0) -> BlockPlan:
+               window: int, min_dist: int = 1, record: int = 16, flags: int = 0, hot_lo: int = 0,
+               hot_hi: int = 0) -> BlockPlan:
     lib().o_block_row_bits.restype = C.c_uint32
     bits = lib().o_block_row_bits(C.c_uint64(n_nodes), C.c_uint32(world))
     return BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, bits,
-                     flags)
+                     flags, hot_lo, hot_hi)
 
 
 def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: int,
-                  first_walk: int, sort: bool = True):
+                  first_walk: int, sort: bool = True, hub_bits=None):
     """(keys, vals, cell_offsets): the pairs of the walks whose centre `plan.rank` owns, sorted
     stably by key = cell << row_bits | centre row (``sort=False``: extraction order)."""
     walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
@@ -343,10 +344,10 @@ def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: 
     L.o_block_extract.restype = C.c_uint64
     args = (C.byref(g.c), C.byref(plan), _ptr(walks_arr), C.c_uint64(n_walks), C.c_uint64(seed),
             C.c_uint64(epoch), C.c_uint64(first_walk))
-    n = int(L.o_block_extract(*args, None, None))
+    n = int(L.o_block_extract(*args, None, None, None))
     keys, vals = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
     if n:
-        L.o_block_extract(*args, _ptr(keys), _ptr(vals))
+        L.o_block_extract(*args, _ptr(hub_bits), _ptr(keys), _ptr(vals))
         if sort:
             L.o_block_sort(_ptr(keys), _ptr(vals), C.c_uint64(n))
     cells = plan.parts * plan.slices
@@ -357,13 +358,15 @@ def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: 
     return keys, vals, offsets
 
 
-def block_alias(g: OracleGraph, parts: int, slices: int):
-    """(alias tables u64[n_nodes] = threshold | alias row << 32, cell_rows u64[cells + 1])."""
+def block_alias(g: OracleGraph, parts: int, slices: int, hot_lo: int = 0, hot_hi: int = 0):
+    """(alias tables u64[n_nodes], cell_rows u64[cells + 1], hub_bits u32[(n_nodes + 31) // 32]):
+    entry = hot(row) | threshold (31 bits) | alias row << 32 | hot(alias row) << 63."""
     table = np.zeros(g.n_nodes, dtype=np.uint64)
     cell_rows = np.empty(parts * slices + 1, dtype=np.uint64)
-    lib().o_block_alias(C.byref(g.c), C.c_uint32(parts), C.c_uint32(slices), _ptr(table),
-                        _ptr(cell_rows))
-    return table, cell_rows
+    hub_bits = np.zeros((g.n_nodes + 31) // 32, dtype=np.uint32)
+    lib().o_block_alias(C.byref(g.c), C.c_uint32(parts), C.c_uint32(slices), C.c_uint32(hot_lo),
+                        C.c_uint32(hot_hi), _ptr(table), _ptr(cell_rows), _ptr(hub_bits))
+    return table, cell_rows, hub_bits
 
 
 def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, keys, vals, cell_offsets, alias,

@@ -93,15 +93,16 @@ int main(void) {
 
     /* block-partitioned schedule: extraction, stable sort, alias tables, one round over every part */
     {
-        o_block_plan bp = {3, 1, 6, 2, 20, 3, 1, 4, o_block_row_bits(N, 3), 0};
+        o_block_plan bp = {3, 1, 6, 2, 20, 3, 1, 4, o_block_row_bits(N, 3), 0, 6, 2};
         uint64_t nw = ns * 3, cap = nw * 20 * 6;
         uint32_t *bk = malloc(sizeof(uint32_t) * cap), *bv = malloc(sizeof(uint32_t) * cap);
-        uint64_t nb = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, bk, bv);
+        uint32_t hub[(N + 31) / 32];
+        uint64_t *alias = malloc(sizeof(uint64_t) * N), poff[13];
+        o_block_alias(&g, 6, 2, bp.hot_lo, bp.hot_hi, alias, poff, hub);
+        uint64_t nb = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, hub, bk, bv);
         o_block_sort(bk, bv, nb);
-        uint64_t off[13], poff[13];
+        uint64_t off[13];
         o_block_cell_offsets(bk, nb, bp.row_bits, 12, off);
-        uint64_t *alias = malloc(sizeof(uint64_t) * N);
-        o_block_alias(&g, 6, 2, alias, poff);
         uint64_t crows = (N + 3 - 1 - 1) / 3 + 1, xrows = N / 6 + 1, trained = 0;
         float *bc = malloc(sizeof(float) * crows * 12), *bx = malloc(sizeof(float) * xrows * 12);
         o_init_table_rows(bc, (N - 1 + 2) / 3, 10, 12, 5, 0, 0.3f, 1, 3);

@@ -89,16 +89,18 @@ class OracleBlockBackend:
     def empty_rows(self, n_rows, ld):
         return torch.zeros((n_rows, ld), dtype=torch.float32)
 
-    def plan(self, world, rank, parts, slices, walk_length, window, min_dist, record, flags):
+    def plan(self, world, rank, parts, slices, walk_length, window, min_dist, record, flags,
+             hot_lo=0, hot_hi=0):
         return O.block_plan(self.graph.get_number_of_nodes(), world, rank, parts, slices,
-                            walk_length, window, min_dist, record, flags)
+                            walk_length, window, min_dist, record, flags, hot_lo, hot_hi)
 
     def alias_tables(self, plan):
-        return O.block_alias(self.og, plan.parts, plan.slices)
+        return O.block_alias(self.og, plan.parts, plan.slices, plan.hot_lo, plan.hot_hi)
 
-    def prepare(self, plan, walks_all, seed, epoch, first_walk):
+    def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None):
         walks = walks_all.cpu().numpy().view(np.uint32)
-        keys, vals, offsets = O.block_extract(self.og, plan, walks, seed, epoch, first_walk)
+        keys, vals, offsets = O.block_extract(self.og, plan, walks, seed, epoch, first_walk,
+                                              hub_bits=hub_bits)
         return keys, vals, offsets, len(keys)
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,

@@ -85,9 +85,9 @@ def test_extraction_partitions_the_pairs_of_the_walks(world, parts, slices):
 
 def _alias_probabilities(table, n):
     """Exact law of a draw from one cell's alias table (thresholds on a 2^32 scale)."""
-    thresh = (table & np.uint64(0xFFFFFFFF)).astype(np.float64)
-    alias = (table >> np.uint64(32)).astype(np.int64)
-    keep = np.where(thresh >= 0xFFFFFFFF, 1.0, thresh / 2.0 ** 32)
+    thresh = (table & np.uint64(0xFFFFFFFE)).astype(np.float64)  # bit 0 is the hot-row flag
+    alias = ((table >> np.uint64(32)) & np.uint64(0x7FFFFFFF)).astype(np.int64)
+    keep = np.where(thresh >= 0xFFFFFFFE, 1.0, thresh / 2.0 ** 32)
     p = keep / n
     np.add.at(p, alias, (1.0 - keep) / n)
     return p
@@ -96,7 +96,11 @@ def _alias_probabilities(table, n):
 def test_alias_tables_are_degree_proportional_inside_a_cell():
     g = _graph(97)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    table, cell_rows = O.block_alias(og, 4, 2)
+    table, cell_rows, hub_bits = O.block_alias(og, 4, 2, hot_lo=4, hot_hi=2)
+    plain = O.block_alias(og, 4, 2)  # default: no hot rows, same law
+    assert not plain[2].any() and not (plain[0] & np.uint64(1)).any() and not (plain[0] >> np.uint64(63)).any()
+    assert np.array_equal(plain[0] >> np.uint64(1) << np.uint64(1) & np.uint64(0x7FFFFFFFFFFFFFFF),
+                          table >> np.uint64(1) << np.uint64(1) & np.uint64(0x7FFFFFFFFFFFFFFF))
     assert cell_rows[-1] == 97 and cell_rows[0] == 0
     indeg = np.bincount(og.col_idx, minlength=97).astype(np.float64)
     for cell in range(8):
@@ -108,7 +112,15 @@ def test_alias_tables_are_degree_proportional_inside_a_cell():
         p = _alias_probabilities(table[lo:hi], hi - lo)
         want = indeg[nodes] / indeg[nodes].sum()
         assert np.abs(p - want).max() < 1e-8 and abs(p.sum() - 1) < 1e-9
-        assert ((table[lo:hi] >> np.uint64(32)) < hi - lo).all()
+        alias_row = (table[lo:hi] >> np.uint64(32)) & np.uint64(0x7FFFFFFF)
+        assert (alias_row < hi - lo).all()
+        # hot rows: share of the cell's edge endpoints in [2^-4, 2^-2)
+        total = indeg[nodes].sum()
+        hot = (indeg[nodes] * 16 >= total) & (indeg[nodes] * 4 < total)
+        assert hot.any() and not hot.all()
+        assert np.array_equal((table[lo:hi] & np.uint64(1)).astype(bool), hot)
+        assert np.array_equal((table[lo:hi] >> np.uint64(63)).astype(bool), hot[alias_row.astype(int)])
+        assert np.array_equal(((hub_bits[nodes >> 5] >> (nodes & 31)) & 1).astype(bool), hot)
     # empirical check of the sampler itself on one cell: chi-square against the degrees
     from scipy import stats
     lo, hi = int(cell_rows[3]), int(cell_rows[4])
@@ -116,8 +128,9 @@ def test_alias_tables_are_degree_proportional_inside_a_cell():
     r = np.array([O.lib().o_draw(C_u64(12345), C_u64(t)) for t in range(40000)], dtype=np.uint64)
     local = ((r >> np.uint64(32)) * np.uint64(n) >> np.uint64(32)).astype(np.int64)  # ~ mulhi
     e = table[lo:hi][local]
-    take_alias = (r & np.uint64(0xFFFFFFFF)) >= (e & np.uint64(0xFFFFFFFF))
-    local = np.where(take_alias, (e >> np.uint64(32)).astype(np.int64), local)
+    take_alias = (r & np.uint64(0xFFFFFFFF)) >= (e & np.uint64(0xFFFFFFFE))
+    local = np.where(take_alias, ((e >> np.uint64(32)) & np.uint64(0x7FFFFFFF)).astype(np.int64),
+                     local)
     nodes = (1 + 2 * np.arange(n)) * 4 + 1
     want = indeg[nodes] / indeg[nodes].sum()
     counts = np.bincount(local, minlength=n).astype(np.float64)
@@ -139,7 +152,7 @@ def test_step_properties_zero_lr_counts_and_untouched_rows():
     walks = O.walks(og, O.WalkParams(L, 1, 1.0, 1.0, 100, 0), 5, 0, 0, 30)
     plan = O.block_plan(97, 1, 0, 2, 1, L, W, 1, 4)
     keys, vals, offsets = O.block_extract(og, plan, walks, 5, 0, 0)
-    alias, cell_rows = O.block_alias(og, 2, 1)
+    alias, cell_rows, _ = O.block_alias(og, 2, 1)
     c = O.init_table_rows(97, D, D, 5, 0, 0.3, 0, 1)
     assert np.array_equal(c, O.init_table(97, D, D, 5, 0, 0.3))
     parts = [O.init_table_rows(stripe_rows(97, p, 2), D, D, 5, 1, 0.3, p, 2) for p in range(2)]
@@ -169,7 +182,7 @@ def test_world_one_trainer_is_the_plain_sequence_of_block_steps():
     g = _graph()
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     plan = O.block_plan(34, 1, 0, 2, 1, L, W, 1, 4)
-    alias, cell_rows = O.block_alias(og, 2, 1)
+    alias, cell_rows, _ = O.block_alias(og, 2, 1)
     rc = O.init_table(34, D, D, 42, 0, D ** -0.5)
     rx = O.init_table(34, D, D, 42, 1, D ** -0.5)
     parts = [np.ascontiguousarray(rx[p::2]) for p in range(2)]

@@ -56,14 +56,16 @@ def test_extraction_and_sort_are_bit_exact(world, rank, parts, slices, md):
     wk = ops.walks(g, ops.walk_params(24, 4, 0.5, 2.0), 5, 1, 100, 300)
     wk[::5, 9:] = -1   # ended walks
     wk[7] = -1         # a padding walk (rank with no walks left)
-    plan = ops.block_plan(g, world, rank, parts, slices, 24, 4, md, 4)
-    oplan = O.block_plan(203, world, rank, parts, slices, 24, 4, md, 4)
+    plan = ops.block_plan(g, world, rank, parts, slices, 24, 4, md, 4, hot_lo=5, hot_hi=0)
+    oplan = O.block_plan(203, world, rank, parts, slices, 24, 4, md, 4, hot_lo=5, hot_hi=0)
     assert plan.row_bits == oplan.row_bits
+    _, _, hub_bits = ops.block_alias(g, plan)
     work, offsets = ops.block_count(g, plan, wk, 5, 1, 100)
     n = int(offsets[-1])
-    keys, vals = ops.block_extract(g, plan, wk, 5, 1, 100, work, n)
-    rk, rv, ro = O.block_extract(og, oplan, _u32(wk), 5, 1, 100)
-    assert n == len(rk) and n > 0
+    keys, vals = ops.block_extract(g, plan, wk, 5, 1, 100, work, n, hub_bits=hub_bits)
+    rk, rv, ro = O.block_extract(og, oplan, _u32(wk), 5, 1, 100,
+                                 hub_bits=O.block_alias(og, parts, slices, 5, 0)[2])
+    assert n == len(rk) and n > 0 and (rv >> 31).any()  # hot context rows are flagged
     assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
     assert np.array_equal(_u32(keys), rk) and np.array_equal(_u32(vals), rv)
     # empty input: no pairs, all offsets zero
@@ -85,28 +87,32 @@ def test_extraction_honours_centre_downsampling(karate, karate_oracle):
     assert np.array_equal(_u32(keys), rk) and np.array_equal(_u32(vals), rv)
 
 
-@pytest.mark.parametrize("parts,slices", [(1, 1), (4, 1), (6, 8), (16, 8)])
-def test_alias_tables_are_bit_exact(parts, slices):
+@pytest.mark.parametrize("parts,slices,band", [(1, 1, (0, 0)), (4, 1, (6, 0)), (6, 8, (5, 2)),
+                                               (16, 8, (0, 0)), (16, 8, (3, 1))])
+def test_alias_tables_are_bit_exact(parts, slices, band):
     g = _ba(997, 4)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2)
-    alias, cell_rows = ops.block_alias(g, plan)
-    ra, rc = O.block_alias(og, parts, slices)
+    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, hot_lo=band[0], hot_hi=band[1])
+    alias, cell_rows, hub_bits = ops.block_alias(g, plan)
+    ra, rc, rh = O.block_alias(og, parts, slices, *band)
     assert np.array_equal(cell_rows.cpu().numpy().astype(np.uint64), rc)
     assert np.array_equal(alias.cpu().numpy().view(np.uint64), ra)
+    assert np.array_equal(hub_bits.cpu().numpy().view(np.uint32), rh) and rh.any() == (band[0] > 0)
 
 
 def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, n_walks=60,
-               wl=14, window=3, part_list=None, scale_free=True, extra=0):
+               wl=14, window=3, part_list=None, scale_free=True, extra=0, band=(0, 0)):
     """One round through gn2v_block_step and through the oracle; returns both table sets."""
     n = g.get_number_of_nodes()
     ld = (d + 3) // 4 * 4
     wk = ops.walks(g, ops.walk_params(wl, 2, 0.5, 2.0), 11, 0, 0, n_walks)
-    plan = ops.block_plan(g, world, rank, parts, slices, wl, window, 1, record)
-    oplan = O.block_plan(n, world, rank, parts, slices, wl, window, 1, record)
+    plan = ops.block_plan(g, world, rank, parts, slices, wl, window, 1, record, hot_lo=band[0],
+                          hot_hi=band[1])
+    oplan = O.block_plan(n, world, rank, parts, slices, wl, window, 1, record, hot_lo=band[0],
+                         hot_hi=band[1])
     work, offsets = ops.block_count(g, plan, wk, 11, 0, 0)
-    keys, vals = ops.block_extract(g, plan, wk, 11, 0, 0, work, int(offsets[-1]))
-    alias, cell_rows = ops.block_alias(g, plan)
+    alias, cell_rows, hub_bits = ops.block_alias(g, plan)
+    keys, vals = ops.block_extract(g, plan, wk, 11, 0, 0, work, int(offsets[-1]), hub_bits=hub_bits)
     sf = (1 if scale_free else 0) | extra
     tp = ops.train_params(0, d, k, window, flags=sf | flags, ld=ld)
     otp = O.TrainParams(0, d, ld, 1, k, window, 0.01, 0.9, 6.0, sf, d ** -0.5)
@@ -144,6 +150,18 @@ def test_deterministic_block_step_over_plans(world, rank, parts, slices, record)
     g = _ba(203)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     c, xs, c_h, xs_h = _step_both(g, og, D, K, world, rank, parts, slices, record, DET)
+    assert np.abs(c - c_h).max() < 1e-5
+    for x, x_h in zip(xs, xs_h):
+        assert np.abs(x - x_h).max() < 1e-5
+
+
+def test_hot_row_flags_do_not_change_the_deterministic_result():
+    """A band that flags many rows as hot: the flags only steer the store flavour, the
+    deterministic schedule still equals the oracle (which masks them).  The mixed store / atomic
+    rounds of the production flavours are exercised, exactly, by the collision-free test below."""
+    g = _ba(203)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    c, xs, c_h, xs_h = _step_both(g, og, D, K, 2, 1, 4, 2, 4, DET, band=(5, 0))
     assert np.abs(c - c_h).max() < 1e-5
     for x, x_h in zip(xs, xs_h):
         assert np.abs(x - x_h).max() < 1e-5
@@ -187,6 +205,7 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
         offsets.append(offsets[-1] + m)
     keys_h = np.concatenate(keys_l).astype(np.uint32)
     vals_h = np.concatenate(vals_l).astype(np.uint32)
+    vals_h[1::2] |= np.uint32(0x80000000)  # every other context row is "hot": updated by atomics
     off_h = np.asarray(offsets, dtype=np.uint64)
     keys = torch.from_numpy(keys_h.view(np.int32)).cuda()
     vals = torch.from_numpy(vals_h.view(np.int32)).cuda()

@@ -134,17 +134,23 @@ def test_random_block_rounds_match_oracle(case):
     seed, epoch, first = int(rng.randint(0, 2 ** 31)), int(rng.randint(0, 5)), int(rng.randint(0, 10 ** 6))
     n_src = g.get_number_of_unique_source_nodes()
     wk = ops.walks(g, ops.walk_params(L, 2, 0.5, 2.0), seed, epoch, first, 2 * n_src)
-    plan = ops.block_plan(g, world, rank, parts, slices, L, w, md, record, flags=down)
-    oplan = O.block_plan(n, world, rank, parts, slices, L, w, md, record, flags=down)
+    band = (int(rng.randint(2, 8)), int(rng.choice([0, 1]))) if rng.rand() < 0.5 else (0, 0)
+    plan = ops.block_plan(g, world, rank, parts, slices, L, w, md, record, flags=down,
+                          hot_lo=band[0], hot_hi=band[1])
+    oplan = O.block_plan(n, world, rank, parts, slices, L, w, md, record, flags=down,
+                         hot_lo=band[0], hot_hi=band[1])
+    alias, cell_rows, hub_bits = ops.block_alias(g, plan)
+    ra, rc, rh = O.block_alias(og, parts, slices, *band)
     work, offsets = ops.block_count(g, plan, wk, seed, epoch, first)
     n_pairs = int(offsets[-1])
-    keys, vals = ops.block_extract(g, plan, wk, seed, epoch, first, work, n_pairs)
-    rk, rv, ro = O.block_extract(og, oplan, wk.cpu().numpy().view(np.uint32), seed, epoch, first)
+    keys, vals = ops.block_extract(g, plan, wk, seed, epoch, first, work, n_pairs,
+                                   hub_bits=hub_bits)
+    rk, rv, ro = O.block_extract(og, oplan, wk.cpu().numpy().view(np.uint32), seed, epoch, first,
+                                 hub_bits=rh)
     assert np.array_equal(keys.cpu().numpy().view(np.uint32), rk)
     assert np.array_equal(vals.cpu().numpy().view(np.uint32), rv)
     assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
-    alias, cell_rows = ops.block_alias(g, plan)
-    ra, rc = O.block_alias(og, parts, slices)
+    assert np.array_equal(hub_bits.cpu().numpy().view(np.uint32), rh)
     assert np.array_equal(alias.cpu().numpy().view(np.uint64), ra)
     assert np.array_equal(cell_rows.cpu().numpy().astype(np.uint64), rc)
     if n_pairs == 0:
