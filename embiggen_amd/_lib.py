@@ -102,7 +102,7 @@ class BlockPlan(C.Structure):
 
     _fields_ = [(name, C.c_uint32) for name in (
         "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
-        "row_bits", "flags", "hot_lo", "hot_hi")]
+        "row_bits", "flags", "hot_lo", "hot_hi", "key_bits")]
 
 
 class BlockIO(C.Structure):
@@ -216,7 +216,7 @@ def lib():
     L.gn2v_block_alias_temp_bytes.argtypes = [u64, C.POINTER(u64)]
     L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, vp, u64, vp]
     L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, vp, vp]
-    L.gn2v_block_extract_temp_bytes.argtypes = [u64, C.POINTER(u64)]
+    L.gn2v_block_extract_temp_bytes.argtypes = [u64, u32, C.POINTER(u64)]
     L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, vp,
                                      u64, vp, vp, vp, u64, vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),

@@ -38,6 +38,7 @@ struct BlockPlan {
     uint32_t L, window, min_dist, record;
     uint32_t row_bits;
     uint32_t flags;  // kFlagDownsample: centres are thinned at extraction (needs the graph)
+    uint32_t key64;  // sort keys are u64 (cell and centre row do not fit 32 bits)
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -170,7 +171,8 @@ struct ExtractArgs {
     unsigned long long *wave_counts;  // [kPrepWaves]: counts out (count pass), offsets in (write)
     unsigned long long *cell_counts;  // [cells] (count pass)
     const uint32_t *hub_bits;         // one bit per node (gn2v_block_alias), or nullptr
-    uint32_t *keys, *vals;
+    void *keys;                       // KeyT[n_pairs]
+    uint32_t *vals;
 };
 
 __device__ __forceinline__ bool keep_centre_at(const GraphView &g, uint64_t wkey, uint32_t i,
@@ -184,7 +186,7 @@ __device__ __forceinline__ bool keep_centre_at(const GraphView &g, uint64_t wkey
     return lhs_hi < rhs_hi || (lhs_hi == rhs_hi && lhs_lo < rhs_lo);
 }
 
-template <bool WRITE>
+template <bool WRITE, class KeyT>
 __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
         for (uint32_t t0 = 0; t0 < n_slots; t0 += 64) {
             const uint32_t t = t0 + lane;
             bool valid = false;
-            uint32_t key = 0, val = 0, cell = 0;
+            KeyT key = 0;
+            uint32_t val = 0, cell = 0;
             if (t < n_slots) {
                 const uint32_t idx = t / w2, slot = t - idx * w2;
                 const uint32_t i = s_own[idx];
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
                         const uint32_t x = s_walk[j];
                         val = x / a.p.parts;
                         cell = (x - val * a.p.parts) * a.p.slices + val % a.p.slices;
-                        key = (cell << a.p.row_bits) | (s_walk[i] / a.p.world);
+                        key = ((KeyT)cell << a.p.row_bits) | (s_walk[i] / a.p.world);
                         if (WRITE && a.hub_bits && ((a.hub_bits[x >> 5] >> (x & 31)) & 1u))
                             val |= kHubBit;
                         valid = true;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
             if constexpr (WRITE) {
                 if (valid) {
                     const unsigned long long pos = base + __popcll(mask & lt_mask);
-                    a.keys[pos] = key;
+                    reinterpret_cast<KeyT *>(a.keys)[pos] = key;
                     a.vals[pos] = val;
                 }
                 base += __popcll(mask);
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(1024) void block_scan_kernel(unsigned long long *wa
 struct BlockArgs {
     GraphView g;
     BlockPlan p;
-    const uint32_t *keys;   // sorted: cell << row_bits | centre row
+    const uint32_t *keys;   // sorted: cell << row_bits | centre row; u64 keys: low words at 2 i
     const uint32_t *vals;   // context row inside its part
     const unsigned long long *cell_offsets;  // [cells + 1] into keys / vals
     const unsigned long long *alias;      // alias tables (threshold | alias << 32), or nullptr:
@@ -366,7 +369,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
     const uint32_t rowmask = a.p.row_bits >= 32 ? 0xFFFFFFFFu : ((1u << a.p.row_bits) - 1u);
     wave_sync();
     if ((uint32_t)lane < n) {
-        s_key[lane] = a.keys[p0 + lane] & rowmask;
+        s_key[lane] = a.keys[(p0 + lane) << a.p.key64] & rowmask;  // the row sits in the low word
         s_val[lane] = a.vals[p0 + lane];
     }
     wave_sync();

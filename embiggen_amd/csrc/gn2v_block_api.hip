@@ -53,12 +53,12 @@ gn2v::BlockPlan device_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     const uint64_t rows = (g->view.n_nodes + p->world - 1) / p->world;
     d.row_bits = bits_for(rows);
     d.flags = p->flags & gn2v::kFlagDownsample;
+    d.key64 = d.row_bits + bits_for((uint64_t)d.parts * d.slices) > 32 ? 1u : 0u;
     return d;
 }
 
 int check_key_width(const gn2v::BlockPlan &d) {
-    if (d.row_bits + bits_for((uint64_t)d.parts * d.slices) > 32)
-        return fail("block keys need more than 32 bits: use fewer parts / slices or more ranks");
+    if (d.row_bits > 32) return fail("centre rows need more than 32 bits");
     return 0;
 }
 
@@ -74,12 +74,15 @@ int sort_pairs(void *temp, size_t temp_bytes, const K *keys_in, K *keys_out, con
     return 0;
 }
 
+template <class K>
 size_t sort_temp_bytes(uint64_t n) {
     size_t need = 0;
-    const uint32_t *k = nullptr;
-    uint32_t *ko = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, need, k, ko, k, ko, n ? n : 1, 0, 32, (hipStream_t)0) !=
-        hipSuccess)
+    const K *k = nullptr;
+    K *ko = nullptr;
+    const uint32_t *v = nullptr;
+    uint32_t *vo = nullptr;
+    if (rocprim::radix_sort_pairs(nullptr, need, k, ko, v, vo, n ? n : 1, 0, 8 * sizeof(K),
+                                  (hipStream_t)0) != hipSuccess)
         return 0;
     return (need + 255) & ~(size_t)255;
 }
@@ -95,6 +98,7 @@ int gn2v_block_plan_check(gn2v_graph *g, gn2v_block_plan *plan) {
     const gn2v::BlockPlan d = device_plan(g, plan);
     if (check_key_width(d)) return 1;
     plan->row_bits = d.row_bits;
+    plan->key_bits = d.key64 ? 64 : 32;
     plan->record = d.record;
     plan->min_dist = d.min_dist;
     return 0;
@@ -163,7 +167,7 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
 static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
                           const uint32_t *d_walks, uint64_t n_walks, uint64_t seed, uint64_t epoch,
                           uint64_t first_walk, uint64_t *d_work, const uint32_t *d_hub_bits,
-                          uint32_t *keys, uint32_t *vals, hipStream_t s) {
+                          void *keys, uint32_t *vals, hipStream_t s) {
     gn2v::ExtractArgs a{};
     a.g = g->view;
     a.p = d;
@@ -180,10 +184,12 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     const size_t lds = (size_t)(gn2v::kPrepBlock / 64) * (2 * d.L + cells) * 4;
     if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
     const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
-    if (write)
-        hipLaunchKernelGGL(gn2v::block_extract_kernel<true>, grid, block, lds, s, a);
+    if (write && d.key64)
+        hipLaunchKernelGGL((gn2v::block_extract_kernel<true, uint64_t>), grid, block, lds, s, a);
+    else if (write)
+        hipLaunchKernelGGL((gn2v::block_extract_kernel<true, uint32_t>), grid, block, lds, s, a);
     else
-        hipLaunchKernelGGL(gn2v::block_extract_kernel<false>, grid, block, lds, s, a);
+        hipLaunchKernelGGL((gn2v::block_extract_kernel<false, uint32_t>), grid, block, lds, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -211,16 +217,19 @@ int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t 
     return 0;
 }
 
-int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes) {
+int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint32_t key_bits, uint64_t *bytes) {
     if (!bytes) return fail("bytes is NULL");
-    *bytes = 2 * align256(n_pairs * 4) + sort_temp_bytes(n_pairs);
+    if (key_bits != 32 && key_bits != 64) return fail("key_bits must be 32 or 64");
+    *bytes = align256(n_pairs * (key_bits / 8)) + align256(n_pairs * 4) +
+             (key_bits == 64 ? sort_temp_bytes<uint64_t>(n_pairs)
+                             : sort_temp_bytes<uint32_t>(n_pairs));
     return 0;
 }
 
 int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                        uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
                        const uint64_t *d_work, const uint32_t *d_hub_bits, uint64_t n_pairs,
-                       uint32_t *d_keys, uint32_t *d_vals, void *d_temp, uint64_t temp_bytes,
+                       void *d_keys, uint32_t *d_vals, void *d_temp, uint64_t temp_bytes,
                        void *stream) {
     if (check_plan(g, plan)) return 1;
     const gn2v::BlockPlan d = device_plan(g, plan);
@@ -228,21 +237,26 @@ int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_
     if (n_pairs == 0) return 0;
     if (!d_work || !d_walks || !d_keys || !d_vals || !d_temp) return fail("NULL pointer");
     uint64_t need = 0;
-    gn2v_block_extract_temp_bytes(n_pairs, &need);
+    const size_t key_bytes = d.key64 ? 8 : 4;
+    gn2v_block_extract_temp_bytes(n_pairs, (uint32_t)key_bytes * 8, &need);
     if (temp_bytes < need) return fail("temporary storage too small for the extraction");
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
     char *t = (char *)d_temp;
-    uint32_t *keys_in = (uint32_t *)t;
-    uint32_t *vals_in = (uint32_t *)(t + align256(n_pairs * 4));
-    void *sort_temp = t + 2 * align256(n_pairs * 4);
+    void *keys_in = t;
+    const size_t head = align256(n_pairs * key_bytes) + align256(n_pairs * 4);
+    uint32_t *vals_in = (uint32_t *)(t + align256(n_pairs * key_bytes));
+    void *sort_temp = t + head;
     if (launch_extract(g, d, true, d_walks, n_walks, seed, epoch, first_walk,
                        const_cast<uint64_t *>(d_work), d_hub_bits, keys_in, vals_in, s))
         return 1;
-    const uint32_t end_bit = d.row_bits + bits_for((uint64_t)d.parts * d.slices);
-    return sort_pairs(sort_temp, temp_bytes - 2 * align256(n_pairs * 4), keys_in, d_keys, vals_in,
-                      d_vals, n_pairs, std::max(1u, end_bit), s);
+    const uint32_t end_bit = std::max(1u, d.row_bits + bits_for((uint64_t)d.parts * d.slices));
+    if (d.key64)
+        return sort_pairs(sort_temp, temp_bytes - head, (const uint64_t *)keys_in,
+                          (uint64_t *)d_keys, vals_in, d_vals, n_pairs, end_bit, s);
+    return sort_pairs(sort_temp, temp_bytes - head, (const uint32_t *)keys_in, (uint32_t *)d_keys,
+                      vals_in, d_vals, n_pairs, end_bit, s);
 }
 
 extern "C++" {
@@ -291,7 +305,7 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     gn2v::BlockArgs a{};
     a.g = g->view;
     a.p = d;
-    a.keys = io->d_keys;
+    a.keys = (const uint32_t *)io->d_keys;
     a.vals = io->d_vals;
     a.cell_offsets = (const unsigned long long *)io->d_cell_offsets;
     const bool scale_free = tp->flags & GN2V_TRAIN_SCALE_FREE;

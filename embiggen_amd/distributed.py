@@ -11,12 +11,12 @@ ever held by two GPUs.
 
 * Central table: striped over the ranks, ``owner(c) = c % world``, row ``c // world``; a rank's
   partition never moves.
-* Contextual table: striped into ``parts = 2 * world`` parts (``x % parts``, row ``x // parts``).
-  A rank holds two parts at a time: the one it trains and the one in flight.  In global episode
-  ``g`` rank ``r`` trains part ``(2 r + g) % parts``; while it does, the part it finished in
-  episode ``g - 1`` travels to rank ``r - 1`` (which needs it in episode ``g + 1``) and the part
-  for episode ``g + 1`` arrives from rank ``r + 1`` -- the transfer of a half partition is hidden
-  behind the training of the other (RCCL send / receive on its own stream).
+* Contextual table: striped into ``parts = P * world`` parts, P >= 2 (``x % parts``, row
+  ``x // parts``).  A rank holds P parts at a time.  In global episode ``g`` rank ``r`` trains part
+  ``(P r + g) % parts``; while it does, the part it finished in episode ``g - 1`` travels to rank
+  ``r - 1`` (which needs it in episode ``g + P - 1``) and the part for episode ``g + P - 1``
+  arrives from rank ``r + 1`` -- every transfer is hidden behind the training of other parts
+  (RCCL send / receive on its own stream); P + 1 part buffers per rank.
 * Pairs: a round = ``round_walks`` walks per rank.  The walks (u32 ids, 512 B each) are
   all-gathered; every rank extracts from ALL walks of the round the (centre, context) pairs whose
   centre it owns, sorted by (context part, centre) -- two passes over the walks and one radix sort
@@ -49,21 +49,20 @@ def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:
     section 7): the smaller a cell, the more of it lives in the XCD's L2 (BA 10 M nodes: 0.67 of
     the HBM roofline unsliced, 0.80 at 4 x 8 cells, 0.87 at 32 x 8) -- and the more often two
     waves read-modify-write the same row at once; link quality stays at or above the walk-ordered
-    trainer's while a cell keeps >= 32 k rows.  With several ranks the number of parts is fixed by
-    the rotation (two per rank)."""
+    trainer's while a cell keeps >= 32 k rows.  With several ranks every rank holds the same
+    number (>= 2) of parts."""
     def pow2_floor(x):
         return 1 << (max(1, int(x)).bit_length() - 1)
 
-    # a sort key is cell << row_bits | centre row, 32 bits in all
-    row_bits = max(0, (stripe_rows(n_nodes, 0, world) - 1).bit_length())
-    max_cells = 1 << max(0, 32 - row_bits)
     if world > 1:
-        parts = 2 * world
-        slices = max(1, min(8, pow2_floor(n_nodes // (parts * MIN_ROWS_PER_CELL))))
-        return parts, max(1, min(slices, pow2_floor(max_cells // parts)))
-    slices = max(1, min(8, pow2_floor(n_nodes // MIN_ROWS_PER_CELL), max_cells))
-    parts = max(1, min(32, pow2_floor(n_nodes // (slices * MIN_ROWS_PER_CELL)),
-                       pow2_floor(max_cells // slices)))
+        # at least two parts per rank (one trains while one travels), more while the cells stay
+        # large enough; at most 128 parts (1 024 cells)
+        slices = max(1, min(8, pow2_floor(n_nodes // (2 * world * MIN_ROWS_PER_CELL))))
+        per_rank = max(2, min(pow2_floor(n_nodes // (world * slices * MIN_ROWS_PER_CELL)),
+                              pow2_floor(max(2, 128 // world))))
+        return per_rank * world, slices
+    slices = max(1, min(8, pow2_floor(n_nodes // MIN_ROWS_PER_CELL)))
+    parts = max(1, min(128, pow2_floor(n_nodes // (slices * MIN_ROWS_PER_CELL))))
     return parts, slices
 
 
@@ -212,9 +211,11 @@ class BlockPartitionedTrainer:
         auto_parts, auto_slices = auto_plan(self.n_nodes, world)
         parts = auto_parts if parts is None else parts
         slices = auto_slices if slices is None else slices
-        if world > 1 and parts != 2 * world:
-            raise ValueError("With several ranks the contextual table is cut into 2 * world parts.")
+        if world > 1 and (parts % world or parts < 2 * world):
+            raise ValueError("With several ranks the number of context parts must be a multiple "
+                             "of the number of ranks, at least two per rank.")
         self.parts, self.slices = parts, slices
+        self.per_rank = parts // world
         self.plan = self.backend.plan(world=world, rank=rank, parts=parts, slices=slices,
                                       walk_length=walk_length, window=window, min_dist=min_dist,
                                       record=record, flags=int(train_params.flags) & 2,
@@ -232,7 +233,7 @@ class BlockPartitionedTrainer:
         # context parts held now: {part id: tensor}
         self.max_part_rows = stripe_rows(self.n_nodes, 0, parts)
         self.held = {}
-        mine = range(parts) if world == 1 else (2 * rank, 2 * rank + 1)
+        mine = range(self.per_rank * rank, self.per_rank * (rank + 1))
         for p in mine:
             buf = self.backend.empty_rows(self.max_part_rows, ld)
             rows = stripe_rows(self.n_nodes, p, parts)
@@ -246,7 +247,7 @@ class BlockPartitionedTrainer:
     # ------------------------------------------------------------------ helpers
     def part_of_episode(self, g: int) -> int:
         world = self.comm.world
-        return g % self.parts if world == 1 else (2 * self.comm.rank + g) % self.parts
+        return (self.per_rank * self.comm.rank + g) % self.parts
 
     def part_rows(self, p: int) -> int:
         return stripe_rows(self.n_nodes, p, self.parts)
@@ -267,10 +268,11 @@ class BlockPartitionedTrainer:
             part = self.part_of_episode(g)
             pending = None
             if world > 1 and g >= 1:
-                # the part finished last episode leaves for rank - 1, the part of the next episode
-                # arrives from rank + 1, both while this episode trains
+                # the part finished last episode leaves for rank - 1 (which trains it per_rank - 1
+                # episodes from now), the part this rank needs per_rank - 1 episodes from now
+                # arrives from rank + 1; both while this episode trains
                 done = self.part_of_episode(g - 1)
-                nxt = self.part_of_episode(g + 1)
+                nxt = self.part_of_episode(g + self.per_rank - 1)
                 send_buf = self.held.pop(done)
                 recv_buf = self._spare
                 pending = comm.sendrecv_start(send_buf[: self.part_rows(done)],

@@ -138,7 +138,7 @@ def block_plan(graph: CSRGraph, world: int, rank: int, parts: int, slices: int, 
     ``hot_hi``: contextual rows whose share of their cell's edge endpoints lies in
     [2^-hot_lo, 2^-hot_hi) are updated with atomics (off by default)."""
     plan = _lib.BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, 0,
-                          flags, hot_lo, hot_hi)
+                          flags, hot_lo, hot_hi, 0)
     _lib.check(_lib.lib().gn2v_block_plan_check(graph.device_graph(device).handle, C.byref(plan)))
     return plan
 
@@ -181,22 +181,25 @@ def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, firs
     return work, cell_offsets
 
 
-def block_extract_temp_bytes(n_pairs: int) -> int:
+def block_extract_temp_bytes(n_pairs: int, key_bits: int = 32) -> int:
     need = C.c_uint64()
-    _lib.check(_lib.lib().gn2v_block_extract_temp_bytes(n_pairs, C.byref(need)))
+    _lib.check(_lib.lib().gn2v_block_extract_temp_bytes(n_pairs, key_bits, C.byref(need)))
     return need.value
 
 
 def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
                   work, n_pairs: int, keys=None, vals=None, temp=None, hub_bits=None):
-    """Pass 2 + sort: (keys int32 [n_pairs], vals int32 [n_pairs]) sorted by key."""
+    """Pass 2 + sort: (keys int32 or int64 [n_pairs] by ``plan.key_bits``, vals int32 [n_pairs])
+    sorted by key."""
     torch = _torch()
     dev = walks_tensor.device
     dg = graph.device_graph(dev.index or 0)
+    key_dtype = torch.int64 if plan.key_bits == 64 else torch.int32
     if keys is None:
-        keys = torch.empty(n_pairs, dtype=torch.int32, device=dev)
+        keys = torch.empty(n_pairs, dtype=key_dtype, device=dev)
         vals = torch.empty(n_pairs, dtype=torch.int32, device=dev)
-    need = block_extract_temp_bytes(n_pairs)
+    assert keys.dtype == key_dtype
+    need = block_extract_temp_bytes(n_pairs, plan.key_bits)
     if temp is None:
         temp = torch.empty(need, dtype=torch.uint8, device=dev)
     assert keys.numel() >= n_pairs and vals.numel() >= n_pairs and temp.numel() >= need

@@ -230,9 +230,11 @@ typedef struct {
      * (e.g. 14 / 9 raises the link AUROC of small cells and costs 28 % speed). */
     uint32_t hot_lo;
     uint32_t hot_hi;
+    uint32_t key_bits;    /* out (gn2v_block_plan_check): 32, or 64 when cell and centre row do
+                             not fit one 32-bit sort key (d_keys is then u64[n_pairs])           */
 } gn2v_block_plan;
 
-/* validates the plan against the graph, fills row_bits and the defaults */
+/* validates the plan against the graph, fills row_bits, key_bits and the defaults */
 int gn2v_block_plan_check(gn2v_graph *g, gn2v_block_plan *plan);
 
 /* rows first_row, first_row + row_stride, ... of the table gn2v_init_table would produce: a
@@ -260,23 +262,23 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
  * gn2v_block_count: pass 1, fills d_work u64[GN2V_BLOCK_WORK_WORDS] (private to the two calls)
  * and d_cell_offsets u64[cells + 1] = where each cell starts in the sorted pair arrays; the last
  * entry is the number of pairs (the caller reads it to size the buffers).
- * gn2v_block_extract: pass 2 + one stable radix sort: d_keys u32[n_pairs] = cell << row_bits |
- * centre row, d_vals u32[n_pairs] = context row (bit 31 set when d_hub_bits, optional, flags the
+ * gn2v_block_extract: pass 2 + one stable radix sort: d_keys u32 / u64 [n_pairs] (plan->key_bits)
+ * = cell << row_bits | centre row, d_vals u32[n_pairs] = context row (bit 31 set when d_hub_bits, optional, flags the
  * context node as hot), sorted by key, ties in walk / position / slot order (independent of the
  * launch geometry). */
 #define GN2V_BLOCK_WORK_WORDS 9216
 int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                      uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
                      uint64_t *d_work, uint64_t *d_cell_offsets, void *stream);
-int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes);
+int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint32_t key_bits, uint64_t *bytes);
 int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                        uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
                        const uint64_t *d_work, const uint32_t *d_hub_bits, uint64_t n_pairs,
-                       uint32_t *d_keys, uint32_t *d_vals, void *d_temp, uint64_t temp_bytes,
+                       void *d_keys, uint32_t *d_vals, void *d_temp, uint64_t temp_bytes,
                        void *stream);
 
 typedef struct {
-    const uint32_t *d_keys;          /* sorted pairs of the round (gn2v_block_extract)         */
+    const void *d_keys;              /* sorted pairs of the round (gn2v_block_extract)         */
     const uint32_t *d_vals;
     const uint64_t *d_cell_offsets;  /* [cells + 1] (gn2v_block_count)                         */
     const uint64_t *d_alias;         /* gn2v_block_alias; unused without GN2V_TRAIN_SCALE_FREE */

@@ -932,6 +932,7 @@ typedef struct {
     uint32_t row_bits;
     uint32_t flags;
     uint32_t hot_lo, hot_hi; /* band of "hot" rows, 0 / 0 = off (see o_block_alias) */
+    uint32_t key_bits;       /* width of the device's sort keys (32 / 64); keys are u64 here */
 } o_block_plan;
 
 uint32_t o_block_row_bits(uint64_t n_nodes, uint32_t world) {
@@ -944,7 +945,7 @@ uint32_t o_block_row_bits(uint64_t n_nodes, uint32_t world) {
 /* pairs of this rank in walk / position / slot order; keys / vals may be NULL (count only) */
 uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t *walks,
                          uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                         const uint32_t *hub_bits, uint32_t *keys, uint32_t *vals) {
+                         const uint32_t *hub_bits, uint64_t *keys, uint32_t *vals) {
     uint64_t n = 0, ekey = o_epoch_key(seed, epoch);
     uint32_t L = p->walk_length, w = p->window, md = p->min_dist ? p->min_dist : 1;
     o_train_params tp;
@@ -966,7 +967,7 @@ uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t
                 uint32_t row = x / p->parts;
                 uint32_t cell = (x % p->parts) * p->slices + row % p->slices;
                 if (keys) {
-                    keys[n] = (cell << p->row_bits) | (c / p->world);
+                    keys[n] = ((uint64_t)cell << p->row_bits) | (c / p->world);
                     /* hot context rows carry bit 31 (updated with atomics on the device) */
                     vals[n] = row | ((hub_bits && ((hub_bits[x >> 5] >> (x & 31)) & 1u)) ? 0x80000000u : 0u);
                 }
@@ -978,7 +979,8 @@ uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t
 }
 
 typedef struct {
-    uint32_t key, val;
+    uint64_t key;
+    uint32_t val;
     uint64_t idx;
 } block_kv;
 
@@ -989,7 +991,7 @@ static int cmp_block_kv(const void *a, const void *b) {
 }
 
 /* stable sort by key */
-void o_block_sort(uint32_t *keys, uint32_t *vals, uint64_t n) {
+void o_block_sort(uint64_t *keys, uint32_t *vals, uint64_t n) {
     block_kv *kv = (block_kv *)malloc(sizeof(block_kv) * (n ? n : 1));
     for (uint64_t i = 0; i < n; ++i) {
         kv[i].key = keys[i];
@@ -1005,11 +1007,11 @@ void o_block_sort(uint32_t *keys, uint32_t *vals, uint64_t n) {
 }
 
 /* cell_offsets[c] = first sorted position whose cell is >= c, c = 0 .. cells */
-void o_block_cell_offsets(const uint32_t *keys, uint64_t n, uint32_t row_bits, uint32_t cells,
+void o_block_cell_offsets(const uint64_t *keys, uint64_t n, uint32_t row_bits, uint32_t cells,
                           uint64_t *offsets) {
     uint64_t p = 0;
     for (uint32_t c = 0; c <= cells; ++c) {
-        while (p < n && (row_bits >= 32 ? 0u : (keys[p] >> row_bits)) < c) ++p;
+        while (p < n && (keys[p] >> row_bits) < c) ++p;
         offsets[c] = c == cells ? n : p;
     }
 }
@@ -1115,12 +1117,12 @@ uint64_t o_block_record_stride(uint64_t R) {
 
 /* one part of one round, strictly sequential; returns the pairs trained */
 uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_plan *p,
-                      const uint32_t *keys, const uint32_t *vals, const uint64_t *cell_offsets,
+                      const uint64_t *keys, const uint32_t *vals, const uint64_t *cell_offsets,
                       const uint64_t *alias, const uint64_t *cell_rows, float *central,
                       float *context, uint64_t block_id, uint32_t part, uint64_t seed,
                       uint64_t epoch, float lr) {
     uint32_t d = tp->d, ld = tp->ld, k = tp->k, C = p->record ? p->record : 16;
-    uint32_t rowmask = p->row_bits >= 32 ? 0xFFFFFFFFu : ((1u << p->row_bits) - 1u);
+    uint64_t rowmask = (1ull << p->row_bits) - 1ull;
     uint64_t ekey = o_epoch_key(seed, epoch), trained = 0;
     uint64_t part_rows = stripe_count(g->n_nodes, part, p->parts);
     float *u = (float *)malloc(sizeof(float) * d), *gacc = (float *)malloc(sizeof(float) * d);
@@ -1139,8 +1141,8 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
             uint32_t n = (uint32_t)(hi - p0 < C ? hi - p0 : C);
             uint32_t r0 = 0;
             while (r0 < n) {
-                uint32_t crow = keys[p0 + r0] & rowmask, r1 = r0 + 1;
-                while (r1 < n && (keys[p0 + r1] & rowmask) == crow) ++r1;
+                uint32_t crow = (uint32_t)(keys[p0 + r0] & rowmask), r1 = r0 + 1;
+                while (r1 < n && (uint32_t)(keys[p0 + r1] & rowmask) == crow) ++r1;
                 uint64_t cgid = (uint64_t)crow * p->world + p->rank;
                 float lrc = centre_lr(g, tp, lr, (uint32_t)cgid);
                 float *cptr = central + (uint64_t)crow * ld;

@@ -322,7 +322,7 @@ class BlockPlan(C.Structure):
 
     _fields_ = [(name, C.c_uint32) for name in (
         "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
-        "row_bits", "flags", "hot_lo", "hot_hi")]
+        "row_bits", "flags", "hot_lo", "hot_hi", "key_bits")]
 
 
 def block_plan(n_nodes: int, world: int, rank: int, parts: int, slices: int, walk_length: int,
@@ -330,14 +330,16 @@ def block_plan(n_nodes: int, world: int, rank: int, parts: int, slices: int, wal
                hot_hi: int = 0) -> BlockPlan:
     lib().o_block_row_bits.restype = C.c_uint32
     bits = lib().o_block_row_bits(C.c_uint64(n_nodes), C.c_uint32(world))
+    cells = parts * slices
+    key_bits = 64 if bits + max(0, (cells - 1).bit_length()) > 32 else 32
     return BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, bits,
-                     flags, hot_lo, hot_hi)
+                     flags, hot_lo, hot_hi, key_bits)
 
 
 def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: int,
                   first_walk: int, sort: bool = True, hub_bits=None):
-    """(keys, vals, cell_offsets): the pairs of the walks whose centre `plan.rank` owns, sorted
-    stably by key = cell << row_bits | centre row (``sort=False``: extraction order)."""
+    """(keys u64, vals u32, cell_offsets): the pairs of the walks whose centre `plan.rank` owns,
+    sorted stably by key = cell << row_bits | centre row (``sort=False``: extraction order)."""
     walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
     n_walks = walks_arr.shape[0]
     L = lib()
@@ -345,7 +347,7 @@ def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: 
     args = (C.byref(g.c), C.byref(plan), _ptr(walks_arr), C.c_uint64(n_walks), C.c_uint64(seed),
             C.c_uint64(epoch), C.c_uint64(first_walk))
     n = int(L.o_block_extract(*args, None, None, None))
-    keys, vals = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+    keys, vals = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint32)
     if n:
         L.o_block_extract(*args, _ptr(hub_bits), _ptr(keys), _ptr(vals))
         if sort:
@@ -373,7 +375,7 @@ def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, keys, vals, cel
                cell_rows, central, context, block_id: int, part: int, seed: int, epoch: int,
                lr: float) -> int:
     """Sequential training of one part (in place on ``central`` / ``context``)."""
-    for a, t in ((keys, np.uint32), (vals, np.uint32), (cell_offsets, np.uint64),
+    for a, t in ((keys, np.uint64), (vals, np.uint32), (cell_offsets, np.uint64),
                  (central, np.float32), (context, np.float32)):
         assert a.dtype == t and a.flags.c_contiguous
     lib().o_block_step.restype = C.c_uint64

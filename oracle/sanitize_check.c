@@ -93,9 +93,10 @@ int main(void) {
 
     /* block-partitioned schedule: extraction, stable sort, alias tables, one round over every part */
     {
-        o_block_plan bp = {3, 1, 6, 2, 20, 3, 1, 4, o_block_row_bits(N, 3), 0, 6, 2};
+        o_block_plan bp = {3, 1, 6, 2, 20, 3, 1, 4, o_block_row_bits(N, 3), 0, 6, 2, 32};
         uint64_t nw = ns * 3, cap = nw * 20 * 6;
-        uint32_t *bk = malloc(sizeof(uint32_t) * cap), *bv = malloc(sizeof(uint32_t) * cap);
+        uint64_t *bk = malloc(sizeof(uint64_t) * cap);
+        uint32_t *bv = malloc(sizeof(uint32_t) * cap);
         uint32_t hub[(N + 31) / 32];
         uint64_t *alias = malloc(sizeof(uint64_t) * N), poff[13];
         o_block_alias(&g, 6, 2, bp.hot_lo, bp.hot_hi, alias, poff, hub);

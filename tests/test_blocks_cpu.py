@@ -68,8 +68,8 @@ def test_extraction_partitions_the_pairs_of_the_walks(world, parts, slices):
         # stable: pairs with equal keys keep the extraction (walk / position / slot) order
         order = np.argsort(raw_k, kind="stable")
         assert np.array_equal(keys, raw_k[order]) and np.array_equal(vals, raw_v[order])
-        cell = keys >> plan.row_bits if plan.row_bits < 32 else np.zeros_like(keys)
-        crow = keys & ((1 << plan.row_bits) - 1)
+        cell = (keys >> np.uint64(plan.row_bits)).astype(np.uint32)
+        crow = (keys & np.uint64((1 << plan.row_bits) - 1)).astype(np.uint32)
         assert offsets[-1] == len(keys)
         for c in range(parts * slices):
             assert (cell[int(offsets[c]):int(offsets[c + 1])] == c).all()
@@ -165,7 +165,7 @@ def test_step_properties_zero_lr_counts_and_untouched_rows():
     n1 = sum(O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows, c, parts[p],
                           0, p, 5, 0, 0.05) for p in range(2))
     assert n0 == offsets[1] and n1 == len(keys) == len(O.walk_pairs(walks, W))
-    centres = np.unique(keys & ((1 << plan.row_bits) - 1))
+    centres = np.unique(keys & np.uint64((1 << plan.row_bits) - 1)).astype(np.int64)
     untouched = np.setdiff1d(np.arange(97), centres)
     assert np.array_equal(c[untouched], c0[untouched]) and not np.array_equal(c, c0)
     indeg = np.bincount(og.col_idx, minlength=97)
@@ -199,15 +199,18 @@ def test_world_one_trainer_is_the_plain_sequence_of_block_steps():
     assert trained == total == 2 * 9 * (2 * W * L - W * (W + 1)) and held == [0, 1]
 
 
-@pytest.mark.parametrize("world,nodes", [(2, 34), (3, 34), (4, 97)])
-def test_ranks_cover_every_pair_once_and_assemble_identical_tables(world, nodes):
-    sims = run_ranks(world, lambda comm: _train(comm, rounds=1, nodes=nodes))
+@pytest.mark.parametrize("world,nodes,per_rank", [(2, 34, 2), (3, 34, 2), (4, 97, 2), (2, 97, 4),
+                                                  (3, 97, 3)])
+def test_ranks_cover_every_pair_once_and_assemble_identical_tables(world, nodes, per_rank):
+    parts = per_rank * world
+    sims = run_ranks(world, lambda comm: _train(comm, rounds=1, nodes=nodes, parts=parts))
     assert sum(s[1] for s in sims) == world * 9 * (2 * W * L - W * (W + 1))
     for s in sims[1:]:
         assert np.array_equal(s[0][0], sims[0][0][0]) and np.array_equal(s[0][1], sims[0][0][1])
-    # after `parts` episodes rank r holds parts 2r - 1 and 2r (one hop from home)
+    # after `parts` episodes rank r holds parts P r - 1 ... P r + P - 2 (one hop from home)
     for r, s in enumerate(sims):
-        assert s[2] == sorted([(2 * r - 1) % (2 * world), (2 * r) % (2 * world)])
+        assert s[2] == sorted((per_rank * r - 1 + j) % parts for j in range(per_rank))
+    assert sorted(p for s in sims for p in s[2]) == list(range(parts))
     init = O.init_table(nodes, D, D, 42, 1, D ** -0.5)
     assert np.abs(sims[0][0][1] - init).max() > 1e-3
     assert np.isfinite(sims[0][0][0]).all() and np.isfinite(sims[0][0][1]).all()
@@ -220,13 +223,13 @@ def test_slices_change_the_negative_cells_not_the_bookkeeping():
     assert not np.array_equal(plain[0][0][1], sliced[0][0][1])
 
 
-def _gloo_worker(rank, world, port, out_dir):
+def _gloo_worker(rank, world, port, out_dir, parts=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    (c, x), _, _ = _train(TorchComm())
+    (c, x), _, _ = _train(TorchComm(), parts=parts)
     np.save(os.path.join(out_dir, f"c{rank}.npy"), c)
     np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
     dist.barrier()
@@ -241,13 +244,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_ranks_equal_the_in_process_simulation(tmp_path, world):
+@pytest.mark.parametrize("world,parts", [(2, None), (3, None), (2, 8)])
+def test_gloo_ranks_equal_the_in_process_simulation(tmp_path, world, parts):
     """No row is ever shared between ranks, so the distributed run is exactly the simulation
     (world 3: ragged parts of 6 / 6 / 6 / 6 / 5 / 5 rows travel round the ring; two rounds, so
-    the rotation continues across the round boundary)."""
-    mp.spawn(_gloo_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    sim = run_ranks(world, lambda comm: _train(comm))
+    the rotation continues across the round boundary; 2 ranks x 4 parts each: a part arrives
+    three episodes before it is trained)."""
+    mp.spawn(_gloo_worker, args=(world, _free_port(), str(tmp_path), parts), nprocs=world,
+             join=True)
+    sim = run_ranks(world, lambda comm: _train(comm, parts=parts))
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), sim[r][0][0])
         assert np.array_equal(np.load(tmp_path / f"x{r}.npy"), sim[r][0][1])

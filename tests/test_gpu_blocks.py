@@ -27,6 +27,12 @@ def _u32(t):
     return t.cpu().numpy().view(np.uint32)
 
 
+def _keys(t):
+    """Device sort keys (int32 or int64 tensor, plan.key_bits) as the oracle's u64."""
+    a = t.cpu().numpy()
+    return a.view(np.uint32).astype(np.uint64) if a.dtype == np.int32 else a.view(np.uint64)
+
+
 def test_walk_pairs_match_oracle(karate, karate_oracle):
     wk = ops.walks(karate, ops.walk_params(20, 2, 0.5, 2.0), 3, 0, 0, 68)
     wk_h = wk.cpu().numpy().view(np.uint32)
@@ -67,11 +73,45 @@ def test_extraction_and_sort_are_bit_exact(world, rank, parts, slices, md):
                                  hub_bits=O.block_alias(og, parts, slices, 5, 0)[2])
     assert n == len(rk) and n > 0 and (rv >> 31).any()  # hot context rows are flagged
     assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
-    assert np.array_equal(_u32(keys), rk) and np.array_equal(_u32(vals), rv)
+    assert np.array_equal(_keys(keys), rk) and np.array_equal(_u32(vals), rv)
     # empty input: no pairs, all offsets zero
     empty = torch.full((4, 24), -1, dtype=torch.int32, device="cuda")
     _, off0 = ops.block_count(g, plan, empty, 5, 1, 0)
     assert int(off0.abs().sum()) == 0
+
+
+def test_wide_sort_keys_when_cell_and_row_do_not_fit_32_bits():
+    """2^23 nodes on one rank (23 row bits) x 1 024 cells (10 bits): the sort keys become u64;
+    extraction + sort stay bit-exact and a deterministic step still equals the oracle."""
+    n = 1 << 23
+    rng = np.random.RandomState(4)
+    src = rng.randint(0, n, 6000)
+    dst = (src + rng.randint(1, 50, 6000)) % n
+    g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=n)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    wk = ops.walks(g, ops.walk_params(12, 1, 1.0, 1.0), 3, 0, 0, min(2000, g.get_number_of_unique_source_nodes()))
+    plan = ops.block_plan(g, 1, 0, 128, 8, 12, 3, 1, 4)
+    oplan = O.block_plan(n, 1, 0, 128, 8, 12, 3, 1, 4)
+    assert plan.key_bits == 64 == oplan.key_bits and plan.row_bits == 23
+    work, offsets = ops.block_count(g, plan, wk, 3, 0, 0)
+    keys, vals = ops.block_extract(g, plan, wk, 3, 0, 0, work, int(offsets[-1]))
+    assert keys.dtype == torch.int64
+    rk, rv, ro = O.block_extract(og, oplan, _u32(wk), 3, 0, 0)
+    assert len(rk) > 1000 and int(rk.max() >> np.uint64(32)) > 0
+    assert np.array_equal(_keys(keys), rk) and np.array_equal(_u32(vals), rv)
+    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
+    part = int(rk[len(rk) // 2] >> np.uint64(23)) // 8  # a part that has pairs
+    rows = stripe_rows(n, part, 128)
+    tp = ops.train_params(0, 8, 0, 3, flags=DET)  # k = 0: no alias tables needed
+    otp = O.TrainParams(0, 8, 8, 1, 0, 3, 0.01, 0.9, 6.0, 0, 8 ** -0.5)
+    c = ops.init_table(n, 8, 5, 0, 0.3)
+    x = ops.init_table_rows(rows, 8, 5, 1, 0.3, part, 128)
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    ops.block_step(g, tp, plan, keys, vals, offsets, None, None, c, x, 0, part, 3, 0, 0.05)
+    trained = O.block_step(og, otp, oplan, rk, rv, ro, None, None, c_h, x_h, 0, part, 3, 0, 0.05)
+    torch.cuda.synchronize()
+    assert trained > 0 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+    assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(c_h - ops.init_table(n, 8, 5, 0, 0.3).cpu().numpy()).max() > 1e-4
 
 
 def test_extraction_honours_centre_downsampling(karate, karate_oracle):
@@ -84,7 +124,7 @@ def test_extraction_honours_centre_downsampling(karate, karate_oracle):
     rk, rv, ro = O.block_extract(karate_oracle, oplan, _u32(wk), 3, 0, 40)
     full = O.block_extract(karate_oracle, O.block_plan(34, 2, 0, 4, 1, 16, 3, 1, 4), _u32(wk), 3, 0, 40)
     assert 0 < n < len(full[0])  # hubs are thinned
-    assert np.array_equal(_u32(keys), rk) and np.array_equal(_u32(vals), rv)
+    assert np.array_equal(_keys(keys), rk) and np.array_equal(_u32(vals), rv)
 
 
 @pytest.mark.parametrize("parts,slices,band", [(1, 1, (0, 0)), (4, 1, (6, 0)), (6, 8, (5, 2)),
@@ -118,7 +158,7 @@ def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, 
     otp = O.TrainParams(0, d, ld, 1, k, window, 0.01, 0.9, 6.0, sf, d ** -0.5)
     c = ops.init_table_rows(stripe_rows(n, rank, world), d, 11, 0, d ** -0.5, rank, world, ld=ld)
     c_h = c.cpu().numpy().copy()
-    rk, rv, ro = _u32(keys), _u32(vals), offsets.cpu().numpy().astype(np.uint64)
+    rk, rv, ro = _keys(keys), _u32(vals), offsets.cpu().numpy().astype(np.uint64)
     rp, rpo = alias.cpu().numpy().view(np.uint64), cell_rows.cpu().numpy().astype(np.uint64)
     got_x, ref_x = [], []
     ops.stats_reset(g)
@@ -203,11 +243,12 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
         keys_l.append((cell << plan.row_bits) | centres)
         vals_l.append(ctx)
         offsets.append(offsets[-1] + m)
-    keys_h = np.concatenate(keys_l).astype(np.uint32)
+    keys_h = np.concatenate(keys_l).astype(np.uint64)
     vals_h = np.concatenate(vals_l).astype(np.uint32)
     vals_h[1::2] |= np.uint32(0x80000000)  # every other context row is "hot": updated by atomics
     off_h = np.asarray(offsets, dtype=np.uint64)
-    keys = torch.from_numpy(keys_h.view(np.int32)).cuda()
+    assert plan.key_bits == 32
+    keys = torch.from_numpy(keys_h.astype(np.uint32).view(np.int32)).cuda()
     vals = torch.from_numpy(vals_h.view(np.int32)).cuda()
     offs = torch.from_numpy(off_h.astype(np.int64)).cuda()
     ld = (d + 3) // 4 * 4

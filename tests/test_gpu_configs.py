@@ -110,7 +110,7 @@ def test_config5_ba_100m_nodes_1b_edges_full_size_properties():
 def test_config4_block_trainer_with_eight_simulated_ranks_at_full_size():
     """BASELINE config 4 ("embedding table row-sharded across 8 x MI355X") at its full size with
     the 8 ranks simulated on one GPU (exact: ranks never share a row): every pair of every round
-    is trained exactly once, the 16 context parts are each held by exactly one rank at the end,
+    is trained exactly once, the context parts are each held by exactly one rank at the end,
     tables stay finite and the link quality equals the single trainer's on the same walks."""
     from embiggen_amd.distributed import BlockPartitionedTrainer, auto_plan
     from sharded_helpers import link_auc_device, run_ranks
@@ -148,7 +148,7 @@ def test_config4_block_trainer_with_eight_simulated_ranks_at_full_size():
     res = run_ranks(world, rank_fn)
     torch.cuda.synchronize()
     assert sum(r[0] for r in res) == total * PAIRS_PER_WALK == ops.stats_read(g)["pairs"]
-    assert sorted(p for r in res for p in r[1]) == list(range(2 * world))
+    assert sorted(p for r in res for p in r[1]) == list(range(auto_plan(n, world)[0]))
     assert all(r[2] for r in res)
     bc, bx = res[0][3]
     gen.manual_seed(1)
