@@ -71,6 +71,9 @@ def parse():
                     help="blocks: XCD slices inside a part (8 = every XCD owns its rows; default: "
                          "distributed.auto_plan)")
     ap.add_argument("--record", type=int, default=16, help="blocks: pairs per record")
+    ap.add_argument("--hot-band", default="0:0",
+                    help="blocks: lo:hi -- contextual rows whose share of their cell's edge "
+                         "endpoints lies in [2^-lo, 2^-hi) are updated with atomics (0:0 = off)")
     ap.add_argument("--local-atomic", action="store_true",
                     help="blocks with slices: contextual rows updated by L2-local f32 atomics")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
@@ -238,7 +241,8 @@ def main():
         comm = TorchComm() if world > 1 else LoopbackComm()
         blocks = BlockPartitionedTrainer(graph, tp, d, ld, 42, d ** -0.5, comm, f"cuda:{local}",
                                          walk_length=128, window=5, parts=args.parts,
-                                         slices=args.slices, record=args.record)
+                                         slices=args.slices, record=args.record,
+                                         hot_band=tuple(int(v) for v in args.hot_band.split(":")))
     else:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local, ld=ld)

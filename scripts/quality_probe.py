@@ -53,6 +53,7 @@ if __name__ == "__main__":
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--modes", default="write_through,write_back,atomic")
+    ap.add_argument("--hot-band", default="0:0", help="blocks modes: lo:hi (see bench.py)")
     a = ap.parse_args()
     g = E.barabasi_albert(a.nodes, a.m, 42)
     n, d = g.get_number_of_nodes(), a.d
@@ -73,7 +74,8 @@ if __name__ == "__main__":
             tp = ops.train_params(0, d, 10, 5, flags=1 | extra, ld=d)
             tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
                                          walk_length=128, window=5, parts=parts, slices=slices,
-                                         record=record)
+                                         record=record,
+                                         hot_band=tuple(int(v) for v in a.hot_band.split(":")))
             ops.stats_reset(g)
             t0 = time.time()
             lr, rounds = a.lr, []
