@@ -411,6 +411,48 @@ def test_multi_gpu_is_an_explicit_opt_in(karate):
     assert out[0].shape == (34, 8) and np.isfinite(out[0]).all()
 
 
+def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
+    """``Node2VecSkipGramEnsmallen.fit_transform`` with ``model._model.comm = TorchComm()`` under
+    ``torch.distributed.run`` (2 ranks, gloo, one shared GPU): both ranks return the same full
+    tables, of single-GPU quality; CBOW inside the same job falls back to its own device."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_fit_check.py")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(port), script, str(tmp_path)], capture_output=True, text=True,
+                         timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    ok = [l for l in res.stdout.splitlines() if l.startswith("OK ")]
+    assert len(ok) == 1 and "'world': 2" in ok[0] and float(ok[0].split()[-1]) > 0.9, res.stdout
+    for name in ("central", "contextual"):
+        a, b = np.load(tmp_path / f"{name}0.npy"), np.load(tmp_path / f"{name}1.npy")
+        assert a.shape == (256, 16) and np.array_equal(a, b) and np.isfinite(a).all()
+
+
+def test_bad_plans_are_refused(karate):
+    for kw in (dict(world=2, rank=2, parts=4), dict(world=2, rank=0, parts=3),
+               dict(world=1, rank=0, parts=1, slices=17), dict(world=1, rank=0, parts=2000),
+               dict(world=1, rank=0, parts=1, record=33), dict(world=1, rank=0, parts=1, hot_lo=3, hot_hi=5)):
+        args = dict(slices=1, walk_length=8, window=2)
+        args.update(kw)
+        with pytest.raises(_lib.Gn2vError):
+            ops.block_plan(karate, **args)
+    plan = ops.block_plan(karate, 1, 0, 2, 1, 8, 2)
+    tp = ops.train_params(0, 8, 2, 2, flags=1)
+    c = ops.init_table(34, 8, 1, 0, 0.3)
+    with pytest.raises(_lib.Gn2vError, match="alias"):  # degree-proportional negatives need tables
+        ops.block_step(karate, tp, plan, c, c, c, None, None, c, c, 0, 0, 1, 0, 0.01)
+    with pytest.raises(_lib.Gn2vError, match="part out of range"):
+        ops.block_step(karate, tp, plan, c, c, c, c, c, c, c, 0, 5, 1, 0, 0.01)
+
+
 def test_one_rank_rccl_group_equals_loopback():
     """The trainer's collectives on the real backend ("nccl" = RCCL) with device tensors; a one-GPU
     box can only host a one-rank group, the multi-rank exchange logic is covered on gloo
