@@ -65,13 +65,27 @@ def reduce_slots(keys, weights) -> Tuple["torch.Tensor", "torch.Tensor"]:
     return keys[ends], sums
 
 
+SORT_LIMIT = 2 ** 31 - 1  # torch.sort refuses longer dimensions
+
+
 def merge(a: Optional[tuple], b: tuple) -> tuple:
-    """Sum of two reduced (keys, counts) sets."""
+    """Sum of two reduced (keys ascending and distinct, counts) sets.  Sets too long for one sort
+    are cut at a pivot key (both are sorted: two binary searches, no masks) and merged by halves."""
     import torch
 
     if a is None:
         return b
-    return reduce_slots(torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]]))
+    if a[0].numel() + b[0].numel() <= SORT_LIMIT or min(a[0].numel(), b[0].numel()) == 0:
+        if min(a[0].numel(), b[0].numel()) == 0:
+            return a if b[0].numel() == 0 else b
+        return reduce_slots(torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]]))
+    big, small = (a, b) if a[0].numel() >= b[0].numel() else (b, a)
+    cut = big[0].numel() // 2
+    pivot = big[0][cut:cut + 1]
+    other = int(torch.searchsorted(small[0], pivot)[0])
+    left = merge((big[0][:cut], big[1][:cut]), (small[0][:other], small[1][:other]))
+    right = merge((big[0][cut:], big[1][cut:]), (small[0][other:], small[1][other:]))
+    return torch.cat([left[0], right[0]]), torch.cat([left[1], right[1]])
 
 
 class Accumulator:
@@ -86,6 +100,9 @@ class Accumulator:
         import torch
 
         b, a = self.runs.pop(), self.runs.pop()
+        if a[0].numel() + b[0].numel() > SORT_LIMIT:
+            self.runs.append(merge(a, b))
+            return
         keys, counts = torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])
         del a, b  # the inputs are dead before the sort allocates its buffers
         self.runs.append(reduce_slots(keys, counts))

@@ -201,3 +201,33 @@ def test_tensor_plumbing_equals_the_oracle(karate_oracle):
     z = torch.tensor([0, 1, -1, 2 ** 62, -(2 ** 63)], dtype=torch.int64)
     assert [v & (2 ** 64 - 1) for v in cooccurrence.mix64_tensor(z).tolist()] == [
         O.mix64(v & (2 ** 64 - 1)) for v in z.tolist()]
+
+
+def test_merging_runs_longer_than_one_sort_allows(monkeypatch):
+    """torch.sort refuses dimensions above INT_MAX: reduced runs whose union is longer (seen on a
+    default GloVe fit of a 1 M-node graph) are cut at a pivot key and merged by halves."""
+    import torch
+
+    from embiggen_amd import cooccurrence as CO
+
+    rng = np.random.RandomState(0)
+
+    def run(n):
+        k = np.unique(rng.randint(0, 10 ** 6, n))
+        return (torch.from_numpy(k.astype(np.int64)),
+                torch.from_numpy(rng.randint(1, 100, len(k)).astype(np.int64)))
+
+    a, b = run(5000), run(7000)
+    want = CO.merge(a, b)
+    monkeypatch.setattr(CO, "SORT_LIMIT", 1000)
+    got = CO.merge(a, b)
+    assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+    acc = CO.Accumulator()
+    total = {}
+    for _ in range(6):
+        r = run(3000)
+        acc.add(r)
+        for k, w in zip(r[0].tolist(), r[1].tolist()):
+            total[k] = total.get(k, 0) + w
+    keys, counts = acc.result()
+    assert keys.tolist() == sorted(total) and counts.tolist() == [total[k] for k in sorted(total)]
