@@ -169,3 +169,33 @@ def test_large_graphs_are_fitted_through_the_block_path_on_one_gpu():
     assert m.get_last_stats()["pairs"] == 400_000 * (2 * 3 * 32 - 3 * 4)
     init = ops.init_table(400_000, 32, 42, 0, 32 ** -0.5).cpu().numpy()
     assert np.abs(res[0] - init).max() > 1e-3
+
+
+def test_block_path_on_a_directed_weighted_graph_with_trap_nodes():
+    """The public class on a graph above the block-path threshold that is directed, weighted and
+    has trap nodes (walks that end early) and nodes nobody points to: every pair of every walk is
+    trained exactly once and the tables stay finite."""
+    rng = np.random.RandomState(7)
+    n, e = 70_000, 280_000
+    src = rng.randint(0, n // 2, e)          # only the lower half has out-edges
+    dst = rng.randint(0, n, e)
+    w = rng.uniform(0.1, 3.0, e)
+    g = E.CSRGraph.from_edge_list(src, dst, w, number_of_nodes=n, directed=True)
+    kw = dict(embedding_size=16, epochs=2, iterations=2, walk_length=12, window_size=3,
+              number_of_negative_samples=4, verbose=False)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = E.Node2VecSkipGramEnsmallen(**kw)
+        res = m.fit_transform(g, return_dataframe=False).get_all_node_embedding()
+    assert m._model.last_plan["parts"] == 1 and m._model.last_plan["slices"] == 2
+    assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
+    expected = 0
+    wp = m._model.walk_params()
+    n_walks = g.get_number_of_unique_source_nodes() * 2
+    for epoch in range(2):
+        wk = ops.walks(g, wp, 42, epoch, 0, n_walks)
+        assert int((wk == -1).sum()) > 0  # trap nodes end walks early
+        expected += ops.walk_pairs(wk, 3, 1).shape[0]
+    assert m.get_last_stats()["pairs"] == expected
