@@ -67,10 +67,15 @@ __device__ __forceinline__ float group16_sum(float x) {
     return x;
 }
 
+// Makes LDS writes of any lane visible to every lane of the same wavefront.  LDS only: a generic
+// wavefront-scope fence compiles to `s_waitcnt vmcnt(0) lgkmcnt(0)` on gfx950, i.e. it also waits
+// for every outstanding global load and (write-through) store -- which serialised the prefetches
+// and cost a memory round trip per call.  The LDS pipeline is in order, so `lgkmcnt(0)` plus a
+// compiler barrier is all a single wave needs; global-memory ordering inside a wave relies, as
+// before, on program order per address (tested: rows repeated in consecutive rounds).
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int CH>
