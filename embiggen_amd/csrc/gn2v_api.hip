@@ -244,7 +244,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     // context cache (store modes, walk-ordered SkipGram on whole tables only)
     const uint32_t slots = 2 * tp->window + 1;
     const size_t cache_words = ((size_t)slots * tp->ld + L + 2 * (size_t)a.max_samples +
-                                (cbow ? 2 * tp->window : 0) + 2 * slots + 3) &
+                                (cbow ? 2 * tp->window + slots : 0) + 2 * slots + 3) &
                                ~(size_t)3;
     const size_t cache_lds = (size_t)waves_per_block * cache_words * 4;
     const bool use_cache = !det && wm != gn2v::kAtomic && !a.split &&

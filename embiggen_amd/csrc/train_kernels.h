@@ -575,10 +575,10 @@ __device__ __forceinline__ void cache_insert(const TrainArgs &a, CtxCache &c, fl
 }
 
 // The row that enters the window at the NEXT centre, fetched one centre ahead into registers
-// (its degree too): the insert then costs no memory round trip.  Only issued for a node that is
-// not in the cache (a cached node is never re-read); it cannot become stale in between: this wave
-// changes contextual rows only through the cache or, for uncached hub rows, in place -- and a hub
-// row is discarded at commit by the same degree test.
+// (its degree too): the insert then costs no memory round trip (win_prefetch_issue / win_insert).
+// Only issued for a node that is not in the cache (a cached node is never re-read); it cannot
+// become stale in between: this wave changes contextual rows only through the cache or, for
+// uncached hub rows, in place -- and a hub row is discarded at commit by the same degree test.
 template <int NC>  // float4 chunks per lane: ld / 4 chunks over 64 lanes
 struct RowPrefetch {
     uint32_t node;
@@ -586,57 +586,6 @@ struct RowPrefetch {
     uint64_t deg;
     float4 chunk[NC];
 };
-
-template <int NC>
-__device__ __forceinline__ void prefetch_issue(const TrainArgs &a, const CtxCache &c,
-                                               const float *table, uint32_t v, int lane,
-                                               RowPrefetch<NC> &pf) {
-    pf.node = v;
-    pf.valid = c.find(v) < 0;
-    if (!pf.valid) return;
-    pf.deg = a.cache_max_degree != 0xFFFFFFFFu ? a.g.row_ptr[v + 1] - a.g.row_ptr[v] : 0;
-    const float *src = table + (uint64_t)v * c.ld;
-#pragma unroll
-    for (int cc = 0; cc < NC; ++cc) {
-        const uint32_t ci = lane + 64 * cc;
-        pf.chunk[cc] = ci < (c.ld >> 2) ? *reinterpret_cast<const float4 *>(src + ci * 4)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-// cache_insert with the prefetched registers when they belong to this node (else the plain path)
-template <int WM, int NC>
-__device__ __forceinline__ void cache_insert_prefetched(const TrainArgs &a, CtxCache &c,
-                                                        float *table, uint32_t v, int lane,
-                                                        const RowPrefetch<NC> &pf) {
-    if (!pf.valid || pf.node != v) {
-        cache_insert<WM>(a, c, table, v, lane);
-        return;
-    }
-    const int hit = c.find(v);
-    wave_sync();
-    if (hit >= 0) {  // cannot happen (nothing is inserted between issue and commit); stay exact
-        if (lane == 0) c.ref[hit] += 1;
-        wave_sync();
-        return;
-    }
-    if (a.cache_max_degree != 0xFFFFFFFFu && pf.deg >= a.cache_max_degree) return;
-    int free_slot = -1;
-    for (uint32_t s = 0; s < c.slots; ++s)
-        if (c.ref[s] == 0 && free_slot < 0) free_slot = (int)s;
-    if (free_slot < 0) return;
-    float *dst = c.rows + (uint32_t)free_slot * c.ld;
-#pragma unroll
-    for (int cc = 0; cc < NC; ++cc) {
-        const uint32_t ci = lane + 64 * cc;
-        if (ci < (c.ld >> 2)) *reinterpret_cast<float4 *>(dst + ci * 4) = pf.chunk[cc];
-    }
-    if (lane == 0) {
-        c.node[free_slot] = v;
-        c.ref[free_slot] = 1;
-    }
-    wave_sync();
-}
 
 template <int WM>
 __device__ __forceinline__ void cache_write_back(CtxCache &c, float *table, uint32_t slot,
@@ -927,6 +876,125 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
     }
 }
 
+// The same window cache with O(1) bookkeeping (CBOW: a centre is only ~40 row transfers, so the
+// directory searches of CtxCache were a large part of its time).  Window position p owns the
+// directory entry pos_slot[p % slots] = the slot that holds its row (several positions naming the
+// same node share a slot through the reference count), or kNoSlot when the row is not cached (hot
+// node).  Finding a node is one parallel compare + ballot instead of a loop over the slots.
+constexpr uint32_t kNoSlot = 0xFFu;
+
+struct WinCache {
+    float *rows;         // [slots][ld]
+    uint32_t *node;      // [slots] node held by the slot
+    uint32_t *ref;       // [slots] window positions naming it (0 = free)
+    uint32_t *pos_slot;  // [slots] indexed by position % slots
+    uint32_t slots, ld;
+
+    __device__ __forceinline__ int lookup(uint32_t v, int lane) const {
+        const bool m = (uint32_t)lane < slots && ref[lane] != 0 && node[lane] == v;
+        const unsigned long long b = __ballot(m);
+        return b ? __ffsll((long long)b) - 1 : -1;
+    }
+    __device__ __forceinline__ int free_slot(uint32_t prefer, int lane) const {
+        if (ref[prefer] == 0) return (int)prefer;
+        const unsigned long long b = __ballot((uint32_t)lane < slots && ref[lane] == 0);
+        return b ? __ffsll((long long)b) - 1 : -1;
+    }
+};
+
+template <int NC>
+__device__ __forceinline__ void win_prefetch_issue(const TrainArgs &a, const WinCache &c,
+                                                   const float *table, uint32_t v, int lane,
+                                                   RowPrefetch<NC> &pf) {
+    pf.node = v;
+    pf.valid = c.lookup(v, lane) < 0;
+    if (!pf.valid) return;
+    pf.deg = a.cache_max_degree != 0xFFFFFFFFu ? a.g.row_ptr[v + 1] - a.g.row_ptr[v] : 0;
+    const float *src = table + (uint64_t)v * c.ld;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+        const uint32_t ci = lane + 64 * cc;
+        pf.chunk[cc] = ci < (c.ld >> 2) ? *reinterpret_cast<const float4 *>(src + ci * 4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// position p (node v) enters the window; pf: registers fetched one centre ahead, if for this node
+template <int NC>
+__device__ __forceinline__ void win_insert(const TrainArgs &a, WinCache &c, const float *table,
+                                           uint32_t p, uint32_t v, int lane,
+                                           const RowPrefetch<NC> *pf) {
+    const uint32_t entry = p % c.slots;
+    const int hit = c.lookup(v, lane);
+    if (hit >= 0) {
+        if (lane == 0) {
+            c.ref[hit] += 1;
+            c.pos_slot[entry] = (uint32_t)hit;
+        }
+        wave_sync();
+        return;
+    }
+    const bool have = pf != nullptr && pf->valid && pf->node == v;
+    if (a.cache_max_degree != 0xFFFFFFFFu) {
+        const uint64_t deg = have ? pf->deg : a.g.row_ptr[v + 1] - a.g.row_ptr[v];
+        if (deg >= a.cache_max_degree) {  // hot node: many waves would hold private copies
+            if (lane == 0) c.pos_slot[entry] = kNoSlot;
+            wave_sync();
+            return;
+        }
+    }
+    const int f = c.free_slot(entry, lane);
+    if (f < 0) {  // cannot happen: at most `slots` positions are live
+        if (lane == 0) c.pos_slot[entry] = kNoSlot;
+        wave_sync();
+        return;
+    }
+    float *dst = c.rows + (uint32_t)f * c.ld;
+    if (have) {
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const uint32_t ci = lane + 64 * cc;
+            if (ci < (c.ld >> 2)) *reinterpret_cast<float4 *>(dst + ci * 4) = pf->chunk[cc];
+        }
+    } else {
+        const float *src = table + (uint64_t)v * c.ld;
+        for (uint32_t ci = lane; ci < (c.ld >> 2); ci += 64)
+            *reinterpret_cast<float4 *>(dst + ci * 4) =
+                *reinterpret_cast<const float4 *>(src + ci * 4);
+    }
+    if (lane == 0) {
+        c.node[f] = v;
+        c.ref[f] = 1;
+        c.pos_slot[entry] = (uint32_t)f;
+    }
+    wave_sync();
+}
+
+template <int WM>
+__device__ __forceinline__ void win_write_back(const WinCache &c, float *table, uint32_t slot,
+                                               int lane) {
+    float *dst = table + (uint64_t)c.node[slot] * c.ld;
+    const float *src = c.rows + slot * c.ld;
+    for (uint32_t ci = lane; ci < (c.ld >> 2); ci += 64) {
+        const float4 x = *reinterpret_cast<const float4 *>(src + ci * 4);
+        if constexpr (WM == kWriteThrough)
+            store_sc1(dst + ci * 4, x);
+        else
+            *reinterpret_cast<float4 *>(dst + ci * 4) = x;
+    }
+}
+
+// position p leaves the window
+template <int WM>
+__device__ __forceinline__ void win_retire(WinCache &c, float *table, uint32_t p, int lane) {
+    const uint32_t h = c.pos_slot[p % c.slots];
+    if (h == kNoSlot) return;
+    if (c.ref[h] == 1) win_write_back<WM>(c, table, h, lane);
+    wave_sync();
+    if (lane == 0) c.ref[h] -= 1;
+    wave_sync();
+}
+
 // CBOW with the same LDS context cache: the window's contextual rows are what CBOW reads for the
 // mean AND read-modify-writes for the gradient (30 of the 52 row transfers of a centre); with the
 // cache they cost one read and one write-back per walk position.  Centre + negatives live in the
@@ -939,9 +1007,9 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
     const uint32_t w = a.window, k = a.k;
     const uint32_t slots = 2 * w + 1;
     const uint32_t per_wave =
-        (slots * a.ld + a.L + 2 * a.max_samples + 2 * w + 2 * slots + 3) & ~3u;
+        (slots * a.ld + a.L + 2 * a.max_samples + 2 * w + 3 * slots + 3) & ~3u;
     uint32_t *base_w = smem + wave * per_wave;
-    CtxCache cache;
+    WinCache cache;
     cache.rows = reinterpret_cast<float *>(base_w);
     uint32_t *s_walk = base_w + slots * a.ld;
     uint32_t *s_rows = s_walk + a.L;
@@ -949,6 +1017,7 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
     uint32_t *s_ctx = s_rows + 2 * a.max_samples;
     cache.node = s_ctx + 2 * w;
     cache.ref = cache.node + slots;
+    cache.pos_slot = cache.ref + slots;
     cache.slots = slots;
     cache.ld = a.ld;
     const uint32_t nchunks = a.ld >> 2;
@@ -963,14 +1032,17 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
         const uint64_t wkey = draw(a.ekey, a.first_walk + b);
         const uint64_t nkey = wkey ^ kTagNeg;
         const uint32_t *ov = a.neg_override ? a.neg_override + b * per_walk_neg : nullptr;
-        if ((uint32_t)lane < slots) cache.ref[lane] = 0;
+        if ((uint32_t)lane < slots) {
+            cache.ref[lane] = 0;
+            cache.pos_slot[lane] = kNoSlot;
+        }
         wave_sync();
+        constexpr int kPfChunks = CH > 4 ? 2 : 1;  // CH <= 4: ld <= 256 floats = 64 chunks
         for (uint32_t p = 0; p < Le && p <= w; ++p)
-            cache_insert<WM>(a, cache, a.contextual, s_walk[p], lane);
+            win_insert<kPfChunks>(a, cache, a.contextual, p, s_walk[p], lane, nullptr);
         // one centre ahead, in registers: the negatives (their ids cost a random col_idx read) and
         // the contextual row that enters the window -- the centre's latency chain shrinks from
         // ~6 dependent memory round trips to the one of its output rows
-        constexpr int kPfChunks = CH > 4 ? 2 : 1;  // CH <= 4: ld <= 256 floats = 64 chunks
         RowPrefetch<kPfChunks> pf;
         pf.valid = false;
         pf.node = kSentinel;
@@ -986,11 +1058,12 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
         };
 
         for (uint32_t i = 0; i < Le; ++i) {
-            if (i >= w + 1) cache_retire<WM>(cache, a.contextual, s_walk[i - w - 1], lane);
+            if (i >= w + 1) win_retire<WM>(cache, a.contextual, i - w - 1, lane);
             if (i >= 1 && i + w < Le)
-                cache_insert_prefetched<WM>(a, cache, a.contextual, s_walk[i + w], lane, pf);
+                win_insert<kPfChunks>(a, cache, a.contextual, i + w, s_walk[i + w], lane, &pf);
             pf.valid = false;
-            if (i + 1 + w < Le) prefetch_issue(a, cache, a.contextual, s_walk[i + 1 + w], lane, pf);
+            if (i + 1 + w < Le)
+                win_prefetch_issue(a, cache, a.contextual, s_walk[i + 1 + w], lane, pf);
 
             const uint32_t c = s_walk[i];
             if (!keep_centre(a, wkey, i, c)) continue;
@@ -1026,10 +1099,9 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
                 }
             }
             for (uint32_t t = lane; t < n_ctx; t += 64) {
-                uint32_t row = s_walk[win.position(t)];
-                const int hit = cache.find(row);
-                if (hit >= 0) row = kCacheBit | (uint32_t)hit;
-                s_ctx[t] = row;
+                const uint32_t j = win.position(t);
+                const uint32_t h = cache.pos_slot[j % slots];
+                s_ctx[t] = h != kNoSlot ? (kCacheBit | h) : s_walk[j];
             }
             wave_sync();
 
@@ -1113,7 +1185,7 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
         }
         wave_sync();
         for (uint32_t s = 0; s < slots; ++s)
-            if (cache.ref[s] != 0) cache_write_back<WM>(cache, a.contextual, s, lane);
+            if (cache.ref[s] != 0) win_write_back<WM>(cache, a.contextual, s, lane);
         wave_sync();
     }
     if (a.counters && lane == 0 && pairs) {
