@@ -62,9 +62,11 @@ def parse():
     ap.add_argument("--parallelism", default="auto", choices=["auto", "single", "blocks"],
                     help="blocks (= auto): the block trainer, on one GPU too (contextual rows in "
                          "XCD-exclusive cells); single: the walk-ordered kernel, 1 GPU only")
-    ap.add_argument("--round-walks", type=int, default=1 << 20,
+    ap.add_argument("--round-walks", type=int, default=1 << 22,
                     help="blocks: walks per rank per round (every context part visits every rank "
-                         "once per round)")
+                         "once per round; a round may span several steps: 2^22 walks = 84 GB of "
+                         "sorted pairs + sort buffer, kernel 0.92 of the roofline against 0.82 at "
+                         "2^20)")
     ap.add_argument("--parts", type=int, default=None,
                     help="blocks: context parts (default 1 on one GPU, 2 x world otherwise)")
     ap.add_argument("--slices", type=int, default=None,
@@ -247,25 +249,26 @@ def main():
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local, ld=ld)
 
-    def block_rounds(first_step, n_steps):
-        """(make_walks, seed, epoch, lr, first_walk) of every round of the given steps"""
-        per_rank = min(args.round_walks, args.walks)
-        out = []
-        for index in range(first_step, first_step + n_steps):
-            base = index * world * args.walks  # ids of the step: [base, base + world * walks)
-            for woff in range(0, args.walks, per_rank):
-                nw = min(per_rank, args.walks - woff)
-                first = base + woff * world
+    def block_rounds(offset, total):
+        """(make_walks, seed, epoch, lr, first_walk) of the rounds that train this rank's walks
+        [offset, offset + total) of the run: rounds of --round-walks walks per rank (a round may
+        span several steps: the longer the round, the more pairs of a centre meet in a cell);
+        round ids are contiguous: [first, first + world * n) with rank r generating its n-th."""
+        out, done = [], 0
+        while done < total:
+            nw = min(args.round_walks, total - done)
+            first = (offset + done) * world
 
-                def make(first=first, nw=nw):
-                    return ops.walks(graph, wp, 42, 0, first + rank * nw, nw, device=local)
+            def make(first=first, nw=nw):
+                return ops.walks(graph, wp, 42, 0, first + rank * nw, nw, device=local)
 
-                out.append((make, 42, 0, 0.01, first))
+            out.append((make, 42, 0, 0.01, first))
+            done += nw
         return out
 
     def run_steps(first_step, n_steps):
         if blocks is not None:
-            blocks.run(block_rounds(first_step, n_steps), overlap=overlap)
+            blocks.run(block_rounds(first_step * args.walks, n_steps * args.walks), overlap=overlap)
             return
         train = ops.cbow_step if cbow else ops.sgns_step
         for index in range(first_step, first_step + n_steps):
@@ -308,7 +311,8 @@ def main():
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         # the two exchanges of a round, timed alone after the measured region (they overlap with
         # training inside it): the all-gather of one round's walks and one half-partition hop
-        wk = torch.zeros((min(args.round_walks, args.walks), 128), dtype=torch.int32, device="cuda")
+        wk = torch.zeros((min(args.round_walks, args.steps * args.walks), 128), dtype=torch.int32,
+                         device="cuda")
         half = next(iter(blocks.held.values()))
         recv = torch.empty_like(half)
         reps = 4
@@ -325,7 +329,7 @@ def main():
             ms.append((time.perf_counter() - t1) / reps * 1e3)
         comm_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                      "per_rank_pairs": per_rank_pairs,
-                     "rounds_per_step": -(-args.walks // min(args.round_walks, args.walks)),
+                     "walks_per_round_per_rank": min(args.round_walks, args.steps * args.walks),
                      "walk_allgather_ms_alone": ms[0],
                      "walk_allgather_bytes_per_rank": wk.numel() * 4,
                      "half_partition_hop_ms_alone": ms[1],
@@ -387,7 +391,7 @@ def main():
                     "blocks": f"{world} GPU(s), central table striped over the ranks, contextual "
                               f"table in {blocks.parts if blocks else 0} travelling parts x "
                               f"{blocks.slices if blocks else 0} XCD slice(s) (no shared rows), rounds of "
-                              f"{min(args.round_walks, args.walks)} walks per GPU, preparation "
+                              f"{min(args.round_walks, args.steps * args.walks)} walks per GPU, preparation "
                               f"{'overlapped' if overlap else 'in line'}",
                 }[mode],
             },

@@ -28,6 +28,8 @@ constexpr int kPrepBlock = 256;
 constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
 constexpr uint32_t kMaxCells = 1024;
 constexpr uint32_t kMaxRecord = 32;
+constexpr uint32_t kCursorStep = 64;  // u64 words between the ticket cursors of two slices
+constexpr uint32_t kTicket = 4;       // records a wave takes per ticket (one returning atomic)
 // "Hot" contextual rows (share of the cell's edge endpoints inside the plan's band; off by
 // default): so many waves read-modify-write them at once that plain stores lose updates.  They
 // carry this bit in the sorted pair values and in the alias tables and are updated with f32 atomics.
@@ -325,7 +327,8 @@ struct BlockArgs {
     const unsigned long long *cell_rows;  // [cells + 1]: first table entry of every cell
     float *central;    // this rank's central partition  [rows][ld]
     float *context;    // the resident context part      [rows][ld]
-    unsigned long long *cursors;  // [slices] record tickets of the part's cells (zeroed per launch)
+    unsigned long long *cursors;  // record tickets of the part's cells, one per slice, kCursorStep
+                                  // words apart (zeroed per launch)
     unsigned long long *counters;
     uint64_t n_nodes;
     uint64_t ekey;
@@ -482,17 +485,23 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
                                                 pairs);
             }
         } else {
+            // a ticket = kTicket consecutive visiting-order indices (the stride order spreads
+            // them over the cell); one returning atomic per ticket on the cell's own cursor line
+            unsigned long long *cursor = a.cursors + (size_t)slice * kCursorStep;
             for (;;) {
                 unsigned long long t = 0;
-                if (lane == 0) t = atomicAdd(&a.cursors[slice], 1ULL);
+                if (lane == 0) t = atomicAdd(cursor, (unsigned long long)kTicket);
                 t = __shfl(t, 0);
                 if (t >= R) break;
-                const uint64_t rec = (t * A) % R;
-                const uint64_t p0 = lo + rec * C;
-                const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
-                train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, alias_lo, cell_n, slice,
-                                                s_key, s_val, s_rows, s_lab, s_tr, lane, grp, q,
-                                                pairs);
+                const uint64_t t_end = min(t + kTicket, (unsigned long long)R);
+                for (; t < t_end; ++t) {
+                    const uint64_t rec = (t * A) % R;
+                    const uint64_t p0 = lo + rec * C;
+                    const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
+                    train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, alias_lo, cell_n,
+                                                    slice, s_key, s_val, s_rows, s_lab, s_tr, lane,
+                                                    grp, q, pairs);
+                }
             }
         }
     }

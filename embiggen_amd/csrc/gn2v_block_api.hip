@@ -30,7 +30,7 @@ int check_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     if (p->world < 1 || p->rank >= p->world) return fail("need rank < world");
     if (p->parts < p->world || p->parts % p->world)
         return fail("parts must be a positive multiple of world");
-    if (p->slices < 1 || p->slices > gn2v_host::kCursorWords)
+    if (p->slices < 1 || p->slices > gn2v_host::kCursorSlices)
         return fail("slices must be in [1, 16]");
     if ((uint64_t)p->parts * p->slices > gn2v::kMaxCells) return fail("too many cells (parts x slices)");
     if (p->walk_length < 2 || p->window < 1) return fail("need walk_length >= 2, window_size >= 1");
@@ -62,26 +62,31 @@ int check_key_width(const gn2v::BlockPlan &d) {
     return 0;
 }
 
+// Stable radix sort of (keys, vals) by the low end_bit key bits between two buffers of the same
+// size (rocPRIM's double-buffer form: no third copy inside the temporary storage); the result is
+// left in keys_out / vals_out.
 template <class K, class V>
-int sort_pairs(void *temp, size_t temp_bytes, const K *keys_in, K *keys_out, const V *vals_in,
-               V *vals_out, uint64_t n, uint32_t end_bit, hipStream_t s) {
+int sort_pairs(void *temp, size_t temp_bytes, K *keys_in, K *keys_out, V *vals_in, V *vals_out,
+               uint64_t n, uint32_t end_bit, hipStream_t s) {
+    rocprim::double_buffer<K> kb(keys_in, keys_out);
+    rocprim::double_buffer<V> vb(vals_in, vals_out);
     size_t need = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, n, 0,
-                                      end_bit, s));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kb, vb, n, 0, end_bit, s));
     if (need > temp_bytes) return fail("temporary storage too small for the radix sort");
-    HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys_in, keys_out, vals_in, vals_out, n, 0,
-                                      end_bit, s));
+    HIP_TRY(rocprim::radix_sort_pairs(temp, need, kb, vb, n, 0, end_bit, s));
+    if (kb.current() != keys_out)
+        HIP_TRY(hipMemcpyAsync(keys_out, kb.current(), n * sizeof(K), hipMemcpyDeviceToDevice, s));
+    if (vb.current() != vals_out)
+        HIP_TRY(hipMemcpyAsync(vals_out, vb.current(), n * sizeof(V), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
 template <class K>
 size_t sort_temp_bytes(uint64_t n) {
     size_t need = 0;
-    const K *k = nullptr;
-    K *ko = nullptr;
-    const uint32_t *v = nullptr;
-    uint32_t *vo = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, need, k, ko, v, vo, n ? n : 1, 0, 8 * sizeof(K),
+    rocprim::double_buffer<K> kb(nullptr, nullptr);
+    rocprim::double_buffer<uint32_t> vb(nullptr, nullptr);
+    if (rocprim::radix_sort_pairs(nullptr, need, kb, vb, n ? n : 1, 0, 8 * sizeof(K),
                                   (hipStream_t)0) != hipSuccess)
         return 0;
     return (need + 255) & ~(size_t)255;
@@ -253,9 +258,9 @@ int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_
         return 1;
     const uint32_t end_bit = std::max(1u, d.row_bits + bits_for((uint64_t)d.parts * d.slices));
     if (d.key64)
-        return sort_pairs(sort_temp, temp_bytes - head, (const uint64_t *)keys_in,
-                          (uint64_t *)d_keys, vals_in, d_vals, n_pairs, end_bit, s);
-    return sort_pairs(sort_temp, temp_bytes - head, (const uint32_t *)keys_in, (uint32_t *)d_keys,
+        return sort_pairs(sort_temp, temp_bytes - head, (uint64_t *)keys_in, (uint64_t *)d_keys,
+                          vals_in, d_vals, n_pairs, end_bit, s);
+    return sort_pairs(sort_temp, temp_bytes - head, (uint32_t *)keys_in, (uint32_t *)d_keys,
                       vals_in, d_vals, n_pairs, end_bit, s);
 }
 

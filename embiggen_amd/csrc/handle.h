@@ -26,9 +26,12 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
-// record-ticket arrays of the block trainer: one per launch, reused round robin (a launch is long
-// over before its slot comes round again)
-constexpr unsigned kCursorWords = 16, kCursorRing = 256;
+// record-ticket cursors of the block trainer: up to 16 slices per launch, every cursor on a
+// 512 B line of its own (eight XCDs taking tickets from neighbouring words of one line
+// serialised on that line); one array per launch, reused round robin (a launch is long over
+// before its slot comes round again)
+constexpr unsigned kCursorSlices = 16, kCursorStride = 64, kCursorRing = 256;
+constexpr unsigned kCursorWords = kCursorSlices * kCursorStride;
 
 // Every entry point runs on the device of its graph handle (or of the buffers it is given) and
 // leaves the calling thread's current HIP device as it found it: a one-process multi-device

@@ -214,7 +214,7 @@ class _WalkBasedModel:
     # quality at or above the walk-ordered schedule's)
     BLOCK_PATH_MIN_NODES = 1 << 16
 
-    def fit_transform_blocks(self, graph, comm, round_walks: int = 1 << 20, slices=None,
+    def fit_transform_blocks(self, graph, comm, round_walks: Optional[int] = None, slices=None,
                              parts=None, overlap: bool = True, max_walks_per_epoch: int = 0):
         """SkipGram over several GPUs, one process per GPU (``comm`` = ``distributed.TorchComm``
         under ``torch.distributed.run``): tables partitioned by node id, no row shared between
@@ -247,6 +247,17 @@ class _WalkBasedModel:
             walks_per_epoch = csr.get_number_of_unique_source_nodes() * self.iterations
             if max_walks_per_epoch:
                 walks_per_epoch = min(walks_per_epoch, max_walks_per_epoch)
+            if round_walks is None:
+                # the longer a round, the more pairs of a centre meet in a cell (the centre row is
+                # read once per such run): up to 2^22 walks per rank, within a third of the free
+                # HBM (16 B per pair while the sort runs + the gathered walks)
+                w = self.window_size
+                per_walk = (2 * w * L - w * (w + 1)) * 16 + 4 * L * comm.world
+                free = torch.cuda.mem_get_info(dev)[0]
+                round_walks = max(1 << 14, min(1 << 22, free // 3 // per_walk))
+                if comm.world > 1:  # every rank must use the same round size
+                    mine = torch.tensor([round_walks], dtype=torch.int64, device=dev)
+                    round_walks = int(comm.all_gather(mine).min())
             round_walks = max(1, min(round_walks, -(-walks_per_epoch // comm.world)))
             stride = comm.world * round_walks
             n_rounds = (walks_per_epoch + stride - 1) // stride
