@@ -41,6 +41,7 @@ struct BlockPlan {
     uint32_t row_bits;
     uint32_t flags;  // kFlagDownsample: centres are thinned at extraction (needs the graph)
     uint32_t key64;  // sort keys are u64 (cell and centre row do not fit 32 bits)
+    uint32_t hubs;   // a hot band is set: rows may carry kHubBit
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -422,7 +423,9 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         load_row<CH>(u, crow, q, nchunks, true);
         zero_row<CH>(g);
         Row<CH> u_upd = u;
-        if constexpr (!DET) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
+        if constexpr (!DET) {  // lane-contiguous copy of u for atomic row updates
+            if (is_atomic(WMX) || a.p.hubs) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
+        }
         if constexpr (!DET && !is_atomic(WMX))  // stores take u, the atomics of hot rows u_upd
             score_samples<CH, WMX, DET, true>(a, a.context, u, u, g, s_rows + r0 * (k + 1),
                                               s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp,

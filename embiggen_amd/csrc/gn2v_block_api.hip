@@ -54,6 +54,7 @@ gn2v::BlockPlan device_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     d.row_bits = bits_for(rows);
     d.flags = p->flags & gn2v::kFlagDownsample;
     d.key64 = d.row_bits + bits_for((uint64_t)d.parts * d.slices) > 32 ? 1u : 0u;
+    d.hubs = p->hot_lo != 0 ? 1u : 0u;
     return d;
 }
 

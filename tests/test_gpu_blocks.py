@@ -227,8 +227,8 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
     # synthetic sorted pairs: centre row i (unique, ascending), context row perm[i] of the cell
     g = _ba(2 * n_rows + 5)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, 1, record)
-    oplan = O.block_plan(2 * n_rows + 5, 1, 0, parts, slices, 8, 2, 1, record)
+    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, 1, record, hot_lo=1)  # hot rows exist
+    oplan = O.block_plan(2 * n_rows + 5, 1, 0, parts, slices, 8, 2, 1, record, hot_lo=1)
     rng = np.random.RandomState(3)
     rows_per_part = stripe_rows(2 * n_rows + 5, 0, parts)
     keys_l, vals_l, offsets = [], [], [0]
