@@ -407,7 +407,13 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         s_lab[t] = lab;
     }
     wave_sync();
+    // Runs of equal centre inside the record (short: a centre's pairs are spread over all cells).
+    // The central row of the NEXT run is loaded while the current run is scored (other runs have
+    // other centres, so it cannot be changed by this record in between).
     uint32_t r0 = 0;
+    Row<CH> u_next;
+    if constexpr (!DET)
+        load_row<CH>(u_next, a.central + (uint64_t)s_key[0] * a.ld, q, nchunks, n != 0);
     while (r0 < n) {
         const uint32_t crow_id = s_key[r0];
         uint32_t r1 = r0 + 1;
@@ -420,7 +426,13 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         }
         float *crow = a.central + (uint64_t)crow_id * a.ld;
         Row<CH> u, g;
-        load_row<CH>(u, crow, q, nchunks, true);
+        if constexpr (DET) {
+            load_row<CH>(u, crow, q, nchunks, true);
+        } else {
+            u = u_next;
+            load_row<CH>(u_next, a.central + (uint64_t)s_key[r1 < n ? r1 : r0] * a.ld, q, nchunks,
+                         r1 < n);
+        }
         zero_row<CH>(g);
         Row<CH> u_upd = u;
         if constexpr (!DET) {  // lane-contiguous copy of u for atomic row updates
