@@ -1,4 +1,5 @@
-// Block-partitioned SkipGram: the multi-GPU form of the fused negative-sampling step.
+// Block-partitioned SkipGram: the fused negative-sampling step over pairs grouped by (context
+// cell, centre) -- the multi-GPU trainer and, with one rank, the default for large graphs.
 //
 // The reference has no counterpart (ensmallen trains in one process with rayon threads; the call
 // being replaced is embedders/ensmallen_embedders/node2vec.py:99).  Scheme:
