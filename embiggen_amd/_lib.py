@@ -27,6 +27,8 @@ TRAIN_WRITE_THROUGH = 64
 TRAIN_NO_CTX_CACHE = 128
 TRAIN_CTX_CACHE_ALL = 256
 TRAIN_LOCAL_ATOMIC = 512
+TRAIN_WALK_ORDERED = 1024
+TRAIN_BLOCK_PATH = 2048
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 
@@ -40,7 +42,7 @@ EXPORTS = [
     "gn2v_touch_rows",
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
     "gn2v_block_alias", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
-    "gn2v_block_extract", "gn2v_block_step",
+    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_auto_plan", "gn2v_train_blocks",
     "gn2v_stats_reset",
     "gn2v_stats_read",
 ]
@@ -131,6 +133,8 @@ class Stats(C.Structure):
         ("walk_ms", C.c_double),
         ("train_launches", C.c_uint32),
         ("walk_launches", C.c_uint32),
+        ("block_parts", C.c_uint32),
+        ("block_slices", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -221,6 +225,9 @@ def lib():
                                      u64, vp, vp, vp, u64, vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),
                                   C.POINTER(BlockIO), u64, u64, f32, vp]
+    L.gn2v_block_auto_plan.argtypes = [u64, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.gn2v_train_blocks.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,
+                                    u64, vp, vp, C.POINTER(Stats), vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]
     L.gn2v_stats_read.argtypes = [vp, C.POINTER(Stats), vp]
     for name in EXPORTS:

@@ -524,6 +524,20 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
     if (a.counters && lane == 0 && pairs) atomicAdd(&a.counters[0], pairs);
 }
 
+// contextual[x] <- part (x % parts), row x / parts: one part written back into the whole table
+static __global__ void scatter_part_kernel(float *__restrict__ table, const float *__restrict__ part,
+                                           uint64_t part_rows, uint32_t ld, uint32_t part_id,
+                                           uint32_t parts) {
+    const uint64_t n = part_rows * (ld >> 2);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / (ld >> 2);
+        const uint32_t c = (uint32_t)(i - r * (ld >> 2));
+        reinterpret_cast<float4 *>(table + (r * parts + part_id) * ld)[c] =
+            reinterpret_cast<const float4 *>(part + r * ld)[c];
+    }
+}
+
 // table row r <- initial values of global row first_row + r * row_stride (shards of a table that
 // never exists as a whole on this device)
 __global__ void init_rows_kernel(float *__restrict__ t, uint64_t n_rows, uint32_t d, uint32_t ld,

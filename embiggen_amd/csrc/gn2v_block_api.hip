@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <vector>
 
 #include "block_kernels.h"
 #include "handle.h"
@@ -95,6 +96,29 @@ size_t sort_temp_bytes(uint64_t n) {
 
 constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+}  // namespace
+
+namespace {
+// device buffers of one gn2v_train_blocks call, released on every exit path
+struct Buffers {
+    std::vector<void *> ptrs;
+    ~Buffers() {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    int alloc(T **out, size_t bytes) {
+        *out = nullptr;
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail("out of device memory in gn2v_train_blocks (" + std::to_string(bytes >> 20) +
+                        " MiB)");
+        }
+        ptrs.push_back(p);
+        *out = (T *)p;
+        return 0;
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -386,6 +410,165 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     HIP_TRY(hipEventRecord(ev.b, s));
     g->train_events.push_back(ev);
     g->train_launches++;
+    return 0;
+}
+
+
+int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t *parts, uint32_t *slices) {
+    if (!parts || !slices || world < 1) return fail("bad arguments");
+    auto pow2_floor = [](uint64_t x) {
+        uint64_t p = 1;
+        while (p * 2 <= x) p *= 2;
+        return x < 1 ? (uint64_t)1 : p;
+    };
+    constexpr uint64_t kMinRows = 32768;
+    if (world > 1) {
+        const uint64_t sl =
+            std::max<uint64_t>(1, std::min<uint64_t>(8, pow2_floor(n_nodes / (2 * world * kMinRows))));
+        const uint64_t per_rank = std::max<uint64_t>(
+            2, std::min(pow2_floor(n_nodes / (world * sl * kMinRows)),
+                        pow2_floor(std::max<uint64_t>(2, 128 / world))));
+        *parts = (uint32_t)(per_rank * world);
+        *slices = (uint32_t)sl;
+        return 0;
+    }
+    const uint64_t sl = std::max<uint64_t>(1, std::min<uint64_t>(8, pow2_floor(n_nodes / kMinRows)));
+    *slices = (uint32_t)sl;
+    *parts = (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>(128, pow2_floor(n_nodes / (sl * kMinRows))));
+    return 0;
+}
+
+
+int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
+                      uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
+                      float *d_central, float *d_contextual, gn2v_stats *stats, void *stream) {
+    if (!g || !wp || !tp) return fail("NULL handle / params");
+    if (tp->model != GN2V_MODEL_SKIPGRAM) return fail("the block path trains SkipGram only");
+    if (!d_central || !d_contextual) return fail("NULL table pointer");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t n = g->view.n_nodes;
+    const uint32_t L = wp->walk_length, w = tp->window, ld = tp->ld;
+
+    gn2v_block_plan plan{};
+    plan.world = 1;
+    plan.rank = 0;
+    if (gn2v_block_auto_plan(n, 1, &plan.parts, &plan.slices)) return 1;
+    plan.walk_length = L;
+    plan.window = w;
+    plan.min_dist = tp->min_dist ? tp->min_dist : 1;
+    plan.record = 16;
+    plan.flags = tp->flags & GN2V_TRAIN_DOWNSAMPLE;
+    while (plan.parts > 1 && n / plan.parts == 0) plan.parts /= 2;
+    if (gn2v_block_plan_check(g, &plan)) return 1;
+    const uint32_t parts = plan.parts, cells = parts * plan.slices;
+    const bool scale_free = tp->flags & GN2V_TRAIN_SCALE_FREE;
+
+    uint64_t walks_per_epoch = g->view.n_sources * (uint64_t)wp->iterations;
+    if (max_walks_per_epoch && max_walks_per_epoch < walks_per_epoch)
+        walks_per_epoch = max_walks_per_epoch;
+    const uint64_t pairs_per_walk = 2ull * w * L;  // upper bound (window untrimmed)
+    const size_t key_bytes = plan.key_bits / 8;
+
+    Buffers buf;
+    // alias tables + hot-row bitmap (the bitmap is all zero: no hot band in the automatic plan)
+    uint64_t *alias = nullptr, *cell_rows = nullptr;
+    uint32_t *hub_bits = nullptr;
+    if (scale_free) {
+        uint64_t tb = 0;
+        gn2v_block_alias_temp_bytes(n, &tb);
+        void *tmp = nullptr;
+        if (buf.alloc(&alias, n * 8) || buf.alloc(&cell_rows, (cells + 1) * 8) ||
+            buf.alloc(&hub_bits, ((n + 31) / 32) * 4) || buf.alloc(&tmp, tb))
+            return 1;
+        if (gn2v_block_alias(g, &plan, alias, cell_rows, hub_bits, tmp, tb, s)) return 1;
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(tmp);
+        buf.ptrs.pop_back();
+    }
+    // the contextual table as `parts` buffers; the central table is the caller's (world = 1)
+    const uint64_t max_rows = gn2v::stripe_count(n, 0, parts);
+    float *ctx = nullptr;
+    if (buf.alloc(&ctx, (size_t)parts * max_rows * ld * sizeof(float))) return 1;
+    if (gn2v_init_table(d_central, n, tp->d, ld, seed, 0, tp->init_scale, s)) return 1;
+    for (uint32_t p = 0; p < parts; ++p)
+        if (gn2v_init_table_rows(ctx + (size_t)p * max_rows * ld, gn2v::stripe_count(n, p, parts),
+                                 tp->d, ld, seed, 1, tp->init_scale, p, parts, s))
+            return 1;
+
+    // round size: the longer, the more pairs of a centre meet in a cell; a third of the free HBM
+    if (round_walks == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t per_walk = pairs_per_walk * (2 * key_bytes + 8) + 4ull * L;
+        round_walks = std::max<uint64_t>(1 << 14, std::min<uint64_t>(1 << 22, free_b / 3 / per_walk));
+    }
+    round_walks = std::max<uint64_t>(1, std::min(round_walks, walks_per_epoch));
+    const uint64_t cap = round_walks * pairs_per_walk;
+    uint32_t *walks = nullptr, *vals = nullptr;
+    void *keys = nullptr, *tmp = nullptr;
+    uint64_t *work = nullptr, *cell_offsets = nullptr;
+    uint64_t tb = 0;
+    gn2v_block_extract_temp_bytes(cap, plan.key_bits, &tb);
+    if (buf.alloc(&walks, round_walks * L * 4) || buf.alloc(&keys, cap * key_bytes) ||
+        buf.alloc(&vals, cap * 4) || buf.alloc(&tmp, tb) ||
+        buf.alloc(&work, GN2V_BLOCK_WORK_WORDS * 8) || buf.alloc(&cell_offsets, (cells + 1) * 8))
+        return 1;
+
+    float lr = tp->lr;
+    uint64_t round_id = 0;
+    for (uint32_t e = 0; e < tp->epochs; ++e) {
+        for (uint64_t first = 0; first < walks_per_epoch; first += round_walks, ++round_id) {
+            const uint64_t nw = std::min(round_walks, walks_per_epoch - first);
+            if (gn2v_walks(g, wp, seed, e, first, nw, walks, s)) return 1;
+            if (gn2v_block_count(g, &plan, walks, nw, seed, e, first, work, cell_offsets, s))
+                return 1;
+            uint64_t n_pairs = 0;  // the one host read of the round
+            HIP_TRY(hipMemcpyAsync(&n_pairs, cell_offsets + cells, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (n_pairs > cap) return fail("internal: more pairs than the round's capacity");
+            if (n_pairs == 0) continue;
+            if (gn2v_block_extract(g, &plan, walks, nw, seed, e, first, work, hub_bits, n_pairs,
+                                   keys, vals, tmp, tb, s))
+                return 1;
+            for (uint32_t p = 0; p < parts; ++p) {
+                gn2v_block_io io{};
+                io.d_keys = keys;
+                io.d_vals = vals;
+                io.d_cell_offsets = cell_offsets;
+                io.d_alias = alias;
+                io.d_cell_rows = cell_rows;
+                io.d_central = d_central;
+                io.d_context = ctx + (size_t)p * max_rows * ld;
+                io.block_id = round_id;
+                io.part = p;
+                if (gn2v_block_step(g, tp, &plan, &io, seed, e, lr, s)) return 1;
+            }
+            if (g->train_events.size() > 2048) {  // bound the event pool on long fits
+                HIP_TRY(hipStreamSynchronize(s));
+                gn2v_stats scratch;
+                if (gn2v_stats_read(g, &scratch, s)) return 1;
+            }
+        }
+        lr *= tp->lr_decay;
+    }
+    for (uint32_t p = 0; p < parts; ++p) {
+        const uint64_t rows = gn2v::stripe_count(n, p, parts);
+        if (!rows) continue;
+        const unsigned blocks =
+            (unsigned)std::min<uint64_t>((rows * (ld >> 2) + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(gn2v::scatter_part_kernel, dim3(blocks), dim3(256), 0, s, d_contextual,
+                           ctx + (size_t)p * max_rows * ld, rows, ld, p, parts);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (stats) {
+        if (gn2v_stats_read(g, stats, s)) return 1;
+        stats->block_parts = parts;
+        stats->block_slices = plan.slices;
+    }
     return 0;
 }
 

@@ -45,25 +45,20 @@ MIN_ROWS_PER_CELL = 32768
 
 
 def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:
-    """(parts, slices) of the contextual table.  Measured (scripts/quality_probe.py, DESIGN.md
-    section 7): the smaller a cell, the more of it lives in the XCD's L2 (BA 10 M nodes: 0.67 of
-    the HBM roofline unsliced, 0.80 at 4 x 8 cells, 0.87 at 32 x 8) -- and the more often two
-    waves read-modify-write the same row at once; link quality stays at or above the walk-ordered
-    trainer's while a cell keeps >= 32 k rows.  With several ranks every rank holds the same
-    number (>= 2) of parts."""
-    def pow2_floor(x):
-        return 1 << (max(1, int(x)).bit_length() - 1)
+    """(parts, slices) of the contextual table (``gn2v_block_auto_plan``: one rule for the C++
+    one-GPU fit and for this trainer).  Measured (scripts/quality_probe.py):
+    the smaller a cell, the more of it lives in the XCD's L2 (BA 10 M nodes: 0.67 of the HBM
+    roofline unsliced, 0.80 at 4 x 8 cells, 0.87 at 32 x 8) -- and the more often two waves
+    read-modify-write the same row at once; link quality stays at or above the walk-ordered
+    trainer's while a cell keeps >= 32 k rows.  slices = 8 (one per XCD); as many parts -- at
+    least two per rank with several ranks, at most 128 -- as keep MIN_ROWS_PER_CELL rows a cell."""
+    import ctypes as C
 
-    if world > 1:
-        # at least two parts per rank (one trains while one travels), more while the cells stay
-        # large enough; at most 128 parts (1 024 cells)
-        slices = max(1, min(8, pow2_floor(n_nodes // (2 * world * MIN_ROWS_PER_CELL))))
-        per_rank = max(2, min(pow2_floor(n_nodes // (world * slices * MIN_ROWS_PER_CELL)),
-                              pow2_floor(max(2, 128 // world))))
-        return per_rank * world, slices
-    slices = max(1, min(8, pow2_floor(n_nodes // MIN_ROWS_PER_CELL)))
-    parts = max(1, min(128, pow2_floor(n_nodes // (slices * MIN_ROWS_PER_CELL))))
-    return parts, slices
+    from . import _lib
+
+    parts, slices = C.c_uint32(), C.c_uint32()
+    _lib.check(_lib.lib().gn2v_block_auto_plan(n_nodes, world, C.byref(parts), C.byref(slices)))
+    return parts.value, slices.value
 
 
 class _Done:

@@ -65,6 +65,7 @@ class _WalkBasedModel:
         update_mode: str = "auto",
         device: int = 0,
         min_distance: int = 1,
+        block_path: Optional[bool] = None,
     ):
         if not isinstance(embedding_size, int) or embedding_size < 1:
             raise ValueError("The embedding size must be a strictly positive integer.")
@@ -119,6 +120,10 @@ class _WalkBasedModel:
         if not 1 <= min_distance <= window_size:
             raise ValueError("min_distance must be in [1, window_size].")
         self.min_distance = int(min_distance)
+        # None: the engine decides (SkipGram, >= 2^16 nodes, default update mode: block path);
+        # True / False force or forbid it
+        self.block_path = block_path
+        self.last_plan = None
         self.last_stats = None
         self.last_seconds = None
 
@@ -154,6 +159,10 @@ class _WalkBasedModel:
             flags |= _lib.TRAIN_WRITE_BACK
         elif self.update_mode == "write_through":
             flags |= _lib.TRAIN_WRITE_THROUGH
+        if self.block_path is True and self.MODEL_ID == _lib.MODEL_SKIPGRAM:
+            flags |= _lib.TRAIN_BLOCK_PATH
+        elif self.block_path is False:
+            flags |= _lib.TRAIN_WALK_ORDERED
         return _lib.TrainParams(
             self.MODEL_ID, self.embedding_size, self.padded_size, self.epochs,
             self.number_of_negative_samples, self.window_size, self.learning_rate,
@@ -175,20 +184,15 @@ class _WalkBasedModel:
         _lib.require_device()
         if not torch.cuda.is_available():
             raise RuntimeError("PyTorch does not see a ROCm device; cannot allocate the tables.")
-        if (self.MODEL_ID == _lib.MODEL_SKIPGRAM and self.update_mode == "auto"
-                and not self.deterministic
-                and csr.get_number_of_nodes() >= self.BLOCK_PATH_MIN_NODES):
-            from .distributed import LoopbackComm
-
-            central, contextual = self.fit_transform_blocks(
-                graph, LoopbackComm(), max_walks_per_epoch=max_walks_per_epoch)
-            return central, contextual, self.last_stats
         dev = torch.device("cuda", self.device)
         dgraph = csr.device_graph(self.device)
         n, ld = csr.get_number_of_nodes(), self.padded_size
         with torch.cuda.device(dev):
             central = torch.empty((n, ld), dtype=torch.float32, device=dev)
             contextual = torch.empty((n, ld), dtype=torch.float32, device=dev)
+            # the library allocates its round buffers itself (block path): hand back what
+            # PyTorch's caching allocator is only keeping for later
+            torch.cuda.empty_cache()
             stream = torch.cuda.current_stream().cuda_stream
             wp, tp, stats = self.walk_params(), self.train_params(), _lib.Stats()
             L = _lib.lib()
@@ -199,19 +203,24 @@ class _WalkBasedModel:
                                     contextual.data_ptr(), C.byref(stats), stream))
             self.last_seconds = time.perf_counter() - start
         self.last_stats = stats.as_dict()
+        self.last_plan = ({"world": 1, "parts": stats.block_parts, "slices": stats.block_slices}
+                          if stats.block_parts else None)
         if self.verbose:
             secs = max(self.last_seconds, 1e-9)
+            path = (f" (block path, {stats.block_parts} parts x {stats.block_slices} slices)"
+                    if stats.block_parts else "")
             print(
-                f"[gn2v] {self.NAME}: {stats.pairs} pairs, {stats.walk_steps} walk steps in "
+                f"[gn2v] {self.NAME}{path}: {stats.pairs} pairs, {stats.walk_steps} walk steps in "
                 f"{secs:.3f}s ({stats.pairs / secs:.3e} pairs/s; train kernels "
                 f"{stats.train_ms:.1f} ms, walk kernels {stats.walk_ms:.1f} ms)",
                 file=sys.stderr,
             )
         return central, contextual, self.last_stats
 
-    # graphs from this size on are trained through the block path on one GPU as well (contextual
-    # rows in XCD-exclusive cells: 0.87 instead of 0.70 of the HBM roofline at 10 M nodes, link
-    # quality at or above the walk-ordered schedule's)
+    # SkipGram on graphs of >= 2^16 nodes in the default update mode is trained through the block
+    # path on one GPU as well (gn2v_train decides; contextual rows in XCD-exclusive cells: 0.93
+    # instead of 0.70 of the HBM roofline at 10 M nodes, link quality at or above the walk-ordered
+    # schedule's)
     BLOCK_PATH_MIN_NODES = 1 << 16
 
     def fit_transform_blocks(self, graph, comm, round_walks: Optional[int] = None, slices=None,

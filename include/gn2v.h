@@ -60,6 +60,11 @@ extern "C" {
  * their updates can be f32 atomics executed inside that XCD's L2 (workgroup scope): no lost
  * update, no trip to memory. */
 #define GN2V_TRAIN_LOCAL_ATOMIC 512u
+/* gn2v_train picks its schedule: SkipGram on graphs of >= 2^16 nodes in the default update mode
+ * runs the block path (gn2v_train_blocks), everything else the walk-ordered kernels.  Overrides: */
+#define GN2V_TRAIN_WALK_ORDERED 1024u /* never the block path                                    */
+#define GN2V_TRAIN_BLOCK_PATH 2048u   /* always the block path (SkipGram; with
+                                         GN2V_TRAIN_DETERMINISTIC: its sequential schedule)      */
 
 #define GN2V_MODEL_SKIPGRAM 0u
 #define GN2V_MODEL_CBOW 1u
@@ -106,6 +111,8 @@ typedef struct {
     double walk_ms;        /* sum of walk-kernel durations                      */
     uint32_t train_launches;
     uint32_t walk_launches;
+    uint32_t block_parts;  /* plan of the block path when gn2v_train took it, else 0    */
+    uint32_t block_slices;
 } gn2v_stats;
 
 typedef struct gn2v_graph gn2v_graph;
@@ -297,6 +304,23 @@ typedef struct {
 int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
                     const gn2v_block_io *io, uint64_t seed, uint64_t epoch, float lr,
                     void *stream);
+
+/* (parts, slices) of the contextual table for a graph of n_nodes on `world` ranks: slices = 8
+ * (one per XCD) and as many parts (at least two per rank, at most 128) as keep >= 32 768 rows in
+ * a cell -- the size from which the link quality of the block path is at or above the
+ * walk-ordered schedule's. */
+int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t *parts, uint32_t *slices);
+
+/* The whole fit (same contract as gn2v_train: caller-allocated tables f32[n_nodes][ld], filled on
+ * return) through the block path on one GPU: automatic plan, alias tables, rounds of
+ * `round_walks` walks (0 = automatic: up to 2^22, within a third of the free HBM), per round walk
+ * generation, pair extraction + sort and one gn2v_block_step per part.  The central table is
+ * trained in place; the contextual table lives in `parts` buffers of the library's own during
+ * the fit and is written to d_contextual at the end.  gn2v_train calls this for SkipGram on
+ * graphs of >= 2^16 nodes. */
+int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
+                      uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
+                      float *d_central, float *d_contextual, gn2v_stats *stats, void *stream);
 
 /* ---- GloVe: the third model of the reference's walk-based table (embedders/ensmallen_embedders/
  * node2vec.py:16-26 "Node2Vec GloVe" / "DeepWalk GloVe": models.GloVe; wrapper kwargs

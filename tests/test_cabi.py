@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.WalkParams) == 32
     assert C.sizeof(_lib.TrainParams) == 48
-    assert C.sizeof(_lib.Stats) == 48
+    assert C.sizeof(_lib.Stats) == 56
+    assert C.sizeof(_lib.BlockPlan) == 13 * 4 and C.sizeof(_lib.BlockIO) == 72
     text = open(HEADER).read()
     for name, value in (("GN2V_TRAIN_SCALE_FREE", _lib.TRAIN_SCALE_FREE),
                         ("GN2V_TRAIN_DOWNSAMPLE", _lib.TRAIN_DOWNSAMPLE),
@@ -42,9 +43,32 @@ def test_struct_layouts_match_header():
                         ("GN2V_TRAIN_ATOMIC", _lib.TRAIN_ATOMIC),
                         ("GN2V_TRAIN_WRITE_BACK", _lib.TRAIN_WRITE_BACK),
                         ("GN2V_TRAIN_WRITE_THROUGH", _lib.TRAIN_WRITE_THROUGH),
+                        ("GN2V_TRAIN_LOCAL_ATOMIC", _lib.TRAIN_LOCAL_ATOMIC),
+                        ("GN2V_TRAIN_WALK_ORDERED", _lib.TRAIN_WALK_ORDERED),
+                        ("GN2V_TRAIN_BLOCK_PATH", _lib.TRAIN_BLOCK_PATH),
                         ("GN2V_GRAPH_DEVICE_PTRS", _lib.GRAPH_DEVICE_PTRS),
                         ("GN2V_GRAPH_SYMMETRIC", _lib.GRAPH_SYMMETRIC)):
         assert re.search(rf"#define {name} +{value}u", text), name
+
+
+def test_automatic_plan_of_the_block_path():
+    """gn2v_block_auto_plan (pure host function: no GPU needed): slices = 8, cells of >= 32 768
+    rows, at least two parts per rank, at most 128 parts."""
+    from embiggen_amd.distributed import auto_plan
+
+    assert auto_plan(34, 1) == (1, 1) and auto_plan(34, 8) == (16, 1)
+    assert auto_plan(65_536, 1) == (1, 2) and auto_plan(262_144, 1) == (1, 8)
+    assert auto_plan(1_000_000, 1) == (2, 8) and auto_plan(2_449_029, 8) == (16, 4)
+    assert all(auto_plan(10_000_000, w) == (32, 8) for w in (1, 2, 4, 8))
+    assert all(auto_plan(100_000_000, w) == (128, 8) for w in (1, 2, 4, 8))
+    for n in (10 ** 5, 10 ** 6, 10 ** 7, 10 ** 8, 3 * 10 ** 9):
+        for world in (1, 2, 3, 8):
+            parts, slices = auto_plan(n, world)
+            assert parts % world == 0 and parts <= 128 and slices in (1, 2, 4, 8)
+            assert world == 1 or parts >= 2 * world
+            assert parts * slices == (world if world == 1 and n < 65536 else parts * slices)
+            if parts > (1 if world == 1 else 2 * world):
+                assert n // (parts * slices) >= 32768
 
 
 def test_errors_are_reported_not_thrown():

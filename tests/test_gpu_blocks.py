@@ -466,3 +466,44 @@ def test_one_rank_rccl_group_equals_loopback():
     assert res.returncode == 0, res.stderr[-3000:]
     ok = [l.split() for l in res.stdout.splitlines() if l.startswith("OK ")]  # RCCL logs to stdout too
     assert len(ok) == 1 and float(ok[0][1]) == 0.0, res.stdout[-500:]
+
+
+def test_gn2v_train_block_path_equals_the_python_trainer():
+    """``gn2v_train`` runs the block path itself (C++ host loop: plan, alias tables, rounds,
+    extraction + sort, one step per part, parts written back) for SkipGram on large graphs; forced
+    here on a small graph in its deterministic schedule, it must equal the Python trainer -- which
+    the tests above tie to the oracle -- over several epochs and rounds."""
+    g = _ba(300, 4)
+    kw = dict(embedding_size=12, epochs=3, walk_length=16, iterations=3, window_size=3,
+              number_of_negative_samples=4, learning_rate=0.05, learning_rate_decay=0.8,
+              deterministic=True, verbose=False)
+    m_c = E.models.SkipGram(block_path=True, **kw)
+    c1, x1, st = m_c.fit_transform_device(g)
+    assert m_c.last_plan == {"world": 1, "parts": 1, "slices": 1}
+    m_py = E.models.SkipGram(**kw)
+    c2, x2 = m_py.fit_transform_blocks(g, LoopbackComm())
+    assert st["pairs"] == m_py.last_stats["pairs"] == 3 * 900 * (2 * 3 * 16 - 3 * 4)
+    assert float((c1 - c2).abs().max()) < 1e-5 and float((x1 - x2).abs().max()) < 1e-5
+    init = ops.init_table(300, 12, 42, 1, 12 ** -0.5)
+    assert float((x1[:, :12] - init).abs().max()) > 1e-3
+    # the walk-ordered schedule is a different order of the same pairs: other numbers, same count
+    m_w = E.models.SkipGram(block_path=False, **kw)
+    c3, _, st3 = m_w.fit_transform_device(g)
+    assert m_w.last_plan is None and st3["pairs"] == st["pairs"]
+    assert float((c1 - c3).abs().max()) > 1e-4
+
+
+def test_gn2v_train_takes_the_block_path_by_itself_from_two_to_the_sixteen_nodes():
+    small, large = E.barabasi_albert(60_000, 5, 1), E.barabasi_albert(70_000, 5, 1)
+    kw = dict(embedding_size=16, epochs=1, iterations=1, walk_length=16, window_size=3,
+              verbose=False)
+    for g, plan in ((small, None), (large, {"world": 1, "parts": 1, "slices": 2})):
+        for cls in (E.models.SkipGram, E.models.CBOW):
+            m = cls(**kw)
+            c, x, st = m.fit_transform_device(g)
+            assert m.last_plan == (plan if cls is E.models.SkipGram else None)
+            assert st["pairs"] == g.get_number_of_nodes() * (2 * 3 * 16 - 3 * 4)
+            assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+    m = E.models.SkipGram(update_mode="write_through", **kw)  # explicit modes: walk-ordered
+    m.fit_transform_device(large)
+    assert m.last_plan is None
