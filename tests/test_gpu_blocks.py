@@ -507,3 +507,32 @@ def test_gn2v_train_takes_the_block_path_by_itself_from_two_to_the_sixteen_nodes
     m = E.models.SkipGram(update_mode="write_through", **kw)  # explicit modes: walk-ordered
     m.fit_transform_device(large)
     assert m.last_plan is None
+
+
+def test_block_path_against_the_committed_golden_fixture(karate):
+    """tests/golden/oracle_blocks.npz (the oracle's block schedule frozen on Karate: rank 1 of 2,
+    4 parts x 2 slices, hot band): the device reproduces extraction, sort, alias tables and
+    flags bit for bit and the deterministic round within 1e-5, with no oracle in the loop."""
+    import os
+
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = np.load(os.path.join(gold_dir, "oracle_blocks.npz"))
+    walks = np.load(os.path.join(gold_dir, "oracle_karate.npz"))["walks"]
+    wk = torch.from_numpy(walks.view(np.int32)).cuda()
+    plan = ops.block_plan(karate, 2, 1, 4, 2, 16, 3, 1, 4, hot_lo=4, hot_hi=1)
+    alias, cell_rows, hub_bits = ops.block_alias(karate, plan)
+    work, offsets = ops.block_count(karate, plan, wk, 42, 0, 0)
+    keys, vals = ops.block_extract(karate, plan, wk, 42, 0, 0, work, int(offsets[-1]),
+                                   hub_bits=hub_bits)
+    assert np.array_equal(_keys(keys), gold["keys"]) and np.array_equal(_u32(vals), gold["vals"])
+    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), gold["offsets"])
+    assert np.array_equal(alias.cpu().numpy().view(np.uint64), gold["alias"])
+    assert np.array_equal(hub_bits.cpu().numpy().view(np.uint32), gold["hub_bits"])
+    tp = ops.train_params(0, 8, 4, 3, flags=1 | DET)
+    c = ops.init_table_rows(17, 8, 42, 0, 8 ** -0.5, 1, 2)
+    for part in range(4):
+        x = ops.init_table_rows((34 - part + 3) // 4, 8, 42, 1, 8 ** -0.5, part, 4)
+        ops.block_step(karate, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, 7, part, 42,
+                       0, 0.05)
+        assert np.abs(x.cpu().numpy() - gold[f"part{part}"]).max() < 1e-5
+    assert np.abs(c.cpu().numpy() - gold["central"]).max() < 1e-5
