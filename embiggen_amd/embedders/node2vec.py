@@ -105,6 +105,15 @@ class Node2VecEnsmallen(EnsmallenEmbedder):
         """Counters / kernel times of the last fit (engine extension, not in the reference)."""
         return self._model.last_stats
 
+    def set_distributed(self, comm) -> "Node2VecEnsmallen":
+        """Opt in to multi-GPU training (engine extension, not in the reference): ``comm`` is an
+        ``embiggen_amd.distributed.TorchComm`` over the job's process group (one process per
+        GPU); every rank must then make the same ``fit_transform`` call and receives the full
+        tables.  ``None`` switches back to this process's own device.  Models without a
+        multi-GPU path (CBOW, GloVe) ignore it."""
+        self._model.comm = comm
+        return self
+
     @classmethod
     def requires_edge_weights(cls) -> bool:
         return False

@@ -377,6 +377,15 @@ class _WalkletsModel:
             m.random_state = int(value)
 
     @property
+    def comm(self):
+        return getattr(self._scales[0], "comm", None)
+
+    @comm.setter
+    def comm(self, value):
+        for m in self._scales:
+            m.comm = value
+
+    @property
     def deterministic(self):
         return self._scales[0].deterministic
 

@@ -25,14 +25,14 @@ model = E.Node2VecSkipGramEnsmallen(embedding_size=16, epochs=3, walk_length=32,
                                     window_size=4, number_of_negative_samples=5,
                                     learning_rate=0.025, return_weight=1.0, explore_weight=1.0,
                                     verbose=False)
-model._model.comm = TorchComm()
+model.set_distributed(TorchComm())
 res = model.fit_transform(g, return_dataframe=False).get_all_node_embedding()
 np.save(os.path.join(out_dir, f"central{rank}.npy"), res[0])
 np.save(os.path.join(out_dir, f"contextual{rank}.npy"), res[1])
 # a model without a multi-GPU path inside the same job runs on its own device
 cbow = E.Node2VecCBOWEnsmallen(embedding_size=8, epochs=1, walk_length=8, iterations=1,
                                window_size=2, verbose=False)
-cbow._model.comm = model._model.comm
+cbow.set_distributed(model._model.comm)
 assert cbow.fit_transform(g, return_dataframe=False).get_all_node_embedding()[0].shape == (n, 8)
 dist.barrier()
 if rank == 0:
