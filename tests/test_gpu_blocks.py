@@ -536,3 +536,34 @@ def test_block_path_against_the_committed_golden_fixture(karate):
                        0, 0.05)
         assert np.abs(x.cpu().numpy() - gold[f"part{part}"]).max() < 1e-5
     assert np.abs(c.cpu().numpy() - gold["central"]).max() < 1e-5
+
+
+def test_gn2v_train_block_path_honours_the_model_options():
+    """The C++ block fit through the public classes on a 70 k-node graph: Walklets scales
+    (min_distance), centre down-sampling, degree-normalised learning rate, uniform negatives and a
+    walk budget all reach it."""
+    g = E.barabasi_albert(70_000, 5, 3)
+    n = g.get_number_of_nodes()
+    base = dict(embedding_size=16, epochs=2, iterations=1, walk_length=16, window_size=3,
+                verbose=False)
+    full = n * (2 * 3 * 16 - 3 * 4) * 2
+    m = E.models.SkipGram(**base)
+    m.fit_transform_device(g)
+    assert m.last_plan is not None and m.last_stats["pairs"] == full
+    m = E.models.SkipGram(stochastic_downsample_by_degree=True, **base)
+    c, x, st = m.fit_transform_device(g)
+    assert m.last_plan is not None and 0.3 * full < st["pairs"] < 0.95 * full
+    assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+    for extra in (dict(normalize_learning_rate_by_degree=True),
+                  dict(use_scale_free_distribution=False)):
+        m = E.models.SkipGram(**base, **extra)
+        c, x, st = m.fit_transform_device(g)
+        assert m.last_plan is not None and st["pairs"] == full and bool(torch.isfinite(x).all())
+    c, x, st = E.models.SkipGram(**base).fit_transform_device(g, max_walks_per_epoch=1000)
+    assert st["pairs"] == 1000 * (2 * 3 * 16 - 3 * 4) * 2
+    w = E.WalkletsSkipGramEnsmallen(embedding_size=24, epochs=1, iterations=1, walk_length=16,
+                                    window_size=3)
+    tabs = w.fit_transform(g, return_dataframe=False).get_all_node_embedding()
+    assert len(tabs) == 6 and all(t.shape == (n, 8) and np.isfinite(t).all() for t in tabs)
+    # scale s trains the pairs exactly s steps apart: 2 (L - s) per walk
+    assert w.get_last_stats()["pairs"] == n * sum(2 * (16 - s) for s in (1, 2, 3))
