@@ -520,3 +520,24 @@ def test_limits_are_reported_as_errors(karate):
     # empty batches are legal no-ops
     ops.sgns_step(karate, ops.train_params(0, 8, 5, 5), wk[:0, :8].contiguous(), 1, 0, 0, 0.01, c, x)
     assert ops.walks(karate, ops.walk_params(8, 1), 1, 0, 0, 0).shape == (0, 8)
+
+
+@pytest.mark.parametrize("k", [11, 14, 70])
+@pytest.mark.parametrize("mode", ["write_through_cache_all", "write_through_plain"])
+def test_cbow_sample_list_lengths_around_the_in_flight_limit(karate, karate_oracle, mode, k):
+    """CBOW scores its k + 1 output rows in flight when they fit three rounds (k + 1 <= 12) and no
+    row repeats, else through the serialising path; negatives are staged one per lane up to 63.
+    On Karate (34 nodes) the lists repeat rows all the time: 12 rows exactly, more than 12 and
+    more than 64 must all reproduce the oracle's sequential result, one walk per launch."""
+    d, w = 16, 3
+    wk = ops.walks(karate, ops.walk_params(20, 1, 4.0, 0.25), 5, 0, 0, 34)
+    wk_h = wk.cpu().numpy().view(np.uint32)
+    c, x = _tables(34, d, 5)
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    tp = ops.train_params(1, d, k, w, flags=1 | MODES[mode])
+    otp = O.TrainParams(1, d, d, 1, k, w, 0.01, 0.9, 6.0, 1, d ** -0.5)
+    for b in range(34):
+        ops.cbow_step(karate, tp, wk[b:b + 1].contiguous(), 5, 0, b, 0.05, c, x)
+    torch.cuda.synchronize()
+    O.train_walks(karate_oracle, otp, wk_h, 5, 0, 0, 0.05, c_h, x_h)
+    assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
