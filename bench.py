@@ -62,11 +62,13 @@ def parse():
     ap.add_argument("--parallelism", default="auto", choices=["auto", "single", "blocks"],
                     help="blocks (= auto): the block trainer, on one GPU too (contextual rows in "
                          "XCD-exclusive cells); single: the walk-ordered kernel, 1 GPU only")
-    ap.add_argument("--round-walks", type=int, default=1 << 22,
+    ap.add_argument("--round-walks", type=int, default=0,
                     help="blocks: walks per rank per round (every context part visits every rank "
                          "once per round; a round may span several steps: 2^22 walks = 84 GB of "
                          "sorted pairs + sort buffer, kernel 0.92 of the roofline against 0.82 at "
-                         "2^20)")
+                         "2^20).  0 = distributed.round_walks_within: 2^22 unless that exceeds "
+                         "three quarters of the free HBM (100 M nodes on 8 GPUs: 64-bit keys, two "
+                         "rounds in flight -> 2^21)")
     ap.add_argument("--parts", type=int, default=None,
                     help="blocks: context parts (default 1 on one GPU, 2 x world otherwise)")
     ap.add_argument("--slices", type=int, default=None,
@@ -86,7 +88,38 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: all ranks use GPU 0 (use with --backend gloo)")
+    ap.add_argument("--phantom-world", type=int, default=0,
+                    help="measurement aid, --gpus 1 only: run ONE rank of a world of this size "
+                         "with its true geometry (central stripe, travelling parts, pairs extracted "
+                         "from the walks of all ranks, two rounds in flight) and no fabric: the "
+                         "other ranks' walks are generated locally, a hop is a local copy.  Gives a "
+                         "rank's compute rate and HBM footprint at that world size; the line says "
+                         "'phantom' and is not the benchmark's value")
+    ap.add_argument("--phantom-rank", type=int, default=0)
     return ap.parse_args()
+
+
+class PhantomComm:
+    """One rank of a world of `world` ranks without peers (--phantom-world): the caller hands over
+    the walks of all ranks already concatenated, a part that leaves comes back as the part that
+    arrives (same size up to one row; the values are those of a trained part)."""
+
+    backend = "phantom"
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def all_gather(self, tensor):
+        return tensor
+
+    def sendrecv_start(self, send, dst, recv, src):
+        from embiggen_amd.distributed import _Done
+
+        rows = min(send.shape[0], recv.shape[0])
+        recv[:rows].copy_(send[:rows])
+        if recv.shape[0] > rows:
+            recv[rows:].copy_(send[: recv.shape[0] - rows])
+        return _Done()
 
 
 def usable_cores() -> int:
@@ -236,11 +269,17 @@ def main():
         raise SystemExit("--parallelism single needs --gpus 1")
     if mode == "blocks" and cbow:
         raise SystemExit("the block-partitioned trainer is SkipGram only")
+    phantom = args.phantom_world > 1
+    if phantom and (world > 1 or mode != "blocks"):
+        raise SystemExit("--phantom-world needs --gpus 1 and the block trainer")
     blocks = comm = None
-    overlap = args.overlap == "on" or (args.overlap == "auto" and world > 1)
+    overlap = args.overlap == "on" or (args.overlap == "auto" and (world > 1 or phantom))
+    # the trainer's view of the job (a phantom rank sees the world it stands in for)
+    t_rank, t_world = (args.phantom_rank, args.phantom_world) if phantom else (rank, world)
     if mode == "blocks":
         # tables partitioned by node id; no row is ever held by two GPUs
-        comm = TorchComm() if world > 1 else LoopbackComm()
+        comm = (PhantomComm(t_rank, t_world) if phantom
+                else TorchComm() if world > 1 else LoopbackComm())
         blocks = BlockPartitionedTrainer(graph, tp, d, ld, 42, d ** -0.5, comm, f"cuda:{local}",
                                          walk_length=128, window=5, parts=args.parts,
                                          slices=args.slices, record=args.record,
@@ -248,6 +287,17 @@ def main():
     else:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local, ld=ld)
+
+    if blocks is not None and not args.round_walks:
+        from embiggen_amd.distributed import round_walks_within
+
+        torch.cuda.empty_cache()  # what building the graph left in the allocator's cache
+        args.round_walks = round_walks_within(torch.cuda.mem_get_info()[0], 128, 5,
+                                              blocks.plan.key_bits, t_world, overlap)
+        if world > 1:  # every rank the same round size
+            agreed = torch.tensor([args.round_walks], dtype=torch.int64, device="cuda")
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            args.round_walks = int(agreed)
 
     def block_rounds(offset, total):
         """(make_walks, seed, epoch, lr, first_walk) of the rounds that train this rank's walks
@@ -257,9 +307,11 @@ def main():
         out, done = [], 0
         while done < total:
             nw = min(args.round_walks, total - done)
-            first = (offset + done) * world
+            first = (offset + done) * t_world
 
             def make(first=first, nw=nw):
+                if phantom:  # the walks of every rank of the round, as the all-gather returns them
+                    return ops.walks(graph, wp, 42, 0, first, t_world * nw, device=local)
                 return ops.walks(graph, wp, 42, 0, first + rank * nw, nw, device=local)
 
             out.append((make, 42, 0, 0.01, first))
@@ -339,11 +391,13 @@ def main():
     total_pairs, total_steps, total_centres = (float(x) for x in counts)
 
     if rank == 0:
+        def finite(table):  # in slabs: isfinite of a 51 GB table would allocate as much again
+            return all(bool(torch.isfinite(slab).all()) for slab in table.split(1 << 20))
+
         if blocks is not None:
-            ok = bool(torch.isfinite(blocks.central).all()) and all(
-                bool(torch.isfinite(t).all()) for t in blocks.held.values())
+            ok = finite(blocks.central) and all(finite(t) for t in blocks.held.values())
         else:
-            ok = bool(torch.isfinite(central).all()) and bool(torch.isfinite(contextual).all())
+            ok = finite(central) and finite(contextual)
         launches = max(st["train_launches"], 1)
         launch_ms = st["train_ms"] / launches
         if cbow:
@@ -388,7 +442,7 @@ def main():
                 "walks_per_launch": args.batch if blocks is None else None,
                 "parallelism": {
                     "single": "1 GPU, walk-ordered kernel",
-                    "blocks": f"{world} GPU(s), central table striped over the ranks, contextual "
+                    "blocks": f"{t_world} GPU(s), central table striped over the ranks, contextual "
                               f"table in {blocks.parts if blocks else 0} travelling parts x "
                               f"{blocks.slices if blocks else 0} XCD slice(s) (no shared rows), rounds of "
                               f"{min(args.round_walks, args.steps * args.walks)} walks per GPU, preparation "
@@ -415,6 +469,17 @@ def main():
         }
         if comm_info is not None:
             line["distributed"] = comm_info
+        line["hbm_peak_gb"] = {"torch_allocated": torch.cuda.max_memory_allocated() / 1e9,
+                               "torch_reserved": torch.cuda.max_memory_reserved() / 1e9,
+                               "device_in_use_now": (lambda f, t: (t - f) / 1e9)(*torch.cuda.mem_get_info())}
+        if phantom:
+            line["metric"] = "PHANTOM RANK (not the benchmark value): " + line["metric"]
+            line["phantom"] = {
+                "world": t_world, "rank": t_rank,
+                "pairs_this_rank": st["pairs"],
+                "walk_steps_generated_here_for_all_ranks": st["walk_steps"],
+                "note": "one rank of that world on one GPU, no fabric: value = this rank's pairs/s; "
+                        "the walks of all ranks are generated here (in a real job 1/world of them)"}
         pmc = committed_traffic(line["config"], args.mode)
         if pmc is not None:
             bytes_per_launch, source = pmc
@@ -422,7 +487,7 @@ def main():
             line["roofline"]["traffic_bytes_per_launch"] = bytes_per_launch
             line["roofline"]["traffic_source"] = f"profiles/{source} (rocprofv3 --pmc FETCH_SIZE / " \
                                                  "WRITE_SIZE, calibrated; same workload)"
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not phantom:
             if blocks is not None:
                 central, contextual = blocks.gather_full()
             line["cpu_baseline"] = cpu_baseline(graph, args, central, contextual, args.cpu_seconds)

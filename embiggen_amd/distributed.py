@@ -41,7 +41,23 @@ def stripe_rows(n: int, first: int, stride: int) -> int:
     return (n - first + stride - 1) // stride if n > first else 0
 
 
+PAIR_ROOM = 1 << 24  # pair buffers are sized in steps of this many pairs
 MIN_ROWS_PER_CELL = 32768
+
+
+def round_walks_within(free_bytes: int, walk_length: int, window: int, key_bits: int, world: int,
+                       overlap: bool, most: int = 1 << 22, fraction: float = 0.75) -> int:
+    """Walks per rank and round: the longer a round, the more pairs of a centre meet in a cell (the
+    centre row is read once per such run), so up to ``most`` (2^22) -- in powers of two, within
+    ``fraction`` of the HBM that is free once tables and graph are resident.  Per pair: key + 4 B
+    value, held by the round that trains, and twice (radix sort double buffer) by the round in
+    preparation; plus the gathered walks.  Every rank must use the same value (take the min)."""
+    w, L = window, walk_length
+    pairs = 2 * w * L - w * (w + 1)
+    per_walk = pairs * (key_bits // 8 + 4) * (3 if overlap else 2)
+    per_walk += 4 * L * (world + 1) * (2 if overlap else 1)
+    fit = max(1, int(free_bytes * fraction) // per_walk)
+    return max(1 << 14, min(most, 1 << (fit.bit_length() - 1)))
 
 
 def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:
@@ -173,11 +189,22 @@ class GpuBlockBackend:
         """-> (keys, vals, cell_offsets, n_pairs); one host read (the pair count)."""
         from . import ops
 
+        import torch
+
         work, offsets = ops.block_count(self.graph, plan, walks_all, seed, epoch, first_walk)
         n_pairs = int(offsets[-1])
-        keys, vals = ops.block_extract(self.graph, plan, walks_all, seed, epoch, first_walk, work,
-                                       n_pairs, hub_bits=hub_bits)
-        return keys, vals, offsets, n_pairs
+        # buffers in steps of 2^24 pairs: the rounds of a fit differ by a fraction of a percent, so
+        # the caching allocator hands the blocks of round t - 2 to round t instead of growing
+        room = max(1, -(-n_pairs // PAIR_ROOM)) * PAIR_ROOM
+        dev = walks_all.device
+        keys = torch.empty(room, dtype=torch.int64 if plan.key_bits == 64 else torch.int32,
+                           device=dev)
+        vals = torch.empty(room, dtype=torch.int32, device=dev)
+        temp = torch.empty(ops.block_extract_temp_bytes(room, plan.key_bits), dtype=torch.uint8,
+                           device=dev)
+        ops.block_extract(self.graph, plan, walks_all, seed, epoch, first_walk, work, n_pairs,
+                          keys=keys, vals=vals, temp=temp, hub_bits=hub_bits)
+        return keys[:n_pairs], vals[:n_pairs], offsets, n_pairs
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
              epoch, lr):
@@ -301,12 +328,13 @@ class BlockPartitionedTrainer:
         if not rounds:
             return
         on_gpu = isinstance(self.backend, GpuBlockBackend)
-        overlap = overlap and on_gpu and len(rounds) > 1
+        overlap = overlap and on_gpu  # a single round too: one allocator pool for all rounds
         make, seed, epoch, lr, first = rounds[0]
-        prepared = self.prepare(make(), seed, epoch, first)
         if not overlap:
+            prepared = self.prepare(make(), seed, epoch, first)
             for t, (_, seed, epoch, lr, _) in enumerate(rounds):
                 self.train_prepared(prepared, seed, epoch, lr)
+                prepared = None  # round t's pairs go back to the allocator before t + 1 is built
                 if t + 1 < len(rounds):
                     make, nseed, nepoch, _, nfirst = rounds[t + 1]
                     prepared = self.prepare(make(), nseed, nepoch, nfirst)
@@ -316,6 +344,13 @@ class BlockPartitionedTrainer:
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(dev)
         side, before = self._side, None
+        # every preparation on the side stream, the first one too: the allocator keeps one pool of
+        # freed blocks per stream, and ~100 GB of pair buffers must come back to the pool that the
+        # next preparation allocates from
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            prepared = self.prepare(make(), seed, epoch, first)
+        main.wait_stream(side)
         for t, (_, seed, epoch, lr, _) in enumerate(rounds):
             self.train_prepared(prepared, seed, epoch, lr)
             done = torch.cuda.Event()

@@ -232,7 +232,7 @@ class _WalkBasedModel:
         import torch
 
         from . import ops
-        from .distributed import BlockPartitionedTrainer
+        from .distributed import BlockPartitionedTrainer, round_walks_within
 
         if self.MODEL_ID != _lib.MODEL_SKIPGRAM:
             raise NotImplementedError(
@@ -257,13 +257,12 @@ class _WalkBasedModel:
             if max_walks_per_epoch:
                 walks_per_epoch = min(walks_per_epoch, max_walks_per_epoch)
             if round_walks is None:
-                # the longer a round, the more pairs of a centre meet in a cell (the centre row is
-                # read once per such run): up to 2^22 walks per rank, within a third of the free
-                # HBM (16 B per pair while the sort runs + the gathered walks)
-                w = self.window_size
-                per_walk = (2 * w * L - w * (w + 1)) * 16 + 4 * L * comm.world
-                free = torch.cuda.mem_get_info(dev)[0]
-                round_walks = max(1 << 14, min(1 << 22, free // 3 // per_walk))
+                # the full tables every rank returns must fit beside the last rounds
+                torch.cuda.empty_cache()
+                result = (2 if comm.world > 1 else 1) * trainer.n_nodes * self.padded_size * 4
+                round_walks = round_walks_within(
+                    max(0, torch.cuda.mem_get_info(dev)[0] - result), L, self.window_size,
+                    trainer.plan.key_bits, comm.world, overlap)
                 if comm.world > 1:  # every rank must use the same round size
                     mine = torch.tensor([round_walks], dtype=torch.int64, device=dev)
                     round_walks = int(comm.all_gather(mine).min())
