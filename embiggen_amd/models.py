@@ -17,6 +17,9 @@ import numpy as np
 from . import _lib
 from .graph import CSRGraph
 
+# `dtype` argument of the reference's wrappers (node2vec_skipgram.py:32,103-104) -> torch dtype name
+_RESULT_DTYPES = {"f16": "float16", "f32": "float32", "f64": "float64"}
+
 
 def _as_csr(graph, normalize_by_degree: bool = False) -> CSRGraph:
     if normalize_by_degree:
@@ -81,8 +84,11 @@ class _WalkBasedModel:
             raise ValueError("return_weight and explore_weight must be strictly positive.")
         if not clipping_value > 0:
             raise ValueError("clipping_value must be strictly positive.")
-        if dtype != "f32":
-            raise ValueError(f"Only dtype 'f32' is supported by the gn2v engine, got {dtype!r}.")
+        if dtype not in _RESULT_DTYPES:
+            raise ValueError(
+                f"dtype must be one of {sorted(_RESULT_DTYPES)}, got {dtype!r} (the engine always "
+                "computes in f32; 'f16' / 'f64' convert the returned tables).")
+        self.dtype = dtype
         if not (change_node_type_weight > 0 and change_edge_type_weight > 0):
             raise ValueError(
                 "change_node_type_weight and change_edge_type_weight must be strictly positive.")
@@ -325,14 +331,22 @@ class _WalkBasedModel:
             central, contextual = self.fit_transform_blocks(graph, comm)
         if central is None:
             central, contextual, _ = self.fit_transform_device(graph)
+        return self._download(central, contextual)
+
+    def _download(self, central, contextual) -> List[np.ndarray]:
+        """Device tables [N, padded] f32 -> host arrays [N, d] of the model's ``dtype`` (converted
+        on the device, so an f16 result crosses PCIe at half the size)."""
+        import torch
+
         d = self.embedding_size
+        as_type = getattr(torch, _RESULT_DTYPES[self.dtype])
         out = []
         for tensor, path in ((central, self.central_nodes_embedding_path),
                              (contextual, self.contextual_nodes_embedding_path)):
-            host = tensor[:, :d].contiguous().cpu().numpy()
+            host = tensor[:, :d].to(as_type).contiguous().cpu().numpy()
             if path is not None:
                 os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-                mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32,
+                mm = np.lib.format.open_memmap(path, mode="w+", dtype=host.dtype,
                                                shape=host.shape)
                 mm[:] = host
                 mm.flush()

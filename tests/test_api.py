@@ -105,8 +105,9 @@ def test_kwarg_coercion_and_errors():
     with pytest.raises(ValueError):  # stochastic model without seed (abstract_model.py:41-48)
         E.embedders.EnsmallenEmbedder.__init__(E.Node2VecSkipGramEnsmallen.__new__(
             E.Node2VecSkipGramEnsmallen), random_state=None, embedding_size=4)
-    with pytest.raises(ValueError):
-        E.Node2VecSkipGramEnsmallen(dtype="f16")
+    with pytest.raises(ValueError):  # f16 / f32 / f64 are the data types there are
+        E.Node2VecSkipGramEnsmallen(dtype="bf16")
+    assert E.Node2VecSkipGramEnsmallen(dtype="f16").parameters()["dtype"] == "f16"
 
 
 def test_walklets_split_the_embedding_size_per_scale():

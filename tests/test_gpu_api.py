@@ -35,6 +35,26 @@ def test_result_order_skipgram_vs_cbow(karate):
     assert np.array_equal(s0, c1) and np.array_equal(s1, c0)  # zero epochs: just the init
 
 
+@pytest.mark.parametrize("dtype,np_type,tol", [("f16", np.float16, 1e-3), ("f64", np.float64, 0)])
+def test_result_data_types(karate, tmp_path, dtype, np_type, tol):
+    """`dtype` (node2vec_skipgram.py:32,103-104): the engine computes in f32, the returned tables
+    (and the memmaps of the *_embedding_path arguments) have the requested type and are the f32
+    result converted."""
+    kw = dict(embedding_size=8, epochs=1, walk_length=8, iterations=1, verbose=False)
+    path = str(tmp_path / f"central_{dtype}.npy")
+    ref = E.Node2VecSkipGramEnsmallen(**kw)
+    got = E.Node2VecSkipGramEnsmallen(dtype=dtype, central_nodes_embedding_path=path, **kw)
+    ref._model.deterministic = got._model.deterministic = True
+    a = ref.fit_transform(karate, return_dataframe=False).get_all_node_embedding()
+    b = got.fit_transform(karate, return_dataframe=False).get_all_node_embedding()
+    for x, y in zip(a, b):
+        assert y.dtype == np_type and y.shape == x.shape
+        assert np.abs(y.astype(np.float64) - x.astype(np.float64)).max() <= tol
+    assert np.load(path).dtype == np_type and np.array_equal(np.load(path), b[0])
+    frames = got.fit_transform(karate).get_all_node_embedding()
+    assert all(str(f.dtypes.iloc[0]) == np.dtype(np_type).name for f in frames)
+
+
 def test_fit_is_reusable_and_seeded(karate):
     m = E.Node2VecSkipGramEnsmallen(embedding_size=8, epochs=1, walk_length=8, iterations=1,
                                     verbose=False)
