@@ -265,8 +265,9 @@ def main():
     mode = args.parallelism
     if mode == "auto":
         mode = "single" if cbow else "blocks"
-    if mode == "single" and world > 1:
+    if mode == "single" and world > 1 and not cbow:
         raise SystemExit("--parallelism single needs --gpus 1")
+    replicas = mode == "single" and world > 1  # CBOW does not shard: N independent fits
     if mode == "blocks" and cbow:
         raise SystemExit("the block-partitioned trainer is SkipGram only")
     phantom = args.phantom_world > 1
@@ -361,6 +362,12 @@ def main():
         per_rank_pairs = [int(t[0]) for t in gathered]
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    if replicas:
+        comm_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "per_rank_pairs": per_rank_pairs,
+                     "note": "replicas only: every rank trains its own tables on its own walk ids; "
+                             "nothing is exchanged inside the timed region"}
+    elif world > 1:
         # the two exchanges of a round, timed alone after the measured region (they overlap with
         # training inside it): the all-gather of one round's walks and one half-partition hop
         wk = torch.zeros((min(args.round_walks, args.steps * args.walks), 128), dtype=torch.int32,
@@ -441,7 +448,8 @@ def main():
                 "update_mode": args.mode,
                 "walks_per_launch": args.batch if blocks is None else None,
                 "parallelism": {
-                    "single": "1 GPU, walk-ordered kernel",
+                    "single": (f"{world} independent replicas (CBOW does not shard), walk-ordered "
+                               "kernel" if replicas else "1 GPU, walk-ordered kernel"),
                     "blocks": f"{t_world} GPU(s), central table striped over the ranks, contextual "
                               f"table in {blocks.parts if blocks else 0} travelling parts x "
                               f"{blocks.slices if blocks else 0} XCD slice(s) (no shared rows), rounds of "

@@ -86,3 +86,28 @@ def test_two_rank_line_through_torch_distributed_run():
     assert dd["walk_allgather_ms_alone"] > 0 and dd["half_partition_hop_ms_alone"] > 0
     pairs = 2 * 2 * 8192 * 1250  # steps x ranks x walks x pairs per walk: the whole-job aggregate
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - pairs) < 1e-3 * pairs
+
+
+def test_cbow_runs_as_independent_replicas_on_two_ranks():
+    """CBOW does not shard: `bench.py --model cbow --gpus N` is N independent fits,
+    the line adds their centres and says "replicas"."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--model", "cbow", "--nodes", "200000", "--walks", "8192", "--backend", "gloo",
+           "--share-device"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["unit"] == "centres/s" and d["finite"] is True
+    assert "2 independent replicas" in d["config"]["parallelism"]
+    assert d["distributed"]["world_size"] == 2 and "replicas only" in d["distributed"]["note"]
+    centres = 2 * 2 * 8192 * 128  # steps x ranks x walks x positions
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - centres) < 1e-3 * centres
