@@ -66,9 +66,10 @@ def parse():
                     help="blocks: walks per rank per round (every context part visits every rank "
                          "once per round; a round may span several steps: 2^22 walks = 84 GB of "
                          "sorted pairs + sort buffer, kernel 0.92 of the roofline against 0.82 at "
-                         "2^20).  0 = distributed.round_walks_within: 2^22 unless that exceeds "
-                         "three quarters of the free HBM (100 M nodes on 8 GPUs: 64-bit keys, two "
-                         "rounds in flight -> 2^21)")
+                         "2^20, 0.96 at 2^23).  0 = gn2v_block_round_walks: the largest power of "
+                         "two <= 2^23 whose pair buffers fit three quarters of the free HBM (bench "
+                         "graph: 2^23 on one GPU, 2^22 with two rounds in flight on several; "
+                         "100 M nodes, 64-bit keys: 2^21)")
     ap.add_argument("--parts", type=int, default=None,
                     help="blocks: context parts (default 1 on one GPU, 2 x world otherwise)")
     ap.add_argument("--slices", type=int, default=None,
@@ -343,6 +344,7 @@ def main():
 
     run_steps(0, args.warmup)
     fence()
+    torch.cuda.empty_cache()  # the warm-up's round buffers (another size than the timed rounds')
     ops.stats_reset(graph, local)
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps)

@@ -42,7 +42,8 @@ EXPORTS = [
     "gn2v_touch_rows",
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
     "gn2v_block_alias", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
-    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_auto_plan", "gn2v_train_blocks",
+    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_auto_plan", "gn2v_block_round_walks",
+    "gn2v_train_blocks",
     "gn2v_stats_reset",
     "gn2v_stats_read",
 ]
@@ -226,6 +227,7 @@ def lib():
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),
                                   C.POINTER(BlockIO), u64, u64, f32, vp]
     L.gn2v_block_auto_plan.argtypes = [u64, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.gn2v_block_round_walks.argtypes = [u64, u32, u32, u32, u32, u32, C.POINTER(u64)]
     L.gn2v_train_blocks.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,
                                     u64, vp, vp, C.POINTER(Stats), vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]

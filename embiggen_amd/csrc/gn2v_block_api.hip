@@ -440,6 +440,22 @@ int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t *parts, uint
 }
 
 
+int gn2v_block_round_walks(uint64_t free_bytes, uint32_t walk_length, uint32_t window,
+                           uint32_t key_bits, uint32_t world, uint32_t overlap,
+                           uint64_t *round_walks) {
+    if (!round_walks || walk_length < 2 || window < 1 || world < 1 ||
+        (key_bits != 32 && key_bits != 64))
+        return fail("bad arguments");
+    const uint64_t L = walk_length, pairs = 2ull * window * L;  // upper bound (window untrimmed)
+    uint64_t per_walk = pairs * (key_bits / 8 + 4) * (overlap ? 3 : 2);
+    per_walk += 4 * L * (world + 1ull) * (overlap ? 2 : 1);
+    const uint64_t fit = free_bytes / 4 * 3 / per_walk;
+    uint64_t r = 1ull << 14;
+    while (r * 2 <= fit && r < (1ull << 23)) r *= 2;
+    *round_walks = r;
+    return 0;
+}
+
 int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
                       uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
                       float *d_central, float *d_contextual, gn2v_stats *stats, void *stream) {
@@ -498,12 +514,11 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
                                  tp->d, ld, seed, 1, tp->init_scale, p, parts, s))
             return 1;
 
-    // round size: the longer, the more pairs of a centre meet in a cell; a third of the free HBM
+    // round size: the longer, the more pairs of a centre meet in a cell
     if (round_walks == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t per_walk = pairs_per_walk * (2 * key_bytes + 8) + 4ull * L;
-        round_walks = std::max<uint64_t>(1 << 14, std::min<uint64_t>(1 << 22, free_b / 3 / per_walk));
+        if (gn2v_block_round_walks(free_b, L, w, plan.key_bits, 1, 0, &round_walks)) return 1;
     }
     round_walks = std::max<uint64_t>(1, std::min(round_walks, walks_per_epoch));
     const uint64_t cap = round_walks * pairs_per_walk;

@@ -46,18 +46,18 @@ MIN_ROWS_PER_CELL = 32768
 
 
 def round_walks_within(free_bytes: int, walk_length: int, window: int, key_bits: int, world: int,
-                       overlap: bool, most: int = 1 << 22, fraction: float = 0.75) -> int:
-    """Walks per rank and round: the longer a round, the more pairs of a centre meet in a cell (the
-    centre row is read once per such run), so up to ``most`` (2^22) -- in powers of two, within
-    ``fraction`` of the HBM that is free once tables and graph are resident.  Per pair: key + 4 B
-    value, held by the round that trains, and twice (radix sort double buffer) by the round in
-    preparation; plus the gathered walks.  Every rank must use the same value (take the min)."""
-    w, L = window, walk_length
-    pairs = 2 * w * L - w * (w + 1)
-    per_walk = pairs * (key_bits // 8 + 4) * (3 if overlap else 2)
-    per_walk += 4 * L * (world + 1) * (2 if overlap else 1)
-    fit = max(1, int(free_bytes * fraction) // per_walk)
-    return max(1 << 14, min(most, 1 << (fit.bit_length() - 1)))
+                       overlap: bool) -> int:
+    """Walks per rank and round for ``free_bytes`` of HBM (``gn2v_block_round_walks``: the largest
+    power of two <= 2^23 whose pair buffers -- held once by the round in training, twice by the
+    round being built -- fit three quarters of it).  Every rank must use the same value."""
+    import ctypes as C
+
+    from . import _lib
+
+    out = C.c_uint64()
+    _lib.check(_lib.lib().gn2v_block_round_walks(int(free_bytes), walk_length, window, key_bits,
+                                                 world, int(bool(overlap)), C.byref(out)))
+    return out.value
 
 
 def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:

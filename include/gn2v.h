@@ -311,9 +311,21 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
  * walk-ordered schedule's. */
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t *parts, uint32_t *slices);
 
+/* Walks per rank and round for `free_bytes` of HBM (what is free once tables and graph are
+ * resident): the longer a round, the more pairs of a centre meet in a cell (its row is read once
+ * per such run: kernel 0.82 / 0.92 / 0.96 of the roofline at 2^20 / 2^22 / 2^23 walks on the bench
+ * graph), so the largest power of two <= 2^23 (>= 2^14) whose pair buffers fit three quarters of
+ * free_bytes.  Per pair key_bits / 8 + 4 bytes, held once by the round in training and twice
+ * (radix sort double buffer) by the round being built: x 2 in line, x 3 with `overlap` (a second
+ * round prepared while the first trains); plus the walks of all `world` ranks.  Pure host
+ * function; every rank of a job must use the same value (take the minimum). */
+int gn2v_block_round_walks(uint64_t free_bytes, uint32_t walk_length, uint32_t window,
+                           uint32_t key_bits, uint32_t world, uint32_t overlap,
+                           uint64_t *round_walks);
+
 /* The whole fit (same contract as gn2v_train: caller-allocated tables f32[n_nodes][ld], filled on
  * return) through the block path on one GPU: automatic plan, alias tables, rounds of
- * `round_walks` walks (0 = automatic: up to 2^22, within a third of the free HBM), per round walk
+ * `round_walks` walks (0 = automatic: gn2v_block_round_walks of the free HBM), per round walk
  * generation, pair extraction + sort and one gn2v_block_step per part.  The central table is
  * trained in place; the contextual table lives in `parts` buffers of the library's own during
  * the fit and is written to d_contextual at the end.  gn2v_train calls this for SkipGram on

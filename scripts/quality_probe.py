@@ -54,6 +54,7 @@ if __name__ == "__main__":
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--modes", default="write_through,write_back,atomic")
     ap.add_argument("--hot-band", default="0:0", help="blocks modes: lo:hi (see bench.py)")
+    ap.add_argument("--round-walks", type=int, default=1 << 19, help="blocks modes: walks per round")
     a = ap.parse_args()
     g = E.barabasi_albert(a.nodes, a.m, 42)
     n, d = g.get_number_of_nodes(), a.d
@@ -80,12 +81,12 @@ if __name__ == "__main__":
             t0 = time.time()
             lr, rounds = a.lr, []
             for e in range(a.epochs):
-                for first in range(0, a.walks, 1 << 19):
-                    nb = min(1 << 19, a.walks - first)
+                for first in range(0, a.walks, a.round_walks):
+                    nb = min(a.round_walks, a.walks - first)
                     rounds.append((lambda e=e, first=first, nb=nb: ops.walks(g, wp, 42, e, first, nb),
                                    42, e, lr, first))
                 lr *= 0.9
-            tr.run(rounds)
+            tr.run(rounds, overlap=False)
             c, x = tr.gather_full()
             st = ops.stats_read(g)
             gen.manual_seed(1)

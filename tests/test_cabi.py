@@ -72,27 +72,29 @@ def test_automatic_plan_of_the_block_path():
 
 
 def test_round_size_follows_the_free_memory():
-    """distributed.round_walks_within: 2^22 walks when they fit three quarters of the free HBM
-    (key + value per pair, x 2 while the sort runs, x 3 with a second round in preparation, plus
-    the gathered walks), powers of two below that, never under 2^14."""
+    """gn2v_block_round_walks (pure host function): the largest power of two <= 2^23 whose pair
+    buffers fit three quarters of the free HBM (key + value per pair, x 2 while the sort runs, x 3
+    with a second round in preparation, plus the gathered walks), never under 2^14."""
     from embiggen_amd.distributed import round_walks_within
 
     GB = 10 ** 9
     # the bench graph: 32-bit keys, one GPU in line, eight GPUs with two rounds in flight
-    assert round_walks_within(277 * GB, 128, 5, 32, 1, False) == 1 << 22
+    assert round_walks_within(277 * GB, 128, 5, 32, 1, False) == 1 << 23
     assert round_walks_within(282 * GB, 128, 5, 32, 8, True) == 1 << 22
     # 100 M nodes: 64-bit keys
-    assert round_walks_within(176 * GB, 128, 5, 64, 1, False) == 1 << 22
+    assert round_walks_within(176 * GB, 128, 5, 64, 1, False) == 1 << 21
     assert round_walks_within(266 * GB, 128, 5, 64, 8, True) == 1 << 21
     assert round_walks_within(40 * GB, 128, 5, 32, 1, False) == 1 << 20
     assert round_walks_within(0, 128, 5, 32, 1, False) == 1 << 14
-    for free in (GB, 10 * GB, 100 * GB):
+    for free in (GB, 10 * GB, 100 * GB, 10 ** 13):
         for world, overlap in ((1, False), (2, True), (8, True)):
             for key_bits in (32, 64):
                 n = round_walks_within(free, 128, 5, key_bits, world, overlap)
-                assert n & (n - 1) == 0
-                need = n * 1250 * (key_bits // 8 + 4) * (3 if overlap else 2)
+                assert n & (n - 1) == 0 and (1 << 14) <= n <= (1 << 23)
+                need = n * 1280 * (key_bits // 8 + 4) * (3 if overlap else 2)
                 assert n == 1 << 14 or need <= 0.75 * free
+    with pytest.raises(RuntimeError):
+        round_walks_within(GB, 128, 5, 48, 1, False)
 
 
 def test_errors_are_reported_not_thrown():
