@@ -515,22 +515,34 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
             return 1;
 
     // round size: the longer, the more pairs of a centre meet in a cell
-    if (round_walks == 0) {
+    const bool automatic = round_walks == 0;
+    if (automatic) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         if (gn2v_block_round_walks(free_b, L, w, plan.key_bits, 1, 0, &round_walks)) return 1;
     }
     round_walks = std::max<uint64_t>(1, std::min(round_walks, walks_per_epoch));
-    const uint64_t cap = round_walks * pairs_per_walk;
     uint32_t *walks = nullptr, *vals = nullptr;
     void *keys = nullptr, *tmp = nullptr;
     uint64_t *work = nullptr, *cell_offsets = nullptr;
     uint64_t tb = 0;
-    gn2v_block_extract_temp_bytes(cap, plan.key_bits, &tb);
-    if (buf.alloc(&walks, round_walks * L * 4) || buf.alloc(&keys, cap * key_bytes) ||
-        buf.alloc(&vals, cap * 4) || buf.alloc(&tmp, tb) ||
-        buf.alloc(&work, GN2V_BLOCK_WORK_WORDS * 8) || buf.alloc(&cell_offsets, (cells + 1) * 8))
+    if (buf.alloc(&work, GN2V_BLOCK_WORK_WORDS * 8) || buf.alloc(&cell_offsets, (cells + 1) * 8))
         return 1;
+    const size_t held = buf.ptrs.size();
+    for (;;) {
+        const uint64_t cap = round_walks * pairs_per_walk;
+        gn2v_block_extract_temp_bytes(cap, plan.key_bits, &tb);
+        if (!(buf.alloc(&walks, round_walks * L * 4) || buf.alloc(&keys, cap * key_bytes) ||
+              buf.alloc(&vals, cap * 4) || buf.alloc(&tmp, tb)))
+            break;
+        // somebody else took the memory between the query and here: an automatic size halves
+        while (buf.ptrs.size() > held) {
+            (void)hipFree(buf.ptrs.back());
+            buf.ptrs.pop_back();
+        }
+        if (!automatic || round_walks <= (1u << 14)) return 1;
+        round_walks /= 2;
+    }
 
     float lr = tp->lr;
     uint64_t round_id = 0;
@@ -543,7 +555,8 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
             uint64_t n_pairs = 0;  // the one host read of the round
             HIP_TRY(hipMemcpyAsync(&n_pairs, cell_offsets + cells, 8, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            if (n_pairs > cap) return fail("internal: more pairs than the round's capacity");
+            if (n_pairs > round_walks * pairs_per_walk)
+                return fail("internal: more pairs than the round's capacity");
             if (n_pairs == 0) continue;
             if (gn2v_block_extract(g, &plan, walks, nw, seed, e, first, work, hub_bits, n_pairs,
                                    keys, vals, tmp, tb, s))

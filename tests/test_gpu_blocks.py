@@ -567,3 +567,27 @@ def test_gn2v_train_block_path_honours_the_model_options():
     assert len(tabs) == 6 and all(t.shape == (n, 8) and np.isfinite(t).all() for t in tabs)
     # scale s trains the pairs exactly s steps apart: 2 (L - s) per walk
     assert w.get_last_stats()["pairs"] == n * sum(2 * (16 - s) for s in (1, 2, 3))
+
+
+def test_round_size_shrinks_with_the_free_memory():
+    """The automatic round size follows what is free on the device when the fit starts
+    (gn2v_block_round_walks): with all but ~6 GB of the HBM taken, a fit whose epoch would need
+    8.5 GB of pair buffers in one round runs in several smaller rounds and trains every pair."""
+    g = E.barabasi_albert(200_000, 5, 5)
+    n = g.get_number_of_nodes()
+    kw = dict(embedding_size=32, epochs=1, iterations=2, walk_length=128, window_size=5,
+              verbose=False)
+    g.device_graph(0)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info()[0]
+    hog = torch.empty(free - (6 << 30), dtype=torch.uint8, device="cuda")
+    try:
+        m = E.models.SkipGram(**kw)
+        c, x, st = m.fit_transform_device(g)
+        assert m.last_plan is not None
+        assert st["pairs"] == 2 * n * 1250 and st["train_launches"] > m.last_plan["parts"]
+        assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+    finally:
+        del hog
+        torch.cuda.empty_cache()
