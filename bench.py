@@ -140,7 +140,7 @@ def usable_cores() -> int:
 
 
 def committed_traffic(config, update_mode):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    """(HBM bytes per algorithmic byte, file) of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/*_pmc.json, made by scripts/profile_bench.sh + summarize_profiles.py) when they were
     taken on this very workload; None otherwise (counters cannot be read from inside the run)."""
     import glob
@@ -156,7 +156,10 @@ def committed_traffic(config, update_mode):
                 and rec.get("config", {}).get("parallelism") == config["parallelism"]
                 and rec.get("config", {}).get("update_mode") == update_mode)
         if same:
-            best = (rec["hbm_traffic_bytes_per_launch"], os.path.basename(path))
+            # per algorithmic byte, so that launches of another size (a run whose steps do not
+            # fill whole rounds) are priced by what they process
+            best = (rec["hbm_traffic_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"],
+                    os.path.basename(path))
     return best
 
 
@@ -301,6 +304,10 @@ def main():
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
             args.round_walks = int(agreed)
 
+    if blocks is not None:
+        # warm-up and timed rounds share their buffers (a phantom rank is handed all ranks' walks)
+        blocks.round_capacity = args.round_walks * (t_world if phantom else 1)
+
     def block_rounds(offset, total):
         """(make_walks, seed, epoch, lr, first_walk) of the rounds that train this rank's walks
         [offset, offset + total) of the run: rounds of --round-walks walks per rank (a round may
@@ -342,14 +349,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def memlog(tag):
+        if os.environ.get("GN2V_BENCH_MEMLOG"):
+            print(f"[mem] {tag}: allocated {torch.cuda.memory_allocated() / 1e9:.1f} GB, reserved "
+                  f"{torch.cuda.memory_reserved() / 1e9:.1f} GB, peak allocated "
+                  f"{torch.cuda.max_memory_allocated() / 1e9:.1f} GB", file=sys.stderr, flush=True)
+
+    memlog("before warm-up")
     run_steps(0, args.warmup)
     fence()
-    torch.cuda.empty_cache()  # the warm-up's round buffers (another size than the timed rounds')
+    memlog("after warm-up")
     ops.stats_reset(graph, local)
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    memlog("after the timed steps")
     st = ops.stats_read(graph, local)
 
     times = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -492,8 +507,10 @@ def main():
                         "the walks of all ranks are generated here (in a real job 1/world of them)"}
         pmc = committed_traffic(line["config"], args.mode)
         if pmc is not None:
-            bytes_per_launch, source = pmc
+            ratio, source = pmc
+            bytes_per_launch = ratio * (algo_bytes / launches)
             line["roofline"]["traffic"] = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+            line["roofline"]["traffic_over_algorithmic"] = ratio
             line["roofline"]["traffic_bytes_per_launch"] = bytes_per_launch
             line["roofline"]["traffic_source"] = f"profiles/{source} (rocprofv3 --pmc FETCH_SIZE / " \
                                                  "WRITE_SIZE, calibrated; same workload)"

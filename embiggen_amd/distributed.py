@@ -27,6 +27,8 @@ ever held by two GPUs.
 Preparation of round ``t + 1`` (walk generation, all-gather, extraction, sort) runs on a second
 stream while round ``t`` trains.
 """
+import os
+import sys
 from typing import List, Optional, Tuple
 
 
@@ -163,6 +165,7 @@ class GpuBlockBackend:
 
         self.graph, self.device = graph, torch.device(device)
         self.index = self.device.index or 0
+        self._slots, self._temp = {}, None  # standing pair buffers (prepare(slot=...))
 
     def init_rows(self, n_rows, d, ld, seed, table_id, scale, first_row, stride, out=None):
         from . import ops
@@ -185,26 +188,62 @@ class GpuBlockBackend:
 
         return ops.block_alias(self.graph, plan, device=self.index)
 
-    def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None):
-        """-> (keys, vals, cell_offsets, n_pairs); one host read (the pair count)."""
+    def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None, scale=1.0,
+                slot=None):
+        """-> (keys, vals, cell_offsets, n_pairs); one host read (the pair count).
+
+        ``slot`` None: fresh buffers of this round's size.  ``slot`` 0 / 1: the trainer's standing
+        buffers -- one (keys, vals) pair per slot and one sort buffer, allocated once for
+        ``scale`` times the pairs of this round (a short first or last round of a fit is sized
+        like the full ones) and kept until ``release()``: 2 x 42 GB + 84 GB per round of 2^22
+        walks must not depend on which cached block the allocator happens to split."""
         from . import ops
 
         import torch
 
         work, offsets = ops.block_count(self.graph, plan, walks_all, seed, epoch, first_walk)
         n_pairs = int(offsets[-1])
-        # buffers in steps of 2^24 pairs: the rounds of a fit differ by a fraction of a percent, so
-        # the caching allocator hands the blocks of round t - 2 to round t instead of growing
-        room = max(1, -(-n_pairs // PAIR_ROOM)) * PAIR_ROOM
         dev = walks_all.device
-        keys = torch.empty(room, dtype=torch.int64 if plan.key_bits == 64 else torch.int32,
-                           device=dev)
-        vals = torch.empty(room, dtype=torch.int32, device=dev)
-        temp = torch.empty(ops.block_extract_temp_bytes(room, plan.key_bits), dtype=torch.uint8,
-                           device=dev)
+        key_type = torch.int64 if plan.key_bits == 64 else torch.int32
+
+        def rounded(n):  # in steps of 2^24 pairs
+            return max(1, -(-int(n) // PAIR_ROOM)) * PAIR_ROOM
+
+        if slot is None:
+            room = rounded(n_pairs)
+            keys = torch.empty(room, dtype=key_type, device=dev)
+            vals = torch.empty(room, dtype=torch.int32, device=dev)
+            temp = torch.empty(ops.block_extract_temp_bytes(room, plan.key_bits),
+                               dtype=torch.uint8, device=dev)
+        else:
+            held = self._slots.get(slot)
+            if held is None or held[0].numel() < n_pairs or held[0].dtype != key_type:
+                self._slots[slot] = held = None  # released before its successor is allocated
+                # the rounds of a fit differ by a fraction of a percent: 1/64 of head room
+                room = rounded(n_pairs * max(1.0, scale) * (1 + 1 / 64))
+                held = self._slots[slot] = (torch.empty(room, dtype=key_type, device=dev),
+                                            torch.empty(room, dtype=torch.int32, device=dev))
+            keys, vals = held
+            need = ops.block_extract_temp_bytes(keys.numel(), plan.key_bits)
+            if self._temp is None or self._temp.numel() < need:
+                self._temp = None
+                self._temp = torch.empty(need, dtype=torch.uint8, device=dev)
+            temp = self._temp
         ops.block_extract(self.graph, plan, walks_all, seed, epoch, first_walk, work, n_pairs,
                           keys=keys, vals=vals, temp=temp, hub_bits=hub_bits)
+        if os.environ.get("GN2V_BENCH_MEMLOG"):
+            print(f"[mem] prepare: {n_pairs} pairs, room {keys.numel()}, slot {slot}, allocated "
+                  f"{torch.cuda.memory_allocated() / 1e9:.1f} GB, reserved "
+                  f"{torch.cuda.memory_reserved() / 1e9:.1f} GB", file=sys.stderr, flush=True)
         return keys[:n_pairs], vals[:n_pairs], offsets, n_pairs
+
+    def release(self):
+        """Give the standing pair buffers back (before the result tables are assembled)."""
+        import torch
+
+        if self._slots or self._temp is not None:
+            torch.cuda.synchronize(self.device)
+            self._slots, self._temp = {}, None
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
              epoch, lr):
@@ -262,6 +301,9 @@ class BlockPartitionedTrainer:
             self.backend.init_rows(rows, d, ld, seed, 1, init_scale, p, parts, out=buf[:rows])
             self.held[p] = buf
         self._spare = self.backend.empty_rows(self.max_part_rows, ld) if world > 1 else None
+        # walks per rank and round the pair buffers are sized for (None: every round by itself);
+        # with it a fit allocates once and a short round reuses the blocks of the full ones
+        self.round_capacity = None
         self.episode = 0      # global episode counter g
         self.rounds_done = 0
         self.last_round = None
@@ -274,11 +316,17 @@ class BlockPartitionedTrainer:
     def part_rows(self, p: int) -> int:
         return stripe_rows(self.n_nodes, p, self.parts)
 
-    def prepare(self, walks, seed: int, epoch: int, first_walk: int):
+    def prepare(self, walks, seed: int, epoch: int, first_walk: int, slot=None):
         """Gather the round's walks from every rank and extract + sort this rank's pairs.
         ``walks``: this rank's int32 [n, L] slice (ids first_walk + rank * n + [0, n)); every rank
-        passes the same n (ranks with fewer walks pad with sentinel rows)."""
+        passes the same n (ranks with fewer walks pad with sentinel rows).  ``slot``: which of the
+        backend's standing buffers receives the pairs (``run`` alternates two when it overlaps;
+        None: buffers of the round's own)."""
         walks_all = self.comm.all_gather(walks)
+        if slot is not None and isinstance(self.backend, GpuBlockBackend):
+            scale = (self.round_capacity or 0) / max(1, walks.shape[0])
+            return self.backend.prepare(self.plan, walks_all, seed, epoch, first_walk,
+                                        self.hub_bits, scale=scale, slot=slot)
         return self.backend.prepare(self.plan, walks_all, seed, epoch, first_walk, self.hub_bits)
 
     def train_prepared(self, prepared, seed: int, epoch: int, lr: float):
@@ -331,13 +379,13 @@ class BlockPartitionedTrainer:
         overlap = overlap and on_gpu  # a single round too: one allocator pool for all rounds
         make, seed, epoch, lr, first = rounds[0]
         if not overlap:
-            prepared = self.prepare(make(), seed, epoch, first)
+            # one standing slot: the stream orders round t's training before round t + 1's pairs
+            prepared = self.prepare(make(), seed, epoch, first, slot=0)
             for t, (_, seed, epoch, lr, _) in enumerate(rounds):
                 self.train_prepared(prepared, seed, epoch, lr)
-                prepared = None  # round t's pairs go back to the allocator before t + 1 is built
                 if t + 1 < len(rounds):
                     make, nseed, nepoch, _, nfirst = rounds[t + 1]
-                    prepared = self.prepare(make(), nseed, nepoch, nfirst)
+                    prepared = self.prepare(make(), nseed, nepoch, nfirst, slot=0)
             return
         dev = self.backend.device
         main = torch.cuda.current_stream(dev)
@@ -348,8 +396,9 @@ class BlockPartitionedTrainer:
         # freed blocks per stream, and ~100 GB of pair buffers must come back to the pool that the
         # next preparation allocates from
         side.wait_stream(main)
+        turn = getattr(self, "_turn", 0)  # two standing slots, alternating across run() calls too
         with torch.cuda.stream(side):
-            prepared = self.prepare(make(), seed, epoch, first)
+            prepared = self.prepare(make(), seed, epoch, first, slot=turn)
         main.wait_stream(side)
         for t, (_, seed, epoch, lr, _) in enumerate(rounds):
             self.train_prepared(prepared, seed, epoch, lr)
@@ -360,10 +409,12 @@ class BlockPartitionedTrainer:
                 if before is not None:
                     before.synchronize()  # round t - 1 is over: its buffers may be reused
                 make, nseed, nepoch, _, nfirst = rounds[t + 1]
+                turn ^= 1
                 with torch.cuda.stream(side):
-                    nxt = self.prepare(make(), nseed, nepoch, nfirst)
+                    nxt = self.prepare(make(), nseed, nepoch, nfirst, slot=turn)
                 main.wait_stream(side)
             before, prepared = done, nxt
+        self._turn = turn ^ 1
 
     # ------------------------------------------------------------------ results
     def gather_full(self):
@@ -371,6 +422,8 @@ class BlockPartitionedTrainer:
         import torch
 
         comm, world, n, ld = self.comm, self.comm.world, self.n_nodes, self.ld
+        if hasattr(self.backend, "release"):
+            self.backend.release()
         if world == 1:
             # the central partition of the only rank IS the table; parts are released one by one
             if self.parts == 1:

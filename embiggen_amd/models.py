@@ -273,6 +273,7 @@ class _WalkBasedModel:
                     mine = torch.tensor([round_walks], dtype=torch.int64, device=dev)
                     round_walks = int(comm.all_gather(mine).min())
             round_walks = max(1, min(round_walks, -(-walks_per_epoch // comm.world)))
+            trainer.round_capacity = round_walks
             stride = comm.world * round_walks
             n_rounds = (walks_per_epoch + stride - 1) // stride
             lr = np.float32(self.learning_rate)
