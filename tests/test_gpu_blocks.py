@@ -268,6 +268,60 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
     assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5
 
 
+@pytest.mark.parametrize("d", [8, 128])
+def test_central_row_collects_every_gradient_from_all_xcds(d):
+    """The opposite of the collision-free case: 160 000 pairs that all share ONE centre, their
+    context rows unique and spread over the 8 XCD slices -- eight XCDs add record gradients to
+    the same central row at once (f32 atomics, ~10 000 row adds).  With a learning rate small
+    enough for the order of the updates not to matter, the row must end where the sequential
+    oracle puts it: an add lost between XCDs (atomics resolved in a non-coherent L2) would leave
+    it short by far more than the tolerance."""
+    slices, record, per_cell = 8, 16, 20_000
+    n_nodes = 8 * 32_768  # cells of 32 768 rows
+    g = _ba(n_nodes)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    plan = ops.block_plan(g, 1, 0, 1, slices, 8, 2, 1, record)
+    oplan = O.block_plan(n_nodes, 1, 0, 1, slices, 8, 2, 1, record)
+    rng = np.random.RandomState(11)
+    centre = 12_345
+    keys_l, vals_l, offsets = [], [], [0]
+    for cell in range(slices):
+        ctx = rng.permutation(np.arange(cell, n_nodes, slices))[:per_cell]
+        keys_l.append(np.full(per_cell, (cell << plan.row_bits) | centre, dtype=np.uint64))
+        vals_l.append(ctx)
+        offsets.append(offsets[-1] + per_cell)
+    keys_h = np.concatenate(keys_l)
+    vals_h = np.concatenate(vals_l).astype(np.uint32)
+    off_h = np.asarray(offsets, dtype=np.uint64)
+    keys = torch.from_numpy(keys_h.astype(np.uint32).view(np.int32)).cuda()
+    vals = torch.from_numpy(vals_h.view(np.int32)).cuda()
+    offs = torch.from_numpy(off_h.astype(np.int64)).cuda()
+    ld = (d + 3) // 4 * 4
+    # the row starts at zero and moves by ~2e-4: the scores stay within 1e-2 of zero, so the
+    # gradients do not depend on the order in which the records arrive
+    lr = 1e-8
+    tp = ops.train_params(0, d, 0, 2, flags=0, ld=ld)  # k = 0; default (production) flavour
+    otp = O.TrainParams(0, d, ld, 1, 0, 2, 0.01, 0.9, 6.0, 0, d ** -0.5)
+    c = ops.init_table(n_nodes, d, 5, 0, 0.5, ld=ld)
+    c[centre] = 0
+    c0 = c.clone()
+    # context rows all positive, so that the gradients of the pairs add up instead of cancelling
+    x = ops.init_table(n_nodes, d, 5, 1, 0.5, ld=ld).abs_()
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    before = c_h[centre, :d].copy()
+    ops.block_step(g, tp, plan, keys, vals, offs, None, None, c, x, 0, 0, 5, 0, lr)
+    O.block_step(og, otp, oplan, keys_h, vals_h, off_h, None, None, c_h, x_h, 0, 0, 5, 0, lr)
+    torch.cuda.synchronize()
+    got = c.cpu().numpy()[centre, :d] - before
+    want = c_h[centre, :d] - before
+    assert np.abs(want).min() > 1e-4  # 160 000 gradients of ~lr/2 * 0.25 each moved the row
+    assert np.abs(got / want - 1).max() < 2e-3
+    # nothing but that row changed in the central table, and every context row moved once
+    changed = torch.nonzero((c != c0).any(dim=1)).flatten().tolist()
+    assert changed == [centre]
+    assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+
+
 def _trainer_run(comm, graph, use_oracle, slices=1, rounds=2, walks_per_round=11, record=4):
     og = O.OracleGraph(graph.row_ptr, graph.col_idx)
     if use_oracle:
