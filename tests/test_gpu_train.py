@@ -541,3 +541,35 @@ def test_cbow_sample_list_lengths_around_the_in_flight_limit(karate, karate_orac
     torch.cuda.synchronize()
     O.train_walks(karate_oracle, otp, wk_h, 5, 0, 0, 0.05, c_h, x_h)
     assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("d", [8, 128])
+def test_atomic_mode_loses_no_update_on_a_row_every_wave_hits(karate, karate_oracle, model, d):
+    """Atomic update mode (the default below 2^16 nodes) under the worst contention: 4 096 walks
+    hub - leaf - hub - leaf ... through ONE hub, every leaf used once.  All waves of all XCDs add
+    to the hub's two rows at once.  With the hub rows starting at zero, the leaves' rows positive
+    and a learning rate that keeps every score within 1e-3 of zero, the order of the updates does
+    not matter and the hub rows must end where the sequential oracle puts them."""
+    n_walks, L, w, k = 4096, 16, 1, 0
+    walks = np.zeros((n_walks, L), dtype=np.uint32)  # node 0 = the hub at the even positions
+    walks[:, 1::2] = 1 + np.arange(n_walks * (L // 2), dtype=np.uint32).reshape(n_walks, L // 2)
+    n_rows = 1 + n_walks * (L // 2)
+    wk = torch.from_numpy(walks.view(np.int32)).cuda()
+    ld = (d + 3) // 4 * 4
+    c, x = _tables(n_rows, d, 9)
+    c.abs_(), x.abs_()
+    c[0] = 0
+    x[0] = 0
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    lr = 1e-7
+    tp = ops.train_params(model, d, k, w, flags=MODES["atomic"])
+    otp = O.TrainParams(model, d, ld, 1, k, w, 0.01, 0.9, 6.0, 0, d ** -0.5)
+    (ops.sgns_step if model == 0 else ops.cbow_step)(karate, tp, wk, 9, 0, 0, lr, c, x)
+    torch.cuda.synchronize()
+    O.train_walks(karate_oracle, otp, walks, 9, 0, 0, lr, c_h, x_h)
+    for got, want in ((c.cpu().numpy()[0, :d], c_h[0, :d]), (x.cpu().numpy()[0, :d], x_h[0, :d])):
+        assert np.abs(want).min() > 2e-5
+        assert np.abs(got / want - 1).max() < 2e-3
+    assert np.abs(c.cpu().numpy()[1:] - c_h[1:]).max() < 1e-6
+    assert np.abs(x.cpu().numpy()[1:] - x_h[1:]).max() < 1e-6
