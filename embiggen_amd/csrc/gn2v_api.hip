@@ -148,7 +148,7 @@ int check_train_params(const gn2v_train_params *tp, uint32_t L) {
     if (!tp) return fail("train params are NULL");
     if (tp->d == 0) return fail("embedding size must be strictly positive");
     if (tp->ld < tp->d || (tp->ld & 3)) return fail("ld must be a multiple of 4 and >= d");
-    if (tp->ld > 512) return fail("embedding sizes above 512 are not supported yet");
+    if (tp->ld > 1024) return fail("embedding sizes above 1024 are not supported");
     if (tp->window < 1) return fail("window_size must be >= 1");
     if (tp->min_dist > tp->window) return fail("min_dist must not exceed window_size");
     if (L < 2) return fail("walk_length must be >= 2");
@@ -290,8 +290,10 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
             GN2V_CACHED(2);
         else if (nchunks <= 64)
             GN2V_CACHED(4);
-        else
+        else if (nchunks <= 128)
             GN2V_CACHED(8);
+        else
+            GN2V_CACHED(16);
 #undef GN2V_CACHED
     } else if (nchunks <= 16)
         launch_train_ch<1>(cbow, wm, det, grid, block, lds, s, a);
@@ -299,8 +301,10 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
         launch_train_ch<2>(cbow, wm, det, grid, block, lds, s, a);
     else if (nchunks <= 64)
         launch_train_ch<4>(cbow, wm, det, grid, block, lds, s, a);
-    else
+    else if (nchunks <= 128)
         launch_train_ch<8>(cbow, wm, det, grid, block, lds, s, a);
+    else  // 512 < ld <= 1024: 64 registers per row, the compiler parks rows in the AGPRs
+        launch_train_ch<16>(cbow, wm, det, grid, block, lds, s, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, s));
     g->train_events.push_back(ev);
@@ -544,7 +548,7 @@ int gn2v_glove_step(gn2v_graph *g, const gn2v_glove_io *io, uint64_t n_entries, 
     if (!io) return fail("glove io is NULL");
     if (d == 0) return fail("embedding size must be strictly positive");
     if (ld < d || (ld & 3)) return fail("ld must be a multiple of 4 and >= d");
-    if (ld > 512) return fail("embedding sizes above 512 are not supported yet");
+    if (ld > 1024) return fail("embedding sizes above 1024 are not supported");
     if (!std::isfinite(lr)) return fail("learning rate must be finite");
     if (n_entries == 0) return 0;
     if (!io->d_rows || !io->d_cols || !io->d_logx || !io->d_fx || !io->d_central ||
@@ -592,8 +596,10 @@ int gn2v_glove_step(gn2v_graph *g, const gn2v_glove_io *io, uint64_t n_entries, 
         launch_glove_ch<2>(wm, det, grid, block, lds, s, a);
     else if (nchunks <= 64)
         launch_glove_ch<4>(wm, det, grid, block, lds, s, a);
-    else
+    else if (nchunks <= 128)
         launch_glove_ch<8>(wm, det, grid, block, lds, s, a);
+    else
+        launch_glove_ch<16>(wm, det, grid, block, lds, s, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, s));
     g->train_events.push_back(ev);
@@ -664,7 +670,8 @@ int gn2v_edge_embedding(const float *d_src_table, const float *d_dst_table, uint
                         const uint32_t *d_src_ids, const uint32_t *d_dst_ids, uint64_t n_edges,
                         uint32_t method, float *d_out, uint32_t out_ld, void *stream) {
     DeviceGuard guard(DeviceGuard::of_pointer(d_out));
-    if (d == 0 || ld < d || (ld & 3) || ld > 512) return fail("need 0 < d <= ld <= 512, ld % 4 == 0");
+    if (d == 0 || ld < d || (ld & 3) || ld > 1024)
+        return fail("need 0 < d <= ld <= 1024, ld % 4 == 0");
     if (method >= gn2v::kEdgeMethodCount) return fail("unknown edge embedding method");
     if (n_edges == 0) return 0;  // empty edge lists are legal (and carry NULL pointers)
     if (!d_src_table || !d_dst_table || !d_src_ids || !d_dst_ids || !d_out)
@@ -687,8 +694,10 @@ int gn2v_edge_embedding(const float *d_src_table, const float *d_dst_table, uint
         GN2V_EDGE(2);
     else if (nchunks <= 64)
         GN2V_EDGE(4);
-    else
+    else if (nchunks <= 128)
         GN2V_EDGE(8);
+    else
+        GN2V_EDGE(16);
 #undef GN2V_EDGE
     HIP_TRY(hipGetLastError());
     return 0;
@@ -700,7 +709,7 @@ int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t
                     void *stream) {
     DeviceGuard guard(DeviceGuard::of_pointer(d_table));
     if (!d_table || !d_ids) return fail("NULL pointer");
-    if (ld == 0 || (ld & 3) || ld > 512) return fail("ld must be a multiple of 4 in [4, 512]");
+    if (ld == 0 || (ld & 3) || ld > 1024) return fail("ld must be a multiple of 4 in [4, 1024]");
     if (n == 0) return 0;
     const int wm = (flags & GN2V_TRAIN_ATOMIC)       ? gn2v::kAtomic
                    : (flags & GN2V_TRAIN_WRITE_BACK) ? gn2v::kWriteBack
@@ -742,8 +751,10 @@ int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t
         GN2V_TOUCH(2);
     else if (nchunks <= 64)
         GN2V_TOUCH(4);
-    else
+    else if (nchunks <= 128)
         GN2V_TOUCH(8);
+    else
+        GN2V_TOUCH(16);
 #undef GN2V_TOUCH
     HIP_TRY(hipGetLastError());
     return 0;

@@ -320,7 +320,7 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     if (!tp || !io) return fail("NULL params / io");
     if (tp->d == 0) return fail("embedding size must be strictly positive");
     if (tp->ld < tp->d || (tp->ld & 3)) return fail("ld must be a multiple of 4 and >= d");
-    if (tp->ld > 512) return fail("embedding sizes above 512 are not supported yet");
+    if (tp->ld > 1024) return fail("embedding sizes above 1024 are not supported");
     if (!std::isfinite(lr) || !std::isfinite(tp->clip) || tp->clip <= 0.f)
         return fail("learning rate / clipping value must be finite, clipping value positive");
     if (io->part >= plan->parts) return fail("part out of range");
@@ -403,8 +403,10 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
             launch_block_ch<2>(x, wmc, det, grid, block, lds, s, a);
         else if (nchunks <= 64)
             launch_block_ch<4>(x, wmc, det, grid, block, lds, s, a);
-        else
+        else if (nchunks <= 128)
             launch_block_ch<8>(x, wmc, det, grid, block, lds, s, a);
+        else
+            launch_block_ch<16>(x, wmc, det, grid, block, lds, s, a);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev.b, s));

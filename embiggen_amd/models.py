@@ -72,8 +72,8 @@ class _WalkBasedModel:
     ):
         if not isinstance(embedding_size, int) or embedding_size < 1:
             raise ValueError("The embedding size must be a strictly positive integer.")
-        if embedding_size > 512:
-            raise ValueError("Embedding sizes above 512 are not supported by the gn2v engine yet.")
+        if embedding_size > 1024:
+            raise ValueError("Embedding sizes above 1024 are not supported by the gn2v engine.")
         if epochs < 0 or walk_length < 2 or iterations < 1 or window_size < 1:
             raise ValueError(
                 "epochs must be >= 0, walk_length >= 2, iterations >= 1 and window_size >= 1."

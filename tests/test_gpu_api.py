@@ -116,3 +116,16 @@ def test_node2vec_sequence_batches_match_oracle(karate, karate_oracle):
         assert set(ref[:, 0].tolist()) == {(first + b) % 34 for b in range(8)}
     a = seq()
     assert a[0][0][0].shape == (384, 4)
+
+
+@pytest.mark.parametrize("cls", [E.Node2VecSkipGramEnsmallen, E.Node2VecCBOWEnsmallen,
+                                 E.Node2VecGloVeEnsmallen])
+def test_wide_embeddings(karate, cls):
+    """embedding_size in (512, 1024]: rows of 16 float4 per lane."""
+    kw = {} if cls is E.Node2VecGloVeEnsmallen else {"iterations": 2}  # GloVe: one iteration
+    m = cls(embedding_size=600, epochs=2, walk_length=16, verbose=False, **kw)
+    tabs = m.fit_transform(karate, return_dataframe=False).get_all_node_embedding()
+    assert all(t.shape == (34, 600) and np.isfinite(t).all() for t in tabs)
+    init = cls(embedding_size=600, epochs=0, verbose=False).fit_transform(
+        karate, return_dataframe=False).get_all_node_embedding()
+    assert all(np.abs(a - b).max() > 1e-4 for a, b in zip(tabs, init))

@@ -175,7 +175,7 @@ def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, 
     return c.cpu().numpy(), got_x, c_h, ref_x
 
 
-@pytest.mark.parametrize("d", [4, 16, 100, 128, 300])
+@pytest.mark.parametrize("d", [4, 16, 100, 128, 300, 1024])
 def test_deterministic_block_step_matches_oracle(karate, karate_oracle, d):
     c, xs, c_h, xs_h = _step_both(karate, karate_oracle, d, 5, 1, 0, 2, 1, 4, DET)
     assert np.abs(c - c_h).max() < 1e-5
@@ -217,7 +217,7 @@ def test_uniform_negatives_and_degree_normalised_learning_rate(karate, karate_or
 
 @pytest.mark.parametrize("flags", [_lib.TRAIN_ATOMIC, _lib.TRAIN_WRITE_THROUGH,
                                    _lib.TRAIN_WRITE_BACK])
-@pytest.mark.parametrize("d,slices", [(8, 1), (128, 1), (128, 8)])
+@pytest.mark.parametrize("d,slices", [(8, 1), (128, 1), (128, 8), (640, 8)])
 def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
     """Thousands of records in one launch with k = 0 and every row used once: with no row shared
     between records the parallel schedule (dynamic record tickets, four rows per wave round, XCD

@@ -74,7 +74,7 @@ def _run_gpu(graph, entries, state, d, lr, flags, passes=1):
     return [t.cpu().numpy() for t in tensors]
 
 
-@pytest.mark.parametrize("d,ld", [(8, 8), (6, 8), (100, 128), (128, 128), (200, 224), (512, 512)])
+@pytest.mark.parametrize("d,ld", [(8, 8), (6, 8), (100, 128), (128, 128), (200, 224), (512, 512), (700, 704)])
 def test_deterministic_kernel_equals_oracle(karate, karate_oracle, d, ld):
     entries = _entries(karate_oracle)
     assert len(entries[0]) > 500

@@ -50,7 +50,7 @@ def _run_both(graph, og, model, d, k, w, walks_t, flags, lr=0.05, seed=7, epoch=
 
 
 @pytest.mark.parametrize("model", [0, 1])
-@pytest.mark.parametrize("d", [4, 5, 8, 64, 100, 128, 200, 256, 300, 512])
+@pytest.mark.parametrize("d", [4, 5, 8, 64, 100, 128, 200, 256, 300, 512, 600, 1024])
 def test_deterministic_step_matches_oracle(karate, karate_oracle, model, d):
     wk = ops.walks(karate, ops.walk_params(16, 2, 0.25, 4.0), 7, 0, 0, 68)
     c, x, c_h, x_h = _run_both(karate, karate_oracle, model, d, 5, 3, wk, 1 | DET)
@@ -114,7 +114,7 @@ def _collision_free_batch(n_walks, L, w, k, block, rng, cbow):
 
 @pytest.mark.parametrize("mode", sorted(MODES))
 @pytest.mark.parametrize("model", [0, 1])
-@pytest.mark.parametrize("d", [8, 128])
+@pytest.mark.parametrize("d", [8, 128, 640])
 def test_collision_free_batch_parallel_schedule_is_exact(karate, karate_oracle, mode, model, d):
     """The production (many-wavefront) schedule, all three update modes: with disjoint rows the
     result must match the sequential oracle to float tolerance.  This also checks that a wave's
@@ -511,12 +511,12 @@ def test_limits_are_reported_as_errors(karate):
     c, x = _tables(34, 8, 1)
     with pytest.raises(_lib.Gn2vError, match="LDS"):
         ops.sgns_step(karate, ops.train_params(0, 8, 5, 5), wk, 1, 0, 0, 0.01, c, x)
-    with pytest.raises(_lib.Gn2vError, match="512"):
-        ops.sgns_step(karate, ops.train_params(0, 600, 5, 5, ld=600), wk[:, :8].contiguous(), 1, 0,
-                      0, 0.01, ops.init_table(34, 600, 1, 0, 0.1, ld=600),
-                      ops.init_table(34, 600, 1, 1, 0.1, ld=600))
+    with pytest.raises(_lib.Gn2vError, match="1024"):
+        ops.sgns_step(karate, ops.train_params(0, 1100, 5, 5, ld=1100), wk[:, :8].contiguous(), 1,
+                      0, 0, 0.01, ops.init_table(34, 1100, 1, 0, 0.1, ld=1100),
+                      ops.init_table(34, 1100, 1, 1, 0.1, ld=1100))
     with pytest.raises(ValueError):
-        E.Node2VecSkipGramEnsmallen(embedding_size=1024)
+        E.Node2VecSkipGramEnsmallen(embedding_size=1025)
     # empty batches are legal no-ops
     ops.sgns_step(karate, ops.train_params(0, 8, 5, 5), wk[:0, :8].contiguous(), 1, 0, 0, 0.01, c, x)
     assert ops.walks(karate, ops.walk_params(8, 1), 1, 0, 0, 0).shape == (0, 8)
