@@ -645,3 +645,35 @@ def test_round_size_shrinks_with_the_free_memory():
     finally:
         del hog
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_run_with_standing_buffers_equals_round_by_round_training(overlap):
+    """``run`` (standing pair buffers, two slots alternating when the preparation overlaps, called
+    twice like bench.py's warm-up and timed phases, a later round larger than the buffers were
+    sized for) against ``train_round`` (fresh buffers per round): the deterministic kernel makes
+    the two bit-equal."""
+    g = _ba(203)
+    tp = ops.train_params(0, D, K, W, flags=1 | DET)
+    wp = ops.walk_params(L, 1, 0.25, 4.0)
+    sizes = [7, 11, 5, 40, 11, 3]
+    firsts = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+
+    def trainer():
+        return BlockPartitionedTrainer(g, tp, D, D, 42, D ** -0.5, LoopbackComm(), "cuda:0",
+                                       walk_length=L, window=W, parts=2, slices=2, record=4)
+
+    a = trainer()
+    for first, n in zip(firsts, sizes):
+        a.train_round(ops.walks(g, wp, 42, 0, first, n), 42, 0, 0.02, first)
+    b = trainer()
+    b.round_capacity = 11
+    rounds = [(lambda first=first, n=n: ops.walks(g, wp, 42, 0, first, n), 42, 0, 0.02, first)
+              for first, n in zip(firsts, sizes)]
+    b.run(rounds[:2], overlap=overlap)
+    b.run(rounds[2:], overlap=overlap)
+    torch.cuda.synchronize()
+    assert len(b.backend._slots) == (2 if overlap else 1)
+    for x, y in zip(a.gather_full(), b.gather_full()):
+        assert torch.equal(x, y)
+    assert not b.backend._slots and b.backend._temp is None  # released with the result
