@@ -116,3 +116,29 @@ def test_errors_are_reported_not_thrown():
     assert L.gn2v_walks(None, None, 0, 0, 0, 0, None, None) != 0
     assert L.gn2v_train(None, None, None, 0, 0, None, None, None, None) != 0
     assert L.gn2v_graph_destroy(None) == 0
+
+
+def test_header_is_valid_c_and_a_plain_c_program_can_call_the_library(tmp_path):
+    """What a cgo / Rust-FFI / JNI binding relies on: include/gn2v.h compiles as strict C11 (and as
+    C++17), and a C program linked against libgn2v.so (tests/c/abi_smoke.c) gets the host-only
+    entry points and the error convention to work -- no GPU, no Python in the process."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = os.path.join(root, "include", "gn2v.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only",
+                    "-x", "c", header], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", header],
+                   check=True)
+    lib_dir = os.path.dirname(_lib.build())
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic",
+                    "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"),
+                    "-L", lib_dir, "-lgn2v", f"-Wl,-rpath,{lib_dir}", "-o", exe], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+    assert f"sizeof(gn2v_stats) = {C.sizeof(_lib.Stats)}" in res.stdout
+    assert f"sizeof(gn2v_block_plan) = {C.sizeof(_lib.BlockPlan)}" in res.stdout
