@@ -101,7 +101,8 @@ typedef struct {
                           window = min_dist = s, embedders/ensmallen_embedders/walklets.py)    */
 } gn2v_train_params;
 
-/* Filled by gn2v_train / gn2v_stats_read.  Times are HIP-event milliseconds measured on the
+/* Filled by gn2v_train / gn2v_stats_read: the handle's counters since the last gn2v_stats_reset
+ * (they accumulate over calls).  Times are HIP-event milliseconds measured on the
  * stream the kernels were launched on. */
 typedef struct {
     uint64_t pairs;        /* (centre, context) training pairs processed        */

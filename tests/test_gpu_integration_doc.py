@@ -43,3 +43,27 @@ def test_the_documented_binding_runs_and_matches_the_package():
     assert C.sizeof(scope["TrainParams"]) == C.sizeof(_lib.TrainParams)
     assert [f[0] for f in scope["WalkParams"]._fields_] == [f[0] for f in _lib.WalkParams._fields_]
     assert [f[0] for f in scope["TrainParams"]._fields_] == [f[0] for f in _lib.TrainParams._fields_]
+
+
+def test_whole_fit_from_a_plain_c_program(tmp_path):
+    """tests/c/fit_from_c.c: graph, tables (hipMalloc) and `gn2v_train` for SkipGram and CBOW from a
+    C11 program with neither Python nor PyTorch in the process; it checks the stats and that the
+    embedding separates the cliques of its graph."""
+    import shutil
+    import subprocess
+
+    from embiggen_amd import _lib
+
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("needs gcc and the ROCm headers")
+    lib_dir = os.path.dirname(_lib.build())
+    exe = str(tmp_path / "fit_from_c")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__",
+                    "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "c", "fit_from_c.c"),
+                    "-L", lib_dir, "-lgn2v", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+                    f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, (res.stdout, res.stderr)
+    lines = res.stdout.strip().splitlines()
+    assert lines[-1] == "ok" and lines[0].startswith("model 0") and lines[1].startswith("model 1")
