@@ -103,24 +103,51 @@ def parse():
 class PhantomComm:
     """One rank of a world of `world` ranks without peers (--phantom-world): the caller hands over
     the walks of all ranks already concatenated, a part that leaves comes back as the part that
-    arrives (same size up to one row; the values are those of a trained part)."""
+    arrives (same size up to one row; the values are those of a trained part).  Like RCCL's, the
+    copy runs on a stream of its own, ordered after the training launched so far and awaited by
+    the compute stream after the next launch; HIP events around it tell how long a small kernel
+    that arrives while the training kernel occupies the CUs takes to get through."""
 
     backend = "phantom"
 
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
+        self._stream, self.hops = None, []
 
     def all_gather(self, tensor):
         return tensor
 
     def sendrecv_start(self, send, dst, recv, src):
-        from embiggen_amd.distributed import _Done
+        import torch
 
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        main, side = torch.cuda.current_stream(), self._stream
+        side.wait_stream(main)
         rows = min(send.shape[0], recv.shape[0])
-        recv[:rows].copy_(send[:rows])
-        if recv.shape[0] > rows:
-            recv[rows:].copy_(send[: recv.shape[0] - rows])
-        return _Done()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side):
+            t0.record()
+            recv[:rows].copy_(send[:rows])
+            if recv.shape[0] > rows:
+                recv[rows:].copy_(send[: recv.shape[0] - rows])
+            t1.record()
+        self.hops.append((t0, t1))
+
+        class _Hop:
+            def wait(_self):
+                main.wait_stream(side)
+
+        return _Hop()
+
+    def hop_ms(self):
+        """(count, mean, max) of the hop copies' durations so far; clears the list."""
+        import torch
+
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.hops]
+        self.hops = []
+        return (len(ms), sum(ms) / max(len(ms), 1), max(ms, default=0.0))
 
 
 def usable_cores() -> int:
@@ -361,9 +388,12 @@ def main():
     memlog("after warm-up")
     ops.stats_reset(graph, local)
     t0 = time.perf_counter()
+    if phantom:
+        comm.hop_ms()  # forget the warm-up's hops
     run_steps(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    hop_stats = comm.hop_ms() if phantom else None
     memlog("after the timed steps")
     st = ops.stats_read(graph, local)
 
@@ -503,6 +533,10 @@ def main():
                 "world": t_world, "rank": t_rank,
                 "pairs_this_rank": st["pairs"],
                 "walk_steps_generated_here_for_all_ranks": st["walk_steps"],
+                "hop_copies": {"count": hop_stats[0], "mean_ms": hop_stats[1], "max_ms": hop_stats[2],
+                               "bytes_each": int(next(iter(blocks.held.values())).numel() * 4),
+                               "what": "a part-sized device copy on its own stream, issued like "
+                                       "an RCCL hop while the training kernel holds the CUs"},
                 "note": "one rank of that world on one GPU, no fabric: value = this rank's pairs/s; "
                         "the walks of all ranks are generated here (in a real job 1/world of them)"}
         pmc = committed_traffic(line["config"], args.mode)
