@@ -67,3 +67,13 @@ def test_whole_fit_from_a_plain_c_program(tmp_path):
     assert res.returncode == 0, (res.stdout, res.stderr)
     lines = res.stdout.strip().splitlines()
     assert lines[-1] == "ok" and lines[0].startswith("model 0") and lines[1].startswith("model 1")
+
+
+def test_the_readme_quick_start_runs_as_written():
+    text = open(os.path.join(ROOT, "README.md")).read()
+    block = re.search(r"```python\n(import embiggen_amd as E\ngraph = .*?)```", text, re.S).group(1)
+    scope = {}
+    exec(compile(block, "README.md", "exec"), scope)  # noqa: S102
+    central, contextual = scope["central"], scope["contextual"]
+    assert central.shape == contextual.shape == (34, 128) and central.dtype == np.float32
+    assert np.isfinite(central).all() and np.isfinite(contextual).all()
