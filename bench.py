@@ -85,6 +85,11 @@ def parse():
                     help="blocks: prepare round t + 1 on a second stream while round t trains "
                          "(auto: with several GPUs, where it hides the walk all-gather; on one GPU "
                          "preparation and training share the same HBM and nothing is gained)")
+    ap.add_argument("--stripes", type=int, default=0,
+                    help="blocks on one GPU: centre stripes trained one after the other over the "
+                         "pairs of a round of `stripes` x as many walks -- the memory of a round "
+                         "of --round-walks / stripes walks, centre runs `stripes` times as long "
+                         "(0 = 8 on one GPU, 1 with several: there the ranks are the stripes)")
     ap.add_argument("--model", default="skipgram", choices=["skipgram", "cbow"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
@@ -308,14 +313,17 @@ def main():
     overlap = args.overlap == "on" or (args.overlap == "auto" and (world > 1 or phantom))
     # the trainer's view of the job (a phantom rank sees the world it stands in for)
     t_rank, t_world = (args.phantom_rank, args.phantom_world) if phantom else (rank, world)
+    stripes = 1
     if mode == "blocks":
         # tables partitioned by node id; no row is ever held by two GPUs
         comm = (PhantomComm(t_rank, t_world) if phantom
                 else TorchComm() if world > 1 else LoopbackComm())
+        stripes = args.stripes if args.stripes else (8 if world == 1 and not phantom else 1)
         blocks = BlockPartitionedTrainer(graph, tp, d, ld, 42, d ** -0.5, comm, f"cuda:{local}",
                                          walk_length=128, window=5, parts=args.parts,
                                          slices=args.slices, record=args.record,
-                                         hot_band=tuple(int(v) for v in args.hot_band.split(":")))
+                                         hot_band=tuple(int(v) for v in args.hot_band.split(":")),
+                                         stripes=stripes)
     else:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local, ld=ld)
@@ -324,8 +332,10 @@ def main():
         from embiggen_amd.distributed import round_walks_within
 
         torch.cuda.empty_cache()  # what building the graph left in the allocator's cache
-        args.round_walks = round_walks_within(torch.cuda.mem_get_info()[0], 128, 5,
-                                              blocks.plan.key_bits, t_world, overlap)
+        # walks whose pairs fit the memory at once, times the stripes that share them
+        args.round_walks = stripes * round_walks_within(
+            torch.cuda.mem_get_info()[0], 128, 5, blocks.plan.key_bits, max(t_world, stripes),
+            overlap and stripes == 1)
         if world > 1:  # every rank the same round size
             agreed = torch.tensor([args.round_walks], dtype=torch.int64, device="cuda")
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
@@ -500,8 +510,9 @@ def main():
                     "blocks": f"{t_world} GPU(s), central table striped over the ranks, contextual "
                               f"table in {blocks.parts if blocks else 0} travelling parts x "
                               f"{blocks.slices if blocks else 0} XCD slice(s) (no shared rows), rounds of "
-                              f"{min(args.round_walks, args.steps * args.walks)} walks per GPU, preparation "
-                              f"{'overlapped' if overlap else 'in line'}",
+                              f"{min(args.round_walks, args.steps * args.walks)} walks per GPU"
+                              + (f" trained in {stripes} centre stripes" if stripes > 1 else "")
+                              + f", preparation {'overlapped' if overlap and stripes == 1 else 'in line'}",
                 }[mode],
             },
             "pairs_per_s": total_pairs / elapsed,

@@ -119,6 +119,7 @@ class BlockIO(C.Structure):
         ("d_context", C.c_void_p),
         ("block_id", C.c_uint64),
         ("part", C.c_uint32),
+        ("central_ld", C.c_uint64),
     ]
 
 
@@ -136,6 +137,8 @@ class Stats(C.Structure):
         ("walk_launches", C.c_uint32),
         ("block_parts", C.c_uint32),
         ("block_slices", C.c_uint32),
+        ("block_stripes", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -229,7 +232,7 @@ def lib():
     L.gn2v_block_auto_plan.argtypes = [u64, u32, C.POINTER(u32), C.POINTER(u32)]
     L.gn2v_block_round_walks.argtypes = [u64, u32, u32, u32, u32, u32, C.POINTER(u64)]
     L.gn2v_train_blocks.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,
-                                    u64, vp, vp, C.POINTER(Stats), vp]
+                                    u64, u32, vp, vp, C.POINTER(Stats), vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]
     L.gn2v_stats_read.argtypes = [vp, C.POINTER(Stats), vp]
     for name in EXPORTS:

@@ -327,7 +327,8 @@ struct BlockArgs {
     const unsigned long long *alias;      // alias tables (threshold | alias << 32), or nullptr:
                                           // negatives uniform over the rows of the cell
     const unsigned long long *cell_rows;  // [cells + 1]: first table entry of every cell
-    float *central;    // this rank's central partition  [rows][ld]
+    float *central;    // this rank's central partition  [rows][cld]
+    uint64_t cld;      // floats between its rows (ld, or world * ld inside the whole table)
     float *context;    // the resident context part      [rows][ld]
     unsigned long long *cursors;  // record tickets of the part's cells, one per slice, kCursorStep
                                   // words apart (zeroed per launch)
@@ -414,7 +415,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
     uint32_t r0 = 0;
     Row<CH> u_next;
     if constexpr (!DET)
-        load_row<CH>(u_next, a.central + (uint64_t)s_key[0] * a.ld, q, nchunks, n != 0);
+        load_row<CH>(u_next, a.central + (uint64_t)s_key[0] * a.cld, q, nchunks, n != 0);
     while (r0 < n) {
         const uint32_t crow_id = s_key[r0];
         uint32_t r1 = r0 + 1;
@@ -425,13 +426,13 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
             const uint64_t deg = a.g.row_ptr[c + 1] - a.g.row_ptr[c];
             if (deg) lrc = a.lr / (float)deg;
         }
-        float *crow = a.central + (uint64_t)crow_id * a.ld;
+        float *crow = a.central + (uint64_t)crow_id * a.cld;
         Row<CH> u, g;
         if constexpr (DET) {
             load_row<CH>(u, crow, q, nchunks, true);
         } else {
             u = u_next;
-            load_row<CH>(u_next, a.central + (uint64_t)s_key[r1 < n ? r1 : r0] * a.ld, q, nchunks,
+            load_row<CH>(u_next, a.central + (uint64_t)s_key[r1 < n ? r1 : r0] * a.cld, q, nchunks,
                          r1 < n);
         }
         zero_row<CH>(g);

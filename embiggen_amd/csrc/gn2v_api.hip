@@ -806,7 +806,7 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
     hipStream_t s = (hipStream_t)stream;
     const bool cbow = tp->model == GN2V_MODEL_CBOW;
     const uint32_t L = wp->walk_length;
-    if (stats) stats->block_parts = stats->block_slices = 0;
+    if (stats) stats->block_parts = stats->block_slices = stats->block_stripes = stats->reserved = 0;
 
     // SkipGram on large graphs in the default update mode: the block path (contextual rows in
     // XCD-exclusive cells)
@@ -815,7 +815,7 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
                                    GN2V_TRAIN_WALK_ORDERED;
     if (!cbow && ((tp->flags & GN2V_TRAIN_BLOCK_PATH) ||
                   (!(tp->flags & explicit_mode) && g->view.n_nodes >= (1ULL << 16))))
-        return gn2v_train_blocks(g, wp, tp, seed, max_walks_per_epoch, 0, d_central, d_contextual,
+        return gn2v_train_blocks(g, wp, tp, seed, max_walks_per_epoch, 0, 0, d_central, d_contextual,
                                  stats, stream);
 
     if (gn2v_init_table(d_central, g->view.n_nodes, tp->d, tp->ld, seed, 0, tp->init_scale, s) ||

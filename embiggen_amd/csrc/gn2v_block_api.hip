@@ -29,8 +29,9 @@ int check_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     if (!g) return fail("graph handle is NULL");
     if (!p) return fail("block plan is NULL");
     if (p->world < 1 || p->rank >= p->world) return fail("need rank < world");
-    if (p->parts < p->world || p->parts % p->world)
-        return fail("parts must be a positive multiple of world");
+    // (ranks that exchange parts need parts % world == 0: the host-side trainer checks that; the
+    // centre stripes of one GPU -- gn2v_block_io.central_ld -- do not)
+    if (p->parts < 1) return fail("parts must be positive");
     if (p->slices < 1 || p->slices > gn2v_host::kCursorSlices)
         return fail("slices must be in [1, 16]");
     if ((uint64_t)p->parts * p->slices > gn2v::kMaxCells) return fail("too many cells (parts x slices)");
@@ -342,6 +343,8 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     a.alias = scale_free ? (const unsigned long long *)io->d_alias : nullptr;
     a.cell_rows = scale_free ? (const unsigned long long *)io->d_cell_rows : nullptr;
     a.central = io->d_central;
+    a.cld = io->central_ld ? io->central_ld : tp->ld;
+    if (a.cld < tp->ld || (a.cld & 3)) return fail("central_ld must be a multiple of 4 and >= ld");
     a.context = io->d_context;
     a.counters = g->counters;
     a.n_nodes = g->view.n_nodes;
@@ -460,18 +463,27 @@ int gn2v_block_round_walks(uint64_t free_bytes, uint32_t walk_length, uint32_t w
 
 int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
                       uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
-                      float *d_central, float *d_contextual, gn2v_stats *stats, void *stream) {
+                      uint32_t stripes, float *d_central, float *d_contextual, gn2v_stats *stats,
+                      void *stream) {
     if (!g || !wp || !tp) return fail("NULL handle / params");
     if (tp->model != GN2V_MODEL_SKIPGRAM) return fail("the block path trains SkipGram only");
     if (!d_central || !d_contextual) return fail("NULL table pointer");
+    if (stripes > 64) return fail("at most 64 centre stripes");
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
     const uint64_t n = g->view.n_nodes;
     const uint32_t L = wp->walk_length, w = tp->window, ld = tp->ld;
 
+    // Centre stripes ("virtual ranks"): stripe j = the centres c with c % V == j is trained over
+    // the pairs of ALL the round's walks before stripe j + 1 -- what V ranks do side by side.  A
+    // pass holds 1 / V of the round's pairs, so a round can be V times as long at the same
+    // memory, and a centre's pairs meet in runs V times as long.
+    uint32_t V = stripes ? stripes : 8;
+    while (V > 1 && n / V < 2) V /= 2;
+
     gn2v_block_plan plan{};
-    plan.world = 1;
+    plan.world = V;
     plan.rank = 0;
     if (gn2v_block_auto_plan(n, 1, &plan.parts, &plan.slices)) return 1;
     plan.walk_length = L;
@@ -480,7 +492,12 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     plan.record = 16;
     plan.flags = tp->flags & GN2V_TRAIN_DOWNSAMPLE;
     while (plan.parts > 1 && n / plan.parts == 0) plan.parts /= 2;
-    if (gn2v_block_plan_check(g, &plan)) return 1;
+    std::vector<gn2v_block_plan> plans(V, plan);
+    for (uint32_t j = 0; j < V; ++j) {
+        plans[j].rank = j;
+        if (gn2v_block_plan_check(g, &plans[j])) return 1;
+    }
+    plan = plans[0];
     const uint32_t parts = plan.parts, cells = parts * plan.slices;
     const bool scale_free = tp->flags & GN2V_TRAIN_SCALE_FREE;
 
@@ -506,7 +523,8 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         (void)hipFree(tmp);
         buf.ptrs.pop_back();
     }
-    // the contextual table as `parts` buffers; the central table is the caller's (world = 1)
+    // the contextual table as `parts` buffers; the central table is the caller's, whole: stripe j
+    // is its rows j, j + V, ... (gn2v_block_io.central_ld)
     const uint64_t max_rows = gn2v::stripe_count(n, 0, parts);
     float *ctx = nullptr;
     if (buf.alloc(&ctx, (size_t)parts * max_rows * ld * sizeof(float))) return 1;
@@ -516,70 +534,91 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
                                  tp->d, ld, seed, 1, tp->init_scale, p, parts, s))
             return 1;
 
-    // round size: the longer, the more pairs of a centre meet in a cell
+    // round size: `round_walks` = the walks whose pairs are held at once (one pass), a round is
+    // V times that; the longer, the more pairs of a centre meet in a cell
     const bool automatic = round_walks == 0;
     if (automatic) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if (gn2v_block_round_walks(free_b, L, w, plan.key_bits, 1, 0, &round_walks)) return 1;
+        if (gn2v_block_round_walks(free_b, L, w, plan.key_bits, V, 0, &round_walks)) return 1;
     }
-    round_walks = std::max<uint64_t>(1, std::min(round_walks, walks_per_epoch));
+    round_walks = std::max<uint64_t>(1, std::min(round_walks, (walks_per_epoch + V - 1) / V));
     uint32_t *walks = nullptr, *vals = nullptr;
     void *keys = nullptr, *tmp = nullptr;
     uint64_t *work = nullptr, *cell_offsets = nullptr;
-    uint64_t tb = 0;
+    uint64_t tb = 0, cap = 0;
     if (buf.alloc(&work, GN2V_BLOCK_WORK_WORDS * 8) || buf.alloc(&cell_offsets, (cells + 1) * 8))
         return 1;
     const size_t held = buf.ptrs.size();
-    for (;;) {
-        const uint64_t cap = round_walks * pairs_per_walk;
-        gn2v_block_extract_temp_bytes(cap, plan.key_bits, &tb);
-        if (!(buf.alloc(&walks, round_walks * L * 4) || buf.alloc(&keys, cap * key_bytes) ||
-              buf.alloc(&vals, cap * 4) || buf.alloc(&tmp, tb)))
-            break;
-        // somebody else took the memory between the query and here: an automatic size halves
+    auto release_round = [&]() {
         while (buf.ptrs.size() > held) {
             (void)hipFree(buf.ptrs.back());
             buf.ptrs.pop_back();
         }
+    };
+    for (;;) {
+        // a stripe's share of the round's pairs is 1 / V up to the weight of its hubs: 1 / 16 of
+        // head room on top of the untrimmed-window bound, more on demand (below)
+        cap = round_walks * pairs_per_walk;
+        if (V > 1) cap += cap / 16;
+        gn2v_block_extract_temp_bytes(cap, plan.key_bits, &tb);
+        if (!(buf.alloc(&walks, V * round_walks * L * 4) || buf.alloc(&keys, cap * key_bytes) ||
+              buf.alloc(&vals, cap * 4) || buf.alloc(&tmp, tb)))
+            break;
+        // somebody else took the memory between the query and here: an automatic size halves
+        release_round();
         if (!automatic || round_walks <= (1u << 14)) return 1;
         round_walks /= 2;
     }
+    const uint64_t super_walks = V * round_walks;
 
     float lr = tp->lr;
     uint64_t round_id = 0;
     for (uint32_t e = 0; e < tp->epochs; ++e) {
-        for (uint64_t first = 0; first < walks_per_epoch; first += round_walks, ++round_id) {
-            const uint64_t nw = std::min(round_walks, walks_per_epoch - first);
+        for (uint64_t first = 0; first < walks_per_epoch; first += super_walks, ++round_id) {
+            const uint64_t nw = std::min(super_walks, walks_per_epoch - first);
             if (gn2v_walks(g, wp, seed, e, first, nw, walks, s)) return 1;
-            if (gn2v_block_count(g, &plan, walks, nw, seed, e, first, work, cell_offsets, s))
-                return 1;
-            uint64_t n_pairs = 0;  // the one host read of the round
-            HIP_TRY(hipMemcpyAsync(&n_pairs, cell_offsets + cells, 8, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (n_pairs > round_walks * pairs_per_walk)
-                return fail("internal: more pairs than the round's capacity");
-            if (n_pairs == 0) continue;
-            if (gn2v_block_extract(g, &plan, walks, nw, seed, e, first, work, hub_bits, n_pairs,
-                                   keys, vals, tmp, tb, s))
-                return 1;
-            for (uint32_t p = 0; p < parts; ++p) {
-                gn2v_block_io io{};
-                io.d_keys = keys;
-                io.d_vals = vals;
-                io.d_cell_offsets = cell_offsets;
-                io.d_alias = alias;
-                io.d_cell_rows = cell_rows;
-                io.d_central = d_central;
-                io.d_context = ctx + (size_t)p * max_rows * ld;
-                io.block_id = round_id;
-                io.part = p;
-                if (gn2v_block_step(g, tp, &plan, &io, seed, e, lr, s)) return 1;
-            }
-            if (g->train_events.size() > 2048) {  // bound the event pool on long fits
+            for (uint32_t j = 0; j < V; ++j) {
+                const gn2v_block_plan *pj = &plans[j];
+                if (gn2v_block_count(g, pj, walks, nw, seed, e, first, work, cell_offsets, s))
+                    return 1;
+                uint64_t n_pairs = 0;  // the one host read of the pass
+                HIP_TRY(hipMemcpyAsync(&n_pairs, cell_offsets + cells, 8, hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                gn2v_stats scratch;
-                if (gn2v_stats_read(g, &scratch, s)) return 1;
+                if (n_pairs == 0) continue;
+                if (n_pairs > cap) {  // a stripe heavier than the head room allows: grow
+                    (void)hipFree(tmp);
+                    (void)hipFree(vals);
+                    (void)hipFree(keys);
+                    buf.ptrs.resize(buf.ptrs.size() - 3);
+                    cap = n_pairs + n_pairs / 16;
+                    gn2v_block_extract_temp_bytes(cap, plan.key_bits, &tb);
+                    if (buf.alloc(&keys, cap * key_bytes) || buf.alloc(&vals, cap * 4) ||
+                        buf.alloc(&tmp, tb))
+                        return 1;
+                }
+                if (gn2v_block_extract(g, pj, walks, nw, seed, e, first, work, hub_bits, n_pairs,
+                                       keys, vals, tmp, tb, s))
+                    return 1;
+                for (uint32_t p = 0; p < parts; ++p) {
+                    gn2v_block_io io{};
+                    io.d_keys = keys;
+                    io.d_vals = vals;
+                    io.d_cell_offsets = cell_offsets;
+                    io.d_alias = alias;
+                    io.d_cell_rows = cell_rows;
+                    io.d_central = d_central + (size_t)j * ld;
+                    io.central_ld = (uint64_t)V * ld;
+                    io.d_context = ctx + (size_t)p * max_rows * ld;
+                    io.block_id = round_id * V + j;
+                    io.part = p;
+                    if (gn2v_block_step(g, tp, pj, &io, seed, e, lr, s)) return 1;
+                }
+                if (g->train_events.size() > 2048) {  // bound the event pool on long fits
+                    HIP_TRY(hipStreamSynchronize(s));
+                    gn2v_stats scratch;
+                    if (gn2v_stats_read(g, &scratch, s)) return 1;
+                }
             }
         }
         lr *= tp->lr_decay;
@@ -598,6 +637,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         if (gn2v_stats_read(g, stats, s)) return 1;
         stats->block_parts = parts;
         stats->block_slices = plan.slices;
+        stats->block_stripes = V;
     }
     return 0;
 }

@@ -246,14 +246,14 @@ class GpuBlockBackend:
             self._slots, self._temp = {}, None
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
-             epoch, lr):
+             epoch, lr, whole_central=False):
         from . import ops
 
         keys, vals, offsets, n_pairs = prepared
         if n_pairs == 0:
             return
         ops.block_step(self.graph, tp, plan, keys, vals, offsets, alias, cell_rows, central,
-                       context, block_id, part, seed, epoch, lr)
+                       context, block_id, part, seed, epoch, lr, whole_central=whole_central)
 
 
 class BlockPartitionedTrainer:
@@ -263,7 +263,14 @@ class BlockPartitionedTrainer:
     def __init__(self, graph, train_params, d: int, ld: int, seed: int, init_scale: float, comm,
                  device, walk_length: int, window: int, min_dist: int = 1,
                  scale_free: bool = True, backend=None, parts: Optional[int] = None,
-                 slices: Optional[int] = None, record: int = 16, hot_band=(0, 0)):
+                 slices: Optional[int] = None, record: int = 16, hot_band=(0, 0),
+                 stripes: int = 1):
+        """``stripes`` (one GPU only): the centres are split into that many stripes (centre c:
+        stripe c % stripes) and a round is trained stripe after stripe, each stripe over the pairs
+        of ALL the round's walks whose centre it owns -- what ``stripes`` ranks would do side by
+        side.  The pairs of a pass, hence the memory, are those of a round of
+        ``walks / stripes`` walks, but a centre's pairs meet in runs ``stripes`` times as long
+        (its row is read and added to once per run)."""
         self.graph, self.tp, self.comm = graph, train_params, comm
         self.d, self.ld, self.seed = d, ld, seed
         self.n_nodes = graph.get_number_of_nodes()
@@ -277,10 +284,19 @@ class BlockPartitionedTrainer:
                              "of the number of ranks, at least two per rank.")
         self.parts, self.slices = parts, slices
         self.per_rank = parts // world
-        self.plan = self.backend.plan(world=world, rank=rank, parts=parts, slices=slices,
-                                      walk_length=walk_length, window=window, min_dist=min_dist,
-                                      record=record, flags=int(train_params.flags) & 2,
-                                      hot_lo=int(hot_band[0]), hot_hi=int(hot_band[1]))
+        self.stripes = max(1, int(stripes))
+        if self.stripes > 1 and world > 1:
+            raise ValueError("Centre stripes are the one-GPU form of several ranks: stripes > 1 "
+                             "needs world == 1.")
+        # plans[j]: the view of stripe j (a rank of a world of `stripes`); plan = plans[0]
+        self.plans = [
+            self.backend.plan(world=self.stripes if self.stripes > 1 else world,
+                              rank=j if self.stripes > 1 else rank, parts=parts, slices=slices,
+                              walk_length=walk_length, window=window, min_dist=min_dist,
+                              record=record, flags=int(train_params.flags) & 2,
+                              hot_lo=int(hot_band[0]), hot_hi=int(hot_band[1]))
+            for j in range(self.stripes)]
+        self.plan = self.plans[0]
         self.scale_free = bool(scale_free)
         # per-cell alias tables for the negatives + the hot-row flags (rows updated by atomics)
         self.alias, self.cell_rows, self.hub_bits = (
@@ -316,7 +332,7 @@ class BlockPartitionedTrainer:
     def part_rows(self, p: int) -> int:
         return stripe_rows(self.n_nodes, p, self.parts)
 
-    def prepare(self, walks, seed: int, epoch: int, first_walk: int, slot=None):
+    def prepare(self, walks, seed: int, epoch: int, first_walk: int, slot=None, stripe: int = 0):
         """Gather the round's walks from every rank and extract + sort this rank's pairs.
         ``walks``: this rank's int32 [n, L] slice (ids first_walk + rank * n + [0, n)); every rank
         passes the same n (ranks with fewer walks pad with sentinel rows).  ``slot``: which of the
@@ -325,14 +341,17 @@ class BlockPartitionedTrainer:
         walks_all = self.comm.all_gather(walks)
         if slot is not None and isinstance(self.backend, GpuBlockBackend):
             scale = (self.round_capacity or 0) / max(1, walks.shape[0])
-            return self.backend.prepare(self.plan, walks_all, seed, epoch, first_walk,
+            return self.backend.prepare(self.plans[stripe], walks_all, seed, epoch, first_walk,
                                         self.hub_bits, scale=scale, slot=slot)
-        return self.backend.prepare(self.plan, walks_all, seed, epoch, first_walk, self.hub_bits)
+        return self.backend.prepare(self.plans[stripe], walks_all, seed, epoch, first_walk,
+                                    self.hub_bits)
 
-    def train_prepared(self, prepared, seed: int, epoch: int, lr: float):
-        """`parts` episodes over the prepared pairs of one round."""
+    def train_prepared(self, prepared, seed: int, epoch: int, lr: float, stripe: int = 0):
+        """`parts` episodes over the prepared pairs of one round (of one centre stripe of it)."""
         comm, world = self.comm, self.comm.world
-        block_id = self.rounds_done * world + comm.rank
+        striped = self.stripes > 1
+        block_id = (self.rounds_done * self.stripes + stripe if striped
+                    else self.rounds_done * world + comm.rank)
         for _ in range(self.parts):
             g = self.episode
             part = self.part_of_episode(g)
@@ -350,19 +369,28 @@ class BlockPartitionedTrainer:
                                               recv_buf[: self.part_rows(nxt)],
                                               (comm.rank + 1) % world)
             ctx = self.held[part]
-            self.backend.step(self.tp, self.plan, prepared, self.alias, self.cell_rows,
-                              self.central, ctx[: self.part_rows(part)], block_id, part, seed,
-                              epoch, lr)
+            if striped:
+                self.backend.step(self.tp, self.plans[stripe], prepared, self.alias,
+                                  self.cell_rows, self.central, ctx[: self.part_rows(part)],
+                                  block_id, part, seed, epoch, lr, whole_central=True)
+            else:
+                self.backend.step(self.tp, self.plan, prepared, self.alias, self.cell_rows,
+                                  self.central, ctx[: self.part_rows(part)], block_id, part, seed,
+                                  epoch, lr)
             if pending is not None:
                 pending.wait()
                 self.held[nxt] = recv_buf
                 self._spare = send_buf
             self.episode += 1
-        self.rounds_done += 1
-        self.last_round = {"pairs_trained": int(prepared[3])}
+        trained = int(prepared[3]) + (self.last_round["pairs_trained"] if stripe else 0)
+        self.last_round = {"pairs_trained": trained}
+        if stripe == self.stripes - 1:
+            self.rounds_done += 1
 
-    def train_round(self, walks, seed: int, epoch: int, lr: float, first_walk: int):
-        self.train_prepared(self.prepare(walks, seed, epoch, first_walk), seed, epoch, lr)
+    def train_round(self, walks, seed: int, epoch: int, lr: float, first_walk: int, slot=None):
+        for j in range(self.stripes):
+            self.train_prepared(self.prepare(walks, seed, epoch, first_walk, slot=slot, stripe=j),
+                                seed, epoch, lr, stripe=j)
 
     def run(self, rounds, overlap: bool = True):
         """Train a sequence of rounds; ``rounds`` is a list of ``(make_walks, seed, epoch, lr,
@@ -376,16 +404,14 @@ class BlockPartitionedTrainer:
         if not rounds:
             return
         on_gpu = isinstance(self.backend, GpuBlockBackend)
-        overlap = overlap and on_gpu  # a single round too: one allocator pool for all rounds
+        # a single round too: one allocator pool for all rounds; centre stripes run in line
+        overlap = overlap and on_gpu and self.stripes == 1
         make, seed, epoch, lr, first = rounds[0]
         if not overlap:
-            # one standing slot: the stream orders round t's training before round t + 1's pairs
-            prepared = self.prepare(make(), seed, epoch, first, slot=0)
-            for t, (_, seed, epoch, lr, _) in enumerate(rounds):
-                self.train_prepared(prepared, seed, epoch, lr)
-                if t + 1 < len(rounds):
-                    make, nseed, nepoch, _, nfirst = rounds[t + 1]
-                    prepared = self.prepare(make(), nseed, nepoch, nfirst, slot=0)
+            # one standing slot: the stream orders a round's (a stripe's) training before the
+            # pairs of the next are written
+            for make, seed, epoch, lr, first in rounds:
+                self.train_round(make(), seed, epoch, lr, first, slot=0)
             return
         dev = self.backend.device
         main = torch.cuda.current_stream(dev)

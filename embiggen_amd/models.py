@@ -209,11 +209,12 @@ class _WalkBasedModel:
                                     contextual.data_ptr(), C.byref(stats), stream))
             self.last_seconds = time.perf_counter() - start
         self.last_stats = stats.as_dict()
-        self.last_plan = ({"world": 1, "parts": stats.block_parts, "slices": stats.block_slices}
-                          if stats.block_parts else None)
+        self.last_plan = ({"world": 1, "parts": stats.block_parts, "slices": stats.block_slices,
+                           "stripes": stats.block_stripes} if stats.block_parts else None)
         if self.verbose:
             secs = max(self.last_seconds, 1e-9)
-            path = (f" (block path, {stats.block_parts} parts x {stats.block_slices} slices)"
+            path = (f" (block path, {stats.block_parts} parts x {stats.block_slices} slices, "
+                    f"{stats.block_stripes} centre stripes)"
                     if stats.block_parts else "")
             print(
                 f"[gn2v] {self.NAME}{path}: {stats.pairs} pairs, {stats.walk_steps} walk steps in "
@@ -230,11 +231,14 @@ class _WalkBasedModel:
     BLOCK_PATH_MIN_NODES = 1 << 16
 
     def fit_transform_blocks(self, graph, comm, round_walks: Optional[int] = None, slices=None,
-                             parts=None, overlap: bool = True, max_walks_per_epoch: int = 0):
+                             parts=None, overlap: bool = True, max_walks_per_epoch: int = 0,
+                             stripes: Optional[int] = None):
         """SkipGram over several GPUs, one process per GPU (``comm`` = ``distributed.TorchComm``
         under ``torch.distributed.run``): tables partitioned by node id, no row shared between
         GPUs (``distributed.BlockPartitionedTrainer``).  Every rank returns the full
-        ``(central, contextual)`` device tensors [N, padded_size]."""
+        ``(central, contextual)`` device tensors [N, padded_size].  With one rank
+        (``LoopbackComm``) this is the Python form of ``gn2v_train_blocks``: ``stripes`` centre
+        stripes (None = 8, as there) play the ranks one after the other."""
         import torch
 
         from . import ops
@@ -251,13 +255,20 @@ class _WalkBasedModel:
         dev = torch.device("cuda", device)
         tp = self.train_params()
         L = self.walk_length
+        if comm.world > 1:
+            stripes = 1
+        else:
+            stripes = 8 if stripes is None else max(1, int(stripes))
+            while stripes > 1 and csr.get_number_of_nodes() // stripes < 2:
+                stripes //= 2
+        lanes = comm.world if comm.world > 1 else stripes  # ranks, or the stripes that play them
         with torch.cuda.device(dev):
             ops.stats_reset(csr, device)
             trainer = BlockPartitionedTrainer(
                 csr, tp, self.embedding_size, self.padded_size, self.random_state,
                 self.init_scale(), comm, dev, walk_length=L, window=self.window_size,
                 min_dist=self.min_distance, scale_free=self.use_scale_free_distribution,
-                slices=slices, parts=parts)
+                slices=slices, parts=parts, stripes=stripes)
             wp = self.walk_params()
             walks_per_epoch = csr.get_number_of_unique_source_nodes() * self.iterations
             if max_walks_per_epoch:
@@ -268,13 +279,15 @@ class _WalkBasedModel:
                 result = (2 if comm.world > 1 else 1) * trainer.n_nodes * self.padded_size * 4
                 round_walks = round_walks_within(
                     max(0, torch.cuda.mem_get_info(dev)[0] - result), L, self.window_size,
-                    trainer.plan.key_bits, comm.world, overlap)
+                    trainer.plan.key_bits, lanes, overlap and stripes == 1)
                 if comm.world > 1:  # every rank must use the same round size
                     mine = torch.tensor([round_walks], dtype=torch.int64, device=dev)
                     round_walks = int(comm.all_gather(mine).min())
-            round_walks = max(1, min(round_walks, -(-walks_per_epoch // comm.world)))
-            trainer.round_capacity = round_walks
-            stride = comm.world * round_walks
+            # round_walks: the walks whose pairs a rank (a stripe) holds at once; a round is
+            # `lanes` times that
+            round_walks = max(1, min(round_walks, -(-walks_per_epoch // lanes)))
+            stride = lanes * round_walks
+            trainer.round_capacity = stride if stripes > 1 else round_walks
             n_rounds = (walks_per_epoch + stride - 1) // stride
             lr = np.float32(self.learning_rate)
             start = time.perf_counter()
@@ -282,12 +295,16 @@ class _WalkBasedModel:
             for epoch in range(self.epochs):
                 for r in range(n_rounds):  # every rank joins every round (collectives inside)
                     first = r * stride
+                    share = stride if comm.world == 1 else round_walks  # one rank: all of them
                     mine = first + comm.rank * round_walks
-                    n = max(0, min(round_walks, walks_per_epoch - mine))
+                    n = max(0, min(share, walks_per_epoch - mine))
 
-                    def make(epoch=epoch, mine=mine, n=n):
+                    def make(epoch=epoch, mine=mine, n=n, share=share):
+                        if comm.world == 1:
+                            return ops.walks(csr, wp, self.random_state, epoch, mine, n,
+                                             device=device)
                         # ranks with fewer walks left pad with ended (sentinel) walks
-                        walks = torch.full((round_walks, L), -1, dtype=torch.int32, device=dev)
+                        walks = torch.full((share, L), -1, dtype=torch.int32, device=dev)
                         if n:
                             walks[:n] = ops.walks(csr, wp, self.random_state, epoch, mine, n,
                                                   device=device)
@@ -300,7 +317,8 @@ class _WalkBasedModel:
             torch.cuda.synchronize(dev)
             self.last_seconds = time.perf_counter() - start
         self.last_stats = ops.stats_read(csr, device)
-        self.last_plan = {"world": comm.world, "parts": trainer.parts, "slices": trainer.slices}
+        self.last_plan = {"world": comm.world, "parts": trainer.parts, "slices": trainer.slices,
+                          "stripes": trainer.stripes}
         if self.verbose and comm.rank == 0:
             st, secs = self.last_stats, max(self.last_seconds, 1e-9)
             print(

@@ -211,15 +211,22 @@ def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, fi
 
 
 def block_step(graph: CSRGraph, tp, plan, keys, vals, cell_offsets, alias, cell_rows, central,
-               context, block_id: int, part: int, seed: int, epoch: int, lr: float):
-    """Train the pairs of one context part (``gn2v_block_step``; tables updated in place)."""
+               context, block_id: int, part: int, seed: int, epoch: int, lr: float,
+               whole_central: bool = False):
+    """Train the pairs of one context part (``gn2v_block_step``; tables updated in place).
+    ``whole_central``: ``central`` is the whole table [n_nodes, ld] and the plan's rank one of its
+    ``world`` centre stripes (one GPU training the stripes one after the other)."""
     dev = central.device
     dg = graph.device_graph(dev.index or 0)
     assert central.is_contiguous() and context.is_contiguous()
     assert central.shape[1] == tp.ld and context.shape[1] == tp.ld
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    c_ptr, c_ld = ptr(central), 0
+    if whole_central:
+        assert central.shape[0] == graph.get_number_of_nodes()
+        c_ptr, c_ld = c_ptr + plan.rank * tp.ld * 4, plan.world * tp.ld
     io = _lib.BlockIO(ptr(keys), ptr(vals), ptr(cell_offsets), ptr(alias), ptr(cell_rows),
-                      ptr(central), ptr(context), block_id, part)
+                      c_ptr, ptr(context), block_id, part, c_ld)
     _lib.check(_lib.lib().gn2v_block_step(dg.handle, C.byref(tp), C.byref(plan), C.byref(io),
                                           seed, epoch, lr, _stream(dev)))
 

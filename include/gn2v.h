@@ -114,6 +114,8 @@ typedef struct {
     uint32_t walk_launches;
     uint32_t block_parts;  /* plan of the block path when gn2v_train took it, else 0    */
     uint32_t block_slices;
+    uint32_t block_stripes; /* centre stripes of that fit (gn2v_train_blocks), else 0   */
+    uint32_t reserved;
 } gn2v_stats;
 
 typedef struct gn2v_graph gn2v_graph;
@@ -223,7 +225,7 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
 typedef struct {
     uint32_t world;       /* ranks = central partitions                                      */
     uint32_t rank;
-    uint32_t parts;       /* context parts, a multiple of world                               */
+    uint32_t parts;       /* context parts (a multiple of world when they travel between ranks) */
     uint32_t slices;      /* 1 .. 16                                                          */
     uint32_t walk_length;
     uint32_t window;      /* window_size                                                      */
@@ -291,10 +293,16 @@ typedef struct {
     const uint64_t *d_cell_offsets;  /* [cells + 1] (gn2v_block_count)                         */
     const uint64_t *d_alias;         /* gn2v_block_alias; unused without GN2V_TRAIN_SCALE_FREE */
     const uint64_t *d_cell_rows;
-    float *d_central;                /* this rank's central partition f32[rows][ld]            */
+    float *d_central;                /* this rank's central partition f32[rows][central_ld]    */
     float *d_context;                /* context part `part`, resident here, f32[rows][ld]      */
     uint64_t block_id;               /* RNG stream of the negatives: unique per (round, rank)  */
     uint32_t part;
+    uint64_t central_ld;             /* floats between consecutive rows of the central partition;
+                                        0 = ld.  One GPU that trains the `world` centre stripes
+                                        of a plan one after the other ("virtual ranks": the runs
+                                        of equal centre grow `world`-fold at the same memory)
+                                        keeps the whole table f32[n_nodes][ld] and passes
+                                        d_central = table + rank * ld, central_ld = world * ld   */
 } gn2v_block_io;
 
 /* The fused gather -> dot -> sigmoid -> scatter-add step over the pairs of one part: a wavefront
@@ -326,14 +334,19 @@ int gn2v_block_round_walks(uint64_t free_bytes, uint32_t walk_length, uint32_t w
 
 /* The whole fit (same contract as gn2v_train: caller-allocated tables f32[n_nodes][ld], filled on
  * return) through the block path on one GPU: automatic plan, alias tables, rounds of
- * `round_walks` walks (0 = automatic: gn2v_block_round_walks of the free HBM), per round walk
- * generation, pair extraction + sort and one gn2v_block_step per part.  The central table is
- * trained in place; the contextual table lives in `parts` buffers of the library's own during
- * the fit and is written to d_contextual at the end.  gn2v_train calls this for SkipGram on
- * graphs of >= 2^16 nodes. */
+ * stripes x round_walks walks, per round walk generation and, for each of the `stripes` centre
+ * stripes in turn (stripe j: the centres c with c % stripes == j -- what `stripes` ranks do side
+ * by side): extraction + sort of the stripe's pairs from all the round's walks and one
+ * gn2v_block_step per part on the stripe's rows of the central table (gn2v_block_io.central_ld).
+ * round_walks = the walks whose pairs are held at once (0 = automatic: gn2v_block_round_walks of
+ * the free HBM); stripes 0 = automatic (8): the pairs of a centre meet in runs `stripes` times as
+ * long at the memory of one round_walks.  The central table is trained in place; the contextual
+ * table lives in `parts` buffers of the library's own during the fit and is written to
+ * d_contextual at the end.  gn2v_train calls this for SkipGram on graphs of >= 2^16 nodes. */
 int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
                       uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
-                      float *d_central, float *d_contextual, gn2v_stats *stats, void *stream);
+                      uint32_t stripes, float *d_central, float *d_contextual, gn2v_stats *stats,
+                      void *stream);
 
 /* ---- GloVe: the third model of the reference's walk-based table (embedders/ensmallen_embedders/
  * node2vec.py:16-26 "Node2Vec GloVe" / "DeepWalk GloVe": models.GloVe; wrapper kwargs

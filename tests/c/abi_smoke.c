@@ -20,7 +20,8 @@ int main(void) {
     if (strstr(gn2v_last_error(), "NULL") == NULL) return 7;
     gn2v_block_plan plan;
     memset(&plan, 0, sizeof plan);
-    printf("gn2v %u: sizeof(gn2v_block_plan) = %zu, sizeof(gn2v_stats) = %zu\n", gn2v_version(),
-           sizeof plan, sizeof(gn2v_stats));
+    printf("gn2v %u: sizeof(gn2v_block_plan) = %zu, sizeof(gn2v_stats) = %zu, "
+           "sizeof(gn2v_block_io) = %zu\n",
+           gn2v_version(), sizeof plan, sizeof(gn2v_stats), sizeof(gn2v_block_io));
     return 0;
 }

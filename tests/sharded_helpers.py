@@ -104,15 +104,17 @@ class OracleBlockBackend:
         return keys, vals, offsets, len(keys)
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
-             epoch, lr):
+             epoch, lr, whole_central=False):
         keys, vals, offsets, n_pairs = prepared
         if n_pairs == 0:
             return
-        c = np.ascontiguousarray(central.numpy())
+        # a centre stripe of the whole table is handed to the oracle as the partition it is
+        mine = central[plan.rank::plan.world] if whole_central else central
+        c = np.ascontiguousarray(mine.numpy())
         x = np.ascontiguousarray(context.numpy())
         O.block_step(self.og, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, block_id,
                      part, seed, epoch, lr)
-        central.copy_(torch.from_numpy(c))
+        mine.copy_(torch.from_numpy(c))
         context.copy_(torch.from_numpy(x))
 
 

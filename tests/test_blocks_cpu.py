@@ -35,12 +35,13 @@ def _otp(flags=1):
     return O.TrainParams(0, D, D, 1, K, W, 0.02, 0.9, 6.0, flags, D ** -0.5)
 
 
-def _train(comm, rounds=2, walks_per_round=9, nodes=34, slices=1, parts=None, record=4):
+def _train(comm, rounds=2, walks_per_round=9, nodes=34, slices=1, parts=None, record=4,
+           stripes=1):
     g = _graph(nodes)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     tr = BlockPartitionedTrainer(g, _otp(), D, D, 42, D ** -0.5, comm, "cpu", walk_length=L,
                                  window=W, backend=OracleBlockBackend(g), slices=slices,
-                                 parts=parts, record=record)
+                                 parts=parts, record=record, stripes=stripes)
     wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
     trained = 0
     for r in range(rounds):
@@ -197,6 +198,44 @@ def test_world_one_trainer_is_the_plain_sequence_of_block_steps():
     rx[0::2], rx[1::2] = parts
     assert np.array_equal(c, rc) and np.array_equal(x, rx)
     assert trained == total == 2 * 9 * (2 * W * L - W * (W + 1)) and held == [0, 1]
+
+
+@pytest.mark.parametrize("stripes,parts,slices", [(2, 2, 1), (3, 2, 2), (8, 1, 1)])
+def test_centre_stripes_are_the_sequence_of_block_steps_of_that_many_ranks(stripes, parts, slices):
+    """One GPU, `stripes` centre stripes trained one after the other (BlockPartitionedTrainer
+    stripes=): per round, for every stripe j, the pairs whose centre is j mod stripes are
+    extracted from ALL the round's walks with the plan of rank j of a world of `stripes`, and
+    trained part by part on the stripe's rows of the one central table; RNG stream
+    round * stripes + j, the rotation of the parts simply continuing."""
+    (c, x), trained, held = _train(LoopbackComm(), nodes=97, parts=parts, slices=slices,
+                                   stripes=stripes)
+    g = _graph(97)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    alias, cell_rows, _ = O.block_alias(og, parts, slices)
+    rc = O.init_table(97, D, D, 42, 0, D ** -0.5)
+    rx = O.init_table(97, D, D, 42, 1, D ** -0.5)
+    ctx = [np.ascontiguousarray(rx[p::parts]) for p in range(parts)]
+    wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
+    total, episode = 0, 0
+    for r in range(2):
+        walks = O.walks(og, wp, 42, 0, r * 9, 9)
+        for j in range(stripes):
+            plan = O.block_plan(97, stripes, j, parts, slices, L, W, 1, 4)
+            keys, vals, offsets = O.block_extract(og, plan, walks, 42, 0, r * 9)
+            mine = np.ascontiguousarray(rc[j::stripes])
+            for _ in range(parts):
+                p = episode % parts
+                total += O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows,
+                                      mine, ctx[p], r * stripes + j, p, 42, 0, 0.02)
+                episode += 1
+            rc[j::stripes] = mine
+    for p in range(parts):
+        rx[p::parts] = ctx[p]
+    assert np.array_equal(c, rc) and np.array_equal(x, rx)
+    # last_round counts the pairs of a whole round (all stripes); two rounds were trained
+    assert trained == total == 2 * 9 * (2 * W * L - W * (W + 1)) and held == list(range(parts))
+    with pytest.raises(ValueError):
+        run_ranks(2, lambda comm: _train(comm, nodes=97, stripes=2))
 
 
 @pytest.mark.parametrize("world,nodes,per_rank", [(2, 34, 2), (3, 34, 2), (4, 97, 2), (2, 97, 4),

@@ -33,8 +33,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.WalkParams) == 32
     assert C.sizeof(_lib.TrainParams) == 48
-    assert C.sizeof(_lib.Stats) == 56
-    assert C.sizeof(_lib.BlockPlan) == 13 * 4 and C.sizeof(_lib.BlockIO) == 72
+    assert C.sizeof(_lib.Stats) == 64
+    assert C.sizeof(_lib.BlockPlan) == 13 * 4 and C.sizeof(_lib.BlockIO) == 80
     text = open(HEADER).read()
     for name, value in (("GN2V_TRAIN_SCALE_FREE", _lib.TRAIN_SCALE_FREE),
                         ("GN2V_TRAIN_DOWNSAMPLE", _lib.TRAIN_DOWNSAMPLE),
@@ -142,3 +142,4 @@ def test_header_is_valid_c_and_a_plain_c_program_can_call_the_library(tmp_path):
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
     assert f"sizeof(gn2v_stats) = {C.sizeof(_lib.Stats)}" in res.stdout
     assert f"sizeof(gn2v_block_plan) = {C.sizeof(_lib.BlockPlan)}" in res.stdout
+    assert f"sizeof(gn2v_block_io) = {C.sizeof(_lib.BlockIO)}" in res.stdout

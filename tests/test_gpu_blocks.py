@@ -322,18 +322,20 @@ def test_central_row_collects_every_gradient_from_all_xcds(d):
     assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
 
 
-def _trainer_run(comm, graph, use_oracle, slices=1, rounds=2, walks_per_round=11, record=4):
+def _trainer_run(comm, graph, use_oracle, slices=1, rounds=2, walks_per_round=11, record=4,
+                 stripes=1, parts=None):
     og = O.OracleGraph(graph.row_ptr, graph.col_idx)
     if use_oracle:
         tp = O.TrainParams(0, D, D, 1, K, W, 0.02, 0.9, 6.0, 1, D ** -0.5)
         tr = BlockPartitionedTrainer(graph, tp, D, D, 42, D ** -0.5, comm, "cpu", walk_length=L,
                                      window=W, backend=OracleBlockBackend(graph), slices=slices,
-                                     record=record)
+                                     record=record, stripes=stripes, parts=parts)
         dev = "cpu"
     else:
         tp = ops.train_params(0, D, K, W, flags=1 | DET)
         tr = BlockPartitionedTrainer(graph, tp, D, D, 42, D ** -0.5, comm, "cuda:0",
-                                     walk_length=L, window=W, slices=slices, record=record)
+                                     walk_length=L, window=W, slices=slices, record=record,
+                                     stripes=stripes, parts=parts)
         dev = "cuda:0"
     wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
     trained = []
@@ -362,6 +364,49 @@ def test_block_trainer_with_simulated_ranks_equals_oracle(world, nodes, slices):
     assert all(np.array_equal(gpu[0][0][0], gpu[r][0][0]) for r in range(world))
     for rnd in range(2):  # every pair of the round is trained exactly once, somewhere
         assert sum(gpu[r][1][rnd] for r in range(world)) == world * 11 * per_walk
+
+
+@pytest.mark.parametrize("stripes,nodes,parts,slices", [(2, 34, 2, 1), (3, 97, 2, 2),
+                                                        (8, 203, 4, 8)])
+def test_centre_stripes_on_one_gpu_equal_the_oracle(stripes, nodes, parts, slices):
+    """`stripes` centre stripes trained one after the other on the whole central table
+    (gn2v_block_io.central_ld = stripes * ld): the deterministic kernel against the oracle-backed
+    trainer running the same schedule (restated step by step in tests/test_blocks_cpu.py)."""
+    g = E.karate_club() if nodes == 34 else _ba(nodes)
+    gpu = _trainer_run(LoopbackComm(), g, False, slices, stripes=stripes, parts=parts)
+    ref = _trainer_run(LoopbackComm(), g, True, slices, stripes=stripes, parts=parts)
+    assert gpu[0][0].shape == (nodes, D)
+    assert np.abs(gpu[0][0] - ref[0][0]).max() < 1e-5 and np.abs(gpu[0][1] - ref[0][1]).max() < 1e-5
+    assert gpu[1] == ref[1] == [11 * (2 * W * L - W * (W + 1))] * 2  # every pair of a round once
+    plain = _trainer_run(LoopbackComm(), g, False, slices, parts=parts)
+    assert np.abs(gpu[0][0] - plain[0][0]).max() > 1e-4  # another order of the same pairs
+
+
+def test_centre_stripes_keep_the_quality_and_lengthen_the_runs():
+    """BA 200 k nodes, production update mode: 8 centre stripes vs none on the same walks -- the
+    link quality of the plain trainer, every pair trained once."""
+    g = E.barabasi_albert(200_000, 8, 42)
+    d, w = 64, 4
+    wp = ops.walk_params(64, 1, 1.0, 1.0)
+    total, per_round = 1 << 21, 1 << 20
+    tp = ops.train_params(0, d, 5, w, flags=1)
+    gen = torch.Generator(device="cuda")
+    aucs = {}
+    for stripes in (1, 8):
+        tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
+                                     walk_length=64, window=w, stripes=stripes)
+        tr.round_capacity = per_round
+        rounds = [(lambda first=first: ops.walks(g, wp, 42, 0, first, per_round), 42, 0, 0.025, first)
+                  for first in range(0, total, per_round)]
+        ops.stats_reset(g)
+        tr.run(rounds, overlap=False)
+        torch.cuda.synchronize()
+        assert ops.stats_read(g)["pairs"] == total * (2 * w * 64 - w * (w + 1))
+        bc, bx = tr.gather_full()
+        gen.manual_seed(1)
+        aucs[stripes] = _auc(g, bc, bx, gen)
+        assert bool(torch.isfinite(bc).all()) and bool(torch.isfinite(bx).all())
+    assert aucs[1] > 0.93 and aucs[8] > aucs[1] - 0.02, aucs
 
 
 def test_eight_simulated_gpus_reach_single_gpu_quality():
@@ -491,7 +536,7 @@ def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
 
 
 def test_bad_plans_are_refused(karate):
-    for kw in (dict(world=2, rank=2, parts=4), dict(world=2, rank=0, parts=3),
+    for kw in (dict(world=2, rank=2, parts=4), dict(world=2, rank=0, parts=0),
                dict(world=1, rank=0, parts=1, slices=17), dict(world=1, rank=0, parts=2000),
                dict(world=1, rank=0, parts=1, record=33), dict(world=1, rank=0, parts=1, hot_lo=3, hot_hi=5)):
         args = dict(slices=1, walk_length=8, window=2)
@@ -505,6 +550,12 @@ def test_bad_plans_are_refused(karate):
         ops.block_step(karate, tp, plan, c, c, c, None, None, c, c, 0, 0, 1, 0, 0.01)
     with pytest.raises(_lib.Gn2vError, match="part out of range"):
         ops.block_step(karate, tp, plan, c, c, c, c, c, c, c, 0, 5, 1, 0, 0.01)
+    # parts that travel between ranks must divide evenly: the trainer's rule, not the kernel's
+    from sharded_helpers import run_ranks
+
+    with pytest.raises(ValueError, match="multiple"):
+        run_ranks(2, lambda comm: BlockPartitionedTrainer(
+            karate, tp, 8, 8, 1, 0.3, comm, "cuda:0", walk_length=8, window=2, parts=3))
 
 
 def test_one_rank_rccl_group_equals_loopback():
@@ -533,7 +584,7 @@ def test_gn2v_train_block_path_equals_the_python_trainer():
               deterministic=True, verbose=False)
     m_c = E.models.SkipGram(block_path=True, **kw)
     c1, x1, st = m_c.fit_transform_device(g)
-    assert m_c.last_plan == {"world": 1, "parts": 1, "slices": 1}
+    assert m_c.last_plan == {"world": 1, "parts": 1, "slices": 1, "stripes": 8}
     m_py = E.models.SkipGram(**kw)
     c2, x2 = m_py.fit_transform_blocks(g, LoopbackComm())
     assert st["pairs"] == m_py.last_stats["pairs"] == 3 * 900 * (2 * 3 * 16 - 3 * 4)
@@ -547,11 +598,40 @@ def test_gn2v_train_block_path_equals_the_python_trainer():
     assert float((c1 - c3).abs().max()) > 1e-4
 
 
+@pytest.mark.parametrize("stripes,round_walks", [(1, 200), (2, 150), (4, 100), (8, 0)])
+def test_gn2v_train_blocks_with_stripes_equals_the_python_trainer(stripes, round_walks):
+    """``gn2v_train_blocks`` called directly with explicit centre stripes and round sizes
+    (several rounds per epoch, the last one short) in its deterministic schedule == the Python
+    trainer running the same stripes and rounds (which the tests above tie to the oracle)."""
+    import ctypes as C
+
+    g = _ba(300, 4)
+    kw = dict(embedding_size=12, epochs=2, walk_length=16, iterations=3, window_size=3,
+              number_of_negative_samples=4, learning_rate=0.05, learning_rate_decay=0.8,
+              deterministic=True, verbose=False)
+    m = E.models.SkipGram(block_path=True, **kw)
+    dg = g.device_graph(0)
+    c1 = torch.empty((300, m.padded_size), dtype=torch.float32, device="cuda")
+    x1 = torch.empty_like(c1)
+    wp, tp, stats = m.walk_params(), m.train_params(), _lib.Stats()
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().gn2v_stats_reset(dg.handle, stream))
+    _lib.check(_lib.lib().gn2v_train_blocks(dg.handle, C.byref(wp), C.byref(tp), 42, 0, round_walks,
+                                           stripes, c1.data_ptr(), x1.data_ptr(), C.byref(stats),
+                                           stream))
+    assert stats.block_stripes == stripes and stats.pairs == 2 * 900 * (2 * 3 * 16 - 3 * 4)
+    m_py = E.models.SkipGram(**kw)
+    c2, x2 = m_py.fit_transform_blocks(g, LoopbackComm(), round_walks=round_walks or None,
+                                       stripes=stripes)
+    assert m_py.last_plan["stripes"] == stripes and m_py.last_stats["pairs"] == stats.pairs
+    assert float((c1 - c2).abs().max()) < 1e-5 and float((x1 - x2).abs().max()) < 1e-5
+
+
 def test_gn2v_train_takes_the_block_path_by_itself_from_two_to_the_sixteen_nodes():
     small, large = E.barabasi_albert(60_000, 5, 1), E.barabasi_albert(70_000, 5, 1)
     kw = dict(embedding_size=16, epochs=1, iterations=1, walk_length=16, window_size=3,
               verbose=False)
-    for g, plan in ((small, None), (large, {"world": 1, "parts": 1, "slices": 2})):
+    for g, plan in ((small, None), (large, {"world": 1, "parts": 1, "slices": 2, "stripes": 8})):
         for cls in (E.models.SkipGram, E.models.CBOW):
             m = cls(**kw)
             c, x, st = m.fit_transform_device(g)
