@@ -479,7 +479,9 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     // the pairs of ALL the round's walks before stripe j + 1 -- what V ranks do side by side.  A
     // pass holds 1 / V of the round's pairs, so a round can be V times as long at the same
     // memory, and a centre's pairs meet in runs V times as long.
-    uint32_t V = stripes ? stripes : 8;
+    // Off unless asked for: the stripes of a round are trained one after the other, not side by
+    // side as ranks would, and that coarser order costs link quality.
+    uint32_t V = stripes ? stripes : 1;
     while (V > 1 && n / V < 2) V /= 2;
 
     gn2v_block_plan plan{};

@@ -238,7 +238,7 @@ class _WalkBasedModel:
         GPUs (``distributed.BlockPartitionedTrainer``).  Every rank returns the full
         ``(central, contextual)`` device tensors [N, padded_size].  With one rank
         (``LoopbackComm``) this is the Python form of ``gn2v_train_blocks``: ``stripes`` centre
-        stripes (None = 8, as there) play the ranks one after the other."""
+        stripes (None = 1 = none, as there) play the ranks one after the other."""
         import torch
 
         from . import ops
@@ -258,7 +258,7 @@ class _WalkBasedModel:
         if comm.world > 1:
             stripes = 1
         else:
-            stripes = 8 if stripes is None else max(1, int(stripes))
+            stripes = 1 if stripes is None else max(1, int(stripes))
             while stripes > 1 and csr.get_number_of_nodes() // stripes < 2:
                 stripes //= 2
         lanes = comm.world if comm.world > 1 else stripes  # ranks, or the stripes that play them

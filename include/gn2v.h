@@ -339,8 +339,10 @@ int gn2v_block_round_walks(uint64_t free_bytes, uint32_t walk_length, uint32_t w
  * by side): extraction + sort of the stripe's pairs from all the round's walks and one
  * gn2v_block_step per part on the stripe's rows of the central table (gn2v_block_io.central_ld).
  * round_walks = the walks whose pairs are held at once (0 = automatic: gn2v_block_round_walks of
- * the free HBM); stripes 0 = automatic (8): the pairs of a centre meet in runs `stripes` times as
- * long at the memory of one round_walks.  The central table is trained in place; the contextual
+ * the free HBM); stripes 0 = 1 (none).  With stripes the pairs of a centre meet in runs `stripes`
+ * times as long at the memory of one round_walks (faster: DESIGN.md 7.4), but the stripes of a
+ * round are trained one after the other, not side by side as ranks would be, which costs link
+ * quality when a fit has few rounds: an option, not the default.  The central table is trained in place; the contextual
  * table lives in `parts` buffers of the library's own during the fit and is written to
  * d_contextual at the end.  gn2v_train calls this for SkipGram on graphs of >= 2^16 nodes. */
 int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,

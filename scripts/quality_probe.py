@@ -55,6 +55,7 @@ if __name__ == "__main__":
     ap.add_argument("--modes", default="write_through,write_back,atomic")
     ap.add_argument("--hot-band", default="0:0", help="blocks modes: lo:hi (see bench.py)")
     ap.add_argument("--round-walks", type=int, default=1 << 19, help="blocks modes: walks per round")
+    ap.add_argument("--stripes", type=int, default=1, help="blocks modes: centre stripes")
     a = ap.parse_args()
     g = E.barabasi_albert(a.nodes, a.m, 42)
     n, d = g.get_number_of_nodes(), a.d
@@ -76,7 +77,8 @@ if __name__ == "__main__":
             tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
                                          walk_length=128, window=5, parts=parts, slices=slices,
                                          record=record,
-                                         hot_band=tuple(int(v) for v in a.hot_band.split(":")))
+                                         hot_band=tuple(int(v) for v in a.hot_band.split(":")),
+                                         stripes=a.stripes)
             ops.stats_reset(g)
             t0 = time.time()
             lr, rounds = a.lr, []

@@ -584,7 +584,7 @@ def test_gn2v_train_block_path_equals_the_python_trainer():
               deterministic=True, verbose=False)
     m_c = E.models.SkipGram(block_path=True, **kw)
     c1, x1, st = m_c.fit_transform_device(g)
-    assert m_c.last_plan == {"world": 1, "parts": 1, "slices": 1, "stripes": 8}
+    assert m_c.last_plan == {"world": 1, "parts": 1, "slices": 1, "stripes": 1}
     m_py = E.models.SkipGram(**kw)
     c2, x2 = m_py.fit_transform_blocks(g, LoopbackComm())
     assert st["pairs"] == m_py.last_stats["pairs"] == 3 * 900 * (2 * 3 * 16 - 3 * 4)
@@ -631,7 +631,7 @@ def test_gn2v_train_takes_the_block_path_by_itself_from_two_to_the_sixteen_nodes
     small, large = E.barabasi_albert(60_000, 5, 1), E.barabasi_albert(70_000, 5, 1)
     kw = dict(embedding_size=16, epochs=1, iterations=1, walk_length=16, window_size=3,
               verbose=False)
-    for g, plan in ((small, None), (large, {"world": 1, "parts": 1, "slices": 2, "stripes": 8})):
+    for g, plan in ((small, None), (large, {"world": 1, "parts": 1, "slices": 2, "stripes": 1})):
         for cls in (E.models.SkipGram, E.models.CBOW):
             m = cls(**kw)
             c, x, st = m.fit_transform_device(g)

@@ -165,7 +165,7 @@ def test_large_graphs_are_fitted_through_the_block_path_on_one_gpu():
     res = m.fit_transform(g, return_dataframe=False).get_all_node_embedding()
     assert res[0].shape == (400_000, 32) and res[1].shape == (400_000, 32)
     assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
-    assert m._model.last_plan == {"world": 1, "parts": 1, "slices": 8, "stripes": 8}  # gn2v_train's own choice
+    assert m._model.last_plan == {"world": 1, "parts": 1, "slices": 8, "stripes": 1}  # gn2v_train's own choice
     assert m.get_last_stats()["pairs"] == 400_000 * (2 * 3 * 32 - 3 * 4)
     init = ops.init_table(400_000, 32, 42, 0, 32 ** -0.5).cpu().numpy()
     assert np.abs(res[0] - init).max() > 1e-3
