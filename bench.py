@@ -13,14 +13,18 @@ tables are resident in HBM before the timed region.
 
 N > 1: one process per GPU, CSR replicated, every rank generates its own slice of the walk ids
 (weak scaling: per-GPU work fixed).  The central table is striped over the ranks (node id % N), the
-contextual table over 2 N parts that travel round the ranks: in every episode a GPU trains the
+contextual table over P N parts (P >= 2 per rank) that travel round the ranks: in every episode a GPU trains the
 pairs (centre it owns, context in the resident part) with negatives from that part while the part
 it just finished and the part it needs next are in flight (RCCL send / receive).  The round's walks
 are all-gathered (512 B per walk) and every rank extracts and sorts its own pairs on the device,
 on a second stream while the previous round trains.  No row is ever shared, so N GPUs compute
 exactly what the single-process simulation of the tests computes.  See DESIGN.md "Multi-GPU".
 
-`--model cbow` times the CBOW kernel on the same workload (unit: centres/s).
+`--model cbow` times the CBOW kernel on the same workload (unit: centres/s; with N > 1 as N
+independent replicas: CBOW does not shard).  Measurement aids, one GPU:
+`--phantom-world N` runs one rank of an N-GPU job with its true geometry and no fabric (the line
+says so and is not the benchmark's value); `--stripes V` the optional centre stripes of
+DESIGN.md 7.4; GN2V_BENCH_MEMLOG=1 logs the allocator's state around the phases.
 
 Prints ONE JSON line on rank 0.
 """
