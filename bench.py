@@ -3,6 +3,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` (N > 1) outside a torch.distributed job starts that job itself: the
+parent process -- which never touches HIP or torch -- runs the second line as a child process
+with `--master-addr 127.0.0.1` and a free port, relays rank 0's JSON line and exits with the
+job's status.
+
 Workload (the graph BASELINE.json's target is quoted on): seeded
 Barabasi-Albert graph, 10 M nodes / 100 M edges, Node2Vec SkipGram with the reference's default
 hyper-parameters (walk_length 128, window 5, 10 negatives, return_weight 0.25, explore_weight 4;
@@ -68,12 +73,13 @@ def parse():
                          "XCD-exclusive cells); single: the walk-ordered kernel, 1 GPU only")
     ap.add_argument("--round-walks", type=int, default=0,
                     help="blocks: walks per rank per round (every context part visits every rank "
-                         "once per round; a round may span several steps: 2^22 walks = 84 GB of "
-                         "sorted pairs + sort buffer, kernel 0.92 of the roofline against 0.82 at "
-                         "2^20, 0.96 at 2^23).  0 = gn2v_block_round_walks: the largest power of "
-                         "two <= 2^23 whose pair buffers fit three quarters of the free HBM (bench "
-                         "graph: 2^23 on one GPU, 2^22 with two rounds in flight on several; "
-                         "100 M nodes, 64-bit keys: 2^21)")
+                         "once per round; a round may span several steps; the longer, the more "
+                         "pairs of a centre meet in a cell: kernel 0.82 / 0.92 / 0.96 of the "
+                         "roofline at 2^20 / 2^22 / 2^23).  0 = gn2v_block_round_plan: 2^23 on the "
+                         "bench graph")
+    ap.add_argument("--group-parts", type=int, default=0,
+                    help="blocks: parts whose pairs are extracted, sorted and held at a time "
+                         "(8 B per pair; 0 = gn2v_block_round_plan: at least four groups per round)")
     ap.add_argument("--parts", type=int, default=None,
                     help="blocks: context parts (default 1 on one GPU, 2 x world otherwise)")
     ap.add_argument("--slices", type=int, default=None,
@@ -176,28 +182,31 @@ def usable_cores() -> int:
     return cores
 
 
-def committed_traffic(config, update_mode):
-    """(HBM bytes per algorithmic byte, file) of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/*_pmc.json, made by scripts/profile_bench.sh + summarize_profiles.py) when they were
-    taken on this very workload; None otherwise (counters cannot be read from inside the run)."""
+def committed_traffic(traffic_key):
+    """((HBM bytes per algorithmic byte, file), None) of the dominant kernel from the committed
+    rocprofv3 --pmc passes (profiles/*_pmc.json, made by scripts/profile_bench.sh +
+    summarize_profiles.py) when they were taken on this very workload and schedule
+    (``config.traffic_key``); (None, reason) otherwise -- counters cannot be read from inside the
+    run, and a line without its traffic figure must say why."""
     import glob
 
-    best = None
+    best, seen = None, []
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
-        same = (rec.get("config", {}).get("workload") == config["workload"]
-                and rec.get("config", {}).get("walks_per_launch") == config["walks_per_launch"]
-                and rec.get("config", {}).get("parallelism") == config["parallelism"]
-                and rec.get("config", {}).get("update_mode") == update_mode)
-        if same:
+        key = rec.get("config", {}).get("traffic_key")
+        seen.append(f"{os.path.basename(path)}: {key}")
+        if key == traffic_key:
             # per algorithmic byte, so that launches of another size (a run whose steps do not
             # fill whole rounds) are priced by what they process
             best = (rec["hbm_traffic_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"],
                     os.path.basename(path))
-    return best
+    if best is not None:
+        return best, None
+    return None, (f"no committed profiles/*_pmc.json was taken on traffic_key {traffic_key!r} "
+                  f"(run scripts/profile_bench.sh on this command line); found: {seen}")
 
 
 def cpu_baseline(graph, args, central, contextual, seconds):
@@ -245,8 +254,38 @@ def cpu_baseline(graph, args, central, contextual, seconds):
     }
 
 
+def launch_job(args):
+    """`bench.py --gpus N` outside a torch.distributed job: run it as the job the contract names
+    (one process per GPU), relay rank 0's JSON line, return the job's status.  This process never
+    initialises HIP, torch.cuda or RCCL: the workers are fresh children, nothing is re-exec'd."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last_json = None
+    for out_line in proc.stdout:
+        if out_line.lstrip().startswith("{"):
+            last_json = out_line.strip()
+        else:
+            sys.stderr.write(out_line)  # RCCL banners and the like
+    status = proc.wait()
+    if last_json is not None:
+        print(last_json, flush=True)
+    return status
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_job(args))
     import torch
 
     import embiggen_amd as E
@@ -256,7 +295,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the job was launched with a "
+                         "different number of processes than --gpus says")
     _lib.require_device()
     if args.share_device:
         local = 0
@@ -333,22 +373,25 @@ def main():
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local, ld=ld)
 
-    if blocks is not None and not args.round_walks:
-        from embiggen_amd.distributed import round_walks_within
+    if blocks is not None:
+        from embiggen_amd.distributed import round_plan
 
         torch.cuda.empty_cache()  # what building the graph left in the allocator's cache
-        # walks whose pairs fit the memory at once, times the stripes that share them
-        args.round_walks = stripes * round_walks_within(
-            torch.cuda.mem_get_info()[0], 128, 5, blocks.plan.key_bits, max(t_world, stripes),
-            overlap and stripes == 1)
-        if world > 1:  # every rank the same round size
-            agreed = torch.tensor([args.round_walks], dtype=torch.int64, device="cuda")
+        # walks one pass extracts from (times the stripes that share them) and the parts whose
+        # pairs are held at a time, from what is free now
+        auto_walks, auto_group = round_plan(
+            torch.cuda.mem_get_info()[0], n, 128, 5, max(t_world, stripes), blocks.parts,
+            blocks.slices, overlap and stripes == 1)
+        if world > 1:  # every rank the same round size and groups
+            agreed = torch.tensor([auto_walks, auto_group], dtype=torch.int64, device="cuda")
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-            args.round_walks = int(agreed)
-
-    if blocks is not None:
+            auto_walks, auto_group = int(agreed[0]), int(agreed[1])
+        if not args.round_walks:
+            args.round_walks = stripes * auto_walks
+        blocks.group_parts = max(1, min(args.group_parts or auto_group, blocks.parts))
         # warm-up and timed rounds share their buffers (a phantom rank is handed all ranks' walks)
-        blocks.round_capacity = args.round_walks * (t_world if phantom else 1)
+        blocks.round_capacity = (min(args.round_walks, (args.warmup + args.steps) * args.walks)
+                                 // stripes)
 
     def block_rounds(offset, total):
         """(make_walks, seed, epoch, lr, first_walk) of the rounds that train this rank's walks
@@ -371,7 +414,8 @@ def main():
 
     def run_steps(first_step, n_steps):
         if blocks is not None:
-            blocks.run(block_rounds(first_step * args.walks, n_steps * args.walks), overlap=overlap)
+            blocks.run(block_rounds(first_step * args.walks, n_steps * args.walks), overlap=overlap,
+                       timed=world > 1)
             return
         train = ops.cbow_step if cbow else ops.sgns_step
         for index in range(first_step, first_step + n_steps):
@@ -412,6 +456,7 @@ def main():
     memlog("after the timed steps")
     st = ops.stats_read(graph, local)
 
+    hop_waits = blocks.hop_wait_ms() if blocks is not None and world > 1 else []
     times = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     counts = torch.tensor([st["pairs"], st["walk_steps"], st["centres"]], dtype=torch.float64,
                           device="cuda")
@@ -448,9 +493,22 @@ def main():
                 fn()
             fence()
             ms.append((time.perf_counter() - t1) / reps * 1e3)
+        # per rank: HBM peak and what the compute stream really waited for its hops (HIP events
+        # around every pending.wait(): a hop had a whole episode to complete)
+        mine = torch.tensor([torch.cuda.max_memory_allocated() / 1e9,
+                             sum(hop_waits) / max(len(hop_waits), 1), max(hop_waits, default=0.0),
+                             sum(hop_waits)], dtype=torch.float64, device="cuda")
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
         comm_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                      "per_rank_pairs": per_rank_pairs,
+                     "per_rank_hbm_peak_gb": [round(float(r[0]), 2) for r in rows],
+                     "exposed_hop_wait_ms": {"hops_per_rank": len(hop_waits),
+                                             "mean_per_rank": [round(float(r[1]), 4) for r in rows],
+                                             "max_per_rank": [round(float(r[2]), 4) for r in rows],
+                                             "total_per_rank": [round(float(r[3]), 2) for r in rows]},
                      "walks_per_round_per_rank": min(args.round_walks, args.steps * args.walks),
+                     "parts_per_group": blocks.group_parts,
                      "walk_allgather_ms_alone": ms[0],
                      "walk_allgather_bytes_per_rank": wk.numel() * 4,
                      "half_partition_hop_ms_alone": ms[1],
@@ -477,6 +535,17 @@ def main():
             algo_bytes = st["pairs"] * (BYTES_PER_PAIR * d // 128)
             unit_name, value = "pairs/s", total_pairs / elapsed
         achieved = algo_bytes / (st["train_ms"] * 1e-3) / 1e9
+        # What this schedule moves when nothing hits in L2: every sample row (context + k
+        # negatives) read and written per pair, the central row once per RUN of equal centre (the
+        # block kernel counts its runs; the walk-ordered kernels hold the centre for its window)
+        row_bytes = 2 * 4 * ld
+        if cbow:
+            sched_bytes = algo_bytes
+        elif blocks is not None:
+            sched_bytes = row_bytes * (st["pairs"] * 11 + st["centres"])
+        else:
+            sched_bytes = row_bytes * (st["pairs"] * 11 + st["centres"])
+        scheduled = sched_bytes / (st["train_ms"] * 1e-3) / 1e9
         if cbow:
             kernel = "gn2v::cbow_cached_kernel" if n >= (1 << 16) else "gn2v::cbow_kernel"
         elif blocks is not None:
@@ -509,13 +578,20 @@ def main():
                             f"{args.explore_weight}, {args.walks} walks per step per GPU",
                 "update_mode": args.mode,
                 "walks_per_launch": args.batch if blocks is None else None,
+                # what a committed PMC profile must share with this run to price its traffic
+                "traffic_key": (f"ba{n}x{args.m}:d{d}:{args.model}:{args.mode}:"
+                                + (f"blocks{t_world}:{blocks.parts}x{blocks.slices}:"
+                                   f"round{min(args.round_walks, args.steps * args.walks)}"
+                                   + (f":stripes{stripes}" if stripes > 1 else "")
+                                   if blocks is not None else f"walk-ordered:{args.batch}")),
                 "parallelism": {
                     "single": (f"{world} independent replicas (CBOW does not shard), walk-ordered "
                                "kernel" if replicas else "1 GPU, walk-ordered kernel"),
                     "blocks": f"{t_world} GPU(s), central table striped over the ranks, contextual "
                               f"table in {blocks.parts if blocks else 0} travelling parts x "
                               f"{blocks.slices if blocks else 0} XCD slice(s) (no shared rows), rounds of "
-                              f"{min(args.round_walks, args.steps * args.walks)} walks per GPU"
+                              f"{min(args.round_walks, args.steps * args.walks)} walks per GPU "
+                              f"prepared {blocks.group_parts if blocks else 0} parts at a time"
                               + (f" trained in {stripes} centre stripes" if stripes > 1 else "")
                               + f", preparation {'overlapped' if overlap and stripes == 1 else 'in line'}",
                 }[mode],
@@ -528,12 +604,25 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": kernel,
+                # bandwidth as bandwidth (filled below from the committed PMC passes): bytes that
+                # really leave L2 per second; a fraction of the 8 TB/s peak, never above 1
+                "achieved_hbm": None,
+                "frac_hbm": None,
+                "traffic": None,
+                # SURVEY 8d's schedule-independent model (12 288 B per pair: every row of every
+                # pair read and written in HBM).  `frac` can exceed what the memory system moves
+                # -- even 1 -- when the schedule keeps the centre in registers and the XCD's L2
+                # serves hub rows: it prices work, `frac_hbm` prices bandwidth
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                # the same with the central row counted once per run of equal centre
+                "scheduled": scheduled,
+                "frac_scheduled": scheduled / HBM_PEAK_GBS,
+                "mean_centre_run": st["pairs"] / max(st["centres"], 1),
                 "algorithmic_bytes_per_launch": algo_bytes // launches,
+                "scheduled_bytes_per_launch": sched_bytes // launches,
                 "avg_launch_ms": launch_ms,
                 "launches": st["train_launches"],
             },
@@ -555,15 +644,21 @@ def main():
                                        "an RCCL hop while the training kernel holds the CUs"},
                 "note": "one rank of that world on one GPU, no fabric: value = this rank's pairs/s; "
                         "the walks of all ranks are generated here (in a real job 1/world of them)"}
-        pmc = committed_traffic(line["config"], args.mode)
+        pmc, why_not = committed_traffic(line["config"]["traffic_key"])
         if pmc is not None:
             ratio, source = pmc
             bytes_per_launch = ratio * (algo_bytes / launches)
-            line["roofline"]["traffic"] = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+            traffic = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+            line["roofline"]["traffic"] = traffic
+            line["roofline"]["achieved_hbm"] = traffic
+            line["roofline"]["frac_hbm"] = traffic / HBM_PEAK_GBS
             line["roofline"]["traffic_over_algorithmic"] = ratio
             line["roofline"]["traffic_bytes_per_launch"] = bytes_per_launch
             line["roofline"]["traffic_source"] = f"profiles/{source} (rocprofv3 --pmc FETCH_SIZE / " \
-                                                 "WRITE_SIZE, calibrated; same workload)"
+                                                 "WRITE_SIZE, calibrated; same workload and schedule, " \
+                                                 "rescaled by this run's launch time)"
+        else:
+            line["roofline"]["traffic_missing_reason"] = why_not
         if world == 1 and not args.no_cpu_baseline and not phantom:
             if blocks is not None:
                 central, contextual = blocks.gather_full()

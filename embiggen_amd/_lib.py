@@ -42,7 +42,7 @@ EXPORTS = [
     "gn2v_touch_rows",
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
     "gn2v_block_alias", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
-    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_auto_plan", "gn2v_block_round_walks",
+    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_auto_plan", "gn2v_block_round_plan", "gn2v_graph_xcds",
     "gn2v_train_blocks",
     "gn2v_stats_reset",
     "gn2v_stats_read",
@@ -105,13 +105,12 @@ class BlockPlan(C.Structure):
 
     _fields_ = [(name, C.c_uint32) for name in (
         "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
-        "row_bits", "flags", "hot_lo", "hot_hi", "key_bits")]
+        "row_bits", "flags", "hot_lo", "hot_hi", "key_bits", "ctx_bits")]
 
 
 class BlockIO(C.Structure):
     _fields_ = [
-        ("d_keys", C.c_void_p),
-        ("d_vals", C.c_void_p),
+        ("d_pairs", C.c_void_p),
         ("d_cell_offsets", C.c_void_p),
         ("d_alias", C.c_void_p),
         ("d_cell_rows", C.c_void_p),
@@ -120,10 +119,11 @@ class BlockIO(C.Structure):
         ("block_id", C.c_uint64),
         ("part", C.c_uint32),
         ("central_ld", C.c_uint64),
+        ("context_ld", C.c_uint64),
     ]
 
 
-BLOCK_WORK_WORDS = 9216
+BLOCK_WORK_WORDS = 16384
 
 
 class Stats(C.Structure):
@@ -138,7 +138,8 @@ class Stats(C.Structure):
         ("block_parts", C.c_uint32),
         ("block_slices", C.c_uint32),
         ("block_stripes", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("block_group_parts", C.c_uint32),
+        ("block_round_walks", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -223,14 +224,17 @@ def lib():
     L.gn2v_init_table_rows.argtypes = [vp, u64, u32, u32, u64, u32, f32, u64, u64, vp]
     L.gn2v_block_alias_temp_bytes.argtypes = [u64, C.POINTER(u64)]
     L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, vp, u64, vp]
-    L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, vp, vp]
-    L.gn2v_block_extract_temp_bytes.argtypes = [u64, u32, C.POINTER(u64)]
-    L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, vp, vp,
-                                     u64, vp, vp, vp, u64, vp]
+    L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, u32, u32, vp,
+                                   vp, vp]
+    L.gn2v_block_extract_temp_bytes.argtypes = [u64, C.POINTER(u64)]
+    L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, u32, u32,
+                                     vp, vp, u64, vp, vp, u64, vp]
+    L.gn2v_graph_xcds.argtypes = [vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),
                                   C.POINTER(BlockIO), u64, u64, f32, vp]
     L.gn2v_block_auto_plan.argtypes = [u64, u32, C.POINTER(u32), C.POINTER(u32)]
-    L.gn2v_block_round_walks.argtypes = [u64, u32, u32, u32, u32, u32, C.POINTER(u64)]
+    L.gn2v_block_round_plan.argtypes = [u64, u64, u32, u32, u32, u32, u32, u32, C.POINTER(u64),
+                                        C.POINTER(u32)]
     L.gn2v_train_blocks.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,
                                     u64, u32, vp, vp, C.POINTER(Stats), vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]

@@ -6,19 +6,26 @@
 // nodes are striped over `world` ranks (centre c lives on rank c % world, row c / world) and over
 // `parts` context parts (context x lives in part x % parts, row x / parts; parts is a multiple of
 // world and the parts travel round the ranks).  Inside a part the rows are striped once more over
-// `slices` (slice = row % slices): on MI355X one slice per XCD, so that every contextual row is
-// only ever touched by the workgroups of ONE XCD during a launch -- its L2 is then coherent for
-// that row, plain write-back stores are safe and hub rows (degree-proportional negatives) stay L2
-// resident.  cell = part * slices + slice.
+// `slices` (slice = row % slices).  When the number of slices is a multiple of the number of XCDs
+// (8 slices on an MI355X: one per XCD) every contextual row is only ever touched by the workgroups
+// of ONE XCD during a launch -- its L2 is then coherent for that row, plain write-back stores are
+// safe and hub rows (degree-proportional negatives) stay L2 resident.  With any other slice count
+// several XCDs share a slice and the rows are updated with write-through stores, like unsliced
+// parts (gn2v_block_step decides).  cell = part * slices + slice.
 //
-// Per round: every (centre, context) pair of the round's walks whose centre this rank owns is
-// emitted as key = cell << row_bits | centre_row, value = context row (two passes over the walks:
-// count, then write at scanned offsets -- the output is in walk / position / slot order, whatever
-// the launch geometry), one stable radix sort by key groups the pairs by cell and centre, and the
-// training kernel walks a cell in implicit records of `record` consecutive pairs: a wave keeps
-// the centre row in registers while the centre does not change, records are visited in a
-// golden-ratio stride order (a hub centre owns thousands of consecutive records; concurrent waves
-// must not all accumulate into the same row).  Nothing is packed, padded or moved after the sort.
+// Per round and group of parts: every (centre, context) pair of the round's walks whose centre
+// this rank owns and whose context lies in the group is emitted as ONE 64-bit word,
+//     cell << (row_bits + ctx_bits) | centre row << ctx_bits | hot << (ctx_bits - 1) | context row
+// (the context row counted inside its cell: (x / parts) / slices), by two passes over the walks
+// (count, then write at scanned offsets -- the output is in walk / position / slot order, whatever
+// the launch geometry); one stable radix sort on the bits above ctx_bits groups the words by cell
+// and centre, and the training kernel walks a cell in implicit records of `record` consecutive
+// pairs: a wave keeps the centre row in registers while the centre does not change, records are
+// visited in a golden-ratio stride order (a hub centre owns thousands of consecutive records;
+// concurrent waves must not all accumulate into the same row).  Nothing is packed, padded or
+// moved after the sort.  8 B per pair whatever the graph's size (100 M nodes on one GPU:
+// 12 + 27 + 17 bits); a round's pairs are extracted and sorted a group of parts at a time, so the
+// buffers hold 1 / groups of the round.
 #pragma once
 #include "train_kernels.h"
 
@@ -27,7 +34,7 @@ namespace gn2v {
 constexpr uint64_t kTagBlock = 0xB10C5EED0B10C5EDULL;
 constexpr int kPrepBlock = 256;
 constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
-constexpr uint32_t kMaxCells = 1024;
+constexpr uint32_t kMaxCells = 8192;    // parts x slices (100 M nodes: 381 x 8 cells of 32 k rows)
 constexpr uint32_t kMaxRecord = 32;
 constexpr uint32_t kCursorStep = 64;  // u64 words between the ticket cursors of two slices
 constexpr uint32_t kTicket = 4;       // records a wave takes per ticket (one returning atomic)
@@ -39,17 +46,11 @@ constexpr uint32_t kHubBit = 0x80000000u;
 struct BlockPlan {
     uint32_t world, rank, parts, slices;
     uint32_t L, window, min_dist, record;
-    uint32_t row_bits;
+    uint32_t row_bits;  // bits of the centre row in a pair word
+    uint32_t ctx_bits;  // bits below it: the context row inside its cell + the hot flag on top
     uint32_t flags;  // kFlagDownsample: centres are thinned at extraction (needs the graph)
-    uint32_t key64;  // sort keys are u64 (cell and centre row do not fit 32 bits)
     uint32_t hubs;   // a hot band is set: rows may carry kHubBit
 };
-
-__device__ __forceinline__ uint32_t xcc_id() {
-    uint32_t v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 0xF;
-}
 
 // --------------------------------------------------------------------------------------------
 // Negative sampling inside a cell, proportional to the degree (use_scale_free_distribution,
@@ -120,9 +121,11 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
     auto node_of = [&](uint64_t i) { return (slice + (uint64_t)slices * i) * parts + part; };
     // hot: share of the cell's endpoints in [2^-lo, 2^-hi) (hi = 0: no upper bound)
     auto hot = [&](uint64_t i) -> unsigned long long {
+        // d * 2^shift >= D  <=>  d >= ceil(D / 2^shift): no overflow whatever the in-degree
         const unsigned long long d = indeg[node_of(i)];
-        return hub_lo_shift != 0 && D != 0 && (d << hub_lo_shift) >= D &&
-                       (hub_hi_shift == 0 || (d << hub_hi_shift) < D)
+        const unsigned long long lo_need = (D + (1ull << hub_lo_shift) - 1) >> hub_lo_shift;
+        const unsigned long long hi_need = (D + (1ull << hub_hi_shift) - 1) >> hub_hi_shift;
+        return hub_lo_shift != 0 && D != 0 && d >= lo_need && (hub_hi_shift == 0 || d < hi_need)
                    ? 1ull
                    : 0ull;
     };
@@ -175,8 +178,9 @@ struct ExtractArgs {
     unsigned long long *wave_counts;  // [kPrepWaves]: counts out (count pass), offsets in (write)
     unsigned long long *cell_counts;  // [cells] (count pass)
     const uint32_t *hub_bits;         // one bit per node (gn2v_block_alias), or nullptr
-    void *keys;                       // KeyT[n_pairs]
-    uint32_t *vals;
+    unsigned long long *pairs;        // [n_pairs] pair words (write pass)
+    uint32_t part_lo, part_n;         // only contexts in the parts part_lo, part_lo + 1, ...
+                                      // (part_n of them, cyclic) are emitted
 };
 
 __device__ __forceinline__ bool keep_centre_at(const GraphView &g, uint64_t wkey, uint32_t i,
@@ -190,34 +194,55 @@ __device__ __forceinline__ bool keep_centre_at(const GraphView &g, uint64_t wkey
     return lhs_hi < rhs_hi || (lhs_hi == rhs_hi && lhs_lo < rhs_lo);
 }
 
-template <bool WRITE, class KeyT>
+template <bool WRITE>
 __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t waves_per_block = kPrepBlock / 64;
     const uint32_t cells = a.p.parts * a.p.slices;
     const uint32_t L = a.p.L, w = a.p.window, w2 = 2 * a.p.window;
-    uint32_t *s_walk = smem + wave * 2 * L;
-    uint32_t *s_own = s_walk + L;
-    unsigned int *s_hist = smem + waves_per_block * 2 * L + wave * cells;
+    // per wave: the walk, per position its context cell (kSentinel: not in this group of parts)
+    // and its context row inside the cell (| hot flag), the compacted own positions
+    uint32_t *s_walk = smem + wave * 4 * L;
+    uint32_t *s_cell = s_walk + L;
+    uint32_t *s_loc = s_cell + L;
+    uint32_t *s_own = s_loc + L;
+    unsigned int *s_hist = smem + waves_per_block * 4 * L;  // [cells], shared by the block
     const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;
     const uint64_t chunk = (a.n_walks + kPrepWaves - 1) / kPrepWaves;
     const uint64_t b0 = gw * chunk;
     const uint64_t b1 = b0 + chunk < a.n_walks ? b0 + chunk : a.n_walks;
     if constexpr (!WRITE) {
-        for (uint32_t c = lane; c < cells; c += 64) s_hist[c] = 0;
+        for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock) s_hist[c] = 0;
+        __syncthreads();
     }
     unsigned long long base = 0;
     if constexpr (WRITE) base = a.wave_counts[gw];
     unsigned long long total = 0;
     const uint64_t lt_mask = (1ULL << lane) - 1;
+    const uint32_t hub_shift = a.p.ctx_bits - 1;
     for (uint64_t b = b0; b < b1; ++b) {
         wave_sync();
         uint32_t Le = L;
         for (uint32_t t = lane; t < L; t += 64) {
-            const uint32_t v = a.walks[b * L + t];
-            s_walk[t] = v;
-            if (v == kSentinel) Le = min(Le, t);
+            const uint32_t x = a.walks[b * L + t];
+            s_walk[t] = x;
+            uint32_t cell = kSentinel, loc = 0;
+            if (x == kSentinel) {
+                Le = min(Le, t);
+            } else {
+                const uint32_t row = x / a.p.parts, part = x - row * a.p.parts;
+                const uint32_t rel = part >= a.part_lo ? part - a.part_lo
+                                                       : part + a.p.parts - a.part_lo;
+                if (rel < a.part_n) {
+                    loc = row / a.p.slices;
+                    cell = part * a.p.slices + (row - loc * a.p.slices);
+                    if (WRITE && a.hub_bits && ((a.hub_bits[x >> 5] >> (x & 31)) & 1u))
+                        loc |= 1u << hub_shift;
+                }
+            }
+            s_cell[t] = cell;
+            s_loc[t] = loc;
         }
         for (int off = 32; off > 0; off >>= 1) Le = min(Le, (uint32_t)__shfl_xor(Le, off));
         wave_sync();
@@ -241,32 +266,28 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
         for (uint32_t t0 = 0; t0 < n_slots; t0 += 64) {
             const uint32_t t = t0 + lane;
             bool valid = false;
-            KeyT key = 0;
-            uint32_t val = 0, cell = 0;
+            unsigned long long word = 0;
+            uint32_t cell = 0;
             if (t < n_slots) {
                 const uint32_t idx = t / w2, slot = t - idx * w2;
                 const uint32_t i = s_own[idx];
                 const int64_t j = slot < w ? (int64_t)i - w + slot : (int64_t)i + 1 + (slot - w);
                 if (j >= 0 && j < (int64_t)Le) {
                     const uint32_t dist = (uint32_t)(j > (int64_t)i ? j - i : i - j);
-                    if (dist >= a.p.min_dist) {
-                        const uint32_t x = s_walk[j];
-                        val = x / a.p.parts;
-                        cell = (x - val * a.p.parts) * a.p.slices + val % a.p.slices;
-                        key = ((KeyT)cell << a.p.row_bits) | (s_walk[i] / a.p.world);
-                        if (WRITE && a.hub_bits && ((a.hub_bits[x >> 5] >> (x & 31)) & 1u))
-                            val |= kHubBit;
+                    cell = s_cell[j];
+                    if (dist >= a.p.min_dist && cell != kSentinel) {
+                        if constexpr (WRITE)
+                            word = ((((unsigned long long)cell << a.p.row_bits) |
+                                     (s_walk[i] / a.p.world))
+                                    << a.p.ctx_bits) |
+                                   s_loc[j];
                         valid = true;
                     }
                 }
             }
             const uint64_t mask = __ballot(valid);
             if constexpr (WRITE) {
-                if (valid) {
-                    const unsigned long long pos = base + __popcll(mask & lt_mask);
-                    reinterpret_cast<KeyT *>(a.keys)[pos] = key;
-                    a.vals[pos] = val;
-                }
+                if (valid) a.pairs[base + __popcll(mask & lt_mask)] = word;
                 base += __popcll(mask);
             } else {
                 if (valid) atomicAdd(&s_hist[cell], 1u);
@@ -275,9 +296,9 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
         }
     }
     if constexpr (!WRITE) {
-        wave_sync();
         if (lane == 0) a.wave_counts[gw] = total;
-        for (uint32_t c = lane; c < cells; c += 64)
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock)
             if (s_hist[c]) atomicAdd(&a.cell_counts[c], (unsigned long long)s_hist[c]);
     }
 }
@@ -321,15 +342,15 @@ __global__ __launch_bounds__(1024) void block_scan_kernel(unsigned long long *wa
 struct BlockArgs {
     GraphView g;
     BlockPlan p;
-    const uint32_t *keys;   // sorted: cell << row_bits | centre row; u64 keys: low words at 2 i
-    const uint32_t *vals;   // context row inside its part
-    const unsigned long long *cell_offsets;  // [cells + 1] into keys / vals
+    const unsigned long long *pairs;  // sorted pair words (see the head of this file)
+    const unsigned long long *cell_offsets;  // [cells + 1] into pairs
     const unsigned long long *alias;      // alias tables (threshold | alias << 32), or nullptr:
                                           // negatives uniform over the rows of the cell
     const unsigned long long *cell_rows;  // [cells + 1]: first table entry of every cell
     float *central;    // this rank's central partition  [rows][cld]
     uint64_t cld;      // floats between its rows (ld, or world * ld inside the whole table)
-    float *context;    // the resident context part      [rows][ld]
+    float *context;    // the resident context part      [rows][xld]
+    uint64_t xld;      // floats between its rows (ld, or parts * ld inside the whole table)
     unsigned long long *cursors;  // record tickets of the part's cells, one per slice, kCursorStep
                                   // words apart (zeroed per launch)
     unsigned long long *counters;
@@ -338,12 +359,13 @@ struct BlockArgs {
     uint64_t block_id;
     uint32_t part;
     uint32_t sweep;  // 1: second launch -- every workgroup serves every cell's leftover records
+    uint32_t xcds;   // XCDs the workgroups are spread over (0 = unknown)
     uint32_t k, ld, flags;
     float lr, clip;
 };
 
 __device__ __forceinline__ float *sample_base(const BlockArgs &a, float *table, uint32_t row) {
-    return table + (uint64_t)(row & ~kHubBit) * a.ld;
+    return table + (uint64_t)(row & ~kHubBit) * a.xld;
 }
 
 __device__ __forceinline__ uint64_t gcd64(uint64_t a, uint64_t b) {
@@ -370,13 +392,18 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
                                              uint64_t alias_lo, uint64_t cell_n, uint32_t slice,
                                              uint32_t *s_key, uint32_t *s_val, uint32_t *s_rows,
                                              float *s_lab, float *s_tr, int lane, int grp, int q,
-                                             unsigned long long &pairs) {
+                                             unsigned long long &pairs,
+                                             unsigned long long &runs) {
     const uint32_t k = a.k, nchunks = a.ld >> 2;
     const uint32_t rowmask = a.p.row_bits >= 32 ? 0xFFFFFFFFu : ((1u << a.p.row_bits) - 1u);
     wave_sync();
     if ((uint32_t)lane < n) {
-        s_key[lane] = a.keys[(p0 + lane) << a.p.key64] & rowmask;  // the row sits in the low word
-        s_val[lane] = a.vals[p0 + lane];
+        const unsigned long long word = a.pairs[p0 + lane];
+        const uint32_t low = (uint32_t)word & ((1u << a.p.ctx_bits) - 1u);
+        const uint32_t hub = low >> (a.p.ctx_bits - 1);
+        const uint32_t local = low & ((1u << (a.p.ctx_bits - 1)) - 1u);
+        s_key[lane] = (uint32_t)(word >> a.p.ctx_bits) & rowmask;
+        s_val[lane] = (slice + a.p.slices * local) | (hub ? kHubBit : 0u);  // row inside the part
     }
     wave_sync();
     const uint32_t n_samples = n * (k + 1);
@@ -452,12 +479,14 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         if (grp == 0) scatter_add<CH, DET ? kWriteBack : WMC>(crow, q, nchunks, 1.0f, g, u);
         if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         r0 = r1;
+        ++runs;  // one central row read + one gradient add per run of equal centre
     }
     pairs += n;
 }
 
-// WMX: store flavour of the contextual rows (kWriteBack only when the cell is exclusive to the
-// XCD the workgroup runs on), WMC: of the central rows (shared between XCDs).
+// WMX: store flavour of the contextual rows (kWriteBack / kLocalAtomic only when every cell is
+// exclusive to one XCD: slices a multiple of the XCDs in use), WMC: of the central rows (shared
+// between XCDs).
 #ifndef GN2V_BLOCK_MIN_BLOCKS
 #define GN2V_BLOCK_MIN_BLOCKS 1  // occupancy experiments: -DGN2V_BLOCK_MIN_BLOCKS=6 caps the VGPRs
 #endif
@@ -473,16 +502,28 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
     uint32_t *s_val = s_key + C;
     uint32_t *s_rows = s_val + C;
     float *s_lab = reinterpret_cast<float *>(s_rows + C * (k + 1));
-    unsigned long long pairs = 0;
+    unsigned long long pairs = 0, runs = 0;
     const uint64_t part_rows = stripe_count(a.n_nodes, a.part, a.p.parts);
 
-    uint32_t first_slice = 0, n_my_slices = a.p.slices;
+    // Which slices this workgroup serves.  When the slices are a multiple of the XCDs in use
+    // (a.xcds; 8 slices on an MI355X), XCD x serves the slices x, x + xcds, ...: every slice --
+    // every contextual row -- is then touched by exactly one XCD during the launch (the host picks
+    // write-back stores only in that case).  Otherwise XCD x serves slice x % slices: several XCDs
+    // share a slice and the stores are write-through.
+    uint32_t first_slice = 0, slice_step = 1, n_my_slices = a.p.slices;
     if (!DET && !a.sweep && a.p.slices > 1) {
-        first_slice = xcc_id() % a.p.slices;  // this workgroup's XCD owns exactly one slice
-        n_my_slices = 1;
+        const uint32_t x = xcc_id();
+        if (a.xcds != 0 && a.p.slices % a.xcds == 0) {
+            first_slice = x;
+            slice_step = a.xcds;
+            n_my_slices = x < a.xcds ? a.p.slices / a.xcds : 0;
+        } else {
+            first_slice = x % a.p.slices;
+            n_my_slices = 1;
+        }
     }
     for (uint32_t si = 0; si < n_my_slices; ++si) {
-        const uint32_t slice = first_slice + si;
+        const uint32_t slice = first_slice + si * slice_step;
         const uint32_t cell = a.part * a.p.slices + slice;
         const uint64_t lo = a.cell_offsets[cell], hi = a.cell_offsets[cell + 1];
         if (hi == lo) continue;
@@ -499,7 +540,7 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
                 const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
                 train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, alias_lo, cell_n, slice,
                                                 s_key, s_val, s_rows, s_lab, s_tr, lane, grp, q,
-                                                pairs);
+                                                pairs, runs);
             }
         } else {
             // a ticket = kTicket consecutive visiting-order indices (the stride order spreads
@@ -517,25 +558,31 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
                     const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
                     train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, alias_lo, cell_n,
                                                     slice, s_key, s_val, s_rows, s_lab, s_tr, lane,
-                                                    grp, q, pairs);
+                                                    grp, q, pairs, runs);
                 }
             }
         }
     }
-    if (a.counters && lane == 0 && pairs) atomicAdd(&a.counters[0], pairs);
+    if (a.counters && lane == 0 && pairs) {
+        atomicAdd(&a.counters[0], pairs);
+        atomicAdd(&a.counters[2], runs);  // "centres": runs of equal centre
+    }
 }
 
-// contextual[x] <- part (x % parts), row x / parts: one part written back into the whole table
-static __global__ void scatter_part_kernel(float *__restrict__ table, const float *__restrict__ part,
-                                           uint64_t part_rows, uint32_t ld, uint32_t part_id,
-                                           uint32_t parts) {
-    const uint64_t n = part_rows * (ld >> 2);
+// natural[x] <- part-major storage: the rows of part p = x % parts lie one after the other from
+// row part_first[p] on (row x / parts of the part)
+static __global__ void parts_to_natural_kernel(float *__restrict__ natural,
+                                               const float *__restrict__ part_major,
+                                               const unsigned long long *__restrict__ part_first,
+                                               uint64_t n_nodes, uint32_t ld, uint32_t parts) {
+    const uint64_t n = n_nodes * (ld >> 2);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = i / (ld >> 2);
-        const uint32_t c = (uint32_t)(i - r * (ld >> 2));
-        reinterpret_cast<float4 *>(table + (r * parts + part_id) * ld)[c] =
-            reinterpret_cast<const float4 *>(part + r * ld)[c];
+        const uint64_t x = i / (ld >> 2);
+        const uint32_t c = (uint32_t)(i - x * (ld >> 2));
+        const uint64_t src = part_first[x % parts] + x / parts;
+        reinterpret_cast<float4 *>(natural + x * ld)[c] =
+            reinterpret_cast<const float4 *>(part_major + src * ld)[c];
     }
 }
 

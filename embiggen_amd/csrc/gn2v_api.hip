@@ -250,6 +250,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     const bool use_cache = !det && wm != gn2v::kAtomic && !a.split &&
                            !a.walk_rows && !a.neg_pool && !(tp->flags & GN2V_TRAIN_NO_CTX_CACHE) &&
                            cache_lds <= 40 * 1024 && L > 2 * tp->window &&
+                           (!cbow || slots <= gn2v::kWinCacheMaxSlots) &&
                            g->view.n_nodes < (1ULL << 30);  // row ids share a word with kCacheBit
     if (use_cache) {
         if (tp->flags & GN2V_TRAIN_CTX_CACHE_ALL) {
@@ -390,9 +391,27 @@ int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const fl
         cleanup();
         return fail("allocating device counters failed");
     }
+    {   // which XCDs do workgroups land on?  (8 on an MI355X in SPX mode; the block trainer uses
+        // write-back stores only for rows that exactly one of them touches)
+        unsigned int *mask = reinterpret_cast<unsigned int *>(g->cursors);
+        unsigned int seen = 0;
+        if (hipMemset(mask, 0, sizeof(unsigned int)) == hipSuccess) {
+            hipLaunchKernelGGL(gn2v::xcc_probe_kernel, dim3(g->n_cus * 16), dim3(64), 0,
+                               (hipStream_t)0, mask);
+            if (hipGetLastError() == hipSuccess &&
+                hipMemcpy(&seen, mask, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess) {
+                int n = 0;
+                while (seen & (1u << n)) ++n;
+                g->n_xcds = (seen == (1u << n) - 1u) ? n : 0;  // contiguous ids only
+            }
+        }
+        (void)hipGetLastError();
+    }
     *out = g;
     return 0;
 }
+
+int gn2v_graph_xcds(gn2v_graph *g) { return g ? g->n_xcds : 0; }
 
 int gn2v_graph_set_types(gn2v_graph *g, const uint32_t *node_types,
                          const uint32_t *edge_types) {
@@ -806,7 +825,11 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
     hipStream_t s = (hipStream_t)stream;
     const bool cbow = tp->model == GN2V_MODEL_CBOW;
     const uint32_t L = wp->walk_length;
-    if (stats) stats->block_parts = stats->block_slices = stats->block_stripes = stats->reserved = 0;
+    if (stats) {
+        stats->block_parts = stats->block_slices = stats->block_stripes = 0;
+        stats->block_group_parts = 0;
+        stats->block_round_walks = 0;
+    }
 
     // SkipGram on large graphs in the default update mode: the block path (contextual rows in
     // XCD-exclusive cells)
@@ -814,9 +837,14 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
                                    GN2V_TRAIN_WRITE_BACK | GN2V_TRAIN_WRITE_THROUGH |
                                    GN2V_TRAIN_WALK_ORDERED;
     if (!cbow && ((tp->flags & GN2V_TRAIN_BLOCK_PATH) ||
-                  (!(tp->flags & explicit_mode) && g->view.n_nodes >= (1ULL << 16))))
-        return gn2v_train_blocks(g, wp, tp, seed, max_walks_per_epoch, 0, 0, d_central, d_contextual,
-                                 stats, stream);
+                  (!(tp->flags & explicit_mode) && g->view.n_nodes >= (1ULL << 16)))) {
+        const int rc = gn2v_train_blocks(g, wp, tp, seed, max_walks_per_epoch, 0, 0, d_central,
+                                         d_contextual, stats, stream);
+        // 2 = device memory ran out before anything was trained (alias tables, pair buffers): the
+        // automatic choice falls back to the walk-ordered schedule, which needs the walks only
+        if (rc != 2 || (tp->flags & GN2V_TRAIN_BLOCK_PATH)) return rc ? 1 : 0;
+        if (stats) stats->block_parts = stats->block_slices = stats->block_stripes = 0;
+    }
 
     if (gn2v_init_table(d_central, g->view.n_nodes, tp->d, tp->ld, seed, 0, tp->init_scale, s) ||
         gn2v_init_table(d_contextual, g->view.n_nodes, tp->d, tp->ld, seed, 1, tp->init_scale, s))

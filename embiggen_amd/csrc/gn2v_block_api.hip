@@ -3,6 +3,7 @@
 // self._model.fit_transform(graph) (embedders/ensmallen_embedders/node2vec.py:99), runs in one
 // process; this is how the same call is spread over the GPUs of a node.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -54,48 +55,63 @@ gn2v::BlockPlan device_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     d.record = p->record ? p->record : 16;
     const uint64_t rows = (g->view.n_nodes + p->world - 1) / p->world;
     d.row_bits = bits_for(rows);
+    // rows of the largest cell: part 0, slice 0
+    const uint64_t part_rows = gn2v::stripe_count(g->view.n_nodes, 0, p->parts);
+    d.ctx_bits = bits_for(gn2v::stripe_count(part_rows, 0, p->slices)) + 1;  // + the hot flag
     d.flags = p->flags & gn2v::kFlagDownsample;
-    d.key64 = d.row_bits + bits_for((uint64_t)d.parts * d.slices) > 32 ? 1u : 0u;
     d.hubs = p->hot_lo != 0 ? 1u : 0u;
     return d;
 }
 
+uint32_t cell_bits(const gn2v::BlockPlan &d) { return bits_for((uint64_t)d.parts * d.slices); }
+
 int check_key_width(const gn2v::BlockPlan &d) {
     if (d.row_bits > 32) return fail("centre rows need more than 32 bits");
+    if (d.ctx_bits > 31) return fail("a cell must have fewer than 2^30 rows");
+    if (cell_bits(d) + d.row_bits + d.ctx_bits > 64)
+        return fail("cell, centre row and context row do not fit one 64-bit pair word: use more "
+                    "ranks or fewer parts");
     return 0;
 }
 
-// Stable radix sort of (keys, vals) by the low end_bit key bits between two buffers of the same
-// size (rocPRIM's double-buffer form: no third copy inside the temporary storage); the result is
-// left in keys_out / vals_out.
-template <class K, class V>
-int sort_pairs(void *temp, size_t temp_bytes, K *keys_in, K *keys_out, V *vals_in, V *vals_out,
-               uint64_t n, uint32_t end_bit, hipStream_t s) {
-    rocprim::double_buffer<K> kb(keys_in, keys_out);
-    rocprim::double_buffer<V> vb(vals_in, vals_out);
+int check_group(const gn2v_block_plan *p, uint32_t part_lo, uint32_t *part_n) {
+    if (*part_n == 0 && part_lo == 0) *part_n = p->parts;  // 0, 0 = every part
+    if (part_lo >= p->parts || *part_n < 1 || *part_n > p->parts)
+        return fail("group of parts out of range");
+    return 0;
+}
+
+// Stable radix sort of the pair words on the bits [begin_bit, end_bit) between two buffers of the
+// same size (rocPRIM's double-buffer form: no third copy inside the temporary storage); the
+// result is left in `out`.
+int sort_words(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out,
+               uint64_t n, uint32_t begin_bit, uint32_t end_bit, hipStream_t s) {
+    rocprim::double_buffer<unsigned long long> kb(in, out);
     size_t need = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, kb, vb, n, 0, end_bit, s));
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, need, kb, n, begin_bit, end_bit, s));
     if (need > temp_bytes) return fail("temporary storage too small for the radix sort");
-    HIP_TRY(rocprim::radix_sort_pairs(temp, need, kb, vb, n, 0, end_bit, s));
-    if (kb.current() != keys_out)
-        HIP_TRY(hipMemcpyAsync(keys_out, kb.current(), n * sizeof(K), hipMemcpyDeviceToDevice, s));
-    if (vb.current() != vals_out)
-        HIP_TRY(hipMemcpyAsync(vals_out, vb.current(), n * sizeof(V), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(rocprim::radix_sort_keys(temp, need, kb, n, begin_bit, end_bit, s));
+    if (kb.current() != out)
+        HIP_TRY(hipMemcpyAsync(out, kb.current(), n * sizeof(unsigned long long),
+                               hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
-template <class K>
 size_t sort_temp_bytes(uint64_t n) {
     size_t need = 0;
-    rocprim::double_buffer<K> kb(nullptr, nullptr);
-    rocprim::double_buffer<uint32_t> vb(nullptr, nullptr);
-    if (rocprim::radix_sort_pairs(nullptr, need, kb, vb, n ? n : 1, 0, 8 * sizeof(K),
-                                  (hipStream_t)0) != hipSuccess)
+    rocprim::double_buffer<unsigned long long> kb(nullptr, nullptr);
+    if (rocprim::radix_sort_keys(nullptr, need, kb, n ? n : 1, 0, 64, (hipStream_t)0) !=
+        hipSuccess)
         return 0;
     return (need + 255) & ~(size_t)255;
 }
 
 constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// every slice of a part is served by exactly one XCD (block_kernels.h, sgns_block_kernel)
+bool slices_are_xcd_exclusive(const gn2v_graph *g, uint32_t slices) {
+    return slices > 1 && g->n_xcds > 0 && slices % (uint32_t)g->n_xcds == 0;
+}
 
 }  // namespace
 
@@ -129,7 +145,8 @@ int gn2v_block_plan_check(gn2v_graph *g, gn2v_block_plan *plan) {
     const gn2v::BlockPlan d = device_plan(g, plan);
     if (check_key_width(d)) return 1;
     plan->row_bits = d.row_bits;
-    plan->key_bits = d.key64 ? 64 : 32;
+    plan->ctx_bits = d.ctx_bits;
+    plan->key_bits = cell_bits(d) + d.row_bits + d.ctx_bits;
     plan->record = d.record;
     plan->min_dist = d.min_dist;
     return 0;
@@ -197,8 +214,8 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
 
 static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
                           const uint32_t *d_walks, uint64_t n_walks, uint64_t seed, uint64_t epoch,
-                          uint64_t first_walk, uint64_t *d_work, const uint32_t *d_hub_bits,
-                          void *keys, uint32_t *vals, hipStream_t s) {
+                          uint64_t first_walk, uint32_t part_lo, uint32_t part_n, uint64_t *d_work,
+                          const uint32_t *d_hub_bits, uint64_t *pairs, hipStream_t s) {
     gn2v::ExtractArgs a{};
     a.g = g->view;
     a.p = d;
@@ -209,36 +226,36 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     a.wave_counts = (unsigned long long *)d_work;
     a.cell_counts = (unsigned long long *)d_work + gn2v::kPrepWaves;
     a.hub_bits = d_hub_bits;
-    a.keys = keys;
-    a.vals = vals;
+    a.pairs = (unsigned long long *)pairs;
+    a.part_lo = part_lo;
+    a.part_n = part_n;
     const uint32_t cells = d.parts * d.slices;
-    const size_t lds = (size_t)(gn2v::kPrepBlock / 64) * (2 * d.L + cells) * 4;
+    const size_t lds = ((size_t)(gn2v::kPrepBlock / 64) * 4 * d.L + cells) * 4;
     if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
     const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
-    if (write && d.key64)
-        hipLaunchKernelGGL((gn2v::block_extract_kernel<true, uint64_t>), grid, block, lds, s, a);
-    else if (write)
-        hipLaunchKernelGGL((gn2v::block_extract_kernel<true, uint32_t>), grid, block, lds, s, a);
+    if (write)
+        hipLaunchKernelGGL((gn2v::block_extract_kernel<true>), grid, block, lds, s, a);
     else
-        hipLaunchKernelGGL((gn2v::block_extract_kernel<false, uint32_t>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((gn2v::block_extract_kernel<false>), grid, block, lds, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                      uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                     uint64_t *d_work, uint64_t *d_cell_offsets, void *stream) {
+                     uint32_t part_lo, uint32_t part_n, uint64_t *d_work,
+                     uint64_t *d_cell_offsets, void *stream) {
     if (check_plan(g, plan)) return 1;
     const gn2v::BlockPlan d = device_plan(g, plan);
-    if (check_key_width(d)) return 1;
+    if (check_key_width(d) || check_group(plan, part_lo, &part_n)) return 1;
     if (!d_work || !d_cell_offsets || (n_walks && !d_walks)) return fail("NULL pointer");
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(d_work, 0, GN2V_BLOCK_WORK_WORDS * sizeof(uint64_t), s));
     if (n_walks &&
-        launch_extract(g, d, false, d_walks, n_walks, seed, epoch, first_walk, d_work, nullptr,
-                       nullptr, nullptr, s))
+        launch_extract(g, d, false, d_walks, n_walks, seed, epoch, first_walk, part_lo, part_n,
+                       d_work, nullptr, nullptr, s))
         return 1;
     hipLaunchKernelGGL(gn2v::block_scan_kernel, dim3(1), dim3(1024), 0, s,
                        (unsigned long long *)d_work,
@@ -248,46 +265,37 @@ int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t 
     return 0;
 }
 
-int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint32_t key_bits, uint64_t *bytes) {
+int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes) {
     if (!bytes) return fail("bytes is NULL");
-    if (key_bits != 32 && key_bits != 64) return fail("key_bits must be 32 or 64");
-    *bytes = align256(n_pairs * (key_bits / 8)) + align256(n_pairs * 4) +
-             (key_bits == 64 ? sort_temp_bytes<uint64_t>(n_pairs)
-                             : sort_temp_bytes<uint32_t>(n_pairs));
+    *bytes = align256(n_pairs * 8) + sort_temp_bytes(n_pairs);
     return 0;
 }
 
 int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                        uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                       const uint64_t *d_work, const uint32_t *d_hub_bits, uint64_t n_pairs,
-                       void *d_keys, uint32_t *d_vals, void *d_temp, uint64_t temp_bytes,
-                       void *stream) {
+                       uint32_t part_lo, uint32_t part_n, const uint64_t *d_work,
+                       const uint32_t *d_hub_bits, uint64_t n_pairs, uint64_t *d_pairs,
+                       void *d_temp, uint64_t temp_bytes, void *stream) {
     if (check_plan(g, plan)) return 1;
     const gn2v::BlockPlan d = device_plan(g, plan);
-    if (check_key_width(d)) return 1;
+    if (check_key_width(d) || check_group(plan, part_lo, &part_n)) return 1;
     if (n_pairs == 0) return 0;
-    if (!d_work || !d_walks || !d_keys || !d_vals || !d_temp) return fail("NULL pointer");
+    if (!d_work || !d_walks || !d_pairs || !d_temp) return fail("NULL pointer");
     uint64_t need = 0;
-    const size_t key_bytes = d.key64 ? 8 : 4;
-    gn2v_block_extract_temp_bytes(n_pairs, (uint32_t)key_bytes * 8, &need);
+    gn2v_block_extract_temp_bytes(n_pairs, &need);
     if (temp_bytes < need) return fail("temporary storage too small for the extraction");
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
     char *t = (char *)d_temp;
-    void *keys_in = t;
-    const size_t head = align256(n_pairs * key_bytes) + align256(n_pairs * 4);
-    uint32_t *vals_in = (uint32_t *)(t + align256(n_pairs * key_bytes));
-    void *sort_temp = t + head;
-    if (launch_extract(g, d, true, d_walks, n_walks, seed, epoch, first_walk,
-                       const_cast<uint64_t *>(d_work), d_hub_bits, keys_in, vals_in, s))
+    unsigned long long *unsorted = (unsigned long long *)t;
+    const size_t head = align256(n_pairs * 8);
+    if (launch_extract(g, d, true, d_walks, n_walks, seed, epoch, first_walk, part_lo, part_n,
+                       const_cast<uint64_t *>(d_work), d_hub_bits, (uint64_t *)unsorted, s))
         return 1;
-    const uint32_t end_bit = std::max(1u, d.row_bits + bits_for((uint64_t)d.parts * d.slices));
-    if (d.key64)
-        return sort_pairs(sort_temp, temp_bytes - head, (uint64_t *)keys_in, (uint64_t *)d_keys,
-                          vals_in, d_vals, n_pairs, end_bit, s);
-    return sort_pairs(sort_temp, temp_bytes - head, (uint32_t *)keys_in, (uint32_t *)d_keys,
-                      vals_in, d_vals, n_pairs, end_bit, s);
+    const uint32_t end_bit = std::max(d.ctx_bits + 1, d.ctx_bits + d.row_bits + cell_bits(d));
+    return sort_words(t + head, temp_bytes - head, unsorted, (unsigned long long *)d_pairs,
+                      n_pairs, d.ctx_bits, end_bit, s);
 }
 
 extern "C++" {
@@ -325,7 +333,7 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     if (!std::isfinite(lr) || !std::isfinite(tp->clip) || tp->clip <= 0.f)
         return fail("learning rate / clipping value must be finite, clipping value positive");
     if (io->part >= plan->parts) return fail("part out of range");
-    if (!io->d_keys || !io->d_vals || !io->d_cell_offsets || !io->d_central || !io->d_context)
+    if (!io->d_pairs || !io->d_cell_offsets || !io->d_central || !io->d_context)
         return fail("NULL pointer");
     if ((tp->flags & GN2V_TRAIN_SCALE_FREE) && (!io->d_alias || !io->d_cell_rows))
         return fail("degree-proportional negatives need the tables of gn2v_block_alias");
@@ -336,8 +344,7 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     gn2v::BlockArgs a{};
     a.g = g->view;
     a.p = d;
-    a.keys = (const uint32_t *)io->d_keys;
-    a.vals = io->d_vals;
+    a.pairs = (const unsigned long long *)io->d_pairs;
     a.cell_offsets = (const unsigned long long *)io->d_cell_offsets;
     const bool scale_free = tp->flags & GN2V_TRAIN_SCALE_FREE;
     a.alias = scale_free ? (const unsigned long long *)io->d_alias : nullptr;
@@ -346,6 +353,8 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     a.cld = io->central_ld ? io->central_ld : tp->ld;
     if (a.cld < tp->ld || (a.cld & 3)) return fail("central_ld must be a multiple of 4 and >= ld");
     a.context = io->d_context;
+    a.xld = io->context_ld ? io->context_ld : tp->ld;
+    if (a.xld < tp->ld || (a.xld & 3)) return fail("context_ld must be a multiple of 4 and >= ld");
     a.counters = g->counters;
     a.n_nodes = g->view.n_nodes;
     a.ekey = gn2v::epoch_key(seed, epoch);
@@ -358,8 +367,8 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     a.clip = tp->clip;
 
     const bool det = tp->flags & GN2V_TRAIN_DETERMINISTIC;
-    // contextual rows: exclusive to one XCD when the part is sliced -> plain write-back stores,
-    // else write-through.  Central rows: the gradient of a whole record is added with hardware
+    // contextual rows: exclusive to one XCD when the part has one slice per XCD -> plain
+    // write-back stores, else write-through.  Central rows: the gradient of a whole record is added with hardware
     // f32 atomics (one row per ~record * (k + 1) sample rows: free, and the records of a hub centre
     // that many waves train at once lose no update).  Small graphs: atomics everywhere.
     int wmc = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
@@ -368,8 +377,14 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
               : g->view.n_nodes < (1ULL << 16)         ? gn2v::kAtomic
                                                        : gn2v::kWriteThrough;
     int wmx = wmc;
-    if (wmc == gn2v::kWriteThrough && d.slices > 1)
+    // One XCD per slice -- the kernel maps XCD x to the slices x, x + n_xcds, ... -- holds only
+    // when the slices are a multiple of the XCDs the workgroups are spread over (8 on an MI355X).
+    // With 2 or 4 slices several XCDs (non-coherent L2s) read-modify-write the same rows: they
+    // keep the write-through stores, as do unsliced parts.
+    const bool exclusive = slices_are_xcd_exclusive(g, d.slices);
+    if (wmc == gn2v::kWriteThrough && exclusive)
         wmx = (tp->flags & GN2V_TRAIN_LOCAL_ATOMIC) ? gn2v::kLocalAtomic : gn2v::kWriteBack;
+    a.xcds = (uint32_t)g->n_xcds;
 
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
     const size_t per_wave_words =
@@ -421,45 +436,59 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
 
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t *parts, uint32_t *slices) {
     if (!parts || !slices || world < 1) return fail("bad arguments");
-    auto pow2_floor = [](uint64_t x) {
-        uint64_t p = 1;
-        while (p * 2 <= x) p *= 2;
-        return x < 1 ? (uint64_t)1 : p;
-    };
-    constexpr uint64_t kMinRows = 32768;
-    if (world > 1) {
-        const uint64_t sl =
-            std::max<uint64_t>(1, std::min<uint64_t>(8, pow2_floor(n_nodes / (2 * world * kMinRows))));
-        const uint64_t per_rank = std::max<uint64_t>(
-            2, std::min(pow2_floor(n_nodes / (world * sl * kMinRows)),
-                        pow2_floor(std::max<uint64_t>(2, 128 / world))));
-        *parts = (uint32_t)(per_rank * world);
-        *slices = (uint32_t)sl;
-        return 0;
-    }
-    const uint64_t sl = std::max<uint64_t>(1, std::min<uint64_t>(8, pow2_floor(n_nodes / kMinRows)));
+    constexpr uint64_t kMinRows = 32768, kXcds = 8;
+    // Slices: one per XCD or none.  Only then is a contextual row exclusive to one XCD's L2 (plain
+    // write-back stores, hub rows L2 resident); 2 or 4 slices would have several XCDs share a
+    // slice and fall back to write-through stores without the locality.
+    const uint64_t min_parts = world > 1 ? 2ull * world : 1;
+    const uint64_t sl = n_nodes / (min_parts * kXcds) >= kMinRows / 4 ? kXcds : 1;
+    // Parts: as many as keep kMinRows rows in a cell (any count: 10 M nodes -> 38, 100 M -> 381);
+    // a multiple of the ranks when they travel, at least two per rank.
+    uint64_t p = n_nodes / (sl * kMinRows);
+    const uint64_t max_parts = gn2v::kMaxCells / sl / world * world;
+    p = p / world * world;
+    p = std::max<uint64_t>(min_parts, std::min<uint64_t>(p, max_parts));
+    while (p > min_parts && n_nodes / p == 0) p -= world;
+    *parts = (uint32_t)p;
     *slices = (uint32_t)sl;
-    *parts = (uint32_t)std::max<uint64_t>(
-        1, std::min<uint64_t>(128, pow2_floor(n_nodes / (sl * kMinRows))));
     return 0;
 }
 
 
-int gn2v_block_round_walks(uint64_t free_bytes, uint32_t walk_length, uint32_t window,
-                           uint32_t key_bits, uint32_t world, uint32_t overlap,
-                           uint64_t *round_walks) {
-    if (!round_walks || walk_length < 2 || window < 1 || world < 1 ||
-        (key_bits != 32 && key_bits != 64))
+int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_length,
+                          uint32_t window, uint32_t world, uint32_t parts, uint32_t slices,
+                          uint32_t overlap, uint64_t *round_walks, uint32_t *group_parts) {
+    if (!round_walks || !group_parts || walk_length < 2 || window < 1 || world < 1 || parts < 1 ||
+        slices < 1 || n_nodes < 1)
         return fail("bad arguments");
-    const uint64_t L = walk_length, pairs = 2ull * window * L;  // upper bound (window untrimmed)
-    uint64_t per_walk = pairs * (key_bits / 8 + 4) * (overlap ? 3 : 2);
-    per_walk += 4 * L * (world + 1ull) * (overlap ? 2 : 1);
-    const uint64_t fit = free_bytes / 4 * 3 / per_walk;
-    uint64_t r = 1ull << 14;
-    while (r * 2 <= fit && r < (1ull << 23)) r *= 2;
+    const uint64_t L = walk_length, pairs = 2ull * window * L;  // per walk (window untrimmed)
+    // Long enough that the pairs of a centre meet in a cell -- 64 per (cell, centre) -- within
+    // [2^20, 2^23] walks (the bench graph wants more than the cap: 3.5 at 2^23).
+    const double want = 64.0 * (double)n_nodes * parts * slices / ((double)world * pairs);
+    uint64_t r = 1ull << 20;
+    while ((double)r < want && r < (1ull << 23)) r *= 2;
+    // Memory, three quarters of what is free: the round's walks (this rank's and, with several
+    // ranks, the gathered ones), and per group of parts the pair words once sorted (twice when a
+    // second group is prepared while the first trains) and once unsorted.  Groups: at least four
+    // per round when there are that many parts, more when memory is short.
+    const uint64_t budget = free_bytes / 4 * 3;
+    const uint64_t copies = overlap ? 3 : 2;
+    auto walk_bytes = [&](uint64_t rw) { return 4 * L * rw * (world > 1 ? world + 1ull : 1ull); };
+    auto group_bytes = [&](uint64_t rw, uint64_t gp) {  // + 1/8: parts are not equally heavy
+        const uint64_t per_part = rw * pairs / parts + 1;
+        return copies * 8 * (per_part * gp + per_part * gp / 8);
+    };
+    while (r > (1ull << 14) && walk_bytes(r) + group_bytes(r, 1) > budget) r /= 2;
+    uint64_t gp = std::max<uint64_t>(1, (parts + 3) / 4);
+    while (gp > 1 && walk_bytes(r) + group_bytes(r, gp) > budget) --gp;
     *round_walks = r;
+    *group_parts = (uint32_t)gp;
     return 0;
 }
+
+// gn2v_train_blocks returns this (instead of 1) when device memory ran out before anything was
+// trained: gn2v_train then falls back to the walk-ordered schedule.
+static constexpr int kOutOfMemory = 2;
 
 int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
                       uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
@@ -476,9 +505,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     const uint32_t L = wp->walk_length, w = tp->window, ld = tp->ld;
 
     // Centre stripes ("virtual ranks"): stripe j = the centres c with c % V == j is trained over
-    // the pairs of ALL the round's walks before stripe j + 1 -- what V ranks do side by side.  A
-    // pass holds 1 / V of the round's pairs, so a round can be V times as long at the same
-    // memory, and a centre's pairs meet in runs V times as long.
+    // the pairs of ALL the round's walks before stripe j + 1 -- what V ranks do side by side.
     // Off unless asked for: the stripes of a round are trained one after the other, not side by
     // side as ranks would, and that coarser order costs link quality.
     uint32_t V = stripes ? stripes : 1;
@@ -493,7 +520,6 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     plan.min_dist = tp->min_dist ? tp->min_dist : 1;
     plan.record = 16;
     plan.flags = tp->flags & GN2V_TRAIN_DOWNSAMPLE;
-    while (plan.parts > 1 && n / plan.parts == 0) plan.parts /= 2;
     std::vector<gn2v_block_plan> plans(V, plan);
     for (uint32_t j = 0; j < V; ++j) {
         plans[j].rank = j;
@@ -507,7 +533,6 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     if (max_walks_per_epoch && max_walks_per_epoch < walks_per_epoch)
         walks_per_epoch = max_walks_per_epoch;
     const uint64_t pairs_per_walk = 2ull * w * L;  // upper bound (window untrimmed)
-    const size_t key_bytes = plan.key_bits / 8;
 
     Buffers buf;
     // alias tables + hot-row bitmap (the bitmap is all zero: no hot band in the automatic plan)
@@ -519,38 +544,34 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         void *tmp = nullptr;
         if (buf.alloc(&alias, n * 8) || buf.alloc(&cell_rows, (cells + 1) * 8) ||
             buf.alloc(&hub_bits, ((n + 31) / 32) * 4) || buf.alloc(&tmp, tb))
-            return 1;
+            return kOutOfMemory;
         if (gn2v_block_alias(g, &plan, alias, cell_rows, hub_bits, tmp, tb, s)) return 1;
         HIP_TRY(hipStreamSynchronize(s));
         (void)hipFree(tmp);
         buf.ptrs.pop_back();
     }
-    // the contextual table as `parts` buffers; the central table is the caller's, whole: stripe j
-    // is its rows j, j + V, ... (gn2v_block_io.central_ld)
-    const uint64_t max_rows = gn2v::stripe_count(n, 0, parts);
-    float *ctx = nullptr;
-    if (buf.alloc(&ctx, (size_t)parts * max_rows * ld * sizeof(float))) return 1;
-    if (gn2v_init_table(d_central, n, tp->d, ld, seed, 0, tp->init_scale, s)) return 1;
-    for (uint32_t p = 0; p < parts; ++p)
-        if (gn2v_init_table_rows(ctx + (size_t)p * max_rows * ld, gn2v::stripe_count(n, p, parts),
-                                 tp->d, ld, seed, 1, tp->init_scale, p, parts, s))
-            return 1;
 
-    // round size: `round_walks` = the walks whose pairs are held at once (one pass), a round is
-    // V times that; the longer, the more pairs of a centre meet in a cell
+    // round size and groups of parts: `round_walks` = the walks one pass extracts from (a round is
+    // V times that); the pairs of a round are extracted, sorted and trained a group at a time
     const bool automatic = round_walks == 0;
-    if (automatic) {
-        size_t free_b = 0, total_b = 0;
+    uint32_t group_parts = 0;
+    size_t free_b = 0, total_b = 0;
+    {
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if (gn2v_block_round_walks(free_b, L, w, plan.key_bits, V, 0, &round_walks)) return 1;
+        uint64_t auto_walks = 0;
+        if (gn2v_block_round_plan(free_b, n, L, w, V, parts, plan.slices, 0, &auto_walks,
+                                  &group_parts))
+            return 1;
+        if (automatic) round_walks = auto_walks;
     }
     round_walks = std::max<uint64_t>(1, std::min(round_walks, (walks_per_epoch + V - 1) / V));
-    uint32_t *walks = nullptr, *vals = nullptr;
-    void *keys = nullptr, *tmp = nullptr;
-    uint64_t *work = nullptr, *cell_offsets = nullptr;
+    uint32_t *walks = nullptr;
+    uint64_t *pairs = nullptr, *work = nullptr, *cell_offsets = nullptr, *part_first = nullptr;
+    void *tmp = nullptr;
     uint64_t tb = 0, cap = 0;
-    if (buf.alloc(&work, GN2V_BLOCK_WORK_WORDS * 8) || buf.alloc(&cell_offsets, (cells + 1) * 8))
-        return 1;
+    if (buf.alloc(&work, GN2V_BLOCK_WORK_WORDS * 8) || buf.alloc(&cell_offsets, (cells + 1) * 8) ||
+        buf.alloc(&part_first, (parts + 1) * 8))
+        return kOutOfMemory;
     const size_t held = buf.ptrs.size();
     auto release_round = [&]() {
         while (buf.ptrs.size() > held) {
@@ -559,20 +580,51 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         }
     };
     for (;;) {
-        // a stripe's share of the round's pairs is 1 / V up to the weight of its hubs: 1 / 16 of
-        // head room on top of the untrimmed-window bound, more on demand (below)
-        cap = round_walks * pairs_per_walk;
-        if (V > 1) cap += cap / 16;
-        gn2v_block_extract_temp_bytes(cap, plan.key_bits, &tb);
-        if (!(buf.alloc(&walks, V * round_walks * L * 4) || buf.alloc(&keys, cap * key_bytes) ||
-              buf.alloc(&vals, cap * 4) || buf.alloc(&tmp, tb)))
+        // a group's share of the round's pairs by its parts, 1 / 8 of head room on the
+        // untrimmed-window bound (parts and stripes are not equally heavy), more on demand (below)
+        cap = round_walks * pairs_per_walk / parts * group_parts;
+        cap += cap / 8 + 1024;
+        gn2v_block_extract_temp_bytes(cap, &tb);
+        if (!(buf.alloc(&walks, V * round_walks * L * 4) || buf.alloc(&pairs, cap * 8) ||
+              buf.alloc(&tmp, tb)))
             break;
-        // somebody else took the memory between the query and here: an automatic size halves
+        // somebody else took the memory between the query and here: smaller groups, then an
+        // automatic round halves
         release_round();
-        if (!automatic || round_walks <= (1u << 14)) return 1;
-        round_walks /= 2;
+        if (group_parts > 1)
+            group_parts = (group_parts + 1) / 2;
+        else if (automatic && round_walks > (1u << 14))
+            round_walks /= 2;
+        else
+            return kOutOfMemory;
     }
     const uint64_t super_walks = V * round_walks;
+
+    // The contextual table is trained in the caller's buffer -- no third table exists during the
+    // fit -- stored part by part (the rows of part p one after the other from row first_row[p]: a
+    // part is one contiguous range for its launches); the natural order is restored at the end
+    // through one scratch copy, for which the pair buffers make room.  When even that copy would
+    // not fit what is free now (or GN2V_BLOCK_LAYOUT=natural asks for it), the rows stay where
+    // they belong and part p is the rows p, p + parts, ... (gn2v_block_io.context_ld).
+    const size_t table_bytes = (size_t)n * ld * sizeof(float);
+    const char *layout = getenv("GN2V_BLOCK_LAYOUT");
+    const bool part_major = parts > 1 && !(layout && !strcmp(layout, "natural")) &&
+                            (free_b > table_bytes + ((size_t)1 << 28) ||
+                             (layout && !strcmp(layout, "parts")));
+    std::vector<uint64_t> first_row(parts + 1, 0);
+    for (uint32_t p = 0; p < parts; ++p)
+        first_row[p + 1] = first_row[p] + gn2v::stripe_count(n, p, parts);
+    HIP_TRY(hipMemcpyAsync(part_first, first_row.data(), (parts + 1) * 8, hipMemcpyHostToDevice, s));
+    if (gn2v_init_table(d_central, n, tp->d, ld, seed, 0, tp->init_scale, s)) return 1;
+    if (!part_major) {
+        if (gn2v_init_table(d_contextual, n, tp->d, ld, seed, 1, tp->init_scale, s)) return 1;
+    } else {
+        for (uint32_t p = 0; p < parts; ++p)
+            if (gn2v_init_table_rows(d_contextual + first_row[p] * ld,
+                                     first_row[p + 1] - first_row[p], tp->d, ld, seed, 1,
+                                     tp->init_scale, p, parts, s))
+                return 1;
+    }
 
     float lr = tp->lr;
     uint64_t round_id = 0;
@@ -582,64 +634,75 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
             if (gn2v_walks(g, wp, seed, e, first, nw, walks, s)) return 1;
             for (uint32_t j = 0; j < V; ++j) {
                 const gn2v_block_plan *pj = &plans[j];
-                if (gn2v_block_count(g, pj, walks, nw, seed, e, first, work, cell_offsets, s))
-                    return 1;
-                uint64_t n_pairs = 0;  // the one host read of the pass
-                HIP_TRY(hipMemcpyAsync(&n_pairs, cell_offsets + cells, 8, hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                if (n_pairs == 0) continue;
-                if (n_pairs > cap) {  // a stripe heavier than the head room allows: grow
-                    (void)hipFree(tmp);
-                    (void)hipFree(vals);
-                    (void)hipFree(keys);
-                    buf.ptrs.resize(buf.ptrs.size() - 3);
-                    cap = n_pairs + n_pairs / 16;
-                    gn2v_block_extract_temp_bytes(cap, plan.key_bits, &tb);
-                    if (buf.alloc(&keys, cap * key_bytes) || buf.alloc(&vals, cap * 4) ||
-                        buf.alloc(&tmp, tb))
+                for (uint32_t p0 = 0; p0 < parts; p0 += group_parts) {
+                    const uint32_t pn = std::min(group_parts, parts - p0);
+                    if (gn2v_block_count(g, pj, walks, nw, seed, e, first, p0, pn, work,
+                                         cell_offsets, s))
                         return 1;
-                }
-                if (gn2v_block_extract(g, pj, walks, nw, seed, e, first, work, hub_bits, n_pairs,
-                                       keys, vals, tmp, tb, s))
-                    return 1;
-                for (uint32_t p = 0; p < parts; ++p) {
-                    gn2v_block_io io{};
-                    io.d_keys = keys;
-                    io.d_vals = vals;
-                    io.d_cell_offsets = cell_offsets;
-                    io.d_alias = alias;
-                    io.d_cell_rows = cell_rows;
-                    io.d_central = d_central + (size_t)j * ld;
-                    io.central_ld = (uint64_t)V * ld;
-                    io.d_context = ctx + (size_t)p * max_rows * ld;
-                    io.block_id = round_id * V + j;
-                    io.part = p;
-                    if (gn2v_block_step(g, tp, pj, &io, seed, e, lr, s)) return 1;
-                }
-                if (g->train_events.size() > 2048) {  // bound the event pool on long fits
+                    uint64_t n_pairs = 0;  // the one host read of the group
+                    HIP_TRY(hipMemcpyAsync(&n_pairs, cell_offsets + cells, 8,
+                                           hipMemcpyDeviceToHost, s));
                     HIP_TRY(hipStreamSynchronize(s));
-                    gn2v_stats scratch;
-                    if (gn2v_stats_read(g, &scratch, s)) return 1;
+                    if (n_pairs == 0) continue;
+                    if (n_pairs > cap) {  // a group heavier than the head room allows: grow
+                        (void)hipFree(tmp);
+                        (void)hipFree(pairs);
+                        buf.ptrs.resize(buf.ptrs.size() - 2);
+                        cap = n_pairs + n_pairs / 16;
+                        gn2v_block_extract_temp_bytes(cap, &tb);
+                        if (buf.alloc(&pairs, cap * 8) || buf.alloc(&tmp, tb)) return 1;
+                    }
+                    if (gn2v_block_extract(g, pj, walks, nw, seed, e, first, p0, pn, work, hub_bits,
+                                           n_pairs, pairs, tmp, tb, s))
+                        return 1;
+                    for (uint32_t p = p0; p < p0 + pn; ++p) {
+                        gn2v_block_io io{};
+                        io.d_pairs = pairs;
+                        io.d_cell_offsets = cell_offsets;
+                        io.d_alias = alias;
+                        io.d_cell_rows = cell_rows;
+                        io.d_central = d_central + (size_t)j * ld;
+                        io.central_ld = (uint64_t)V * ld;
+                        io.d_context = part_major ? d_contextual + first_row[p] * ld
+                                                  : d_contextual + (size_t)p * ld;
+                        io.context_ld = part_major ? 0 : (uint64_t)parts * ld;
+                        io.block_id = round_id * V + j;
+                        io.part = p;
+                        if (gn2v_block_step(g, tp, pj, &io, seed, e, lr, s)) return 1;
+                    }
+                    if (g->train_events.size() > 2048) {  // bound the event pool on long fits
+                        HIP_TRY(hipStreamSynchronize(s));
+                        gn2v_stats scratch;
+                        if (gn2v_stats_read(g, &scratch, s)) return 1;
+                    }
                 }
             }
         }
         lr *= tp->lr_decay;
     }
-    for (uint32_t p = 0; p < parts; ++p) {
-        const uint64_t rows = gn2v::stripe_count(n, p, parts);
-        if (!rows) continue;
-        const unsigned blocks =
-            (unsigned)std::min<uint64_t>((rows * (ld >> 2) + 255) / 256, 256 * 32);
-        hipLaunchKernelGGL(gn2v::scatter_part_kernel, dim3(blocks), dim3(256), 0, s, d_contextual,
-                           ctx + (size_t)p * max_rows * ld, rows, ld, p, parts);
-        HIP_TRY(hipGetLastError());
-    }
     HIP_TRY(hipStreamSynchronize(s));
+    release_round();
+    if (part_major) {  // part-major -> natural order
+        float *scratch = nullptr;
+        if (buf.alloc(&scratch, table_bytes))
+            return fail("out of device memory while restoring the row order of the contextual "
+                        "table (GN2V_BLOCK_LAYOUT=natural trains without that copy)");
+        HIP_TRY(hipMemcpyAsync(scratch, d_contextual, table_bytes, hipMemcpyDeviceToDevice, s));
+        const unsigned blocks =
+            (unsigned)std::min<uint64_t>((n * (ld >> 2) + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(gn2v::parts_to_natural_kernel, dim3(blocks), dim3(256), 0, s,
+                           d_contextual, scratch, (const unsigned long long *)part_first, n, ld,
+                           parts);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     if (stats) {
         if (gn2v_stats_read(g, stats, s)) return 1;
         stats->block_parts = parts;
         stats->block_slices = plan.slices;
         stats->block_stripes = V;
+        stats->block_group_parts = group_parts;
+        stats->block_round_walks = round_walks;
     }
     return 0;
 }

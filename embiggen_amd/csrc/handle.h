@@ -70,6 +70,9 @@ struct gn2v_graph {
     gn2v::GraphView view{};
     int device = 0;
     int n_cus = 256;
+    // XCDs (one L2 each) workgroups are spread over, ids 0 .. n_xcds - 1, found by a probe launch
+    // when the handle is made; 0 = unknown (then no row is ever treated as exclusive to one XCD)
+    int n_xcds = 0;
     bool owns = false;
     void *own_row_ptr = nullptr, *own_col_idx = nullptr, *own_cumw = nullptr,
          *own_sources = nullptr, *own_node_types = nullptr, *own_edge_types = nullptr;

@@ -47,6 +47,14 @@ struct TrainArgs {
     float lr, clip;
 };
 
+// The XCD (accelerator complex) a wavefront runs on.  Each XCD of an MI355X has an L2 of its own;
+// L2s are not coherent with one another inside a launch.
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xF;
+}
+
 template <int CH>
 struct Row {
     float4 c[CH];
@@ -882,6 +890,10 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
 // same node share a slot through the reference count), or kNoSlot when the row is not cached (hot
 // node).  Finding a node is one parallel compare + ballot instead of a loop over the slots.
 constexpr uint32_t kNoSlot = 0xFFu;
+// lookup / free_slot are one ballot over the 64 lanes: the host only takes this kernel when
+// slots = 2 * window + 1 <= kWinCacheMaxSlots (larger windows run the uncached kernel)
+constexpr uint32_t kWinCacheMaxSlots = 64;
+static_assert(kWinCacheMaxSlots <= 64 && kWinCacheMaxSlots < kNoSlot, "one ballot, one byte");
 
 struct WinCache {
     float *rows;         // [slots][ld]
@@ -1037,7 +1049,9 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
             cache.pos_slot[lane] = kNoSlot;
         }
         wave_sync();
-        constexpr int kPfChunks = CH > 4 ? 2 : 1;  // CH <= 4: ld <= 256 floats = 64 chunks
+        // float4 chunks per lane of a whole row spread over the 64 lanes: ld / 256, rounded up
+        // (CH <= 4: ld <= 256 floats = 64 chunks; CH = 16: ld <= 1024 = 256 chunks)
+        constexpr int kPfChunks = CH > 8 ? 4 : CH > 4 ? 2 : 1;
         for (uint32_t p = 0; p < Le && p <= w; ++p)
             win_insert<kPfChunks>(a, cache, a.contextual, p, s_walk[p], lane, nullptr);
         // one centre ahead, in registers: the negatives (their ids cost a random col_idx read) and

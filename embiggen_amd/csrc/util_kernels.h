@@ -2,8 +2,14 @@
 // used by the benchmark configurations.
 #pragma once
 #include "rng.h"
+#include "train_kernels.h"
 
 namespace gn2v {
+
+// mask[0] |= 1 << (XCD of this workgroup): a launch of many workgroups reports the XCDs in use
+static __global__ void xcc_probe_kernel(unsigned int *mask) {
+    if (threadIdx.x == 0) atomicOr(mask, 1u << xcc_id());
+}
 
 // table[r][c] = (2*u24 - 1) * scale with u24 from draw(key, r*d + c); padding columns are zero.
 __global__ void init_kernel(float *__restrict__ t, uint64_t n_rows, uint32_t d, uint32_t ld,

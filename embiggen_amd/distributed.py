@@ -19,13 +19,15 @@ ever held by two GPUs.
   (RCCL send / receive on its own stream); P + 1 part buffers per rank.
 * Pairs: a round = ``round_walks`` walks per rank.  The walks (u32 ids, 512 B each) are
   all-gathered; every rank extracts from ALL walks of the round the (centre, context) pairs whose
-  centre it owns, sorted by (context part, centre) -- two passes over the walks and one radix sort
-  in HIP (``gn2v_block_count`` / ``gn2v_block_extract``); nothing else crosses the fabric.
+  centre it owns -- one 64-bit word per pair, a *group* of consecutive episodes' parts at a time:
+  two passes over the walks and one radix sort in HIP (``gn2v_block_count`` /
+  ``gn2v_block_extract``), so the pair buffers hold 1 / groups of the round; nothing else
+  crosses the fabric.
 * Training: ``gn2v_block_step`` per part, negatives drawn degree-proportionally inside the
   cell of the pair's context (one alias table per cell).
 
-Preparation of round ``t + 1`` (walk generation, all-gather, extraction, sort) runs on a second
-stream while round ``t`` trains.
+Preparation of the next group (for the first group of a round: walk generation and all-gather;
+then extraction and sort) runs on a second stream while the current group trains.
 """
 import os
 import sys
@@ -47,19 +49,22 @@ PAIR_ROOM = 1 << 24  # pair buffers are sized in steps of this many pairs
 MIN_ROWS_PER_CELL = 32768
 
 
-def round_walks_within(free_bytes: int, walk_length: int, window: int, key_bits: int, world: int,
-                       overlap: bool) -> int:
-    """Walks per rank and round for ``free_bytes`` of HBM (``gn2v_block_round_walks``: the largest
-    power of two <= 2^23 whose pair buffers -- held once by the round in training, twice by the
-    round being built -- fit three quarters of it).  Every rank must use the same value."""
+def round_plan(free_bytes: int, n_nodes: int, walk_length: int, window: int, world: int,
+               parts: int, slices: int, overlap: bool) -> Tuple[int, int]:
+    """(walks per rank and round, parts per extraction group) for ``free_bytes`` of HBM
+    (``gn2v_block_round_plan``: a round long enough for 64 pairs per (cell, centre) within
+    [2^20, 2^23] walks; groups of parts -- at least four per round -- whose pair words, held once
+    sorted (twice when the next group is prepared meanwhile) and once unsorted, fit three quarters
+    of it beside the walks).  Every rank must use the same values."""
     import ctypes as C
 
     from . import _lib
 
-    out = C.c_uint64()
-    _lib.check(_lib.lib().gn2v_block_round_walks(int(free_bytes), walk_length, window, key_bits,
-                                                 world, int(bool(overlap)), C.byref(out)))
-    return out.value
+    walks, group = C.c_uint64(), C.c_uint32()
+    _lib.check(_lib.lib().gn2v_block_round_plan(int(free_bytes), n_nodes, walk_length, window,
+                                                world, parts, slices, int(bool(overlap)),
+                                                C.byref(walks), C.byref(group)))
+    return walks.value, group.value
 
 
 def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:
@@ -68,8 +73,9 @@ def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:
     the smaller a cell, the more of it lives in the XCD's L2 (BA 10 M nodes: 0.67 of the HBM
     roofline unsliced, 0.80 at 4 x 8 cells, 0.87 at 32 x 8) -- and the more often two waves
     read-modify-write the same row at once; link quality stays at or above the walk-ordered
-    trainer's while a cell keeps >= 32 k rows.  slices = 8 (one per XCD); as many parts -- at
-    least two per rank with several ranks, at most 128 -- as keep MIN_ROWS_PER_CELL rows a cell."""
+    trainer's while a cell keeps >= 32 k rows.  slices = 8 (one per XCD: only then is a row
+    exclusive to one L2; graphs too small for cells of 8 k rows: 1); as many parts -- any count,
+    a multiple of the ranks, at least two per rank -- as keep MIN_ROWS_PER_CELL rows a cell."""
     import ctypes as C
 
     from . import _lib
@@ -96,6 +102,12 @@ class LoopbackComm:
     def sendrecv_start(self, send, dst, recv, src):
         recv.copy_(send)
         return _Done()
+
+    def broadcast(self, tensor, src):
+        return tensor
+
+    def send_to_root(self, tensor, root, buffer=None, src=None):
+        return tensor
 
 
 class _Works:
@@ -156,6 +168,36 @@ class TorchComm:
                                         dist.P2POp(dist.irecv, recv, src, self._group)])
         return _Works(works)
 
+    def broadcast(self, tensor, src):
+        """`tensor` of rank `src` into `tensor` of every rank (in place)."""
+        if self._staged and tensor.is_cuda:
+            host = tensor.cpu()
+            self._dist.broadcast(host, src, group=self._group)
+            tensor.copy_(host)
+            return tensor
+        self._dist.broadcast(tensor, src, group=self._group)
+        return tensor
+
+    def send_to_root(self, tensor, root, buffer=None, src=None):
+        """Rank `src` sends `tensor`; rank `root` receives it into `buffer` (same shape) and gets
+        it back; every other rank gets None.  src == root: no transfer."""
+        dist = self._dist
+        if src == root:
+            return tensor if self.rank == root else None
+        if self.rank == src:
+            t = tensor.cpu() if self._staged and tensor.is_cuda else tensor
+            dist.send(t.contiguous(), root, group=self._group)
+            return None
+        if self.rank == root:
+            if self._staged and buffer.is_cuda:
+                host = buffer.cpu()
+                dist.recv(host, src, group=self._group)
+                buffer.copy_(host)
+            else:
+                dist.recv(buffer, src, group=self._group)
+            return buffer
+        return None
+
 
 class GpuBlockBackend:
     """Device side of the trainer: thin calls into the C ABI (``ops``)."""
@@ -188,54 +230,54 @@ class GpuBlockBackend:
 
         return ops.block_alias(self.graph, plan, device=self.index)
 
-    def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None, scale=1.0,
-                slot=None):
-        """-> (keys, vals, cell_offsets, n_pairs); one host read (the pair count).
+    def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None, part_lo=0,
+                part_n=0, capacity=0, slot=None):
+        """-> (pairs, cell_offsets, n_pairs): the sorted pair words of the group of parts
+        ``part_lo, part_lo + 1, ...`` (``part_n`` of them, cyclic; 0, 0 = every part); one host
+        read (the pair count).
 
-        ``slot`` None: fresh buffers of this round's size.  ``slot`` 0 / 1: the trainer's standing
-        buffers -- one (keys, vals) pair per slot and one sort buffer, allocated once for
-        ``scale`` times the pairs of this round (a short first or last round of a fit is sized
-        like the full ones) and kept until ``release()``: 2 x 42 GB + 84 GB per round of 2^22
-        walks must not depend on which cached block the allocator happens to split."""
+        ``slot`` None: fresh buffers of this group's size.  ``slot`` 0 / 1: the trainer's standing
+        buffers -- one pair buffer per slot and one buffer for the unsorted words + the sort,
+        allocated once for ``capacity`` pairs (what a full group of a full round holds; a short
+        first or last round reuses them) and kept until ``release()``: tens of GB must not depend
+        on which cached block the allocator happens to split."""
         from . import ops
 
         import torch
 
-        work, offsets = ops.block_count(self.graph, plan, walks_all, seed, epoch, first_walk)
+        work, offsets = ops.block_count(self.graph, plan, walks_all, seed, epoch, first_walk,
+                                        part_lo=part_lo, part_n=part_n)
         n_pairs = int(offsets[-1])
         dev = walks_all.device
-        key_type = torch.int64 if plan.key_bits == 64 else torch.int32
 
         def rounded(n):  # in steps of 2^24 pairs
             return max(1, -(-int(n) // PAIR_ROOM)) * PAIR_ROOM
 
         if slot is None:
             room = rounded(n_pairs)
-            keys = torch.empty(room, dtype=key_type, device=dev)
-            vals = torch.empty(room, dtype=torch.int32, device=dev)
-            temp = torch.empty(ops.block_extract_temp_bytes(room, plan.key_bits),
-                               dtype=torch.uint8, device=dev)
+            pairs = torch.empty(room, dtype=torch.int64, device=dev)
+            temp = torch.empty(ops.block_extract_temp_bytes(room), dtype=torch.uint8, device=dev)
         else:
-            held = self._slots.get(slot)
-            if held is None or held[0].numel() < n_pairs or held[0].dtype != key_type:
-                self._slots[slot] = held = None  # released before its successor is allocated
-                # the rounds of a fit differ by a fraction of a percent: 1/64 of head room
-                room = rounded(n_pairs * max(1.0, scale) * (1 + 1 / 64))
-                held = self._slots[slot] = (torch.empty(room, dtype=key_type, device=dev),
-                                            torch.empty(room, dtype=torch.int32, device=dev))
-            keys, vals = held
-            need = ops.block_extract_temp_bytes(keys.numel(), plan.key_bits)
+            pairs = self._slots.get(slot)
+            if pairs is None or pairs.numel() < n_pairs:
+                self._slots[slot] = pairs = None  # released before its successor is allocated
+                # the groups of a fit differ by a few percent: 1/64 on top of the largest seen
+                room = rounded(max(n_pairs, capacity) * (1 + 1 / 64))
+                pairs = self._slots[slot] = torch.empty(room, dtype=torch.int64, device=dev)
+            need = ops.block_extract_temp_bytes(pairs.numel())
             if self._temp is None or self._temp.numel() < need:
                 self._temp = None
                 self._temp = torch.empty(need, dtype=torch.uint8, device=dev)
             temp = self._temp
         ops.block_extract(self.graph, plan, walks_all, seed, epoch, first_walk, work, n_pairs,
-                          keys=keys, vals=vals, temp=temp, hub_bits=hub_bits)
+                          pairs=pairs, temp=temp, hub_bits=hub_bits, part_lo=part_lo,
+                          part_n=part_n)
         if os.environ.get("GN2V_BENCH_MEMLOG"):
-            print(f"[mem] prepare: {n_pairs} pairs, room {keys.numel()}, slot {slot}, allocated "
+            print(f"[mem] prepare: parts {part_lo}+{part_n}: {n_pairs} pairs, room "
+                  f"{pairs.numel()}, slot {slot}, allocated "
                   f"{torch.cuda.memory_allocated() / 1e9:.1f} GB, reserved "
                   f"{torch.cuda.memory_reserved() / 1e9:.1f} GB", file=sys.stderr, flush=True)
-        return keys[:n_pairs], vals[:n_pairs], offsets, n_pairs
+        return pairs[:n_pairs], offsets, n_pairs
 
     def release(self):
         """Give the standing pair buffers back (before the result tables are assembled)."""
@@ -249,10 +291,10 @@ class GpuBlockBackend:
              epoch, lr, whole_central=False):
         from . import ops
 
-        keys, vals, offsets, n_pairs = prepared
+        pairs, offsets, n_pairs = prepared[:3]
         if n_pairs == 0:
             return
-        ops.block_step(self.graph, tp, plan, keys, vals, offsets, alias, cell_rows, central,
+        ops.block_step(self.graph, tp, plan, pairs, offsets, alias, cell_rows, central,
                        context, block_id, part, seed, epoch, lr, whole_central=whole_central)
 
 
@@ -264,8 +306,12 @@ class BlockPartitionedTrainer:
                  device, walk_length: int, window: int, min_dist: int = 1,
                  scale_free: bool = True, backend=None, parts: Optional[int] = None,
                  slices: Optional[int] = None, record: int = 16, hot_band=(0, 0),
-                 stripes: int = 1):
-        """``stripes`` (one GPU only): the centres are split into that many stripes (centre c:
+                 stripes: int = 1, group_parts: Optional[int] = None):
+        """``group_parts``: the parts whose pairs are extracted, sorted and held at a time (None:
+        all of a round at once; ``models.fit_transform_blocks`` and ``bench.py`` take it from
+        ``round_plan``).  Every rank must pass the same value.
+
+        ``stripes`` (one GPU only): the centres are split into that many stripes (centre c:
         stripe c % stripes) and a round is trained stripe after stripe, each stripe over the pairs
         of ALL the round's walks whose centre it owns -- what ``stripes`` ranks would do side by
         side.  The pairs of a pass, hence the memory, are those of a round of
@@ -274,6 +320,7 @@ class BlockPartitionedTrainer:
         self.graph, self.tp, self.comm = graph, train_params, comm
         self.d, self.ld, self.seed = d, ld, seed
         self.n_nodes = graph.get_number_of_nodes()
+        self.walk_length, self.window = walk_length, window
         rank, world = comm.rank, comm.world
         self.backend = backend if backend is not None else GpuBlockBackend(graph, device)
         auto_parts, auto_slices = auto_plan(self.n_nodes, world)
@@ -284,6 +331,7 @@ class BlockPartitionedTrainer:
                              "of the number of ranks, at least two per rank.")
         self.parts, self.slices = parts, slices
         self.per_rank = parts // world
+        self.group_parts = parts if not group_parts else max(1, min(int(group_parts), parts))
         self.stripes = max(1, int(stripes))
         if self.stripes > 1 and world > 1:
             raise ValueError("Centre stripes are the one-GPU form of several ranks: stripes > 1 "
@@ -317,42 +365,71 @@ class BlockPartitionedTrainer:
             self.backend.init_rows(rows, d, ld, seed, 1, init_scale, p, parts, out=buf[:rows])
             self.held[p] = buf
         self._spare = self.backend.empty_rows(self.max_part_rows, ld) if world > 1 else None
-        # walks per rank and round the pair buffers are sized for (None: every round by itself);
+        # walks per rank and round the pair buffers are sized for (None: every group by itself);
         # with it a fit allocates once and a short round reuses the blocks of the full ones
         self.round_capacity = None
         self.episode = 0      # global episode counter g
         self.rounds_done = 0
+        self._round_episodes = 0  # episodes of the current round so far (all stripes)
         self.last_round = None
+        self.wait_ms = []     # HIP events around the wait for each hop (timed=True in run())
 
     # ------------------------------------------------------------------ helpers
     def part_of_episode(self, g: int) -> int:
-        world = self.comm.world
         return (self.per_rank * self.comm.rank + g) % self.parts
 
     def part_rows(self, p: int) -> int:
         return stripe_rows(self.n_nodes, p, self.parts)
 
-    def prepare(self, walks, seed: int, epoch: int, first_walk: int, slot=None, stripe: int = 0):
-        """Gather the round's walks from every rank and extract + sort this rank's pairs.
-        ``walks``: this rank's int32 [n, L] slice (ids first_walk + rank * n + [0, n)); every rank
-        passes the same n (ranks with fewer walks pad with sentinel rows).  ``slot``: which of the
-        backend's standing buffers receives the pairs (``run`` alternates two when it overlaps;
-        None: buffers of the round's own)."""
-        walks_all = self.comm.all_gather(walks)
-        if slot is not None and isinstance(self.backend, GpuBlockBackend):
-            scale = (self.round_capacity or 0) / max(1, walks.shape[0])
-            return self.backend.prepare(self.plans[stripe], walks_all, seed, epoch, first_walk,
-                                        self.hub_bits, scale=scale, slot=slot)
-        return self.backend.prepare(self.plans[stripe], walks_all, seed, epoch, first_walk,
-                                    self.hub_bits)
+    def groups(self) -> List[Tuple[int, int]]:
+        """(first part, number of parts) of the groups a round is prepared and trained in, in
+        this rank's episode order (a round starts at an episode that is a multiple of `parts`:
+        this rank's first part is always per_rank * rank; the parts of a group are consecutive
+        modulo `parts`)."""
+        gp = self.group_parts
+        return [(self.part_of_episode(e), min(gp, self.parts - e))
+                for e in range(0, self.parts, gp)]
 
-    def train_prepared(self, prepared, seed: int, epoch: int, lr: float, stripe: int = 0):
-        """`parts` episodes over the prepared pairs of one round (of one centre stripe of it)."""
+    def group_capacity(self) -> int:
+        """Pairs the standing buffers are sized for: a full group of a full round (untrimmed
+        windows) plus 1/8 -- parts, and with them groups, are not equally heavy."""
+        if not self.round_capacity:
+            return 0
+        pairs = self.round_capacity * 2 * self.window * self.walk_length
+        share = pairs * min(self.group_parts, self.parts) // self.parts
+        return share + share // 8
+
+    def gather_walks(self, walks):
+        """This rank's int32 [n, L] walks of the round -> the walks of every rank (all-gathered;
+        ids first_walk + rank * n + [0, n)); every rank passes the same n (ranks with fewer
+        walks pad with sentinel rows)."""
+        return self.comm.all_gather(walks)
+
+    def prepare(self, walks_all, seed: int, epoch: int, first_walk: int, group=None, slot=None,
+                stripe: int = 0):
+        """Extract + sort this rank's pairs of one group of parts (``group`` = (first part,
+        number of parts), None = the whole round) from the round's gathered walks.  ``slot``:
+        which of the backend's standing buffers receives the pairs (``run`` alternates two when it
+        overlaps; None: buffers of the group's own)."""
+        lo, n = group if group is not None else (self.part_of_episode(0), self.parts)
+        kw = {}
+        if slot is not None and isinstance(self.backend, GpuBlockBackend):
+            kw = {"capacity": self.group_capacity(), "slot": slot}
+        pairs, offsets, n_pairs = self.backend.prepare(
+            self.plans[stripe], walks_all, seed, epoch, first_walk, self.hub_bits, part_lo=lo,
+            part_n=n, **kw)
+        return pairs, offsets, n_pairs, lo, n
+
+    def train_prepared(self, prepared, seed: int, epoch: int, lr: float, stripe: int = 0,
+                       timed: bool = False):
+        """The episodes of one prepared group (all `parts` of them when the group is a round)."""
         comm, world = self.comm, self.comm.world
         striped = self.stripes > 1
         block_id = (self.rounds_done * self.stripes + stripe if striped
                     else self.rounds_done * world + comm.rank)
-        for _ in range(self.parts):
+        lo, n_parts = prepared[3], prepared[4]
+        assert self.part_of_episode(self.episode) == lo, "groups must be trained in episode order"
+        for _ in range(n_parts):
             g = self.episode
             part = self.part_of_episode(g)
             pending = None
@@ -369,35 +446,58 @@ class BlockPartitionedTrainer:
                                               recv_buf[: self.part_rows(nxt)],
                                               (comm.rank + 1) % world)
             ctx = self.held[part]
-            if striped:
-                self.backend.step(self.tp, self.plans[stripe], prepared, self.alias,
-                                  self.cell_rows, self.central, ctx[: self.part_rows(part)],
-                                  block_id, part, seed, epoch, lr, whole_central=True)
-            else:
-                self.backend.step(self.tp, self.plan, prepared, self.alias, self.cell_rows,
-                                  self.central, ctx[: self.part_rows(part)], block_id, part, seed,
-                                  epoch, lr)
+            self.backend.step(self.tp, self.plans[stripe], prepared, self.alias, self.cell_rows,
+                              self.central, ctx[: self.part_rows(part)], block_id, part, seed,
+                              epoch, lr, whole_central=striped)
             if pending is not None:
-                pending.wait()
+                if timed:
+                    self._timed_wait(pending)
+                else:
+                    pending.wait()
                 self.held[nxt] = recv_buf
                 self._spare = send_buf
             self.episode += 1
-        trained = int(prepared[3]) + (self.last_round["pairs_trained"] if stripe else 0)
-        self.last_round = {"pairs_trained": trained}
-        if stripe == self.stripes - 1:
+        if self._round_episodes == 0:
+            self.last_round = {"pairs_trained": 0}
+        self.last_round["pairs_trained"] += int(prepared[2])
+        self._round_episodes += n_parts
+        if self._round_episodes == self.parts * self.stripes:
+            self._round_episodes = 0
             self.rounds_done += 1
 
-    def train_round(self, walks, seed: int, epoch: int, lr: float, first_walk: int, slot=None):
-        for j in range(self.stripes):
-            self.train_prepared(self.prepare(walks, seed, epoch, first_walk, slot=slot, stripe=j),
-                                seed, epoch, lr, stripe=j)
+    def _timed_wait(self, pending):
+        """pending.wait() between two events on the current stream: what the compute stream
+        really waits for a hop that had a whole episode to complete (read with hop_wait_ms())."""
+        import torch
 
-    def run(self, rounds, overlap: bool = True):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        pending.wait()
+        b.record()
+        self.wait_ms.append((a, b))
+
+    def hop_wait_ms(self):
+        """Exposed wait per hop in ms (after a synchronize): list of floats."""
+        out = [a.elapsed_time(b) for a, b in self.wait_ms]
+        self.wait_ms = []
+        return out
+
+    def train_round(self, walks, seed: int, epoch: int, lr: float, first_walk: int, slot=None):
+        walks_all = self.gather_walks(walks)
+        for j in range(self.stripes):
+            for group in self.groups():
+                self.train_prepared(
+                    self.prepare(walks_all, seed, epoch, first_walk, group=group, slot=slot,
+                                 stripe=j), seed, epoch, lr, stripe=j)
+
+    def run(self, rounds, overlap: bool = True, timed: bool = False):
         """Train a sequence of rounds; ``rounds`` is a list of ``(make_walks, seed, epoch, lr,
         first_walk)`` where ``make_walks()`` returns this rank's int32 [n, L] walks of the round
-        (called on the stream the preparation runs on).  With ``overlap`` the preparation of round
-        t + 1 -- walk generation, all-gather, pair extraction, sort -- runs on a second stream
-        while round t trains; at most two rounds are in flight."""
+        (called on the stream the preparation runs on).  With ``overlap`` the preparation of the
+        next group -- for the first group of a round: walk generation and all-gather; then pair
+        extraction and sort -- runs on a second stream while the current group trains; two groups
+        are in flight at most.  ``timed``: HIP events around every wait for a hop
+        (``hop_wait_ms()``)."""
         import torch
 
         rounds = list(rounds)
@@ -406,47 +506,61 @@ class BlockPartitionedTrainer:
         on_gpu = isinstance(self.backend, GpuBlockBackend)
         # a single round too: one allocator pool for all rounds; centre stripes run in line
         overlap = overlap and on_gpu and self.stripes == 1
-        make, seed, epoch, lr, first = rounds[0]
         if not overlap:
-            # one standing slot: the stream orders a round's (a stripe's) training before the
-            # pairs of the next are written
+            # one standing slot: the stream orders a group's training before the pairs of the
+            # next are written
             for make, seed, epoch, lr, first in rounds:
-                self.train_round(make(), seed, epoch, lr, first, slot=0)
+                self.train_round(make(), seed, epoch, lr, first, slot=0 if on_gpu else None)
             return
         dev = self.backend.device
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(dev)
-        side, before = self._side, None
-        # every preparation on the side stream, the first one too: the allocator keeps one pool of
-        # freed blocks per stream, and ~100 GB of pair buffers must come back to the pool that the
-        # next preparation allocates from
+        side = self._side
+        groups = self.groups()
+        units = [(r, gi) for r in range(len(rounds)) for gi in range(len(groups))]
+        state = {"walks_all": None}
+
+        def prep(unit, turn):
+            r, gi = unit
+            make, seed, epoch, _, first = rounds[r]
+            # every preparation on the side stream, the first one too: the allocator keeps one
+            # pool of freed blocks per stream, and tens of GB of walks and pair buffers must come
+            # back to the pool that the next preparation allocates from
+            with torch.cuda.stream(side):
+                if gi == 0:
+                    state["walks_all"] = None  # the last round's walks go back to the pool first
+                    state["walks_all"] = self.gather_walks(make())
+                return self.prepare(state["walks_all"], seed, epoch, first, group=groups[gi],
+                                    slot=turn)
+
         side.wait_stream(main)
         turn = getattr(self, "_turn", 0)  # two standing slots, alternating across run() calls too
-        with torch.cuda.stream(side):
-            prepared = self.prepare(make(), seed, epoch, first, slot=turn)
+        prepared = prep(units[0], turn)
         main.wait_stream(side)
-        for t, (_, seed, epoch, lr, _) in enumerate(rounds):
-            self.train_prepared(prepared, seed, epoch, lr)
+        before = None
+        for u, (r, gi) in enumerate(units):
+            _, seed, epoch, lr, _ = rounds[r]
+            self.train_prepared(prepared, seed, epoch, lr, timed=timed)
             done = torch.cuda.Event()
             done.record(main)
             nxt = None
-            if t + 1 < len(rounds):
+            if u + 1 < len(units):
                 if before is not None:
-                    before.synchronize()  # round t - 1 is over: its buffers may be reused
-                make, nseed, nepoch, _, nfirst = rounds[t + 1]
+                    side.wait_event(before)  # group u - 1 is over: its slot may be rewritten
                 turn ^= 1
-                with torch.cuda.stream(side):
-                    nxt = self.prepare(make(), nseed, nepoch, nfirst, slot=turn)
+                nxt = prep(units[u + 1], turn)
                 main.wait_stream(side)
             before, prepared = done, nxt
+        state["walks_all"] = None
         self._turn = turn ^ 1
 
     # ------------------------------------------------------------------ results
-    def gather_full(self):
-        """(central, contextual) as full [N, ld] tables on every rank."""
-        import torch
-
+    def gather_full(self, root: Optional[int] = None):
+        """(central, contextual) as full [N, ld] tables: on every rank (``root`` None), or on rank
+        ``root`` only (the other ranks get ``(None, None)`` and hold nothing beyond their own
+        shards).  Partitions travel one at a time through a staging buffer of one partition: a
+        rank that assembles holds the two tables plus that buffer, never a second copy."""
         comm, world, n, ld = self.comm, self.comm.world, self.n_nodes, self.ld
         if hasattr(self.backend, "release"):
             self.backend.release()
@@ -458,21 +572,39 @@ class BlockPartitionedTrainer:
             for p in sorted(self.held):
                 context[p::self.parts] = self.held[p][: self.part_rows(p)]
             return self.central, context
-        central = self.backend.empty_rows(n, ld)
-        context = self.backend.empty_rows(n, ld)
-        max_c = stripe_rows(n, 0, world)
-        padded = self.backend.empty_rows(max_c, ld)
-        padded.zero_()
-        padded[: self.central.shape[0]] = self.central
-        every = comm.all_gather(padded)
+        import torch
+
+        assemble = root is None or comm.rank == root
+        central = self.backend.empty_rows(n, ld) if assemble else None
+        context = self.backend.empty_rows(n, ld) if assemble else None
+        stage = self.backend.empty_rows(stripe_rows(n, 0, world), ld)
         for r in range(world):
-            central[r::world] = every[r * max_c: r * max_c + stripe_rows(n, r, world)]
-        del every, padded
+            rows = stripe_rows(n, r, world)
+            got = self._move(self.central if comm.rank == r else None, stage[:rows], r, root)
+            if assemble:
+                central[r::world] = got
+        del stage
+        # which rank holds which part now (the rotation stops anywhere): every rank learns it
         ids = sorted(self.held)
-        mine = torch.stack([self.held[p] for p in ids])          # [2, max_rows, ld]
-        id_t = torch.tensor(ids, dtype=torch.int64, device=mine.device)
-        all_ids = comm.all_gather(id_t).tolist()
-        every = comm.all_gather(mine)
-        for i, p in enumerate(all_ids):
-            context[p::self.parts] = every[i][: self.part_rows(p)]
+        id_t = torch.tensor(ids, dtype=torch.int64, device=self.central.device)
+        owners = comm.all_gather(id_t).tolist()      # [world * per_rank], rank-major
+        stage = self._spare
+        for i, p in enumerate(owners):
+            r = i // self.per_rank
+            rows = self.part_rows(p)
+            got = self._move(self.held[p][:rows] if comm.rank == r else None, stage[:rows], r, root)
+            if assemble:
+                context[p::self.parts] = got
         return central, context
+
+    def _move(self, mine, stage, src: int, root: Optional[int]):
+        """The tensor `mine` of rank `src` as seen by the assembling rank(s): broadcast through
+        `stage` (root None) or sent to `root`."""
+        comm = self.comm
+        if root is None:
+            if comm.rank == src:
+                stage.copy_(mine)
+            return comm.broadcast(stage, src)
+        if src == root:
+            return mine
+        return comm.send_to_root(mine, root, buffer=stage, src=src)

@@ -210,7 +210,9 @@ class _WalkBasedModel:
             self.last_seconds = time.perf_counter() - start
         self.last_stats = stats.as_dict()
         self.last_plan = ({"world": 1, "parts": stats.block_parts, "slices": stats.block_slices,
-                           "stripes": stats.block_stripes} if stats.block_parts else None)
+                           "stripes": stats.block_stripes,
+                           "group_parts": stats.block_group_parts,
+                           "round_walks": stats.block_round_walks} if stats.block_parts else None)
         if self.verbose:
             secs = max(self.last_seconds, 1e-9)
             path = (f" (block path, {stats.block_parts} parts x {stats.block_slices} slices, "
@@ -232,17 +234,21 @@ class _WalkBasedModel:
 
     def fit_transform_blocks(self, graph, comm, round_walks: Optional[int] = None, slices=None,
                              parts=None, overlap: bool = True, max_walks_per_epoch: int = 0,
-                             stripes: Optional[int] = None):
+                             stripes: Optional[int] = None, group_parts: Optional[int] = None,
+                             root: Optional[int] = None):
         """SkipGram over several GPUs, one process per GPU (``comm`` = ``distributed.TorchComm``
         under ``torch.distributed.run``): tables partitioned by node id, no row shared between
         GPUs (``distributed.BlockPartitionedTrainer``).  Every rank returns the full
-        ``(central, contextual)`` device tensors [N, padded_size].  With one rank
+        ``(central, contextual)`` device tensors [N, padded_size] -- or, with ``root``, that rank
+        only (the others return ``(None, None)`` and never hold more than their shards).
+        ``group_parts``: parts whose pairs are extracted and held at a time (None: from the free
+        HBM, ``distributed.round_plan``).  With one rank
         (``LoopbackComm``) this is the Python form of ``gn2v_train_blocks``: ``stripes`` centre
         stripes (None = 1 = none, as there) play the ranks one after the other."""
         import torch
 
         from . import ops
-        from .distributed import BlockPartitionedTrainer, round_walks_within
+        from .distributed import BlockPartitionedTrainer, round_plan
 
         if self.MODEL_ID != _lib.MODEL_SKIPGRAM:
             raise NotImplementedError(
@@ -273,21 +279,27 @@ class _WalkBasedModel:
             walks_per_epoch = csr.get_number_of_unique_source_nodes() * self.iterations
             if max_walks_per_epoch:
                 walks_per_epoch = min(walks_per_epoch, max_walks_per_epoch)
-            if round_walks is None:
-                # the full tables every rank returns must fit beside the last rounds
+            if round_walks is None or group_parts is None:
+                # the full tables a rank returns must fit beside the last rounds
                 torch.cuda.empty_cache()
-                result = (2 if comm.world > 1 else 1) * trainer.n_nodes * self.padded_size * 4
-                round_walks = round_walks_within(
-                    max(0, torch.cuda.mem_get_info(dev)[0] - result), L, self.window_size,
-                    trainer.plan.key_bits, lanes, overlap and stripes == 1)
-                if comm.world > 1:  # every rank must use the same round size
-                    mine = torch.tensor([round_walks], dtype=torch.int64, device=dev)
-                    round_walks = int(comm.all_gather(mine).min())
+                holds = comm.world > 1 and (root is None or root == comm.rank)
+                result = (2 if holds else 0) * trainer.n_nodes * self.padded_size * 4
+                auto_walks, auto_group = round_plan(
+                    max(0, torch.cuda.mem_get_info(dev)[0] - result), trainer.n_nodes, L,
+                    self.window_size, lanes, trainer.parts, trainer.slices,
+                    overlap and stripes == 1)
+                if comm.world > 1:  # every rank must use the same round size and groups
+                    mine = torch.tensor([auto_walks, auto_group], dtype=torch.int64, device=dev)
+                    agreed = comm.all_gather(mine).view(-1, 2).min(0).values
+                    auto_walks, auto_group = int(agreed[0]), int(agreed[1])
+                round_walks = auto_walks if round_walks is None else round_walks
+                group_parts = auto_group if group_parts is None else group_parts
+            trainer.group_parts = max(1, min(int(group_parts), trainer.parts))
             # round_walks: the walks whose pairs a rank (a stripe) holds at once; a round is
             # `lanes` times that
             round_walks = max(1, min(round_walks, -(-walks_per_epoch // lanes)))
             stride = lanes * round_walks
-            trainer.round_capacity = stride if stripes > 1 else round_walks
+            trainer.round_capacity = round_walks  # per rank (per stripe pass)
             n_rounds = (walks_per_epoch + stride - 1) // stride
             lr = np.float32(self.learning_rate)
             start = time.perf_counter()
@@ -313,12 +325,13 @@ class _WalkBasedModel:
                     rounds.append((make, self.random_state, epoch, float(lr), first))
                 lr = np.float32(lr * np.float32(self.learning_rate_decay))
             trainer.run(rounds, overlap=overlap)
-            central, contextual = trainer.gather_full()
+            central, contextual = trainer.gather_full(root=root)
             torch.cuda.synchronize(dev)
             self.last_seconds = time.perf_counter() - start
         self.last_stats = ops.stats_read(csr, device)
         self.last_plan = {"world": comm.world, "parts": trainer.parts, "slices": trainer.slices,
-                          "stripes": trainer.stripes}
+                          "stripes": trainer.stripes, "group_parts": trainer.group_parts,
+                          "round_walks": round_walks}
         if self.verbose and comm.rank == 0:
             st, secs = self.last_stats, max(self.last_seconds, 1e-9)
             print(
@@ -347,7 +360,13 @@ class _WalkBasedModel:
 
                 comm = TorchComm()
         if comm is not None and comm.world > 1 and self.MODEL_ID == _lib.MODEL_SKIPGRAM:
-            central, contextual = self.fit_transform_blocks(graph, comm)
+            # model.gather_root = r: only rank r assembles (and returns) the tables, the other
+            # ranks return None -- 1 / world of the result traffic and no full tables beside
+            # their shards; default (None): every rank returns them, like the reference's call
+            root = getattr(self, "gather_root", None)
+            central, contextual = self.fit_transform_blocks(graph, comm, root=root)
+            if central is None:
+                return None
         if central is None:
             central, contextual, _ = self.fit_transform_device(graph)
         return self._download(central, contextual)

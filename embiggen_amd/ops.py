@@ -138,7 +138,7 @@ def block_plan(graph: CSRGraph, world: int, rank: int, parts: int, slices: int, 
     ``hot_hi``: contextual rows whose share of their cell's edge endpoints lies in
     [2^-hot_lo, 2^-hot_hi) are updated with atomics (off by default)."""
     plan = _lib.BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, 0,
-                          flags, hot_lo, hot_hi, 0)
+                          flags, hot_lo, hot_hi, 0, 0)
     _lib.check(_lib.lib().gn2v_block_plan_check(graph.device_graph(device).handle, C.byref(plan)))
     return plan
 
@@ -164,9 +164,10 @@ def block_alias(graph: CSRGraph, plan, device: int = 0):
 
 
 def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
-                work=None, cell_offsets=None):
+                work=None, cell_offsets=None, part_lo: int = 0, part_n: int = 0):
     """Pass 1 of the pair extraction: (work, cell_offsets int64 [cells + 1]); the last offset is
-    the number of pairs this rank trains in the round."""
+    the number of pairs this rank trains in the group of parts ``part_lo, part_lo + 1, ...``
+    (``part_n`` of them, cyclic; 0, 0 = every part)."""
     torch = _torch()
     dev = walks_tensor.device
     dg = graph.device_graph(dev.index or 0)
@@ -177,58 +178,69 @@ def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, firs
     assert walks_tensor.is_contiguous()
     _lib.check(_lib.lib().gn2v_block_count(
         dg.handle, C.byref(plan), walks_tensor.data_ptr(), walks_tensor.shape[0], seed, epoch,
-        first_walk, work.data_ptr(), cell_offsets.data_ptr(), _stream(dev)))
+        first_walk, part_lo, part_n, work.data_ptr(), cell_offsets.data_ptr(), _stream(dev)))
     return work, cell_offsets
 
 
-def block_extract_temp_bytes(n_pairs: int, key_bits: int = 32) -> int:
+def block_extract_temp_bytes(n_pairs: int) -> int:
     need = C.c_uint64()
-    _lib.check(_lib.lib().gn2v_block_extract_temp_bytes(n_pairs, key_bits, C.byref(need)))
+    _lib.check(_lib.lib().gn2v_block_extract_temp_bytes(n_pairs, C.byref(need)))
     return need.value
 
 
 def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
-                  work, n_pairs: int, keys=None, vals=None, temp=None, hub_bits=None):
-    """Pass 2 + sort: (keys int32 or int64 [n_pairs] by ``plan.key_bits``, vals int32 [n_pairs])
-    sorted by key."""
+                  work, n_pairs: int, pairs=None, temp=None, hub_bits=None, part_lo: int = 0,
+                  part_n: int = 0):
+    """Pass 2 + sort: the pair words int64 [n_pairs] (``cell << (row_bits + ctx_bits) | centre
+    row << ctx_bits | hot << (ctx_bits - 1) | context row inside its cell``) grouped by cell and
+    centre row."""
     torch = _torch()
     dev = walks_tensor.device
     dg = graph.device_graph(dev.index or 0)
-    key_dtype = torch.int64 if plan.key_bits == 64 else torch.int32
-    if keys is None:
-        keys = torch.empty(n_pairs, dtype=key_dtype, device=dev)
-        vals = torch.empty(n_pairs, dtype=torch.int32, device=dev)
-    assert keys.dtype == key_dtype
-    need = block_extract_temp_bytes(n_pairs, plan.key_bits)
+    if pairs is None:
+        pairs = torch.empty(n_pairs, dtype=torch.int64, device=dev)
+    assert pairs.dtype == torch.int64 and pairs.is_contiguous()
+    need = block_extract_temp_bytes(n_pairs)
     if temp is None:
         temp = torch.empty(need, dtype=torch.uint8, device=dev)
-    assert keys.numel() >= n_pairs and vals.numel() >= n_pairs and temp.numel() >= need
+    assert pairs.numel() >= n_pairs and temp.numel() >= need
     _lib.check(_lib.lib().gn2v_block_extract(
         dg.handle, C.byref(plan), walks_tensor.data_ptr(), walks_tensor.shape[0], seed, epoch,
-        first_walk, work.data_ptr(), None if hub_bits is None else hub_bits.data_ptr(), n_pairs,
-        keys.data_ptr(), vals.data_ptr(), temp.data_ptr(), temp.numel(), _stream(dev)))
-    return keys, vals
+        first_walk, part_lo, part_n, work.data_ptr(),
+        None if hub_bits is None else hub_bits.data_ptr(), n_pairs, pairs.data_ptr(),
+        temp.data_ptr(), temp.numel(), _stream(dev)))
+    return pairs
 
 
-def block_step(graph: CSRGraph, tp, plan, keys, vals, cell_offsets, alias, cell_rows, central,
+def block_step(graph: CSRGraph, tp, plan, pairs, cell_offsets, alias, cell_rows, central,
                context, block_id: int, part: int, seed: int, epoch: int, lr: float,
-               whole_central: bool = False):
+               whole_central: bool = False, whole_context: bool = False):
     """Train the pairs of one context part (``gn2v_block_step``; tables updated in place).
     ``whole_central``: ``central`` is the whole table [n_nodes, ld] and the plan's rank one of its
-    ``world`` centre stripes (one GPU training the stripes one after the other)."""
+    ``world`` centre stripes (one GPU training the stripes one after the other);
+    ``whole_context``: ``context`` is the whole contextual table and the part its rows
+    ``part, part + parts, ...``."""
     dev = central.device
     dg = graph.device_graph(dev.index or 0)
     assert central.is_contiguous() and context.is_contiguous()
     assert central.shape[1] == tp.ld and context.shape[1] == tp.ld
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-    c_ptr, c_ld = ptr(central), 0
+    c_ptr, c_ld, x_ptr, x_ld = ptr(central), 0, ptr(context), 0
     if whole_central:
         assert central.shape[0] == graph.get_number_of_nodes()
         c_ptr, c_ld = c_ptr + plan.rank * tp.ld * 4, plan.world * tp.ld
-    io = _lib.BlockIO(ptr(keys), ptr(vals), ptr(cell_offsets), ptr(alias), ptr(cell_rows),
-                      c_ptr, ptr(context), block_id, part, c_ld)
+    if whole_context:
+        assert context.shape[0] == graph.get_number_of_nodes()
+        x_ptr, x_ld = x_ptr + part * tp.ld * 4, plan.parts * tp.ld
+    io = _lib.BlockIO(ptr(pairs), ptr(cell_offsets), ptr(alias), ptr(cell_rows), c_ptr, x_ptr,
+                      block_id, part, c_ld, x_ld)
     _lib.check(_lib.lib().gn2v_block_step(dg.handle, C.byref(tp), C.byref(plan), C.byref(io),
                                           seed, epoch, lr, _stream(dev)))
+
+
+def graph_xcds(graph: CSRGraph, device: int = 0) -> int:
+    """XCDs (one L2 each) the device's workgroups are spread over (8 on an MI355X; 0 unknown)."""
+    return _lib.lib().gn2v_graph_xcds(graph.device_graph(device).handle)
 
 
 def _step(fn_name: str, graph: CSRGraph, tp, walks_tensor, seed, epoch, first_walk, lr, central,

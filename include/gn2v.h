@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GN2V_VERSION 100 /* 0.1.0 */
+#define GN2V_VERSION 200 /* 0.2.0: pair words, part groups */
 
 #define GN2V_SENTINEL 0xFFFFFFFFu /* walk positions after a trap node */
 
@@ -115,7 +115,8 @@ typedef struct {
     uint32_t block_parts;  /* plan of the block path when gn2v_train took it, else 0    */
     uint32_t block_slices;
     uint32_t block_stripes; /* centre stripes of that fit (gn2v_train_blocks), else 0   */
-    uint32_t reserved;
+    uint32_t block_group_parts; /* parts whose pairs were extracted + sorted at a time, else 0 */
+    uint64_t block_round_walks; /* walks per round of that fit, else 0                   */
 } gn2v_stats;
 
 typedef struct gn2v_graph gn2v_graph;
@@ -220,8 +221,15 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
  * context parts (context x: part x % parts, row x / parts); the parts travel round the ranks, a
  * pair (c, x) is trained on the owner of c while part x % parts is resident there, with
  * negatives drawn inside the cell of x.  `slices` stripes the rows of a part once more
- * (slice = row % slices): with 8 slices every XCD of an MI355X owns the rows it updates.
- * cell = part * slices + slice.  No row is ever held by two ranks. */
+ * (slice = row % slices): with one slice per XCD (8 on an MI355X; any multiple of the XCD count)
+ * every XCD owns the rows it updates and they are updated with plain write-back stores; with any
+ * other slice count several XCDs share a slice and the updates are write-through stores.
+ * cell = part * slices + slice.  No row is ever held by two ranks.
+ *
+ * A (centre, context) pair is ONE 64-bit word,
+ *     cell << (row_bits + ctx_bits) | centre row << ctx_bits | hot << (ctx_bits - 1) | context row
+ * with the context row counted inside its cell ((x / parts) / slices): 8 bytes per pair whatever
+ * the size of the graph. */
 typedef struct {
     uint32_t world;       /* ranks = central partitions                                      */
     uint32_t rank;
@@ -231,7 +239,7 @@ typedef struct {
     uint32_t window;      /* window_size                                                      */
     uint32_t min_dist;    /* 0 = 1 (Walklets: = window)                                       */
     uint32_t record;      /* consecutive sorted pairs a wavefront takes at a time; 0 = 16     */
-    uint32_t row_bits;    /* out (gn2v_block_plan_check): bits of the centre row in a key     */
+    uint32_t row_bits;    /* out (gn2v_block_plan_check): bits of the centre row in a pair word */
     uint32_t flags;       /* GN2V_TRAIN_DOWNSAMPLE: centres thinned while pairs are extracted */
     /* Hot rows (off by default, both 0): contextual rows whose share of their cell's edge
      * endpoints lies in [2^-hot_lo, 2^-hot_hi) (hot_hi = 0: no upper bound) are flagged by
@@ -240,11 +248,11 @@ typedef struct {
      * (e.g. 14 / 9 raises the link AUROC of small cells and costs 28 % speed). */
     uint32_t hot_lo;
     uint32_t hot_hi;
-    uint32_t key_bits;    /* out (gn2v_block_plan_check): 32, or 64 when cell and centre row do
-                             not fit one 32-bit sort key (d_keys is then u64[n_pairs])           */
+    uint32_t key_bits;    /* out (gn2v_block_plan_check): bits of a pair word in use (<= 64)   */
+    uint32_t ctx_bits;    /* out: low bits of a pair word = context row inside its cell + hot flag */
 } gn2v_block_plan;
 
-/* validates the plan against the graph, fills row_bits, key_bits and the defaults */
+/* validates the plan against the graph, fills row_bits, ctx_bits, key_bits and the defaults */
 int gn2v_block_plan_check(gn2v_graph *g, gn2v_block_plan *plan);
 
 /* rows first_row, first_row + row_stride, ... of the table gn2v_init_table would produce: a
@@ -268,33 +276,38 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
                      uint64_t temp_bytes, void *stream);
 
 /* Pairs of a round.  d_walks holds the walks of ALL ranks for the round (ids first_walk,
- * first_walk + 1, ...; all-gathered); this rank keeps the pairs whose centre it owns.
+ * first_walk + 1, ...; all-gathered); this rank keeps the pairs whose centre it owns and whose
+ * context lies in the group of parts part_lo, part_lo + 1, ... (part_n of them, cyclic modulo
+ * `parts`; part_lo = part_n = 0: every part).  A round is extracted, sorted and trained a group at
+ * a time, so the pair buffers hold one group, not the round.
  * gn2v_block_count: pass 1, fills d_work u64[GN2V_BLOCK_WORK_WORDS] (private to the two calls)
- * and d_cell_offsets u64[cells + 1] = where each cell starts in the sorted pair arrays; the last
- * entry is the number of pairs (the caller reads it to size the buffers).
- * gn2v_block_extract: pass 2 + one stable radix sort: d_keys u32 / u64 [n_pairs] (plan->key_bits)
- * = cell << row_bits | centre row, d_vals u32[n_pairs] = context row (bit 31 set when d_hub_bits, optional, flags the
- * context node as hot), sorted by key, ties in walk / position / slot order (independent of the
- * launch geometry). */
-#define GN2V_BLOCK_WORK_WORDS 9216
+ * and d_cell_offsets u64[cells + 1] = where each cell starts in the sorted pair words (cells
+ * outside the group are empty); the last entry is the number of pairs (the caller reads it to
+ * size the buffers).
+ * gn2v_block_extract: pass 2 + one stable radix sort on the bits above ctx_bits: d_pairs
+ * u64[n_pairs] = the pair words (hot flag set when d_hub_bits, optional, flags the context node)
+ * grouped by cell and centre row, ties in walk / position / slot order (independent of the launch
+ * geometry).  d_temp: gn2v_block_extract_temp_bytes(n_pairs) bytes (the unsorted words + the
+ * sort's own storage). */
+#define GN2V_BLOCK_WORK_WORDS 16384 /* 8192 extraction waves + 8192 cells */
 int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                      uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                     uint64_t *d_work, uint64_t *d_cell_offsets, void *stream);
-int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint32_t key_bits, uint64_t *bytes);
+                     uint32_t part_lo, uint32_t part_n, uint64_t *d_work,
+                     uint64_t *d_cell_offsets, void *stream);
+int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes);
 int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                        uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                       const uint64_t *d_work, const uint32_t *d_hub_bits, uint64_t n_pairs,
-                       void *d_keys, uint32_t *d_vals, void *d_temp, uint64_t temp_bytes,
-                       void *stream);
+                       uint32_t part_lo, uint32_t part_n, const uint64_t *d_work,
+                       const uint32_t *d_hub_bits, uint64_t n_pairs, uint64_t *d_pairs,
+                       void *d_temp, uint64_t temp_bytes, void *stream);
 
 typedef struct {
-    const void *d_keys;              /* sorted pairs of the round (gn2v_block_extract)         */
-    const uint32_t *d_vals;
+    const uint64_t *d_pairs;         /* sorted pair words of the group (gn2v_block_extract)    */
     const uint64_t *d_cell_offsets;  /* [cells + 1] (gn2v_block_count)                         */
     const uint64_t *d_alias;         /* gn2v_block_alias; unused without GN2V_TRAIN_SCALE_FREE */
     const uint64_t *d_cell_rows;
     float *d_central;                /* this rank's central partition f32[rows][central_ld]    */
-    float *d_context;                /* context part `part`, resident here, f32[rows][ld]      */
+    float *d_context;                /* context part `part`, resident here, f32[rows][context_ld] */
     uint64_t block_id;               /* RNG stream of the negatives: unique per (round, rank)  */
     uint32_t part;
     uint64_t central_ld;             /* floats between consecutive rows of the central partition;
@@ -303,48 +316,61 @@ typedef struct {
                                         of equal centre grow `world`-fold at the same memory)
                                         keeps the whole table f32[n_nodes][ld] and passes
                                         d_central = table + rank * ld, central_ld = world * ld   */
+    uint64_t context_ld;             /* the same for the context part; 0 = ld.  A part trained in
+                                        place inside the whole contextual table f32[n_nodes][ld]:
+                                        d_context = table + part * ld, context_ld = parts * ld   */
 } gn2v_block_io;
 
 /* The fused gather -> dot -> sigmoid -> scatter-add step over the pairs of one part: a wavefront
  * takes `record` consecutive sorted pairs at a time (records visited in a golden-ratio stride
  * order), keeps the centre row in registers while the centre does not change and applies
  * [context, k negatives] per pair.  tp: d, ld, k, clip, flags (update mode as gn2v_sgns_step;
- * sliced parts use plain stores for the contextual rows: they are exclusive to one XCD). */
+ * parts with one slice per XCD use plain stores for the contextual rows: they are exclusive to
+ * one XCD; any other slicing keeps the write-through stores). */
 int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
                     const gn2v_block_io *io, uint64_t seed, uint64_t epoch, float lr,
                     void *stream);
 
+/* XCDs (accelerator complexes, one L2 each) the workgroups of this graph's device are spread
+ * over, found by a probe launch in gn2v_graph_create: 8 on an MI355X; 0 = unknown. */
+int gn2v_graph_xcds(gn2v_graph *g);
+
 /* (parts, slices) of the contextual table for a graph of n_nodes on `world` ranks: slices = 8
- * (one per XCD) and as many parts (at least two per rank, at most 128) as keep >= 32 768 rows in
- * a cell -- the size from which the link quality of the block path is at or above the
- * walk-ordered schedule's. */
+ * (one per XCD; 1 on graphs too small to keep 8 192 rows in a cell) and as many parts (any count;
+ * a multiple of world, at least two per rank) as keep >= 32 768 rows in a cell -- the size from
+ * which the link quality of the block path is at or above the walk-ordered schedule's
+ * (DESIGN.md 7.3): 10 M nodes -> 38 x 8, 100 M -> 381 x 8. */
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t *parts, uint32_t *slices);
 
-/* Walks per rank and round for `free_bytes` of HBM (what is free once tables and graph are
- * resident): the longer a round, the more pairs of a centre meet in a cell (its row is read once
- * per such run: kernel 0.82 / 0.92 / 0.96 of the roofline at 2^20 / 2^22 / 2^23 walks on the bench
- * graph), so the largest power of two <= 2^23 (>= 2^14) whose pair buffers fit three quarters of
- * free_bytes.  Per pair key_bits / 8 + 4 bytes, held once by the round in training and twice
- * (radix sort double buffer) by the round being built: x 2 in line, x 3 with `overlap` (a second
- * round prepared while the first trains); plus the walks of all `world` ranks.  Pure host
- * function; every rank of a job must use the same value (take the minimum). */
-int gn2v_block_round_walks(uint64_t free_bytes, uint32_t walk_length, uint32_t window,
-                           uint32_t key_bits, uint32_t world, uint32_t overlap,
-                           uint64_t *round_walks);
+/* Walks per rank and round, and parts per extraction group, for `free_bytes` of HBM (what is free
+ * once tables and graph are resident).  The longer a round, the more pairs of a centre meet in a
+ * cell (its row is read once per such run: kernel 0.82 / 0.92 / 0.96 of the roofline at 2^20 /
+ * 2^22 / 2^23 walks on the bench graph): the power of two in [2^20, 2^23] that gives 64 pairs per
+ * (cell, centre), less when memory is short (>= 2^14).  group_parts: at least four groups per
+ * round when there are that many parts, more (smaller groups) when three quarters of free_bytes
+ * do not hold the walks plus, per group, its pair words once sorted (twice with `overlap`: the
+ * next group is prepared while this one trains) and once unsorted, 8 B per pair.  Pure host
+ * function; every rank of a job must use the same values (take the minimum). */
+int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_length,
+                          uint32_t window, uint32_t world, uint32_t parts, uint32_t slices,
+                          uint32_t overlap, uint64_t *round_walks, uint32_t *group_parts);
 
 /* The whole fit (same contract as gn2v_train: caller-allocated tables f32[n_nodes][ld], filled on
  * return) through the block path on one GPU: automatic plan, alias tables, rounds of
  * stripes x round_walks walks, per round walk generation and, for each of the `stripes` centre
  * stripes in turn (stripe j: the centres c with c % stripes == j -- what `stripes` ranks do side
- * by side): extraction + sort of the stripe's pairs from all the round's walks and one
- * gn2v_block_step per part on the stripe's rows of the central table (gn2v_block_io.central_ld).
- * round_walks = the walks whose pairs are held at once (0 = automatic: gn2v_block_round_walks of
- * the free HBM); stripes 0 = 1 (none).  With stripes the pairs of a centre meet in runs `stripes`
- * times as long at the memory of one round_walks (faster: DESIGN.md 7.4), but the stripes of a
- * round are trained one after the other, not side by side as ranks would be, which costs link
- * quality when a fit has few rounds: an option, not the default.  The central table is trained in place; the contextual
- * table lives in `parts` buffers of the library's own during the fit and is written to
- * d_contextual at the end.  gn2v_train calls this for SkipGram on graphs of >= 2^16 nodes. */
+ * by side) and each group of parts: extraction + sort of the group's pairs from all the round's
+ * walks and one gn2v_block_step per part on the stripe's rows of the central table
+ * (gn2v_block_io.central_ld).  round_walks = the walks one pass extracts from (0 = automatic:
+ * gn2v_block_round_plan of the free HBM); stripes 0 = 1 (none).  With stripes the pairs of a
+ * centre meet in runs `stripes` times as long (faster: DESIGN.md 7.4), but the stripes of a round
+ * are trained one after the other, not side by side as ranks would be, which costs link quality
+ * when a fit has few rounds: an option, not the default.  Both tables are trained in the caller's
+ * buffers (the contextual one stored part by part during the fit and put back in node order at
+ * the end through one scratch copy; GN2V_BLOCK_LAYOUT=natural in the environment, or too little
+ * free memory for that copy, trains it in node order with strided parts instead).  Returns 2
+ * when device memory ran out before anything was trained.  gn2v_train calls this for SkipGram on
+ * graphs of >= 2^16 nodes and falls back to the walk-ordered schedule on that 2. */
 int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
                       uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
                       uint32_t stripes, float *d_central, float *d_contextual, gn2v_stats *stats,

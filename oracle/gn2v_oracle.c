@@ -914,17 +914,21 @@ double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *log
  * are striped over `world` ranks (centre c: rank c % world, row c / world) and over `parts`
  * context parts (x: part x % parts, row x / parts), the rows of a part once more over `slices`
  * (row % slices); cell = part * slices + slice.  A rank extracts, from the walks of all ranks of
- * a round, the pairs whose centre it owns as (key = cell << row_bits | centre row, value = context
- * row) in walk / position / slot order, sorts them stably by key, and trains one part at a time:
+ * a round, the pairs whose centre it owns (and whose context lies in a given group of parts) as
+ * ONE 64-bit word each,
+ *     cell << (row_bits + ctx_bits) | centre row << ctx_bits | hot << (ctx_bits - 1) | context row
+ * (context row counted inside its cell: (x / parts) / slices) in walk / position / slot order,
+ * sorts them stably on the bits above ctx_bits, and trains one part at a time:
  * per cell, implicit records of `record` consecutive sorted pairs visited in the stride order
  * rec(t) = t * A mod R (A ~ R / golden ratio, coprime with R); inside a record every run of equal
  * centre is one "centre" of Semantic S (copy of the central row, samples [context, k negatives]
  * applied one after the other, gradient added at the end of the run).  Negative n of the pair at
  * position p of its cell: a row of the cell, degree-proportional through the cell's alias table
- * (or uniform), picked by draw(cell_key, p * k + n), cell_key = draw(mix64(epoch_key ^ TAG_BLOCK), block_id * 1024 + cell);
+ * (or uniform), picked by draw(cell_key, p * k + n), cell_key = draw(mix64(epoch_key ^ TAG_BLOCK), block_id * O_MAX_CELLS + cell);
  * skipped when it is the context or the centre itself. */
 
 #define O_TAG_BLOCK 0xB10C5EED0B10C5EDULL
+#define O_MAX_CELLS 8192ULL /* parts x slices of a plan, at most */
 
 typedef struct {
     uint32_t world, rank, parts, slices;
@@ -932,25 +936,45 @@ typedef struct {
     uint32_t row_bits;
     uint32_t flags;
     uint32_t hot_lo, hot_hi; /* band of "hot" rows, 0 / 0 = off (see o_block_alias) */
-    uint32_t key_bits;       /* width of the device's sort keys (32 / 64); keys are u64 here */
+    uint32_t key_bits;       /* bits of a pair word in use */
+    uint32_t ctx_bits;       /* low bits: context row inside its cell + the hot flag on top */
 } o_block_plan;
 
-uint32_t o_block_row_bits(uint64_t n_nodes, uint32_t world) {
-    uint64_t rows = (n_nodes + world - 1) / world;
+static inline uint64_t stripe_count(uint64_t n, uint64_t first, uint64_t stride) {
+    return n > first ? (n - first + stride - 1) / stride : 0;
+}
+
+static uint32_t bits_for(uint64_t n) { /* smallest b with 2^b >= n */
     uint32_t b = 0;
-    while ((1ULL << b) < rows) ++b;
+    while ((1ULL << b) < n) ++b;
     return b;
 }
 
-/* pairs of this rank in walk / position / slot order; keys / vals may be NULL (count only) */
+uint32_t o_block_row_bits(uint64_t n_nodes, uint32_t world) {
+    return bits_for((n_nodes + world - 1) / world);
+}
+
+/* rows of the largest cell (part 0, slice 0), plus one bit for the hot flag */
+uint32_t o_block_ctx_bits(uint64_t n_nodes, uint32_t parts, uint32_t slices) {
+    return bits_for(stripe_count(stripe_count(n_nodes, 0, parts), 0, slices)) + 1;
+}
+
+uint32_t o_block_cell_bits(uint32_t parts, uint32_t slices) {
+    return bits_for((uint64_t)parts * slices);
+}
+
+/* pair words of this rank in walk / position / slot order, contexts in the parts part_lo,
+ * part_lo + 1, ... (part_n of them, cyclic; 0, 0 = every part); words may be NULL (count only) */
 uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t *walks,
                          uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                         const uint32_t *hub_bits, uint64_t *keys, uint32_t *vals) {
+                         uint32_t part_lo, uint32_t part_n, const uint32_t *hub_bits,
+                         uint64_t *words) {
     uint64_t n = 0, ekey = o_epoch_key(seed, epoch);
     uint32_t L = p->walk_length, w = p->window, md = p->min_dist ? p->min_dist : 1;
     o_train_params tp;
     memset(&tp, 0, sizeof(tp));
     tp.flags = p->flags & O_FLAG_DOWNSAMPLE;
+    if (part_lo == 0 && part_n == 0) part_n = p->parts;
     for (uint64_t b = 0; b < n_walks; ++b) {
         const uint32_t *wk = walks + b * L;
         uint32_t Le = effective_len(wk, L);
@@ -964,12 +988,14 @@ uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t
                 if (j < 0 || j >= (int64_t)Le) continue;
                 if (!is_context(i, (uint32_t)j, md)) continue;
                 uint32_t x = wk[j];
-                uint32_t row = x / p->parts;
-                uint32_t cell = (x % p->parts) * p->slices + row % p->slices;
-                if (keys) {
-                    keys[n] = ((uint64_t)cell << p->row_bits) | (c / p->world);
-                    /* hot context rows carry bit 31 (updated with atomics on the device) */
-                    vals[n] = row | ((hub_bits && ((hub_bits[x >> 5] >> (x & 31)) & 1u)) ? 0x80000000u : 0u);
+                uint32_t row = x / p->parts, part = x % p->parts;
+                if ((part + p->parts - part_lo) % p->parts >= part_n) continue;
+                uint32_t cell = part * p->slices + row % p->slices;
+                if (words) {
+                    /* hot context rows carry the flag (updated with atomics on the device) */
+                    uint64_t hot = (hub_bits && ((hub_bits[x >> 5] >> (x & 31)) & 1u)) ? 1u : 0u;
+                    words[n] = (((((uint64_t)cell << p->row_bits) | (c / p->world))) << p->ctx_bits) |
+                               (hot << (p->ctx_bits - 1)) | (row / p->slices);
                 }
                 ++n;
             }
@@ -979,45 +1005,40 @@ uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t
 }
 
 typedef struct {
-    uint64_t key;
-    uint32_t val;
+    uint64_t word;
     uint64_t idx;
 } block_kv;
 
+static uint32_t g_sort_shift; /* qsort has no context argument */
+
 static int cmp_block_kv(const void *a, const void *b) {
     const block_kv *x = (const block_kv *)a, *y = (const block_kv *)b;
-    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    uint64_t kx = x->word >> g_sort_shift, ky = y->word >> g_sort_shift;
+    if (kx != ky) return kx < ky ? -1 : 1;
     return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
 }
 
-/* stable sort by key */
-void o_block_sort(uint64_t *keys, uint32_t *vals, uint64_t n) {
+/* stable sort on the bits above ctx_bits (cell, centre row) */
+void o_block_sort(uint64_t *words, uint64_t n, uint32_t ctx_bits) {
     block_kv *kv = (block_kv *)malloc(sizeof(block_kv) * (n ? n : 1));
     for (uint64_t i = 0; i < n; ++i) {
-        kv[i].key = keys[i];
-        kv[i].val = vals[i];
+        kv[i].word = words[i];
         kv[i].idx = i;
     }
+    g_sort_shift = ctx_bits;
     qsort(kv, n, sizeof(block_kv), cmp_block_kv);
-    for (uint64_t i = 0; i < n; ++i) {
-        keys[i] = kv[i].key;
-        vals[i] = kv[i].val;
-    }
+    for (uint64_t i = 0; i < n; ++i) words[i] = kv[i].word;
     free(kv);
 }
 
 /* cell_offsets[c] = first sorted position whose cell is >= c, c = 0 .. cells */
-void o_block_cell_offsets(const uint64_t *keys, uint64_t n, uint32_t row_bits, uint32_t cells,
+void o_block_cell_offsets(const uint64_t *words, uint64_t n, uint32_t cell_shift, uint32_t cells,
                           uint64_t *offsets) {
     uint64_t p = 0;
     for (uint32_t c = 0; c <= cells; ++c) {
-        while (p < n && (keys[p] >> row_bits) < c) ++p;
+        while (p < n && (words[p] >> cell_shift) < c) ++p;
         offsets[c] = c == cells ? n : p;
     }
-}
-
-static inline uint64_t stripe_count(uint64_t n, uint64_t first, uint64_t stride) {
-    return n > first ? (n - first + stride - 1) / stride : 0;
 }
 
 /* floor(w * 2^32 / D) for w < D < 2^48 */
@@ -1059,9 +1080,11 @@ void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t h
         for (uint64_t i = 0; i < n; ++i) D += indeg[(slice + (uint64_t)slices * i) * parts + part];
         uint64_t n_small = 0, n_large = 0; /* small stack from st[0], large from st[n - 1] */
 #define O_NODE_OF(i) ((slice + (uint64_t)slices * (i)) * parts + part)
-#define O_HOT(i)                                                                  \
-    ((uint64_t)(hot_lo != 0 && D != 0 && ((uint64_t)indeg[O_NODE_OF(i)] << hot_lo) >= D && \
-                (hot_hi == 0 || ((uint64_t)indeg[O_NODE_OF(i)] << hot_hi) < D)))
+/* share of the cell's endpoints in [2^-hot_lo, 2^-hot_hi): d * 2^s >= D <=> d >= ceil(D / 2^s) */
+#define O_HOT(i)                                                                            \
+    ((uint64_t)(hot_lo != 0 && D != 0 &&                                                    \
+                indeg[O_NODE_OF(i)] >= ((D + (1ULL << hot_lo) - 1) >> hot_lo) &&            \
+                (hot_hi == 0 || indeg[O_NODE_OF(i)] < ((D + (1ULL << hot_hi) - 1) >> hot_hi))))
         for (uint64_t i = 0; i < n; ++i) {
             uint64_t p = (uint64_t)indeg[O_NODE_OF(i)] * n;
             w[i] = p;
@@ -1117,7 +1140,7 @@ uint64_t o_block_record_stride(uint64_t R) {
 
 /* one part of one round, strictly sequential; returns the pairs trained */
 uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_plan *p,
-                      const uint64_t *keys, const uint32_t *vals, const uint64_t *cell_offsets,
+                      const uint64_t *words, const uint64_t *cell_offsets,
                       const uint64_t *alias, const uint64_t *cell_rows, float *central,
                       float *context, uint64_t block_id, uint32_t part, uint64_t seed,
                       uint64_t epoch, float lr) {
@@ -1131,7 +1154,7 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
         uint64_t lo = cell_offsets[cell], hi = cell_offsets[cell + 1];
         if (hi == lo) continue;
         uint64_t R = (hi - lo + C - 1) / C, A = o_block_record_stride(R);
-        uint64_t ckey = o_draw(o_mix64(ekey ^ O_TAG_BLOCK), block_id * 1024 + cell);
+        uint64_t ckey = o_draw(o_mix64(ekey ^ O_TAG_BLOCK), block_id * O_MAX_CELLS + cell);
         int use_alias = (tp->flags & O_FLAG_SCALE_FREE) && alias;
         uint64_t alias_lo = use_alias ? cell_rows[cell] : 0;
         uint64_t cell_n = stripe_count(part_rows, slice, p->slices);
@@ -1141,15 +1164,17 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
             uint32_t n = (uint32_t)(hi - p0 < C ? hi - p0 : C);
             uint32_t r0 = 0;
             while (r0 < n) {
-                uint32_t crow = (uint32_t)(keys[p0 + r0] & rowmask), r1 = r0 + 1;
-                while (r1 < n && (uint32_t)(keys[p0 + r1] & rowmask) == crow) ++r1;
+                uint32_t crow = (uint32_t)((words[p0 + r0] >> p->ctx_bits) & rowmask), r1 = r0 + 1;
+                while (r1 < n && (uint32_t)((words[p0 + r1] >> p->ctx_bits) & rowmask) == crow) ++r1;
                 uint64_t cgid = (uint64_t)crow * p->world + p->rank;
                 float lrc = centre_lr(g, tp, lr, (uint32_t)cgid);
                 float *cptr = central + (uint64_t)crow * ld;
                 memcpy(u, cptr, d * sizeof(float));
                 memset(gacc, 0, d * sizeof(float));
                 for (uint32_t pr = r0; pr < r1; ++pr) {
-                    uint32_t xrow = vals[p0 + pr] & 0x7FFFFFFFu; /* bit 31: hot-row flag */
+                    /* row inside the part; the flag bit above the cell-local row is ignored */
+                    uint32_t xrow = slice + p->slices * (uint32_t)(words[p0 + pr] &
+                                                                   ((1ULL << (p->ctx_bits - 1)) - 1));
                     for (uint32_t s = 0; s <= k; ++s) {
                         uint32_t row = xrow;
                         float label = 1.0f;

@@ -322,42 +322,74 @@ class BlockPlan(C.Structure):
 
     _fields_ = [(name, C.c_uint32) for name in (
         "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
-        "row_bits", "flags", "hot_lo", "hot_hi", "key_bits")]
+        "row_bits", "flags", "hot_lo", "hot_hi", "key_bits", "ctx_bits")]
 
 
 def block_plan(n_nodes: int, world: int, rank: int, parts: int, slices: int, walk_length: int,
                window: int, min_dist: int = 1, record: int = 16, flags: int = 0, hot_lo: int = 0,
                hot_hi: int = 0) -> BlockPlan:
-    lib().o_block_row_bits.restype = C.c_uint32
-    bits = lib().o_block_row_bits(C.c_uint64(n_nodes), C.c_uint32(world))
-    cells = parts * slices
-    key_bits = 64 if bits + max(0, (cells - 1).bit_length()) > 32 else 32
-    return BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, bits,
-                     flags, hot_lo, hot_hi, key_bits)
+    L = lib()
+    for fn in (L.o_block_row_bits, L.o_block_ctx_bits, L.o_block_cell_bits):
+        fn.restype = C.c_uint32
+    row_bits = L.o_block_row_bits(C.c_uint64(n_nodes), C.c_uint32(world))
+    ctx_bits = L.o_block_ctx_bits(C.c_uint64(n_nodes), C.c_uint32(parts), C.c_uint32(slices))
+    cell_bits = L.o_block_cell_bits(C.c_uint32(parts), C.c_uint32(slices))
+    return BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, row_bits,
+                     flags, hot_lo, hot_hi, cell_bits + row_bits + ctx_bits, ctx_bits)
 
 
 def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: int,
-                  first_walk: int, sort: bool = True, hub_bits=None):
-    """(keys u64, vals u32, cell_offsets): the pairs of the walks whose centre `plan.rank` owns,
-    sorted stably by key = cell << row_bits | centre row (``sort=False``: extraction order)."""
+                  first_walk: int, sort: bool = True, hub_bits=None, part_lo: int = 0,
+                  part_n: int = 0):
+    """(words u64, cell_offsets): the pairs of the walks whose centre `plan.rank` owns (contexts
+    in the parts part_lo, part_lo + 1, ... cyclic; 0, 0 = all) as pair words
+    ``cell << (row_bits + ctx_bits) | centre row << ctx_bits | hot << (ctx_bits - 1) | context
+    row inside its cell``, sorted stably on the bits above ctx_bits (``sort=False``: extraction
+    order)."""
     walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
     n_walks = walks_arr.shape[0]
     L = lib()
     L.o_block_extract.restype = C.c_uint64
     args = (C.byref(g.c), C.byref(plan), _ptr(walks_arr), C.c_uint64(n_walks), C.c_uint64(seed),
-            C.c_uint64(epoch), C.c_uint64(first_walk))
-    n = int(L.o_block_extract(*args, None, None, None))
-    keys, vals = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint32)
+            C.c_uint64(epoch), C.c_uint64(first_walk), C.c_uint32(part_lo), C.c_uint32(part_n))
+    n = int(L.o_block_extract(*args, None, None))
+    words = np.empty(n, dtype=np.uint64)
     if n:
-        L.o_block_extract(*args, _ptr(hub_bits), _ptr(keys), _ptr(vals))
+        L.o_block_extract(*args, _ptr(hub_bits), _ptr(words))
         if sort:
-            L.o_block_sort(_ptr(keys), _ptr(vals), C.c_uint64(n))
+            L.o_block_sort(_ptr(words), C.c_uint64(n), C.c_uint32(plan.ctx_bits))
     cells = plan.parts * plan.slices
     offsets = np.zeros(cells + 1, dtype=np.uint64)
     if sort:
-        L.o_block_cell_offsets(_ptr(keys), C.c_uint64(n), C.c_uint32(plan.row_bits),
-                               C.c_uint32(cells), _ptr(offsets))
-    return keys, vals, offsets
+        L.o_block_cell_offsets(_ptr(words), C.c_uint64(n),
+                               C.c_uint32(plan.row_bits + plan.ctx_bits), C.c_uint32(cells),
+                               _ptr(offsets))
+    return words, offsets
+
+
+def block_unpack(words, plan: BlockPlan):
+    """Pair words -> (cell, centre row, context row inside its PART, hot flag) arrays."""
+    words = np.asarray(words, dtype=np.uint64)
+    low = words & np.uint64((1 << plan.ctx_bits) - 1)
+    hot = (low >> np.uint64(plan.ctx_bits - 1)).astype(np.uint32)
+    local = (low & np.uint64((1 << (plan.ctx_bits - 1)) - 1)).astype(np.uint32)
+    key = words >> np.uint64(plan.ctx_bits)
+    cell = (key >> np.uint64(plan.row_bits)).astype(np.uint32)
+    crow = (key & np.uint64((1 << plan.row_bits) - 1)).astype(np.uint32)
+    row = (cell % np.uint32(plan.slices)) + np.uint32(plan.slices) * local
+    return cell, crow, row, hot
+
+
+def block_pack(cell, centre_row, part_row, plan: BlockPlan, hot=None):
+    """The inverse: pair words from cells, centre rows and context rows inside their part (the
+    row's slice must be the cell's: part_row % slices == cell % slices)."""
+    cell = np.asarray(cell, dtype=np.uint64)
+    part_row = np.asarray(part_row, dtype=np.uint64)
+    assert ((part_row % np.uint64(plan.slices)) == (cell % np.uint64(plan.slices))).all()
+    local = part_row // np.uint64(plan.slices)
+    hot = np.zeros(len(part_row), dtype=np.uint64) if hot is None else np.asarray(hot, np.uint64)
+    key = (cell << np.uint64(plan.row_bits)) | np.asarray(centre_row, dtype=np.uint64)
+    return (key << np.uint64(plan.ctx_bits)) | (hot << np.uint64(plan.ctx_bits - 1)) | local
 
 
 def block_alias(g: OracleGraph, parts: int, slices: int, hot_lo: int = 0, hot_hi: int = 0):
@@ -371,16 +403,16 @@ def block_alias(g: OracleGraph, parts: int, slices: int, hot_lo: int = 0, hot_hi
     return table, cell_rows, hub_bits
 
 
-def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, keys, vals, cell_offsets, alias,
+def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, words, cell_offsets, alias,
                cell_rows, central, context, block_id: int, part: int, seed: int, epoch: int,
                lr: float) -> int:
     """Sequential training of one part (in place on ``central`` / ``context``)."""
-    for a, t in ((keys, np.uint64), (vals, np.uint32), (cell_offsets, np.uint64),
-                 (central, np.float32), (context, np.float32)):
+    for a, t in ((words, np.uint64), (cell_offsets, np.uint64), (central, np.float32),
+                 (context, np.float32)):
         assert a.dtype == t and a.flags.c_contiguous
     lib().o_block_step.restype = C.c_uint64
     return int(lib().o_block_step(
-        C.byref(g.c), C.byref(tp), C.byref(plan), _ptr(keys), _ptr(vals), _ptr(cell_offsets),
+        C.byref(g.c), C.byref(tp), C.byref(plan), _ptr(words), _ptr(cell_offsets),
         _ptr(alias), _ptr(cell_rows), _ptr(central), _ptr(context), C.c_uint64(block_id),
         C.c_uint32(part), C.c_uint64(seed), C.c_uint64(epoch), C.c_float(lr)))
 

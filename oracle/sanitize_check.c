@@ -93,27 +93,32 @@ int main(void) {
 
     /* block-partitioned schedule: extraction, stable sort, alias tables, one round over every part */
     {
-        o_block_plan bp = {3, 1, 6, 2, 20, 3, 1, 4, o_block_row_bits(N, 3), 0, 6, 2, 32};
+        o_block_plan bp = {3, 1, 6, 2, 20, 3, 1, 4, o_block_row_bits(N, 3), 0, 6, 2, 0,
+                           o_block_ctx_bits(N, 6, 2)};
+        bp.key_bits = o_block_cell_bits(6, 2) + bp.row_bits + bp.ctx_bits;
         uint64_t nw = ns * 3, cap = nw * 20 * 6;
         uint64_t *bk = malloc(sizeof(uint64_t) * cap);
-        uint32_t *bv = malloc(sizeof(uint32_t) * cap);
         uint32_t hub[(N + 31) / 32];
         uint64_t *alias = malloc(sizeof(uint64_t) * N), poff[13];
         o_block_alias(&g, 6, 2, bp.hot_lo, bp.hot_hi, alias, poff, hub);
-        uint64_t nb = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, hub, bk, bv);
-        o_block_sort(bk, bv, nb);
+        /* two groups of parts (the second wraps round), then the whole round */
+        uint64_t n_a = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 4, 3, hub, bk);
+        uint64_t n_b = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 1, 3, hub, bk);
+        uint64_t nb = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 0, 0, hub, bk);
+        if (n_a + n_b != nb) return 1;
+        o_block_sort(bk, nb, bp.ctx_bits);
         uint64_t off[13];
-        o_block_cell_offsets(bk, nb, bp.row_bits, 12, off);
+        o_block_cell_offsets(bk, nb, bp.row_bits + bp.ctx_bits, 12, off);
         uint64_t crows = (N + 3 - 1 - 1) / 3 + 1, xrows = N / 6 + 1, trained = 0;
         float *bc = malloc(sizeof(float) * crows * 12), *bx = malloc(sizeof(float) * xrows * 12);
         o_init_table_rows(bc, (N - 1 + 2) / 3, 10, 12, 5, 0, 0.3f, 1, 3);
         for (uint32_t part = 0; part < 6; ++part) {
             o_init_table_rows(bx, (N - part + 5) / 6, 10, 12, 5, 1, 0.3f, part, 6);
-            trained += o_block_step(&g, &tp, &bp, bk, bv, off, alias, poff, bc, bx, 2, part, 7, 1,
+            trained += o_block_step(&g, &tp, &bp, bk, off, alias, poff, bc, bx, 2, part, 7, 1,
                                     0.02f);
         }
         if (trained != nb) return 1;
-        free(bk); free(bv); free(alias); free(bc); free(bx);
+        free(bk); free(alias); free(bc); free(bx);
     }
 
     uint32_t *bs = malloc(sizeof(uint32_t) * 999 * 4), *bd = malloc(sizeof(uint32_t) * 999 * 4);

@@ -7,13 +7,15 @@
 #include "gn2v.h"
 
 int main(void) {
-    if (gn2v_version() < 100) return 1;
-    uint32_t parts = 0, slices = 0;
+    if (gn2v_version() < 200) return 1;
+    uint32_t parts = 0, slices = 0, group = 0;
     if (gn2v_block_auto_plan(10000000, 8, &parts, &slices) || parts != 32 || slices != 8) return 2;
     uint64_t walks = 0;
-    if (gn2v_block_round_walks(277000000000ull, 128, 5, 32, 1, 0, &walks) || walks != (1u << 23))
+    if (gn2v_block_round_plan(270000000000ull, 10000000, 128, 5, 1, 38, 8, 0, &walks, &group) ||
+        walks != (1u << 23) || group != 10)
         return 3;
-    if (gn2v_block_round_walks(1, 128, 5, 48, 1, 0, &walks) == 0) return 4; /* bad key width */
+    if (gn2v_block_round_plan(1, 10000000, 1, 5, 1, 38, 8, 0, &walks, &group) == 0)
+        return 4; /* a walk of one node */
     if (strlen(gn2v_last_error()) == 0) return 5;
     gn2v_graph *g = NULL;
     if (gn2v_graph_create(NULL, NULL, NULL, NULL, 2, 2, 2, 0, 0, &g) == 0) return 6;

@@ -30,8 +30,8 @@ if __name__ == "__main__":
     # block-partitioned schedule (round 2): rank 1 of 2, 4 parts x 2 slices, a hot band
     blk = {}
     plan = O.block_plan(34, 2, 1, 4, 2, 16, 3, 1, 4, hot_lo=4, hot_hi=1)
-    keys, vals, offsets = O.block_extract(og, plan, out["walks"], 42, 0, 0,
-                                          hub_bits=O.block_alias(og, 4, 2, 4, 1)[2])
+    words, offsets = O.block_extract(og, plan, out["walks"], 42, 0, 0,
+                                     hub_bits=O.block_alias(og, 4, 2, 4, 1)[2])
     alias, cell_rows, hub_bits = O.block_alias(og, 4, 2, 4, 1)
     tp = O.TrainParams(0, 8, 8, 1, 4, 3, 0.01, 0.9, 6.0, 1, 8 ** -0.5)
     central = O.init_table_rows(17, 8, 8, 42, 0, 8 ** -0.5, 1, 2)
@@ -39,10 +39,10 @@ if __name__ == "__main__":
     for part in range(4):
         rows = (34 - part + 3) // 4
         x = O.init_table_rows(rows, 8, 8, 42, 1, 8 ** -0.5, part, 4)
-        O.block_step(og, tp, plan, keys, vals, offsets, alias, cell_rows, central, x, 7, part, 42,
+        O.block_step(og, tp, plan, words, offsets, alias, cell_rows, central, x, 7, part, 42,
                      0, 0.05)
         parts.append(x)
-    blk.update(keys=keys, vals=vals, offsets=offsets, alias=alias, cell_rows=cell_rows,
+    blk.update(words=words, offsets=offsets, alias=alias, cell_rows=cell_rows,
                hub_bits=hub_bits, central=central, **{f"part{p}": x for p, x in enumerate(parts)})
     np.savez_compressed(os.path.join(HERE, "oracle_blocks.npz"), **blk)
     print("written", {k: np.shape(v) for k, v in blk.items()})

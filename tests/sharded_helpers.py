@@ -47,6 +47,33 @@ class ThreadComm:
 
         return Handle()
 
+    def broadcast(self, tensor, src):
+        s = self.shared
+        if tensor.is_cuda:
+            torch.cuda.current_stream(tensor.device).synchronize()
+        if self.rank == src:
+            s.mail[("bcast", src)] = tensor.clone()
+        s.barrier.wait()
+        tensor.copy_(s.mail[("bcast", src)])
+        s.barrier.wait()
+        return tensor
+
+    def send_to_root(self, tensor, root, buffer=None, src=None):
+        s = self.shared
+        if src == root:
+            return tensor if self.rank == root else None
+        if self.rank == src:
+            if tensor.is_cuda:
+                torch.cuda.current_stream(tensor.device).synchronize()
+            s.mail[("root", src)] = tensor.clone()
+        s.barrier.wait()
+        out = None
+        if self.rank == root:
+            buffer.copy_(s.mail[("root", src)])
+            out = buffer
+        s.barrier.wait()
+        return out
+
 
 def run_ranks(world, fn):
     """Run fn(comm) for every rank in its own thread; returns the list of results."""
@@ -97,22 +124,23 @@ class OracleBlockBackend:
     def alias_tables(self, plan):
         return O.block_alias(self.og, plan.parts, plan.slices, plan.hot_lo, plan.hot_hi)
 
-    def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None):
+    def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None, part_lo=0,
+                part_n=0):
         walks = walks_all.cpu().numpy().view(np.uint32)
-        keys, vals, offsets = O.block_extract(self.og, plan, walks, seed, epoch, first_walk,
-                                              hub_bits=hub_bits)
-        return keys, vals, offsets, len(keys)
+        words, offsets = O.block_extract(self.og, plan, walks, seed, epoch, first_walk,
+                                         hub_bits=hub_bits, part_lo=part_lo, part_n=part_n)
+        return words, offsets, len(words)
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
              epoch, lr, whole_central=False):
-        keys, vals, offsets, n_pairs = prepared
+        words, offsets, n_pairs = prepared[:3]
         if n_pairs == 0:
             return
         # a centre stripe of the whole table is handed to the oracle as the partition it is
         mine = central[plan.rank::plan.world] if whole_central else central
         c = np.ascontiguousarray(mine.numpy())
         x = np.ascontiguousarray(context.numpy())
-        O.block_step(self.og, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, block_id,
+        O.block_step(self.og, tp, plan, words, offsets, alias, cell_rows, c, x, block_id,
                      part, seed, epoch, lr)
         mine.copy_(torch.from_numpy(c))
         context.copy_(torch.from_numpy(x))

@@ -36,12 +36,13 @@ def _otp(flags=1):
 
 
 def _train(comm, rounds=2, walks_per_round=9, nodes=34, slices=1, parts=None, record=4,
-           stripes=1):
+           stripes=1, group_parts=None, root=None):
     g = _graph(nodes)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     tr = BlockPartitionedTrainer(g, _otp(), D, D, 42, D ** -0.5, comm, "cpu", walk_length=L,
                                  window=W, backend=OracleBlockBackend(g), slices=slices,
-                                 parts=parts, record=record, stripes=stripes)
+                                 parts=parts, record=record, stripes=stripes,
+                                 group_parts=group_parts)
     wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
     trained = 0
     for r in range(rounds):
@@ -49,7 +50,8 @@ def _train(comm, rounds=2, walks_per_round=9, nodes=34, slices=1, parts=None, re
         mine = O.walks(og, wp, 42, 0, first + comm.rank * walks_per_round, walks_per_round)
         tr.train_round(torch.from_numpy(mine.view(np.int32)), 42, 0, 0.02, first)
         trained += tr.last_round["pairs_trained"]
-    return [t.numpy().copy() for t in tr.gather_full()], trained, sorted(tr.held)
+    tables = [None if t is None else t.numpy().copy() for t in tr.gather_full(root=root)]
+    return tables, trained, sorted(tr.held)
 
 
 # ------------------------------------------------------------------ the restated schedule itself
@@ -63,19 +65,26 @@ def test_extraction_partitions_the_pairs_of_the_walks(world, parts, slices):
     got = []
     for rank in range(world):
         plan = O.block_plan(97, world, rank, parts, slices, L, W, 1, 4)
-        keys, vals, offsets = O.block_extract(og, plan, walks, 3, 0, 0)
-        raw_k, raw_v, _ = O.block_extract(og, plan, walks, 3, 0, 0, sort=False)
+        words, offsets = O.block_extract(og, plan, walks, 3, 0, 0)
+        raw, _ = O.block_extract(og, plan, walks, 3, 0, 0, sort=False)
+        keys = words >> np.uint64(plan.ctx_bits)
         assert (np.diff(keys.astype(np.int64)) >= 0).all()
-        # stable: pairs with equal keys keep the extraction (walk / position / slot) order
-        order = np.argsort(raw_k, kind="stable")
-        assert np.array_equal(keys, raw_k[order]) and np.array_equal(vals, raw_v[order])
-        cell = (keys >> np.uint64(plan.row_bits)).astype(np.uint32)
-        crow = (keys & np.uint64((1 << plan.row_bits) - 1)).astype(np.uint32)
-        assert offsets[-1] == len(keys)
+        # stable: pairs with equal (cell, centre) keep the extraction (walk / position / slot) order
+        order = np.argsort(raw >> np.uint64(plan.ctx_bits), kind="stable")
+        assert np.array_equal(words, raw[order])
+        assert plan.key_bits <= 64 and not (words >> np.uint64(plan.key_bits)).any()
+        cell, crow, vals, hot = O.block_unpack(words, plan)
+        assert not hot.any() and np.array_equal(O.block_pack(cell, crow, vals, plan), words)
+        assert offsets[-1] == len(words)
         for c in range(parts * slices):
             assert (cell[int(offsets[c]):int(offsets[c + 1])] == c).all()
         part, slc = cell // slices, cell % slices
         assert (vals % slices == slc).all()
+        # a group of parts (cyclic) holds exactly the pairs of those parts, in the same order
+        lo, n_grp = parts - 1, min(2, parts)
+        grp, grp_off = O.block_extract(og, plan, walks, 3, 0, 0, part_lo=lo, part_n=n_grp)
+        in_grp = ((part + parts - lo) % parts) < n_grp
+        assert np.array_equal(grp, words[in_grp]) and grp_off[-1] == in_grp.sum()
         centre = crow.astype(np.int64) * world + rank
         context = vals.astype(np.int64) * parts + part
         got.append(np.stack([centre, context], 1))
@@ -152,7 +161,7 @@ def test_step_properties_zero_lr_counts_and_untouched_rows():
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     walks = O.walks(og, O.WalkParams(L, 1, 1.0, 1.0, 100, 0), 5, 0, 0, 30)
     plan = O.block_plan(97, 1, 0, 2, 1, L, W, 1, 4)
-    keys, vals, offsets = O.block_extract(og, plan, walks, 5, 0, 0)
+    words, offsets = O.block_extract(og, plan, walks, 5, 0, 0)
     alias, cell_rows, _ = O.block_alias(og, 2, 1)
     c = O.init_table_rows(97, D, D, 5, 0, 0.3, 0, 1)
     assert np.array_equal(c, O.init_table(97, D, D, 5, 0, 0.3))
@@ -160,13 +169,14 @@ def test_step_properties_zero_lr_counts_and_untouched_rows():
     full = O.init_table(97, D, D, 5, 1, 0.3)
     assert np.array_equal(parts[0], full[0::2]) and np.array_equal(parts[1], full[1::2])
     c0, x0 = c.copy(), [p.copy() for p in parts]
-    n0 = O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows, c, parts[0], 0, 0,
+    n0 = O.block_step(og, _otp(), plan, words, offsets, alias, cell_rows, c, parts[0], 0, 0,
                       5, 0, 0.0)
     assert np.array_equal(c, c0) and np.array_equal(parts[0], x0[0])  # lr = 0: identity
-    n1 = sum(O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows, c, parts[p],
+    n1 = sum(O.block_step(og, _otp(), plan, words, offsets, alias, cell_rows, c, parts[p],
                           0, p, 5, 0, 0.05) for p in range(2))
-    assert n0 == offsets[1] and n1 == len(keys) == len(O.walk_pairs(walks, W))
-    centres = np.unique(keys & np.uint64((1 << plan.row_bits) - 1)).astype(np.int64)
+    assert n0 == offsets[1] and n1 == len(words) == len(O.walk_pairs(walks, W))
+    _, crow, vals, _ = O.block_unpack(words, plan)
+    centres = np.unique(crow).astype(np.int64)
     untouched = np.setdiff1d(np.arange(97), centres)
     assert np.array_equal(c[untouched], c0[untouched]) and not np.array_equal(c, c0)
     indeg = np.bincount(og.col_idx, minlength=97)
@@ -191,9 +201,9 @@ def test_world_one_trainer_is_the_plain_sequence_of_block_steps():
     total = 0
     for r in range(2):
         walks = O.walks(og, wp, 42, 0, r * 9, 9)
-        keys, vals, offsets = O.block_extract(og, plan, walks, 42, 0, r * 9)
+        words, offsets = O.block_extract(og, plan, walks, 42, 0, r * 9)
         for p in range(2):
-            total += O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows, rc,
+            total += O.block_step(og, _otp(), plan, words, offsets, alias, cell_rows, rc,
                                   parts[p], r, p, 42, 0, 0.02)
     rx[0::2], rx[1::2] = parts
     assert np.array_equal(c, rc) and np.array_equal(x, rx)
@@ -221,11 +231,11 @@ def test_centre_stripes_are_the_sequence_of_block_steps_of_that_many_ranks(strip
         walks = O.walks(og, wp, 42, 0, r * 9, 9)
         for j in range(stripes):
             plan = O.block_plan(97, stripes, j, parts, slices, L, W, 1, 4)
-            keys, vals, offsets = O.block_extract(og, plan, walks, 42, 0, r * 9)
+            words, offsets = O.block_extract(og, plan, walks, 42, 0, r * 9)
             mine = np.ascontiguousarray(rc[j::stripes])
             for _ in range(parts):
                 p = episode % parts
-                total += O.block_step(og, _otp(), plan, keys, vals, offsets, alias, cell_rows,
+                total += O.block_step(og, _otp(), plan, words, offsets, alias, cell_rows,
                                       mine, ctx[p], r * stripes + j, p, 42, 0, 0.02)
                 episode += 1
             rc[j::stripes] = mine
@@ -260,6 +270,35 @@ def test_slices_change_the_negative_cells_not_the_bookkeeping():
     sliced = run_ranks(2, lambda comm: _train(comm, rounds=1, nodes=97, slices=2))
     assert plain[0][1] + plain[1][1] == sliced[0][1] + sliced[1][1]
     assert not np.array_equal(plain[0][0][1], sliced[0][0][1])
+
+
+@pytest.mark.parametrize("world,parts,group_parts", [(1, 4, 1), (1, 4, 3), (2, 4, 1), (2, 8, 3),
+                                                     (3, 6, 4)])
+def test_groups_of_parts_change_the_memory_not_the_result(world, parts, group_parts):
+    """A round extracted, sorted and trained a group of parts at a time (each rank's groups
+    start at its own first part and wrap round) is bit-equal to the round prepared at once: a
+    cell's pairs keep their order, the negatives' streams are keyed by the position inside the
+    cell."""
+    whole = run_ranks(world, lambda comm: _train(comm, nodes=97, parts=parts, slices=2))
+    grouped = run_ranks(world, lambda comm: _train(comm, nodes=97, parts=parts, slices=2,
+                                                   group_parts=group_parts))
+    for a, b in zip(whole, grouped):
+        assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1])
+        assert a[1] == b[1] and a[2] == b[2]
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 1)])
+def test_gather_to_one_rank_only(world, root):
+    """gather_full(root=r): rank r assembles the tables every rank would assemble; the others
+    get nothing."""
+    every = run_ranks(world, lambda comm: _train(comm, nodes=97))
+    rooted = run_ranks(world, lambda comm: _train(comm, nodes=97, root=root))
+    for r in range(world):
+        if r == root:
+            assert np.array_equal(rooted[r][0][0], every[r][0][0])
+            assert np.array_equal(rooted[r][0][1], every[r][0][1])
+        else:
+            assert rooted[r][0] == [None, None]
 
 
 def _gloo_worker(rank, world, port, out_dir, parts=None):

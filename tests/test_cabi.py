@@ -27,14 +27,14 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_lib.build())
     for name in declared_symbols():
         assert hasattr(L, name), name
-    assert _lib.lib().gn2v_version() == 100
+    assert _lib.lib().gn2v_version() == 200
 
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.WalkParams) == 32
     assert C.sizeof(_lib.TrainParams) == 48
-    assert C.sizeof(_lib.Stats) == 64
-    assert C.sizeof(_lib.BlockPlan) == 13 * 4 and C.sizeof(_lib.BlockIO) == 80
+    assert C.sizeof(_lib.Stats) == 72
+    assert C.sizeof(_lib.BlockPlan) == 14 * 4 and C.sizeof(_lib.BlockIO) == 80
     text = open(HEADER).read()
     for name, value in (("GN2V_TRAIN_SCALE_FREE", _lib.TRAIN_SCALE_FREE),
                         ("GN2V_TRAIN_DOWNSAMPLE", _lib.TRAIN_DOWNSAMPLE),
@@ -52,49 +52,60 @@ def test_struct_layouts_match_header():
 
 
 def test_automatic_plan_of_the_block_path():
-    """gn2v_block_auto_plan (pure host function: no GPU needed): slices = 8, cells of >= 32 768
-    rows, at least two parts per rank, at most 128 parts."""
+    """gn2v_block_auto_plan (pure host function: no GPU needed): one slice per XCD (8) or none --
+    never 2 or 4, which would have several XCDs share a slice --, cells of >= 32 768 rows, any
+    number of parts (a multiple of the ranks, at least two per rank)."""
     from embiggen_amd.distributed import auto_plan
 
     assert auto_plan(34, 1) == (1, 1) and auto_plan(34, 8) == (16, 1)
-    assert auto_plan(65_536, 1) == (1, 2) and auto_plan(262_144, 1) == (1, 8)
-    assert auto_plan(1_000_000, 1) == (2, 8) and auto_plan(2_449_029, 8) == (16, 4)
-    assert all(auto_plan(10_000_000, w) == (32, 8) for w in (1, 2, 4, 8))
-    assert all(auto_plan(100_000_000, w) == (128, 8) for w in (1, 2, 4, 8))
+    assert auto_plan(40_000, 1) == (1, 1)
+    assert auto_plan(65_536, 1) == (1, 8) and auto_plan(169_343, 1) == (1, 8)
+    assert auto_plan(262_144, 1) == (1, 8) and auto_plan(1_000_000, 1) == (3, 8)
+    assert auto_plan(2_449_029, 1) == (9, 8) and auto_plan(2_449_029, 8) == (16, 8)
+    assert auto_plan(200_000, 8) == (16, 1)
+    assert [auto_plan(10_000_000, w) for w in (1, 2, 4, 8)] == [(38, 8), (38, 8), (36, 8), (32, 8)]
+    assert [auto_plan(100_000_000, w) for w in (1, 8)] == [(381, 8), (376, 8)]
     for n in (10 ** 5, 10 ** 6, 10 ** 7, 10 ** 8, 3 * 10 ** 9):
         for world in (1, 2, 3, 8):
             parts, slices = auto_plan(n, world)
-            assert parts % world == 0 and parts <= 128 and slices in (1, 2, 4, 8)
+            assert parts % world == 0 and parts * slices <= 8192 and slices in (1, 8)
             assert world == 1 or parts >= 2 * world
-            assert parts * slices == (world if world == 1 and n < 65536 else parts * slices)
-            if parts > (1 if world == 1 else 2 * world):
-                assert n // (parts * slices) >= 32768
+            if parts > (1 if world == 1 else 2 * world) and parts * slices < 8192 - 8 * world:
+                assert 32768 <= n // (parts * slices) < 2 * 32768 * (world + 1)
 
 
-def test_round_size_follows_the_free_memory():
-    """gn2v_block_round_walks (pure host function): the largest power of two <= 2^23 whose pair
-    buffers fit three quarters of the free HBM (key + value per pair, x 2 while the sort runs, x 3
-    with a second round in preparation, plus the gathered walks), never under 2^14."""
-    from embiggen_amd.distributed import round_walks_within
+def test_round_size_and_groups_follow_the_free_memory():
+    """gn2v_block_round_plan (pure host function): rounds long enough for 64 pairs per (cell,
+    centre) inside [2^20, 2^23] walks; per group of parts the pair words (8 B) are held once
+    sorted (twice with a group in preparation) and once unsorted, and the walks beside them must
+    fit three quarters of the free HBM; at least four groups per round."""
+    from embiggen_amd.distributed import round_plan
 
     GB = 10 ** 9
-    # the bench graph: 32-bit keys, one GPU in line, eight GPUs with two rounds in flight
-    assert round_walks_within(277 * GB, 128, 5, 32, 1, False) == 1 << 23
-    assert round_walks_within(282 * GB, 128, 5, 32, 8, True) == 1 << 22
-    # 100 M nodes: 64-bit keys
-    assert round_walks_within(176 * GB, 128, 5, 64, 1, False) == 1 << 21
-    assert round_walks_within(266 * GB, 128, 5, 64, 8, True) == 1 << 21
-    assert round_walks_within(40 * GB, 128, 5, 32, 1, False) == 1 << 20
-    assert round_walks_within(0, 128, 5, 32, 1, False) == 1 << 14
+    # the bench graph on one GPU: 38 x 8 cells, rounds at the cap, four groups of <= 10 parts
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 38, 8, False) == (1 << 23, 10)
+    # eight GPUs, a group in preparation while one trains
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 8, 32, 8, True) == (1 << 23, 8)
+    # 100 M nodes on one GPU, 170 GB free beside the tables
+    assert round_plan(170 * GB, 100_000_000, 128, 5, 1, 381, 8, False) == (1 << 23, 96)
+    # a mid-size graph wants no more than it needs; a small one the floor
+    assert round_plan(270 * GB, 1_000_000, 128, 5, 1, 3, 8, False) == (1 << 21, 1)
+    assert round_plan(270 * GB, 169_343, 128, 5, 1, 1, 8, False) == (1 << 20, 1)
+    # short memory: smaller groups first, then shorter rounds
+    walks, group = round_plan(20 * GB, 10_000_000, 128, 5, 1, 38, 8, False)
+    assert walks == 1 << 23 and group < 10
+    walks, group = round_plan(2 * GB, 10_000_000, 128, 5, 1, 38, 8, False)
+    assert walks < 1 << 23 and group == 1
+    assert round_plan(0, 10_000_000, 128, 5, 1, 38, 8, False) == (1 << 14, 1)
     for free in (GB, 10 * GB, 100 * GB, 10 ** 13):
-        for world, overlap in ((1, False), (2, True), (8, True)):
-            for key_bits in (32, 64):
-                n = round_walks_within(free, 128, 5, key_bits, world, overlap)
-                assert n & (n - 1) == 0 and (1 << 14) <= n <= (1 << 23)
-                need = n * 1280 * (key_bits // 8 + 4) * (3 if overlap else 2)
-                assert n == 1 << 14 or need <= 0.75 * free
+        for world, overlap, parts in ((1, False, 38), (2, True, 38), (8, True, 32)):
+            n, gp = round_plan(free, 10_000_000, 128, 5, world, parts, 8, overlap)
+            assert n & (n - 1) == 0 and (1 << 14) <= n <= (1 << 23) and 1 <= gp <= (parts + 3) // 4
+            need = (4 * 128 * n * (world + 1 if world > 1 else 1)
+                    + (3 if overlap else 2) * 8 * (n * 1280 // parts) * gp)
+            assert (n == 1 << 14 and gp == 1) or need <= 0.75 * free
     with pytest.raises(RuntimeError):
-        round_walks_within(GB, 128, 5, 48, 1, False)
+        round_plan(GB, 10_000_000, 1, 5, 1, 38, 8, False)
 
 
 def test_errors_are_reported_not_thrown():

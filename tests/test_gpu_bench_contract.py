@@ -33,6 +33,11 @@ def test_single_gpu_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    # bandwidth first: either the PMC-based figure or the reason it is missing (this tiny
+    # workload has no committed profile); the schedule-aware model never exceeds the algorithmic
+    assert "frac_hbm" in r and (r["traffic"] is not None or "no committed" in r["traffic_missing_reason"])
+    assert 0 < r["scheduled"] <= r["achieved"] and r["mean_centre_run"] >= 1
+    assert "traffic_key" in d["config"]
     pairs = 2 * 16384 * 1250
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - pairs) < 1e-3 * pairs
     c = d["cpu_baseline"]
@@ -84,8 +89,34 @@ def test_two_rank_line_through_torch_distributed_run():
     assert dd["backend"] == "gloo" and dd["world_size"] == 2 and len(dd["per_rank_pairs"]) == 2
     assert sum(dd["per_rank_pairs"]) == 2 * 2 * 8192 * 1250 and min(dd["per_rank_pairs"]) > 0
     assert dd["walk_allgather_ms_alone"] > 0 and dd["half_partition_hop_ms_alone"] > 0
+    # what a reader needs to judge a scaling record: round size, groups, memory and exposed waits
+    assert dd["walks_per_round_per_rank"] == 8192 and dd["parts_per_group"] >= 1
+    assert len(dd["per_rank_hbm_peak_gb"]) == 2 and min(dd["per_rank_hbm_peak_gb"]) > 0
+    waits = dd["exposed_hop_wait_ms"]
+    assert waits["hops_per_rank"] > 0 and len(waits["mean_per_rank"]) == 2
     pairs = 2 * 2 * 8192 * 1250  # steps x ranks x walks x pairs per walk: the whole-job aggregate
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - pairs) < 1e-3 * pairs
+
+
+def test_bench_gpus_two_starts_its_own_job():
+    """`python bench.py --gpus 2 ...` with no torch.distributed environment: the parent (which
+    never touches the GPU) launches the two workers, relays the one JSON line and their status."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--nodes", "200000", "--walks", "8192", "--round-walks", "8192",
+           "--backend", "gloo", "--share-device"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout[-500:]  # nothing but the line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["finite"] is True and d["distributed"]["world_size"] == 2
+    assert sum(d["distributed"]["per_rank_pairs"]) == 2 * 2 * 8192 * 1250
+    # a failing job is reported as failing
+    bad = subprocess.run(cmd + ["--parallelism", "single"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
 def test_cbow_runs_as_independent_replicas_on_two_ranks():

@@ -27,10 +27,13 @@ def _u32(t):
     return t.cpu().numpy().view(np.uint32)
 
 
-def _keys(t):
-    """Device sort keys (int32 or int64 tensor, plan.key_bits) as the oracle's u64."""
-    a = t.cpu().numpy()
-    return a.view(np.uint32).astype(np.uint64) if a.dtype == np.int32 else a.view(np.uint64)
+def _words(t):
+    """Device pair words (int64 tensor) as the oracle's u64."""
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _dev_words(words):
+    return torch.from_numpy(np.ascontiguousarray(words).view(np.int64)).cuda()
 
 
 def test_walk_pairs_match_oracle(karate, karate_oracle):
@@ -64,25 +67,35 @@ def test_extraction_and_sort_are_bit_exact(world, rank, parts, slices, md):
     wk[7] = -1         # a padding walk (rank with no walks left)
     plan = ops.block_plan(g, world, rank, parts, slices, 24, 4, md, 4, hot_lo=5, hot_hi=0)
     oplan = O.block_plan(203, world, rank, parts, slices, 24, 4, md, 4, hot_lo=5, hot_hi=0)
-    assert plan.row_bits == oplan.row_bits
+    assert (plan.row_bits, plan.ctx_bits, plan.key_bits) == (oplan.row_bits, oplan.ctx_bits,
+                                                             oplan.key_bits)
     _, _, hub_bits = ops.block_alias(g, plan)
+    ohub = O.block_alias(og, parts, slices, 5, 0)[2]
     work, offsets = ops.block_count(g, plan, wk, 5, 1, 100)
     n = int(offsets[-1])
-    keys, vals = ops.block_extract(g, plan, wk, 5, 1, 100, work, n, hub_bits=hub_bits)
-    rk, rv, ro = O.block_extract(og, oplan, _u32(wk), 5, 1, 100,
-                                 hub_bits=O.block_alias(og, parts, slices, 5, 0)[2])
-    assert n == len(rk) and n > 0 and (rv >> 31).any()  # hot context rows are flagged
+    pairs = ops.block_extract(g, plan, wk, 5, 1, 100, work, n, hub_bits=hub_bits)
+    rw, ro = O.block_extract(og, oplan, _u32(wk), 5, 1, 100, hub_bits=ohub)
+    assert n == len(rw) and n > 0 and O.block_unpack(rw, oplan)[3].any()  # hot rows are flagged
     assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
-    assert np.array_equal(_keys(keys), rk) and np.array_equal(_u32(vals), rv)
+    assert np.array_equal(_words(pairs), rw)
+    # a group of parts (cyclic: the last part and the first): the same words, the others left out
+    lo, cnt = parts - 1, min(2, parts)
+    work, goff = ops.block_count(g, plan, wk, 5, 1, 100, part_lo=lo, part_n=cnt)
+    grp = ops.block_extract(g, plan, wk, 5, 1, 100, work, int(goff[-1]), hub_bits=hub_bits,
+                            part_lo=lo, part_n=cnt)
+    gw, go = O.block_extract(og, oplan, _u32(wk), 5, 1, 100, hub_bits=ohub, part_lo=lo, part_n=cnt)
+    assert np.array_equal(_words(grp), gw) and np.array_equal(goff.cpu().numpy().astype(np.uint64), go)
+    assert 0 < len(gw) <= n
     # empty input: no pairs, all offsets zero
     empty = torch.full((4, 24), -1, dtype=torch.int32, device="cuda")
     _, off0 = ops.block_count(g, plan, empty, 5, 1, 0)
     assert int(off0.abs().sum()) == 0
 
 
-def test_wide_sort_keys_when_cell_and_row_do_not_fit_32_bits():
-    """2^23 nodes on one rank (23 row bits) x 1 024 cells (10 bits): the sort keys become u64;
-    extraction + sort stay bit-exact and a deterministic step still equals the oracle."""
+def test_pair_words_of_a_graph_whose_cell_and_row_do_not_fit_32_bits():
+    """2^23 nodes on one rank (23 row bits) x 1 024 cells (10 bits) + 11 context bits: the pair
+    word uses 47 of its 64 bits; extraction + sort stay bit-exact and a deterministic step still
+    equals the oracle.  (8 192 cells, the most a plan may have: checked for the bit budget.)"""
     n = 1 << 23
     rng = np.random.RandomState(4)
     src = rng.randint(0, n, 6000)
@@ -90,25 +103,27 @@ def test_wide_sort_keys_when_cell_and_row_do_not_fit_32_bits():
     g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=n)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     wk = ops.walks(g, ops.walk_params(12, 1, 1.0, 1.0), 3, 0, 0, min(2000, g.get_number_of_unique_source_nodes()))
-    plan = ops.block_plan(g, 1, 0, 128, 8, 12, 3, 1, 4)
-    oplan = O.block_plan(n, 1, 0, 128, 8, 12, 3, 1, 4)
-    assert plan.key_bits == 64 == oplan.key_bits and plan.row_bits == 23
-    work, offsets = ops.block_count(g, plan, wk, 3, 0, 0)
-    keys, vals = ops.block_extract(g, plan, wk, 3, 0, 0, work, int(offsets[-1]))
-    assert keys.dtype == torch.int64
-    rk, rv, ro = O.block_extract(og, oplan, _u32(wk), 3, 0, 0)
-    assert len(rk) > 1000 and int(rk.max() >> np.uint64(32)) > 0
-    assert np.array_equal(_keys(keys), rk) and np.array_equal(_u32(vals), rv)
-    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
-    part = int(rk[len(rk) // 2] >> np.uint64(23)) // 8  # a part that has pairs
-    rows = stripe_rows(n, part, 128)
+    for parts in (128, 1024):
+        plan = ops.block_plan(g, 1, 0, parts, 8, 12, 3, 1, 4)
+        oplan = O.block_plan(n, 1, 0, parts, 8, 12, 3, 1, 4)
+        assert plan.row_bits == 23 and plan.key_bits == oplan.key_bits == 47
+        assert plan.ctx_bits == oplan.ctx_bits == (14 if parts == 128 else 11)
+        work, offsets = ops.block_count(g, plan, wk, 3, 0, 0)
+        pairs = ops.block_extract(g, plan, wk, 3, 0, 0, work, int(offsets[-1]))
+        rw, ro = O.block_extract(og, oplan, _u32(wk), 3, 0, 0)
+        assert len(rw) > 1000 and int(rw.max() >> np.uint64(32)) > 0
+        assert np.array_equal(_words(pairs), rw)
+        assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
+    cell = O.block_unpack(rw, oplan)[0]
+    part = int(cell[len(rw) // 2]) // 8  # a part that has pairs
+    rows = stripe_rows(n, part, parts)
     tp = ops.train_params(0, 8, 0, 3, flags=DET)  # k = 0: no alias tables needed
     otp = O.TrainParams(0, 8, 8, 1, 0, 3, 0.01, 0.9, 6.0, 0, 8 ** -0.5)
     c = ops.init_table(n, 8, 5, 0, 0.3)
-    x = ops.init_table_rows(rows, 8, 5, 1, 0.3, part, 128)
+    x = ops.init_table_rows(rows, 8, 5, 1, 0.3, part, parts)
     c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
-    ops.block_step(g, tp, plan, keys, vals, offsets, None, None, c, x, 0, part, 3, 0, 0.05)
-    trained = O.block_step(og, otp, oplan, rk, rv, ro, None, None, c_h, x_h, 0, part, 3, 0, 0.05)
+    ops.block_step(g, tp, plan, pairs, offsets, None, None, c, x, 0, part, 3, 0, 0.05)
+    trained = O.block_step(og, otp, oplan, rw, ro, None, None, c_h, x_h, 0, part, 3, 0, 0.05)
     torch.cuda.synchronize()
     assert trained > 0 and np.abs(x.cpu().numpy() - x_h).max() < 1e-5
     assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(c_h - ops.init_table(n, 8, 5, 0, 0.3).cpu().numpy()).max() > 1e-4
@@ -120,11 +135,11 @@ def test_extraction_honours_centre_downsampling(karate, karate_oracle):
     oplan = O.block_plan(34, 2, 0, 4, 1, 16, 3, 1, 4, flags=O.FLAG_DOWNSAMPLE)
     work, offsets = ops.block_count(karate, plan, wk, 3, 0, 40)
     n = int(offsets[-1])
-    keys, vals = ops.block_extract(karate, plan, wk, 3, 0, 40, work, n)
-    rk, rv, ro = O.block_extract(karate_oracle, oplan, _u32(wk), 3, 0, 40)
+    pairs = ops.block_extract(karate, plan, wk, 3, 0, 40, work, n)
+    rw, ro = O.block_extract(karate_oracle, oplan, _u32(wk), 3, 0, 40)
     full = O.block_extract(karate_oracle, O.block_plan(34, 2, 0, 4, 1, 16, 3, 1, 4), _u32(wk), 3, 0, 40)
     assert 0 < n < len(full[0])  # hubs are thinned
-    assert np.array_equal(_keys(keys), rk) and np.array_equal(_u32(vals), rv)
+    assert np.array_equal(_words(pairs), rw)
 
 
 @pytest.mark.parametrize("parts,slices,band", [(1, 1, (0, 0)), (4, 1, (6, 0)), (6, 8, (5, 2)),
@@ -152,13 +167,13 @@ def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, 
                          hot_hi=band[1])
     work, offsets = ops.block_count(g, plan, wk, 11, 0, 0)
     alias, cell_rows, hub_bits = ops.block_alias(g, plan)
-    keys, vals = ops.block_extract(g, plan, wk, 11, 0, 0, work, int(offsets[-1]), hub_bits=hub_bits)
+    pairs = ops.block_extract(g, plan, wk, 11, 0, 0, work, int(offsets[-1]), hub_bits=hub_bits)
     sf = (1 if scale_free else 0) | extra
     tp = ops.train_params(0, d, k, window, flags=sf | flags, ld=ld)
     otp = O.TrainParams(0, d, ld, 1, k, window, 0.01, 0.9, 6.0, sf, d ** -0.5)
     c = ops.init_table_rows(stripe_rows(n, rank, world), d, 11, 0, d ** -0.5, rank, world, ld=ld)
     c_h = c.cpu().numpy().copy()
-    rk, rv, ro = _keys(keys), _u32(vals), offsets.cpu().numpy().astype(np.uint64)
+    rw, ro = _words(pairs), offsets.cpu().numpy().astype(np.uint64)
     rp, rpo = alias.cpu().numpy().view(np.uint64), cell_rows.cpu().numpy().astype(np.uint64)
     got_x, ref_x = [], []
     ops.stats_reset(g)
@@ -166,8 +181,8 @@ def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, 
     for part in (range(parts) if part_list is None else part_list):
         x = ops.init_table_rows(stripe_rows(n, part, parts), d, 11, 1, d ** -0.5, part, parts, ld=ld)
         x_h = x.cpu().numpy().copy()
-        ops.block_step(g, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, 3, part, 11, 0, lr)
-        trained += O.block_step(og, otp, oplan, rk, rv, ro, rp, rpo, c_h, x_h, 3, part, 11, 0, lr)
+        ops.block_step(g, tp, plan, pairs, offsets, alias, cell_rows, c, x, 3, part, 11, 0, lr)
+        trained += O.block_step(og, otp, oplan, rw, ro, rp, rpo, c_h, x_h, 3, part, 11, 0, lr)
         got_x.append(x.cpu().numpy())
         ref_x.append(x_h)
     torch.cuda.synchronize()
@@ -231,7 +246,7 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
     oplan = O.block_plan(2 * n_rows + 5, 1, 0, parts, slices, 8, 2, 1, record, hot_lo=1)
     rng = np.random.RandomState(3)
     rows_per_part = stripe_rows(2 * n_rows + 5, 0, parts)
-    keys_l, vals_l, offsets = [], [], [0]
+    words_l, offsets = [], [0]
     next_centre = 0
     for cell in range(parts * slices):
         slc = cell % slices
@@ -240,16 +255,12 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
         ctx = rng.permutation(cand)[:m]
         centres = next_centre + np.arange(m)
         next_centre += m
-        keys_l.append((cell << plan.row_bits) | centres)
-        vals_l.append(ctx)
+        hot = np.arange(m) % 2  # every other context row is "hot": updated by atomics
+        words_l.append(O.block_pack(np.full(m, cell), centres, ctx, oplan, hot=hot))
         offsets.append(offsets[-1] + m)
-    keys_h = np.concatenate(keys_l).astype(np.uint64)
-    vals_h = np.concatenate(vals_l).astype(np.uint32)
-    vals_h[1::2] |= np.uint32(0x80000000)  # every other context row is "hot": updated by atomics
+    words_h = np.concatenate(words_l).astype(np.uint64)
     off_h = np.asarray(offsets, dtype=np.uint64)
-    assert plan.key_bits == 32
-    keys = torch.from_numpy(keys_h.astype(np.uint32).view(np.int32)).cuda()
-    vals = torch.from_numpy(vals_h.view(np.int32)).cuda()
+    pairs = _dev_words(words_h)
     offs = torch.from_numpy(off_h.astype(np.int64)).cuda()
     ld = (d + 3) // 4 * 4
     tp = ops.train_params(0, d, 0, 2, flags=flags, ld=ld)  # k = 0, no alias tables needed
@@ -259,8 +270,8 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
     for part in range(parts):
         x = ops.init_table(rows_per_part, d, 5, 1 + part, 0.5, ld=ld)
         x_h = x.cpu().numpy().copy()
-        ops.block_step(g, tp, plan, keys, vals, offs, None, None, c, x, 0, part, 5, 0, 0.05)
-        O.block_step(og, otp, oplan, keys_h, vals_h, off_h, None, None, c_h, x_h, 0, part, 5, 0, 0.05)
+        ops.block_step(g, tp, plan, pairs, offs, None, None, c, x, 0, part, 5, 0, 0.05)
+        O.block_step(og, otp, oplan, words_h, off_h, None, None, c_h, x_h, 0, part, 5, 0, 0.05)
         torch.cuda.synchronize()
         assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
         assert np.abs(x_h - ops.init_table(rows_per_part, d, 5, 1 + part, 0.5, ld=ld).cpu().numpy()
@@ -284,17 +295,14 @@ def test_central_row_collects_every_gradient_from_all_xcds(d):
     oplan = O.block_plan(n_nodes, 1, 0, 1, slices, 8, 2, 1, record)
     rng = np.random.RandomState(11)
     centre = 12_345
-    keys_l, vals_l, offsets = [], [], [0]
+    words_l, offsets = [], [0]
     for cell in range(slices):
         ctx = rng.permutation(np.arange(cell, n_nodes, slices))[:per_cell]
-        keys_l.append(np.full(per_cell, (cell << plan.row_bits) | centre, dtype=np.uint64))
-        vals_l.append(ctx)
+        words_l.append(O.block_pack(np.full(per_cell, cell), np.full(per_cell, centre), ctx, oplan))
         offsets.append(offsets[-1] + per_cell)
-    keys_h = np.concatenate(keys_l)
-    vals_h = np.concatenate(vals_l).astype(np.uint32)
+    words_h = np.concatenate(words_l)
     off_h = np.asarray(offsets, dtype=np.uint64)
-    keys = torch.from_numpy(keys_h.astype(np.uint32).view(np.int32)).cuda()
-    vals = torch.from_numpy(vals_h.view(np.int32)).cuda()
+    pairs = _dev_words(words_h)
     offs = torch.from_numpy(off_h.astype(np.int64)).cuda()
     ld = (d + 3) // 4 * 4
     # the row starts at zero and moves by ~2e-4: the scores stay within 1e-2 of zero, so the
@@ -309,8 +317,8 @@ def test_central_row_collects_every_gradient_from_all_xcds(d):
     x = ops.init_table(n_nodes, d, 5, 1, 0.5, ld=ld).abs_()
     c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
     before = c_h[centre, :d].copy()
-    ops.block_step(g, tp, plan, keys, vals, offs, None, None, c, x, 0, 0, 5, 0, lr)
-    O.block_step(og, otp, oplan, keys_h, vals_h, off_h, None, None, c_h, x_h, 0, 0, 5, 0, lr)
+    ops.block_step(g, tp, plan, pairs, offs, None, None, c, x, 0, 0, 5, 0, lr)
+    O.block_step(og, otp, oplan, words_h, off_h, None, None, c_h, x_h, 0, 0, 5, 0, lr)
     torch.cuda.synchronize()
     got = c.cpu().numpy()[centre, :d] - before
     want = c_h[centre, :d] - before
@@ -537,7 +545,7 @@ def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
 
 def test_bad_plans_are_refused(karate):
     for kw in (dict(world=2, rank=2, parts=4), dict(world=2, rank=0, parts=0),
-               dict(world=1, rank=0, parts=1, slices=17), dict(world=1, rank=0, parts=2000),
+               dict(world=1, rank=0, parts=1, slices=17), dict(world=1, rank=0, parts=9000),
                dict(world=1, rank=0, parts=1, record=33), dict(world=1, rank=0, parts=1, hot_lo=3, hot_hi=5)):
         args = dict(slices=1, walk_length=8, window=2)
         args.update(kw)
@@ -547,9 +555,15 @@ def test_bad_plans_are_refused(karate):
     tp = ops.train_params(0, 8, 2, 2, flags=1)
     c = ops.init_table(34, 8, 1, 0, 0.3)
     with pytest.raises(_lib.Gn2vError, match="alias"):  # degree-proportional negatives need tables
-        ops.block_step(karate, tp, plan, c, c, c, None, None, c, c, 0, 0, 1, 0, 0.01)
+        ops.block_step(karate, tp, plan, c, c, None, None, c, c, 0, 0, 1, 0, 0.01)
     with pytest.raises(_lib.Gn2vError, match="part out of range"):
-        ops.block_step(karate, tp, plan, c, c, c, c, c, c, c, 0, 5, 1, 0, 0.01)
+        ops.block_step(karate, tp, plan, c, c, c, c, c, c, 0, 5, 1, 0, 0.01)
+    work = torch.empty(_lib.BLOCK_WORK_WORDS, dtype=torch.int64, device="cuda")
+    wk = ops.walks(karate, ops.walk_params(8, 1, 1.0, 1.0), 1, 0, 0, 34)
+    with pytest.raises(_lib.Gn2vError, match="group of parts"):
+        ops.block_count(karate, plan, wk, 1, 0, 0, work=work, part_lo=2, part_n=1)
+    with pytest.raises(_lib.Gn2vError, match="group of parts"):
+        ops.block_count(karate, plan, wk, 1, 0, 0, work=work, part_lo=1, part_n=3)
     # parts that travel between ranks must divide evenly: the trainer's rule, not the kernel's
     from sharded_helpers import run_ranks
 
@@ -584,7 +598,8 @@ def test_gn2v_train_block_path_equals_the_python_trainer():
               deterministic=True, verbose=False)
     m_c = E.models.SkipGram(block_path=True, **kw)
     c1, x1, st = m_c.fit_transform_device(g)
-    assert m_c.last_plan == {"world": 1, "parts": 1, "slices": 1, "stripes": 1}
+    assert m_c.last_plan == {"world": 1, "parts": 1, "slices": 1, "stripes": 1, "group_parts": 1,
+                             "round_walks": 900}
     m_py = E.models.SkipGram(**kw)
     c2, x2 = m_py.fit_transform_blocks(g, LoopbackComm())
     assert st["pairs"] == m_py.last_stats["pairs"] == 3 * 900 * (2 * 3 * 16 - 3 * 4)
@@ -631,7 +646,8 @@ def test_gn2v_train_takes_the_block_path_by_itself_from_two_to_the_sixteen_nodes
     small, large = E.barabasi_albert(60_000, 5, 1), E.barabasi_albert(70_000, 5, 1)
     kw = dict(embedding_size=16, epochs=1, iterations=1, walk_length=16, window_size=3,
               verbose=False)
-    for g, plan in ((small, None), (large, {"world": 1, "parts": 1, "slices": 2, "stripes": 1})):
+    for g, plan in ((small, None), (large, {"world": 1, "parts": 1, "slices": 8, "stripes": 1,
+                                            "group_parts": 1, "round_walks": 70_000})):
         for cls in (E.models.SkipGram, E.models.CBOW):
             m = cls(**kw)
             c, x, st = m.fit_transform_device(g)
@@ -656,9 +672,9 @@ def test_block_path_against_the_committed_golden_fixture(karate):
     plan = ops.block_plan(karate, 2, 1, 4, 2, 16, 3, 1, 4, hot_lo=4, hot_hi=1)
     alias, cell_rows, hub_bits = ops.block_alias(karate, plan)
     work, offsets = ops.block_count(karate, plan, wk, 42, 0, 0)
-    keys, vals = ops.block_extract(karate, plan, wk, 42, 0, 0, work, int(offsets[-1]),
-                                   hub_bits=hub_bits)
-    assert np.array_equal(_keys(keys), gold["keys"]) and np.array_equal(_u32(vals), gold["vals"])
+    pairs = ops.block_extract(karate, plan, wk, 42, 0, 0, work, int(offsets[-1]),
+                              hub_bits=hub_bits)
+    assert np.array_equal(_words(pairs), gold["words"])
     assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), gold["offsets"])
     assert np.array_equal(alias.cpu().numpy().view(np.uint64), gold["alias"])
     assert np.array_equal(hub_bits.cpu().numpy().view(np.uint32), gold["hub_bits"])
@@ -666,7 +682,7 @@ def test_block_path_against_the_committed_golden_fixture(karate):
     c = ops.init_table_rows(17, 8, 42, 0, 8 ** -0.5, 1, 2)
     for part in range(4):
         x = ops.init_table_rows((34 - part + 3) // 4, 8, 42, 1, 8 ** -0.5, part, 4)
-        ops.block_step(karate, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, 7, part, 42,
+        ops.block_step(karate, tp, plan, pairs, offsets, alias, cell_rows, c, x, 7, part, 42,
                        0, 0.05)
         assert np.abs(x.cpu().numpy() - gold[f"part{part}"]).max() < 1e-5
     assert np.abs(c.cpu().numpy() - gold["central"]).max() < 1e-5
@@ -705,8 +721,8 @@ def test_gn2v_train_block_path_honours_the_model_options():
 
 def test_round_size_shrinks_with_the_free_memory():
     """The automatic round size follows what is free on the device when the fit starts
-    (gn2v_block_round_walks): with all but ~6 GB of the HBM taken, a fit whose epoch would need
-    8.5 GB of pair buffers in one round runs in several smaller rounds and trains every pair."""
+    (gn2v_block_round_plan): with all but ~6 GB of the HBM taken, a fit whose epoch would need
+    9 GB of pair buffers in one round runs in several smaller rounds and trains every pair."""
     g = E.barabasi_albert(200_000, 5, 5)
     n = g.get_number_of_nodes()
     kw = dict(embedding_size=32, epochs=1, iterations=2, walk_length=128, window_size=5,
@@ -727,12 +743,14 @@ def test_round_size_shrinks_with_the_free_memory():
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_run_with_standing_buffers_equals_round_by_round_training(overlap):
+@pytest.mark.parametrize("overlap,group_parts", [(False, None), (True, None), (False, 1), (True, 1),
+                                                 (True, 3)])
+def test_run_with_standing_buffers_equals_round_by_round_training(overlap, group_parts):
     """``run`` (standing pair buffers, two slots alternating when the preparation overlaps, called
     twice like bench.py's warm-up and timed phases, a later round larger than the buffers were
-    sized for) against ``train_round`` (fresh buffers per round): the deterministic kernel makes
-    the two bit-equal."""
+    sized for; the round's pairs prepared at once or a group of parts at a time, the next group
+    prepared on the side stream while one trains) against ``train_round`` (fresh buffers per round,
+    all parts at once): the deterministic kernel makes the two bit-equal."""
     g = _ba(203)
     tp = ops.train_params(0, D, K, W, flags=1 | DET)
     wp = ops.walk_params(L, 1, 0.25, 4.0)
@@ -741,12 +759,13 @@ def test_run_with_standing_buffers_equals_round_by_round_training(overlap):
 
     def trainer():
         return BlockPartitionedTrainer(g, tp, D, D, 42, D ** -0.5, LoopbackComm(), "cuda:0",
-                                       walk_length=L, window=W, parts=2, slices=2, record=4)
+                                       walk_length=L, window=W, parts=4, slices=2, record=4)
 
     a = trainer()
     for first, n in zip(firsts, sizes):
         a.train_round(ops.walks(g, wp, 42, 0, first, n), 42, 0, 0.02, first)
     b = trainer()
+    b.group_parts = group_parts or b.parts  # groups change the buffers, never the result
     b.round_capacity = 11
     rounds = [(lambda first=first, n=n: ops.walks(g, wp, 42, 0, first, n), 42, 0, 0.02, first)
               for first, n in zip(firsts, sizes)]
@@ -757,3 +776,133 @@ def test_run_with_standing_buffers_equals_round_by_round_training(overlap):
     for x, y in zip(a.gather_full(), b.gather_full()):
         assert torch.equal(x, y)
     assert not b.backend._slots and b.backend._temp is None  # released with the result
+
+
+# ------------------------------------------------------------------ XCD ownership of the rows
+def test_the_device_reports_its_xcds(karate):
+    """gn2v_graph_create probes which XCDs workgroups land on: 8 on an MI355X (SPX mode)."""
+    assert ops.graph_xcds(karate) == 8
+
+
+def _shared_row_displacement(slices, flags, n_pairs=100_000, d=128):
+    """n_pairs pairs with unique centres and ONE shared context row (k = 0, a learning rate so
+    small that the order of the updates does not matter): how far the row moves, relative to the
+    sequential oracle.  Every pair sits in the row's cell, so with `slices` < 8 the records are
+    spread over 8 / slices XCDs (non-coherent L2s)."""
+    n_nodes = 8 * 32_768
+    g = _ba(n_nodes)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    plan = ops.block_plan(g, 1, 0, 1, slices, 8, 2, 1, 16)
+    oplan = O.block_plan(n_nodes, 1, 0, 1, slices, 8, 2, 1, 16)
+    shared = 4242  # row 4242 of the only part: cell 4242 % slices
+    cell = shared % slices
+    centres = np.arange(n_pairs)
+    words_h = O.block_pack(np.full(n_pairs, cell), centres, np.full(n_pairs, shared), oplan)
+    off_h = np.zeros(slices + 1, dtype=np.uint64)
+    off_h[cell + 1:] = n_pairs
+    pairs = _dev_words(words_h)
+    offs = torch.from_numpy(off_h.astype(np.int64)).cuda()
+    lr = 1e-8
+    tp = ops.train_params(0, d, 0, 2, flags=flags, ld=d)
+    otp = O.TrainParams(0, d, d, 1, 0, 2, 0.01, 0.9, 6.0, 0, d ** -0.5)
+    c = ops.init_table(n_nodes, d, 5, 0, 0.5).abs_()  # all positive: the gradients add up
+    x = ops.init_table(n_nodes, d, 5, 1, 0.5)
+    x[shared] = 0
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    ops.block_step(g, tp, plan, pairs, offs, None, None, c, x, 0, 0, 5, 0, lr)
+    O.block_step(og, otp, oplan, words_h, off_h, None, None, c_h, x_h, 0, 0, 5, 0, lr)
+    torch.cuda.synchronize()
+    got, want = x[shared].cpu().numpy(), x_h[shared]
+    assert np.abs(want).min() > 1e-5
+    return float(np.median(got / want))
+
+
+def test_contextual_rows_shared_by_several_xcds_keep_write_through_stores():
+    """Round 2 gave every sliced part plain write-back stores, but only 8 slices give each XCD a
+    slice of its own: with 2 or 4 slices XCD x and XCD x + slices read-modify-wrote the same rows
+    from their own L2s, and a row that stayed resident kept one XCD's updates (1/4 or 1/2 of the
+    displacement).  Now such parts use write-through stores: the default mode must move a row
+    that every record of a launch updates as far as the explicit write-through mode does (both
+    lose updates to plain Hogwild races; neither may lose an XCD's worth), and hardware atomics
+    must lose none."""
+    exact = _shared_row_displacement(4, _lib.TRAIN_ATOMIC)
+    assert abs(exact - 1) < 2e-3, exact
+    report = {}
+    for slices in (2, 4, 8):
+        auto = np.mean([_shared_row_displacement(slices, 0) for _ in range(3)])
+        wt = np.mean([_shared_row_displacement(slices, _lib.TRAIN_WRITE_THROUGH) for _ in range(3)])
+        report[slices] = (auto, wt)
+    print("shared-row displacement / sequential (default, write-through):", report)
+    for slices in (2, 4):
+        auto, wt = report[slices]
+        assert auto > 0.6 * wt, report
+
+
+def test_negatives_keep_their_degree_proportional_law_through_the_cells():
+    """The reference documents negatives proportional to the degree (use_scale_free_distribution,
+    node2vec_skipgram.py:101-102).  The block path draws them inside the context's cell; this
+    measures what comes out over a whole round: central rows = one constant vector u,
+    contextual rows = 0, a tiny learning rate and exact (atomic) accumulation make every
+    contextual row end at (times it was a context - times it was a negative) * lr / 2 * u, and the
+    context counts are known from the walks.  Inside a cell the negative counts must follow
+    in-degree / cell total (chi-square), and over all cells the marginal must stay close to
+    in-degree / total in-degree -- cells receive pairs in proportion to the degrees they hold."""
+    from scipy import stats
+
+    n, d, k, w, L = 1_000_000, 8, 5, 5, 64
+    g = E.barabasi_albert(n, 10, 42)
+    wp = ops.walk_params(L, 1, 1.0, 1.0)
+    n_walks = 1 << 20
+    lr = 1e-9  # scores stay below 1e-4: sigmoid = 1/2 to 3e-5, the order of the updates is moot
+    tp = ops.train_params(0, d, k, w, lr=lr, flags=1 | _lib.TRAIN_ATOMIC, ld=d)
+    tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
+                                 walk_length=L, window=w)
+    assert (tr.parts, tr.slices) == (3, 8)
+    u = d ** -0.5
+    tr.central.fill_(u)
+    for t in tr.held.values():
+        t.zero_()
+    wk = ops.walks(g, wp, 42, 0, 0, n_walks)
+    ops.stats_reset(g)
+    tr.train_round(wk, 42, 0, lr, 0)
+    torch.cuda.synchronize()
+    n_pairs = ops.stats_read(g)["pairs"]
+    assert n_pairs == n_walks * (2 * w * L - w * (w + 1))
+    _, x = tr.gather_full()
+    net = (x.double().mean(1) / u / (0.5 * lr)).round().long()   # contexts - negatives per node
+    # how often every node is a context: position j of a walk is the context of the centres at
+    # distance 1 .. w on either side
+    idx = torch.arange(L, device="cuda")
+    times = (torch.minimum(idx, torch.tensor(w, device="cuda"))
+             + torch.minimum(L - 1 - idx, torch.tensor(w, device="cuda")))
+    pos = torch.zeros(n, dtype=torch.long, device="cuda")
+    pos.index_add_(0, wk.long().flatten(), times.repeat(n_walks))
+    assert int(pos.sum()) == n_pairs
+    neg = (pos - net).cpu().numpy()
+    assert neg.min() >= -3  # f32 accumulation of ~10^5 equal increments: a few counts of rounding
+    neg = np.maximum(neg, 0)
+    skipped = k * n_pairs - neg.sum()            # negatives equal to the context or the centre
+    assert abs(skipped) < 5e-4 * k * n_pairs
+    indeg = np.bincount(g.col_idx, minlength=n).astype(np.float64)
+    node = np.arange(n)
+    cell = (node % tr.parts) * tr.slices + (node // tr.parts) % tr.slices
+    # inside a cell: chi-square of the counts against in-degree / cell total (hubs one by one,
+    # the tail pooled by degree so that every bin expects >= 50 draws)
+    pvals = []
+    for c in (0, 7, 13, 23):
+        rows = np.nonzero(cell == c)[0]
+        order = rows[np.argsort(-indeg[rows])]
+        obs, exp = neg[order].astype(np.float64), indeg[order] / indeg[order].sum() * neg[order].sum()
+        head = 300
+        groups = np.array_split(np.arange(head, len(order)), 50)
+        o = np.concatenate([obs[:head], [obs[i].sum() for i in groups]])
+        e = np.concatenate([exp[:head], [exp[i].sum() for i in groups]])
+        assert e.min() > 50
+        pvals.append(stats.chisquare(o, e * o.sum() / e.sum()).pvalue)
+    assert min(pvals) > 1e-4, pvals
+    # over all cells: the share of the negatives that each degree class receives
+    order = np.argsort(-indeg)
+    classes = np.array_split(order, 40)
+    got = np.array([neg[i].sum() for i in classes]) / neg.sum()
+    want = np.array([indeg[i].sum() for i in classes]) / indeg.sum()
+    assert np.abs(got / want - 1).max() < 0.05, (got / want)

@@ -11,6 +11,13 @@ properties (the oracle cannot run these sizes in seconds):
 Tables are checked through exact per-row integer checksums so that the 2 x 51.2 GB tables of
 config 5 need no second copy.  Config 4 additionally runs the block-partitioned multi-GPU trainer
 with 8 simulated ranks at full size (tests/test_gpu_blocks.py holds the small exact cases).
+
+``block_path_properties`` drives the kernel that SHIPS at these sizes -- SkipGram on >= 2^16 nodes
+goes through ``gn2v_train`` -> ``gn2v_train_blocks`` (automatic plan, alias tables, pair words,
+groups of parts, ``sgns_block_kernel``, the contextual table trained part-major in the caller's
+buffer and put back in node order) -- for configs 3, 4, 5a and 5 with a walk budget;
+``full_size_properties`` keeps the walk-ordered kernel (CBOW's, small graphs', explicit update
+modes') honest at the same sizes.
 """
 import numpy as np
 import pytest
@@ -87,6 +94,74 @@ def full_size_properties(g, n_walks, d=128):
     return st
 
 
+def block_path_properties(g, n_walks, plan, d=128, return_weight=0.25, explore_weight=4.0):
+    """The whole fit through ``gn2v_train`` (block path by the library's own choice) on a budget of
+    ``n_walks`` walks: lr = 0 is the identity (row checksums against the freshly initialised
+    tables, in NODE order: the part-major storage of the fit is undone); pairs == the closed
+    form; central rows move only for walk nodes and nearly every walk node's row moves; the
+    contextual rows of (nearly) all walk nodes move and the negatives reach beyond them; finite."""
+    n = g.get_number_of_nodes()
+    kw = dict(embedding_size=d, epochs=1, walk_length=128, iterations=10, window_size=5,
+              number_of_negative_samples=10, return_weight=return_weight,
+              explore_weight=explore_weight, verbose=False)
+    scale = d ** -0.5
+    c0 = row_checksums(ops.init_table(n, d, 42, 0, scale))
+    x0 = row_checksums(ops.init_table(n, d, 42, 1, scale))
+    torch.cuda.empty_cache()
+    m = E.models.SkipGram(learning_rate=0.0, **kw)
+    c, x, st = m.fit_transform_device(g, max_walks_per_epoch=n_walks)
+    got = {k: m.last_plan[k] for k in ("parts", "slices")}
+    assert got == plan, m.last_plan
+    assert st["pairs"] == n_walks * PAIRS_PER_WALK
+    assert torch.equal(row_checksums(c), c0) and torch.equal(row_checksums(x), x0)
+    del c, x
+    torch.cuda.empty_cache()
+    m = E.models.SkipGram(learning_rate=0.01, **kw)
+    c, x, st = m.fit_transform_device(g, max_walks_per_epoch=n_walks)
+    assert st["pairs"] == n_walks * PAIRS_PER_WALK
+    assert 0 < st["centres"] <= st["pairs"]  # runs of equal centre inside the records
+    assert all_finite(c) and all_finite(x)
+    wk = ops.walks(g, m.walk_params(), 42, 0, 0, n_walks)  # the walks of that fit
+    visited = torch.zeros(n, dtype=torch.bool, device="cuda")
+    visited[wk.long().flatten() & 0xFFFFFFFF] = True
+    c1, x1 = row_checksums(c), row_checksums(x)
+    assert torch.equal(c1[~visited], c0[~visited])  # central rows move only for walk nodes
+    assert float((c1[visited] != c0[visited]).float().mean()) > 0.99
+    assert float((x1[visited] != x0[visited]).float().mean()) > 0.99  # every walk node is a context
+    assert int((x1 != x0).sum()) > int(visited.sum())  # negatives reach beyond the walk nodes
+    return m.last_plan, st
+
+
+def test_config3_arxiv_shaped_block_path_full_size_properties():
+    """BASELINE config 3's shape (169 343 nodes, p = 0.5 / q = 2): the plan is 1 part x 8 slices
+    -- one slice per XCD; round 2 shipped 1 x 4 here, with write-back stores on rows that two
+    XCDs shared."""
+    g = E.barabasi_albert(169_343, 7, 42, name="BA-shaped-like-ogbn-arxiv")
+    block_path_properties(g, 1 << 15, {"parts": 1, "slices": 8}, return_weight=2.0,
+                          explore_weight=0.5)
+
+
+def test_config4_products_shaped_block_path_full_size_properties():
+    g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
+    block_path_properties(g, 1 << 16, {"parts": 9, "slices": 8})
+
+
+def test_config5a_bench_graph_block_path_full_size_properties():
+    """The roofline configuration (BA 10 M / 100 M) through the path the bench times."""
+    g = E.barabasi_albert(10_000_000, 10, 42)
+    plan, _ = block_path_properties(g, 1 << 17, {"parts": 38, "slices": 8})
+    assert plan["group_parts"] == 10  # four groups of parts per round
+
+
+def test_config5_ba_100m_block_path_full_size_properties():
+    """BASELINE config 5 (BA 100 M / 1 B) on one GPU: 381 x 8 cells of 32.8 k rows, 56-bit pair
+    words (12 + 27 + 17), 100 M-row alias tables, the 51.2 GB contextual table trained part-major
+    in the caller's buffer and restored through one scratch copy."""
+    g = E.barabasi_albert(100_000_000, 10, 42)
+    plan, _ = block_path_properties(g, 1 << 17, {"parts": 381, "slices": 8})
+    assert plan["group_parts"] == 96
+
+
 def test_config4_ogbn_products_shaped_full_size_properties():
     """BASELINE config 4: ogbn-products-shaped BA graph, 2 449 029 nodes / ~61.2 M edges
     (m = 25), d = 128, reference defaults; one launch of 2^16 walks on one GPU."""
@@ -128,7 +203,7 @@ def test_config4_block_trainer_with_eight_simulated_ranks_at_full_size():
     gen.manual_seed(1)
     auc_single = link_auc_device(g, c, x, gen)
     del c, x
-    assert auto_plan(n, world) == (16, 4)
+    assert auto_plan(n, world) == (16, 8)
 
     def rank_fn(comm):
         tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, comm, "cuda:0", walk_length=128,
@@ -165,7 +240,8 @@ def test_large_graphs_are_fitted_through_the_block_path_on_one_gpu():
     res = m.fit_transform(g, return_dataframe=False).get_all_node_embedding()
     assert res[0].shape == (400_000, 32) and res[1].shape == (400_000, 32)
     assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
-    assert m._model.last_plan == {"world": 1, "parts": 1, "slices": 8, "stripes": 1}  # gn2v_train's own choice
+    plan = m._model.last_plan  # gn2v_train's own choice
+    assert (plan["world"], plan["parts"], plan["slices"], plan["stripes"]) == (1, 1, 8, 1)
     assert m.get_last_stats()["pairs"] == 400_000 * (2 * 3 * 32 - 3 * 4)
     init = ops.init_table(400_000, 32, 42, 0, 32 ** -0.5).cpu().numpy()
     assert np.abs(res[0] - init).max() > 1e-3
@@ -189,7 +265,7 @@ def test_block_path_on_a_directed_weighted_graph_with_trap_nodes():
         warnings.simplefilter("ignore")
         m = E.Node2VecSkipGramEnsmallen(**kw)
         res = m.fit_transform(g, return_dataframe=False).get_all_node_embedding()
-    assert m._model.last_plan["parts"] == 1 and m._model.last_plan["slices"] == 2
+    assert m._model.last_plan["parts"] == 1 and m._model.last_plan["slices"] == 8
     assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
     expected = 0
     wp = m._model.walk_params()

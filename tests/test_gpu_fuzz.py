@@ -141,17 +141,21 @@ def test_random_block_rounds_match_oracle(case):
                          hot_lo=band[0], hot_hi=band[1])
     alias, cell_rows, hub_bits = ops.block_alias(g, plan)
     ra, rc, rh = O.block_alias(og, parts, slices, *band)
-    work, offsets = ops.block_count(g, plan, wk, seed, epoch, first)
+    # a random group of parts (cyclic) or the whole round
+    part_lo = int(rng.randint(0, parts))
+    part_n = int(rng.randint(1, parts + 1))
+    if rng.rand() < 0.4:
+        part_lo, part_n = 0, 0
+    work, offsets = ops.block_count(g, plan, wk, seed, epoch, first, part_lo=part_lo,
+                                    part_n=part_n)
     n_pairs = int(offsets[-1])
-    keys, vals = ops.block_extract(g, plan, wk, seed, epoch, first, work, n_pairs,
-                                   hub_bits=hub_bits)
-    rk, rv, ro = O.block_extract(og, oplan, wk.cpu().numpy().view(np.uint32), seed, epoch, first,
-                                 hub_bits=rh)
-    assert plan.key_bits == oplan.key_bits
-    ka = keys.cpu().numpy()
-    ka = ka.view(np.uint32).astype(np.uint64) if ka.dtype == np.int32 else ka.view(np.uint64)
-    assert np.array_equal(ka, rk)
-    assert np.array_equal(vals.cpu().numpy().view(np.uint32), rv)
+    pairs = ops.block_extract(g, plan, wk, seed, epoch, first, work, n_pairs, hub_bits=hub_bits,
+                              part_lo=part_lo, part_n=part_n)
+    rw, ro = O.block_extract(og, oplan, wk.cpu().numpy().view(np.uint32), seed, epoch, first,
+                             hub_bits=rh, part_lo=part_lo, part_n=part_n)
+    assert (plan.key_bits, plan.ctx_bits, plan.row_bits) == (oplan.key_bits, oplan.ctx_bits,
+                                                             oplan.row_bits)
+    assert np.array_equal(pairs.cpu().numpy().view(np.uint64), rw)
     assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
     assert np.array_equal(hub_bits.cpu().numpy().view(np.uint32), rh)
     assert np.array_equal(alias.cpu().numpy().view(np.uint64), ra)
@@ -167,9 +171,9 @@ def test_random_block_rounds_match_oracle(case):
         rows = stripe_rows(n, part, parts)
         x = ops.init_table_rows(rows, d, seed, 1, d ** -0.5, part, parts, ld=ld)
         x_h = x.cpu().numpy().copy()
-        ops.block_step(g, tp, plan, keys, vals, offsets, alias, cell_rows, c, x, case, part, seed,
+        ops.block_step(g, tp, plan, pairs, offsets, alias, cell_rows, c, x, case, part, seed,
                        epoch, 0.05)
-        O.block_step(og, otp, oplan, rk, rv, ro, ra, rc, c_h, x_h, case, part, seed, epoch, 0.05)
+        O.block_step(og, otp, oplan, rw, ro, ra, rc, c_h, x_h, case, part, seed, epoch, 0.05)
         torch.cuda.synchronize()
         assert np.abs(x.cpu().numpy() - x_h).max() < 2e-5, (part,)
     assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5

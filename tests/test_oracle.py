@@ -278,15 +278,16 @@ def test_self_golden_of_the_block_schedule(karate_oracle):
     walks = np.load(os.path.join(GOLDEN, "oracle_karate.npz"))["walks"]
     plan = O.block_plan(34, 2, 1, 4, 2, 16, 3, 1, 4, hot_lo=4, hot_hi=1)
     alias, cell_rows, hub_bits = O.block_alias(karate_oracle, 4, 2, 4, 1)
-    keys, vals, offsets = O.block_extract(karate_oracle, plan, walks, 42, 0, 0, hub_bits=hub_bits)
-    for name, got in (("keys", keys), ("vals", vals), ("offsets", offsets), ("alias", alias),
+    words, offsets = O.block_extract(karate_oracle, plan, walks, 42, 0, 0, hub_bits=hub_bits)
+    assert O.block_unpack(words, plan)[3].any()  # the band flags some context rows
+    for name, got in (("words", words), ("offsets", offsets), ("alias", alias),
                       ("cell_rows", cell_rows), ("hub_bits", hub_bits)):
         assert np.array_equal(got, gold[name]), name
     tp = O.TrainParams(0, 8, 8, 1, 4, 3, 0.01, 0.9, 6.0, 1, 8 ** -0.5)
     central = O.init_table_rows(17, 8, 8, 42, 0, 8 ** -0.5, 1, 2)
     for part in range(4):
         x = O.init_table_rows((34 - part + 3) // 4, 8, 8, 42, 1, 8 ** -0.5, part, 4)
-        O.block_step(karate_oracle, tp, plan, keys, vals, offsets, alias, cell_rows, central, x, 7,
+        O.block_step(karate_oracle, tp, plan, words, offsets, alias, cell_rows, central, x, 7,
                      part, 42, 0, 0.05)
         assert np.allclose(x, gold[f"part{part}"], atol=1e-6)
     assert np.allclose(central, gold["central"], atol=1e-6)
