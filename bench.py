@@ -85,12 +85,18 @@ def parse():
     ap.add_argument("--slices", type=int, default=None,
                     help="blocks: XCD slices inside a part (8 = every XCD owns its rows; default: "
                          "distributed.auto_plan)")
-    ap.add_argument("--record", type=int, default=16, help="blocks: pairs per record")
+    ap.add_argument("--record", type=int, default=32, help="blocks: pairs per record")
     ap.add_argument("--hot-band", default="0:0",
                     help="blocks: lo:hi -- contextual rows whose share of their cell's edge "
                          "endpoints lies in [2^-lo, 2^-hi) are updated with atomics (0:0 = off)")
     ap.add_argument("--local-atomic", action="store_true",
                     help="blocks with slices: contextual rows updated by L2-local f32 atomics")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="blocks: CUs of every XCD left to other work (RCCL's transfer kernels): "
+                         "the training kernel runs on a CU-masked stream (gn2v_graph_reserve_cus)")
+    ap.add_argument("--central-atomic", action="store_true",
+                    help="blocks: every central row update by atomics (round 2's behaviour; default: "
+                         "a store when the run is its centre's only one in the cell)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="blocks: prepare round t + 1 on a second stream while round t trains "
                          "(auto: with several GPUs, where it hides the walk all-gather; on one GPU "
@@ -313,12 +319,15 @@ def main():
     cbow = args.model == "cbow"
     graph = E.barabasi_albert(args.nodes, args.m, 42, device=local)
     n, d = graph.get_number_of_nodes(), args.d
+    reserved = ops.graph_reserve_cus(graph, args.reserve_cus, local) if args.reserve_cus else None
     ld = (d + 3) // 4 * 4 if d <= 16 else (d + 31) // 32 * 32  # the engine's padded row stride
     flags = _lib.TRAIN_SCALE_FREE | {
         "auto": 0, "write_through": _lib.TRAIN_WRITE_THROUGH,
         "write_back": _lib.TRAIN_WRITE_BACK, "atomic": _lib.TRAIN_ATOMIC}[args.mode]
     if args.local_atomic:
         flags |= _lib.TRAIN_LOCAL_ATOMIC
+    if args.central_atomic:
+        flags |= _lib.TRAIN_CENTRAL_ATOMIC
     if args.calibrate:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         perm = torch.randperm(n, device="cuda", dtype=torch.int64).to(torch.int32)
@@ -627,6 +636,9 @@ def main():
                 "launches": st["train_launches"],
             },
         }
+        if reserved is not None:
+            line["config"]["reserved_cus_per_xcd"] = args.reserve_cus
+            line["config"]["active_cus_per_xcd"] = reserved
         if comm_info is not None:
             line["distributed"] = comm_info
         line["hbm_peak_gb"] = {"torch_allocated": torch.cuda.max_memory_allocated() / 1e9,

@@ -29,6 +29,7 @@ TRAIN_CTX_CACHE_ALL = 256
 TRAIN_LOCAL_ATOMIC = 512
 TRAIN_WALK_ORDERED = 1024
 TRAIN_BLOCK_PATH = 2048
+TRAIN_CENTRAL_ATOMIC = 4096
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 
@@ -42,7 +43,7 @@ EXPORTS = [
     "gn2v_touch_rows",
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
     "gn2v_block_alias", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
-    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_auto_plan", "gn2v_block_round_plan", "gn2v_graph_xcds",
+    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_auto_plan", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
     "gn2v_train_blocks",
     "gn2v_stats_reset",
     "gn2v_stats_read",
@@ -97,6 +98,7 @@ class StepIO(C.Structure):
         ("neg_id_mul", C.c_uint32),
         ("neg_id_add", C.c_uint32),
         ("d_neg_override", C.c_void_p),
+        ("d_context_delta", C.c_void_p),
     ]
 
 
@@ -230,6 +232,7 @@ def lib():
     L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, u32, u32,
                                      vp, vp, u64, vp, vp, u64, vp]
     L.gn2v_graph_xcds.argtypes = [vp]
+    L.gn2v_graph_reserve_cus.argtypes = [vp, u32, vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),
                                   C.POINTER(BlockIO), u64, u64, f32, vp]
     L.gn2v_block_auto_plan.argtypes = [u64, u32, C.POINTER(u32), C.POINTER(u32)]

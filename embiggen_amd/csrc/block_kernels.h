@@ -360,6 +360,7 @@ struct BlockArgs {
     uint32_t part;
     uint32_t sweep;  // 1: second launch -- every workgroup serves every cell's leftover records
     uint32_t xcds;   // XCDs the workgroups are spread over (0 = unknown)
+    uint32_t central_atomic;  // 1: every central row update by atomics (GN2V_TRAIN_CENTRAL_ATOMIC)
     uint32_t k, ld, flags;
     float lr, clip;
 };
@@ -388,10 +389,11 @@ __device__ __forceinline__ uint64_t record_stride(uint64_t R) {
 
 template <int CH, int WMX, int WMC, bool DET>
 __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, uint64_t lo,
-                                             uint64_t p0, uint32_t n, uint64_t ckey,
+                                             uint64_t hi, uint64_t p0, uint32_t n, uint64_t ckey,
                                              uint64_t alias_lo, uint64_t cell_n, uint32_t slice,
                                              uint32_t *s_key, uint32_t *s_val, uint32_t *s_rows,
-                                             float *s_lab, float *s_tr, int lane, int grp, int q,
+                                             float *s_lab, uint32_t *s_nb, float *s_tr, int lane,
+                                             int grp, int q,
                                              unsigned long long &pairs,
                                              unsigned long long &runs) {
     const uint32_t k = a.k, nchunks = a.ld >> 2;
@@ -405,6 +407,12 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         s_key[lane] = (uint32_t)(word >> a.p.ctx_bits) & rowmask;
         s_val[lane] = (slice + a.p.slices * local) | (hub ? kHubBit : 0u);  // row inside the part
     }
+    // the centres just before and just after the record in the cell (kSentinel at its borders):
+    // a run that has no equal neighbour is the ONLY run of its centre in this cell
+    if (lane == 62)
+        s_nb[0] = p0 > lo ? (uint32_t)(a.pairs[p0 - 1] >> a.p.ctx_bits) & rowmask : kSentinel;
+    if (lane == 63)
+        s_nb[1] = p0 + n < hi ? (uint32_t)(a.pairs[p0 + n] >> a.p.ctx_bits) & rowmask : kSentinel;
     wave_sync();
     const uint32_t n_samples = n * (k + 1);
     for (uint32_t t = lane; t < n_samples; t += 64) {
@@ -475,8 +483,28 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
             score_samples<CH, WMX, DET>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
                                         s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
         if constexpr (!DET) reduce_groups<CH>(g);
-        if constexpr (!DET && WMC == kAtomic) to_contig_layout<CH>(g, g, s_tr, grp, q, a.ld);
-        if (grp == 0) scatter_add<CH, DET ? kWriteBack : WMC>(crow, q, nchunks, 1.0f, g, u);
+        // The gradient of the run goes to the central row.  A centre whose pairs in this cell are
+        // all in this run (the rule at 100 M nodes, where a round holds 1.1 pairs per cell and
+        // centre) is updated with one write-through store of u + g: u is still in registers, no
+        // other wave of this XCD names the row in this launch, and the seven other XCDs reach it
+        // -- through their own cells -- at some other moment of the launch with probability
+        // ~1 - 1e-4.  A centre that spans records (hubs: thousands of consecutive records that many
+        // waves train at once) gets its gradient added with hardware f32 atomics: no add is lost.
+        // An atomic row add costs ~5 stored rows (128 dword atomics through the L2 atomic units).
+        bool alone = false;
+        if constexpr (!DET && WMC == kAtomic)
+            alone = !a.central_atomic && (r0 > 0 || s_nb[0] != crow_id) &&
+                    (r1 < n || s_nb[1] != crow_id);
+        if constexpr (!DET && WMC == kAtomic) {
+            if (alone) {
+                if (grp == 0) scatter_add<CH, kWriteThrough>(crow, q, nchunks, 1.0f, g, u);
+            } else {
+                to_contig_layout<CH>(g, g, s_tr, grp, q, a.ld);
+                if (grp == 0) scatter_add<CH, kAtomic>(crow, q, nchunks, 1.0f, g, u);
+            }
+        } else {
+            if (grp == 0) scatter_add<CH, DET ? kWriteBack : WMC>(crow, q, nchunks, 1.0f, g, u);
+        }
         if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         r0 = r1;
         ++runs;  // one central row read + one gradient add per run of equal centre
@@ -496,12 +524,13 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
     const uint32_t C = a.p.record, k = a.k;
-    const uint32_t per_wave = (a.ld + 2 * C + 2 * C * (k + 1) + 3) & ~3u;
+    const uint32_t per_wave = (a.ld + 2 * C + 2 * C * (k + 1) + 2 + 3) & ~3u;
     float *s_tr = reinterpret_cast<float *>(smem + wave * per_wave);
     uint32_t *s_key = smem + wave * per_wave + a.ld;
     uint32_t *s_val = s_key + C;
     uint32_t *s_rows = s_val + C;
     float *s_lab = reinterpret_cast<float *>(s_rows + C * (k + 1));
+    uint32_t *s_nb = s_rows + 2 * C * (k + 1);  // centres next to the record
     unsigned long long pairs = 0, runs = 0;
     const uint64_t part_rows = stripe_count(a.n_nodes, a.part, a.p.parts);
 
@@ -538,9 +567,9 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
                 const uint64_t rec = (t * A) % R;
                 const uint64_t p0 = lo + rec * C;
                 const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
-                train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, alias_lo, cell_n, slice,
-                                                s_key, s_val, s_rows, s_lab, s_tr, lane, grp, q,
-                                                pairs, runs);
+                train_record<CH, WMX, WMC, DET>(a, cell, lo, hi, p0, n, ckey, alias_lo, cell_n,
+                                                slice, s_key, s_val, s_rows, s_lab, s_nb, s_tr,
+                                                lane, grp, q, pairs, runs);
             }
         } else {
             // a ticket = kTicket consecutive visiting-order indices (the stride order spreads
@@ -556,9 +585,9 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
                     const uint64_t rec = (t * A) % R;
                     const uint64_t p0 = lo + rec * C;
                     const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
-                    train_record<CH, WMX, WMC, DET>(a, cell, lo, p0, n, ckey, alias_lo, cell_n,
-                                                    slice, s_key, s_val, s_rows, s_lab, s_tr, lane,
-                                                    grp, q, pairs, runs);
+                    train_record<CH, WMX, WMC, DET>(a, cell, lo, hi, p0, n, ckey, alias_lo,
+                                                    cell_n, slice, s_key, s_val, s_rows, s_lab,
+                                                    s_nb, s_tr, lane, grp, q, pairs, runs);
                 }
             }
         }

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -198,6 +199,9 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     a.walks = io->d_walks;
     a.walk_rows = io->d_walk_rows;
     a.neg_override = io->d_neg_override;
+    a.ctx_delta = cbow ? io->d_context_delta : nullptr;
+    if (io->d_context_delta && (!cbow || (tp->flags & GN2V_TRAIN_DETERMINISTIC)))
+        return fail("d_context_delta is for CBOW in the parallel update modes");
     a.central = io->d_central;
     a.contextual = io->d_contextual;
     float *positive_table = cbow ? io->d_central : io->d_contextual;
@@ -247,7 +251,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
                                 (cbow ? 2 * tp->window + slots : 0) + 2 * slots + 3) &
                                ~(size_t)3;
     const size_t cache_lds = (size_t)waves_per_block * cache_words * 4;
-    const bool use_cache = !det && wm != gn2v::kAtomic && !a.split &&
+    const bool use_cache = !det && wm != gn2v::kAtomic && !a.split && !a.ctx_delta &&
                            !a.walk_rows && !a.neg_pool && !(tp->flags & GN2V_TRAIN_NO_CTX_CACHE) &&
                            cache_lds <= 40 * 1024 && L > 2 * tp->window &&
                            (!cbow || slots <= gn2v::kWinCacheMaxSlots) &&
@@ -408,10 +412,76 @@ int gn2v_graph_create(const uint64_t *row_ptr, const uint32_t *col_idx, const fl
         (void)hipGetLastError();
     }
     *out = g;
+    if (const char *reserve = getenv("GN2V_RESERVE_CUS")) {
+        const int k = atoi(reserve);
+        if (k > 0 && gn2v_graph_reserve_cus(g, (uint32_t)k, nullptr)) {
+            *out = nullptr;
+            gn2v_graph_destroy(g);
+            return 1;
+        }
+    }
     return 0;
 }
 
 int gn2v_graph_xcds(gn2v_graph *g) { return g ? g->n_xcds : 0; }
+
+int gn2v_graph_reserve_cus(gn2v_graph *g, uint32_t cus_per_xcd, uint32_t *active_per_xcd) {
+    if (!g) return fail("graph handle is NULL");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    std::lock_guard<std::mutex> lock(g->mu);
+    HIP_TRY(hipDeviceSynchronize());
+    if (g->train_stream) {
+        (void)hipStreamDestroy(g->train_stream);
+        g->train_stream = nullptr;
+    }
+    g->reserved_cus = 0;
+    if (active_per_xcd) std::memset(active_per_xcd, 0, 16 * sizeof(uint32_t));
+    if (cus_per_xcd == 0) return 0;
+    const uint32_t xcds = g->n_xcds > 0 ? (uint32_t)g->n_xcds : 1u;
+    const uint32_t n_cus = (uint32_t)g->n_cus;
+    if (cus_per_xcd * xcds >= n_cus) return fail("cannot reserve every compute unit");
+    // bit i of the mask = logical CU i; logical CUs are dealt round robin over the XCDs, so the
+    // first cus_per_xcd * xcds bits take cus_per_xcd CUs from each -- checked below, not assumed
+    std::vector<uint32_t> mask((n_cus + 31) / 32, 0u);
+    for (uint32_t i = cus_per_xcd * xcds; i < n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    unsigned int *seen = reinterpret_cast<unsigned int *>(g->cursors);
+    uint32_t host[16 * 8] = {0};
+    hipError_t e = hipMemsetAsync(seen, 0, sizeof(host), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gn2v::cu_probe_kernel, dim3(n_cus * 32), dim3(64), 0, st, seen);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, seen, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(st);
+        return fail(std::string("probing the CU mask failed: ") + hipGetErrorString(e));
+    }
+    const uint32_t want = n_cus / xcds - cus_per_xcd;
+    bool ok = true;
+    for (uint32_t x = 0; x < 16; ++x) {
+        uint32_t active = 0;
+        for (uint32_t w = 0; w < 8; ++w) active += (uint32_t)__builtin_popcount(host[x * 8 + w]);
+        if (active_per_xcd) active_per_xcd[x] = active;
+        if (x < xcds ? active > want || active == 0 : active != 0) ok = false;
+    }
+    if (!ok) {
+        (void)hipStreamDestroy(st);
+        return fail("the CU mask did not leave " + std::to_string(cus_per_xcd) +
+                    " compute unit(s) of every XCD free (logical CU numbering differs from the "
+                    "assumed round robin over the XCDs)");
+    }
+    if (!g->ts_in) {
+        HIP_TRY(hipEventCreateWithFlags(&g->ts_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g->ts_out, hipEventDisableTiming));
+    }
+    g->train_stream = st;
+    g->reserved_cus = cus_per_xcd;
+    return 0;
+}
 
 int gn2v_graph_set_types(gn2v_graph *g, const uint32_t *node_types,
                          const uint32_t *edge_types) {
@@ -462,6 +532,9 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->own_edge_types) (void)hipFree(g->own_edge_types);
     if (g->counters) (void)hipFree(g->counters);
     if (g->cursors) (void)hipFree(g->cursors);
+    if (g->train_stream) (void)hipStreamDestroy(g->train_stream);
+    if (g->ts_in) (void)hipEventDestroy(g->ts_in);
+    if (g->ts_out) (void)hipEventDestroy(g->ts_out);
     for (auto *v : {&g->train_events, &g->walk_events, &g->free_events})
         for (auto &ev : *v) {
             (void)hipEventDestroy(ev.a);

@@ -52,7 +52,7 @@ gn2v::BlockPlan device_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     d.L = p->walk_length;
     d.window = p->window;
     d.min_dist = p->min_dist ? p->min_dist : 1;
-    d.record = p->record ? p->record : 16;
+    d.record = p->record ? p->record : 32;
     const uint64_t rows = (g->view.n_nodes + p->world - 1) / p->world;
     d.row_bits = bits_for(rows);
     // rows of the largest cell: part 0, slice 0
@@ -385,13 +385,15 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     if (wmc == gn2v::kWriteThrough && exclusive)
         wmx = (tp->flags & GN2V_TRAIN_LOCAL_ATOMIC) ? gn2v::kLocalAtomic : gn2v::kWriteBack;
     a.xcds = (uint32_t)g->n_xcds;
+    a.central_atomic = (tp->flags & GN2V_TRAIN_CENTRAL_ATOMIC) ? 1u : 0u;
 
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
     const size_t per_wave_words =
-        ((size_t)tp->ld + 2 * d.record + 2 * (size_t)d.record * (tp->k + 1) + 3) & ~(size_t)3;
+        ((size_t)tp->ld + 2 * d.record + 2 * (size_t)d.record * (tp->k + 1) + 2 + 3) & ~(size_t)3;
     const size_t lds = (size_t)waves_per_block * per_wave_words * 4;
     if (lds > 64 * 1024) return fail("record / negatives too large for the LDS plan");
-    uint64_t blocks = det ? 1 : (uint64_t)g->n_cus * 8;
+    const uint64_t cus = (uint64_t)g->n_cus - (uint64_t)g->reserved_cus * std::max(1, g->n_xcds);
+    uint64_t blocks = det ? 1 : cus * 8;
     if (!det) {
         // at most one concurrent wave per table row on average (staleness of the records of one
         // centre trained from the same copy of its row; binds on tiny graphs only)
@@ -402,6 +404,14 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kTrainBlock);
 
     std::lock_guard<std::mutex> lock(g->mu);
+    // gn2v_graph_reserve_cus: the launch runs on the CU-masked stream, between the caller's
+    // stream's past and future
+    hipStream_t caller = s;
+    if (g->train_stream) {
+        HIP_TRY(hipEventRecord(g->ts_in, caller));
+        HIP_TRY(hipStreamWaitEvent(g->train_stream, g->ts_in, 0));
+        s = g->train_stream;
+    }
     a.cursors = g->cursors + (size_t)(g->cursor_slot++ % kCursorRing) * kCursorWords;
     HIP_TRY(hipMemsetAsync(a.cursors, 0, kCursorWords * sizeof(unsigned long long), s));
     EventPair ev;
@@ -430,6 +440,10 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     HIP_TRY(hipEventRecord(ev.b, s));
     g->train_events.push_back(ev);
     g->train_launches++;
+    if (g->train_stream) {
+        HIP_TRY(hipEventRecord(g->ts_out, s));
+        HIP_TRY(hipStreamWaitEvent(caller, g->ts_out, 0));
+    }
     return 0;
 }
 
@@ -518,7 +532,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     plan.walk_length = L;
     plan.window = w;
     plan.min_dist = tp->min_dist ? tp->min_dist : 1;
-    plan.record = 16;
+    plan.record = 32;
     plan.flags = tp->flags & GN2V_TRAIN_DOWNSAMPLE;
     std::vector<gn2v_block_plan> plans(V, plan);
     for (uint32_t j = 0; j < V; ++j) {

@@ -76,6 +76,11 @@ struct gn2v_graph {
     bool owns = false;
     void *own_row_ptr = nullptr, *own_col_idx = nullptr, *own_cumw = nullptr,
          *own_sources = nullptr, *own_node_types = nullptr, *own_edge_types = nullptr;
+    // gn2v_graph_reserve_cus: the training kernels run on a stream whose CU mask leaves some CUs
+    // of every XCD to other work (RCCL's transfer kernels); nullptr: the caller's stream
+    hipStream_t train_stream = nullptr;
+    hipEvent_t ts_in = nullptr, ts_out = nullptr;
+    uint32_t reserved_cus = 0;
     unsigned long long *counters = nullptr;  // device, 4 x u64
     unsigned long long *cursors = nullptr;   // device, ring of record-ticket arrays (block trainer)
     uint32_t cursor_slot = 0;

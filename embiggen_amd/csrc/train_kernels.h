@@ -27,6 +27,7 @@ struct TrainArgs {
     const uint32_t *walks;      // global node ids [n_walks][L]
     const uint32_t *walk_rows;  // row of every walk node in central/contextual, or nullptr (= id)
     const uint32_t *neg_override;
+    float *ctx_delta;           // CBOW: add the contexts' gradients here instead of to `contextual`
     float *central;
     float *contextual;
     float *negative;            // table the negative rows live in (== contextual / central when
@@ -855,6 +856,17 @@ __global__ __launch_bounds__(kTrainBlock) void cbow_kernel(TrainArgs a) {
                     load_row<CH>(v, base, q, nchunks, true);
                     if (grp == 0) scatter_add<CH, kWriteBack>(base, q, nchunks, invC, g, v);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                }
+            } else if (a.ctx_delta) {
+                // batch form: contextual is read-only in this launch, the gradients are summed
+                // (exactly: hardware atomics) in the delta table
+                Row<CH> gc = g;
+                if constexpr (WM != kAtomic) to_contig_layout<CH>(gc, g, s_tr, grp, q, a.ld);
+                for (uint32_t r0 = 0; r0 < n_ctx; r0 += 4) {
+                    const uint32_t rank = r0 + grp;
+                    if (rank < n_ctx)
+                        scatter_add<CH, kAtomic>(a.ctx_delta + (uint64_t)s_ctx[rank] * a.ld, q,
+                                                 nchunks, invC, gc, gc);
                 }
             } else {
                 // context node ids of this centre were staged behind the sample list

@@ -11,6 +11,20 @@ static __global__ void xcc_probe_kernel(unsigned int *mask) {
     if (threadIdx.x == 0) atomicOr(mask, 1u << xcc_id());
 }
 
+// seen[xcc * 8 + word] |= bit of the physical CU (SE, SH, CU id inside the XCD) this workgroup
+// runs on; the short sleep keeps the first CUs from draining the whole grid before the others
+// get their share.  gn2v_graph_reserve_cus reads back which CUs a masked stream really uses.
+static __global__ void cu_probe_kernel(unsigned int *seen) {
+    if (threadIdx.x == 0) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const uint32_t cu = (hw >> 8) & 0xF, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;
+        const uint32_t id = (se << 5) | (sh << 4) | cu;  // < 256
+        atomicOr(&seen[xcc_id() * 8 + (id >> 5)], 1u << (id & 31));
+    }
+    for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // table[r][c] = (2*u24 - 1) * scale with u24 from draw(key, r*d + c); padding columns are zero.
 __global__ void init_kernel(float *__restrict__ t, uint64_t n_rows, uint32_t d, uint32_t ld,
                             uint64_t key, float scale) {

@@ -305,7 +305,7 @@ class BlockPartitionedTrainer:
     def __init__(self, graph, train_params, d: int, ld: int, seed: int, init_scale: float, comm,
                  device, walk_length: int, window: int, min_dist: int = 1,
                  scale_free: bool = True, backend=None, parts: Optional[int] = None,
-                 slices: Optional[int] = None, record: int = 16, hot_band=(0, 0),
+                 slices: Optional[int] = None, record: int = 32, hot_band=(0, 0),
                  stripes: int = 1, group_parts: Optional[int] = None):
         """``group_parts``: the parts whose pairs are extracted, sorted and held at a time (None:
         all of a round at once; ``models.fit_transform_blocks`` and ``bench.py`` take it from

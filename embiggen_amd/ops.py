@@ -132,7 +132,7 @@ def init_table_rows(n_rows: int, d: int, seed: int, table_id: int, scale: float,
 
 # ------------------------------------------------------------- block-partitioned SkipGram
 def block_plan(graph: CSRGraph, world: int, rank: int, parts: int, slices: int, walk_length: int,
-               window: int, min_dist: int = 1, record: int = 16, flags: int = 0, device: int = 0,
+               window: int, min_dist: int = 1, record: int = 32, flags: int = 0, device: int = 0,
                hot_lo: int = 0, hot_hi: int = 0):
     """A validated ``gn2v_block_plan`` (row_bits filled in by the library).  ``hot_lo`` /
     ``hot_hi``: contextual rows whose share of their cell's edge endpoints lies in
@@ -238,6 +238,18 @@ def block_step(graph: CSRGraph, tp, plan, pairs, cell_offsets, alias, cell_rows,
                                           seed, epoch, lr, _stream(dev)))
 
 
+def graph_reserve_cus(graph: CSRGraph, cus_per_xcd: int, device: int = 0):
+    """Leave ``cus_per_xcd`` CUs of every XCD to other work (RCCL): the training kernels of this
+    graph then run on a CU-masked stream (``gn2v_graph_reserve_cus``).  Returns the CUs each XCD
+    runs workgroups on under the mask, as verified by a probe launch; 0 switches it off."""
+    import numpy as np
+
+    active = np.zeros(16, dtype=np.uint32)
+    _lib.check(_lib.lib().gn2v_graph_reserve_cus(graph.device_graph(device).handle, cus_per_xcd,
+                                                 active.ctypes.data))
+    return [int(v) for v in active if v]
+
+
 def graph_xcds(graph: CSRGraph, device: int = 0) -> int:
     """XCDs (one L2 each) the device's workgroups are spread over (8 on an MI355X; 0 unknown)."""
     return _lib.lib().gn2v_graph_xcds(graph.device_graph(device).handle)
@@ -272,20 +284,21 @@ def cbow_step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, con
 
 def step(graph, tp, walks_tensor, seed, epoch, first_walk, lr, central, contextual,
          walk_rows=None, negative=None, neg_pool=None, neg_id_mul: int = 0, neg_id_add: int = 0,
-         neg_override=None):
+         neg_override=None, context_delta=None):
     """General training step (``gn2v_step``): ``walk_rows`` gives the row of every walk node in
     ``central`` / ``contextual`` (compact row caches), negatives are rows of ``negative`` drawn
     from ``neg_pool``.  ``tp.model`` selects SkipGram / CBOW."""
     dev = central.device
     dg = graph.device_graph(dev.index or 0)
     n_walks, L = walks_tensor.shape
-    tensors = [walks_tensor, central, contextual, walk_rows, negative, neg_pool, neg_override]
+    tensors = [walks_tensor, central, contextual, walk_rows, negative, neg_pool, neg_override,
+               context_delta]
     assert all(t is None or t.is_contiguous() for t in tensors)
     assert central.shape[1] == tp.ld and contextual.shape[1] == tp.ld
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     io = _lib.StepIO(ptr(walks_tensor), ptr(walk_rows), ptr(central), ptr(contextual),
                      ptr(negative), ptr(neg_pool), 0 if neg_pool is None else neg_pool.numel(),
-                     neg_id_mul, neg_id_add, ptr(neg_override))
+                     neg_id_mul, neg_id_add, ptr(neg_override), ptr(context_delta))
     _lib.check(_lib.lib().gn2v_step(dg.handle, C.byref(tp), C.byref(io), n_walks, L, seed, epoch,
                                     first_walk, lr, _stream(dev)))
 

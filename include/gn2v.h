@@ -66,6 +66,12 @@ extern "C" {
 #define GN2V_TRAIN_BLOCK_PATH 2048u   /* always the block path (SkipGram; with
                                          GN2V_TRAIN_DETERMINISTIC: its sequential schedule)      */
 
+/* Block path: the gradient of a run of equal centre is added to the central row with hardware
+ * atomics when the centre spans records (hubs) and with one write-through store of row +
+ * gradient when the run is the centre's only one in its cell (no other wave of the XCD names the
+ * row; an atomic row add costs ~5 stored rows).  This bit: atomics for every run. */
+#define GN2V_TRAIN_CENTRAL_ATOMIC 4096u
+
 #define GN2V_MODEL_SKIPGRAM 0u
 #define GN2V_MODEL_CBOW 1u
 
@@ -200,6 +206,11 @@ typedef struct {
     uint32_t neg_id_mul;         /* global id of negative row r = r * mul + add (0, 0 = identity), */
     uint32_t neg_id_add;         /*   used to skip negatives equal to the centre / context       */
     const uint32_t *d_neg_override;
+    float *d_context_delta;      /* optional, CBOW: the input-side gradient of every centre is
+                                    ADDED (f32 atomics) to this table f32[rows][ld] instead of
+                                    being applied to d_contextual, which is then only read during
+                                    the launch: the caller applies the sum later (the batch form a
+                                    CBOW spread over several GPUs needs: DESIGN.md 8)             */
 } gn2v_step_io;
 
 int gn2v_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_step_io *io,
@@ -238,7 +249,7 @@ typedef struct {
     uint32_t walk_length;
     uint32_t window;      /* window_size                                                      */
     uint32_t min_dist;    /* 0 = 1 (Walklets: = window)                                       */
-    uint32_t record;      /* consecutive sorted pairs a wavefront takes at a time; 0 = 16     */
+    uint32_t record;      /* consecutive sorted pairs a wavefront takes at a time; 0 = 32     */
     uint32_t row_bits;    /* out (gn2v_block_plan_check): bits of the centre row in a pair word */
     uint32_t flags;       /* GN2V_TRAIN_DOWNSAMPLE: centres thinned while pairs are extracted */
     /* Hot rows (off by default, both 0): contextual rows whose share of their cell's edge
@@ -330,6 +341,16 @@ typedef struct {
 int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
                     const gn2v_block_io *io, uint64_t seed, uint64_t epoch, float lr,
                     void *stream);
+
+/* Leave `cus_per_xcd` compute units of every XCD to other work: from now on the training kernels
+ * of this handle (gn2v_block_step, gn2v_sgns_step, ...) run on a stream of the library's own
+ * created with hipExtStreamCreateWithCUMask, ordered after the caller's stream at entry and before
+ * it at exit (two events per call).  For multi-GPU jobs: the training kernel's workgroups stay
+ * resident for a whole launch, and RCCL's transfer kernels must find a CU.  The
+ * mask is verified by a probe launch: active_per_xcd (u32[16], optional) receives the CUs each
+ * XCD really runs workgroups on.  0 = back to the caller's stream.  Also set at graph creation
+ * from the environment variable GN2V_RESERVE_CUS. */
+int gn2v_graph_reserve_cus(gn2v_graph *g, uint32_t cus_per_xcd, uint32_t *active_per_xcd);
 
 /* XCDs (accelerator complexes, one L2 each) the workgroups of this graph's device are spread
  * over, found by a probe launch in gn2v_graph_create: 8 on an MI355X; 0 = unknown. */

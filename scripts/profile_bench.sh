@@ -9,7 +9,12 @@ ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 8 --warmup 8 --no-cpu-baseline $*"  # whole rounds of 2^23 walks in both phases
+# the driver's own command line (bench.py's defaults: --steps 20 --warmup 5) unless the caller
+# names other step counts; the summary works on totals over all launches, whatever their sizes
+case " $* " in
+  *" --steps "*) ARGS="--no-cpu-baseline $*" ;;
+  *) ARGS="--steps 20 --warmup 5 --no-cpu-baseline $*" ;;
+esac
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOTDIR/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$ROOTDIR/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python3 "$ROOTDIR/bench.py" $ARGS > "$OUT/write.log" 2>&1

@@ -78,13 +78,16 @@ def main(tag):
     mean = lambda v: sum(v) / len(v)  # noqa: E731
     fetch_factor = cal["read_bytes_per_launch"] / (mean(cf) * 1024)
     write_factor = cal["write_bytes_per_launch"] / (mean(cw) * 1024)
-    raw_f, raw_w = mean(f_vals) * 1024, mean(w_vals) * 1024
+    # Totals over ALL launches of the run (warm-up and timed steps alike: their launches differ
+    # in size when the steps do not fill whole rounds), divided by the launches: per-launch means
+    # whose ratio is the ratio of the totals.
+    n_calls = int(sg["Calls"])
+    raw_f, raw_w = sum(f_vals) * 1024 / n_calls, sum(w_vals) * 1024 / n_calls
     read_b, write_b = raw_f * fetch_factor, raw_w * write_factor
-    # the bench line counts one launch per training call; the block trainer's call is the main
-    # kernel plus a (normally empty) sweep launch, so scale by the calls rocprof saw
-    calls_ratio = bench["roofline"]["launches"] / max(1, int(sg["Calls"]) * bench["steps"]
-                                                        / (bench["steps"] + bench["warmup"]))
-    alg = bench["roofline"]["algorithmic_bytes_per_launch"] * calls_ratio
+    # algorithmic bytes of the whole run: every step of both phases trains walks x pairs per walk
+    # (the bench line holds the timed phase: bytes per launch x launches)
+    timed_alg = bench["roofline"]["algorithmic_bytes_per_launch"] * bench["roofline"]["launches"]
+    alg = timed_alg * (bench["steps"] + bench["warmup"]) / bench["steps"] / n_calls
     pairs_per_launch = alg / BYTES_PER_PAIR
     out = {
         "tag": tag,
@@ -97,8 +100,8 @@ def main(tag):
         "algorithmic_bytes_per_launch": alg,
         "algorithmic_GBps": alg / (avg_ms * 1e-3) / 1e9,
         "frac_of_8TBps": alg / (avg_ms * 1e-3) / 8e12,
-        "FETCH_SIZE_KiB_per_launch": mean(f_vals),
-        "WRITE_SIZE_KiB_per_launch": mean(w_vals),
+        "FETCH_SIZE_KiB_per_launch": raw_f / 1024,
+        "WRITE_SIZE_KiB_per_launch": raw_w / 1024,
         "calibration": {
             "kernel": "gn2v::touch_rows_kernel",
             "known_read_bytes": cal["read_bytes_per_launch"],
@@ -128,7 +131,7 @@ def main(tag):
         f.write(f"\n`{sg['Name'].split('(')[0].replace('void ', '')}`: {units}, {avg_ms:.2f} ms (rocprof) vs "
                 f"{bench['roofline']['avg_launch_ms']:.2f} ms (HIP events in bench.py) -> "
                 f"{out['algorithmic_GBps']:.0f} GB/s algorithmic = {out['frac_of_8TBps']:.3f} of 8 TB/s.\n\n")
-        f.write(f"PMC (separate passes): FETCH_SIZE {mean(f_vals):.0f} KiB, WRITE_SIZE {mean(w_vals):.0f} KiB per launch; "
+        f.write(f"PMC (separate passes): FETCH_SIZE {raw_f / 1024:.0f} KiB, WRITE_SIZE {raw_w / 1024:.0f} KiB per launch (mean over all {n_calls} launches); "
                 f"calibration on `touch_rows_kernel` (known bytes): fetch x{fetch_factor:.3f}, write x{write_factor:.3f} -> "
                 f"HBM traffic {out['hbm_traffic_bytes_per_launch'] / 1e9:.1f} GB per launch = {out['hbm_traffic_GBps']:.0f} GB/s "
                 f"({out['traffic_over_algorithmic']:.3f} x the algorithmic bytes).\n")

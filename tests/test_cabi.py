@@ -46,6 +46,7 @@ def test_struct_layouts_match_header():
                         ("GN2V_TRAIN_LOCAL_ATOMIC", _lib.TRAIN_LOCAL_ATOMIC),
                         ("GN2V_TRAIN_WALK_ORDERED", _lib.TRAIN_WALK_ORDERED),
                         ("GN2V_TRAIN_BLOCK_PATH", _lib.TRAIN_BLOCK_PATH),
+                        ("GN2V_TRAIN_CENTRAL_ATOMIC", _lib.TRAIN_CENTRAL_ATOMIC),
                         ("GN2V_GRAPH_DEVICE_PTRS", _lib.GRAPH_DEVICE_PTRS),
                         ("GN2V_GRAPH_SYMMETRIC", _lib.GRAPH_SYMMETRIC)):
         assert re.search(rf"#define {name} +{value}u", text), name

@@ -886,13 +886,29 @@ def test_negatives_keep_their_degree_proportional_law_through_the_cells():
     indeg = np.bincount(g.col_idx, minlength=n).astype(np.float64)
     node = np.arange(n)
     cell = (node % tr.parts) * tr.slices + (node // tr.parts) % tr.slices
-    # inside a cell: chi-square of the counts against in-degree / cell total (hubs one by one,
-    # the tail pooled by degree so that every bin expects >= 50 draws)
+    # A negative equal to the pair's context or centre is skipped (oracle and kernel alike), so
+    # node x of cell c is offered to every pair of the cell but those whose context is x
+    # (pos[x]) or whose centre is x (centre and context in the same cell).
+    cell_t = torch.from_numpy(cell).cuda()
+    wl = wk.long()
+    own = torch.zeros(n, dtype=torch.long, device="cuda")  # pairs whose centre is x, in x's cell
+    for off in range(1, w + 1):
+        a, b = wl[:, :-off].flatten(), wl[:, off:].flatten()
+        same = cell_t[a] == cell_t[b]
+        own.index_add_(0, a[same], torch.ones_like(a[same]))
+        own.index_add_(0, b[same], torch.ones_like(b[same]))
+    pairs_in_cell = np.bincount(cell, weights=pos.cpu().numpy(), minlength=tr.parts * tr.slices)
+    offered = pairs_in_cell[cell] - pos.cpu().numpy() - own.cpu().numpy()
+    assert offered.min() > 0
+    # inside a cell: chi-square of the counts against in-degree / cell total x the pairs that
+    # offered the node (hubs one by one, the tail pooled so that every bin expects >= 50 draws)
     pvals = []
     for c in (0, 7, 13, 23):
         rows = np.nonzero(cell == c)[0]
         order = rows[np.argsort(-indeg[rows])]
-        obs, exp = neg[order].astype(np.float64), indeg[order] / indeg[order].sum() * neg[order].sum()
+        obs = neg[order].astype(np.float64)
+        exp = k * indeg[order] / indeg[order].sum() * offered[order]
+        assert abs(obs.sum() / exp.sum() - 1) < 2e-3  # the absolute number of draws, too
         head = 300
         groups = np.array_split(np.arange(head, len(order)), 50)
         o = np.concatenate([obs[:head], [obs[i].sum() for i in groups]])
@@ -906,3 +922,27 @@ def test_negatives_keep_their_degree_proportional_law_through_the_cells():
     got = np.array([neg[i].sum() for i in classes]) / neg.sum()
     want = np.array([indeg[i].sum() for i in classes]) / indeg.sum()
     assert np.abs(got / want - 1).max() < 0.05, (got / want)
+
+
+def test_training_on_a_cu_masked_stream_leaves_cus_free_and_changes_nothing():
+    """gn2v_graph_reserve_cus: one CU of every XCD is left to other work (a probe launch on the
+    masked stream confirms 31 of 32 active per XCD), the block step then runs on that stream
+    between the caller's stream's past and future -- same result in the deterministic schedule,
+    every pair trained in the parallel one."""
+    g = _ba(203)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    base = _step_both(g, og, D, K, 1, 0, 2, 8, 4, DET)
+    try:
+        active = ops.graph_reserve_cus(g, 1)
+        assert len(active) == 8 and all(a == 31 for a in active), active
+        masked = _step_both(g, og, D, K, 1, 0, 2, 8, 4, DET)
+        assert np.array_equal(base[0], masked[0])
+        for x, y in zip(base[1], masked[1]):
+            assert np.array_equal(x, y)
+        _step_both(g, og, D, K, 1, 0, 2, 8, 4, 0)  # parallel flavour: the pair count is asserted
+        with pytest.raises(_lib.Gn2vError, match="every compute unit"):
+            ops.graph_reserve_cus(g, 32)
+    finally:
+        assert ops.graph_reserve_cus(g, 0) == []
+    again = _step_both(g, og, D, K, 1, 0, 2, 8, 4, DET)
+    assert np.array_equal(base[0], again[0])
