@@ -36,6 +36,16 @@ constexpr int kPrepBlock = 256;
 constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
 constexpr uint32_t kMaxCells = 8192;    // parts x slices (100 M nodes: 381 x 8 cells of 32 k rows)
 constexpr uint32_t kMaxRecord = 32;
+// A run -- consecutive pairs of one centre inside a record, trained against ONE copy of the central
+// row, their gradients summed -- is at most this long; a longer stretch of equal centres is cut
+// into several runs, each starting from the row the previous one left.  (A run is a mini-batch on
+// the centre's row: 32 pairs x (1 + k) samples summed at one stale value overshoot when a small
+// graph fills every record with one centre -- link AUROC 0.985 -> 0.93 with 8 centre stripes on
+// BA 200 k.)
+#ifndef GN2V_MAX_RUN
+#define GN2V_MAX_RUN 16
+#endif
+constexpr uint32_t kMaxRun = GN2V_MAX_RUN;
 constexpr uint32_t kCursorStep = 64;  // u64 words between the ticket cursors of two slices
 constexpr uint32_t kTicket = 4;       // records a wave takes per ticket (one returning atomic)
 // "Hot" contextual rows (share of the cell's edge endpoints inside the plan's band; off by
@@ -454,7 +464,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
     while (r0 < n) {
         const uint32_t crow_id = s_key[r0];
         uint32_t r1 = r0 + 1;
-        while (r1 < n && s_key[r1] == crow_id) ++r1;
+        while (r1 < n && r1 - r0 < kMaxRun && s_key[r1] == crow_id) ++r1;
         float lrc = a.lr;
         if (a.flags & kFlagNormLr) {
             const uint64_t c = (uint64_t)crow_id * a.p.world + a.p.rank;
@@ -491,10 +501,23 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         // ~1 - 1e-4.  A centre that spans records (hubs: thousands of consecutive records that many
         // waves train at once) gets its gradient added with hardware f32 atomics: no add is lost.
         // An atomic row add costs ~5 stored rows (128 dword atomics through the L2 atomic units).
+        if constexpr (!DET) {
+            // the next run continues this centre (a stretch cut at kMaxRun): its row was fetched
+            // before this run's gradient existed
+            if (r1 < n && s_key[r1] == crow_id) {
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) {
+                    u_next.c[cc].x = u.c[cc].x + g.c[cc].x;
+                    u_next.c[cc].y = u.c[cc].y + g.c[cc].y;
+                    u_next.c[cc].z = u.c[cc].z + g.c[cc].z;
+                    u_next.c[cc].w = u.c[cc].w + g.c[cc].w;
+                }
+            }
+        }
         bool alone = false;
         if constexpr (!DET && WMC == kAtomic)
-            alone = !a.central_atomic && (r0 > 0 || s_nb[0] != crow_id) &&
-                    (r1 < n || s_nb[1] != crow_id);
+            alone = !a.central_atomic && (r0 > 0 ? s_key[r0 - 1] != crow_id : s_nb[0] != crow_id) &&
+                    (r1 < n ? s_key[r1] != crow_id : s_nb[1] != crow_id);
         if constexpr (!DET && WMC == kAtomic) {
             if (alone) {
                 if (grp == 0) scatter_add<CH, kWriteThrough>(crow, q, nchunks, 1.0f, g, u);
@@ -574,6 +597,13 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
         } else {
             // a ticket = kTicket consecutive visiting-order indices (the stride order spreads
             // them over the cell); one returning atomic per ticket on the cell's own cursor line
+            // Every cell starts its stride order somewhere else (an offset drawn from the cell's
+            // key).  The cells of a part hold the same centres in the same (sorted) order and
+            // their XCDs advance at the same pace: without the offset all eight would work on
+            // the same centre rows at the same moment, all launch long -- the one situation in
+            // which the single-run store of train_record loses updates (and in which the atomic
+            // adds of a hub centre queue up behind one another).
+            const uint64_t start = mulhi64(ckey, R);
             unsigned long long *cursor = a.cursors + (size_t)slice * kCursorStep;
             for (;;) {
                 unsigned long long t = 0;
@@ -582,7 +612,7 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
                 if (t >= R) break;
                 const uint64_t t_end = min(t + kTicket, (unsigned long long)R);
                 for (; t < t_end; ++t) {
-                    const uint64_t rec = (t * A) % R;
+                    const uint64_t rec = (t * A + start) % R;
                     const uint64_t p0 = lo + rec * C;
                     const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
                     train_record<CH, WMX, WMC, DET>(a, cell, lo, hi, p0, n, ckey, alias_lo,

@@ -1023,8 +1023,11 @@ __device__ __forceinline__ void win_retire(WinCache &c, float *table, uint32_t p
 // mean AND read-modify-writes for the gradient (30 of the 52 row transfers of a centre); with the
 // cache they cost one read and one write-back per walk position.  Centre + negatives live in the
 // central table, which the cache never holds, so only the context list needs directory lookups.
+#ifndef GN2V_CBOW_MIN_BLOCKS
+#define GN2V_CBOW_MIN_BLOCKS 1  // occupancy experiments: 4 caps the kernel at 128 VGPRs
+#endif
 template <int CH, int WM>
-__global__ __launch_bounds__(kTrainBlock) void cbow_cached_kernel(TrainArgs a) {
+__global__ __launch_bounds__(kTrainBlock, GN2V_CBOW_MIN_BLOCKS) void cbow_cached_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;

@@ -921,7 +921,7 @@ double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *log
  * sorts them stably on the bits above ctx_bits, and trains one part at a time:
  * per cell, implicit records of `record` consecutive sorted pairs visited in the stride order
  * rec(t) = t * A mod R (A ~ R / golden ratio, coprime with R); inside a record every run of equal
- * centre is one "centre" of Semantic S (copy of the central row, samples [context, k negatives]
+ * centre (at most O_MAX_RUN pairs) is one "centre" of Semantic S (copy of the central row, samples [context, k negatives]
  * applied one after the other, gradient added at the end of the run).  Negative n of the pair at
  * position p of its cell: a row of the cell, degree-proportional through the cell's alias table
  * (or uniform), picked by draw(cell_key, p * k + n), cell_key = draw(mix64(epoch_key ^ TAG_BLOCK), block_id * O_MAX_CELLS + cell);
@@ -929,6 +929,7 @@ double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *log
 
 #define O_TAG_BLOCK 0xB10C5EED0B10C5EDULL
 #define O_MAX_CELLS 8192ULL /* parts x slices of a plan, at most */
+#define O_MAX_RUN 16u       /* pairs trained against one copy of the central row, at most */
 
 typedef struct {
     uint32_t world, rank, parts, slices;
@@ -1165,7 +1166,10 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
             uint32_t r0 = 0;
             while (r0 < n) {
                 uint32_t crow = (uint32_t)((words[p0 + r0] >> p->ctx_bits) & rowmask), r1 = r0 + 1;
-                while (r1 < n && (uint32_t)((words[p0 + r1] >> p->ctx_bits) & rowmask) == crow) ++r1;
+                /* a run is at most O_MAX_RUN pairs: a longer stretch of one centre is several runs */
+                while (r1 < n && r1 - r0 < O_MAX_RUN &&
+                       (uint32_t)((words[p0 + r1] >> p->ctx_bits) & rowmask) == crow)
+                    ++r1;
                 uint64_t cgid = (uint64_t)crow * p->world + p->rank;
                 float lrc = centre_lr(g, tp, lr, (uint32_t)cgid);
                 float *cptr = central + (uint64_t)crow * ld;

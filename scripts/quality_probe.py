@@ -56,6 +56,9 @@ if __name__ == "__main__":
     ap.add_argument("--hot-band", default="0:0", help="blocks modes: lo:hi (see bench.py)")
     ap.add_argument("--round-walks", type=int, default=1 << 19, help="blocks modes: walks per round")
     ap.add_argument("--stripes", type=int, default=1, help="blocks modes: centre stripes")
+    ap.add_argument("--central-atomic", action="store_true",
+                    help="blocks modes: every central row update by atomics")
+    ap.add_argument("--group-parts", type=int, default=0, help="blocks modes: parts per group")
     a = ap.parse_args()
     g = E.barabasi_albert(a.nodes, a.m, 42)
     n, d = g.get_number_of_nodes(), a.d
@@ -71,14 +74,16 @@ if __name__ == "__main__":
 
             f = mode.split(":")
             parts, slices = int(f[1]), int(f[2])
-            record = int(f[3]) if len(f) > 3 and f[3] else 16
+            record = int(f[3]) if len(f) > 3 and f[3] else 32
             extra = _lib.TRAIN_LOCAL_ATOMIC if len(f) > 4 and f[4] == "la" else 0
+            if a.central_atomic:
+                extra |= _lib.TRAIN_CENTRAL_ATOMIC
             tp = ops.train_params(0, d, 10, 5, flags=1 | extra, ld=d)
             tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
                                          walk_length=128, window=5, parts=parts, slices=slices,
                                          record=record,
                                          hot_band=tuple(int(v) for v in a.hot_band.split(":")),
-                                         stripes=a.stripes)
+                                         stripes=a.stripes, group_parts=a.group_parts or None)
             ops.stats_reset(g)
             t0 = time.time()
             lr, rounds = a.lr, []

@@ -946,3 +946,40 @@ def test_training_on_a_cu_masked_stream_leaves_cus_free_and_changes_nothing():
         assert ops.graph_reserve_cus(g, 0) == []
     again = _step_both(g, og, D, K, 1, 0, 2, 8, 4, DET)
     assert np.array_equal(base[0], again[0])
+
+
+@pytest.mark.parametrize("flags", [DET, 0, _lib.TRAIN_CENTRAL_ATOMIC])
+def test_long_stretches_of_one_centre_are_cut_into_runs_of_sixteen(flags):
+    """Records of 32 pairs, every record filled by ONE centre (unique context rows, k = 0): the
+    stretch is trained as two runs of 16 -- the second starts from the row the first left (in the
+    parallel schedule: row + gradient kept in registers, the add to memory still in flight) --
+    exactly as the oracle restates it; deterministic and parallel flavours alike."""
+    n_nodes, slices, record, d = 8 * 32_768, 8, 32, 64
+    g = _ba(n_nodes)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    plan = ops.block_plan(g, 1, 0, 1, slices, 8, 2, 1, record)
+    oplan = O.block_plan(n_nodes, 1, 0, 1, slices, 8, 2, 1, record)
+    rng = np.random.RandomState(2)
+    words_l, offsets, centre = [], [0], 0
+    for cell in range(slices):
+        ctx = rng.permutation(np.arange(cell, n_nodes, slices))[:40 * record]
+        centres = centre + np.repeat(np.arange(40), record)  # 40 records, one centre each
+        centre += 40
+        words_l.append(O.block_pack(np.full(len(ctx), cell), centres, ctx, oplan))
+        offsets.append(offsets[-1] + len(ctx))
+    words_h = np.concatenate(words_l)
+    off_h = np.asarray(offsets, dtype=np.uint64)
+    pairs, offs = _dev_words(words_h), torch.from_numpy(off_h.astype(np.int64)).cuda()
+    tp = ops.train_params(0, d, 0, 2, flags=flags, ld=d)
+    otp = O.TrainParams(0, d, d, 1, 0, 2, 0.01, 0.9, 6.0, 0, d ** -0.5)
+    c = ops.init_table(n_nodes, d, 5, 0, 0.5)
+    x = ops.init_table(n_nodes, d, 5, 1, 0.5)
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    lr = 0.2  # large: the second run must see what the first did to the row
+    ops.block_step(g, tp, plan, pairs, offs, None, None, c, x, 0, 0, 5, 0, lr)
+    O.block_step(og, otp, oplan, words_h, off_h, None, None, c_h, x_h, 0, 0, 5, 0, lr)
+    torch.cuda.synchronize()
+    assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5 and np.abs(x.cpu().numpy() - x_h).max() < 2e-5
+    # one run of 32 would end elsewhere: the oracle with the cut undone is measurably different
+    moved = np.abs(c_h[:320] - ops.init_table(n_nodes, d, 5, 0, 0.5).cpu().numpy()[:320]).max()
+    assert moved > 0.05
