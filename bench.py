@@ -556,7 +556,7 @@ def main():
             sched_bytes = row_bytes * (st["pairs"] * 11 + st["centres"])
         scheduled = sched_bytes / (st["train_ms"] * 1e-3) / 1e9
         if cbow:
-            kernel = "gn2v::cbow_cached_kernel" if n >= (1 << 16) else "gn2v::cbow_kernel"
+            kernel = "gn2v::cbow_lazy_kernel" if n >= (1 << 16) else "gn2v::cbow_kernel"
         elif blocks is not None:
             kernel = "gn2v::sgns_block_kernel"
         elif n >= (1 << 16) and args.mode in ("auto", "write_through", "write_back"):

@@ -17,6 +17,7 @@
 #include "edge_kernels.h"
 #include "glove_kernels.h"
 #include "train_kernels.h"
+#include "cbow_lazy_kernel.h"
 #include "util_kernels.h"
 #include "walk_kernels.h"
 
@@ -256,6 +257,14 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
                            cache_lds <= 40 * 1024 && L > 2 * tp->window &&
                            (!cbow || slots <= gn2v::kWinCacheMaxSlots) &&
                            g->view.n_nodes < (1ULL << 30);  // row ids share a word with kCacheBit
+    // CBOW, ordinary windows: the lazy form of the window cache (cbow_lazy_kernel.h)
+    const size_t lazy_words = ((size_t)(slots + 2) * tp->ld + L + 2 * (size_t)a.max_samples +
+                               2 * tp->window + 3 * slots + 3) &
+                              ~(size_t)3;
+    const size_t lazy_lds = (size_t)waves_per_block * lazy_words * 4;
+    const char *lazy_env = getenv("GN2V_CBOW_LAZY");
+    const bool use_lazy = use_cache && cbow && a.min_dist == 1 && lazy_lds <= 40 * 1024 &&
+                          !(lazy_env && lazy_env[0] == '0');
     if (use_cache) {
         if (tp->flags & GN2V_TRAIN_CTX_CACHE_ALL) {
             a.cache_max_degree = 0xFFFFFFFFu;
@@ -276,7 +285,13 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     if (use_cache) {
 #define GN2V_CACHED(CH)                                                                        \
     do {                                                                                       \
-        if (cbow && wm == gn2v::kWriteBack)                                                    \
+        if (use_lazy && wm == gn2v::kWriteBack)                                                \
+            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteBack>), grid, block,    \
+                               lazy_lds, s, a);                                                \
+        else if (use_lazy)                                                                     \
+            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteThrough>), grid, block, \
+                               lazy_lds, s, a);                                                \
+        else if (cbow && wm == gn2v::kWriteBack)                                               \
             hipLaunchKernelGGL((gn2v::cbow_cached_kernel<CH, gn2v::kWriteBack>), grid, block,  \
                                cache_lds, s, a);                                               \
         else if (cbow)                                                                         \

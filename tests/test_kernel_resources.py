@@ -45,6 +45,9 @@ def test_walk_ordered_kernels_keep_their_occupancy(tmp_path):
     # cbow_cached_kernel<CH = 2, write-through / write-back>: 4 waves per SIMD, no scratch
     for name, r in pick(table, "cbow_cached_kernelILi2E").items():
         assert r["vgprs"] <= 128 and r["waves"] >= 4 and r["scratch"] == 0, (name, r)
+    # cbow_lazy_kernel (the CBOW default): capped at 4 waves per SIMD, at most a handful of spills
+    for name, r in pick(table, "cbow_lazy_kernelILi2E").items():
+        assert r["vgprs"] <= 128 and r["waves"] >= 4 and r["scratch"] <= 32, (name, r)
     for name, r in pick(table, "sgns_cached_kernelILi2E").items():
         assert r["vgprs"] <= 102 and r["waves"] >= 5 and r["scratch"] == 0, (name, r)
     # the training kernels never spill at CH <= 8 (d <= 512)
