@@ -31,6 +31,23 @@
 
 namespace gn2v {
 
+// A/B: -DGN2V_BLOCK_SERIALISE keeps the per-round duplicate analysis in the parallel schedule
+template <int CH, int WM, bool HUB, class Args>
+__device__ __forceinline__ void score_samples_checked(const Args &a, float *table,
+                                                      const Row<CH> &u, const Row<CH> &u_upd,
+                                                      Row<CH> &g, const uint32_t *s_rows,
+                                                      const float *s_lab, uint32_t n_samples,
+                                                      float lrc, int grp, int q,
+                                                      const Row<CH> *u_hub) {
+    score_samples<CH, WM, false, HUB>(a, table, u, u_upd, g, s_rows, s_lab, n_samples, lrc, grp, q,
+                                      u_hub);
+}
+#ifdef GN2V_BLOCK_SERIALISE
+#define GN2V_BLOCK_SCORE score_samples_checked
+#else
+#define GN2V_BLOCK_SCORE score_samples_racy
+#endif
+
 constexpr uint64_t kTagBlock = 0xB10C5EED0B10C5EDULL;
 constexpr int kPrepBlock = 256;
 constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
@@ -454,6 +471,78 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         s_lab[t] = lab;
     }
     wave_sync();
+    // Records of (almost) only single-pair runs -- the rule at 100 M nodes, where a round holds
+    // 1.1 pairs per (cell, centre) -- are trained PAIR PER GROUP: each 16-lane group owns one pair
+    // at a time (its central row, its gradient, its k + 1 sample rows one after the other), four
+    // pairs side by side in one instruction stream.  Same four rows in flight per wave, but the
+    // per-run work (row fetch, gradient hand-over, bookkeeping) is issued once for four pairs and
+    // the reduction over the groups disappears: the kernel is issue bound as much as bandwidth
+    // bound (SIMDs busy 77 % of the time).  A pair whose neighbours share its centre adds its
+    // gradient with atomics (several groups, or waves, hold that row), a lone pair stores row +
+    // gradient.  Runs proper (the bench graph: 3.4 pairs) keep the run-major loop below: there a
+    // group-private centre would re-read the central row per pair.
+#ifndef GN2V_BLOCK_NO_PPG
+    if constexpr (!DET && !is_atomic(WMX) && WMC == kAtomic) {
+        uint32_t n_runs = 0;
+        {
+            const bool starts = (uint32_t)lane < n && (lane == 0 || s_key[lane] != s_key[lane - 1]);
+            n_runs = (uint32_t)__popcll(__ballot(starts));
+        }
+        if (!a.p.hubs && !a.central_atomic && n_runs * 4 >= n * 3) {
+            const uint32_t kk = k + 1;
+            for (uint32_t p4 = 0; p4 < n; p4 += 4) {
+                const uint32_t pr = p4 + grp;
+                const bool have = pr < n;
+                const uint32_t crow_id = s_key[have ? pr : 0];
+                float *crow = a.central + (uint64_t)crow_id * a.cld;
+                Row<CH> u, g;
+                load_row<CH>(u, crow, q, nchunks, have);
+                zero_row<CH>(g);
+                float lrc = a.lr;
+                if (a.flags & kFlagNormLr) {
+                    const uint64_t c = (uint64_t)crow_id * a.p.world + a.p.rank;
+                    const uint64_t deg = a.g.row_ptr[c + 1] - a.g.row_ptr[c];
+                    if (deg) lrc = a.lr / (float)deg;
+                }
+                for (uint32_t sidx = 0; sidx < kk; ++sidx) {
+                    const uint32_t t = (have ? pr : 0) * kk + sidx;
+                    const uint32_t row = have ? s_rows[t] : kSentinel;
+                    const float lab = s_lab[t];
+                    const bool valid = row != kSentinel;
+                    float *base = sample_base(a, a.context, valid ? row : 0);
+                    Row<CH> v;
+                    load_row<CH>(v, base, q, nchunks, valid);
+                    const float dot = dot_rows<CH>(u, v);
+                    const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+                    axpy<CH>(g, var, v);
+                    if (valid) scatter_add<CH, WMX>(base, q, nchunks, var, u, v);
+                }
+                if (have) {
+                    const bool same_prev = pr > 0 ? s_key[pr - 1] == crow_id : s_nb[0] == crow_id;
+                    const bool same_next = pr + 1 < n ? s_key[pr + 1] == crow_id : s_nb[1] == crow_id;
+                    if (!same_prev && !same_next) {
+                        scatter_add<CH, kWriteThrough>(crow, q, nchunks, 1.0f, g, u);
+                    } else {  // the centre has other pairs here: no add may be lost
+#pragma unroll
+                        for (int cc = 0; cc < CH; ++cc) {
+                            const uint32_t ci = cc * 16 + q;
+                            if (ci < nchunks) {
+                                float *pc = crow + ci * 4;
+                                unsafeAtomicAdd(pc + 0, g.c[cc].x);
+                                unsafeAtomicAdd(pc + 1, g.c[cc].y);
+                                unsafeAtomicAdd(pc + 2, g.c[cc].z);
+                                unsafeAtomicAdd(pc + 3, g.c[cc].w);
+                            }
+                        }
+                    }
+                }
+            }
+            pairs += n;
+            runs += n;  // one central row read and one hand-over per pair
+            return;
+        }
+    }
+#endif
     // Runs of equal centre inside the record (short: a centre's pairs are spread over all cells).
     // The central row of the NEXT run is loaded while the current run is scored (other runs have
     // other centres, so it cannot be changed by this record in between).
@@ -485,13 +574,17 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
         if constexpr (!DET) {  // lane-contiguous copy of u for atomic row updates
             if (is_atomic(WMX) || a.p.hubs) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
         }
-        if constexpr (!DET && !is_atomic(WMX))  // stores take u, the atomics of hot rows u_upd
-            score_samples<CH, WMX, DET, true>(a, a.context, u, u, g, s_rows + r0 * (k + 1),
-                                              s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp,
-                                              q, &u_upd);
-        else
+        if constexpr (DET)
             score_samples<CH, WMX, DET>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
                                         s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
+        else if constexpr (!is_atomic(WMX))  // stores take u, the atomics of hot rows u_upd
+            GN2V_BLOCK_SCORE<CH, WMX, true>(a, a.context, u, u, g, s_rows + r0 * (k + 1),
+                                            s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q,
+                                            &u_upd);
+        else
+            GN2V_BLOCK_SCORE<CH, WMX, false>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
+                                             s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp,
+                                             q, nullptr);
         if constexpr (!DET) reduce_groups<CH>(g);
         // The gradient of the run goes to the central row.  A centre whose pairs in this cell are
         // all in this run (the rule at 100 M nodes, where a round holds 1.1 pairs per cell and

@@ -187,6 +187,27 @@ __device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks
     }
 }
 
+// x summed over the four 16-lane rows of the wave, in every lane, with gfx950's row swaps instead
+// of two ds_bpermute round trips through the LDS pipeline: v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second (a = [x0 x0 x2 x2], b = [x1 x1 x3 x3]
+// when both start as x), v_permlane32_swap the upper half of the first with the lower half of the
+// second.  Inline assembly: the clang builtin of this ROCm release returns the first result twice
+// (`v_add_f32 v1, v1, v1` after the swap).  The s_nop covers the VALU-write -> permlane-read hazard.
+__device__ __forceinline__ float sum_rows4(float x) {
+#ifdef GN2V_REDUCE_BPERMUTE
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+#else
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+#endif
+}
+
 // sum a register row over the four 16-lane groups of the wave
 template <int CH>
 __device__ __forceinline__ void reduce_groups(Row<CH> &r) {
@@ -194,12 +215,7 @@ __device__ __forceinline__ void reduce_groups(Row<CH> &r) {
     for (int cc = 0; cc < CH; ++cc) {
         float *f = reinterpret_cast<float *>(&r.c[cc]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = f[e];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            f[e] = v;
-        }
+        for (int e = 0; e < 4; ++e) f[e] = sum_rows4(f[e]);
     }
 }
 
@@ -380,6 +396,42 @@ __device__ __forceinline__ void score_samples(const Args &a, float *table, const
                     if (mine) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
                 }
             }
+        }
+    }
+}
+
+// The parallel schedules' lean form: a round is the four sample rows t0 .. t0 + 3, one per group,
+// with NO check for a row named twice inside the round.  Two groups that meet on a row (a hub
+// drawn twice among four samples: ~1e-4 of the rounds in a cell of 32 k rows) both read the old
+// value and one store wins -- the loss every pair of concurrent waves risks on every row anyway
+// (Hogwild).  Saves the per-round duplicate analysis of score_samples (three LDS reads, the pass
+// numbers, the pass loop): the block kernel issues ~800 instructions per pair with its SIMDs
+// busy 77 % of the time (rocprofv3 SQ_* counters, round 3), so instructions are not free.
+template <int CH, int WM, bool HUB, class Args>
+__device__ __forceinline__ void score_samples_racy(const Args &a, float *table, const Row<CH> &u,
+                                                   const Row<CH> &u_upd, Row<CH> &g,
+                                                   const uint32_t *s_rows, const float *s_lab,
+                                                   uint32_t n_samples, float lrc, int grp, int q,
+                                                   const Row<CH> *u_hub) {
+    const uint32_t nchunks = a.ld >> 2;
+    for (uint32_t t0 = 0; t0 < n_samples; t0 += 4) {
+        const uint32_t t = t0 + grp;
+        const uint32_t row = t < n_samples ? s_rows[t] : kSentinel;
+        const float lab = t < n_samples ? s_lab[t] : 0.f;
+        const bool valid = row != kSentinel;
+        float *base = sample_base(a, table, valid ? row : 0);
+        Row<CH> v;
+        load_row<CH>(v, base, q, nchunks, valid);
+        const float dot = dot_rows<CH>(u, v);
+        const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+        axpy<CH>(g, var, v);
+        if constexpr (HUB) {
+            if (valid && (row & 0x80000000u))
+                scatter_add<CH, kAtomic>(base, q, nchunks, var, *u_hub, v);
+            else if (valid)
+                scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
+        } else {
+            if (valid) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
         }
     }
 }
@@ -622,7 +674,7 @@ __device__ __forceinline__ void cache_retire(CtxCache &c, float *table, uint32_t
 }
 
 template <int CH, int WM>
-__global__ __launch_bounds__(kTrainBlock) void sgns_cached_kernel(TrainArgs a) {
+__global__ __launch_bounds__(kTrainBlock, (CH <= 2 ? 5 : 1)) void sgns_cached_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
