@@ -634,8 +634,13 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
 #ifndef GN2V_BLOCK_MIN_BLOCKS
 #define GN2V_BLOCK_MIN_BLOCKS 1  // occupancy experiments: -DGN2V_BLOCK_MIN_BLOCKS=6 caps the VGPRs
 #endif
-template <int CH, int WMX, int WMC, bool DET>
+// FULL: the row stride is exactly CH * 64 floats (d = 128 -> CH = 2; every d that pads to 64, 128,
+// 256, 512 or 1024): the compiler then knows ld, every "is this chunk inside the row" predicate
+// folds away (they were sixteen 64-bit masks held in SGPRs across the whole kernel) and the
+// per-chunk bounds tests leave the instruction stream.
+template <int CH, int WMX, int WMC, bool DET, bool FULL = false>
 __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block_kernel(BlockArgs a) {
+    if constexpr (FULL) a.ld = CH * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;

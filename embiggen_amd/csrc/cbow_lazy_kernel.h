@@ -66,8 +66,11 @@ __device__ __forceinline__ void row_axpy(Row<CH> &acc, float s, const Row<CH> &x
     axpy<CH>(acc, s, x);
 }
 
-template <int CH, int WM>
+// FULL: the row stride is exactly CH * 64 floats (d = 128 -> CH = 2): ld becomes a compile-time
+// constant and the per-chunk bounds predicates fold away (fewer instructions, fewer SGPR masks).
+template <int CH, int WM, bool FULL = false>
 __global__ __launch_bounds__(kTrainBlock, GN2V_CBOW_LAZY_MIN_BLOCKS) void cbow_lazy_kernel(TrainArgs a) {
+    if constexpr (FULL) a.ld = CH * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;

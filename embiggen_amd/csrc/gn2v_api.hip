@@ -288,6 +288,9 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
         if (use_lazy && wm == gn2v::kWriteBack)                                                \
             hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteBack>), grid, block,    \
                                lazy_lds, s, a);                                                \
+        else if (use_lazy && tp->ld == CH * 64 && !getenv("GN2V_BLOCK_NO_FULL"))               \
+            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteThrough, true>), grid,  \
+                               block, lazy_lds, s, a);                                         \
         else if (use_lazy)                                                                     \
             hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteThrough>), grid, block, \
                                lazy_lds, s, a);                                                \

@@ -302,8 +302,18 @@ extern "C++" {
 template <int CH>
 static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, size_t lds,
                             hipStream_t s, const gn2v::BlockArgs &a) {
-#define GN2V_BLOCK(WMX, WMC, DT) \
-    hipLaunchKernelGGL((gn2v::sgns_block_kernel<CH, WMX, WMC, DT>), grid, block, lds, s, a)
+    // the row stride is a compile-time constant (GN2V_BLOCK_NO_FULL=1: the general kernel, for A/Bs)
+    static const bool no_full = getenv("GN2V_BLOCK_NO_FULL") != nullptr;
+    const bool full = a.ld == (uint32_t)CH * 64 && !no_full;
+#define GN2V_BLOCK(WMX, WMC, DT)                                                                  \
+    do {                                                                                          \
+        if (full && !DT)                                                                          \
+            hipLaunchKernelGGL((gn2v::sgns_block_kernel<CH, WMX, WMC, DT, true>), grid, block,    \
+                               lds, s, a);                                                        \
+        else                                                                                      \
+            hipLaunchKernelGGL((gn2v::sgns_block_kernel<CH, WMX, WMC, DT, false>), grid, block,   \
+                               lds, s, a);                                                        \
+    } while (0)
     if (det)
         GN2V_BLOCK(gn2v::kWriteBack, gn2v::kWriteBack, true);
     else if (wmx == gn2v::kAtomic)
