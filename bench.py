@@ -634,6 +634,12 @@ def main():
                 "scheduled_bytes_per_launch": sched_bytes // launches,
                 "avg_launch_ms": launch_ms,
                 "launches": st["train_launches"],
+                "note": "frac_hbm = bytes that leave L2 (rocprofv3 PMC, committed profile of this "
+                        "workload) / time / peak: bandwidth, never above 1.  frac = SURVEY 8d's "
+                        "schedule-independent bytes (every row of every pair read and written in "
+                        "HBM) / time / peak: it prices work and may exceed 1 because the centre row "
+                        "of a run stays in registers and the XCD's L2 serves hub rows; "
+                        "frac_scheduled counts the centre once per run",
             },
         }
         if reserved is not None:
