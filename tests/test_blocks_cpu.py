@@ -301,15 +301,16 @@ def test_gather_to_one_rank_only(world, root):
             assert rooted[r][0] == [None, None]
 
 
-def _gloo_worker(rank, world, port, out_dir, parts=None):
+def _gloo_worker(rank, world, port, out_dir, parts=None, root=None, group_parts=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    (c, x), _, _ = _train(TorchComm(), parts=parts)
-    np.save(os.path.join(out_dir, f"c{rank}.npy"), c)
-    np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
+    (c, x), _, _ = _train(TorchComm(), parts=parts, root=root, group_parts=group_parts)
+    if c is not None:
+        np.save(os.path.join(out_dir, f"c{rank}.npy"), c)
+        np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -336,3 +337,14 @@ def test_gloo_ranks_equal_the_in_process_simulation(tmp_path, world, parts):
         assert np.array_equal(np.load(tmp_path / f"x{r}.npy"), sim[r][0][1])
     init = O.init_table(34, D, D, 42, 0, D ** -0.5)
     assert np.abs(sim[0][0][0] - init).max() > 1e-3
+
+
+def test_gloo_ranks_gather_to_one_rank_and_train_in_groups(tmp_path):
+    """3 gloo ranks, 6 parts prepared two at a time, the result assembled on rank 1 only (central
+    partitions and context parts sent point to point, one at a time): rank 1 holds exactly what
+    the simulation computes, the other ranks write nothing."""
+    mp.spawn(_gloo_worker, args=(3, _free_port(), str(tmp_path), 6, 1, 2), nprocs=3, join=True)
+    sim = run_ranks(3, lambda comm: _train(comm, parts=6))
+    assert sorted(os.listdir(tmp_path)) == ["c1.npy", "x1.npy"]
+    assert np.array_equal(np.load(tmp_path / "c1.npy"), sim[1][0][0])
+    assert np.array_equal(np.load(tmp_path / "x1.npy"), sim[1][0][1])
