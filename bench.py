@@ -26,7 +26,10 @@ on a second stream while the previous round trains.  No row is ever shared, so N
 exactly what the single-process simulation of the tests computes.  See DESIGN.md "Multi-GPU".
 
 `--model cbow` times the CBOW kernel on the same workload (unit: centres/s; with N > 1 as N
-independent replicas: CBOW does not shard).  Measurement aids, one GPU:
+independent replicas: CBOW does not shard).  A/B switches: `--central-atomic`
+(atomics for every central row update), `--reserve-cus k` (training kernel on a CU-masked stream
+that leaves k CUs of every XCD to RCCL), `--record`, `--group-parts`, `--round-walks`,
+`--overlap`.  Measurement aids, one GPU:
 `--phantom-world N` runs one rank of an N-GPU job with its true geometry and no fabric (the line
 says so and is not the benchmark's value); `--stripes V` the optional centre stripes of
 DESIGN.md 7.4; GN2V_BENCH_MEMLOG=1 logs the allocator's state around the phases.

@@ -262,9 +262,15 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
                                2 * tp->window + 3 * slots + 3) &
                               ~(size_t)3;
     const size_t lazy_lds = (size_t)waves_per_block * lazy_words * 4;
-    const char *lazy_env = getenv("GN2V_CBOW_LAZY");
-    const bool use_lazy = use_cache && cbow && a.min_dist == 1 && lazy_lds <= 40 * 1024 &&
-                          !(lazy_env && lazy_env[0] == '0');
+    // A/B switches, read once: GN2V_CBOW_LAZY=0 keeps cbow_cached_kernel, GN2V_BLOCK_NO_FULL=1 the
+    // kernels that do not know the row stride at compile time
+    static const bool lazy_off = [] {
+        const char *e = getenv("GN2V_CBOW_LAZY");
+        return e && e[0] == '0';
+    }();
+    static const bool no_full = getenv("GN2V_BLOCK_NO_FULL") != nullptr;
+    const bool use_lazy =
+        use_cache && cbow && a.min_dist == 1 && lazy_lds <= 40 * 1024 && !lazy_off;
     if (use_cache) {
         if (tp->flags & GN2V_TRAIN_CTX_CACHE_ALL) {
             a.cache_max_degree = 0xFFFFFFFFu;
@@ -288,7 +294,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
         if (use_lazy && wm == gn2v::kWriteBack)                                                \
             hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteBack>), grid, block,    \
                                lazy_lds, s, a);                                                \
-        else if (use_lazy && tp->ld == CH * 64 && !getenv("GN2V_BLOCK_NO_FULL"))               \
+        else if (use_lazy && tp->ld == CH * 64 && !no_full)                                    \
             hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteThrough, true>), grid,  \
                                block, lazy_lds, s, a);                                         \
         else if (use_lazy)                                                                     \
