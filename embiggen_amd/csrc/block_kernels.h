@@ -59,6 +59,10 @@ constexpr uint32_t kMaxRecord = 32;
 // the centre's row: 32 pairs x (1 + k) samples summed at one stale value overshoot when a small
 // graph fills every record with one centre -- link AUROC 0.985 -> 0.93 with 8 centre stripes on
 // BA 200 k.)
+// records whose runs are at least this many per 100 pairs are trained pair per group
+#ifndef GN2V_PPG_MIN_PCT
+#define GN2V_PPG_MIN_PCT 75
+#endif
 #ifndef GN2V_MAX_RUN
 #define GN2V_MAX_RUN 16
 #endif
@@ -488,7 +492,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
             const bool starts = (uint32_t)lane < n && (lane == 0 || s_key[lane] != s_key[lane - 1]);
             n_runs = (uint32_t)__popcll(__ballot(starts));
         }
-        if (!a.p.hubs && !a.central_atomic && n_runs * 4 >= n * 3) {
+        if (!a.p.hubs && !a.central_atomic && n_runs * 100 >= n * GN2V_PPG_MIN_PCT) {
             const uint32_t kk = k + 1;
             for (uint32_t p4 = 0; p4 < n; p4 += 4) {
                 const uint32_t pr = p4 + grp;
