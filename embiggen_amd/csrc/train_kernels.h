@@ -61,6 +61,7 @@ struct Row {
     float4 c[CH];
 };
 
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __builtin_bit_cast(
