@@ -30,7 +30,10 @@
  * Everything random is counter based (splitmix64 finaliser keyed by seed/epoch/walk/draw) so the
  * HIP implementation can reproduce walks bit-exactly and training to float tolerance.
  *
- * Plain C11; build: see oracle/Makefile.
+ * Plain C11; build: see oracle/Makefile.  Two builds of this one source: libgn2v_oracle.so (strict:
+ * float sums in the written order; THE CHECKER of every parity test) and libgn2v_oracle_fast.so
+ * (-ffast-math -DO_FAST: reassociated sums + prefetch hints; only bench.py's cpu_baseline times it,
+ * so that the CPU figure beside the GPU's is a tuned Hogwild trainer, not a serial-latency one).
  */
 #include <math.h>
 #include <stdint.h>
@@ -462,6 +465,25 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const o_step_io *io
             if (!is_context(i, j, md)) continue;
             uint32_t slot = j < i ? (j + w - i) : (j + w - i - 1); /* 0 .. 2w-1 */
             uint32_t ctx = walk[j];
+#ifdef O_FAST
+            /* Tuned build only (the timed CPU baseline, see the Makefile): hints, results
+             * unchanged -- the rows of the NEXT context slot are requested while this slot is
+             * processed, so that a dozen DRAM accesses are in flight instead of one. */
+            {
+                uint32_t jn = j + 1 == i ? j + 2 : j + 1;
+                if (jn <= hi && !neg_override) {
+                    uint32_t slot_n = jn < i ? (jn + w - i) : (jn + w - i - 1);
+                    const char *pv = (const char *)(contextual + (uint64_t)wrow[jn] * ld);
+                    for (uint32_t b = 0; b < d * sizeof(float); b += 64) __builtin_prefetch(pv + b, 1, 1);
+                    for (uint32_t s = 1; s <= k; ++s) {
+                        uint64_t q = ((uint64_t)i * 2 * w + slot_n) * k + (s - 1);
+                        uint32_t row = draw_negative(g, tp, io, nkey, q);
+                        pv = (const char *)(negative + (uint64_t)row * ld);
+                        for (uint32_t b = 0; b < d * sizeof(float); b += 64) __builtin_prefetch(pv + b, 1, 1);
+                    }
+                }
+            }
+#endif
             for (uint32_t s = 0; s <= k; ++s) {
                 float *v;
                 float label;

@@ -63,33 +63,51 @@ class Graph(C.Structure):
     ]
 
 
-def build(force: bool = False, asan: bool = False) -> str:
-    """Compile the oracle with gcc (idempotent) and return the path of the shared object."""
-    target = "libgn2v_oracle_asan.so" if asan else "libgn2v_oracle.so"
-    path = os.path.join(_HERE, target)
+def build(force: bool = False, asan: bool = False, fast: bool = False) -> str:
+    """Compile the oracle with gcc (idempotent) and return the path of the shared object.
+    ``fast``: the tuned build of the same source (``-ffast-math -DO_FAST``: vectorised dot
+    products, software prefetch) that only ``bench.py``'s ``cpu_baseline`` times; with neither
+    flag both the strict and the tuned library are brought up to date."""
     src = os.path.join(_HERE, "gn2v_oracle.c")
-    if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
-    return path
+    names = (["libgn2v_oracle_asan.so"] if asan else ["libgn2v_oracle_fast.so"] if fast
+             else ["libgn2v_oracle.so", "libgn2v_oracle_fast.so"])
+    for target in names:
+        path = os.path.join(_HERE, target)
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
+    return os.path.join(_HERE, names[0])
 
 
 _lib = None
+_fast_lib = None
+
+
+def _declare(L):
+    L.o_mix64.restype = C.c_uint64
+    L.o_mix64.argtypes = [C.c_uint64]
+    L.o_draw.restype = C.c_uint64
+    L.o_draw.argtypes = [C.c_uint64, C.c_uint64]
+    L.o_walk_key.restype = C.c_uint64
+    L.o_walk_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    L.o_fit.restype = C.c_uint64
+    L.o_window_batch.restype = C.c_uint64
+    L.o_walk_pairs.restype = C.c_uint64
+    return L
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
-        _lib.o_mix64.restype = C.c_uint64
-        _lib.o_mix64.argtypes = [C.c_uint64]
-        _lib.o_draw.restype = C.c_uint64
-        _lib.o_draw.argtypes = [C.c_uint64, C.c_uint64]
-        _lib.o_walk_key.restype = C.c_uint64
-        _lib.o_walk_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
-        _lib.o_fit.restype = C.c_uint64
-        _lib.o_window_batch.restype = C.c_uint64
-        _lib.o_walk_pairs.restype = C.c_uint64
+        _lib = _declare(C.CDLL(build()))
     return _lib
+
+
+def fast_lib():
+    """The tuned build (timed CPU baseline only; never the checker)."""
+    global _fast_lib
+    if _fast_lib is None:
+        _fast_lib = _declare(C.CDLL(build(fast=True)))
+    return _fast_lib
 
 
 def _ptr(a):
@@ -155,15 +173,17 @@ def init_table(n_rows: int, d: int, ld: int, seed: int, table_id: int, scale: fl
 
 def train_walks(g: OracleGraph, tp: TrainParams, walks_arr, seed: int, epoch: int,
                 first_walk: int, lr: float, central, contextual, neg_override=None,
-                threads: int = 1):
-    """In-place update of ``central`` / ``contextual`` ([N, ld] float32, C-contiguous)."""
+                threads: int = 1, fast: bool = False):
+    """In-place update of ``central`` / ``contextual`` ([N, ld] float32, C-contiguous).
+    ``fast``: through the tuned build (the timed CPU baseline)."""
     walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
     assert central.flags.c_contiguous and contextual.flags.c_contiguous
     assert central.dtype == np.float32 and contextual.dtype == np.float32
     if neg_override is not None:
         neg_override = np.ascontiguousarray(neg_override, dtype=np.uint32)
     n_walks, L = walks_arr.shape
-    lib().o_train_walks(C.byref(g.c), C.byref(tp), _ptr(walks_arr), C.c_uint64(n_walks),
+    (fast_lib() if fast else lib()).o_train_walks(
+                        C.byref(g.c), C.byref(tp), _ptr(walks_arr), C.c_uint64(n_walks),
                         C.c_uint32(L), C.c_uint64(seed), C.c_uint64(epoch),
                         C.c_uint64(first_walk), C.c_float(lr), _ptr(central), _ptr(contextual),
                         _ptr(neg_override), C.c_int(threads))

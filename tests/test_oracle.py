@@ -359,3 +359,23 @@ def test_max_neighbours_never_changes_the_walks(karate, karate_oracle, max_neigh
             continue
         pvals.append(stats.chisquare(counts, probs * counts.sum()).pvalue)
     assert len(pvals) >= 5 and min(pvals) > 1e-3 / len(pvals), (pvals,)
+
+
+def test_tuned_oracle_build_is_the_same_algorithm(karate_oracle):
+    """oracle/libgn2v_oracle_fast.so (``-ffast-math -DO_FAST``: what ``bench.py``'s
+    ``cpu_baseline`` times) is the strict oracle's source with reassociated sums and prefetch
+    hints: same updates to 1e-5, SkipGram and CBOW.  It is never the checker: every parity test
+    uses the strict build."""
+    wp = O.WalkParams(16, 2, 0.25, 4.0, 100, 0)
+    walks = O.walks(karate_oracle, wp, 42, 0, 0, 68)
+    for model in (0, 1):
+        tp = O.TrainParams(model, 8, 8, 1, 4, 3, 0.01, 0.9, 6.0, 1, 8 ** -0.5)
+        out = []
+        for fast in (False, True):
+            c = O.init_table(34, 8, 8, 42, 0, 8 ** -0.5)
+            x = O.init_table(34, 8, 8, 42, 1, 8 ** -0.5)
+            O.train_walks(karate_oracle, tp, walks, 42, 0, 0, 0.05, c, x, fast=fast)
+            out.append((c, x))
+        assert np.abs(out[0][0] - out[1][0]).max() < 1e-5
+        assert np.abs(out[0][1] - out[1][1]).max() < 1e-5
+        assert np.abs(out[0][0] - O.init_table(34, 8, 8, 42, 0, 8 ** -0.5)).max() > 1e-3
