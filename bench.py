@@ -226,6 +226,8 @@ def cpu_baseline(graph, args, central, contextual, seconds):
     from oracle import oracle as O
 
     cores = usable_cores()
+    # the tuned build is compiled for THIS host (-march=native), not for wherever the tree came from
+    O.build(force=True, fast=True)
     og = O.OracleGraph(graph.row_ptr, graph.col_idx)
     d = args.d
     c = central[:, :d].contiguous().cpu().numpy()

@@ -146,6 +146,15 @@ def test_config4_products_shaped_block_path_full_size_properties():
     block_path_properties(g, 1 << 16, {"parts": 9, "slices": 8})
 
 
+def test_config4_block_path_with_the_parts_trained_in_node_order(monkeypatch):
+    """``GN2V_BLOCK_LAYOUT=natural``: the contextual table stays in node order during the fit,
+    part p = its rows p, p + parts, ... (``gn2v_block_io.context_ld``) -- what ``gn2v_train_blocks``
+    falls back to when the scratch copy of the part-major layout would not fit.  Same properties."""
+    monkeypatch.setenv("GN2V_BLOCK_LAYOUT", "natural")
+    g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
+    block_path_properties(g, 1 << 16, {"parts": 9, "slices": 8})
+
+
 def test_config5a_bench_graph_block_path_full_size_properties():
     """The roofline configuration (BA 10 M / 100 M) through the path the bench times."""
     g = E.barabasi_albert(10_000_000, 10, 42)
