@@ -675,7 +675,7 @@ __device__ __forceinline__ void cache_retire(CtxCache &c, float *table, uint32_t
 }
 
 template <int CH, int WM>
-__global__ __launch_bounds__(kTrainBlock, (CH <= 2 ? 5 : 1)) void sgns_cached_kernel(TrainArgs a) {
+__global__ __launch_bounds__(kTrainBlock, (CH <= 2 ? 5 : CH == 4 ? 4 : 1)) void sgns_cached_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
