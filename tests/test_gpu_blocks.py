@@ -983,3 +983,43 @@ def test_long_stretches_of_one_centre_are_cut_into_runs_of_sixteen(flags):
     # one run of 32 would end elsewhere: the oracle with the cut undone is measurably different
     moved = np.abs(c_h[:320] - ops.init_table(n_nodes, d, 5, 0, 0.5).cpu().numpy()[:320]).max()
     assert moved > 0.05
+
+
+@pytest.mark.parametrize("d", [16, 128])
+def test_pair_per_group_path_adds_shared_centres_with_atomics(d):
+    """Records of mostly single-pair runs are trained pair per group (four pairs side by side).
+    Here every fourth pair shares its centre with its neighbour -- both inside one step of four,
+    so both groups read the row before either adds its gradient, exactly the oracle's run of two
+    -- and must hand its gradient over with atomics (a store would lose one of the two); lone
+    pairs store row + gradient.  Unique context rows, k = 0: equal to the sequential oracle."""
+    n_nodes, slices, record = 8 * 32_768, 8, 32
+    g = _ba(n_nodes)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    plan = ops.block_plan(g, 1, 0, 1, slices, 8, 2, 1, record)
+    oplan = O.block_plan(n_nodes, 1, 0, 1, slices, 8, 2, 1, record)
+    rng = np.random.RandomState(8)
+    per_cell = 64 * record
+    words_l, offsets, centre = [], [0], 0
+    for cell in range(slices):
+        ctx = rng.permutation(np.arange(cell, n_nodes, slices))[:per_cell]
+        # centres c, c, c+1, c+2 | c+3, c+3, c+4, c+5 | ...: 3 runs per 4 pairs (75 % -> the path)
+        steps = np.arange(per_cell) // 4
+        centres = centre + steps * 3 + np.maximum(np.arange(per_cell) % 4 - 1, 0)
+        centre = int(centres[-1]) + 1
+        words_l.append(O.block_pack(np.full(per_cell, cell), centres, ctx, oplan))
+        offsets.append(offsets[-1] + per_cell)
+    words_h = np.concatenate(words_l)
+    off_h = np.asarray(offsets, dtype=np.uint64)
+    pairs, offs = _dev_words(words_h), torch.from_numpy(off_h.astype(np.int64)).cuda()
+    tp = ops.train_params(0, d, 0, 2, flags=0, ld=d)  # default flavour: the path that ships
+    otp = O.TrainParams(0, d, d, 1, 0, 2, 0.01, 0.9, 6.0, 0, d ** -0.5)
+    c = ops.init_table(n_nodes, d, 5, 0, 0.5)
+    x = ops.init_table(n_nodes, d, 5, 1, 0.5)
+    c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
+    ops.stats_reset(g)
+    ops.block_step(g, tp, plan, pairs, offs, None, None, c, x, 0, 0, 5, 0, 0.1)
+    O.block_step(og, otp, oplan, words_h, off_h, None, None, c_h, x_h, 0, 0, 5, 0, 0.1)
+    torch.cuda.synchronize()
+    st = ops.stats_read(g)
+    assert st["pairs"] == slices * per_cell == st["centres"]  # one hand-over per pair: that path
+    assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5 and np.abs(x.cpu().numpy() - x_h).max() < 2e-5
