@@ -123,6 +123,29 @@ _GOLDEN = 0x9E3779B97F4A7C15
 _SIGN = -(1 << 63)
 
 
+def _row_hash_order(keys, salt: int):
+    """Positions that put ascending keys into (row, mix64(key ^ salt)) order: a stable sort by the
+    hash, then a stable sort by the row.  Sets too long for one sort are cut where a row starts
+    (the keys arrive ascending, so a row's entries are contiguous) and ordered a piece at a time."""
+    import torch
+
+    n = keys.numel()
+    order = torch.empty(n, dtype=torch.int64, device=keys.device)
+    lo = 0
+    while lo < n:
+        hi = min(n, lo + SORT_LIMIT)
+        if hi < n:  # back to the first entry of the row that holds keys[hi]
+            hi = int(torch.searchsorted(keys, (keys[hi:hi + 1] >> 32) << 32)[0])
+            if hi <= lo:
+                raise RuntimeError(f"one row holds more than {SORT_LIMIT} co-occurrence entries")
+        piece = keys[lo:hi]
+        by_hash = torch.argsort(mix64_tensor(piece ^ salt) ^ _SIGN, stable=True)
+        order[lo:hi] = by_hash[torch.argsort(_lsr(piece[by_hash], 32), stable=True)] + lo
+        del by_hash
+        lo = hi
+    return order
+
+
 def entries(keys, counts, seed: int, alpha: float):
     """Training slots (rows i32, cols i32, log X f32, f(X) f32) laid out as records of RECORD
     consecutive slots that share their central row (the engine trains a record per wavefront with
@@ -139,9 +162,7 @@ def entries(keys, counts, seed: int, alpha: float):
         empty_f = torch.empty(0, dtype=torch.float32, device=dev)
         return empty_i, empty_i.clone(), empty_f, empty_f.clone()
     salt = _signed(mix64_int(seed ^ _TAG_GLOVE))
-    # order by (row, hash of key): stable sort by the hash, then stable sort by the row
-    order = torch.argsort(mix64_tensor(keys ^ salt) ^ _SIGN, stable=True)
-    order = order[torch.argsort(_lsr(keys[order], 32), stable=True)]
+    order = _row_hash_order(keys, salt)
     keys, counts = keys[order], counts[order]
     del order
     row = _lsr(keys, 32)

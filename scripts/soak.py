@@ -5,10 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np, torch
 import embiggen_amd as E
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None  # class names to run
 g = E.barabasi_albert(n, 7, 42)
 for cls, kw in ((E.Node2VecSkipGramEnsmallen, {}), (E.Node2VecCBOWEnsmallen, {}),
                 (E.WalkletsSkipGramEnsmallen, {"epochs": 3}), (E.Node2VecGloVeEnsmallen, {}),
                 (E.DeepWalkGloVeEnsmallen, {"epochs": 20})):
+    if only and cls.__name__ not in only:
+        continue
     m = cls(**kw)
     t0 = time.time()
     res = m.fit_transform(g, return_dataframe=False)

@@ -231,3 +231,27 @@ def test_merging_runs_longer_than_one_sort_allows(monkeypatch):
             total[k] = total.get(k, 0) + w
     keys, counts = acc.result()
     assert keys.tolist() == sorted(total) and counts.tolist() == [total[k] for k in sorted(total)]
+
+
+def test_ordering_more_entries_than_one_sort_allows(monkeypatch):
+    """The training order of `entries` (row, hash of key) when the entry set is longer than one
+    sort takes (a default GloVe fit of a 1 M-node graph holds > 2^31 distinct pairs): pieces cut
+    where a row starts give the same slots as one sort."""
+    import torch
+
+    from embiggen_amd import cooccurrence as CO
+
+    rng = np.random.RandomState(3)
+    rows = np.sort(rng.randint(0, 300, 6000)).astype(np.int64)
+    keys = np.unique((rows << 32) | rng.randint(0, 5000, 6000))
+    tk = torch.from_numpy(keys)
+    tc = torch.from_numpy(rng.randint(1, 1 << 22, len(keys)).astype(np.int64))
+    want = CO.entries(tk, tc, 42, 0.75)
+    monkeypatch.setattr(CO, "SORT_LIMIT", 257)
+    got = CO.entries(tk, tc, 42, 0.75)
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    # a row that alone exceeds the limit cannot be cut
+    monkeypatch.setattr(CO, "SORT_LIMIT", 8)
+    with pytest.raises(RuntimeError, match="one row holds"):
+        CO.entries(tk, tc, 42, 0.75)
