@@ -123,27 +123,23 @@ _GOLDEN = 0x9E3779B97F4A7C15
 _SIGN = -(1 << 63)
 
 
-def _row_hash_order(keys, salt: int):
-    """Positions that put ascending keys into (row, mix64(key ^ salt)) order: a stable sort by the
-    hash, then a stable sort by the row.  Sets too long for one sort are cut where a row starts
-    (the keys arrive ascending, so a row's entries are contiguous) and ordered a piece at a time."""
+def _row_pieces(keys):
+    """[lo, hi) ranges of ascending keys that hold whole rows and at most SORT_LIMIT entries each
+    (torch.sort / nonzero / cumsum work on one range at a time, so the entry set itself may be
+    longer than INT_MAX: a default GloVe fit of a 1 M-node graph holds > 2^31 distinct pairs)."""
     import torch
 
-    n = keys.numel()
-    order = torch.empty(n, dtype=torch.int64, device=keys.device)
-    lo = 0
+    n, lo, out = keys.numel(), 0, []
     while lo < n:
         hi = min(n, lo + SORT_LIMIT)
         if hi < n:  # back to the first entry of the row that holds keys[hi]
-            hi = int(torch.searchsorted(keys, (keys[hi:hi + 1] >> 32) << 32)[0])
+            first = (keys[hi:hi + 1] >> 32) << 32
+            hi = lo + int(torch.searchsorted(keys[lo:hi], first)[0])
             if hi <= lo:
                 raise RuntimeError(f"one row holds more than {SORT_LIMIT} co-occurrence entries")
-        piece = keys[lo:hi]
-        by_hash = torch.argsort(mix64_tensor(piece ^ salt) ^ _SIGN, stable=True)
-        order[lo:hi] = by_hash[torch.argsort(_lsr(piece[by_hash], 32), stable=True)] + lo
-        del by_hash
+        out.append((lo, hi))
         lo = hi
-    return order
+    return out
 
 
 def entries(keys, counts, seed: int, alpha: float):
@@ -152,7 +148,7 @@ def entries(keys, counts, seed: int, alpha: float):
     that row in registers): every row's entries in ascending mix64(key ^ salt) are cut into records,
     the records are shuffled (ascending draw(mix64(row ^ salt), record index in the row)); unused
     slots of a row's last record hold col = -1.  X = count / max count.  Same order as the oracle
-    (o_glove_entries)."""
+    (o_glove_entries).  `keys` ascending and distinct (reduce_slots / merge leave them so)."""
     import torch
 
     dev = keys.device
@@ -162,44 +158,68 @@ def entries(keys, counts, seed: int, alpha: float):
         empty_f = torch.empty(0, dtype=torch.float32, device=dev)
         return empty_i, empty_i.clone(), empty_f, empty_f.clone()
     salt = _signed(mix64_int(seed ^ _TAG_GLOVE))
-    order = _row_hash_order(keys, salt)
-    keys, counts = keys[order], counts[order]
-    del order
-    row = _lsr(keys, 32)
-    start = torch.ones(n, dtype=torch.bool, device=dev)
-    torch.ne(row[1:], row[:-1], out=start[1:])
-    run_pos = torch.nonzero(start).flatten()
-    run_id = torch.cumsum(start, 0) - 1
-    del start
-    rank = torch.arange(n, dtype=torch.int64, device=dev) - run_pos[run_id]
-    run_len = torch.diff(run_pos, append=torch.tensor([n], dtype=torch.int64, device=dev))
-    recs = torch.div(run_len + (RECORD - 1), RECORD, rounding_mode="floor")
-    first_rec = torch.cumsum(recs, 0) - recs
-    rec_id = first_rec[run_id] + torch.div(rank, RECORD, rounding_mode="floor")
-    del run_id, run_len
-    n_rec = int(recs.sum())
-    rec_run = torch.repeat_interleave(torch.arange(recs.numel(), device=dev), recs)
-    rec_row = row[run_pos][rec_run]
-    rec_q = torch.arange(n_rec, dtype=torch.int64, device=dev) - first_rec[rec_run]
-    del rec_run, first_rec, recs, run_pos
-    h = mix64_tensor(mix64_tensor(rec_row ^ salt) + (rec_q + 1) * _signed(_GOLDEN)) ^ _SIGN
+    # pass 1, a range of whole rows at a time: (row, hash of key) order, the rows' records
+    pieces, rec_rows, rec_hash, n_rec, top = [], [], [], 0, None
+    for lo, hi in _row_pieces(keys):
+        piece = keys[lo:hi]
+        m = hi - lo
+        # stable sort by the hash, then stable sort by the row
+        order = torch.argsort(mix64_tensor(piece ^ salt) ^ _SIGN, stable=True)
+        order = order[torch.argsort(_lsr(piece[order], 32), stable=True)]
+        pkeys, pcounts = piece[order], counts[lo:hi][order]
+        del order, piece
+        row = _lsr(pkeys, 32)
+        start = torch.ones(m, dtype=torch.bool, device=dev)
+        torch.ne(row[1:], row[:-1], out=start[1:])
+        run_pos = torch.nonzero(start).flatten()
+        run_id = torch.cumsum(start, 0) - 1
+        del start
+        rank = torch.arange(m, dtype=torch.int64, device=dev) - run_pos[run_id]
+        run_len = torch.diff(run_pos, append=torch.tensor([m], dtype=torch.int64, device=dev))
+        recs = torch.div(run_len + (RECORD - 1), RECORD, rounding_mode="floor")
+        first_rec = torch.cumsum(recs, 0) - recs
+        rec_id = first_rec[run_id] + torch.div(rank, RECORD, rounding_mode="floor") + n_rec
+        del run_id, run_len
+        piece_recs = int(recs.sum())
+        rec_run = torch.repeat_interleave(torch.arange(recs.numel(), device=dev), recs)
+        rec_row = row[run_pos][rec_run]
+        rec_q = torch.arange(piece_recs, dtype=torch.int64, device=dev) - first_rec[rec_run]
+        del rec_run, first_rec, recs, run_pos, row
+        rec_hash.append(mix64_tensor(mix64_tensor(rec_row ^ salt) + (rec_q + 1) * _signed(_GOLDEN)) ^ _SIGN)
+        rec_rows.append(rec_row)
+        del rec_q
+        pieces.append(((pkeys & 0xFFFFFFFF).to(torch.int32), pcounts, rec_id,
+                       (rank % RECORD).to(torch.int8)))
+        piece_top = pcounts.max()
+        top = piece_top if top is None else torch.maximum(top, piece_top)
+        del pkeys, rank
+        n_rec += piece_recs
+    if n_rec > SORT_LIMIT:
+        raise RuntimeError(f"{n_rec} records of co-occurrence entries are more than one sort takes")
+    rec_row = torch.cat(rec_rows) if len(rec_rows) > 1 else rec_rows[0]
+    h = torch.cat(rec_hash) if len(rec_hash) > 1 else rec_hash[0]
+    del rec_rows, rec_hash
     rec_order = torch.argsort(h, stable=True)  # ties keep the (row, index) order
-    del h, rec_q
+    del h
     new_pos = torch.empty(n_rec, dtype=torch.int64, device=dev)
     new_pos[rec_order] = torch.arange(n_rec, dtype=torch.int64, device=dev)
-    slot = new_pos[rec_id] * RECORD + rank % RECORD
-    del rec_id, rank, new_pos
-    rows = rec_row[rec_order].to(torch.int32).repeat_interleave(RECORD).contiguous()
+    rows = rec_row[rec_order].to(torch.int32).unsqueeze(1).expand(n_rec, RECORD).reshape(-1)
     del rec_row, rec_order
+    # pass 2: every entry into its slot
     cols = torch.full((n_rec * RECORD,), -1, dtype=torch.int32, device=dev)
-    cols[slot] = (keys & 0xFFFFFFFF).to(torch.int32)
-    del keys, row
-    top = counts.max().to(torch.float64)
     logx = torch.zeros(n_rec * RECORD, dtype=torch.float32, device=dev)
     fx = torch.zeros_like(logx)
+    top = top.to(torch.float64)
     step = 1 << 26  # float64 temporaries of a slice at a time
-    for lo in range(0, n, step):
-        x = (counts[lo:lo + step].to(torch.float64) / top).to(torch.float32).to(torch.float64)
-        logx[slot[lo:lo + step]] = torch.log(x).to(torch.float32)
-        fx[slot[lo:lo + step]] = torch.pow(x, float(alpha)).to(torch.float32)
+    while pieces:
+        pcols, pcounts, rec_id, lane = pieces.pop(0)
+        slot = new_pos[rec_id] * RECORD + lane
+        del rec_id, lane
+        cols[slot] = pcols
+        del pcols
+        for lo in range(0, slot.numel(), step):
+            x = (pcounts[lo:lo + step].to(torch.float64) / top).to(torch.float32).to(torch.float64)
+            logx[slot[lo:lo + step]] = torch.log(x).to(torch.float32)
+            fx[slot[lo:lo + step]] = torch.pow(x, float(alpha)).to(torch.float32)
+        del slot, pcounts
     return rows, cols, logx, fx

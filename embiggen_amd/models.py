@@ -516,6 +516,7 @@ class GloVe(_WalkBasedModel):
             ops.stats_reset(csr, self.device)
             start = time.perf_counter()
             keys, counts = self.cooccurrence_device(csr)
+            n_entries = int(keys.numel())  # record slots minus padding
             rows, cols, logx, fx = cooccurrence.entries(keys, counts, self.random_state, self.alpha)
             del keys, counts
             central = ops.init_table(n, d, self.random_state, 0, self.init_scale(), self.device, ld)
@@ -530,7 +531,7 @@ class GloVe(_WalkBasedModel):
             torch.cuda.synchronize(dev)
             self.last_seconds = time.perf_counter() - start
         stats = ops.stats_read(csr, self.device)
-        stats["entries"] = int((cols != -1).sum())  # record slots minus padding
+        stats["entries"] = n_entries
         stats["pairs"] = stats["entries"] * self.epochs  # entry updates
         self.last_stats = stats
         if self.verbose:

@@ -1,5 +1,5 @@
 """First-contact GPU check: parity of every kernel against the oracle + a quick speed probe.
-Run on the GPU box:  python scripts/gpu_check.py [--perf N_NODES]
+Run on the GPU box:  python tests/gpu_check.py [--perf N_NODES]
 """
 import argparse
 import os
