@@ -6,7 +6,9 @@ window batch generator of ``embiggen.sequences``.  Compute runs in hand-written 
 gfx950 reached through the C ABI in ``include/gn2v.h``; there is no CPU execution path.
 """
 from . import _lib
-from .embedding_transformers import EdgeTransformer, GraphTransformer, NodeTransformer
+from .embedding_transformers import (EdgeLabelPredictionTransformer, EdgePredictionTransformer,
+                                     EdgeTransformer, GraphTransformer,
+                                     NodeLabelPredictionTransformer, NodeTransformer)
 from .embedders import (DeepWalkCBOWEnsmallen, DeepWalkGloVeEnsmallen, DeepWalkSkipGramEnsmallen,
                         Node2VecCBOWEnsmallen, Node2VecGloVeEnsmallen, Node2VecSkipGramEnsmallen,
                         WalkletsCBOWEnsmallen, WalkletsGloVeEnsmallen,
@@ -27,4 +29,6 @@ __all__ = [
     "DeepWalkGloVeEnsmallen", "WalkletsGloVeEnsmallen",
     "get_models_dataframe", "get_available_models_for_node_embedding", "normalize_kwargs",
     "Node2VecSequence", "EdgeTransformer", "NodeTransformer", "GraphTransformer",
+    "EdgePredictionTransformer", "EdgeLabelPredictionTransformer",
+    "NodeLabelPredictionTransformer",
 ]

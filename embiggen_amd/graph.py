@@ -419,6 +419,96 @@ class CSRGraph:
         if self.is_multigraph():
             raise ValueError("The graph is a multigraph.")
 
+    # --- label getters of the prediction transformers (ensmallen's names as used by
+    #     embedding_transformers/edge_prediction_transformer.py:118-144,
+    #     edge_label_prediction_transformer.py:125-229, node_label_prediction_transformer.py:84-150)
+    def has_compatible_node_vocabularies(self, other: "CSRGraph") -> bool:
+        """Same nodes under the same ids, and node types present in both or in neither."""
+        return (self._n_nodes == other.get_number_of_nodes()
+                and self.has_node_types() == other.has_node_types()
+                and (not (self._named or getattr(other, "_named", True))
+                     or self.get_node_names() == other.get_node_names()))
+
+    def has_unknown_node_types(self) -> bool:
+        return self.has_node_types() and bool((self.node_type_ids == UNKNOWN_TYPE).any())
+
+    def has_known_node_types(self) -> bool:
+        return self.has_node_types() and bool((self.node_type_ids != UNKNOWN_TYPE).any())
+
+    def get_nodes_with_known_node_types_mask(self) -> np.ndarray:
+        if not self.has_node_types():
+            raise ValueError("The graph does not have node types.")
+        return self.node_type_ids != UNKNOWN_TYPE
+
+    def has_multilabel_node_types(self) -> bool:
+        return self.has_node_types() and any(
+            ids is not None and len(ids) > 1 for ids in self.get_node_type_ids())
+
+    def _node_label_counts(self) -> np.ndarray:
+        """Nodes per individual label (a multi-label node counts once for each of its labels)."""
+        labels = [ids for ids in self.get_node_type_ids() if ids is not None]
+        if not labels:
+            return np.zeros(0, dtype=np.int64)
+        return np.bincount(np.concatenate(labels).astype(np.int64))
+
+    def has_homogeneous_node_types(self) -> bool:
+        return int((self._node_label_counts() > 0).sum()) == 1
+
+    def has_singleton_node_types(self) -> bool:
+        return bool((self._node_label_counts() == 1).any())
+
+    def get_one_hot_encoded_node_types(self) -> np.ndarray:
+        """bool [nodes, labels]: the labels of every node (all False for an unknown type)."""
+        lists = self.get_node_type_ids()
+        out = np.zeros((self._n_nodes, len(self.get_unique_node_type_names())), dtype=bool)
+        for node, ids in enumerate(lists):
+            if ids is not None:
+                out[node, ids] = True
+        return out
+
+    def has_known_edge_types(self) -> bool:
+        return self.has_edge_types() and bool((self.edge_type_ids != UNKNOWN_TYPE).any())
+
+    def get_directed_edges_with_known_edge_types_mask(self) -> np.ndarray:
+        return self._edge_types_or_raise() != UNKNOWN_TYPE
+
+    def get_upper_triangular_known_edge_types_mask(self) -> np.ndarray:
+        return self.get_directed_edges_with_known_edge_types_mask()[self._upper_triangular()]
+
+    def get_directed_known_edge_type_ids(self) -> np.ndarray:
+        ids = self._edge_types_or_raise()
+        return ids[ids != UNKNOWN_TYPE]
+
+    def get_upper_triangular_known_edge_type_ids(self) -> np.ndarray:
+        ids = self._edge_types_or_raise()[self._upper_triangular()]
+        return ids[ids != UNKNOWN_TYPE]
+
+    def get_number_of_known_edge_types(self) -> int:
+        """Directed edges whose type is known."""
+        return int(self.get_directed_edges_with_known_edge_types_mask().sum())
+
+    def get_edge_type_names_counts_hashmap(self) -> dict:
+        """Edge type name -> directed edges of that type (types without edges included)."""
+        vocabulary = self.get_unique_edge_type_names()
+        counts = np.bincount(self.get_directed_known_edge_type_ids().astype(np.int64),
+                             minlength=len(vocabulary))
+        return {name: int(c) for name, c in zip(vocabulary, counts)}
+
+    def has_homogeneous_edge_types(self) -> bool:
+        return sum(c > 0 for c in self.get_edge_type_names_counts_hashmap().values()) == 1
+
+    def has_singleton_edge_types(self) -> bool:
+        """Some type labels exactly one edge (one directed edge, or the two directions of one
+        undirected edge)."""
+        once = 1 if self._directed else 2
+        ids = self._edge_types_or_raise()
+        loops = self.get_directed_source_node_ids() == self.col_idx
+        per_type = np.bincount(ids[ids != UNKNOWN_TYPE].astype(np.int64))
+        loop_per_type = np.bincount(ids[(ids != UNKNOWN_TYPE) & loops].astype(np.int64),
+                                    minlength=len(per_type))
+        undirected_edges = (per_type + loop_per_type) // once if not self._directed else per_type
+        return bool((undirected_edges == 1).any())
+
     def with_types(self, node_type_ids=None, edge_type_ids=None) -> "CSRGraph":
         """Same graph (arrays shared) with the given type ids attached: u32 arrays, or device
         tensors (int32) for a device-resident graph."""

@@ -17,6 +17,10 @@
    names) of the reference's NodeTransformer, EdgeTransformer and GraphTransformer on the scenario
    table ``helpers.transformer_cases``; the graph argument is a small pure-Python stand-in for
    ``ensmallen.Graph`` defined below (the reference only calls getters on it).
+5. ``prediction_cases.npz`` / ``prediction_cases.json`` -- the same for its EdgePrediction-,
+   EdgeLabelPrediction- and NodeLabelPredictionTransformer on ``helpers.prediction_cases``
+   (the (X, y) pair of every scenario as one array), over the stand-in graphs of
+   ``helpers.prediction_graph_specs``.
 
 Only data (inputs -> expected outcomes, names -> default values) is written; no reference source
 text is stored.
@@ -31,7 +35,8 @@ import sys
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from helpers import probe, scenarios, transformer_cases, transformer_graph_spec  # noqa: E402
+from helpers import (prediction_cases, probe, scenarios, transformer_cases,  # noqa: E402
+                     transformer_graph_spec)
 
 
 def embedding_result_cases():
@@ -162,51 +167,135 @@ def edge_embedding_cases():
 
 
 class StandInGraph:
-    """The getters embedding_transformers/graph_transformer.py:150-243 and
-    node_transformer.py:186-190 call on an ensmallen.Graph, over transformer_graph_spec():
-    undirected, CSR edge order, type vocabularies in order of first appearance."""
+    """The getters the reference's transformers call on an ensmallen.Graph
+    (embedding_transformers/graph_transformer.py:150-243, node_transformer.py:186-190,
+    edge_prediction_transformer.py:118-144, edge_label_prediction_transformer.py:125-229,
+    node_label_prediction_transformer.py:84-150), over one entry of
+    helpers.prediction_graph_specs() (default: transformer_graph_spec()): CSR edge order, type
+    vocabularies in order of first appearance, None = unknown type."""
 
-    def __init__(self):
+    UNKNOWN = 0xFFFFFFFF
+
+    def __init__(self, spec=None):
         import numpy as np
 
-        names, edges, edge_types, node_types = transformer_graph_spec()
-        self.names = names
-        directed = {}
-        for (a, b), t in zip(edges, edge_types):
-            directed[(a, b)] = t
-            directed[(b, a)] = t
-        keys = sorted(directed)
+        if spec is None:
+            names, edges, edge_types, node_types = transformer_graph_spec()
+            spec = dict(names=names, edges=edges, directed=False, edge_types=edge_types,
+                        node_types=node_types)
+        self.names = spec["names"]
+        self.directed = spec["directed"]
+        edge_types = spec["edge_types"]
+        self.typed_edges = edge_types is not None
+        labels = edge_types if self.typed_edges else [None] * len(spec["edges"])
+        self.edge_vocab = list(dict.fromkeys(t for t in labels if t is not None))
+        triples = set()
+        for (a, b), t in zip(spec["edges"], labels):
+            tid = self.UNKNOWN if t is None else self.edge_vocab.index(t)
+            triples.add((a, b, tid))
+            if not self.directed:
+                triples.add((b, a, tid))
+        keys = sorted(triples)
         self.src = np.array([k[0] for k in keys], dtype=np.uint32)
         self.dst = np.array([k[1] for k in keys], dtype=np.uint32)
-        self.edge_vocab = list(dict.fromkeys(edge_types))
-        self.etype = np.array([self.edge_vocab.index(directed[k]) for k in keys], dtype=np.uint32)
-        self.node_vocab = list(dict.fromkeys(t for ts in node_types if ts for t in ts))
-        self.ntype = [None if ts is None else
+        self.etype = np.array([k[2] for k in keys], dtype=np.uint32)
+        self.multi = len({(k[0], k[1]) for k in keys}) != len(keys)
+        node_types = spec["node_types"]
+        self.typed_nodes = node_types is not None
+        per_node = node_types if self.typed_nodes else [None] * len(self.names)
+        per_node = [None if ts is None else (list(ts) if isinstance(ts, (list, tuple)) else [ts])
+                    for ts in per_node]
+        self.node_vocab = list(dict.fromkeys(t for ts in per_node if ts for t in ts))
+        self.ntype = [None if not ts else
                       np.array(sorted(self.node_vocab.index(t) for t in ts), dtype=np.uint32)
-                      for ts in node_types]
+                      for ts in per_node]
         self.upper = self.src <= self.dst
 
-    def is_directed(self): return False
+    def get_name(self): return "StandIn"
+    def is_directed(self): return self.directed
+    def is_multigraph(self): return self.multi
+    def get_number_of_nodes(self): return len(self.names)
+    def get_number_of_directed_edges(self): return len(self.src)
+    def get_number_of_edges(self): return len(self.src)
     def get_node_names(self): return self.names
     def get_directed_source_node_ids(self): return self.src
     def get_directed_destination_node_ids(self): return self.dst
-    def get_source_node_ids(self, directed=True): return self.src if directed else self.src[self.upper]
-    def get_destination_node_ids(self, directed=True): return self.dst if directed else self.dst[self.upper]
+    def get_source_node_ids(self, directed=True):
+        return self.src if directed or self.directed else self.src[self.upper]
+    def get_destination_node_ids(self, directed=True):
+        return self.dst if directed or self.directed else self.dst[self.upper]
     def get_directed_edge_node_names(self):
         return [(self.names[s], self.names[d]) for s, d in zip(self.src, self.dst)]
+    def has_compatible_node_vocabularies(self, other):
+        return self.names == other.names and self.typed_nodes == other.typed_nodes
+    # node types
+    def has_node_types(self): return self.typed_nodes
     def get_node_type_ids(self): return self.ntype
     def get_node_type_ids_from_node_id(self, i): return self.ntype[int(i)]
     def get_node_type_names_from_node_name(self, name):
         ids = self.ntype[self.names.index(name)]
         return None if ids is None else [self.node_vocab[i] for i in ids]
-    def must_not_contain_unknown_edge_types(self): pass
-    def must_not_be_multigraph(self): pass
-    def get_imputed_directed_edge_type_ids(self, imputation_edge_type_id=0): return self.etype
+    def has_unknown_node_types(self): return self.typed_nodes and any(t is None for t in self.ntype)
+    def has_known_node_types(self): return any(t is not None for t in self.ntype)
+    def _node_label_counts(self):
+        counts = [0] * len(self.node_vocab)
+        for ids in self.ntype:
+            for t in ([] if ids is None else ids):
+                counts[int(t)] += 1
+        return counts
+    def has_homogeneous_node_types(self): return sum(c > 0 for c in self._node_label_counts()) == 1
+    def has_singleton_node_types(self): return any(c == 1 for c in self._node_label_counts())
+    def has_multilabel_node_types(self): return any(t is not None and len(t) > 1 for t in self.ntype)
+    def get_one_hot_encoded_node_types(self):
+        import numpy as np
+        out = np.zeros((len(self.names), len(self.node_vocab)), dtype=bool)
+        for i, ids in enumerate(self.ntype):
+            if ids is not None:
+                out[i, ids] = True
+        return out
+    def get_nodes_with_known_node_types_mask(self):
+        import numpy as np
+        return np.array([t is not None for t in self.ntype])
+    # edge types
+    def has_edge_types(self): return self.typed_edges
+    def has_unknown_edge_types(self): return self.typed_edges and bool((self.etype == self.UNKNOWN).any())
+    def has_known_edge_types(self): return self.typed_edges and bool((self.etype != self.UNKNOWN).any())
+    def must_not_contain_unknown_edge_types(self):
+        if self.has_unknown_edge_types():
+            raise ValueError("unknown edge types")
+    def must_not_be_multigraph(self):
+        if self.multi:
+            raise ValueError("multigraph")
+    def get_imputed_directed_edge_type_ids(self, imputation_edge_type_id=0):
+        import numpy as np
+        return np.where(self.etype == self.UNKNOWN, np.uint32(imputation_edge_type_id), self.etype)
     def get_imputed_upper_triangular_edge_type_ids(self, imputation_edge_type_id=0):
-        return self.etype[self.upper]
-    def get_directed_edge_type_names(self): return [self.edge_vocab[t] for t in self.etype]
+        return self.get_imputed_directed_edge_type_ids(imputation_edge_type_id)[self.upper]
+    def get_directed_edge_type_names(self):
+        return [None if t == self.UNKNOWN else self.edge_vocab[t] for t in self.etype]
     def get_upper_triangular_edge_type_names(self):
-        return [self.edge_vocab[t] for t in self.etype[self.upper]]
+        return [None if t == self.UNKNOWN else self.edge_vocab[t] for t in self.etype[self.upper]]
+    def get_directed_edges_with_known_edge_types_mask(self): return self.etype != self.UNKNOWN
+    def get_upper_triangular_known_edge_types_mask(self): return (self.etype != self.UNKNOWN)[self.upper]
+    def get_directed_known_edge_type_ids(self): return self.etype[self.etype != self.UNKNOWN]
+    def get_upper_triangular_known_edge_type_ids(self):
+        upper = self.etype[self.upper]
+        return upper[upper != self.UNKNOWN]
+    def get_number_of_known_edge_types(self): return int((self.etype != self.UNKNOWN).sum())
+    def get_edge_type_names_counts_hashmap(self):
+        known = self.etype[self.etype != self.UNKNOWN]
+        return {name: int((known == i).sum()) for i, name in enumerate(self.edge_vocab)}
+    def has_homogeneous_edge_types(self):
+        return sum(c > 0 for c in self.get_edge_type_names_counts_hashmap().values()) == 1
+    def has_singleton_edge_types(self):
+        once = 1 if self.directed else 2
+        loops = self.src == self.dst
+        for i in range(len(self.edge_vocab)):
+            mine = self.etype == i
+            edges = int(mine.sum()) if self.directed else (int(mine.sum()) + int((mine & loops).sum())) // once
+            if edges == 1:
+                return True
+        return False
 
 
 def transformer_fixture():
@@ -232,15 +321,23 @@ def transformer_fixture():
     base = os.path.join(REF, "embiggen/embedding_transformers")
     try:
         loaded = {}
-        for stem in ("node_transformer", "edge_transformer", "graph_transformer"):
+        for stem in ("node_transformer", "edge_transformer", "graph_transformer",
+                     "edge_prediction_transformer", "edge_label_prediction_transformer",
+                     "node_label_prediction_transformer"):
             full = f"embiggen.embedding_transformers.{stem}"
             spec = importlib.util.spec_from_file_location(full, os.path.join(base, stem + ".py"))
             loaded[stem] = put(full, importlib.util.module_from_spec(spec))
             spec.loader.exec_module(loaded[stem])
-        T = types.SimpleNamespace(NodeTransformer=loaded["node_transformer"].NodeTransformer,
-                                  EdgeTransformer=loaded["edge_transformer"].EdgeTransformer,
-                                  GraphTransformer=loaded["graph_transformer"].GraphTransformer)
-        return transformer_cases(T, StandInGraph())
+        T = types.SimpleNamespace(
+            NodeTransformer=loaded["node_transformer"].NodeTransformer,
+            EdgeTransformer=loaded["edge_transformer"].EdgeTransformer,
+            GraphTransformer=loaded["graph_transformer"].GraphTransformer,
+            EdgePredictionTransformer=loaded["edge_prediction_transformer"].EdgePredictionTransformer,
+            EdgeLabelPredictionTransformer=loaded[
+                "edge_label_prediction_transformer"].EdgeLabelPredictionTransformer,
+            NodeLabelPredictionTransformer=loaded[
+                "node_label_prediction_transformer"].NodeLabelPredictionTransformer)
+        return transformer_cases(T, StandInGraph()), prediction_cases(T, StandInGraph)
     finally:
         for name in added:
             del sys.modules[name]
@@ -249,12 +346,12 @@ def transformer_fixture():
 if __name__ == "__main__":
     import numpy as np
 
-    cases = transformer_fixture()
-    np.savez_compressed(os.path.join(HERE, "transformer_cases.npz"),
-                        **{k: v for k, v in cases.items() if not isinstance(v, str)})
-    with open(os.path.join(HERE, "transformer_cases.json"), "w") as f:
-        json.dump({k: v for k, v in cases.items() if isinstance(v, str)}, f, indent=1,
-                  sort_keys=True)
+    for stem, cases in zip(("transformer_cases", "prediction_cases"), transformer_fixture()):
+        np.savez_compressed(os.path.join(HERE, stem + ".npz"),
+                            **{k: v for k, v in cases.items() if not isinstance(v, str)})
+        with open(os.path.join(HERE, stem + ".json"), "w") as f:
+            json.dump({k: v for k, v in cases.items() if isinstance(v, str)}, f, indent=1,
+                      sort_keys=True)
 
     np.savez_compressed(os.path.join(HERE, "edge_embedding_cases.npz"), **edge_embedding_cases())
     with open(os.path.join(HERE, "embedding_result_cases.json"), "w") as f:

@@ -386,3 +386,154 @@ def transformer_cases(T, graph, only=None):
         except Exception as e:  # noqa: BLE001
             out[name] = type(e).__name__
     return out
+
+
+def prediction_graph_specs():
+    """Small graphs for the prediction transformers: name -> dict(names, edges, directed,
+    edge_types (one label per listed edge, None = unknown; or None), node_types (one label, a list
+    of labels or None per node; or None))."""
+    names, edges, edge_types, node_types = transformer_graph_spec()
+    n = len(names)
+    negative = [(0, 5), (1, 7), (2, 9), (4, 10), (6, 11), (8, 8), (1, 10)]
+    directed_edges = [(0, 1), (1, 0), (1, 2), (2, 5), (5, 2), (3, 4), (4, 6), (6, 7), (7, 3),
+                      (8, 9), (9, 11), (11, 10), (10, 8), (2, 2), (0, 7)]
+    directed_types = ["a", "b", None, "c", "a", "b", "a", None, "c", "b", "a", "c", "b", "a", "c"]
+    single = ["x", "y", None, "x", "z", "y", "z", "x", None, "y", "z", "x"]
+    two_types = ["p" if k % 3 else "q" for k in range(len(directed_edges))]
+    two_types[0] = "p"  # vocabulary order p, q
+    unbalanced_edges = [(i, (i + k) % n) for k in (1, 2, 3) for i in range(n)]
+    unbalanced_types = ["common"] * len(unbalanced_edges)
+    unbalanced_types[5] = unbalanced_types[17] = "rare"
+    return {
+        "base": dict(names=names, edges=edges, directed=False, edge_types=edge_types,
+                     node_types=node_types),
+        "negative": dict(names=names, edges=negative, directed=False, edge_types=None,
+                         node_types=node_types),
+        "smaller": dict(names=names[:9], edges=[(0, 1), (2, 3), (4, 8)], directed=False,
+                        edge_types=None, node_types=node_types[:9]),
+        "directed": dict(names=names, edges=directed_edges, directed=True,
+                         edge_types=directed_types, node_types=single),
+        "two": dict(names=names, edges=directed_edges, directed=True, edge_types=two_types,
+                    node_types=["u" if i % 2 else "v" for i in range(n)]),
+        "homogeneous": dict(names=names, edges=directed_edges, directed=True,
+                            edge_types=["only"] * len(directed_edges), node_types=["only"] * n),
+        "untyped": dict(names=names, edges=directed_edges, directed=True, edge_types=None,
+                        node_types=None),
+        "unknown": dict(names=names, edges=directed_edges, directed=True,
+                        edge_types=[None] * len(directed_edges), node_types=[None] * n),
+        "multigraph": dict(names=names, edges=directed_edges + [(0, 1)], directed=True,
+                           edge_types=directed_types + ["c"], node_types=single),
+        "unbalanced": dict(names=names, edges=unbalanced_edges, directed=True,
+                           edge_types=unbalanced_types, node_types=single),
+    }
+
+
+def prediction_cases(T, make_graph, only=None):
+    """Outcome of every scenario of the three prediction transformers (EdgePrediction-,
+    EdgeLabelPrediction-, NodeLabelPredictionTransformer of the namespace `T`): the (X, y) pair
+    as one float64 array [rows, features + labels], or the exception type name.  `make_graph`
+    builds the implementation's graph object from a prediction_graph_specs() entry."""
+    import warnings
+
+    i = transformer_inputs()
+    X, Y, TF, dfX = i["X"], i["Y"], i["TF"], i["dfX"]
+    G = {name: make_graph(spec) for name, spec in prediction_graph_specs().items()}
+    rng = np.random.RandomState(5)
+    pairs_pos = [[0, 1], [2, 3], [5, 5], [7, 9]]
+    pairs_neg = np.array([[1, 4], [6, 2], [10, 0]])
+
+    def ep(methods, aligned, both, *fit_args, **fit_kwargs):
+        t = T.EdgePredictionTransformer(methods=methods, aligned_mapping=aligned,
+                                        include_both_undirected_edges=both)
+        t.fit(*fit_args, **fit_kwargs)
+        return t
+
+    def el(methods, aligned, both, *fit_args, **fit_kwargs):
+        t = T.EdgeLabelPredictionTransformer(methods=methods, aligned_mapping=aligned,
+                                             include_both_undirected_edges=both)
+        t.fit(*fit_args, **fit_kwargs)
+        return t
+
+    def nl(aligned, feature):
+        t = T.NodeLabelPredictionTransformer(aligned_mapping=aligned)
+        t.fit(feature)
+        return t
+
+    n_base, n_neg = 29, 13  # directed edges of "base" and "negative"
+    extra = rng.normal(size=(n_base + n_neg, 2))
+    extra_lists = rng.normal(size=(len(pairs_pos) + len(pairs_neg), 3))
+    extra_directed = rng.normal(size=(16, 2))
+    cases = {
+        # ---- EdgePredictionTransformer
+        "ep_graphs": lambda: ep("Hadamard", True, True, X).transform(G["base"], G["negative"]),
+        "ep_graphs_upper": lambda: ep("L1", True, False, X).transform(G["base"], G["negative"]),
+        "ep_two_methods": lambda: ep(["Sum", "CosineSimilarity"], True, True, [X, Y]).transform(
+            G["base"], G["negative"]),
+        "ep_lists": lambda: ep("Average", True, True, X).transform(pairs_pos, pairs_neg),
+        "ep_graph_and_list": lambda: ep("Average", True, True, X).transform(G["base"], pairs_neg),
+        "ep_unaligned": lambda: ep("Concatenate", False, True, dfX).transform(G["base"], G["negative"]),
+        "ep_shuffle": lambda: ep("Hadamard", True, True, X).transform(
+            G["base"], G["negative"], shuffle=True, random_state=7),
+        "ep_shuffle_default_seed": lambda: ep("Hadamard", True, True, X).transform(
+            pairs_pos, pairs_neg, shuffle=True),
+        "ep_node_type_features": lambda: ep("L2", True, True, X, node_type_feature=TF).transform(
+            G["base"], G["negative"]),
+        "ep_edge_features": lambda: ep("Min", True, True, X).transform(
+            G["base"], G["negative"], edge_features=extra),
+        "ep_edge_features_lists": lambda: ep("Max", True, True, X).transform(
+            pairs_pos, pairs_neg, edge_features=[extra_lists, extra_lists[:, :1]]),
+        "ep_edge_features_rows_error": lambda: ep("Min", True, True, X).transform(
+            pairs_pos, pairs_neg, edge_features=extra_lists[:-1]),
+        "ep_edge_features_kind_error": lambda: ep("Min", True, True, X).transform(
+            pairs_pos, pairs_neg, edge_features=[extra_lists.tolist()]),
+        "ep_incompatible_error": lambda: ep("Sum", True, True, X).transform(G["base"], G["smaller"]),
+        "ep_typed_vs_untyped_error": lambda: ep("Sum", True, True, X).transform(
+            G["directed"], G["untyped"]),
+        "ep_not_fit_error": lambda: T.EdgePredictionTransformer().transform(pairs_pos, pairs_neg),
+        # ---- EdgeLabelPredictionTransformer
+        "el_directed_drop_by_default": lambda: el("Hadamard", True, True, X).transform(G["directed"]),
+        "el_directed_drop": lambda: el("Sum", True, True, [X, Y]).transform(
+            G["directed"], behaviour_for_unknown_edge_labels="drop"),
+        "el_directed_keep": lambda: el("Sum", True, True, X).transform(
+            G["directed"], behaviour_for_unknown_edge_labels="keep"),
+        "el_two_types_boolean": lambda: el("L1", True, True, X).transform(G["two"]),
+        "el_undirected_upper": lambda: el("Hadamard", True, False, X).transform(G["base"]),
+        "el_undirected_both": lambda: el("Hadamard", True, True, X).transform(G["base"]),
+        "el_unaligned": lambda: el("Average", False, True, dfX).transform(G["two"]),
+        "el_unbalanced": lambda: el("Hadamard", True, True, X).transform(G["unbalanced"]),
+        "el_edge_features": lambda: el("Hadamard", True, True, X).transform(
+            G["two"], edge_features=extra_directed[:15]),
+        "el_untyped_error": lambda: el("Sum", True, True, X).transform(G["untyped"]),
+        "el_unknown_only_error": lambda: el("Sum", True, True, X).transform(G["unknown"]),
+        "el_homogeneous_error": lambda: el("Sum", True, True, X).transform(G["homogeneous"]),
+        "el_multigraph_error": lambda: el("Sum", True, True, X).transform(G["multigraph"]),
+        # ---- NodeLabelPredictionTransformer
+        "nl_multilabel_drop_by_default": lambda: nl(True, X).transform(G["base"]),
+        "nl_multilabel_keep": lambda: nl(True, X).transform(
+            G["base"], behaviour_for_unknown_node_labels="keep"),
+        "nl_single_label": lambda: nl(True, [X, Y]).transform(G["directed"]),
+        "nl_single_label_keep": lambda: nl(True, X).transform(
+            G["directed"], behaviour_for_unknown_node_labels="keep"),
+        "nl_unaligned": lambda: nl(False, dfX).transform(G["two"]),
+        "nl_shuffle": lambda: nl(True, X).transform(
+            G["directed"], behaviour_for_unknown_node_labels="drop", shuffle=True, random_state=3),
+        "nl_untyped_error": lambda: nl(True, X).transform(G["untyped"]),
+        "nl_unknown_only_error": lambda: nl(True, X).transform(G["unknown"]),
+        "nl_homogeneous_error": lambda: nl(True, X).transform(G["homogeneous"]),
+        "nl_not_fit_error": lambda: T.NodeLabelPredictionTransformer().transform(G["two"]),
+    }
+    out = {}
+    for name, fn in cases.items():
+        if only is not None and not only(name):
+            continue
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                x, y = fn()
+            y = np.asarray(y, dtype=np.float64)
+            out[name] = np.hstack([np.asarray(x, dtype=np.float64), y.reshape(len(y), -1)])
+        except AssertionError:
+            out[name] = "AssertionError"
+        except Exception as e:  # noqa: BLE001
+            out[name] = type(e).__name__
+    return out
