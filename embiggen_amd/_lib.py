@@ -27,6 +27,7 @@ TRAIN_WRITE_THROUGH = 64
 TRAIN_NO_CTX_CACHE = 128
 TRAIN_CTX_CACHE_ALL = 256
 TRAIN_LOCAL_ATOMIC = 512
+BLOCK_PATH_MIN_NODES = 2560  # GN2V_BLOCK_PATH_MIN_NODES
 TRAIN_WALK_ORDERED = 1024
 TRAIN_BLOCK_PATH = 2048
 TRAIN_CENTRAL_ATOMIC = 4096

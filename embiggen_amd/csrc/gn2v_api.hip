@@ -928,13 +928,14 @@ int gn2v_train(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_param
         stats->block_round_walks = 0;
     }
 
-    // SkipGram on large graphs in the default update mode: the block path (contextual rows in
-    // XCD-exclusive cells)
+    // SkipGram in the default update mode, unless the graph is tiny: the block path (contextual
+    // rows in XCD-exclusive cells)
     const uint32_t explicit_mode = GN2V_TRAIN_DETERMINISTIC | GN2V_TRAIN_ATOMIC |
                                    GN2V_TRAIN_WRITE_BACK | GN2V_TRAIN_WRITE_THROUGH |
                                    GN2V_TRAIN_WALK_ORDERED;
     if (!cbow && ((tp->flags & GN2V_TRAIN_BLOCK_PATH) ||
-                  (!(tp->flags & explicit_mode) && g->view.n_nodes >= (1ULL << 16)))) {
+                  (!(tp->flags & explicit_mode) &&
+                   g->view.n_nodes >= GN2V_BLOCK_PATH_MIN_NODES))) {
         const int rc = gn2v_train_blocks(g, wp, tp, seed, max_walks_per_epoch, 0, 0, d_central,
                                          d_contextual, stats, stream);
         // 2 = device memory ran out before anything was trained (alias tables, pair buffers): the

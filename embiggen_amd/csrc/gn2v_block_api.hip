@@ -381,17 +381,21 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     // write-back stores, else write-through.  Central rows: the gradient of a whole record is added with hardware
     // f32 atomics (one row per ~record * (k + 1) sample rows: free, and the records of a hub centre
     // that many waves train at once lose no update).  Small graphs: atomics everywhere.
-    int wmc = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
-              : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
-              : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
-              : g->view.n_nodes < (1ULL << 16)         ? gn2v::kAtomic
-                                                       : gn2v::kWriteThrough;
-    int wmx = wmc;
     // One XCD per slice -- the kernel maps XCD x to the slices x, x + n_xcds, ... -- holds only
     // when the slices are a multiple of the XCDs the workgroups are spread over (8 on an MI355X).
     // With 2 or 4 slices several XCDs (non-coherent L2s) read-modify-write the same rows: they
-    // keep the write-through stores, as do unsliced parts.
+    // keep the write-through stores, as do unsliced parts (atomics on small graphs, where all
+    // wavefronts meet on the same few rows: exclusive slices divide that crowd by the XCDs and
+    // keep it inside one L2, which is why they need no atomics from GN2V_BLOCK_PATH_MIN_NODES up).
     const bool exclusive = slices_are_xcd_exclusive(g, d.slices);
+    int wmc = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
+              : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
+              : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
+              : (g->view.n_nodes < (1ULL << 16) &&
+                 !(exclusive && g->view.n_nodes >= GN2V_BLOCK_PATH_MIN_NODES))
+                  ? gn2v::kAtomic
+                  : gn2v::kWriteThrough;
+    int wmx = wmc;
     if (wmc == gn2v::kWriteThrough && exclusive)
         wmx = (tp->flags & GN2V_TRAIN_LOCAL_ATOMIC) ? gn2v::kLocalAtomic : gn2v::kWriteBack;
     a.xcds = (uint32_t)g->n_xcds;
@@ -465,7 +469,12 @@ int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t *parts, uint
     // write-back stores, hub rows L2 resident); 2 or 4 slices would have several XCDs share a
     // slice and fall back to write-through stores without the locality.
     const uint64_t min_parts = world > 1 ? 2ull * world : 1;
-    const uint64_t sl = n_nodes / (min_parts * kXcds) >= kMinRows / 4 ? kXcds : 1;
+    // One GPU: from GN2V_BLOCK_PATH_MIN_NODES nodes up (a single part: the slices only divide the
+    // rows among the XCDs, nothing concentrates in time).  Travelling parts: cells of 8 k rows.
+    const uint64_t sl = (world == 1 ? n_nodes >= GN2V_BLOCK_PATH_MIN_NODES
+                                    : n_nodes / (min_parts * kXcds) >= kMinRows / 4)
+                            ? kXcds
+                            : 1;
     // Parts: as many as keep kMinRows rows in a cell (any count: 10 M nodes -> 38, 100 M -> 381);
     // a multiple of the ranks when they travel, at least two per rank.
     uint64_t p = n_nodes / (sl * kMinRows);

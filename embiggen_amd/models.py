@@ -126,7 +126,7 @@ class _WalkBasedModel:
         if not 1 <= min_distance <= window_size:
             raise ValueError("min_distance must be in [1, window_size].")
         self.min_distance = int(min_distance)
-        # None: the engine decides (SkipGram, >= 2^16 nodes, default update mode: block path);
+        # None: the engine decides (SkipGram, >= 2 560 nodes, default update mode: block path);
         # True / False force or forbid it
         self.block_path = block_path
         self.last_plan = None
@@ -226,11 +226,12 @@ class _WalkBasedModel:
             )
         return central, contextual, self.last_stats
 
-    # SkipGram on graphs of >= 2^16 nodes in the default update mode is trained through the block
-    # path on one GPU as well (gn2v_train decides; contextual rows in XCD-exclusive cells: 0.93
-    # instead of 0.70 of the HBM roofline at 10 M nodes, link quality at or above the walk-ordered
-    # schedule's)
-    BLOCK_PATH_MIN_NODES = 1 << 16
+    # SkipGram on graphs of >= GN2V_BLOCK_PATH_MIN_NODES nodes in the default update mode is
+    # trained through the block path on one GPU as well (gn2v_train decides; contextual rows in
+    # XCD-exclusive cells: 1.0 instead of 0.70 of the HBM roofline at 10 M nodes, 22 x the speed
+    # of atomics at 2 708 nodes, link quality at or above the walk-ordered schedule's; DESIGN.md
+    # section 7)
+    BLOCK_PATH_MIN_NODES = _lib.BLOCK_PATH_MIN_NODES
 
     def fit_transform_blocks(self, graph, comm, round_walks: Optional[int] = None, slices=None,
                              parts=None, overlap: bool = True, max_walks_per_epoch: int = 0,

@@ -43,11 +43,13 @@ extern "C" {
 #define GN2V_TRAIN_DOWNSAMPLE 2u     /* stochastic_downsample_by_degree (:97-98)                */
 #define GN2V_TRAIN_NORM_LR 4u        /* normalize_learning_rate_by_degree (:99-100)             */
 #define GN2V_TRAIN_DETERMINISTIC 8u  /* one wavefront, strict walk order: oracle-exact, slow    */
-/* How row updates reach memory.  With none of the three bits set the engine picks: graphs below
- * 2^16 nodes (where thousands of concurrent wavefronts collide on the same rows all the time:
- * measured CBOW link AUROC 0.80 vs 0.99 at 1 k nodes, equal from 16 k nodes up) use atomics,
- * larger ones Hogwild write-through stores (the CPU reference is racy by design as well; 2x the
- * speed of atomics, DESIGN.md "Update modes"). */
+/* How row updates reach memory.  With none of the three bits set the engine picks: the
+ * walk-ordered kernels use atomics on graphs below 2^16 nodes (where thousands of concurrent
+ * wavefronts collide on the same rows all the time: measured CBOW link AUROC 0.80 vs 0.99 at 1 k
+ * nodes, equal from 16 k nodes up) and Hogwild write-through stores on larger ones (the CPU
+ * reference is racy by design as well; 2x the speed of atomics, DESIGN.md "Update modes"); the
+ * block path uses plain stores on contextual rows that are exclusive to one XCD and atomics per
+ * run of equal centre on the central rows at every size. */
 #define GN2V_TRAIN_ATOMIC 16u        /* hardware f32 atomics on every element: no lost update   */
 #define GN2V_TRAIN_WRITE_BACK 32u    /* read-modify-write, plain L2 write-back stores            */
 #define GN2V_TRAIN_WRITE_THROUGH 64u /* read-modify-write, 16 B write-through (sc1) stores       */
@@ -60,8 +62,13 @@ extern "C" {
  * their updates can be f32 atomics executed inside that XCD's L2 (workgroup scope): no lost
  * update, no trip to memory. */
 #define GN2V_TRAIN_LOCAL_ATOMIC 512u
-/* gn2v_train picks its schedule: SkipGram on graphs of >= 2^16 nodes in the default update mode
- * runs the block path (gn2v_train_blocks), everything else the walk-ordered kernels.  Overrides: */
+/* gn2v_train picks its schedule: SkipGram on graphs of >= GN2V_BLOCK_PATH_MIN_NODES nodes in the
+ * default update mode runs the block path (gn2v_train_blocks; one part of 8 XCD slices up to 2^18
+ * nodes), everything else the walk-ordered kernels.  The limit is where the link quality of the
+ * block path meets that of atomics on every row (BA graphs, 30 epochs: cosine AUROC 0.9959 vs
+ * 0.9966 at 2 708 nodes, 0.989 vs 0.994 at 2 048, 0.88 vs 0.96 at 512) -- at 22 x the speed:
+ * thousands of wavefronts adding to the same few rows serialise in the atomic units.  Overrides: */
+#define GN2V_BLOCK_PATH_MIN_NODES 2560u
 #define GN2V_TRAIN_WALK_ORDERED 1024u /* never the block path                                    */
 #define GN2V_TRAIN_BLOCK_PATH 2048u   /* always the block path (SkipGram; with
                                          GN2V_TRAIN_DETERMINISTIC: its sequential schedule)      */
@@ -391,7 +398,8 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
  * the end through one scratch copy; GN2V_BLOCK_LAYOUT=natural in the environment, or too little
  * free memory for that copy, trains it in node order with strided parts instead).  Returns 2
  * when device memory ran out before anything was trained.  gn2v_train calls this for SkipGram on
- * graphs of >= 2^16 nodes and falls back to the walk-ordered schedule on that 2. */
+ * graphs of >= GN2V_BLOCK_PATH_MIN_NODES nodes and falls back to the walk-ordered schedule on
+ * that 2. */
 int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
                       uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
                       uint32_t stripes, float *d_central, float *d_contextual, gn2v_stats *stats,

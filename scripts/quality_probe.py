@@ -75,7 +75,12 @@ if __name__ == "__main__":
             f = mode.split(":")
             parts, slices = int(f[1]), int(f[2])
             record = int(f[3]) if len(f) > 3 and f[3] else 32
-            extra = _lib.TRAIN_LOCAL_ATOMIC if len(f) > 4 and f[4] == "la" else 0
+            # 5th field: "la" = L2-local atomics on the XCD-exclusive contextual rows, "st" = plain
+            # stores there; both name the store flavour explicitly, so they also apply below 2^16
+            # nodes, where the automatic choice is atomics on every row
+            kind = f[4] if len(f) > 4 else ""
+            extra = {"": 0, "la": _lib.TRAIN_LOCAL_ATOMIC | _lib.TRAIN_WRITE_THROUGH,
+                     "st": _lib.TRAIN_WRITE_THROUGH}[kind]
             if a.central_atomic:
                 extra |= _lib.TRAIN_CENTRAL_ATOMIC
             tp = ops.train_params(0, d, 10, 5, flags=1 | extra, ld=d)

@@ -54,12 +54,19 @@ def test_struct_layouts_match_header():
 
 def test_automatic_plan_of_the_block_path():
     """gn2v_block_auto_plan (pure host function: no GPU needed): one slice per XCD (8) or none --
-    never 2 or 4, which would have several XCDs share a slice --, cells of >= 32 768 rows, any
-    number of parts (a multiple of the ranks, at least two per rank)."""
+    never 2 or 4, which would have several XCDs share a slice --, cells of >= 32 768 rows once
+    there are several parts, any number of parts (a multiple of the ranks, at least two per
+    rank)."""
     from embiggen_amd.distributed import auto_plan
 
     assert auto_plan(34, 1) == (1, 1) and auto_plan(34, 8) == (16, 1)
-    assert auto_plan(40_000, 1) == (1, 1)
+    # one GPU: a single part in 8 slices from GN2V_BLOCK_PATH_MIN_NODES nodes up (where gn2v_train
+    # starts to use the block path); travelling parts keep cells of >= 8 192 rows
+    from embiggen_amd import _lib
+    assert _lib.BLOCK_PATH_MIN_NODES == 2560
+    assert auto_plan(2_559, 1) == (1, 1) and auto_plan(2_560, 1) == (1, 8)
+    assert auto_plan(2_708, 1) == (1, 8) and auto_plan(40_000, 1) == (1, 8)
+    assert auto_plan(40_000, 2) == (4, 1)
     assert auto_plan(65_536, 1) == (1, 8) and auto_plan(169_343, 1) == (1, 8)
     assert auto_plan(262_144, 1) == (1, 8) and auto_plan(1_000_000, 1) == (3, 8)
     assert auto_plan(2_449_029, 1) == (9, 8) and auto_plan(2_449_029, 8) == (16, 8)

@@ -642,12 +642,15 @@ def test_gn2v_train_blocks_with_stripes_equals_the_python_trainer(stripes, round
     assert float((c1 - c2).abs().max()) < 1e-5 and float((x1 - x2).abs().max()) < 1e-5
 
 
-def test_gn2v_train_takes_the_block_path_by_itself_from_two_to_the_sixteen_nodes():
-    small, large = E.barabasi_albert(60_000, 5, 1), E.barabasi_albert(70_000, 5, 1)
+def test_gn2v_train_takes_the_block_path_by_itself_from_2560_nodes():
+    """GN2V_BLOCK_PATH_MIN_NODES: below it the walk-ordered kernel with atomics on every row, from
+    it up one part of 8 XCD slices (plain stores on the XCD-exclusive contextual rows)."""
+    assert E.models.SkipGram.BLOCK_PATH_MIN_NODES == _lib.BLOCK_PATH_MIN_NODES == 2560
+    small, large = E.barabasi_albert(2_559, 3, 1), E.barabasi_albert(2_560, 3, 1)
     kw = dict(embedding_size=16, epochs=1, iterations=1, walk_length=16, window_size=3,
               verbose=False)
     for g, plan in ((small, None), (large, {"world": 1, "parts": 1, "slices": 8, "stripes": 1,
-                                            "group_parts": 1, "round_walks": 70_000})):
+                                            "group_parts": 1, "round_walks": 2_560})):
         for cls in (E.models.SkipGram, E.models.CBOW):
             m = cls(**kw)
             c, x, st = m.fit_transform_device(g)
@@ -1023,3 +1026,29 @@ def test_pair_per_group_path_adds_shared_centres_with_atomics(d):
     st = ops.stats_read(g)
     assert st["pairs"] == slices * per_cell == st["centres"]  # one hand-over per pair: that path
     assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5 and np.abs(x.cpu().numpy() - x_h).max() < 2e-5
+
+
+def test_small_graph_through_the_block_path_learns_what_atomics_learn():
+    """A graph the size of Cora (2 708 nodes: BASELINE config 1's shape) takes the block path by
+    default since GN2V_BLOCK_PATH_MIN_NODES = 2 560: one part of 8 XCD slices, plain stores on the
+    contextual rows.  Same walks, 10 epochs: link AUROC (symmetrised c.x over all node pairs, and
+    cosine of the central vectors) within 0.004 of atomics on every row, which it replaces at
+    20 x the speed (profiles/r03_logs/r3_small_quality*.log)."""
+    from sklearn.metrics import roc_auc_score
+
+    from helpers import adjacency, cosine_matrix, link_auc
+
+    g = E.barabasi_albert(2708, 2, 42)
+    kw = dict(embedding_size=128, epochs=10, verbose=False)
+    got = {}
+    for name, extra in (("blocks", {}), ("atomic", {"update_mode": "atomic"})):
+        m = E.models.SkipGram(**kw, **extra)
+        c, x, st = m.fit_transform_device(g)
+        assert (m.last_plan is not None) == (name == "blocks")
+        assert st["pairs"] == 10 * 27080 * 1250
+        c, x = c[:, :128].cpu().numpy(), x[:, :128].cpu().numpy()
+        assert np.isfinite(c).all() and np.isfinite(x).all()
+        iu = np.triu_indices(2708, 1)
+        got[name] = (link_auc(g, c, x), float(roc_auc_score(adjacency(g)[iu], cosine_matrix(c)[iu])))
+    assert got["atomic"][0] > 0.98 and got["atomic"][1] > 0.98
+    assert got["blocks"][0] > got["atomic"][0] - 0.004 and got["blocks"][1] > got["atomic"][1] - 0.004
