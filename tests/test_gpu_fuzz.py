@@ -3,6 +3,7 @@ over random graphs (directed / undirected, weighted, typed, trap nodes) and rand
 through the public model classes.  Walks must be bit-exact, fits equal to float tolerance."""
 import numpy as np
 import pytest
+import torch
 
 import embiggen_amd as E
 from embiggen_amd import _lib, models, ops
@@ -177,3 +178,54 @@ def test_random_block_rounds_match_oracle(case):
         torch.cuda.synchronize()
         assert np.abs(x.cpu().numpy() - x_h).max() < 2e-5, (part,)
     assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5
+
+
+def mid_graph(rng):
+    """Random graph in the range where the default SkipGram fit takes the block path on one part
+    of 8 XCD slices (GN2V_BLOCK_PATH_MIN_NODES <= n < 2^16): directed or not, weighted or not,
+    with nodes nobody points to (never drawn as negatives, some never visited)."""
+    n = int(rng.randint(_lib.BLOCK_PATH_MIN_NODES, 6000))
+    e = int(rng.randint(n, 4 * n))
+    src, dst = rng.randint(0, n, e), rng.randint(0, n - n // 10, e)
+    directed = bool(rng.rand() < 0.5)
+    weights = rng.uniform(0.05, 4.0, e) if rng.rand() < 0.5 else None
+    return E.CSRGraph.from_edge_list(src, dst, weights, number_of_nodes=n, directed=directed)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_default_fit_on_the_block_path_does_the_work_of_the_strict_one(case):
+    """The parallel default (block path: pairs extracted and sorted by cell, negatives drawn inside
+    the context's cell) against the strict walk-ordered schedule on the same random graph and
+    parameters: the same number of training pairs, finite tables, a change from the initial
+    tables of the same size (the samples differ, so the tables do not agree element by element),
+    and rows of nodes no walk visits and no negative can hit left exactly as initialised."""
+    rng = np.random.RandomState(3000 + case)
+    g = mid_graph(rng)
+    n = g.get_number_of_nodes()
+    L, w = int(rng.randint(2, 24)), int(rng.randint(1, 6))
+    kw = dict(embedding_size=int(rng.choice([8, 33, 64, 128])), random_state=int(rng.randint(0, 2 ** 31)),
+              epochs=int(rng.randint(1, 3)), walk_length=L, iterations=1, window_size=w,
+              min_distance=int(rng.randint(1, w + 1)), number_of_negative_samples=int(rng.randint(0, 6)),
+              return_weight=float(rng.choice([0.25, 1.0, 4.0])), explore_weight=float(rng.choice([0.25, 1.0, 4.0])),
+              learning_rate=0.01, use_scale_free_distribution=bool(rng.rand() < 0.7),
+              stochastic_downsample_by_degree=bool(rng.rand() < 0.3),
+              normalize_learning_rate_by_degree=bool(rng.rand() < 0.3), verbose=False)
+    fast, strict = models.SkipGram(**kw), models.SkipGram(deterministic=True, **kw)
+    c1, x1, st1 = fast.fit_transform_device(g)
+    c0, x0, st0 = strict.fit_transform_device(g)
+    assert fast.last_plan is not None and fast.last_plan["slices"] == 8 and strict.last_plan is None
+    assert st1["pairs"] == st0["pairs"]  # 0 when min_distance exceeds what a walk of L nodes holds
+    d, ld = kw["embedding_size"], fast.padded_size
+    init_c = ops.init_table(n, d, kw["random_state"], 0, d ** -0.5, ld=ld)
+    init_x = ops.init_table(n, d, kw["random_state"], 1, d ** -0.5, ld=ld)
+    for got, want, init in ((c1, c0, init_c), (x1, x0, init_x)):
+        assert bool(torch.isfinite(got).all())
+        moved, should = float((got - init).norm()), float((want - init).norm())
+        assert 0.5 * should <= moved <= 2.0 * should, (moved, should)
+        assert (st0["pairs"] == 0) == (moved == 0.0)
+    # nodes that start no walk and that no edge points to: never a centre, a context or a negative
+    indeg = np.bincount(g.col_idx, minlength=n)
+    outdeg = np.diff(g.row_ptr.astype(np.int64))
+    idle = torch.from_numpy(np.flatnonzero((indeg == 0) & (outdeg == 0))).cuda()
+    if kw["use_scale_free_distribution"] and len(idle):
+        assert torch.equal(c1[idle], init_c[idle]) and torch.equal(x1[idle], init_x[idle])
