@@ -564,7 +564,13 @@ def main():
             sched_bytes = row_bytes * (st["pairs"] * 11 + st["centres"])
         scheduled = sched_bytes / (st["train_ms"] * 1e-3) / 1e9
         if cbow:
-            kernel = "gn2v::cbow_lazy_kernel" if n >= (1 << 16) else "gn2v::cbow_kernel"
+            # mirror of launch_train's choice (gn2v_api.hip): the lazy window needs its LDS --
+            # 4 waves x ((2w + 3) rows + walk + samples + bookkeeping) words -- within 64 KB
+            lazy_words = (13 * ld + 128 + 2 * 11 + 10 + 33 + 3) & ~3
+            store_mode = args.mode in ("write_through", "write_back") or (
+                args.mode == "auto" and n >= (1 << 16))
+            kernel = ("gn2v::cbow_lazy_kernel" if store_mode and 16 * lazy_words <= 64 * 1024
+                      else "gn2v::cbow_kernel")
         elif blocks is not None:
             kernel = "gn2v::sgns_block_kernel"
         elif n >= (1 << 16) and args.mode in ("auto", "write_through", "write_back"):

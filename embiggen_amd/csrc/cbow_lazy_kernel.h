@@ -36,6 +36,25 @@
 #ifndef GN2V_CBOW_LAZY_MIN_BLOCKS
 #define GN2V_CBOW_LAZY_MIN_BLOCKS 4
 #endif
+// Wider rows (CH = 4 / 8 / 16: d up to 256 / 512 / 1024) hold 4 * CH registers per row vector:
+// under the 128-register cap they spilled 184 / 570 / 1 500 B per lane.  Their caps follow the
+// rows and the LDS the window takes (64 KB budget: three workgroups per CU up to ~ 230 floats per
+// row, two at 256).  Same box, BA 1 M, centres/s at d = 160 / 200 / 256: cap 4 1.75 / 1.29 /
+// 1.14e8, cap 3 1.93 / 1.65 / 1.56e8, cap 2 1.61 / 1.38 / 1.61e8 (uncached kernel: 1.75 / 1.39 /
+// 1.31e8) -> 3, and 2 for the rows of exactly 256 floats (FULL).  CH = 8 / 16 never run today
+// (their windows exceed the LDS budget; the uncached kernel serves d > 256).
+#ifndef GN2V_CBOW_LAZY_MIN_BLOCKS_CH4
+#define GN2V_CBOW_LAZY_MIN_BLOCKS_CH4 3
+#endif
+#ifndef GN2V_CBOW_LAZY_MIN_BLOCKS_CH4_FULL
+#define GN2V_CBOW_LAZY_MIN_BLOCKS_CH4_FULL 2
+#endif
+#ifndef GN2V_CBOW_LAZY_MIN_BLOCKS_CH8
+#define GN2V_CBOW_LAZY_MIN_BLOCKS_CH8 2
+#endif
+#ifndef GN2V_CBOW_LAZY_MIN_BLOCKS_CH16
+#define GN2V_CBOW_LAZY_MIN_BLOCKS_CH16 1
+#endif
 
 namespace gn2v {
 
@@ -69,7 +88,12 @@ __device__ __forceinline__ void row_axpy(Row<CH> &acc, float s, const Row<CH> &x
 // FULL: the row stride is exactly CH * 64 floats (d = 128 -> CH = 2): ld becomes a compile-time
 // constant and the per-chunk bounds predicates fold away (fewer instructions, fewer SGPR masks).
 template <int CH, int WM, bool FULL = false>
-__global__ __launch_bounds__(kTrainBlock, GN2V_CBOW_LAZY_MIN_BLOCKS) void cbow_lazy_kernel(TrainArgs a) {
+__global__ __launch_bounds__(kTrainBlock, (CH <= 2   ? GN2V_CBOW_LAZY_MIN_BLOCKS
+                                          : CH == 4 ? (FULL ? GN2V_CBOW_LAZY_MIN_BLOCKS_CH4_FULL
+                                                            : GN2V_CBOW_LAZY_MIN_BLOCKS_CH4)
+                                          : CH == 8 ? GN2V_CBOW_LAZY_MIN_BLOCKS_CH8
+                                                    : GN2V_CBOW_LAZY_MIN_BLOCKS_CH16)) void
+cbow_lazy_kernel(TrainArgs a) {
     if constexpr (FULL) a.ld = CH * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -252,9 +252,21 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
                                 (cbow ? 2 * tp->window + slots : 0) + 2 * slots + 3) &
                                ~(size_t)3;
     const size_t cache_lds = (size_t)waves_per_block * cache_words * 4;
-    const bool use_cache = !det && wm != gn2v::kAtomic && !a.split && !a.ctx_delta &&
+    // LDS budget of a workgroup of the caching kernels: 40 KB leaves room for four of them per CU
+    // (160 KB).  The lazy CBOW window may take up to 64 KB -- rows of 132-256 floats, three or two
+    // workgroups per CU, which is what their registers allow anyway: + 19 % at d = 200, + 9 % at
+    // d = 256 over the uncached kernel on one box; the eager window cache loses there (-5 %).
+    // GN2V_CTX_CACHE_LDS_KB / GN2V_CBOW_LAZY_LDS_KB override both budgets (A/B, up to 64).
+    static const auto budget_kb = [](const char *name, long def) {
+        const char *e = getenv(name);
+        const long kb = e ? atol(e) : def;
+        return (size_t)(kb < 1 ? 1 : kb > 64 ? 64 : kb) * 1024;
+    };
+    static const size_t cache_budget = budget_kb("GN2V_CTX_CACHE_LDS_KB", 40);
+    static const size_t lazy_budget = budget_kb("GN2V_CBOW_LAZY_LDS_KB", 64);
+    const bool cacheable = !det && wm != gn2v::kAtomic && !a.split && !a.ctx_delta &&
                            !a.walk_rows && !a.neg_pool && !(tp->flags & GN2V_TRAIN_NO_CTX_CACHE) &&
-                           cache_lds <= 40 * 1024 && L > 2 * tp->window &&
+                           L > 2 * tp->window &&
                            (!cbow || slots <= gn2v::kWinCacheMaxSlots) &&
                            g->view.n_nodes < (1ULL << 30);  // row ids share a word with kCacheBit
     // CBOW, ordinary windows: the lazy form of the window cache (cbow_lazy_kernel.h)
@@ -270,7 +282,8 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     }();
     static const bool no_full = getenv("GN2V_BLOCK_NO_FULL") != nullptr;
     const bool use_lazy =
-        use_cache && cbow && a.min_dist == 1 && lazy_lds <= 40 * 1024 && !lazy_off;
+        cacheable && cbow && a.min_dist == 1 && lazy_lds <= lazy_budget && !lazy_off;
+    const bool use_cache = use_lazy || (cacheable && cache_lds <= cache_budget);
     if (use_cache) {
         if (tp->flags & GN2V_TRAIN_CTX_CACHE_ALL) {
             a.cache_max_degree = 0xFFFFFFFFu;

@@ -429,13 +429,15 @@ def test_general_step_with_row_caches_and_negative_pool(karate, karate_oracle, m
 
 @pytest.mark.parametrize("model", [0, 1])
 @pytest.mark.parametrize("rw,ew", [(4.0, 0.25), (0.25, 4.0)])
-@pytest.mark.parametrize("d", [8, 100, 128])
+@pytest.mark.parametrize("d", [8, 100, 128, 200, 256, 288])
 def test_context_cache_is_sequentially_exact_on_real_walks(karate, karate_oracle, rw, ew, d,
                                                            model):
     """The LDS context cache with every row cached: return-heavy Karate walks revisit nodes inside
     the window (reference counts), negatives hit cached nodes (served from LDS), windows slide and
     write back.  One walk per launch must equal the sequential oracle; so must a following
-    uncached launch that re-reads everything from HBM (write-back happened)."""
+    uncached launch that re-reads everything from HBM (write-back happened).  d = 200 / 256 / 288:
+    the wide-row instantiations (CH = 4, its FULL form, CH = 8) of the lazy CBOW window, which the
+    64 KB LDS budget admits, and of the SkipGram cache up to 256."""
     k, w, L = 6, 4, 40
     ld = (d + 3) // 4 * 4
     wk = ops.walks(karate, ops.walk_params(L, 1, rw, ew), 3, 0, 0, 34)

@@ -48,6 +48,11 @@ def test_walk_ordered_kernels_keep_their_occupancy(tmp_path):
     # cbow_lazy_kernel (the CBOW default): capped at 4 waves per SIMD, at most a handful of spills
     for name, r in pick(table, "cbow_lazy_kernelILi2E").items():
         assert r["vgprs"] <= 128 and r["waves"] >= 4 and r["scratch"] <= 32, (name, r)
+    # rows of 132-256 floats (CH = 4): three workgroups per CU, two for rows of exactly 256 (FULL;
+    # its window takes 56 KB of LDS): no 128-register cap there, next to no spills
+    for name, r in pick(table, "cbow_lazy_kernelILi4E").items():
+        full = name.endswith("Lb1EEEvNS_9TrainArgsE")
+        assert r["waves"] >= (2 if full else 3) and r["scratch"] <= 32, (name, r)
     for name, r in pick(table, "sgns_cached_kernelILi2E").items():
         assert r["vgprs"] <= 102 and r["waves"] >= 5 and r["scratch"] == 0, (name, r)
     # d = 256: the cached SkipGram kernel is capped at 4 waves (2 registers spilled), GloVe runs at 4
