@@ -1,5 +1,8 @@
 #!/bin/bash
 # same-box check: default CBOW bench with today's dispatch / launch-bound changes vs the build before them
+# (ab_old_csrc/ = `git show 73e0f7c:embiggen_amd/csrc/{gn2v_api.hip,cbow_lazy_kernel.h}`, made for this run and removed after:
+#  head 3.539 / 3.540e8 centres/s, before 3.541 / 3.541e8 -- no change at d = 128; the box was 7 % slower than the one
+#  the committed r03_cbow profile was taken on)
 mkdir -p gpurun_out
 one() { timeout 900 python bench.py --model cbow --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
