@@ -568,7 +568,7 @@ def main():
             # 4 waves x ((2w + 3) rows + walk + samples + bookkeeping) words -- within 64 KB
             lazy_words = (13 * ld + 128 + 2 * 11 + 10 + 33 + 3) & ~3
             store_mode = args.mode in ("write_through", "write_back") or (
-                args.mode == "auto" and n >= (1 << 16))
+                args.mode == "auto" and n * ld >= (1 << 22))  # GN2V_CBOW_STORES_MIN_ELEMENTS
             kernel = ("gn2v::cbow_lazy_kernel" if store_mode and 16 * lazy_words <= 64 * 1024
                       else "gn2v::cbow_kernel")
         elif blocks is not None:

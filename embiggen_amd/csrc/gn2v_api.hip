@@ -230,10 +230,17 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     a.clip = tp->clip;
 
     const bool det = tp->flags & GN2V_TRAIN_DETERMINISTIC;
+    // automatic choice: atomics while the tables are small enough for the waves in flight to meet
+    // on the same rows all the time -- below 2^16 nodes for SkipGram (which leaves this kernel for
+    // the block path at GN2V_BLOCK_PATH_MIN_NODES anyway); for CBOW while a table holds fewer than
+    // GN2V_CBOW_STORES_MIN_ELEMENTS floats: narrow rows are trained faster, so more of them are
+    // in flight at once and stores need a larger graph to lose nothing (gn2v.h)
+    const bool small = cbow ? g->view.n_nodes * (uint64_t)tp->ld < GN2V_CBOW_STORES_MIN_ELEMENTS
+                            : g->view.n_nodes < (1ULL << 16);
     const int wm = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
                    : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
                    : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
-                   : g->view.n_nodes < (1ULL << 16)         ? gn2v::kAtomic
+                   : small                                  ? gn2v::kAtomic
                                                             : gn2v::kWriteThrough;
     const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
     const size_t per_wave_words =

@@ -44,12 +44,17 @@ extern "C" {
 #define GN2V_TRAIN_NORM_LR 4u        /* normalize_learning_rate_by_degree (:99-100)             */
 #define GN2V_TRAIN_DETERMINISTIC 8u  /* one wavefront, strict walk order: oracle-exact, slow    */
 /* How row updates reach memory.  With none of the three bits set the engine picks: the
- * walk-ordered kernels use atomics on graphs below 2^16 nodes (where thousands of concurrent
- * wavefronts collide on the same rows all the time: measured CBOW link AUROC 0.80 vs 0.99 at 1 k
- * nodes, equal from 16 k nodes up) and Hogwild write-through stores on larger ones (the CPU
- * reference is racy by design as well; 2x the speed of atomics, DESIGN.md "Update modes"); the
- * block path uses plain stores on contextual rows that are exclusive to one XCD and atomics per
- * run of equal centre on the central rows at every size. */
+ * walk-ordered kernels use atomics on small graphs (where thousands of concurrent wavefronts
+ * collide on the same rows all the time: measured CBOW link AUROC 0.80 vs 0.99 at 1 k nodes) and
+ * Hogwild write-through stores on larger ones (the CPU reference is racy by design as well; 2x
+ * the speed of atomics, DESIGN.md "Update modes") -- SkipGram from 2^16 nodes, CBOW once a table
+ * holds GN2V_CBOW_STORES_MIN_ELEMENTS floats (nodes x row stride; BA graphs, link AUROC of stores
+ * minus atomics': 8 k nodes -0.015 / -0.006 / -0.002 at d = 32 / 64 / 128, 32 k -0.004 / -0.001 /
+ * -0.0001, 64 k -0.0025 / -0.0004 / 0: the limit follows the -0.0004 line, 32 k nodes at d = 128,
+ * 64 k at d = 64; graphs without hubs lose nothing from 8 k nodes on); the block path uses plain
+ * stores on contextual rows that are exclusive to one XCD and atomics per run of equal centre on
+ * the central rows at every size. */
+#define GN2V_CBOW_STORES_MIN_ELEMENTS (1u << 22)
 #define GN2V_TRAIN_ATOMIC 16u        /* hardware f32 atomics on every element: no lost update   */
 #define GN2V_TRAIN_WRITE_BACK 32u    /* read-modify-write, plain L2 write-back stores            */
 #define GN2V_TRAIN_WRITE_THROUGH 64u /* read-modify-write, 16 B write-through (sc1) stores       */

@@ -575,3 +575,29 @@ def test_atomic_mode_loses_no_update_on_a_row_every_wave_hits(karate, karate_ora
         assert np.abs(got / want - 1).max() < 2e-3
     assert np.abs(c.cpu().numpy()[1:] - c_h[1:]).max() < 1e-6
     assert np.abs(x.cpu().numpy()[1:] - x_h[1:]).max() < 1e-6
+
+
+def test_cbow_takes_stores_once_a_table_holds_four_million_floats():
+    """GN2V_CBOW_STORES_MIN_ELEMENTS = 2^22 floats per table (nodes x row stride): below it the
+    automatic choice is atomics on every row, from it up write-through stores (and with them the
+    lazy window kernel).  BA 32 768 nodes (hubs: the hardest family measured,
+    profiles/r03_logs/r3_cbow_threshold.log, r3_cbow_store_graphs.log), same walks: at d = 128 the
+    automatic choice is the store mode -- link AUROC within 0.001 of atomics', in less kernel
+    time --, at d = 64 (2^21 floats) it still is atomics."""
+    import embiggen_amd as E
+    from sharded_helpers import link_auc_device
+
+    g = E.barabasi_albert(32768, 5, 42)
+    gen = torch.Generator(device="cuda")
+    for d, stores in ((128, True), (64, False)):
+        got = {}
+        for name, extra in (("auto", {}), ("atomic", {"update_mode": "atomic"}),
+                            ("stores", {"update_mode": "write_through"})):
+            m = E.models.CBOW(embedding_size=d, epochs=3, verbose=False, **extra)
+            c, x, st = m.fit_transform_device(g)
+            gen.manual_seed(1)
+            got[name] = (link_auc_device(g, x[:, :d], c[:, :d], gen), st["train_ms"])
+            assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+        assert got["atomic"][0] > 0.99 and got["auto"][0] > got["atomic"][0] - 0.001, (d, got)
+        like, unlike = ("stores", "atomic") if stores else ("atomic", "stores")
+        assert abs(got["auto"][1] - got[like][1]) < abs(got["auto"][1] - got[unlike][1]), (d, got)
