@@ -241,7 +241,7 @@ def test_config4_block_trainer_with_eight_simulated_ranks_at_full_size():
 
 
 def test_large_graphs_are_fitted_through_the_block_path_on_one_gpu():
-    """``fit_transform`` of the public class on a graph above ``BLOCK_PATH_MIN_NODES`` (2^16): the block
+    """``fit_transform`` of the public class on a graph far above ``BLOCK_PATH_MIN_NODES``: the block
     path with the automatic plan; every pair is counted, the result has the API's shape."""
     g = E.barabasi_albert(400_000, 5, 42)
     m = E.Node2VecSkipGramEnsmallen(embedding_size=32, epochs=1, iterations=1, walk_length=32,
