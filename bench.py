@@ -89,11 +89,13 @@ def parse():
                     help="blocks: XCD slices inside a part (8 = every XCD owns its rows; default: "
                          "distributed.auto_plan)")
     ap.add_argument("--record", type=int, default=32, help="blocks: pairs per record")
-    ap.add_argument("--hot-band", default="0:0",
-                    help="blocks: lo:hi -- contextual rows whose share of their cell's edge "
-                         "endpoints lies in [2^-lo, 2^-hi) are updated with atomics (0:0 = off)")
-    ap.add_argument("--local-atomic", action="store_true",
-                    help="blocks with slices: contextual rows updated by L2-local f32 atomics")
+    ap.add_argument("--hot-rows", type=int, default=None,
+                    help="blocks: rows of every cell (highest in-degrees) whose updates accumulate "
+                         "in LDS and reach the row through atomics (default: the library's; 0 = "
+                         "none, plain stores on every contextual row)")
+    ap.add_argument("--hot-flush", type=int, default=0,
+                    help="blocks: a hot row's pending sum is handed over on average every this "
+                         "many updates per workgroup (power of two; 0 = 16)")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="blocks: CUs of every XCD left to other work (RCCL's transfer kernels): "
                          "the training kernel runs on a CU-masked stream (gn2v_graph_reserve_cus)")
@@ -332,8 +334,6 @@ def main():
     flags = _lib.TRAIN_SCALE_FREE | {
         "auto": 0, "write_through": _lib.TRAIN_WRITE_THROUGH,
         "write_back": _lib.TRAIN_WRITE_BACK, "atomic": _lib.TRAIN_ATOMIC}[args.mode]
-    if args.local_atomic:
-        flags |= _lib.TRAIN_LOCAL_ATOMIC
     if args.central_atomic:
         flags |= _lib.TRAIN_CENTRAL_ATOMIC
     if args.calibrate:
@@ -384,7 +384,7 @@ def main():
         blocks = BlockPartitionedTrainer(graph, tp, d, ld, 42, d ** -0.5, comm, f"cuda:{local}",
                                          walk_length=128, window=5, parts=args.parts,
                                          slices=args.slices, record=args.record,
-                                         hot_band=tuple(int(v) for v in args.hot_band.split(":")),
+                                         hot_rows=args.hot_rows, hot_flush=args.hot_flush,
                                          stripes=stripes)
     else:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)

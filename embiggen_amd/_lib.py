@@ -26,7 +26,6 @@ TRAIN_WRITE_BACK = 32
 TRAIN_WRITE_THROUGH = 64
 TRAIN_NO_CTX_CACHE = 128
 TRAIN_CTX_CACHE_ALL = 256
-TRAIN_LOCAL_ATOMIC = 512
 BLOCK_PATH_MIN_NODES = 2560  # GN2V_BLOCK_PATH_MIN_NODES
 TRAIN_WALK_ORDERED = 1024
 TRAIN_BLOCK_PATH = 2048
@@ -108,7 +107,7 @@ class BlockPlan(C.Structure):
 
     _fields_ = [(name, C.c_uint32) for name in (
         "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
-        "row_bits", "flags", "hot_lo", "hot_hi", "key_bits", "ctx_bits")]
+        "row_bits", "flags", "hot_rows", "hot_flush", "key_bits", "ctx_bits")]
 
 
 class BlockIO(C.Structure):
@@ -117,6 +116,8 @@ class BlockIO(C.Structure):
         ("d_cell_offsets", C.c_void_p),
         ("d_alias", C.c_void_p),
         ("d_cell_rows", C.c_void_p),
+        ("d_hot_list", C.c_void_p),
+        ("d_hot_slot", C.c_void_p),
         ("d_central", C.c_void_p),
         ("d_context", C.c_void_p),
         ("block_id", C.c_uint64),
@@ -127,6 +128,8 @@ class BlockIO(C.Structure):
 
 
 BLOCK_WORK_WORDS = 16384
+BLOCK_HOT_MAX = 192      # GN2V_BLOCK_HOT_MAX
+BLOCK_HOT_DEFAULT = 192  # GN2V_BLOCK_HOT_DEFAULT
 
 
 class Stats(C.Structure):
@@ -226,7 +229,7 @@ def lib():
     L.gn2v_block_plan_check.argtypes = [vp, C.POINTER(BlockPlan)]
     L.gn2v_init_table_rows.argtypes = [vp, u64, u32, u32, u64, u32, f32, u64, u64, vp]
     L.gn2v_block_alias_temp_bytes.argtypes = [u64, C.POINTER(u64)]
-    L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, vp, u64, vp]
+    L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, vp, vp, vp, u64, vp]
     L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, u32, u32, vp,
                                    vp, vp]
     L.gn2v_block_extract_temp_bytes.argtypes = [u64, C.POINTER(u64)]

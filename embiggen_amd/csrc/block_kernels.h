@@ -27,26 +27,10 @@
 // 12 + 27 + 17 bits); a round's pairs are extracted and sorted a group of parts at a time, so the
 // buffers hold 1 / groups of the round.
 #pragma once
+#include "../../include/gn2v.h"
 #include "train_kernels.h"
 
 namespace gn2v {
-
-// A/B: -DGN2V_BLOCK_SERIALISE keeps the per-round duplicate analysis in the parallel schedule
-template <int CH, int WM, bool HUB, class Args>
-__device__ __forceinline__ void score_samples_checked(const Args &a, float *table,
-                                                      const Row<CH> &u, const Row<CH> &u_upd,
-                                                      Row<CH> &g, const uint32_t *s_rows,
-                                                      const float *s_lab, uint32_t n_samples,
-                                                      float lrc, int grp, int q,
-                                                      const Row<CH> *u_hub) {
-    score_samples<CH, WM, false, HUB>(a, table, u, u_upd, g, s_rows, s_lab, n_samples, lrc, grp, q,
-                                      u_hub);
-}
-#ifdef GN2V_BLOCK_SERIALISE
-#define GN2V_BLOCK_SCORE score_samples_checked
-#else
-#define GN2V_BLOCK_SCORE score_samples_racy
-#endif
 
 constexpr uint64_t kTagBlock = 0xB10C5EED0B10C5EDULL;
 constexpr int kPrepBlock = 256;
@@ -58,21 +42,22 @@ constexpr uint32_t kMaxRecord = 32;
 // into several runs, each starting from the row the previous one left.  (A run is a mini-batch on
 // the centre's row: 32 pairs x (1 + k) samples summed at one stale value overshoot when a small
 // graph fills every record with one centre -- link AUROC 0.985 -> 0.93 with 8 centre stripes on
-// BA 200 k.)
+// BA 200 k.)  The oracle restates it (O_MAX_RUN).
+constexpr uint32_t kMaxRun = 16;
 // records whose runs are at least this many per 100 pairs are trained pair per group
-#ifndef GN2V_PPG_MIN_PCT
-#define GN2V_PPG_MIN_PCT 75
-#endif
-#ifndef GN2V_MAX_RUN
-#define GN2V_MAX_RUN 16
-#endif
-constexpr uint32_t kMaxRun = GN2V_MAX_RUN;
+constexpr uint32_t kPpgMinPct = 75;
 constexpr uint32_t kCursorStep = 64;  // u64 words between the ticket cursors of two slices
 constexpr uint32_t kTicket = 4;       // records a wave takes per ticket (one returning atomic)
-// "Hot" contextual rows (share of the cell's edge endpoints inside the plan's band; off by
-// default): so many waves read-modify-write them at once that plain stores lose updates.  They
-// carry this bit in the sorted pair values and in the alias tables and are updated with f32 atomics.
+// "Hot" contextual rows: the rows of a cell with the highest in-degrees -- the targets of the
+// degree-proportional negatives, read-modify-written by so many waves at once that plain stores
+// keep a fraction of a percent of their updates.  A cell flags up to kHotMax of them
+// (gn2v_block_alias: one bit in the alias-table entries, one in the pair words, a slot number per
+// row); a workgroup accumulates the updates of a flagged row in LDS (ds_add_f32: exact inside the
+// workgroup) and hands the sum to the row with f32 atomics every few updates: no add is lost,
+// at the speed of the stores (SURVEY section 7 "hard parts": LDS combine before the HBM atomic).
+// In the staged sample lists a hot row is kHubBit | slot.
 constexpr uint32_t kHubBit = 0x80000000u;
+constexpr uint32_t kHotMax = GN2V_BLOCK_HOT_MAX;
 
 struct BlockPlan {
     uint32_t world, rank, parts, slices;
@@ -80,7 +65,7 @@ struct BlockPlan {
     uint32_t row_bits;  // bits of the centre row in a pair word
     uint32_t ctx_bits;  // bits below it: the context row inside its cell + the hot flag on top
     uint32_t flags;  // kFlagDownsample: centres are thinned at extraction (needs the graph)
-    uint32_t hubs;   // a hot band is set: rows may carry kHubBit
+    uint32_t hot_rows;  // rows a cell flags as hot (0: none)
 };
 
 // --------------------------------------------------------------------------------------------
@@ -130,43 +115,56 @@ static __global__ void cell_rows_kernel(uint64_t n_nodes, uint32_t parts, uint32
 // p_i = indeg_i * n against the cell total D; "small" rows (p < D) keep threshold p * 2^32 / D and
 // borrow the rest from a "large" row.  work: u64 weight[n_nodes] | u32 stack[n_nodes].
 // Entry of row i: bit 0 = row i is hot, bits 1..31 = threshold (its lowest bit dropped), bits
-// 32..62 = alias row, bit 63 = the alias row is hot.  hub_bits: one bit per node id.
+// 32..62 = alias row, bit 63 = the alias row is hot.
+// Hot rows of a cell: its `hot_rows` rows of highest in-degree (>= 1; ties: the lower row first).
+// hot_list[cell][s] = row inside the cell of slot s (kSentinel beyond the cell's count), slots in
+// decreasing order of in-degree, so a launch whose LDS holds fewer slots takes a prefix;
+// hot_slot[cell_rows[cell] + row] = slot (0xFF: not hot; preset by the host); hub_bits: one bit
+// per node id (for the extraction).
 static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t n_nodes,
                                     uint32_t parts, uint32_t slices,
                                     const unsigned long long *__restrict__ cell_rows,
                                     unsigned long long *__restrict__ table,
                                     unsigned long long *__restrict__ weight,
                                     uint32_t *__restrict__ stack,
-                                    uint32_t *__restrict__ hub_bits, uint32_t hub_lo_shift,
-                                    uint32_t hub_hi_shift) {
+                                    uint32_t *__restrict__ hub_bits, uint32_t hot_rows,
+                                    uint32_t *__restrict__ hot_list,
+                                    uint8_t *__restrict__ hot_slot) {
     const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= parts * slices) return;
     const uint32_t part = cell / slices, slice = cell - part * slices;
     const uint64_t lo = cell_rows[cell], n = cell_rows[cell + 1] - lo;
+    uint32_t *hl = hot_list + (size_t)cell * kHotMax;
+    for (uint32_t s = 0; s < kHotMax; ++s) hl[s] = kSentinel;
     if (n == 0) return;
     unsigned long long *w = weight + lo, *t = table + lo;
     uint32_t *st = stack + lo;
-    unsigned long long D = 0;
-    for (uint64_t i = 0; i < n; ++i) D += indeg[(slice + (uint64_t)slices * i) * parts + part];
-    uint64_t n_small = 0, n_large = 0;  // small stack grows from st[0], large from st[n - 1]
     auto node_of = [&](uint64_t i) { return (slice + (uint64_t)slices * i) * parts + part; };
-    // hot: share of the cell's endpoints in [2^-lo, 2^-hi) (hi = 0: no upper bound)
-    auto hot = [&](uint64_t i) -> unsigned long long {
-        // d * 2^shift >= D  <=>  d >= ceil(D / 2^shift): no overflow whatever the in-degree
-        const unsigned long long d = indeg[node_of(i)];
-        const unsigned long long lo_need = (D + (1ull << hub_lo_shift) - 1) >> hub_lo_shift;
-        const unsigned long long hi_need = (D + (1ull << hub_hi_shift) - 1) >> hub_hi_shift;
-        return hub_lo_shift != 0 && D != 0 && d >= lo_need && (hub_hi_shift == 0 || d < hi_need)
-                   ? 1ull
-                   : 0ull;
-    };
+    unsigned long long D = 0;
+    uint32_t n_hot = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t d = indeg[node_of(i)];
+        D += d;
+        if (d != 0 && hot_rows != 0 &&
+            (n_hot < hot_rows || d > indeg[node_of(hl[n_hot - 1])])) {  // insertion, stable
+            uint32_t pos = n_hot < hot_rows ? n_hot++ : n_hot - 1;
+            while (pos > 0 && indeg[node_of(hl[pos - 1])] < d) {
+                hl[pos] = hl[pos - 1];
+                --pos;
+            }
+            hl[pos] = (uint32_t)i;
+        }
+    }
+    for (uint32_t s = 0; s < n_hot; ++s) {
+        hot_slot[lo + hl[s]] = (uint8_t)s;
+        const uint64_t x = node_of(hl[s]);
+        atomicOr(&hub_bits[x >> 5], 1u << (x & 31));
+    }
+    uint64_t n_small = 0, n_large = 0;  // small stack grows from st[0], large from st[n - 1]
+    auto hot = [&](uint64_t i) -> unsigned long long { return hot_slot[lo + i] != kNoSlot; };
     for (uint64_t i = 0; i < n; ++i) {
         const unsigned long long p = (unsigned long long)indeg[node_of(i)] * n;
         w[i] = p;
-        if (hot(i)) {
-            const uint64_t x = node_of(i);
-            atomicOr(&hub_bits[x >> 5], 1u << (x & 31));
-        }
         if (D == 0 || p >= D)
             st[n - 1 - n_large++] = (uint32_t)i;
         else
@@ -378,6 +376,8 @@ struct BlockArgs {
     const unsigned long long *alias;      // alias tables (threshold | alias << 32), or nullptr:
                                           // negatives uniform over the rows of the cell
     const unsigned long long *cell_rows;  // [cells + 1]: first table entry of every cell
+    const uint32_t *hot_list;  // [cells][kHotMax]: row inside its cell of hot slot s (or nullptr)
+    const uint8_t *hot_slot;   // [n_nodes], by cell_rows[cell] + row inside the cell: slot | 0xFF
     float *central;    // this rank's central partition  [rows][cld]
     uint64_t cld;      // floats between its rows (ld, or world * ld inside the whole table)
     float *context;    // the resident context part      [rows][xld]
@@ -392,12 +392,14 @@ struct BlockArgs {
     uint32_t sweep;  // 1: second launch -- every workgroup serves every cell's leftover records
     uint32_t xcds;   // XCDs the workgroups are spread over (0 = unknown)
     uint32_t central_atomic;  // 1: every central row update by atomics (GN2V_TRAIN_CENTRAL_ATOMIC)
+    uint32_t hot_n;      // hot slots the LDS of this launch holds (0: hot rows are ordinary rows)
+    uint32_t hot_mask;   // a slot's pending sum goes to its row after ~hot_mask + 1 updates (2^j - 1)
     uint32_t k, ld, flags;
     float lr, clip;
 };
 
 __device__ __forceinline__ float *sample_base(const BlockArgs &a, float *table, uint32_t row) {
-    return table + (uint64_t)(row & ~kHubBit) * a.xld;
+    return table + (uint64_t)row * a.xld;
 }
 
 __device__ __forceinline__ uint64_t gcd64(uint64_t a, uint64_t b) {
@@ -418,25 +420,198 @@ __device__ __forceinline__ uint64_t record_stride(uint64_t R) {
     return s % R;
 }
 
+// ---- hot rows: the workgroup's LDS copies -------------------------------------------------------
+// For each of the cell's hot rows a workgroup holds, in LDS, base[s][ld] -- the row as the
+// workgroup last saw it in memory -- and delta[s][ld] -- what its waves have added to it since
+// they last handed their sum over.  A sample on a hot row never touches memory: it reads base +
+// delta, scores, and adds var * u to delta[s] with ds_add_f32 (atomic inside the CU's LDS: the
+// waves of the workgroup lose nothing to one another, and each sees the others' updates at once).
+// Every ~hot_mask + 1 updates of a slot -- decided by mantissa bits of the update's own
+// coefficient: the same in the 16 lanes of a group, no counter -- the group HANDS OVER, alone in
+// the workgroup for that slot (an LDS try-lock; a second group that draws the slot meanwhile
+// moves on): it takes delta out of the LDS (ds_wrxchg with 0; added to base at once, so the
+// workgroup's view is continuous) and adds it to the row in memory with RETURNING f32 atomics --
+// the only place where workgroups meet, so every update arrives exactly once --; what they
+// return, the row as it was when the sum arrived (the other workgroups' sums and this one's
+// earlier ones included), plus the sum is the new base: one round trip.  What is pending when
+// the workgroup leaves the cell is handed over then.
+// Why the copies: a first form kept only delta and read the row from memory for every sample.
+// The atomics drop the row's lines from the L2, so the hottest row of a cell -- 4 % of its
+// samples -- became a load on one memory channel for every wave: -14 % on the bench with a single
+// hot row.  Why the lock and the row coming back with the hand-over: what a workgroup does not
+// see (the other workgroups' pending sums, and their handed-over sums until its own next
+// hand-over) acts like a mini-batch on the row -- the restoring force of the loss is computed on
+// a stale value -- and a hub row DIVERGES when too many updates are in limbo: measured on BA 1 M
+// at learning rate 0.01, ~ 400 unseen updates are fine, ~ 770 blow the tables up to 1e11 (the
+// bound is on unseen updates x learning rate; gn2v_block_step picks the hand-over period from
+// it).  Hand-overs that overlapped wrote older snapshots over newer ones and kept the view behind
+// for good, whatever the period.  The atomics are the device-scope ones: on gfx950 the
+// workgroup-scope form compiles to the same global_atomic_add_f32.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+struct HotLds {
+    float *base;
+    float *delta;
+    uint32_t *grow;  // row inside the part of slot s
+    uint32_t *lock;  // 1 while a group hands slot s over
+    uint32_t n, ld, mask;
+};
+
+__device__ __forceinline__ void lds_add_f32(float *p, float x) {
+    (void)__hip_atomic_fetch_add((lds_f32 *)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ float lds_take_f32(float *p) {
+    return __builtin_bit_cast(float, __hip_atomic_exchange((lds_u32 *)p, 0u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+
+// One 16-lane group hands the pending sum of a slot to its row (lane-contiguous: 64 B per
+// instruction and group, the shape in which f32 atomics run 4 x faster than float4-strided).
+// REFRESH: under the slot's lock, and the row is read back into base afterwards.
+template <int CH, bool REFRESH>
+__device__ __forceinline__ void hot_hand_over(float *hb, float *dl, uint32_t *lock, float *row,
+                                              int q, uint32_t ld) {
+    if constexpr (REFRESH) {
+        uint32_t busy = 1;
+        if (q == 0)
+            busy = __hip_atomic_exchange((lds_u32 *)lock, 1u, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+        // lane 0 of the group decides for its 16 lanes
+        const uint64_t free_groups = __ballot(q == 0 && busy == 0);
+        if (!((free_groups >> (__lane_id() & 48)) & 1)) return;
+    }
+    float x[CH * 4];
+#pragma unroll
+    for (int i = 0; i < CH * 4; ++i) {
+        const uint32_t f = i * 16 + q;
+        x[i] = 0.f;
+        if (f < ld) {
+            x[i] = lds_take_f32(dl + f);
+            // the view (base + delta) stays what it was until the row is back
+            if constexpr (REFRESH) lds_add_f32(hb + f, x[i]);
+        }
+    }
+    if constexpr (!REFRESH) {
+#pragma unroll
+        for (int i = 0; i < CH * 4; ++i) {
+            const uint32_t f = i * 16 + q;
+            if (f < ld && x[i] != 0.f) unsafeAtomicAdd(row + f, x[i]);
+        }
+    } else {
+        // returning atomics: the row as it was when this sum arrived -- the other workgroups'
+        // sums and this one's earlier ones included -- in the same round trip
+        float old[CH * 4];
+#pragma unroll
+        for (int i = 0; i < CH * 4; ++i) {
+            const uint32_t f = i * 16 + q;
+            old[i] = f < ld ? unsafeAtomicAdd(row + f, x[i]) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CH * 4; ++i) {
+            const uint32_t f = i * 16 + q;
+            if (f < ld) hb[f] = old[i] + x[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (q == 0)
+            __hip_atomic_store((lds_u32 *)lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// One sample row against the register row u of its centre (a 16-lane group): v = row, var =
+// (label - sigmoid(clip(u.v))) * lr, g += var * v, row += var * u -- a read-modify-write of the
+// row in memory, or of the workgroup's LDS copy when the row is hot.
+template <int CH, int WMX>
+__device__ __forceinline__ void score_sample(const BlockArgs &a, const HotLds &h,
+                                             const Row<CH> &u, Row<CH> &g, uint32_t row, float lab,
+                                             float lrc, int q, uint32_t nchunks) {
+    const bool valid = row != kSentinel;
+    const bool hot = valid && (row & kHubBit) != 0;
+    const bool cold = valid && !hot;
+    float *base = sample_base(a, a.context, cold ? row : 0);
+    Row<CH> v;
+    load_row<CH>(v, base, q, nchunks, cold);
+    float *hb = nullptr, *dl = nullptr;
+    if (hot) {
+        const uint32_t off = (row & 0xFFu) * h.ld;
+        hb = h.base + off;
+        dl = h.delta + off;
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) {
+            const uint32_t ci = cc * 16 + q;
+            if (ci < nchunks) {
+                const float4 b = *reinterpret_cast<const float4 *>(hb + ci * 4);
+                const float4 p = *reinterpret_cast<const float4 *>(dl + ci * 4);
+                v.c[cc] = make_float4(b.x + p.x, b.y + p.y, b.z + p.z, b.w + p.w);
+            }
+        }
+    }
+    const float dot = dot_rows<CH>(u, v);
+    const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+    axpy<CH>(g, var, v);
+    if (hot) {
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) {
+            const uint32_t ci = cc * 16 + q;
+            if (ci < nchunks) {
+                lds_add_f32(dl + ci * 4 + 0, var * u.c[cc].x);
+                lds_add_f32(dl + ci * 4 + 1, var * u.c[cc].y);
+                lds_add_f32(dl + ci * 4 + 2, var * u.c[cc].z);
+                lds_add_f32(dl + ci * 4 + 3, var * u.c[cc].w);
+            }
+        }
+        if (((__float_as_uint(var) >> 3) & h.mask) == 0)
+            hot_hand_over<CH, true>(hb, dl, h.lock + (row & 0xFFu),
+                                    sample_base(a, a.context, h.grow[row & 0xFFu]), q, h.ld);
+    } else if (cold) {
+        scatter_add<CH, WMX>(base, q, nchunks, var, u, v);
+    }
+}
+
+// the sample list of a run against the register row u (replicated in the four groups): a round
+// is the four sample rows t0 .. t0 + 3, one per group, with no check for a row named twice in it
+template <int CH, int WMX>
+__device__ __forceinline__ void score_run(const BlockArgs &a, const HotLds &h, const Row<CH> &u,
+                                          Row<CH> &g, const uint32_t *s_rows, const float *s_lab,
+                                          uint32_t n_samples, float lrc, int grp, int q) {
+    const uint32_t nchunks = a.ld >> 2;
+    for (uint32_t t0 = 0; t0 < n_samples; t0 += 4) {
+        const uint32_t t = t0 + grp;
+        const uint32_t row = t < n_samples ? s_rows[t] : kSentinel;
+        const float lab = t < n_samples ? s_lab[t] : 0.f;
+        score_sample<CH, WMX>(a, h, u, g, row, lab, lrc, q, nchunks);
+    }
+}
+
 template <int CH, int WMX, int WMC, bool DET>
-__device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, uint64_t lo,
-                                             uint64_t hi, uint64_t p0, uint32_t n, uint64_t ckey,
-                                             uint64_t alias_lo, uint64_t cell_n, uint32_t slice,
-                                             uint32_t *s_key, uint32_t *s_val, uint32_t *s_rows,
-                                             float *s_lab, uint32_t *s_nb, float *s_tr, int lane,
-                                             int grp, int q,
+__device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h, uint32_t cell,
+                                             uint64_t lo, uint64_t hi, uint64_t p0, uint32_t n,
+                                             uint64_t ckey, uint64_t cell_lo, uint64_t cell_n,
+                                             uint32_t slice, uint32_t *s_key, uint32_t *s_val,
+                                             uint32_t *s_hs, uint32_t *s_rows, float *s_lab,
+                                             uint32_t *s_nb, float *s_tr, int lane, int grp, int q,
                                              unsigned long long &pairs,
                                              unsigned long long &runs) {
     const uint32_t k = a.k, nchunks = a.ld >> 2;
     const uint32_t rowmask = a.p.row_bits >= 32 ? 0xFFFFFFFFu : ((1u << a.p.row_bits) - 1u);
+    // hot rows are served from the LDS accumulators in the parallel store schedules only
+    const uint32_t hot_n = (DET || is_atomic(WMX)) ? 0u : h.n;
     wave_sync();
     if ((uint32_t)lane < n) {
         const unsigned long long word = a.pairs[p0 + lane];
         const uint32_t low = (uint32_t)word & ((1u << a.p.ctx_bits) - 1u);
         const uint32_t hub = low >> (a.p.ctx_bits - 1);
         const uint32_t local = low & ((1u << (a.p.ctx_bits - 1)) - 1u);
+        uint32_t val = slice + a.p.slices * local;  // row inside the part
+        uint32_t hs = kNoSlot;
+        if (hub && hot_n) {
+            hs = a.hot_slot[cell_lo + local];
+            if (hs < hot_n) val |= kHubBit;
+        }
         s_key[lane] = (uint32_t)(word >> a.p.ctx_bits) & rowmask;
-        s_val[lane] = (slice + a.p.slices * local) | (hub ? kHubBit : 0u);  // row inside the part
+        s_val[lane] = val;
+        s_hs[lane] = hs;
     }
     // the centres just before and just after the record in the cell (kSentinel at its borders):
     // a run that has no equal neighbour is the ONLY run of its centre in this cell
@@ -448,14 +623,16 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
     const uint32_t n_samples = n * (k + 1);
     for (uint32_t t = lane; t < n_samples; t += 64) {
         const uint32_t pr = t / (k + 1), s = t - pr * (k + 1);
-        const uint32_t xrow = s_val[pr];  // may carry kHubBit
+        const uint32_t xrow = s_val[pr];  // kHubBit: served from LDS slot s_hs[pr]
         uint32_t row = xrow;
         float lab = 1.f;
-        if (s != 0) {
+        if (s == 0) {
+            if (xrow & kHubBit) row = kHubBit | s_hs[pr];
+        } else {
             const uint64_t r = draw(ckey, (p0 - lo + pr) * k + (s - 1));
             uint32_t local = (uint32_t)mulhi64(r, cell_n), hub = 0;
             if (a.alias) {
-                const unsigned long long e = a.alias[alias_lo + local];
+                const unsigned long long e = a.alias[cell_lo + local];
                 hub = (uint32_t)e & 1u;
                 if ((uint32_t)r >= ((uint32_t)e & ~1u)) {
                     local = (uint32_t)(e >> 32) & ~kHubBit;
@@ -466,10 +643,12 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
             lab = 0.f;
             const uint64_t ngid = (uint64_t)row * a.p.parts + a.part;
             const uint64_t cgid = (uint64_t)s_key[pr] * a.p.world + a.p.rank;
-            if (row == (xrow & ~kHubBit) || ngid == cgid)
+            if (row == (xrow & ~kHubBit) || ngid == cgid) {
                 row = kSentinel;
-            else if (hub)
-                row |= kHubBit;
+            } else if (hub && hot_n) {
+                const uint32_t slot = a.hot_slot[cell_lo + local];
+                if (slot < hot_n) row = kHubBit | slot;
+            }
         }
         s_rows[t] = row;
         s_lab[t] = lab;
@@ -485,14 +664,13 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
     // gradient with atomics (several groups, or waves, hold that row), a lone pair stores row +
     // gradient.  Runs proper (the bench graph: 3.4 pairs) keep the run-major loop below: there a
     // group-private centre would re-read the central row per pair.
-#ifndef GN2V_BLOCK_NO_PPG
     if constexpr (!DET && !is_atomic(WMX) && WMC == kAtomic) {
         uint32_t n_runs = 0;
         {
             const bool starts = (uint32_t)lane < n && (lane == 0 || s_key[lane] != s_key[lane - 1]);
             n_runs = (uint32_t)__popcll(__ballot(starts));
         }
-        if (!a.p.hubs && !a.central_atomic && n_runs * 100 >= n * GN2V_PPG_MIN_PCT) {
+        if (!a.central_atomic && n_runs * 100 >= n * kPpgMinPct) {
             const uint32_t kk = k + 1;
             for (uint32_t p4 = 0; p4 < n; p4 += 4) {
                 const uint32_t pr = p4 + grp;
@@ -511,15 +689,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
                 for (uint32_t sidx = 0; sidx < kk; ++sidx) {
                     const uint32_t t = (have ? pr : 0) * kk + sidx;
                     const uint32_t row = have ? s_rows[t] : kSentinel;
-                    const float lab = s_lab[t];
-                    const bool valid = row != kSentinel;
-                    float *base = sample_base(a, a.context, valid ? row : 0);
-                    Row<CH> v;
-                    load_row<CH>(v, base, q, nchunks, valid);
-                    const float dot = dot_rows<CH>(u, v);
-                    const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
-                    axpy<CH>(g, var, v);
-                    if (valid) scatter_add<CH, WMX>(base, q, nchunks, var, u, v);
+                    score_sample<CH, WMX>(a, h, u, g, row, s_lab[t], lrc, q, nchunks);
                 }
                 if (have) {
                     const bool same_prev = pr > 0 ? s_key[pr - 1] == crow_id : s_nb[0] == crow_id;
@@ -546,7 +716,6 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
             return;
         }
     }
-#endif
     // Runs of equal centre inside the record (short: a centre's pairs are spread over all cells).
     // The central row of the NEXT run is loaded while the current run is scored (other runs have
     // other centres, so it cannot be changed by this record in between).
@@ -574,21 +743,18 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
                          r1 < n);
         }
         zero_row<CH>(g);
-        Row<CH> u_upd = u;
-        if constexpr (!DET) {  // lane-contiguous copy of u for atomic row updates
-            if (is_atomic(WMX) || a.p.hubs) to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
-        }
-        if constexpr (DET)
-            score_samples<CH, WMX, DET>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
+        if constexpr (DET) {
+            score_samples<CH, WMX, DET>(a, a.context, u, u, g, s_rows + r0 * (k + 1),
                                         s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
-        else if constexpr (!is_atomic(WMX))  // stores take u, the atomics of hot rows u_upd
-            GN2V_BLOCK_SCORE<CH, WMX, true>(a, a.context, u, u, g, s_rows + r0 * (k + 1),
-                                            s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q,
-                                            &u_upd);
-        else
-            GN2V_BLOCK_SCORE<CH, WMX, false>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
-                                             s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp,
-                                             q, nullptr);
+        } else if constexpr (!is_atomic(WMX)) {
+            score_run<CH, WMX>(a, h, u, g, s_rows + r0 * (k + 1), s_lab + r0 * (k + 1),
+                               (r1 - r0) * (k + 1), lrc, grp, q);
+        } else {  // atomics on every row: u in the lane-contiguous layout for the row updates
+            Row<CH> u_upd;
+            to_contig_layout<CH>(u_upd, u, s_tr, grp, q, a.ld);
+            score_samples_racy<CH, WMX>(a, a.context, u, u_upd, g, s_rows + r0 * (k + 1),
+                                        s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
+        }
         if constexpr (!DET) reduce_groups<CH>(g);
         // The gradient of the run goes to the central row.  A centre whose pairs in this cell are
         // all in this run (the rule at 100 M nodes, where a round holds 1.1 pairs per cell and
@@ -632,32 +798,48 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, uint32_t cell, 
     pairs += n;
 }
 
-// WMX: store flavour of the contextual rows (kWriteBack / kLocalAtomic only when every cell is
-// exclusive to one XCD: slices a multiple of the XCDs in use), WMC: of the central rows (shared
-// between XCDs).
-#ifndef GN2V_BLOCK_MIN_BLOCKS
-#define GN2V_BLOCK_MIN_BLOCKS 1  // occupancy experiments: -DGN2V_BLOCK_MIN_BLOCKS=6 caps the VGPRs
-#endif
+// WMX: store flavour of the contextual rows (kWriteBack only when every cell is exclusive to one
+// XCD: slices a multiple of the XCDs in use), WMC: of the central rows (shared between XCDs).
 // FULL: the row stride is exactly CH * 64 floats (d = 128 -> CH = 2; every d that pads to 64, 128,
 // 256, 512 or 1024): the compiler then knows ld, every "is this chunk inside the row" predicate
 // folds away (they were sixteen 64-bit masks held in SGPRs across the whole kernel) and the
 // per-chunk bounds tests leave the instruction stream.
-template <int CH, int WMX, int WMC, bool DET, bool FULL = false>
-__global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block_kernel(BlockArgs a) {
+// LDS: per wave  transpose row[ld] | centre rows[C] | context rows[C] | hot slots[C] |
+// sample rows[C (k + 1)] | labels[C (k + 1)] | neighbour centres[2];  then, shared by the
+// workgroup, the hot rows  base[hot_n][ld] | delta[hot_n][ld] | rows[hot_n] | locks[hot_n].
+// WG: threads of a workgroup.  256 (four workgroups per CU), or 1 024 = one workgroup per CU: its
+// sixteen waves share ONE set of hot rows -- four times the rows in the same LDS, a quarter of
+// the copies per XCD (what is in limbo between the copies shrinks with them).
+template <int CH, int WMX, int WMC, bool DET, bool FULL = false, int WG = kTrainBlock>
+__global__ __launch_bounds__(WG) void sgns_block_kernel(BlockArgs a) {
     if constexpr (FULL) a.ld = CH * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
     const uint32_t C = a.p.record, k = a.k;
-    const uint32_t per_wave = (a.ld + 2 * C + 2 * C * (k + 1) + 2 + 3) & ~3u;
+    const uint32_t per_wave = (a.ld + 3 * C + 2 * C * (k + 1) + 2 + 3) & ~3u;
     float *s_tr = reinterpret_cast<float *>(smem + wave * per_wave);
     uint32_t *s_key = smem + wave * per_wave + a.ld;
     uint32_t *s_val = s_key + C;
-    uint32_t *s_rows = s_val + C;
+    uint32_t *s_hs = s_val + C;
+    uint32_t *s_rows = s_hs + C;
     float *s_lab = reinterpret_cast<float *>(s_rows + C * (k + 1));
     uint32_t *s_nb = s_rows + 2 * C * (k + 1);  // centres next to the record
     unsigned long long pairs = 0, runs = 0;
     const uint64_t part_rows = stripe_count(a.n_nodes, a.part, a.p.parts);
+    const uint32_t n_waves = blockDim.x >> 6;
+    HotLds h{};
+    if constexpr (!DET && !is_atomic(WMX)) {
+        if (a.hot_n && !a.sweep) {
+            h.n = a.hot_n;
+            h.ld = a.ld;
+            h.mask = a.hot_mask;
+            h.base = reinterpret_cast<float *>(smem + n_waves * per_wave);
+            h.delta = h.base + h.n * a.ld;
+            h.grow = smem + n_waves * per_wave + 2 * h.n * a.ld;
+            h.lock = h.grow + h.n;
+        }
+    }
 
     // Which slices this workgroup serves.  When the slices are a multiple of the XCDs in use
     // (a.xcds; 8 slices on an MI355X), XCD x serves the slices x, x + xcds, ...: every slice --
@@ -680,48 +862,74 @@ __global__ __launch_bounds__(kTrainBlock, GN2V_BLOCK_MIN_BLOCKS) void sgns_block
         const uint32_t slice = first_slice + si * slice_step;
         const uint32_t cell = a.part * a.p.slices + slice;
         const uint64_t lo = a.cell_offsets[cell], hi = a.cell_offsets[cell + 1];
-        if (hi == lo) continue;
-        const uint64_t R = (hi - lo + C - 1) / C;
-        const uint64_t A = record_stride(R);
-        const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kMaxCells + cell);
         const uint64_t cell_n = stripe_count(part_rows, slice, a.p.slices);
-        const uint64_t alias_lo = a.alias ? a.cell_rows[cell] : 0;
-        if (cell_n == 0) continue;  // cannot happen when the cell has pairs (their contexts)
-        if constexpr (DET) {
-            for (uint64_t t = 0; t < R; ++t) {
-                const uint64_t rec = (t * A) % R;
-                const uint64_t p0 = lo + rec * C;
-                const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
-                train_record<CH, WMX, WMC, DET>(a, cell, lo, hi, p0, n, ckey, alias_lo, cell_n,
-                                                slice, s_key, s_val, s_rows, s_lab, s_nb, s_tr,
-                                                lane, grp, q, pairs, runs);
-            }
-        } else {
-            // a ticket = kTicket consecutive visiting-order indices (the stride order spreads
-            // them over the cell); one returning atomic per ticket on the cell's own cursor line
-            // Every cell starts its stride order somewhere else (an offset drawn from the cell's
-            // key).  The cells of a part hold the same centres in the same (sorted) order and
-            // their XCDs advance at the same pace: without the offset all eight would work on
-            // the same centre rows at the same moment, all launch long -- the one situation in
-            // which the single-run store of train_record loses updates (and in which the atomic
-            // adds of a hub centre queue up behind one another).
-            const uint64_t start = mulhi64(ckey, R);
-            unsigned long long *cursor = a.cursors + (size_t)slice * kCursorStep;
-            for (;;) {
-                unsigned long long t = 0;
-                if (lane == 0) t = atomicAdd(cursor, (unsigned long long)kTicket);
-                t = __shfl(t, 0);
-                if (t >= R) break;
-                const uint64_t t_end = min(t + kTicket, (unsigned long long)R);
-                for (; t < t_end; ++t) {
-                    const uint64_t rec = (t * A + start) % R;
-                    const uint64_t p0 = lo + rec * C;
-                    const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
-                    train_record<CH, WMX, WMC, DET>(a, cell, lo, hi, p0, n, ckey, alias_lo,
-                                                    cell_n, slice, s_key, s_val, s_rows, s_lab,
-                                                    s_nb, s_tr, lane, grp, q, pairs, runs);
+        const bool work = hi != lo && cell_n != 0;  // pairs imply rows: their contexts
+        if (h.n) {  // the same for every wave of the workgroup: the barriers are uniform
+            for (uint32_t i = threadIdx.x; i < h.n * a.ld; i += blockDim.x) {
+                const uint32_t s = i / a.ld, f = i - s * a.ld;
+                const uint32_t r = a.hot_list[(size_t)cell * kHotMax + s];
+                h.delta[i] = 0.f;
+                h.base[i] = r == kSentinel ? 0.f
+                                           : sample_base(a, a.context, slice + a.p.slices * r)[f];
+                if (f == 0) {
+                    h.grow[s] = r == kSentinel ? kSentinel : slice + a.p.slices * r;
+                    h.lock[s] = 0;
                 }
             }
+            __syncthreads();
+        }
+        if (work) {
+            const uint64_t R = (hi - lo + C - 1) / C;
+            const uint64_t A = record_stride(R);
+            const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kMaxCells + cell);
+            const uint64_t cell_lo = a.cell_rows ? a.cell_rows[cell] : 0;
+            if constexpr (DET) {
+                for (uint64_t t = 0; t < R; ++t) {
+                    const uint64_t rec = (t * A) % R;
+                    const uint64_t p0 = lo + rec * C;
+                    const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
+                    train_record<CH, WMX, WMC, DET>(a, h, cell, lo, hi, p0, n, ckey, cell_lo,
+                                                    cell_n, slice, s_key, s_val, s_hs, s_rows,
+                                                    s_lab, s_nb, s_tr, lane, grp, q, pairs, runs);
+                }
+            } else {
+                // a ticket = kTicket consecutive visiting-order indices (the stride order spreads
+                // them over the cell); one returning atomic per ticket on the cell's own cursor line
+                // Every cell starts its stride order somewhere else (an offset drawn from the cell's
+                // key).  The cells of a part hold the same centres in the same (sorted) order and
+                // their XCDs advance at the same pace: without the offset all eight would work on
+                // the same centre rows at the same moment, all launch long -- the one situation in
+                // which the single-run store of train_record loses updates (and in which the atomic
+                // adds of a hub centre queue up behind one another).
+                const uint64_t start = mulhi64(ckey, R);
+                unsigned long long *cursor = a.cursors + (size_t)slice * kCursorStep;
+                for (;;) {
+                    unsigned long long t = 0;
+                    if (lane == 0) t = atomicAdd(cursor, (unsigned long long)kTicket);
+                    t = __shfl(t, 0);
+                    if (t >= R) break;
+                    const uint64_t t_end = min(t + kTicket, (unsigned long long)R);
+                    for (; t < t_end; ++t) {
+                        const uint64_t rec = (t * A + start) % R;
+                        const uint64_t p0 = lo + rec * C;
+                        const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
+                        train_record<CH, WMX, WMC, DET>(a, h, cell, lo, hi, p0, n, ckey, cell_lo,
+                                                        cell_n, slice, s_key, s_val, s_hs, s_rows,
+                                                        s_lab, s_nb, s_tr, lane, grp, q, pairs,
+                                                        runs);
+                    }
+                }
+            }
+        }
+        if (h.n) {  // what is still pending goes to the rows before the workgroup leaves the cell
+            __syncthreads();
+            for (uint32_t s = wave * 4 + grp; s < h.n; s += n_waves * 4) {
+                const uint32_t r = h.grow[s];
+                if (r != kSentinel)
+                    hot_hand_over<CH, false>(h.base + s * a.ld, h.delta + s * a.ld, nullptr,
+                                             sample_base(a, a.context, r), q, a.ld);
+            }
+            __syncthreads();
         }
     }
     if (a.counters && lane == 0 && pairs) {

@@ -39,7 +39,10 @@ int check_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     if (p->walk_length < 2 || p->window < 1) return fail("need walk_length >= 2, window_size >= 1");
     if (p->min_dist > p->window) return fail("min_dist must not exceed window_size");
     if (p->record > gn2v::kMaxRecord) return fail("record must be at most 32 pairs");
-    if (p->hot_lo > 40 || p->hot_hi > p->hot_lo) return fail("need hot_hi <= hot_lo <= 40");
+    if (p->hot_rows > GN2V_BLOCK_HOT_MAX)
+        return fail("hot_rows must be at most " + std::to_string(GN2V_BLOCK_HOT_MAX));
+    if (p->hot_flush > 1024 || (p->hot_flush & (p->hot_flush - 1)))
+        return fail("hot_flush must be a power of two, at most 1024 (0 = 16)");
     return 0;
 }
 
@@ -59,8 +62,18 @@ gn2v::BlockPlan device_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     const uint64_t part_rows = gn2v::stripe_count(g->view.n_nodes, 0, p->parts);
     d.ctx_bits = bits_for(gn2v::stripe_count(part_rows, 0, p->slices)) + 1;  // + the hot flag
     d.flags = p->flags & gn2v::kFlagDownsample;
-    d.hubs = p->hot_lo != 0 ? 1u : 0u;
+    d.hot_rows = p->hot_rows;
     return d;
+}
+
+// LDS words a wavefront of sgns_block_kernel stages a record in (block_kernels.h)
+size_t block_lds_words_per_wave(uint32_t ld, uint32_t record, uint32_t k) {
+    return ((size_t)ld + 3 * record + 2 * (size_t)record * (k + 1) + 2 + 3) & ~(size_t)3;
+}
+
+size_t env_size(const char *name, size_t fallback) {
+    const char *v = getenv(name);
+    return v && *v ? (size_t)strtoull(v, nullptr, 10) : fallback;
 }
 
 uint32_t cell_bits(const gn2v::BlockPlan &d) { return bits_for((uint64_t)d.parts * d.slices); }
@@ -175,10 +188,11 @@ int gn2v_block_alias_temp_bytes(uint64_t n_nodes, uint64_t *bytes) {
 }
 
 int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_alias,
-                     uint64_t *d_cell_rows, uint32_t *d_hub_bits, void *d_temp,
-                     uint64_t temp_bytes, void *stream) {
+                     uint64_t *d_cell_rows, uint32_t *d_hub_bits, uint32_t *d_hot_list,
+                     uint8_t *d_hot_slot, void *d_temp, uint64_t temp_bytes, void *stream) {
     if (check_plan(g, plan)) return 1;
-    if (!d_alias || !d_cell_rows || !d_hub_bits || !d_temp) return fail("NULL pointer");
+    if (!d_alias || !d_cell_rows || !d_hub_bits || !d_hot_list || !d_hot_slot || !d_temp)
+        return fail("NULL pointer");
     if ((g->view.n_nodes + plan->parts - 1) / plan->parts >= (1ULL << 31))
         return fail("a context part must have fewer than 2^31 rows");
     const uint64_t n = g->view.n_nodes;
@@ -195,6 +209,7 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
     unsigned long long *weight = (unsigned long long *)(t + 2 * align256(n * 4));
     HIP_TRY(hipMemsetAsync(indeg, 0, n * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(d_hub_bits, 0, ((n + 31) / 32) * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(d_hot_slot, 0xFF, n, s));
     const uint64_t E = g->view.n_edges;
     const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(gn2v::indegree_kernel, dim3(blocks), dim3(256), 0, s, g->view.col_idx, E,
@@ -204,10 +219,10 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
                        plan->slices, (unsigned long long *)d_cell_rows);
     HIP_TRY(hipGetLastError());
     const uint32_t cells = plan->parts * plan->slices;
-    const uint32_t hub_lo = plan->hot_lo, hub_hi = plan->hot_hi;
     hipLaunchKernelGGL(gn2v::alias_kernel, dim3((cells + 63) / 64), dim3(64), 0, s, indeg, n,
                        plan->parts, plan->slices, (const unsigned long long *)d_cell_rows,
-                       (unsigned long long *)d_alias, weight, stack, d_hub_bits, hub_lo, hub_hi);
+                       (unsigned long long *)d_alias, weight, stack, d_hub_bits, plan->hot_rows,
+                       d_hot_list, d_hot_slot);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -299,6 +314,14 @@ int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_
 }
 
 extern "C++" {
+// dynamic LDS beyond 64 KB has to be allowed per kernel, once
+template <class K>
+static void allow_lds(K kernel, size_t lds) {
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 template <int CH>
 static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, size_t lds,
                             hipStream_t s, const gn2v::BlockArgs &a) {
@@ -314,6 +337,28 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
             hipLaunchKernelGGL((gn2v::sgns_block_kernel<CH, WMX, WMC, DT, false>), grid, block,   \
                                lds, s, a);                                                        \
     } while (0)
+// one workgroup of sixteen waves per CU (rows up to 128 floats, the store flavours)
+#define GN2V_BLOCK_WIDE(WMX)                                                                      \
+    do {                                                                                          \
+        if (full) {                                                                               \
+            auto kernel = gn2v::sgns_block_kernel<CH, WMX, gn2v::kAtomic, false, true, 1024>;     \
+            allow_lds(kernel, lds);                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, lds, s, a);                                   \
+        } else {                                                                                  \
+            auto kernel = gn2v::sgns_block_kernel<CH, WMX, gn2v::kAtomic, false, false, 1024>;    \
+            allow_lds(kernel, lds);                                                               \
+            hipLaunchKernelGGL(kernel, grid, block, lds, s, a);                                   \
+        }                                                                                         \
+    } while (0)
+    if constexpr (CH <= 2) {
+        if (block.x == 1024) {
+            if (wmx == gn2v::kWriteBack)
+                GN2V_BLOCK_WIDE(gn2v::kWriteBack);
+            else
+                GN2V_BLOCK_WIDE(gn2v::kWriteThrough);
+            return;
+        }
+    }
     if (det)
         GN2V_BLOCK(gn2v::kWriteBack, gn2v::kWriteBack, true);
     else if (wmx == gn2v::kAtomic)
@@ -322,11 +367,10 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
         GN2V_BLOCK(gn2v::kWriteBack, gn2v::kWriteBack, false);
     else if (wmx == gn2v::kWriteBack)
         GN2V_BLOCK(gn2v::kWriteBack, gn2v::kAtomic, false);
-    else if (wmx == gn2v::kLocalAtomic)
-        GN2V_BLOCK(gn2v::kLocalAtomic, gn2v::kAtomic, false);
     else
         GN2V_BLOCK(gn2v::kWriteThrough, gn2v::kAtomic, false);
 #undef GN2V_BLOCK
+#undef GN2V_BLOCK_WIDE
 }
 }  // extern "C++"
 
@@ -358,7 +402,12 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     a.cell_offsets = (const unsigned long long *)io->d_cell_offsets;
     const bool scale_free = tp->flags & GN2V_TRAIN_SCALE_FREE;
     a.alias = scale_free ? (const unsigned long long *)io->d_alias : nullptr;
-    a.cell_rows = scale_free ? (const unsigned long long *)io->d_cell_rows : nullptr;
+    a.cell_rows = (const unsigned long long *)io->d_cell_rows;
+    if ((io->d_hot_list != nullptr) != (io->d_hot_slot != nullptr) ||
+        (io->d_hot_list && !io->d_cell_rows))
+        return fail("the hot rows need d_hot_list, d_hot_slot and d_cell_rows together");
+    a.hot_list = io->d_hot_list;
+    a.hot_slot = io->d_hot_slot;
     a.central = io->d_central;
     a.cld = io->central_ld ? io->central_ld : tp->ld;
     if (a.cld < tp->ld || (a.cld & 3)) return fail("central_ld must be a multiple of 4 and >= ld");
@@ -396,18 +445,53 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
                   ? gn2v::kAtomic
                   : gn2v::kWriteThrough;
     int wmx = wmc;
-    if (wmc == gn2v::kWriteThrough && exclusive)
-        wmx = (tp->flags & GN2V_TRAIN_LOCAL_ATOMIC) ? gn2v::kLocalAtomic : gn2v::kWriteBack;
+    if (wmc == gn2v::kWriteThrough && exclusive) wmx = gn2v::kWriteBack;
     a.xcds = (uint32_t)g->n_xcds;
     a.central_atomic = (tp->flags & GN2V_TRAIN_CENTRAL_ATOMIC) ? 1u : 0u;
 
-    const int waves_per_block = det ? 1 : gn2v::kTrainBlock / 64;
-    const size_t per_wave_words =
-        ((size_t)tp->ld + 2 * d.record + 2 * (size_t)d.record * (tp->k + 1) + 2 + 3) & ~(size_t)3;
-    const size_t lds = (size_t)waves_per_block * per_wave_words * 4;
-    if (lds > 64 * 1024) return fail("record / negatives too large for the LDS plan");
+    // Hot rows (block_kernels.h "hot rows"): only with ONE workgroup of sixteen waves per CU --
+    // rows up to 128 floats, store flavours, central rows by atomics -- whose waves share one set
+    // of LDS copies: 32 workgroups per XCD instead of 128 keep what is in limbo between the copies
+    // small, and the LDS holds four times the rows (100 at d = 128).  The hand-over period T
+    // follows from the stability bound "unseen updates x learning rate": a workgroup does not see
+    // the other workgroups' pending sums (T / 2 each on average) nor what they handed over since
+    // its own last hand-over (T each): 1.5 T (W - 1) updates for W workgroups side by side on the
+    // cell.  Measured on BA 1 M (d = 128, lr = 0.01): 380 such updates train well, 770 diverge;
+    // the largest T in {8, 4, 2, 1} that keeps 1.5 T W lr <= 2 is taken (lr = 0.01: T = 4), and
+    // when even T = 1 does not, the rows stay ordinary rows (plain stores lose updates on hub rows
+    // -- which is also what keeps them stable at any learning rate).
+    const bool stores = !det && wmx != gn2v::kAtomic;
+    static const size_t wide_env = env_size("GN2V_BLOCK_WIDE", 1);  // 0: never (A/B)
+    const size_t per_wave_words = block_lds_words_per_wave(tp->ld, d.record, tp->k);
+    bool wide = stores && a.hot_list && d.hot_rows && wide_env && tp->ld <= 128 &&
+                wmc != gn2v::kWriteBack && per_wave_words * 4 * 16 <= 96 * 1024;
     const uint64_t cus = (uint64_t)g->n_cus - (uint64_t)g->reserved_cus * std::max(1, g->n_xcds);
-    uint64_t blocks = det ? 1 : cus * 8;
+    uint32_t hot_period = 0;
+    if (wide) {
+        const uint64_t rows = g->view.n_nodes / d.parts;
+        const uint64_t wgs = std::min<uint64_t>(cus, std::max<uint64_t>(d.slices, rows / 16));
+        const double side_by_side = (double)std::max<uint64_t>(1, exclusive ? wgs / g->n_xcds : wgs);
+        hot_period = plan->hot_flush;
+        if (!hot_period)
+            for (uint32_t t = 8; t >= 1 && !hot_period; t >>= 1)
+                if (1.5 * t * side_by_side * std::fabs(lr) <= 2.0) hot_period = t;
+        static const size_t flush_override = env_size("GN2V_HOT_FLUSH_OVERRIDE", 0);  // A/B
+        if (flush_override) hot_period = (uint32_t)flush_override;
+        if (!hot_period) wide = false;
+    }
+    const int waves_per_block = det ? 1 : wide ? 16 : gn2v::kTrainBlock / 64;
+    size_t lds = (size_t)waves_per_block * per_wave_words * 4;
+    if (lds > 64 * 1024 && !wide) return fail("record / negatives too large for the LDS plan");
+    if (wide) {
+        static const size_t budget = env_size("GN2V_HOT_LDS_BYTES", 160 * 1024);
+        const size_t per_row = (size_t)tp->ld * 8 + 8;
+        if (budget > lds) a.hot_n = (uint32_t)std::min<size_t>(d.hot_rows, (budget - lds) / per_row);
+        static const size_t cap = env_size("GN2V_HOT_ROWS", GN2V_BLOCK_HOT_MAX);
+        a.hot_n = (uint32_t)std::min<size_t>(a.hot_n, cap);
+        a.hot_mask = hot_period - 1u;
+        lds += (size_t)a.hot_n * per_row;
+    }
+    uint64_t blocks = det ? 1 : wide ? cus : cus * 8;
     if (!det) {
         // at most one concurrent wave per table row on average (staleness of the records of one
         // centre trained from the same copy of its row; binds on tiny graphs only)
@@ -415,7 +499,7 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
         const uint64_t max_blocks = std::max<uint64_t>(d.slices, rows / waves_per_block);
         if (blocks > max_blocks) blocks = max_blocks;
     }
-    dim3 grid((unsigned)blocks), block(det ? 64 : gn2v::kTrainBlock);
+    dim3 grid((unsigned)blocks), block(det ? 64 : waves_per_block * 64);
 
     std::lock_guard<std::mutex> lock(g->mu);
     // gn2v_graph_reserve_cus: the launch runs on the CU-masked stream, between the caller's
@@ -553,6 +637,8 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     plan.min_dist = tp->min_dist ? tp->min_dist : 1;
     plan.record = 32;
     plan.flags = tp->flags & GN2V_TRAIN_DOWNSAMPLE;
+    plan.hot_rows = (uint32_t)env_size("GN2V_HOT_ROWS", GN2V_BLOCK_HOT_DEFAULT);
+    plan.hot_flush = (uint32_t)env_size("GN2V_HOT_FLUSH", 0);
     std::vector<gn2v_block_plan> plans(V, plan);
     for (uint32_t j = 0; j < V; ++j) {
         plans[j].rank = j;
@@ -568,17 +654,21 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     const uint64_t pairs_per_walk = 2ull * w * L;  // upper bound (window untrimmed)
 
     Buffers buf;
-    // alias tables + hot-row bitmap (the bitmap is all zero: no hot band in the automatic plan)
+    // alias tables + the hot rows of every cell (flags for the extraction, slot tables)
     uint64_t *alias = nullptr, *cell_rows = nullptr;
-    uint32_t *hub_bits = nullptr;
+    uint32_t *hub_bits = nullptr, *hot_list = nullptr;
+    uint8_t *hot_slot = nullptr;
     if (scale_free) {
         uint64_t tb = 0;
         gn2v_block_alias_temp_bytes(n, &tb);
         void *tmp = nullptr;
         if (buf.alloc(&alias, n * 8) || buf.alloc(&cell_rows, (cells + 1) * 8) ||
-            buf.alloc(&hub_bits, ((n + 31) / 32) * 4) || buf.alloc(&tmp, tb))
+            buf.alloc(&hub_bits, ((n + 31) / 32) * 4) ||
+            buf.alloc(&hot_list, (size_t)cells * GN2V_BLOCK_HOT_MAX * 4) ||
+            buf.alloc(&hot_slot, n) || buf.alloc(&tmp, tb))
             return kOutOfMemory;
-        if (gn2v_block_alias(g, &plan, alias, cell_rows, hub_bits, tmp, tb, s)) return 1;
+        if (gn2v_block_alias(g, &plan, alias, cell_rows, hub_bits, hot_list, hot_slot, tmp, tb, s))
+            return 1;
         HIP_TRY(hipStreamSynchronize(s));
         (void)hipFree(tmp);
         buf.ptrs.pop_back();
@@ -694,6 +784,8 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
                         io.d_cell_offsets = cell_offsets;
                         io.d_alias = alias;
                         io.d_cell_rows = cell_rows;
+                        io.d_hot_list = hot_list;
+                        io.d_hot_slot = hot_slot;
                         io.d_central = d_central + (size_t)j * ld;
                         io.central_ld = (uint64_t)V * ld;
                         io.d_context = part_major ? d_contextual + first_row[p] * ld

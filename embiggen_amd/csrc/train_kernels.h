@@ -131,20 +131,9 @@ __device__ __forceinline__ void axpy(Row<CH> &acc, float s, const Row<CH> &x) {
 //                  until evicted: hot rows diverge per XCD inside a launch).
 //   kAtomic:       hardware f32 atomics, one per element, lane-contiguous addresses (no lost
 //                  update; ~2-3x the store cost).
-//   kLocalAtomic:  f32 atomics at workgroup scope: executed by the XCD's L2 without leaving it.
-//                  Only valid for rows that a single XCD touches during the launch (the sliced
-//                  parts of the block trainer): exact accumulation at L2 speed.
-enum WriteMode : int { kWriteThrough = 0, kWriteBack = 1, kAtomic = 2, kLocalAtomic = 3 };
+enum WriteMode : int { kWriteThrough = 0, kWriteBack = 1, kAtomic = 2 };
 
-__host__ __device__ constexpr bool is_atomic(int wm) { return wm == kAtomic || wm == kLocalAtomic; }
-
-template <int WM>
-__device__ __forceinline__ void atomic_add_f32(float *p, float v) {
-    if constexpr (WM == kLocalAtomic)
-        (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-        unsafeAtomicAdd(p, v);
-}
+__host__ __device__ constexpr bool is_atomic(int wm) { return wm == kAtomic; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -166,10 +155,10 @@ __device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks
             // throughput of float4-shaped (16 B strided) atomics.
             float *pc = base + cc * 64 + q;
             const uint32_t f = cc * 64 + q, ldf = nchunks * 4;
-            if (f < ldf) atomic_add_f32<WM>(pc + 0, s * x.c[cc].x);
-            if (f + 16 < ldf) atomic_add_f32<WM>(pc + 16, s * x.c[cc].y);
-            if (f + 32 < ldf) atomic_add_f32<WM>(pc + 32, s * x.c[cc].z);
-            if (f + 48 < ldf) atomic_add_f32<WM>(pc + 48, s * x.c[cc].w);
+            if (f < ldf) unsafeAtomicAdd(pc + 0, s * x.c[cc].x);
+            if (f + 16 < ldf) unsafeAtomicAdd(pc + 16, s * x.c[cc].y);
+            if (f + 32 < ldf) unsafeAtomicAdd(pc + 32, s * x.c[cc].z);
+            if (f + 48 < ldf) unsafeAtomicAdd(pc + 48, s * x.c[cc].w);
         } else {
             const uint32_t ci = cc * 16 + q;
             if (ci < nchunks) {
@@ -195,18 +184,12 @@ __device__ __forceinline__ void scatter_add(float *base, int q, uint32_t nchunks
 // second.  Inline assembly: the clang builtin of this ROCm release returns the first result twice
 // (`v_add_f32 v1, v1, v1` after the swap).  The s_nop covers the VALU-write -> permlane-read hazard.
 __device__ __forceinline__ float sum_rows4(float x) {
-#ifdef GN2V_REDUCE_BPERMUTE
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    return x;
-#else
     float a = x, b = x;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     a += b;
     b = a;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
-#endif
 }
 
 // sum a register row over the four 16-lane groups of the wave
@@ -350,14 +333,12 @@ __device__ __forceinline__ float *sample_base(const TrainArgs &a, float *table, 
 // for each sample row v: var = (label - sigmoid(clip(u.v))) * lr ; g += var * v ; v += var * u.
 // u_upd is the copy of u the row update consumes (lane-contiguous shape in atomic mode).
 // DET: one sample at a time, all groups redundantly, group 0 writes (strict sequential semantics).
-// HUB: staged ids may carry bit 31 ("hot row", block trainer): such a row is updated with f32
-// atomics from *u_hub (u in the lane-contiguous layout) whatever WM says.
-template <int CH, int WM, bool DET, bool HUB = false, class Args>
+template <int CH, int WM, bool DET, class Args>
 __device__ __forceinline__ void score_samples(const Args &a, float *table, const Row<CH> &u,
                                               const Row<CH> &u_upd, Row<CH> &g,
                                               const uint32_t *s_rows,
                                               const float *s_lab, uint32_t n_samples, float lrc,
-                                              int grp, int q, const Row<CH> *u_hub = nullptr) {
+                                              int grp, int q) {
     const uint32_t nchunks = a.ld >> 2;
     if constexpr (DET) {
         for (uint32_t t = 0; t < n_samples; ++t) {
@@ -388,14 +369,7 @@ __device__ __forceinline__ void score_samples(const Args &a, float *table, const
                 const float dot = dot_rows<CH>(u, v);
                 const float var = mine ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
                 axpy<CH>(g, var, v);
-                if constexpr (HUB) {
-                    if (mine && (row & 0x80000000u))
-                        scatter_add<CH, kAtomic>(base, q, nchunks, var, *u_hub, v);
-                    else if (mine)
-                        scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
-                } else {
-                    if (mine) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
-                }
+                if (mine) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
             }
         }
     }
@@ -408,12 +382,11 @@ __device__ __forceinline__ void score_samples(const Args &a, float *table, const
 // (Hogwild).  Saves the per-round duplicate analysis of score_samples (three LDS reads, the pass
 // numbers, the pass loop): the block kernel issues ~800 instructions per pair with its SIMDs
 // busy 77 % of the time (rocprofv3 SQ_* counters, round 3), so instructions are not free.
-template <int CH, int WM, bool HUB, class Args>
+template <int CH, int WM, class Args>
 __device__ __forceinline__ void score_samples_racy(const Args &a, float *table, const Row<CH> &u,
                                                    const Row<CH> &u_upd, Row<CH> &g,
                                                    const uint32_t *s_rows, const float *s_lab,
-                                                   uint32_t n_samples, float lrc, int grp, int q,
-                                                   const Row<CH> *u_hub) {
+                                                   uint32_t n_samples, float lrc, int grp, int q) {
     const uint32_t nchunks = a.ld >> 2;
     for (uint32_t t0 = 0; t0 < n_samples; t0 += 4) {
         const uint32_t t = t0 + grp;
@@ -426,14 +399,7 @@ __device__ __forceinline__ void score_samples_racy(const Args &a, float *table, 
         const float dot = dot_rows<CH>(u, v);
         const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
         axpy<CH>(g, var, v);
-        if constexpr (HUB) {
-            if (valid && (row & 0x80000000u))
-                scatter_add<CH, kAtomic>(base, q, nchunks, var, *u_hub, v);
-            else if (valid)
-                scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
-        } else {
-            if (valid) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
-        }
+        if (valid) scatter_add<CH, WM>(base, q, nchunks, var, u_upd, v);
     }
 }
 

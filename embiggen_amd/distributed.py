@@ -288,14 +288,15 @@ class GpuBlockBackend:
             self._slots, self._temp = {}, None
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
-             epoch, lr, whole_central=False):
+             epoch, lr, whole_central=False, hot=None):
         from . import ops
 
         pairs, offsets, n_pairs = prepared[:3]
         if n_pairs == 0:
             return
         ops.block_step(self.graph, tp, plan, pairs, offsets, alias, cell_rows, central,
-                       context, block_id, part, seed, epoch, lr, whole_central=whole_central)
+                       context, block_id, part, seed, epoch, lr, whole_central=whole_central,
+                       hot=hot)
 
 
 class BlockPartitionedTrainer:
@@ -305,11 +306,15 @@ class BlockPartitionedTrainer:
     def __init__(self, graph, train_params, d: int, ld: int, seed: int, init_scale: float, comm,
                  device, walk_length: int, window: int, min_dist: int = 1,
                  scale_free: bool = True, backend=None, parts: Optional[int] = None,
-                 slices: Optional[int] = None, record: int = 32, hot_band=(0, 0),
-                 stripes: int = 1, group_parts: Optional[int] = None):
+                 slices: Optional[int] = None, record: int = 32, hot_rows: Optional[int] = None,
+                 hot_flush: int = 0, stripes: int = 1, group_parts: Optional[int] = None):
         """``group_parts``: the parts whose pairs are extracted, sorted and held at a time (None:
         all of a round at once; ``models.fit_transform_blocks`` and ``bench.py`` take it from
         ``round_plan``).  Every rank must pass the same value.
+
+        ``hot_rows``: the rows of every cell with the highest in-degrees whose updates are
+        accumulated in LDS and handed to the row with atomics (None: ``BLOCK_HOT_DEFAULT``; 0:
+        none, every row takes the plain stores); ``hot_flush``: see ``ops.block_plan``.
 
         ``stripes`` (one GPU only): the centres are split into that many stripes (centre c:
         stripe c % stripes) and a round is trained stripe after stripe, each stripe over the pairs
@@ -331,6 +336,10 @@ class BlockPartitionedTrainer:
                              "of the number of ranks, at least two per rank.")
         self.parts, self.slices = parts, slices
         self.per_rank = parts // world
+        if hot_rows is None:
+            from . import _lib
+
+            hot_rows = _lib.BLOCK_HOT_DEFAULT if scale_free else 0
         self.group_parts = parts if not group_parts else max(1, min(int(group_parts), parts))
         self.stripes = max(1, int(stripes))
         if self.stripes > 1 and world > 1:
@@ -342,13 +351,14 @@ class BlockPartitionedTrainer:
                               rank=j if self.stripes > 1 else rank, parts=parts, slices=slices,
                               walk_length=walk_length, window=window, min_dist=min_dist,
                               record=record, flags=int(train_params.flags) & 2,
-                              hot_lo=int(hot_band[0]), hot_hi=int(hot_band[1]))
+                              hot_rows=int(hot_rows), hot_flush=int(hot_flush))
             for j in range(self.stripes)]
         self.plan = self.plans[0]
         self.scale_free = bool(scale_free)
-        # per-cell alias tables for the negatives + the hot-row flags (rows updated by atomics)
-        self.alias, self.cell_rows, self.hub_bits = (
-            self.backend.alias_tables(self.plan) if scale_free else (None, None, None))
+        # per-cell alias tables for the negatives + the hot rows of every cell (flags, slots)
+        self.alias, self.cell_rows, self.hub_bits, hot_list, hot_slot = (
+            self.backend.alias_tables(self.plan) if scale_free else (None,) * 5)
+        self.hot = (hot_list, hot_slot) if hot_list is not None and hot_rows else None
         for p in range(parts):
             if stripe_rows(self.n_nodes, p, parts) == 0:
                 raise ValueError("A context part owns no node: graph too small to split this far.")
@@ -448,7 +458,7 @@ class BlockPartitionedTrainer:
             ctx = self.held[part]
             self.backend.step(self.tp, self.plans[stripe], prepared, self.alias, self.cell_rows,
                               self.central, ctx[: self.part_rows(part)], block_id, part, seed,
-                              epoch, lr, whole_central=striped)
+                              epoch, lr, whole_central=striped, hot=self.hot)
             if pending is not None:
                 if timed:
                     self._timed_wait(pending)

@@ -133,19 +133,21 @@ def init_table_rows(n_rows: int, d: int, seed: int, table_id: int, scale: float,
 # ------------------------------------------------------------- block-partitioned SkipGram
 def block_plan(graph: CSRGraph, world: int, rank: int, parts: int, slices: int, walk_length: int,
                window: int, min_dist: int = 1, record: int = 32, flags: int = 0, device: int = 0,
-               hot_lo: int = 0, hot_hi: int = 0):
-    """A validated ``gn2v_block_plan`` (row_bits filled in by the library).  ``hot_lo`` /
-    ``hot_hi``: contextual rows whose share of their cell's edge endpoints lies in
-    [2^-hot_lo, 2^-hot_hi) are updated with atomics (off by default)."""
+               hot_rows: int = 0, hot_flush: int = 0):
+    """A validated ``gn2v_block_plan`` (row_bits filled in by the library).  ``hot_rows``: the
+    rows of every cell with the highest in-degrees that ``block_alias`` flags (at most
+    ``_lib.BLOCK_HOT_MAX``; their updates are accumulated in LDS and handed over with atomics, on
+    average every ``hot_flush`` updates: 0 = 16)."""
     plan = _lib.BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, 0,
-                          flags, hot_lo, hot_hi, 0, 0)
+                          flags, hot_rows, hot_flush, 0, 0)
     _lib.check(_lib.lib().gn2v_block_plan_check(graph.device_graph(device).handle, C.byref(plan)))
     return plan
 
 
 def block_alias(graph: CSRGraph, plan, device: int = 0):
-    """(alias int64 [n_nodes], cell_rows int64 [cells + 1], hub_bits int32 [(n_nodes + 31) // 32]):
-    per-cell alias tables for degree-proportional negatives and the hot-row flags
+    """(alias int64 [n_nodes], cell_rows int64 [cells + 1], hub_bits int32 [(n_nodes + 31) // 32],
+    hot_list int32 [cells, BLOCK_HOT_MAX], hot_slot uint8 [n_nodes]): per-cell alias tables for
+    degree-proportional negatives, the hot-row flags and the hot rows' slots
     (``gn2v_block_alias``)."""
     torch = _torch()
     dg = graph.device_graph(device)
@@ -157,10 +159,14 @@ def block_alias(graph: CSRGraph, plan, device: int = 0):
     alias = torch.empty(n, dtype=torch.int64, device=dev)
     cell_rows = torch.empty(plan.parts * plan.slices + 1, dtype=torch.int64, device=dev)
     hub_bits = torch.empty((n + 31) // 32, dtype=torch.int32, device=dev)
+    hot_list = torch.empty((plan.parts * plan.slices, _lib.BLOCK_HOT_MAX), dtype=torch.int32,
+                           device=dev)
+    hot_slot = torch.empty(n, dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().gn2v_block_alias(dg.handle, C.byref(plan), alias.data_ptr(),
                                            cell_rows.data_ptr(), hub_bits.data_ptr(),
+                                           hot_list.data_ptr(), hot_slot.data_ptr(),
                                            temp.data_ptr(), need.value, _stream(dev)))
-    return alias, cell_rows, hub_bits
+    return alias, cell_rows, hub_bits, hot_list, hot_slot
 
 
 def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
@@ -214,8 +220,10 @@ def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, fi
 
 def block_step(graph: CSRGraph, tp, plan, pairs, cell_offsets, alias, cell_rows, central,
                context, block_id: int, part: int, seed: int, epoch: int, lr: float,
-               whole_central: bool = False, whole_context: bool = False):
+               whole_central: bool = False, whole_context: bool = False, hot=None):
     """Train the pairs of one context part (``gn2v_block_step``; tables updated in place).
+    ``hot``: (hot_list, hot_slot) of ``block_alias`` -- with them (and ``cell_rows``) the rows the
+    plan flags as hot accumulate their updates in LDS; without, they are ordinary rows.
     ``whole_central``: ``central`` is the whole table [n_nodes, ld] and the plan's rank one of its
     ``world`` centre stripes (one GPU training the stripes one after the other);
     ``whole_context``: ``context`` is the whole contextual table and the part its rows
@@ -232,8 +240,9 @@ def block_step(graph: CSRGraph, tp, plan, pairs, cell_offsets, alias, cell_rows,
     if whole_context:
         assert context.shape[0] == graph.get_number_of_nodes()
         x_ptr, x_ld = x_ptr + part * tp.ld * 4, plan.parts * tp.ld
-    io = _lib.BlockIO(ptr(pairs), ptr(cell_offsets), ptr(alias), ptr(cell_rows), c_ptr, x_ptr,
-                      block_id, part, c_ld, x_ld)
+    hot_list, hot_slot = hot if hot is not None else (None, None)
+    io = _lib.BlockIO(ptr(pairs), ptr(cell_offsets), ptr(alias), ptr(cell_rows), ptr(hot_list),
+                      ptr(hot_slot), c_ptr, x_ptr, block_id, part, c_ld, x_ld)
     _lib.check(_lib.lib().gn2v_block_step(dg.handle, C.byref(tp), C.byref(plan), C.byref(io),
                                           seed, epoch, lr, _stream(dev)))
 

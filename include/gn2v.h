@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GN2V_VERSION 200 /* 0.2.0: pair words, part groups */
+#define GN2V_VERSION 300 /* 0.3.0: hot rows of a cell accumulate in LDS (plan.hot_rows) */
 
 #define GN2V_SENTINEL 0xFFFFFFFFu /* walk positions after a trap node */
 
@@ -63,10 +63,6 @@ extern "C" {
  * left in HBM.  Switches: */
 #define GN2V_TRAIN_NO_CTX_CACHE 128u  /* always use the plain kernel                             */
 #define GN2V_TRAIN_CTX_CACHE_ALL 256u /* cache every row regardless of degree (tests)            */
-/* Block trainer with sliced parts: the contextual rows of a slice are touched by one XCD only, so
- * their updates can be f32 atomics executed inside that XCD's L2 (workgroup scope): no lost
- * update, no trip to memory. */
-#define GN2V_TRAIN_LOCAL_ATOMIC 512u
 /* gn2v_train picks its schedule: SkipGram on graphs of >= GN2V_BLOCK_PATH_MIN_NODES nodes in the
  * default update mode runs the block path (gn2v_train_blocks; one part of 8 XCD slices up to 2^18
  * nodes), everything else the walk-ordered kernels.  The limit is where the link quality of the
@@ -264,13 +260,16 @@ typedef struct {
     uint32_t record;      /* consecutive sorted pairs a wavefront takes at a time; 0 = 32     */
     uint32_t row_bits;    /* out (gn2v_block_plan_check): bits of the centre row in a pair word */
     uint32_t flags;       /* GN2V_TRAIN_DOWNSAMPLE: centres thinned while pairs are extracted */
-    /* Hot rows (off by default, both 0): contextual rows whose share of their cell's edge
-     * endpoints lies in [2^-hot_lo, 2^-hot_hi) (hot_hi = 0: no upper bound) are flagged by
-     * gn2v_block_alias and updated with hardware f32 atomics by gn2v_block_step: no lost update
-     * on rows that many wavefronts modify at once, at the price of the atomic units' throughput
-     * (e.g. 14 / 9 raises the link AUROC of small cells and costs 28 % speed). */
-    uint32_t hot_lo;
-    uint32_t hot_hi;
+    /* Hot rows: the `hot_rows` rows of every cell with the highest in-degrees (<=
+     * GN2V_BLOCK_HOT_MAX; 0 = none) are flagged by gn2v_block_alias.  They are the targets of the
+     * degree-proportional negatives (node2vec_skipgram.py:101-102): so many wavefronts
+     * read-modify-write them at once that plain stores keep a fraction of a percent of their
+     * updates.  gn2v_block_step accumulates the updates of a flagged row in the workgroup's LDS
+     * (exact) and hands the sums to the row with f32 atomics, on average every `hot_flush`
+     * updates of the row and workgroup (a power of two; 0 = 16): no update is lost, at the speed
+     * of the stores.  A launch whose LDS holds fewer rows takes the hottest. */
+    uint32_t hot_rows;
+    uint32_t hot_flush;
     uint32_t key_bits;    /* out (gn2v_block_plan_check): bits of a pair word in use (<= 64)   */
     uint32_t ctx_bits;    /* out: low bits of a pair word = context row inside its cell + hot flag */
 } gn2v_block_plan;
@@ -289,14 +288,18 @@ int gn2v_init_table_rows(float *d_table, uint64_t n_rows, uint32_t d, uint32_t l
  * (2^32 scale) | alias row << 32, cells in order, rows of a cell in order; d_cell_rows
  * u64[cells + 1] = first entry of every cell.  Weights are the in-degrees (a uniform random
  * edge's endpoint); integer arithmetic throughout.
- * Hot rows (plan->hot_lo / hot_hi, off by default) are flagged: bit 0 of an entry (the row itself;
- * the threshold keeps 31 bits), bit 63 (its alias row), and d_hub_bits u32[(n_nodes + 31) / 32],
- * one bit per node id; gn2v_block_step updates flagged rows with hardware f32 atomics (north
- * star: "HBM atomics on embedding rows"). */
+ * Hot rows (plan->hot_rows per cell: highest in-degree first, ties by row; in-degree >= 1) are
+ * flagged: bit 0 of an entry (the row itself; the threshold keeps 31 bits), bit 63 (its alias
+ * row), d_hub_bits u32[(n_nodes + 31) / 32] = one bit per node id (gn2v_block_extract copies it
+ * into the pair words), d_hot_list u32[cells][GN2V_BLOCK_HOT_MAX] = row inside its cell of hot
+ * slot s (GN2V_SENTINEL beyond the cell's count) and d_hot_slot u8[n_nodes] = slot of entry
+ * d_cell_rows[cell] + row (0xFF: not hot). */
+#define GN2V_BLOCK_HOT_MAX 192u
+#define GN2V_BLOCK_HOT_DEFAULT 192u /* what gn2v_train_blocks and the Python trainer flag */
 int gn2v_block_alias_temp_bytes(uint64_t n_nodes, uint64_t *bytes);
 int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_alias,
-                     uint64_t *d_cell_rows, uint32_t *d_hub_bits, void *d_temp,
-                     uint64_t temp_bytes, void *stream);
+                     uint64_t *d_cell_rows, uint32_t *d_hub_bits, uint32_t *d_hot_list,
+                     uint8_t *d_hot_slot, void *d_temp, uint64_t temp_bytes, void *stream);
 
 /* Pairs of a round.  d_walks holds the walks of ALL ranks for the round (ids first_walk,
  * first_walk + 1, ...; all-gathered); this rank keeps the pairs whose centre it owns and whose
@@ -328,7 +331,9 @@ typedef struct {
     const uint64_t *d_pairs;         /* sorted pair words of the group (gn2v_block_extract)    */
     const uint64_t *d_cell_offsets;  /* [cells + 1] (gn2v_block_count)                         */
     const uint64_t *d_alias;         /* gn2v_block_alias; unused without GN2V_TRAIN_SCALE_FREE */
-    const uint64_t *d_cell_rows;
+    const uint64_t *d_cell_rows;     /* gn2v_block_alias: needed for d_alias and for the hot rows */
+    const uint32_t *d_hot_list;      /* gn2v_block_alias; both NULL: flagged rows are ordinary rows */
+    const uint8_t *d_hot_slot;
     float *d_central;                /* this rank's central partition f32[rows][central_ld]    */
     float *d_context;                /* context part `part`, resident here, f32[rows][context_ld] */
     uint64_t block_id;               /* RNG stream of the negatives: unique per (round, rank)  */

@@ -958,7 +958,8 @@ typedef struct {
     uint32_t walk_length, window, min_dist, record;
     uint32_t row_bits;
     uint32_t flags;
-    uint32_t hot_lo, hot_hi; /* band of "hot" rows, 0 / 0 = off (see o_block_alias) */
+    uint32_t hot_rows;  /* rows a cell flags as "hot", 0 = none (see o_block_alias) */
+    uint32_t hot_flush; /* device only: how often a hot row's pending sum reaches the row */
     uint32_t key_bits;       /* bits of a pair word in use */
     uint32_t ctx_bits;       /* low bits: context row inside its cell + the hot flag on top */
 } o_block_plan;
@@ -1075,15 +1076,22 @@ static inline uint64_t scaled_threshold(uint64_t w, uint64_t D) {
  * random directed edge, node2vec_skipgram.py:101-102).  table[cell_rows[c] + i] = threshold on a
  * 2^32 scale | alias row << 32 for row i of cell c.  A draw r picks i = mulhi(r, n) and keeps it
  * when (u32) r < threshold, else takes the alias. */
-/* Hot rows (in-degree share of the cell's total in [2^-hot_lo, 2^-hot_hi); 0 / 0 = none) are
- * flagged: bit 0 of an entry = the row itself (the threshold keeps its upper 31 bits), bit 63 =
- * its alias row, hub_bits = one bit per node id.  The flags steer the device's store flavour
- * only; this file's arithmetic ignores them. */
-void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t hot_lo,
-                   uint32_t hot_hi, uint64_t *table, uint64_t *cell_rows, uint32_t *hub_bits) {
+/* Hot rows of a cell: its `hot_rows` rows of highest in-degree (>= 1; ties: the lower row first;
+ * at most O_HOT_MAX).  They are flagged: bit 0 of an entry = the row itself (the threshold keeps
+ * its upper 31 bits), bit 63 = its alias row, hub_bits = one bit per node id; hot_list[cell][s] =
+ * row inside the cell of slot s in decreasing order of in-degree (0xFFFFFFFF beyond the cell's
+ * count), hot_slot[cell_rows[cell] + row] = slot (0xFF: not hot).  The flags steer how the device
+ * accumulates the updates of such rows (LDS sums handed over with atomics); this file's
+ * arithmetic ignores them. */
+#define O_HOT_MAX 192u
+void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t hot_rows,
+                   uint64_t *table, uint64_t *cell_rows, uint32_t *hub_bits, uint32_t *hot_list,
+                   uint8_t *hot_slot) {
     uint32_t *indeg = (uint32_t *)calloc(g->n_nodes, sizeof(uint32_t));
     for (uint64_t e = 0; e < g->n_edges; ++e) indeg[g->col_idx[e]]++;
     memset(hub_bits, 0, sizeof(uint32_t) * ((g->n_nodes + 31) / 32));
+    memset(hot_slot, 0xFF, g->n_nodes);
+    if (hot_rows > O_HOT_MAX) hot_rows = O_HOT_MAX;
     uint64_t run = 0;
     for (uint32_t p = 0; p < parts; ++p) {
         uint64_t part_rows = stripe_count(g->n_nodes, p, parts);
@@ -1099,19 +1107,34 @@ void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t h
         uint32_t part = cell / slices, slice = cell % slices;
         uint64_t lo = cell_rows[cell], n = cell_rows[cell + 1] - lo, D = 0;
         uint64_t *t = table + lo;
+        uint32_t *hl = hot_list + (size_t)cell * O_HOT_MAX, n_hot = 0;
+        for (uint32_t s = 0; s < O_HOT_MAX; ++s) hl[s] = 0xFFFFFFFFu;
         if (n == 0) continue;
-        for (uint64_t i = 0; i < n; ++i) D += indeg[(slice + (uint64_t)slices * i) * parts + part];
-        uint64_t n_small = 0, n_large = 0; /* small stack from st[0], large from st[n - 1] */
 #define O_NODE_OF(i) ((slice + (uint64_t)slices * (i)) * parts + part)
-/* share of the cell's endpoints in [2^-hot_lo, 2^-hot_hi): d * 2^s >= D <=> d >= ceil(D / 2^s) */
-#define O_HOT(i)                                                                            \
-    ((uint64_t)(hot_lo != 0 && D != 0 &&                                                    \
-                indeg[O_NODE_OF(i)] >= ((D + (1ULL << hot_lo) - 1) >> hot_lo) &&            \
-                (hot_hi == 0 || indeg[O_NODE_OF(i)] < ((D + (1ULL << hot_hi) - 1) >> hot_hi))))
+        for (uint64_t i = 0; i < n; ++i) {
+            uint32_t d = indeg[O_NODE_OF(i)];
+            D += d;
+            /* the hot_rows highest in-degrees by insertion: a later row only displaces a
+             * strictly smaller in-degree */
+            if (d != 0 && hot_rows != 0 &&
+                (n_hot < hot_rows || d > indeg[O_NODE_OF(hl[n_hot - 1])])) {
+                uint32_t pos = n_hot < hot_rows ? n_hot++ : n_hot - 1;
+                while (pos > 0 && indeg[O_NODE_OF(hl[pos - 1])] < d) {
+                    hl[pos] = hl[pos - 1];
+                    --pos;
+                }
+                hl[pos] = (uint32_t)i;
+            }
+        }
+        for (uint32_t s = 0; s < n_hot; ++s) {
+            hot_slot[lo + hl[s]] = (uint8_t)s;
+            hub_bits[O_NODE_OF(hl[s]) >> 5] |= 1u << (O_NODE_OF(hl[s]) & 31);
+        }
+        uint64_t n_small = 0, n_large = 0; /* small stack from st[0], large from st[n - 1] */
+#define O_HOT(i) ((uint64_t)(hot_slot[lo + (i)] != 0xFF))
         for (uint64_t i = 0; i < n; ++i) {
             uint64_t p = (uint64_t)indeg[O_NODE_OF(i)] * n;
             w[i] = p;
-            if (O_HOT(i)) hub_bits[O_NODE_OF(i) >> 5] |= 1u << (O_NODE_OF(i) & 31);
             if (D == 0 || p >= D)
                 st[n - 1 - n_large++] = (uint32_t)i;
             else

@@ -342,12 +342,12 @@ class BlockPlan(C.Structure):
 
     _fields_ = [(name, C.c_uint32) for name in (
         "world", "rank", "parts", "slices", "walk_length", "window", "min_dist", "record",
-        "row_bits", "flags", "hot_lo", "hot_hi", "key_bits", "ctx_bits")]
+        "row_bits", "flags", "hot_rows", "hot_flush", "key_bits", "ctx_bits")]
 
 
 def block_plan(n_nodes: int, world: int, rank: int, parts: int, slices: int, walk_length: int,
-               window: int, min_dist: int = 1, record: int = 16, flags: int = 0, hot_lo: int = 0,
-               hot_hi: int = 0) -> BlockPlan:
+               window: int, min_dist: int = 1, record: int = 16, flags: int = 0,
+               hot_rows: int = 0) -> BlockPlan:
     L = lib()
     for fn in (L.o_block_row_bits, L.o_block_ctx_bits, L.o_block_cell_bits):
         fn.restype = C.c_uint32
@@ -355,7 +355,7 @@ def block_plan(n_nodes: int, world: int, rank: int, parts: int, slices: int, wal
     ctx_bits = L.o_block_ctx_bits(C.c_uint64(n_nodes), C.c_uint32(parts), C.c_uint32(slices))
     cell_bits = L.o_block_cell_bits(C.c_uint32(parts), C.c_uint32(slices))
     return BlockPlan(world, rank, parts, slices, walk_length, window, min_dist, record, row_bits,
-                     flags, hot_lo, hot_hi, cell_bits + row_bits + ctx_bits, ctx_bits)
+                     flags, hot_rows, 0, cell_bits + row_bits + ctx_bits, ctx_bits)
 
 
 def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: int,
@@ -412,15 +412,24 @@ def block_pack(cell, centre_row, part_row, plan: BlockPlan, hot=None):
     return (key << np.uint64(plan.ctx_bits)) | (hot << np.uint64(plan.ctx_bits - 1)) | local
 
 
-def block_alias(g: OracleGraph, parts: int, slices: int, hot_lo: int = 0, hot_hi: int = 0):
-    """(alias tables u64[n_nodes], cell_rows u64[cells + 1], hub_bits u32[(n_nodes + 31) // 32]):
-    entry = hot(row) | threshold (31 bits) | alias row << 32 | hot(alias row) << 63."""
+HOT_MAX = 192  # O_HOT_MAX / GN2V_BLOCK_HOT_MAX
+
+
+def block_alias(g: OracleGraph, parts: int, slices: int, hot_rows: int = 0):
+    """(alias tables u64[n_nodes], cell_rows u64[cells + 1], hub_bits u32[(n_nodes + 31) // 32],
+    hot_list u32[cells, HOT_MAX], hot_slot u8[n_nodes]):
+    entry = hot(row) | threshold (31 bits) | alias row << 32 | hot(alias row) << 63; the hot rows
+    of a cell are its ``hot_rows`` rows of highest in-degree (hot_list: slot -> row inside the
+    cell, hot_slot: entry -> slot or 0xFF)."""
     table = np.zeros(g.n_nodes, dtype=np.uint64)
     cell_rows = np.empty(parts * slices + 1, dtype=np.uint64)
     hub_bits = np.zeros((g.n_nodes + 31) // 32, dtype=np.uint32)
-    lib().o_block_alias(C.byref(g.c), C.c_uint32(parts), C.c_uint32(slices), C.c_uint32(hot_lo),
-                        C.c_uint32(hot_hi), _ptr(table), _ptr(cell_rows), _ptr(hub_bits))
-    return table, cell_rows, hub_bits
+    hot_list = np.empty((parts * slices, HOT_MAX), dtype=np.uint32)
+    hot_slot = np.empty(g.n_nodes, dtype=np.uint8)
+    lib().o_block_alias(C.byref(g.c), C.c_uint32(parts), C.c_uint32(slices), C.c_uint32(hot_rows),
+                        _ptr(table), _ptr(cell_rows), _ptr(hub_bits), _ptr(hot_list),
+                        _ptr(hot_slot))
+    return table, cell_rows, hub_bits, hot_list, hot_slot
 
 
 def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, words, cell_offsets, alias,

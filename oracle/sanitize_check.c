@@ -100,7 +100,11 @@ int main(void) {
         uint64_t *bk = malloc(sizeof(uint64_t) * cap);
         uint32_t hub[(N + 31) / 32];
         uint64_t *alias = malloc(sizeof(uint64_t) * N), poff[13];
-        o_block_alias(&g, 6, 2, bp.hot_lo, bp.hot_hi, alias, poff, hub);
+        uint32_t *hot_list = malloc(sizeof(uint32_t) * 12 * 192);
+        uint8_t *hot_slot = malloc(N);
+        o_block_alias(&g, 6, 2, bp.hot_rows, alias, poff, hub, hot_list, hot_slot);
+        free(hot_list);
+        free(hot_slot);
         /* two groups of parts (the second wraps round), then the whole round */
         uint64_t n_a = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 4, 3, hub, bk);
         uint64_t n_b = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 1, 3, hub, bk);

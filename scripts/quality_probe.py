@@ -53,7 +53,9 @@ if __name__ == "__main__":
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--modes", default="write_through,write_back,atomic")
-    ap.add_argument("--hot-band", default="0:0", help="blocks modes: lo:hi (see bench.py)")
+    ap.add_argument("--hot-rows", type=int, default=None,
+                    help="blocks modes: hot rows per cell (see bench.py; default the library's)")
+    ap.add_argument("--hot-flush", type=int, default=0, help="blocks modes: see bench.py")
     ap.add_argument("--round-walks", type=int, default=1 << 19, help="blocks modes: walks per round")
     ap.add_argument("--stripes", type=int, default=1, help="blocks modes: centre stripes")
     ap.add_argument("--central-atomic", action="store_true",
@@ -75,19 +77,18 @@ if __name__ == "__main__":
             f = mode.split(":")
             parts, slices = int(f[1]), int(f[2])
             record = int(f[3]) if len(f) > 3 and f[3] else 32
-            # 5th field: "la" = L2-local atomics on the XCD-exclusive contextual rows, "st" = plain
-            # stores there; both name the store flavour explicitly, so they also apply below 2^16
-            # nodes, where the automatic choice is atomics on every row
+            # 5th field: "st" = plain stores on the XCD-exclusive contextual rows named explicitly,
+            # so that they also apply below 2^16 nodes, where the automatic choice is atomics on
+            # every row; "at" = atomics on every row
             kind = f[4] if len(f) > 4 else ""
-            extra = {"": 0, "la": _lib.TRAIN_LOCAL_ATOMIC | _lib.TRAIN_WRITE_THROUGH,
-                     "st": _lib.TRAIN_WRITE_THROUGH}[kind]
+            extra = {"": 0, "st": _lib.TRAIN_WRITE_THROUGH, "at": _lib.TRAIN_ATOMIC}[kind]
             if a.central_atomic:
                 extra |= _lib.TRAIN_CENTRAL_ATOMIC
             tp = ops.train_params(0, d, 10, 5, flags=1 | extra, ld=d)
             tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
                                          walk_length=128, window=5, parts=parts, slices=slices,
                                          record=record,
-                                         hot_band=tuple(int(v) for v in a.hot_band.split(":")),
+                                         hot_rows=a.hot_rows, hot_flush=a.hot_flush,
                                          stripes=a.stripes, group_parts=a.group_parts or None)
             ops.stats_reset(g)
             t0 = time.time()

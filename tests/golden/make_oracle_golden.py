@@ -27,12 +27,11 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "oracle_karate.npz"), **out)
     print("written", {k: np.shape(v) for k, v in out.items()})
 
-    # block-partitioned schedule (round 2): rank 1 of 2, 4 parts x 2 slices, a hot band
+    # block-partitioned schedule (round 2): rank 1 of 2, 4 parts x 2 slices, two hot rows per cell
     blk = {}
-    plan = O.block_plan(34, 2, 1, 4, 2, 16, 3, 1, 4, hot_lo=4, hot_hi=1)
-    words, offsets = O.block_extract(og, plan, out["walks"], 42, 0, 0,
-                                     hub_bits=O.block_alias(og, 4, 2, 4, 1)[2])
-    alias, cell_rows, hub_bits = O.block_alias(og, 4, 2, 4, 1)
+    plan = O.block_plan(34, 2, 1, 4, 2, 16, 3, 1, 4, hot_rows=2)
+    alias, cell_rows, hub_bits, hot_list, hot_slot = O.block_alias(og, 4, 2, 2)
+    words, offsets = O.block_extract(og, plan, out["walks"], 42, 0, 0, hub_bits=hub_bits)
     tp = O.TrainParams(0, 8, 8, 1, 4, 3, 0.01, 0.9, 6.0, 1, 8 ** -0.5)
     central = O.init_table_rows(17, 8, 8, 42, 0, 8 ** -0.5, 1, 2)
     parts = []
@@ -43,6 +42,6 @@ if __name__ == "__main__":
                      0, 0.05)
         parts.append(x)
     blk.update(words=words, offsets=offsets, alias=alias, cell_rows=cell_rows,
-               hub_bits=hub_bits, central=central, **{f"part{p}": x for p, x in enumerate(parts)})
+               hub_bits=hub_bits, hot_list=hot_list, hot_slot=hot_slot, central=central, **{f"part{p}": x for p, x in enumerate(parts)})
     np.savez_compressed(os.path.join(HERE, "oracle_blocks.npz"), **blk)
     print("written", {k: np.shape(v) for k, v in blk.items()})

@@ -117,12 +117,12 @@ class OracleBlockBackend:
         return torch.zeros((n_rows, ld), dtype=torch.float32)
 
     def plan(self, world, rank, parts, slices, walk_length, window, min_dist, record, flags,
-             hot_lo=0, hot_hi=0):
+             hot_rows=0, hot_flush=0):
         return O.block_plan(self.graph.get_number_of_nodes(), world, rank, parts, slices,
-                            walk_length, window, min_dist, record, flags, hot_lo, hot_hi)
+                            walk_length, window, min_dist, record, flags, hot_rows)
 
     def alias_tables(self, plan):
-        return O.block_alias(self.og, plan.parts, plan.slices, plan.hot_lo, plan.hot_hi)
+        return O.block_alias(self.og, plan.parts, plan.slices, plan.hot_rows)
 
     def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None, part_lo=0,
                 part_n=0):
@@ -132,7 +132,7 @@ class OracleBlockBackend:
         return words, offsets, len(words)
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
-             epoch, lr, whole_central=False):
+             epoch, lr, whole_central=False, hot=None):
         words, offsets, n_pairs = prepared[:3]
         if n_pairs == 0:
             return

@@ -106,8 +106,9 @@ def _alias_probabilities(table, n):
 def test_alias_tables_are_degree_proportional_inside_a_cell():
     g = _graph(97)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    table, cell_rows, hub_bits = O.block_alias(og, 4, 2, hot_lo=4, hot_hi=2)
+    table, cell_rows, hub_bits, hot_list, hot_slot = O.block_alias(og, 4, 2, hot_rows=3)
     plain = O.block_alias(og, 4, 2)  # default: no hot rows, same law
+    assert (plain[3] == 0xFFFFFFFF).all() and (plain[4] == 0xFF).all()
     assert not plain[2].any() and not (plain[0] & np.uint64(1)).any() and not (plain[0] >> np.uint64(63)).any()
     assert np.array_equal(plain[0] >> np.uint64(1) << np.uint64(1) & np.uint64(0x7FFFFFFFFFFFFFFF),
                           table >> np.uint64(1) << np.uint64(1) & np.uint64(0x7FFFFFFFFFFFFFFF))
@@ -124,10 +125,15 @@ def test_alias_tables_are_degree_proportional_inside_a_cell():
         assert np.abs(p - want).max() < 1e-8 and abs(p.sum() - 1) < 1e-9
         alias_row = (table[lo:hi] >> np.uint64(32)) & np.uint64(0x7FFFFFFF)
         assert (alias_row < hi - lo).all()
-        # hot rows: share of the cell's edge endpoints in [2^-4, 2^-2)
-        total = indeg[nodes].sum()
-        hot = (indeg[nodes] * 16 >= total) & (indeg[nodes] * 4 < total)
-        assert hot.any() and not hot.all()
+        # hot rows: the three highest in-degrees of the cell (ties: the lower row first), in
+        # slot order; every other slot of the list is empty
+        order = sorted(range(hi - lo), key=lambda i: (-indeg[nodes[i]], i))[:3]
+        assert list(hot_list[cell][:3]) == order and (hot_list[cell][3:] == 0xFFFFFFFF).all()
+        hot = np.zeros(hi - lo, dtype=bool)
+        hot[order] = True
+        want_slot = np.full(hi - lo, 0xFF, dtype=np.uint8)
+        want_slot[order] = np.arange(3)
+        assert np.array_equal(hot_slot[lo:hi], want_slot)
         assert np.array_equal((table[lo:hi] & np.uint64(1)).astype(bool), hot)
         assert np.array_equal((table[lo:hi] >> np.uint64(63)).astype(bool), hot[alias_row.astype(int)])
         assert np.array_equal(((hub_bits[nodes >> 5] >> (nodes & 31)) & 1).astype(bool), hot)
@@ -162,7 +168,7 @@ def test_step_properties_zero_lr_counts_and_untouched_rows():
     walks = O.walks(og, O.WalkParams(L, 1, 1.0, 1.0, 100, 0), 5, 0, 0, 30)
     plan = O.block_plan(97, 1, 0, 2, 1, L, W, 1, 4)
     words, offsets = O.block_extract(og, plan, walks, 5, 0, 0)
-    alias, cell_rows, _ = O.block_alias(og, 2, 1)
+    alias, cell_rows = O.block_alias(og, 2, 1)[:2]
     c = O.init_table_rows(97, D, D, 5, 0, 0.3, 0, 1)
     assert np.array_equal(c, O.init_table(97, D, D, 5, 0, 0.3))
     parts = [O.init_table_rows(stripe_rows(97, p, 2), D, D, 5, 1, 0.3, p, 2) for p in range(2)]
@@ -193,7 +199,7 @@ def test_world_one_trainer_is_the_plain_sequence_of_block_steps():
     g = _graph()
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     plan = O.block_plan(34, 1, 0, 2, 1, L, W, 1, 4)
-    alias, cell_rows, _ = O.block_alias(og, 2, 1)
+    alias, cell_rows = O.block_alias(og, 2, 1)[:2]
     rc = O.init_table(34, D, D, 42, 0, D ** -0.5)
     rx = O.init_table(34, D, D, 42, 1, D ** -0.5)
     parts = [np.ascontiguousarray(rx[p::2]) for p in range(2)]
@@ -221,7 +227,7 @@ def test_centre_stripes_are_the_sequence_of_block_steps_of_that_many_ranks(strip
                                    stripes=stripes)
     g = _graph(97)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    alias, cell_rows, _ = O.block_alias(og, parts, slices)
+    alias, cell_rows = O.block_alias(og, parts, slices)[:2]
     rc = O.init_table(97, D, D, 42, 0, D ** -0.5)
     rx = O.init_table(97, D, D, 42, 1, D ** -0.5)
     ctx = [np.ascontiguousarray(rx[p::parts]) for p in range(parts)]

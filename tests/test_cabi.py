@@ -27,14 +27,14 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_lib.build())
     for name in declared_symbols():
         assert hasattr(L, name), name
-    assert _lib.lib().gn2v_version() == 200
+    assert _lib.lib().gn2v_version() == 300
 
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.WalkParams) == 32
     assert C.sizeof(_lib.TrainParams) == 48
     assert C.sizeof(_lib.Stats) == 72
-    assert C.sizeof(_lib.BlockPlan) == 14 * 4 and C.sizeof(_lib.BlockIO) == 80
+    assert C.sizeof(_lib.BlockPlan) == 14 * 4 and C.sizeof(_lib.BlockIO) == 96
     text = open(HEADER).read()
     for name, value in (("GN2V_TRAIN_SCALE_FREE", _lib.TRAIN_SCALE_FREE),
                         ("GN2V_TRAIN_DOWNSAMPLE", _lib.TRAIN_DOWNSAMPLE),
@@ -43,7 +43,6 @@ def test_struct_layouts_match_header():
                         ("GN2V_TRAIN_ATOMIC", _lib.TRAIN_ATOMIC),
                         ("GN2V_TRAIN_WRITE_BACK", _lib.TRAIN_WRITE_BACK),
                         ("GN2V_TRAIN_WRITE_THROUGH", _lib.TRAIN_WRITE_THROUGH),
-                        ("GN2V_TRAIN_LOCAL_ATOMIC", _lib.TRAIN_LOCAL_ATOMIC),
                         ("GN2V_TRAIN_WALK_ORDERED", _lib.TRAIN_WALK_ORDERED),
                         ("GN2V_TRAIN_BLOCK_PATH", _lib.TRAIN_BLOCK_PATH),
                         ("GN2V_TRAIN_CENTRAL_ATOMIC", _lib.TRAIN_CENTRAL_ATOMIC),

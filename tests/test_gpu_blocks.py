@@ -36,6 +36,23 @@ def _dev_words(words):
     return torch.from_numpy(np.ascontiguousarray(words).view(np.int64)).cuda()
 
 
+def _hot_tables(n_nodes, parts, slices, hot):
+    """(cell_rows, (hot_list, hot_slot)) device tensors for hand-made pair words: ``hot`` maps a
+    cell to the rows inside it (row of the part // slices) that are hot, in slot order."""
+    cell_rows = np.zeros(parts * slices + 1, dtype=np.int64)
+    for p in range(parts):
+        rows = stripe_rows(n_nodes, p, parts)
+        for sl in range(slices):
+            cell_rows[p * slices + sl + 1] = cell_rows[p * slices + sl] + stripe_rows(rows, sl, slices)
+    hot_list = np.full((parts * slices, _lib.BLOCK_HOT_MAX), -1, dtype=np.int32)
+    hot_slot = np.full(n_nodes, 0xFF, dtype=np.uint8)
+    for cell, rows in hot.items():
+        hot_list[cell, :len(rows)] = rows
+        hot_slot[cell_rows[cell] + np.asarray(rows, dtype=np.int64)] = np.arange(len(rows))
+    return (torch.from_numpy(cell_rows).cuda(),
+            (torch.from_numpy(hot_list).cuda(), torch.from_numpy(hot_slot).cuda()))
+
+
 def test_walk_pairs_match_oracle(karate, karate_oracle):
     wk = ops.walks(karate, ops.walk_params(20, 2, 0.5, 2.0), 3, 0, 0, 68)
     wk_h = wk.cpu().numpy().view(np.uint32)
@@ -65,12 +82,12 @@ def test_extraction_and_sort_are_bit_exact(world, rank, parts, slices, md):
     wk = ops.walks(g, ops.walk_params(24, 4, 0.5, 2.0), 5, 1, 100, 300)
     wk[::5, 9:] = -1   # ended walks
     wk[7] = -1         # a padding walk (rank with no walks left)
-    plan = ops.block_plan(g, world, rank, parts, slices, 24, 4, md, 4, hot_lo=5, hot_hi=0)
-    oplan = O.block_plan(203, world, rank, parts, slices, 24, 4, md, 4, hot_lo=5, hot_hi=0)
+    plan = ops.block_plan(g, world, rank, parts, slices, 24, 4, md, 4, hot_rows=5)
+    oplan = O.block_plan(203, world, rank, parts, slices, 24, 4, md, 4, hot_rows=5)
     assert (plan.row_bits, plan.ctx_bits, plan.key_bits) == (oplan.row_bits, oplan.ctx_bits,
                                                              oplan.key_bits)
-    _, _, hub_bits = ops.block_alias(g, plan)
-    ohub = O.block_alias(og, parts, slices, 5, 0)[2]
+    hub_bits = ops.block_alias(g, plan)[2]
+    ohub = O.block_alias(og, parts, slices, 5)[2]
     work, offsets = ops.block_count(g, plan, wk, 5, 1, 100)
     n = int(offsets[-1])
     pairs = ops.block_extract(g, plan, wk, 5, 1, 100, work, n, hub_bits=hub_bits)
@@ -142,31 +159,34 @@ def test_extraction_honours_centre_downsampling(karate, karate_oracle):
     assert np.array_equal(_words(pairs), rw)
 
 
-@pytest.mark.parametrize("parts,slices,band", [(1, 1, (0, 0)), (4, 1, (6, 0)), (6, 8, (5, 2)),
-                                               (16, 8, (0, 0)), (16, 8, (3, 1))])
-def test_alias_tables_are_bit_exact(parts, slices, band):
+@pytest.mark.parametrize("parts,slices,hot_rows", [(1, 1, 0), (4, 1, 6), (6, 8, 5), (16, 8, 0),
+                                                   (16, 8, 3), (1, 8, 192), (2, 2, 48)])
+def test_alias_tables_are_bit_exact(parts, slices, hot_rows):
+    """Alias tables, hot-row flags, the cells' hot lists (slot -> row, by decreasing in-degree)
+    and the slot table (row -> slot) against the oracle's restatement."""
     g = _ba(997, 4)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, hot_lo=band[0], hot_hi=band[1])
-    alias, cell_rows, hub_bits = ops.block_alias(g, plan)
-    ra, rc, rh = O.block_alias(og, parts, slices, *band)
+    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, hot_rows=hot_rows)
+    alias, cell_rows, hub_bits, hot_list, hot_slot = ops.block_alias(g, plan)
+    ra, rc, rh, rl, rs = O.block_alias(og, parts, slices, hot_rows)
     assert np.array_equal(cell_rows.cpu().numpy().astype(np.uint64), rc)
     assert np.array_equal(alias.cpu().numpy().view(np.uint64), ra)
-    assert np.array_equal(hub_bits.cpu().numpy().view(np.uint32), rh) and rh.any() == (band[0] > 0)
+    assert np.array_equal(hub_bits.cpu().numpy().view(np.uint32), rh) and rh.any() == (hot_rows > 0)
+    assert np.array_equal(hot_list.cpu().numpy().view(np.uint32), rl)
+    assert np.array_equal(hot_slot.cpu().numpy(), rs) and (rs != 0xFF).any() == (hot_rows > 0)
 
 
 def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, n_walks=60,
-               wl=14, window=3, part_list=None, scale_free=True, extra=0, band=(0, 0)):
+               wl=14, window=3, part_list=None, scale_free=True, extra=0, hot_rows=0):
     """One round through gn2v_block_step and through the oracle; returns both table sets."""
     n = g.get_number_of_nodes()
     ld = (d + 3) // 4 * 4
     wk = ops.walks(g, ops.walk_params(wl, 2, 0.5, 2.0), 11, 0, 0, n_walks)
-    plan = ops.block_plan(g, world, rank, parts, slices, wl, window, 1, record, hot_lo=band[0],
-                          hot_hi=band[1])
-    oplan = O.block_plan(n, world, rank, parts, slices, wl, window, 1, record, hot_lo=band[0],
-                         hot_hi=band[1])
+    plan = ops.block_plan(g, world, rank, parts, slices, wl, window, 1, record,
+                          hot_rows=hot_rows)
+    oplan = O.block_plan(n, world, rank, parts, slices, wl, window, 1, record, hot_rows=hot_rows)
     work, offsets = ops.block_count(g, plan, wk, 11, 0, 0)
-    alias, cell_rows, hub_bits = ops.block_alias(g, plan)
+    alias, cell_rows, hub_bits, hot_list, hot_slot = ops.block_alias(g, plan)
     pairs = ops.block_extract(g, plan, wk, 11, 0, 0, work, int(offsets[-1]), hub_bits=hub_bits)
     sf = (1 if scale_free else 0) | extra
     tp = ops.train_params(0, d, k, window, flags=sf | flags, ld=ld)
@@ -181,7 +201,8 @@ def _step_both(g, og, d, k, world, rank, parts, slices, record, flags, lr=0.05, 
     for part in (range(parts) if part_list is None else part_list):
         x = ops.init_table_rows(stripe_rows(n, part, parts), d, 11, 1, d ** -0.5, part, parts, ld=ld)
         x_h = x.cpu().numpy().copy()
-        ops.block_step(g, tp, plan, pairs, offsets, alias, cell_rows, c, x, 3, part, 11, 0, lr)
+        ops.block_step(g, tp, plan, pairs, offsets, alias, cell_rows, c, x, 3, part, 11, 0, lr,
+                       hot=(hot_list, hot_slot))
         trained += O.block_step(og, otp, oplan, rw, ro, rp, rpo, c_h, x_h, 3, part, 11, 0, lr)
         got_x.append(x.cpu().numpy())
         ref_x.append(x_h)
@@ -211,12 +232,12 @@ def test_deterministic_block_step_over_plans(world, rank, parts, slices, record)
 
 
 def test_hot_row_flags_do_not_change_the_deterministic_result():
-    """A band that flags many rows as hot: the flags only steer the store flavour, the
-    deterministic schedule still equals the oracle (which masks them).  The mixed store / atomic
+    """Many rows flagged as hot: the flags only steer how the parallel schedules accumulate, the
+    deterministic schedule still equals the oracle (which masks them).  The mixed store / LDS
     rounds of the production flavours are exercised, exactly, by the collision-free test below."""
     g = _ba(203)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    c, xs, c_h, xs_h = _step_both(g, og, D, K, 2, 1, 4, 2, 4, DET, band=(5, 0))
+    c, xs, c_h, xs_h = _step_both(g, og, D, K, 2, 1, 4, 2, 4, DET, hot_rows=12)
     assert np.abs(c - c_h).max() < 1e-5
     for x, x_h in zip(xs, xs_h):
         assert np.abs(x - x_h).max() < 1e-5
@@ -236,18 +257,20 @@ def test_uniform_negatives_and_degree_normalised_learning_rate(karate, karate_or
 def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
     """Thousands of records in one launch with k = 0 and every row used once: with no row shared
     between records the parallel schedule (dynamic record tickets, four rows per wave round, XCD
-    slices, every store flavour) must equal the sequential oracle."""
+    slices, every store flavour, hot rows through the LDS accumulators) must equal the
+    sequential oracle."""
     n_pairs, parts, record = 40_000, 2, 16
     n_rows = 2 * n_pairs
     # synthetic sorted pairs: centre row i (unique, ascending), context row perm[i] of the cell
     g = _ba(2 * n_rows + 5)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, 1, record, hot_lo=1)  # hot rows exist
-    oplan = O.block_plan(2 * n_rows + 5, 1, 0, parts, slices, 8, 2, 1, record, hot_lo=1)
+    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, 1, record, hot_rows=192)
+    oplan = O.block_plan(2 * n_rows + 5, 1, 0, parts, slices, 8, 2, 1, record, hot_rows=192)
     rng = np.random.RandomState(3)
     rows_per_part = stripe_rows(2 * n_rows + 5, 0, parts)
     words_l, offsets = [], [0]
     next_centre = 0
+    hot_rows = {}
     for cell in range(parts * slices):
         slc = cell % slices
         cand = np.arange(slc, rows_per_part - 1, slices)
@@ -255,9 +278,14 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
         ctx = rng.permutation(cand)[:m]
         centres = next_centre + np.arange(m)
         next_centre += m
-        hot = np.arange(m) % 2  # every other context row is "hot": updated by atomics
+        # every 20th context row is "hot" (more of them than any launch holds LDS slots for: the
+        # first ones go through the accumulators, the others fall back to the stores)
+        hot = (np.arange(m) % 20 == 0).astype(np.uint64)
+        hot_rows[cell] = (ctx[hot == 1] // slices)[:_lib.BLOCK_HOT_MAX]
+        hot[np.nonzero(hot)[0][_lib.BLOCK_HOT_MAX:]] = 0
         words_l.append(O.block_pack(np.full(m, cell), centres, ctx, oplan, hot=hot))
         offsets.append(offsets[-1] + m)
+    cell_rows, hot_t = _hot_tables(2 * n_rows + 5, parts, slices, hot_rows)
     words_h = np.concatenate(words_l).astype(np.uint64)
     off_h = np.asarray(offsets, dtype=np.uint64)
     pairs = _dev_words(words_h)
@@ -270,7 +298,8 @@ def test_parallel_block_step_on_collision_free_pairs(karate, flags, d, slices):
     for part in range(parts):
         x = ops.init_table(rows_per_part, d, 5, 1 + part, 0.5, ld=ld)
         x_h = x.cpu().numpy().copy()
-        ops.block_step(g, tp, plan, pairs, offs, None, None, c, x, 0, part, 5, 0, 0.05)
+        ops.block_step(g, tp, plan, pairs, offs, None, cell_rows, c, x, 0, part, 5, 0, 0.05,
+                       hot=hot_t)
         O.block_step(og, otp, oplan, words_h, off_h, None, None, c_h, x_h, 0, part, 5, 0, 0.05)
         torch.cuda.synchronize()
         assert np.abs(x.cpu().numpy() - x_h).max() < 1e-5
@@ -546,7 +575,8 @@ def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
 def test_bad_plans_are_refused(karate):
     for kw in (dict(world=2, rank=2, parts=4), dict(world=2, rank=0, parts=0),
                dict(world=1, rank=0, parts=1, slices=17), dict(world=1, rank=0, parts=9000),
-               dict(world=1, rank=0, parts=1, record=33), dict(world=1, rank=0, parts=1, hot_lo=3, hot_hi=5)):
+               dict(world=1, rank=0, parts=1, record=33), dict(world=1, rank=0, parts=1, hot_rows=193),
+               dict(world=1, rank=0, parts=1, hot_rows=4, hot_flush=12)):
         args = dict(slices=1, walk_length=8, window=2)
         args.update(kw)
         with pytest.raises(_lib.Gn2vError):
@@ -664,7 +694,7 @@ def test_gn2v_train_takes_the_block_path_by_itself_from_2560_nodes():
 
 def test_block_path_against_the_committed_golden_fixture(karate):
     """tests/golden/oracle_blocks.npz (the oracle's block schedule frozen on Karate: rank 1 of 2,
-    4 parts x 2 slices, hot band): the device reproduces extraction, sort, alias tables and
+    4 parts x 2 slices, two hot rows per cell): the device reproduces extraction, sort, alias tables and
     flags bit for bit and the deterministic round within 1e-5, with no oracle in the loop."""
     import os
 
@@ -672,8 +702,8 @@ def test_block_path_against_the_committed_golden_fixture(karate):
     gold = np.load(os.path.join(gold_dir, "oracle_blocks.npz"))
     walks = np.load(os.path.join(gold_dir, "oracle_karate.npz"))["walks"]
     wk = torch.from_numpy(walks.view(np.int32)).cuda()
-    plan = ops.block_plan(karate, 2, 1, 4, 2, 16, 3, 1, 4, hot_lo=4, hot_hi=1)
-    alias, cell_rows, hub_bits = ops.block_alias(karate, plan)
+    plan = ops.block_plan(karate, 2, 1, 4, 2, 16, 3, 1, 4, hot_rows=2)
+    alias, cell_rows, hub_bits, hot_list, hot_slot = ops.block_alias(karate, plan)
     work, offsets = ops.block_count(karate, plan, wk, 42, 0, 0)
     pairs = ops.block_extract(karate, plan, wk, 42, 0, 0, work, int(offsets[-1]),
                               hub_bits=hub_bits)
@@ -681,6 +711,8 @@ def test_block_path_against_the_committed_golden_fixture(karate):
     assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), gold["offsets"])
     assert np.array_equal(alias.cpu().numpy().view(np.uint64), gold["alias"])
     assert np.array_equal(hub_bits.cpu().numpy().view(np.uint32), gold["hub_bits"])
+    assert np.array_equal(hot_list.cpu().numpy().view(np.uint32), gold["hot_list"])
+    assert np.array_equal(hot_slot.cpu().numpy(), gold["hot_slot"])
     tp = ops.train_params(0, 8, 4, 3, flags=1 | DET)
     c = ops.init_table_rows(17, 8, 42, 0, 8 ** -0.5, 1, 2)
     for part in range(4):
@@ -787,20 +819,23 @@ def test_the_device_reports_its_xcds(karate):
     assert ops.graph_xcds(karate) == 8
 
 
-def _shared_row_displacement(slices, flags, n_pairs=100_000, d=128):
+def _shared_row_displacement(slices, flags, n_pairs=100_000, d=128, hot=False):
     """n_pairs pairs with unique centres and ONE shared context row (k = 0, a learning rate so
     small that the order of the updates does not matter): how far the row moves, relative to the
     sequential oracle.  Every pair sits in the row's cell, so with `slices` < 8 the records are
-    spread over 8 / slices XCDs (non-coherent L2s)."""
+    spread over 8 / slices XCDs (non-coherent L2s).  ``hot``: the row is the hot row of its cell
+    (what gn2v_block_alias makes of the highest in-degree)."""
     n_nodes = 8 * 32_768
     g = _ba(n_nodes)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
-    plan = ops.block_plan(g, 1, 0, 1, slices, 8, 2, 1, 16)
+    plan = ops.block_plan(g, 1, 0, 1, slices, 8, 2, 1, 16, hot_rows=4 if hot else 0)
     oplan = O.block_plan(n_nodes, 1, 0, 1, slices, 8, 2, 1, 16)
     shared = 4242  # row 4242 of the only part: cell 4242 % slices
     cell = shared % slices
     centres = np.arange(n_pairs)
-    words_h = O.block_pack(np.full(n_pairs, cell), centres, np.full(n_pairs, shared), oplan)
+    words_h = O.block_pack(np.full(n_pairs, cell), centres, np.full(n_pairs, shared), oplan,
+                           hot=np.full(n_pairs, 1 if hot else 0))
+    cell_rows, hot_t = _hot_tables(n_nodes, 1, slices, {cell: [shared // slices]})
     off_h = np.zeros(slices + 1, dtype=np.uint64)
     off_h[cell + 1:] = n_pairs
     pairs = _dev_words(words_h)
@@ -812,7 +847,8 @@ def _shared_row_displacement(slices, flags, n_pairs=100_000, d=128):
     x = ops.init_table(n_nodes, d, 5, 1, 0.5)
     x[shared] = 0
     c_h, x_h = c.cpu().numpy().copy(), x.cpu().numpy().copy()
-    ops.block_step(g, tp, plan, pairs, offs, None, None, c, x, 0, 0, 5, 0, lr)
+    ops.block_step(g, tp, plan, pairs, offs, None, cell_rows if hot else None, c, x, 0, 0, 5, 0,
+                   lr, hot=hot_t if hot else None)
     O.block_step(og, otp, oplan, words_h, off_h, None, None, c_h, x_h, 0, 0, 5, 0, lr)
     torch.cuda.synchronize()
     got, want = x[shared].cpu().numpy(), x_h[shared]
@@ -839,6 +875,21 @@ def test_contextual_rows_shared_by_several_xcds_keep_write_through_stores():
     for slices in (2, 4):
         auto, wt = report[slices]
         assert auto > 0.6 * wt, report
+
+
+@pytest.mark.parametrize("slices", [1, 2, 8])
+def test_a_hot_row_keeps_every_update_at_store_speed(slices):
+    """The contended extreme, in the default (store) mode: one context row shared by all 10^5
+    pairs of a launch.  As an ordinary row it keeps a fraction of a percent of its updates (every
+    wave read-modify-writes its own copy and the last store wins: 0.0023-0.0096 of the sequential
+    displacement, test above).  As the hot row of its cell its updates are summed in the
+    workgroups' LDS and handed over with f32 atomics: all of them must arrive -- through one
+    XCD's L2 (8 slices) as well as from all eight XCDs at once (1 or 2 slices)."""
+    plain = _shared_row_displacement(slices, 0)
+    kept = _shared_row_displacement(slices, 0, hot=True)
+    print(f"shared-row displacement / sequential, {slices} slices: plain {plain:.4f}, hot {kept:.4f}")
+    assert plain < 0.1
+    assert abs(kept - 1) < 2e-3, kept
 
 
 def test_negatives_keep_their_degree_proportional_law_through_the_cells():

@@ -135,13 +135,15 @@ def test_random_block_rounds_match_oracle(case):
     seed, epoch, first = int(rng.randint(0, 2 ** 31)), int(rng.randint(0, 5)), int(rng.randint(0, 10 ** 6))
     n_src = g.get_number_of_unique_source_nodes()
     wk = ops.walks(g, ops.walk_params(L, 2, 0.5, 2.0), seed, epoch, first, 2 * n_src)
-    band = (int(rng.randint(2, 8)), int(rng.choice([0, 1]))) if rng.rand() < 0.5 else (0, 0)
+    hot_rows = int(rng.choice([1, 4, 48, 192])) if rng.rand() < 0.5 else 0
     plan = ops.block_plan(g, world, rank, parts, slices, L, w, md, record, flags=down,
-                          hot_lo=band[0], hot_hi=band[1])
+                          hot_rows=hot_rows)
     oplan = O.block_plan(n, world, rank, parts, slices, L, w, md, record, flags=down,
-                         hot_lo=band[0], hot_hi=band[1])
-    alias, cell_rows, hub_bits = ops.block_alias(g, plan)
-    ra, rc, rh = O.block_alias(og, parts, slices, *band)
+                         hot_rows=hot_rows)
+    alias, cell_rows, hub_bits, hot_list, hot_slot = ops.block_alias(g, plan)
+    ra, rc, rh, rl, rs = O.block_alias(og, parts, slices, hot_rows)
+    assert np.array_equal(hot_list.cpu().numpy().view(np.uint32), rl)
+    assert np.array_equal(hot_slot.cpu().numpy(), rs)
     # a random group of parts (cyclic) or the whole round
     part_lo = int(rng.randint(0, parts))
     part_n = int(rng.randint(1, parts + 1))
@@ -173,7 +175,7 @@ def test_random_block_rounds_match_oracle(case):
         x = ops.init_table_rows(rows, d, seed, 1, d ** -0.5, part, parts, ld=ld)
         x_h = x.cpu().numpy().copy()
         ops.block_step(g, tp, plan, pairs, offsets, alias, cell_rows, c, x, case, part, seed,
-                       epoch, 0.05)
+                       epoch, 0.05, hot=(hot_list, hot_slot))
         O.block_step(og, otp, oplan, rw, ro, ra, rc, c_h, x_h, case, part, seed, epoch, 0.05)
         torch.cuda.synchronize()
         assert np.abs(x.cpu().numpy() - x_h).max() < 2e-5, (part,)

@@ -273,15 +273,16 @@ def test_self_golden(karate_oracle):
 def test_self_golden_of_the_block_schedule(karate_oracle):
     """The restated block-partitioned schedule, frozen (regression pin between rounds, not
     reference-derived; made by tests/golden/make_oracle_golden.py): extraction + sort, alias
-    tables with a hot band, one round over every part."""
+    tables with two hot rows per cell, one round over every part."""
     gold = np.load(os.path.join(GOLDEN, "oracle_blocks.npz"))
     walks = np.load(os.path.join(GOLDEN, "oracle_karate.npz"))["walks"]
-    plan = O.block_plan(34, 2, 1, 4, 2, 16, 3, 1, 4, hot_lo=4, hot_hi=1)
-    alias, cell_rows, hub_bits = O.block_alias(karate_oracle, 4, 2, 4, 1)
+    plan = O.block_plan(34, 2, 1, 4, 2, 16, 3, 1, 4, hot_rows=2)
+    alias, cell_rows, hub_bits, hot_list, hot_slot = O.block_alias(karate_oracle, 4, 2, 2)
     words, offsets = O.block_extract(karate_oracle, plan, walks, 42, 0, 0, hub_bits=hub_bits)
-    assert O.block_unpack(words, plan)[3].any()  # the band flags some context rows
+    assert O.block_unpack(words, plan)[3].any()  # some context rows are hot
     for name, got in (("words", words), ("offsets", offsets), ("alias", alias),
-                      ("cell_rows", cell_rows), ("hub_bits", hub_bits)):
+                      ("cell_rows", cell_rows), ("hub_bits", hub_bits), ("hot_list", hot_list),
+                      ("hot_slot", hot_slot)):
         assert np.array_equal(got, gold[name]), name
     tp = O.TrainParams(0, 8, 8, 1, 4, 3, 0.01, 0.9, 6.0, 1, 8 ** -0.5)
     central = O.init_table_rows(17, 8, 8, 42, 0, 8 ** -0.5, 1, 2)
