@@ -26,8 +26,8 @@ on a second stream while the previous round trains.  No row is ever shared, so N
 exactly what the single-process simulation of the tests computes.  See DESIGN.md "Multi-GPU".
 
 `--model cbow` times the CBOW kernel on the same workload (unit: centres/s; with N > 1 as N
-independent replicas: CBOW does not shard).  A/B switches: `--central-atomic`
-(atomics for every central row update), `--reserve-cus k` (training kernel on a CU-masked stream
+independent replicas: CBOW does not shard).  A/B switches: `--central-store`
+(a centre's only run in a cell stores row + gradient instead of adding with atomics), `--reserve-cus k` (training kernel on a CU-masked stream
 that leaves k CUs of every XCD to RCCL), `--record`, `--group-parts`, `--round-walks`,
 `--overlap`.  Measurement aids, one GPU:
 `--phantom-world N` runs one rank of an N-GPU job with its true geometry and no fabric (the line
@@ -99,9 +99,10 @@ def parse():
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="blocks: CUs of every XCD left to other work (RCCL's transfer kernels): "
                          "the training kernel runs on a CU-masked stream (gn2v_graph_reserve_cus)")
-    ap.add_argument("--central-atomic", action="store_true",
-                    help="blocks: every central row update by atomics (round 2's behaviour; default: "
-                         "a store when the run is its centre's only one in the cell)")
+    ap.add_argument("--central-store", action="store_true",
+                    help="blocks: a run that is its centre's only one in the cell stores row + "
+                         "gradient (round 3's default; loses the update when another XCD holds "
+                         "the centre at that moment) instead of adding the gradient with atomics")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="blocks: prepare round t + 1 on a second stream while round t trains "
                          "(auto: with several GPUs, where it hides the walk all-gather; on one GPU "
@@ -112,6 +113,18 @@ def parse():
                          "of --round-walks / stripes walks, centre runs `stripes` times as long; "
                          "faster (8 stripes: +7 %) but the stripes of a round are trained one "
                          "after the other, which costs link quality: 0 = 1 = off, what ships")
+    ap.add_argument("--job-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 started from a plain shell: seconds after which the parent "
+                         "terminates the job's process group and prints a JSON line with "
+                         "\"error\": \"timeout\", the phase each rank had reached and the last stderr "
+                         "lines (0 = no watchdog)")
+    ap.add_argument("--entry", default="auto", choices=["auto", "c", "python"],
+                    help="blocks on one GPU: which host loop drives the rounds.  c (= auto when no "
+                         "plan switch is given): ONE call of gn2v_train, the C-ABI entry "
+                         "INTEGRATION.md binds in place of the reference's "
+                         "self._model.fit_transform(graph) (node2vec.py:99), with the steps' walks "
+                         "as its walk budget; python: embiggen_amd.distributed's trainer (the "
+                         "multi-GPU host loop, which every N > 1 uses)")
     ap.add_argument("--model", default="skipgram", choices=["skipgram", "cbow"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
@@ -270,12 +283,32 @@ def cpu_baseline(graph, args, central, contextual, seconds):
     }
 
 
+PHASE_TAG = "[bench phase] "
+
+
+def phase(name):
+    """Workers mark where they are (stderr, every rank): the parent's watchdog reports the last
+    mark when a job hangs.  GN2V_BENCH_STALL=<phase>:<seconds> makes a worker sleep on reaching
+    that phase (tests: a stand-in for an RCCL bootstrap that never returns)."""
+    print(f"{PHASE_TAG}{name} rank={os.environ.get('RANK', '0')} t={time.time():.3f}",
+          file=sys.stderr, flush=True)
+    stall = os.environ.get("GN2V_BENCH_STALL", "")
+    if stall.partition(":")[0] == name:
+        time.sleep(float(stall.partition(":")[2] or 1e9))
+
+
 def launch_job(args):
     """`bench.py --gpus N` outside a torch.distributed job: run it as the job the contract names
     (one process per GPU), relay rank 0's JSON line, return the job's status.  This process never
-    initialises HIP, torch.cuda or RCCL: the workers are fresh children, nothing is re-exec'd."""
+    initialises HIP, torch.cuda or RCCL: the workers are fresh children, nothing is re-exec'd.
+    A watchdog bounds the job: after --job-timeout seconds the whole process group of the job is
+    terminated and ONE JSON line says so -- error, the phase every rank had reached and the last
+    lines of the job's stderr -- so that a hang (an RCCL bootstrap that never completes) leaves a
+    record instead of an expired lease."""
+    import signal
     import socket
     import subprocess
+    import threading
 
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -285,16 +318,60 @@ def launch_job(args):
            str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    last_json = None
-    for out_line in proc.stdout:
-        if out_line.lstrip().startswith("{"):
-            last_json = out_line.strip()
-        else:
-            sys.stderr.write(out_line)  # RCCL banners and the like
-    status = proc.wait()
-    if last_json is not None:
-        print(last_json, flush=True)
+    # a session of its own: the watchdog can end the launcher AND its workers as one group
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
+                            text=True, start_new_session=True)
+    state = {"json": None, "tail": [], "phases": {}}
+
+    def read_stdout():
+        for out_line in proc.stdout:
+            if out_line.lstrip().startswith("{"):
+                state["json"] = out_line.strip()
+            else:
+                sys.stderr.write(out_line)  # RCCL banners and the like
+
+    def read_stderr():
+        for err_line in proc.stderr:
+            sys.stderr.write(err_line)
+            if err_line.startswith(PHASE_TAG):
+                fields = err_line[len(PHASE_TAG):].split()
+                rank = next((f[5:] for f in fields if f.startswith("rank=")), "?")
+                state["phases"][rank] = fields[0]
+            else:
+                state["tail"] = (state["tail"] + [err_line.rstrip()])[-20:]
+
+    readers = [threading.Thread(target=read_stdout, daemon=True),
+               threading.Thread(target=read_stderr, daemon=True)]
+    for t in readers:
+        t.start()
+    try:
+        status = proc.wait(timeout=args.job_timeout if args.job_timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+            try:
+                os.killpg(proc.pid, sig)  # the job's own process group, nothing else
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        for t in readers:
+            t.join(timeout=5)
+        print(json.dumps({
+            "error": "timeout",
+            "detail": f"the {args.gpus}-process job did not finish within --job-timeout "
+                      f"{args.job_timeout} s and was terminated",
+            "phase_reached_per_rank": state["phases"],
+            "stderr_tail": state["tail"],
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "argv": sys.argv[1:]}), flush=True)
+        return 124
+    for t in readers:
+        t.join(timeout=5)
+    if state["json"] is not None:
+        print(state["json"], flush=True)
     return status
 
 
@@ -307,6 +384,7 @@ def main():
     import embiggen_amd as E
     from embiggen_amd import _lib, ops
 
+    phase("start")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -321,12 +399,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        phase("init_process_group")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend=args.backend)
 
     cbow = args.model == "cbow"
+    phase("graph")
     graph = E.barabasi_albert(args.nodes, args.m, 42, device=local)
     n, d = graph.get_number_of_nodes(), args.d
     reserved = ops.graph_reserve_cus(graph, args.reserve_cus, local) if args.reserve_cus else None
@@ -334,8 +414,8 @@ def main():
     flags = _lib.TRAIN_SCALE_FREE | {
         "auto": 0, "write_through": _lib.TRAIN_WRITE_THROUGH,
         "write_back": _lib.TRAIN_WRITE_BACK, "atomic": _lib.TRAIN_ATOMIC}[args.mode]
-    if args.central_atomic:
-        flags |= _lib.TRAIN_CENTRAL_ATOMIC
+    if args.central_store:
+        flags |= _lib.TRAIN_CENTRAL_STORE
     if args.calibrate:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         perm = torch.randperm(n, device="cuda", dtype=torch.int64).to(torch.int32)
@@ -372,11 +452,24 @@ def main():
     if phantom and (world > 1 or mode != "blocks"):
         raise SystemExit("--phantom-world needs --gpus 1 and the block trainer")
     blocks = comm = None
+    # N = 1, nothing but the defaults: the timed region is one call of the C-ABI entry
+    plan_switches = (args.parts is not None or args.slices is not None or args.record != 32
+                     or args.hot_rows is not None or args.hot_flush or args.group_parts
+                     or args.overlap == "on" or args.reserve_cus)
+    c_entry = (mode == "blocks" and world == 1 and not phantom
+               and (args.entry == "c" or (args.entry == "auto" and not plan_switches)))
+    if args.entry == "c" and not c_entry:
+        raise SystemExit("--entry c needs --gpus 1, the block path and no --phantom-world")
     overlap = args.overlap == "on" or (args.overlap == "auto" and (world > 1 or phantom))
     # the trainer's view of the job (a phantom rank sees the world it stands in for)
     t_rank, t_world = (args.phantom_rank, args.phantom_world) if phantom else (rank, world)
     stripes = 1
-    if mode == "blocks":
+    phase("trainer")
+    if c_entry:
+        central = torch.empty((n, ld), dtype=torch.float32, device=f"cuda:{local}")
+        contextual = torch.empty((n, ld), dtype=torch.float32, device=f"cuda:{local}")
+        c_stats = _lib.Stats()
+    elif mode == "blocks":
         # tables partitioned by node id; no row is ever held by two GPUs
         comm = (PhantomComm(t_rank, t_world) if phantom
                 else TorchComm() if world > 1 else LoopbackComm())
@@ -430,6 +523,27 @@ def main():
         return out
 
     def run_steps(first_step, n_steps):
+        if c_entry:
+            # the whole of the reference's one call: tables initialised, alias tables built, the
+            # walks of n_steps steps generated and trained round by round, tables back in node
+            # order -- all of it inside the timed region
+            import ctypes as C
+
+            if n_steps == 0:
+                return
+            handle = graph.device_graph(local).handle
+            stream = torch.cuda.current_stream().cuda_stream
+            L = _lib.lib()
+            if args.round_walks or args.stripes:
+                _lib.check(L.gn2v_train_blocks(handle, C.byref(wp), C.byref(tp), 42,
+                                               n_steps * args.walks, args.round_walks,
+                                               args.stripes, central.data_ptr(),
+                                               contextual.data_ptr(), C.byref(c_stats), stream))
+            else:
+                _lib.check(L.gn2v_train(handle, C.byref(wp), C.byref(tp), 42, n_steps * args.walks,
+                                        central.data_ptr(), contextual.data_ptr(),
+                                        C.byref(c_stats), stream))
+            return
         if blocks is not None:
             blocks.run(block_rounds(first_step * args.walks, n_steps * args.walks), overlap=overlap,
                        timed=world > 1)
@@ -459,21 +573,25 @@ def main():
                   f"{torch.cuda.max_memory_allocated() / 1e9:.1f} GB", file=sys.stderr, flush=True)
 
     memlog("before warm-up")
+    phase("warmup")
     run_steps(0, args.warmup)
     fence()
     memlog("after warm-up")
     ops.stats_reset(graph, local)
+    phase("timed")
     t0 = time.perf_counter()
     if phantom:
         comm.hop_ms()  # forget the warm-up's hops
     run_steps(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    phase("report")
     hop_stats = comm.hop_ms() if phantom else None
     memlog("after the timed steps")
     st = ops.stats_read(graph, local)
 
     hop_waits = blocks.hop_wait_ms() if blocks is not None and world > 1 else []
+    phases_ms = blocks.phase_ms() if blocks is not None and world > 1 else {}
     times = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     counts = torch.tensor([st["pairs"], st["walk_steps"], st["centres"]], dtype=torch.float64,
                           device="cuda")
@@ -512,9 +630,12 @@ def main():
             ms.append((time.perf_counter() - t1) / reps * 1e3)
         # per rank: HBM peak and what the compute stream really waited for its hops (HIP events
         # around every pending.wait(): a hop had a whole episode to complete)
+        phase_names = ["walk_generation", "walk_allgather", "extract_and_sort", "training",
+                       "exposed_preparation_wait"]
         mine = torch.tensor([torch.cuda.max_memory_allocated() / 1e9,
                              sum(hop_waits) / max(len(hop_waits), 1), max(hop_waits, default=0.0),
-                             sum(hop_waits)], dtype=torch.float64, device="cuda")
+                             sum(hop_waits)] + [phases_ms.get(k, 0.0) for k in phase_names],
+                            dtype=torch.float64, device="cuda")
         rows = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(rows, mine)
         comm_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
@@ -524,6 +645,12 @@ def main():
                                              "mean_per_rank": [round(float(r[1]), 4) for r in rows],
                                              "max_per_rank": [round(float(r[2]), 4) for r in rows],
                                              "total_per_rank": [round(float(r[3]), 2) for r in rows]},
+                     # HIP events inside the timed region, per rank (ms, totals): the first
+                     # three run on the preparation stream beside the training; `training`
+                     # includes the hop waits above; `exposed_preparation_wait` is what the
+                     # compute stream stood still for the preparation (walk gather included)
+                     "phase_ms_per_rank": {k: [round(float(r[4 + i]), 2) for r in rows]
+                                           for i, k in enumerate(phase_names)},
                      "walks_per_round_per_rank": min(args.round_walks, args.steps * args.walks),
                      "parts_per_group": blocks.group_parts,
                      "walk_allgather_ms_alone": ms[0],
@@ -538,6 +665,15 @@ def main():
         def finite(table):  # in slabs: isfinite of a 51 GB table would allocate as much again
             return all(bool(torch.isfinite(slab).all()) for slab in table.split(1 << 20))
 
+        if c_entry:  # what the C loop planned (gn2v_stats of the timed call)
+            class _Plan:
+                parts, slices = c_stats.block_parts, c_stats.block_slices
+                group_parts = c_stats.block_group_parts
+            assert _Plan.parts, "gn2v_train did not take the block path"
+            blocks_view, stripes = _Plan, max(1, c_stats.block_stripes)
+            args.round_walks = c_stats.block_round_walks * stripes
+        else:
+            blocks_view = blocks
         if blocks is not None:
             ok = finite(blocks.central) and all(finite(t) for t in blocks.held.values())
         else:
@@ -558,7 +694,7 @@ def main():
         row_bytes = 2 * 4 * ld
         if cbow:
             sched_bytes = algo_bytes
-        elif blocks is not None:
+        elif blocks_view is not None:
             sched_bytes = row_bytes * (st["pairs"] * 11 + st["centres"])
         else:
             sched_bytes = row_bytes * (st["pairs"] * 11 + st["centres"])
@@ -571,7 +707,7 @@ def main():
                 args.mode == "auto" and n * ld >= (1 << 22))  # GN2V_CBOW_STORES_MIN_ELEMENTS
             kernel = ("gn2v::cbow_lazy_kernel" if store_mode and 16 * lazy_words <= 64 * 1024
                       else "gn2v::cbow_kernel")
-        elif blocks is not None:
+        elif blocks_view is not None:
             kernel = "gn2v::sgns_block_kernel"
         elif n >= (1 << 16) and args.mode in ("auto", "write_through", "write_back"):
             kernel = "gn2v::sgns_cached_kernel"
@@ -600,21 +736,26 @@ def main():
                             f" 10 negatives, return_weight {args.return_weight}, explore_weight "
                             f"{args.explore_weight}, {args.walks} walks per step per GPU",
                 "update_mode": args.mode,
-                "walks_per_launch": args.batch if blocks is None else None,
+                "walks_per_launch": args.batch if blocks_view is None else None,
+                # the host loop that drove the timed region
+                "entry": ("gn2v_train (C ABI, include/gn2v.h: one call = tables initialised + "
+                          "alias tables + all rounds + node order restored)" if c_entry else
+                          "embiggen_amd.distributed.BlockPartitionedTrainer (Python host loop)"
+                          if blocks is not None else "per-launch step entry points"),
                 # what a committed PMC profile must share with this run to price its traffic
                 "traffic_key": (f"ba{n}x{args.m}:d{d}:{args.model}:{args.mode}:"
-                                + (f"blocks{t_world}:{blocks.parts}x{blocks.slices}:"
+                                + (f"blocks{t_world}:{blocks_view.parts}x{blocks_view.slices}:"
                                    f"round{min(args.round_walks, args.steps * args.walks)}"
                                    + (f":stripes{stripes}" if stripes > 1 else "")
-                                   if blocks is not None else f"walk-ordered:{args.batch}")),
+                                   if blocks_view is not None else f"walk-ordered:{args.batch}")),
                 "parallelism": {
                     "single": (f"{world} independent replicas (CBOW does not shard), walk-ordered "
                                "kernel" if replicas else "1 GPU, walk-ordered kernel"),
                     "blocks": f"{t_world} GPU(s), central table striped over the ranks, contextual "
-                              f"table in {blocks.parts if blocks else 0} travelling parts x "
-                              f"{blocks.slices if blocks else 0} XCD slice(s) (no shared rows), rounds of "
+                              f"table in {blocks_view.parts if blocks_view else 0} travelling parts x "
+                              f"{blocks_view.slices if blocks_view else 0} XCD slice(s) (no shared rows), rounds of "
                               f"{min(args.round_walks, args.steps * args.walks)} walks per GPU "
-                              f"prepared {blocks.group_parts if blocks else 0} parts at a time"
+                              f"prepared {blocks_view.group_parts if blocks_view else 0} parts at a time"
                               + (f" trained in {stripes} centre stripes" if stripes > 1 else "")
                               + f", preparation {'overlapped' if overlap and stripes == 1 else 'in line'}",
                 }[mode],

@@ -13,6 +13,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libgn2v.so")
 _UNITS = ["gn2v_api.hip", "gn2v_block_api.hip"]  # translation units of libgn2v.so
 _HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v.h")
+_HEADER_EXPERIMENTAL = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v_experimental.h")
 
 SENTINEL = 0xFFFFFFFF
 GRAPH_DEVICE_PTRS = 1
@@ -29,7 +30,7 @@ TRAIN_CTX_CACHE_ALL = 256
 BLOCK_PATH_MIN_NODES = 2560  # GN2V_BLOCK_PATH_MIN_NODES
 TRAIN_WALK_ORDERED = 1024
 TRAIN_BLOCK_PATH = 2048
-TRAIN_CENTRAL_ATOMIC = 4096
+TRAIN_CENTRAL_STORE = 4096
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 
@@ -38,7 +39,7 @@ EXPORTS = [
     "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
     "gn2v_graph_destroy", "gn2v_graph_set_types", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_walk_pairs",
     "gn2v_init_table",
-    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_step", "gn2v_train", "gn2v_edge_embedding",
+    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_train", "gn2v_edge_embedding",
     "gn2v_cooc_slots", "gn2v_glove_step",
     "gn2v_touch_rows",
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
@@ -127,6 +128,9 @@ class BlockIO(C.Structure):
     ]
 
 
+# include/gn2v_experimental.h: measured-and-rejected designs kept for their scripts and tests
+EXPERIMENTAL_EXPORTS = ["gn2v_step"]
+
 BLOCK_WORK_WORDS = 16384
 BLOCK_HOT_MAX = 192      # GN2V_BLOCK_HOT_MAX
 BLOCK_HOT_DEFAULT = 192  # GN2V_BLOCK_HOT_DEFAULT
@@ -162,7 +166,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     # every header and unit in csrc/ is a dependency: a stale library must never survive an edit
     srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip")))
-    srcs.append(_HEADER)
+    srcs += [_HEADER, _HEADER_EXPERIMENTAL]
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(s) for s in srcs)
         if os.path.getmtime(LIB_PATH) >= newest:
@@ -246,7 +250,7 @@ def lib():
                                     u64, u32, vp, vp, C.POINTER(Stats), vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]
     L.gn2v_stats_read.argtypes = [vp, C.POINTER(Stats), vp]
-    for name in EXPORTS:
+    for name in EXPORTS + EXPERIMENTAL_EXPORTS:
         fn = getattr(L, name)
         if name not in ("gn2v_last_error",):
             fn.restype = i32

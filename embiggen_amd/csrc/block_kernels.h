@@ -391,7 +391,8 @@ struct BlockArgs {
     uint32_t part;
     uint32_t sweep;  // 1: second launch -- every workgroup serves every cell's leftover records
     uint32_t xcds;   // XCDs the workgroups are spread over (0 = unknown)
-    uint32_t central_atomic;  // 1: every central row update by atomics (GN2V_TRAIN_CENTRAL_ATOMIC)
+    uint32_t central_store;  // 1: a centre's only run in a cell stores row + gradient instead of
+                             // adding the gradient with atomics (GN2V_TRAIN_CENTRAL_STORE)
     uint32_t hot_n;      // hot slots the LDS of this launch holds (0: hot rows are ordinary rows)
     uint32_t hot_mask;   // a slot's pending sum goes to its row after ~hot_mask + 1 updates (2^j - 1)
     uint32_t k, ld, flags;
@@ -670,7 +671,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
             const bool starts = (uint32_t)lane < n && (lane == 0 || s_key[lane] != s_key[lane - 1]);
             n_runs = (uint32_t)__popcll(__ballot(starts));
         }
-        if (!a.central_atomic && n_runs * 100 >= n * kPpgMinPct) {
+        if (n_runs * 100 >= n * kPpgMinPct) {
             const uint32_t kk = k + 1;
             for (uint32_t p4 = 0; p4 < n; p4 += 4) {
                 const uint32_t pr = p4 + grp;
@@ -691,21 +692,38 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
                     const uint32_t row = have ? s_rows[t] : kSentinel;
                     score_sample<CH, WMX>(a, h, u, g, row, s_lab[t], lrc, q, nchunks);
                 }
-                if (have) {
+                // the pair's gradient goes to its central row: one store of row + gradient when
+                // the plan allows it and the pair's neighbours have other centres (a.central_store),
+                // else f32 atomics in the lane-contiguous shape -- the four groups take turns at
+                // the wave's transposition row
+                bool store = false;
+                if (have && a.central_store) {
                     const bool same_prev = pr > 0 ? s_key[pr - 1] == crow_id : s_nb[0] == crow_id;
                     const bool same_next = pr + 1 < n ? s_key[pr + 1] == crow_id : s_nb[1] == crow_id;
-                    if (!same_prev && !same_next) {
-                        scatter_add<CH, kWriteThrough>(crow, q, nchunks, 1.0f, g, u);
-                    } else {  // the centre has other pairs here: no add may be lost
+                    store = !same_prev && !same_next;
+                }
+                if (store) scatter_add<CH, kWriteThrough>(crow, q, nchunks, 1.0f, g, u);
+                if (__ballot(have && !store)) {
 #pragma unroll
-                        for (int cc = 0; cc < CH; ++cc) {
-                            const uint32_t ci = cc * 16 + q;
-                            if (ci < nchunks) {
-                                float *pc = crow + ci * 4;
-                                unsafeAtomicAdd(pc + 0, g.c[cc].x);
-                                unsafeAtomicAdd(pc + 1, g.c[cc].y);
-                                unsafeAtomicAdd(pc + 2, g.c[cc].z);
-                                unsafeAtomicAdd(pc + 3, g.c[cc].w);
+                    for (int turn = 0; turn < 4; ++turn) {
+                        wave_sync();
+                        if (grp == turn) {
+#pragma unroll
+                            for (int cc = 0; cc < CH; ++cc) {
+                                const uint32_t ci = cc * 16 + q;
+                                if (ci < nchunks)
+                                    *reinterpret_cast<float4 *>(s_tr + ci * 4) = g.c[cc];
+                            }
+                        }
+                        wave_sync();
+                        if (grp == turn && have && !store) {
+#pragma unroll
+                            for (int cc = 0; cc < CH; ++cc) {
+                                const uint32_t f = cc * 64 + q;
+                                if (f < a.ld) unsafeAtomicAdd(crow + f, s_tr[f]);
+                                if (f + 16 < a.ld) unsafeAtomicAdd(crow + f + 16, s_tr[f + 16]);
+                                if (f + 32 < a.ld) unsafeAtomicAdd(crow + f + 32, s_tr[f + 32]);
+                                if (f + 48 < a.ld) unsafeAtomicAdd(crow + f + 48, s_tr[f + 48]);
                             }
                         }
                     }
@@ -779,14 +797,28 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
         }
         bool alone = false;
         if constexpr (!DET && WMC == kAtomic)
-            alone = !a.central_atomic && (r0 > 0 ? s_key[r0 - 1] != crow_id : s_nb[0] != crow_id) &&
+            alone = a.central_store && (r0 > 0 ? s_key[r0 - 1] != crow_id : s_nb[0] != crow_id) &&
                     (r1 < n ? s_key[r1] != crow_id : s_nb[1] != crow_id);
         if constexpr (!DET && WMC == kAtomic) {
             if (alone) {
                 if (grp == 0) scatter_add<CH, kWriteThrough>(crow, q, nchunks, 1.0f, g, u);
             } else {
-                to_contig_layout<CH>(g, g, s_tr, grp, q, a.ld);
-                if (grp == 0) scatter_add<CH, kAtomic>(crow, q, nchunks, 1.0f, g, u);
+                // every group holds the run's gradient (reduce_groups): through the wave's
+                // transposition row into the lane-contiguous shape, a quarter of the row per group
+                wave_sync();
+                if (grp == 0) {
+#pragma unroll
+                    for (int cc = 0; cc < CH; ++cc) {
+                        const uint32_t ci = cc * 16 + q;
+                        if (ci < nchunks) *reinterpret_cast<float4 *>(s_tr + ci * 4) = g.c[cc];
+                    }
+                }
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const uint32_t f = (grp * CH + j) * 16 + q;
+                    if (f < a.ld) unsafeAtomicAdd(crow + f, s_tr[f]);
+                }
             }
         } else {
             if (grp == 0) scatter_add<CH, DET ? kWriteBack : WMC>(crow, q, nchunks, 1.0f, g, u);

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/gn2v.h"
+#include "../../include/gn2v_experimental.h"
 #include "rng.h"
 #include "edge_kernels.h"
 #include "glove_kernels.h"

@@ -71,6 +71,11 @@ size_t block_lds_words_per_wave(uint32_t ld, uint32_t record, uint32_t k) {
     return ((size_t)ld + 3 * record + 2 * (size_t)record * (k + 1) + 2 + 3) & ~(size_t)3;
 }
 
+// the extraction stages, per wave, the walk and three words per position, plus one counter per cell
+size_t extract_lds_bytes(uint32_t walk_length, uint32_t cells) {
+    return ((size_t)(gn2v::kPrepBlock / 64) * 4 * walk_length + cells) * 4;
+}
+
 size_t env_size(const char *name, size_t fallback) {
     const char *v = getenv(name);
     return v && *v ? (size_t)strtoull(v, nullptr, 10) : fallback;
@@ -245,7 +250,7 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     a.part_lo = part_lo;
     a.part_n = part_n;
     const uint32_t cells = d.parts * d.slices;
-    const size_t lds = ((size_t)(gn2v::kPrepBlock / 64) * 4 * d.L + cells) * 4;
+    const size_t lds = extract_lds_bytes(d.L, cells);
     if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
     const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
     if (write)
@@ -447,7 +452,7 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     int wmx = wmc;
     if (wmc == gn2v::kWriteThrough && exclusive) wmx = gn2v::kWriteBack;
     a.xcds = (uint32_t)g->n_xcds;
-    a.central_atomic = (tp->flags & GN2V_TRAIN_CENTRAL_ATOMIC) ? 1u : 0u;
+    a.central_store = (tp->flags & GN2V_TRAIN_CENTRAL_STORE) ? 1u : 0u;
 
     // Hot rows (block_kernels.h "hot rows"): only with ONE workgroup of sixteen waves per CU --
     // rows up to 128 floats, store flavours, central rows by atomics -- whose waves share one set
@@ -603,9 +608,11 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     return 0;
 }
 
-// gn2v_train_blocks returns this (instead of 1) when device memory ran out before anything was
-// trained: gn2v_train then falls back to the walk-ordered schedule.
+// gn2v_train_blocks returns this (instead of 1) when it cannot run this fit -- device memory ran
+// out, or the walk / the sample list of a record does not fit the kernels' LDS plans -- before
+// anything was trained or initialised: gn2v_train then falls back to the walk-ordered schedule.
 static constexpr int kOutOfMemory = 2;
+
 
 int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_train_params *tp,
                       uint64_t seed, uint64_t max_walks_per_epoch, uint64_t round_walks,
@@ -635,7 +642,17 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     plan.walk_length = L;
     plan.window = w;
     plan.min_dist = tp->min_dist ? tp->min_dist : 1;
-    plan.record = 32;
+    // records of 32 pairs, fewer when 1 + k samples per pair would not fit a workgroup's LDS; a
+    // walk the extraction cannot stage, or a sample list too long even for records of 8, is not
+    // for this path (status 2, before anything is touched: gn2v_train takes the walk-ordered one)
+    plan.record = 0;
+    for (uint32_t r = 32; r >= 8 && !plan.record; r >>= 1)
+        if (block_lds_words_per_wave(ld, r, tp->k) * 4 * (gn2v::kTrainBlock / 64) <= 64 * 1024)
+            plan.record = r;
+    if (!plan.record || extract_lds_bytes(L, plan.parts * plan.slices) > 64 * 1024) {
+        fail("walk_length / number_of_negative_samples beyond the block path's LDS plans");
+        return kOutOfMemory;
+    }
     plan.flags = tp->flags & GN2V_TRAIN_DOWNSAMPLE;
     plan.hot_rows = (uint32_t)env_size("GN2V_HOT_ROWS", GN2V_BLOCK_HOT_DEFAULT);
     plan.hot_flush = (uint32_t)env_size("GN2V_HOT_FLUSH", 0);
@@ -658,7 +675,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     uint64_t *alias = nullptr, *cell_rows = nullptr;
     uint32_t *hub_bits = nullptr, *hot_list = nullptr;
     uint8_t *hot_slot = nullptr;
-    if (scale_free) {
+    if (scale_free || plan.hot_rows) {  // uniform negatives: the hot rows (frequent contexts) only
         uint64_t tb = 0;
         gn2v_block_alias_temp_bytes(n, &tb);
         void *tmp = nullptr;

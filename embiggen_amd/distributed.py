@@ -339,7 +339,7 @@ class BlockPartitionedTrainer:
         if hot_rows is None:
             from . import _lib
 
-            hot_rows = _lib.BLOCK_HOT_DEFAULT if scale_free else 0
+            hot_rows = _lib.BLOCK_HOT_DEFAULT
         self.group_parts = parts if not group_parts else max(1, min(int(group_parts), parts))
         self.stripes = max(1, int(stripes))
         if self.stripes > 1 and world > 1:
@@ -356,9 +356,13 @@ class BlockPartitionedTrainer:
         self.plan = self.plans[0]
         self.scale_free = bool(scale_free)
         # per-cell alias tables for the negatives + the hot rows of every cell (flags, slots)
+        # (with uniform negatives the alias tables are not used: the hot rows, the most frequent
+        # contexts, still are)
         self.alias, self.cell_rows, self.hub_bits, hot_list, hot_slot = (
-            self.backend.alias_tables(self.plan) if scale_free else (None,) * 5)
+            self.backend.alias_tables(self.plan) if scale_free or hot_rows else (None,) * 5)
         self.hot = (hot_list, hot_slot) if hot_list is not None and hot_rows else None
+        if not scale_free:
+            self.alias = None
         for p in range(parts):
             if stripe_rows(self.n_nodes, p, parts) == 0:
                 raise ValueError("A context part owns no node: graph too small to split this far.")
@@ -383,6 +387,7 @@ class BlockPartitionedTrainer:
         self._round_episodes = 0  # episodes of the current round so far (all stripes)
         self.last_round = None
         self.wait_ms = []     # HIP events around the wait for each hop (timed=True in run())
+        self.spans = []       # (phase, start event, end event) of run(timed=True): phase_ms()
 
     # ------------------------------------------------------------------ helpers
     def part_of_episode(self, g: int) -> int:
@@ -486,6 +491,38 @@ class BlockPartitionedTrainer:
         b.record()
         self.wait_ms.append((a, b))
 
+    def _span(self, name, stream=None):
+        """Context manager: HIP events on ``stream`` (default: the current one) around a phase of
+        run(timed=True); read with phase_ms()."""
+        import contextlib
+
+        import torch
+
+        trainer = self
+
+        @contextlib.contextmanager
+        def span():
+            s = stream if stream is not None else torch.cuda.current_stream()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s)
+            try:
+                yield
+            finally:
+                b.record(s)
+                trainer.spans.append((name, a, b))
+
+        return span()
+
+    def phase_ms(self):
+        """{phase: total ms} of the spans recorded since the last call (after a synchronize):
+        walk generation, walk all-gather, pair extraction + sort (all on the preparation stream),
+        training, and what the compute stream waited for the preparation ("exposed")."""
+        out = {}
+        for name, a, b in self.spans:
+            out[name] = out.get(name, 0.0) + a.elapsed_time(b)
+        self.spans = []
+        return out
+
     def hop_wait_ms(self):
         """Exposed wait per hop in ms (after a synchronize): list of floats."""
         out = [a.elapsed_time(b) for a, b in self.wait_ms]
@@ -540,18 +577,41 @@ class BlockPartitionedTrainer:
             with torch.cuda.stream(side):
                 if gi == 0:
                     state["walks_all"] = None  # the last round's walks go back to the pool first
-                    state["walks_all"] = self.gather_walks(make())
+                    if timed:
+                        with self._span("walk_generation"):
+                            mine = make()
+                        with self._span("walk_allgather"):
+                            state["walks_all"] = self.gather_walks(mine)
+                        del mine
+                    else:
+                        state["walks_all"] = self.gather_walks(make())
+                if timed:
+                    with self._span("extract_and_sort"):
+                        return self.prepare(state["walks_all"], seed, epoch, first,
+                                            group=groups[gi], slot=turn)
                 return self.prepare(state["walks_all"], seed, epoch, first, group=groups[gi],
                                     slot=turn)
+
+        def wait_for_preparation():
+            # what the compute stream really waits for the preparation stream: exposed time
+            if timed:
+                with self._span("exposed_preparation_wait", main):
+                    main.wait_stream(side)
+            else:
+                main.wait_stream(side)
 
         side.wait_stream(main)
         turn = getattr(self, "_turn", 0)  # two standing slots, alternating across run() calls too
         prepared = prep(units[0], turn)
-        main.wait_stream(side)
+        wait_for_preparation()
         before = None
         for u, (r, gi) in enumerate(units):
             _, seed, epoch, lr, _ = rounds[r]
-            self.train_prepared(prepared, seed, epoch, lr, timed=timed)
+            if timed:
+                with self._span("training", main):
+                    self.train_prepared(prepared, seed, epoch, lr, timed=timed)
+            else:
+                self.train_prepared(prepared, seed, epoch, lr, timed=timed)
             done = torch.cuda.Event()
             done.record(main)
             nxt = None
@@ -560,7 +620,7 @@ class BlockPartitionedTrainer:
                     side.wait_event(before)  # group u - 1 is over: its slot may be rewritten
                 turn ^= 1
                 nxt = prep(units[u + 1], turn)
-                main.wait_stream(side)
+                wait_for_preparation()
             before, prepared = done, nxt
         state["walks_all"] = None
         self._turn = turn ^ 1

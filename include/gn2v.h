@@ -75,10 +75,11 @@ extern "C" {
                                          GN2V_TRAIN_DETERMINISTIC: its sequential schedule)      */
 
 /* Block path: the gradient of a run of equal centre is added to the central row with hardware
- * atomics when the centre spans records (hubs) and with one write-through store of row +
- * gradient when the run is the centre's only one in its cell (no other wave of the XCD names the
- * row; an atomic row add costs ~5 stored rows).  This bit: atomics for every run. */
-#define GN2V_TRAIN_CENTRAL_ATOMIC 4096u
+ * f32 atomics (lane-contiguous; the row is shared by the XCDs, which reach it through their own
+ * cells).  This bit: a run that is its centre's only one in the cell writes row + gradient with
+ * one write-through store instead -- 1-2 % faster, but an update is lost whenever another XCD
+ * holds the same centre at that moment (counted: tests/test_gpu_default_vs_oracle.py). */
+#define GN2V_TRAIN_CENTRAL_STORE 4096u
 
 #define GN2V_MODEL_SKIPGRAM 0u
 #define GN2V_MODEL_CBOW 1u
@@ -196,34 +197,6 @@ int gn2v_cbow_step(gn2v_graph *g, const gn2v_train_params *tp, const uint32_t *d
                    uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
                    uint64_t first_walk, float lr, float *d_central, float *d_contextual,
                    const uint32_t *d_neg_override, void *stream);
-
-/* General form of one training step (the row-cache experiments of DESIGN.md section 7.1 run
- * through it): the walk nodes may live in compact row caches (d_walk_rows gives the row of every
- * walk position in d_central / d_contextual) while negatives are drawn from a caller-supplied pool
- * of rows of a third table (the local shard).  With every optional field NULL / 0 this is exactly
- * gn2v_sgns_step / gn2v_cbow_step. */
-typedef struct {
-    const uint32_t *d_walks;     /* global node ids u32[n_walks][walk_length]                    */
-    const uint32_t *d_walk_rows; /* optional u32[n_walks][walk_length]: row of each walk node    */
-    float *d_central;
-    float *d_contextual;
-    float *d_negative;           /* optional: table of the negative rows (default: d_contextual
-                                    for SkipGram, d_central for CBOW)                            */
-    const uint32_t *d_neg_pool;  /* optional: negatives = d_neg_pool[uniform draw]               */
-    uint64_t neg_pool_size;
-    uint32_t neg_id_mul;         /* global id of negative row r = r * mul + add (0, 0 = identity), */
-    uint32_t neg_id_add;         /*   used to skip negatives equal to the centre / context       */
-    const uint32_t *d_neg_override;
-    float *d_context_delta;      /* optional, CBOW: the input-side gradient of every centre is
-                                    ADDED (f32 atomics) to this table f32[rows][ld] instead of
-                                    being applied to d_contextual, which is then only read during
-                                    the launch: the caller applies the sum later (the batch form a
-                                    CBOW spread over several GPUs needs: DESIGN.md 8)             */
-} gn2v_step_io;
-
-int gn2v_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_step_io *io,
-              uint64_t n_walks, uint32_t walk_length, uint64_t seed, uint64_t epoch,
-              uint64_t first_walk, float lr, void *stream);
 
 /* The whole of `models.SkipGram/CBOW(...).fit_transform(graph)` (node2vec.py:99): initialise both
  * caller-allocated tables f32[n_nodes][ld], then per epoch generate every walk and train on it.

@@ -58,8 +58,8 @@ if __name__ == "__main__":
     ap.add_argument("--hot-flush", type=int, default=0, help="blocks modes: see bench.py")
     ap.add_argument("--round-walks", type=int, default=1 << 19, help="blocks modes: walks per round")
     ap.add_argument("--stripes", type=int, default=1, help="blocks modes: centre stripes")
-    ap.add_argument("--central-atomic", action="store_true",
-                    help="blocks modes: every central row update by atomics")
+    ap.add_argument("--central-store", action="store_true",
+                    help="blocks modes: single-run centres by a store instead of atomics")
     ap.add_argument("--group-parts", type=int, default=0, help="blocks modes: parts per group")
     a = ap.parse_args()
     g = E.barabasi_albert(a.nodes, a.m, 42)
@@ -82,8 +82,8 @@ if __name__ == "__main__":
             # every row; "at" = atomics on every row
             kind = f[4] if len(f) > 4 else ""
             extra = {"": 0, "st": _lib.TRAIN_WRITE_THROUGH, "at": _lib.TRAIN_ATOMIC}[kind]
-            if a.central_atomic:
-                extra |= _lib.TRAIN_CENTRAL_ATOMIC
+            if a.central_store:
+                extra |= _lib.TRAIN_CENTRAL_STORE
             tp = ops.train_params(0, d, 10, 5, flags=1 | extra, ld=d)
             tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
                                          walk_length=128, window=5, parts=parts, slices=slices,

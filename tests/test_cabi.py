@@ -13,19 +13,25 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
                       "gn2v.h")
 
 
-def declared_symbols():
-    text = open(HEADER).read()
+EXPERIMENTAL = os.path.join(os.path.dirname(HEADER), "gn2v_experimental.h")
+
+
+def declared_symbols(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(gn2v_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
     assert declared_symbols() == sorted(_lib.EXPORTS)
+    # rejected designs live in a header of their own, outside the drop-in boundary
+    assert declared_symbols(EXPERIMENTAL) == sorted(_lib.EXPERIMENTAL_EXPORTS)
+    assert not set(_lib.EXPERIMENTAL_EXPORTS) & set(_lib.EXPORTS)
 
 
 def test_library_exports_every_declared_symbol():
     L = C.CDLL(_lib.build())
-    for name in declared_symbols():
+    for name in declared_symbols() + declared_symbols(EXPERIMENTAL):
         assert hasattr(L, name), name
     assert _lib.lib().gn2v_version() == 300
 
@@ -45,7 +51,7 @@ def test_struct_layouts_match_header():
                         ("GN2V_TRAIN_WRITE_THROUGH", _lib.TRAIN_WRITE_THROUGH),
                         ("GN2V_TRAIN_WALK_ORDERED", _lib.TRAIN_WALK_ORDERED),
                         ("GN2V_TRAIN_BLOCK_PATH", _lib.TRAIN_BLOCK_PATH),
-                        ("GN2V_TRAIN_CENTRAL_ATOMIC", _lib.TRAIN_CENTRAL_ATOMIC),
+                        ("GN2V_TRAIN_CENTRAL_STORE", _lib.TRAIN_CENTRAL_STORE),
                         ("GN2V_GRAPH_DEVICE_PTRS", _lib.GRAPH_DEVICE_PTRS),
                         ("GN2V_GRAPH_SYMMETRIC", _lib.GRAPH_SYMMETRIC)):
         assert re.search(rf"#define {name} +{value}u", text), name

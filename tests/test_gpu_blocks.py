@@ -692,6 +692,27 @@ def test_gn2v_train_takes_the_block_path_by_itself_from_2560_nodes():
     assert m.last_plan is None
 
 
+def test_default_fits_beyond_the_block_paths_lds_plans_still_run():
+    """The default SkipGram fit on a 4 k-node graph with parameters the block path's LDS plans
+    cannot hold at records of 32: 64 negatives (the record shrinks to 16 pairs: still the block
+    path) and walks of 1 024 nodes (the extraction cannot stage them: gn2v_train_blocks says so
+    before it touches anything and gn2v_train takes the walk-ordered schedule).  Both used to
+    fail after the tables had been initialised."""
+    g = E.barabasi_albert(4_000, 3, 1)
+    many = E.models.SkipGram(embedding_size=128, epochs=1, iterations=1, walk_length=16,
+                             window_size=2, number_of_negative_samples=64, verbose=False)
+    c, x, st = many.fit_transform_device(g)
+    assert many.last_plan is not None and many.last_plan["slices"] == 8
+    assert st["pairs"] == 4_000 * (2 * 2 * 16 - 2 * 3)
+    assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+    long_walks = E.models.SkipGram(embedding_size=16, epochs=1, iterations=1, walk_length=1024,
+                                   window_size=2, number_of_negative_samples=2, verbose=False)
+    c, x, st = long_walks.fit_transform_device(g)
+    assert long_walks.last_plan is None  # the walk-ordered schedule
+    assert st["pairs"] == 4_000 * (2 * 2 * 1024 - 2 * 3)
+    assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+
+
 def test_block_path_against_the_committed_golden_fixture(karate):
     """tests/golden/oracle_blocks.npz (the oracle's block schedule frozen on Karate: rank 1 of 2,
     4 parts x 2 slices, two hot rows per cell): the device reproduces extraction, sort, alias tables and
@@ -1002,7 +1023,7 @@ def test_training_on_a_cu_masked_stream_leaves_cus_free_and_changes_nothing():
     assert np.array_equal(base[0], again[0])
 
 
-@pytest.mark.parametrize("flags", [DET, 0, _lib.TRAIN_CENTRAL_ATOMIC])
+@pytest.mark.parametrize("flags", [DET, 0, _lib.TRAIN_CENTRAL_STORE])
 def test_long_stretches_of_one_centre_are_cut_into_runs_of_sixteen(flags):
     """Records of 32 pairs, every record filled by ONE centre (unique context rows, k = 0): the
     stretch is trained as two runs of 16 -- the second starts from the row the first left (in the
