@@ -119,13 +119,84 @@ gn2v::WalkConsts walk_consts(const gn2v_graph *g, const gn2v_walk_params *wp) {
         const double n = std::ceil(37.0 / a);
         c.max_trials = n < 32.0 ? 32u : (uint32_t)n;
     }
+    // the previous node proposed on its own (walk_kernels.h WalkConsts.apart; same rule and
+    // arithmetic as the oracle's make_walk_consts)
+    const double m = ew > 1.0 ? ew : 1.0;
+    c.apart = c.second_order && !c.node_bias && !c.edge_bias && g->view.cumw == nullptr &&
+              rw > m && rw <= 1024.0 && m <= 1024.0;
+    if (c.apart) {
+        c.rq = (uint64_t)std::floor(rw * 1048576.0);
+        c.mq = (uint64_t)std::floor(m * 1048576.0);
+        c.s_common = (uint64_t)std::floor(1.0 / m * s);
+        c.s_explore = (uint64_t)std::floor(ew / m * s);
+        c.s_min = std::min(c.s_common, c.s_explore);
+        c.s_max = std::max(c.s_common, c.s_explore);
+        const double a2 = (double)c.s_min / s;
+        if (!(a2 > 37.0 / 1024.0)) {
+            c.max_trials = 1024;
+        } else {
+            const double n = std::ceil(37.0 / a2);
+            c.max_trials = n < 32.0 ? 32u : (uint32_t)n;
+        }
+    }
     return c;
+}
+
+// The edge set of the second-order sampler (walk_kernels.h): 8 B per slot, 2 .. 4 slots per
+// directed edge (a power of two at load <= 1/2): 3.2 GB for the 10 M / 100 M bench graph, 32 GB at
+// 100 M / 1 B.  Built once per handle, on the first walk that needs it, when it fits a quarter of
+// the free memory; GN2V_WALK_EDGE_SET=0 keeps the binary searches (same walks either way).
+int ensure_edge_set(gn2v_graph *g, hipStream_t s) {
+    if (g->edge_set_tried) return 0;
+    g->edge_set_tried = true;
+    const char *env = getenv("GN2V_WALK_EDGE_SET");
+    if (env && *env == '0') return 0;
+    const uint64_t E = g->view.n_edges;
+    if (E == 0 || g->view.n_nodes >= 0xFFFFFFFFULL) return 0;
+    uint64_t slots = 16;
+    while (slots < 2 * E) slots <<= 1;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || slots * 8 > free_b / 4) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    unsigned long long *table = nullptr;
+    if (hipMalloc((void **)&table, slots * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    HIP_TRY(hipMemsetAsync(table, 0xFF, slots * 8, s));
+    // the filter in front of it: one word per 8 edges, rounded up to a power of two
+    // (GN2V_WALK_EDGE_FILTER=0: the set alone)
+    uint64_t words = 16;
+    while (words * 8 < E) words <<= 1;
+    unsigned long long *filter = nullptr;
+    const char *fenv = getenv("GN2V_WALK_EDGE_FILTER");
+    if (!(fenv && *fenv == '0') && hipMalloc((void **)&filter, words * 8) == hipSuccess)
+        HIP_TRY(hipMemsetAsync(filter, 0, words * 8, s));
+    else
+        (void)hipGetLastError();
+    const unsigned blocks = (unsigned)std::min<uint64_t>((g->view.n_nodes + 255) / 256, 1u << 20);
+    hipLaunchKernelGGL(gn2v::edge_set_kernel, dim3(blocks), dim3(256), 0, s, g->view.row_ptr,
+                       g->view.col_idx, g->view.n_nodes, table, slots - 1, filter, words - 1);
+    HIP_TRY(hipGetLastError());
+    g->edge_set = table;
+    g->edge_filter = filter;
+    g->view.edge_set = table;
+    g->view.edge_mask = slots - 1;
+    g->view.edge_filter = filter;
+    g->view.filter_mask = words - 1;
+    return 0;
 }
 
 int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
                  uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, hipStream_t s) {
     if (n_walks == 0) return 0;
     const gn2v::WalkConsts c = walk_consts(g, wp);
+    if (c.second_order) {
+        std::lock_guard<std::mutex> lock(g->mu);
+        if (ensure_edge_set(g, s)) return 1;
+    }
     const uint64_t blocks = (n_walks + gn2v::kWalkBlock - 1) / gn2v::kWalkBlock;
     if (blocks > 0x7FFFFFFFULL) return fail("too many walks in one launch");
     std::lock_guard<std::mutex> lock(g->mu);
@@ -577,6 +648,8 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->own_edge_types) (void)hipFree(g->own_edge_types);
     if (g->counters) (void)hipFree(g->counters);
     if (g->cursors) (void)hipFree(g->cursors);
+    if (g->edge_set) (void)hipFree(g->edge_set);
+    if (g->edge_filter) (void)hipFree(g->edge_filter);
     if (g->train_stream) (void)hipStreamDestroy(g->train_stream);
     if (g->ts_in) (void)hipEventDestroy(g->ts_in);
     if (g->ts_out) (void)hipEventDestroy(g->ts_out);

@@ -81,6 +81,9 @@ struct gn2v_graph {
     hipStream_t train_stream = nullptr;
     hipEvent_t ts_in = nullptr, ts_out = nullptr;
     uint32_t reserved_cus = 0;
+    // the second-order sampler's edge set (GraphView.edge_set), built on the first biased walk
+    unsigned long long *edge_set = nullptr, *edge_filter = nullptr;
+    bool edge_set_tried = false;
     unsigned long long *counters = nullptr;  // device, 4 x u64
     unsigned long long *cursors = nullptr;   // device, ring of record-ticket arrays (block trainer)
     uint32_t cursor_slot = 0;

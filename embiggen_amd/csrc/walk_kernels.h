@@ -29,7 +29,78 @@ struct GraphView {
     uint64_t n_edges;
     uint64_t n_sources;
     uint32_t symmetric;  // every edge is stored in both directions (undirected graph)
+    // Set of the directed edges (open addressing, key = source << 32 | destination, load <= 1/2;
+    // nullptr: not built): the second-order sampler's "is x adjacent to prev" in about one memory
+    // round trip instead of a binary search of log2(degree) dependent ones.  An accelerator only:
+    // the answer, hence every walk, is the same.
+    const unsigned long long *edge_set;
+    uint64_t edge_mask;  // slots - 1 (a power of two)
+    // A filter in front of it: one 64-bit word per ~8 edges with three bits set per edge (8-16
+    // bits per edge: 256 MB for the 10 M / 100 M bench graph -- the size of the Infinity Cache).
+    // Most candidates are NOT adjacent to the previous node, and a word that lacks one of the
+    // three bits says so for certain (5 % pass by chance and are looked up in the set): the
+    // adjacency test of the typical candidate becomes a cache hit instead of a random DRAM
+    // access -- the sampler runs at the DRAM's random-access ceiling (5.4e10 sectors per second)
+    // once the binary searches are gone.
+    const unsigned long long *edge_filter;
+    uint64_t filter_mask;  // words - 1 (a power of two)
 };
+
+constexpr unsigned long long kNoEdge = ~0ULL;
+
+__device__ __forceinline__ uint64_t edge_slot(unsigned long long key, uint64_t mask) {
+    return mix64(key) & mask;
+}
+
+constexpr unsigned long long kFilterSalt = 0xF117E2ED6E5E7ULL;
+
+// (word, three bits) of an edge in the filter
+__device__ __forceinline__ unsigned long long filter_bits(unsigned long long key, uint64_t mask,
+                                                          uint64_t *word) {
+    const uint64_t h = mix64(key ^ kFilterSalt);
+    *word = h & mask;
+    return (1ULL << (h >> 58)) | (1ULL << ((h >> 52) & 63)) | (1ULL << ((h >> 46) & 63));
+}
+
+static __global__ void edge_set_kernel(const uint64_t *__restrict__ row_ptr,
+                                       const uint32_t *__restrict__ col, uint64_t n_nodes,
+                                       unsigned long long *__restrict__ table, uint64_t mask,
+                                       unsigned long long *__restrict__ filter,
+                                       uint64_t filter_mask) {
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_nodes;
+         u += (uint64_t)gridDim.x * blockDim.x) {
+        for (uint64_t e = row_ptr[u]; e < row_ptr[u + 1]; ++e) {
+            const unsigned long long key = (u << 32) | col[e];
+            if (filter) {
+                uint64_t word;
+                const unsigned long long bits = filter_bits(key, filter_mask, &word);
+                atomicOr(&filter[word], bits);
+            }
+            uint64_t slot = edge_slot(key, mask);
+            for (;;) {
+                const unsigned long long old = atomicCAS(&table[slot], kNoEdge, key);
+                if (old == kNoEdge || old == key) break;
+                slot = (slot + 1) & mask;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool edge_set_contains(const GraphView &g, uint32_t u, uint32_t v) {
+    const unsigned long long key = ((unsigned long long)u << 32) | v;
+    if (g.edge_filter) {
+        uint64_t word;
+        const unsigned long long bits = filter_bits(key, g.filter_mask, &word);
+        if ((g.edge_filter[word] & bits) != bits) return false;
+    }
+    uint64_t slot = edge_slot(key, g.edge_mask);
+    for (;;) {
+        const unsigned long long k = g.edge_set[slot];
+        if (k == key) return true;
+        if (k == kNoEdge) return false;
+        slot = (slot + 1) & g.edge_mask;
+    }
+}
 
 struct WalkConsts {
     uint32_t walk_length;
@@ -39,6 +110,14 @@ struct WalkConsts {
     uint64_t t_ret, t_common, t_explore;  // acceptance thresholds on a 2^32 scale
     uint64_t t_min, t_max;                // min / max of (t_common, t_explore)
     uint64_t fn_same, fn_diff, fe_same, fe_diff;
+    // "Return apart" (return_weight above every other weight; unweighted untyped graphs): the
+    // previous node is proposed on its own -- with probability R / (R + deg M) -- and the other
+    // neighbours are accepted against their own envelope M = max(1, explore_weight): 2-4 x fewer
+    // trials than one envelope for all (oracle: walk_consts.apart)
+    uint32_t apart;
+    uint64_t rq, mq;                      // R and M on a 2^20 scale
+    uint64_t s_common, s_explore;         // 1 / M and explore_weight / M on a 2^32 scale
+    uint64_t s_min, s_max;
 };
 
 __device__ __forceinline__ bool adj_contains(const uint32_t *__restrict__ col, uint64_t lo,
@@ -61,6 +140,7 @@ constexpr uint64_t kLongRow = 64;
 
 __device__ __forceinline__ bool is_common_neighbour(const GraphView &g, uint32_t x, uint32_t prev,
                                                     uint64_t pstart, uint64_t pend) {
+    if (g.edge_set) return edge_set_contains(g, prev, x);
     if (g.symmetric && pend - pstart > kLongRow) {
         const uint64_t xs = g.row_ptr[x], xe = g.row_ptr[x + 1];
         if (xe - xs < pend - pstart) return adj_contains(g.col_idx, xs, xe, prev);
@@ -244,6 +324,69 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                         const uint64_t r = draw(wkey, ctr++);
                         idx = pick_index(g, start, deg, r);
                     } else {
+                        if (!TYPED && c.apart) {
+                            // The previous node proposed on its own (WalkConsts.apart).  Trial j
+                            // draws r1 (prev or a uniform neighbour?) and, for a neighbour, r2
+                            // (which one, and the acceptance draw): counter based, so the
+                            // candidate of trial j + 1 is fetched while trial j waits for its own
+                            // candidate and, when its draw lies between the class thresholds,
+                            // for the adjacency test -- one memory round trip per trial instead
+                            // of two; the look-ahead of an accepted trial is simply not consumed.
+                            bool accepted = false;
+                            idx = 0;
+                            uint32_t trial = 0;
+                            const uint64_t z = c.rq + deg * c.mq;
+                            // the trial in hand: direct (prev) or a neighbour i = x with draw r32
+                            bool direct = mulhi64(draw(wkey, ctr), z) < c.rq;
+                            uint64_t r2 = direct ? 0 : draw(wkey, ctr + 1);
+                            uint64_t i = ((r2 >> 32) * deg) >> 32;
+                            uint32_t x = direct ? 0u : g.col_idx[start + i];
+                            while (trial < c.max_trials) {
+                                const uint64_t used = direct ? 1 : 2;
+                                // look ahead: the next trial's candidate
+                                const bool n_direct = mulhi64(draw(wkey, ctr + used), z) < c.rq;
+                                const uint64_t n_r2 = n_direct ? 0 : draw(wkey, ctr + used + 1);
+                                const uint64_t n_i = ((n_r2 >> 32) * deg) >> 32;
+                                const uint32_t n_x = (n_direct || trial + 1 >= c.max_trials)
+                                                         ? 0u
+                                                         : g.col_idx[start + n_i];
+                                ++trial;
+                                ctr += used;
+                                if (direct) {
+                                    uint64_t lo = start, hi = end;
+                                    while (lo < hi) {
+                                        const uint64_t mid = lo + ((hi - lo) >> 1);
+                                        if (g.col_idx[mid] < prev)
+                                            lo = mid + 1;
+                                        else
+                                            hi = mid;
+                                    }
+                                    if (lo < end && g.col_idx[lo] == prev) {
+                                        idx = lo - start;
+                                        accepted = true;
+                                    }
+                                } else if (x != prev) {
+                                    const uint64_t r32 = r2 & 0xFFFFFFFFULL;
+                                    if (r32 < c.s_min)
+                                        accepted = true;
+                                    else if (r32 < c.s_max)
+                                        accepted = r32 < (is_common_neighbour(g, x, prev, pstart, pend)
+                                                              ? c.s_common
+                                                              : c.s_explore);
+                                    if (accepted) idx = i;
+                                }
+                                if (accepted) break;
+                                direct = n_direct;
+                                r2 = n_r2;
+                                i = n_i;
+                                x = n_x;
+                            }
+                            if (!accepted) {
+                                const uint64_t r = draw(wkey, ctr++);
+                                idx = exact_scan<TYPED>(g, c, r, cur, start, deg, prev, pstart,
+                                                        pend, ptype);
+                            }
+                        } else {
                         // Trials in two phases so that the wave pays for an adjacency search
                         // only when some lane's draw falls between the class thresholds: phase A
                         // runs trials until one is decided without the search (accept) or needs
@@ -285,6 +428,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                             const uint64_t r = draw(wkey, ctr++);
                             idx = exact_scan<TYPED>(g, c, r, cur, start, deg, prev, pstart, pend,
                                                     ptype);
+                        }
                         }
                     }
                     const uint32_t nxt = g.col_idx[start + idx];

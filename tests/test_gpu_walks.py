@@ -48,6 +48,27 @@ def test_walks_bit_exact_on_ba_graph():
         assert np.array_equal(got, O.walks(og, O.WalkParams(64, 2, rw, ew, 100, 0), 5, 1, 0, 10000))
 
 
+@pytest.mark.parametrize("rw,ew", [(0.25, 4.0), (2.0, 0.5), (4.0, 0.25)])
+def test_edge_set_and_filter_only_accelerate_the_adjacency_test(monkeypatch, rw, ew):
+    """The second-order sampler asks "is x adjacent to prev" of a hash set of the edges behind a
+    three-bit filter (built on a handle's first biased walk) instead of binary searches: the
+    same walks with the filter switched off, with the set switched off (binary searches, as in
+    rounds 1-3), and in the oracle."""
+    s, d = O.ba_edges(5000, 4, 11)
+    owp = O.WalkParams(40, 2, rw, ew, 100, 0)
+    ref = None
+    for env in ({}, {"GN2V_WALK_EDGE_FILTER": "0"}, {"GN2V_WALK_EDGE_SET": "0"}):
+        for k in ("GN2V_WALK_EDGE_FILTER", "GN2V_WALK_EDGE_SET"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=5000)  # a handle of its own
+        got = _u32(ops.walks(g, ops.walk_params(40, 2, rw, ew), 7, 1, 0, 10_000))
+        if ref is None:
+            ref = O.walks(O.OracleGraph(g.row_ptr, g.col_idx), owp, 7, 1, 0, 10_000)
+        assert np.array_equal(got, ref), env
+
+
 def test_weighted_walks_bit_exact():
     rng = np.random.RandomState(3)
     s, d = O.ba_edges(800, 3, 5)

@@ -70,6 +70,32 @@ def test_second_order_transition_distribution(karate, karate_oracle, rw, ew):
     assert min(pvals) > 1e-3 / checked, (min(pvals), checked)
 
 
+def test_return_apart_on_a_directed_graph_where_the_way_back_is_no_edge():
+    """return_weight above every other weight: the previous node is proposed on its own
+    (walk_consts.apart) and must be turned down when cur -> prev is not an edge.  Directed graph
+    0 -> {1, 2}, 1 -> {2, 3, 4}: from (prev 0, cur 1) the walk continues to 2 (adjacent to 0:
+    weight 1), 3 or 4 (weight explore_weight), never back to 0."""
+    src = np.array([0, 0, 1, 1, 1, 2, 3, 4])
+    dst = np.array([1, 2, 2, 3, 4, 0, 0, 0])
+    g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=5, directed=True)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    rw, ew = 4.0, 0.25
+    w = O.walks(og, O.WalkParams(3, 1, rw, ew, 100, 0), 5, 0, 0, 5 * 40000)
+    sel = (w[:, 0] == 0) & (w[:, 1] == 1)
+    assert sel.sum() > 10000 and not (w[sel, 2] == 0).any()
+    counts = np.array([(w[sel, 2] == x).sum() for x in (2, 3, 4)], dtype=np.float64)
+    want = np.array([1.0, ew, ew]) / (1.0 + 2 * ew)
+    assert stats.chisquare(counts, want * counts.sum()).pvalue > 1e-4
+    # and with the way back present (undirected): prev takes return_weight
+    g2 = E.CSRGraph.from_edge_list(src[:5], dst[:5], number_of_nodes=5)
+    og2 = O.OracleGraph(g2.row_ptr, g2.col_idx)
+    w = O.walks(og2, O.WalkParams(3, 1, rw, ew, 100, 0), 5, 0, 0, 5 * 40000)
+    sel = (w[:, 0] == 0) & (w[:, 1] == 1)
+    counts = np.array([(w[sel, 2] == x).sum() for x in (0, 2, 3, 4)], dtype=np.float64)
+    want = np.array([rw, 1.0, ew, ew]) / (rw + 1.0 + 2 * ew)
+    assert stats.chisquare(counts, want * counts.sum()).pvalue > 1e-4
+
+
 def test_extreme_weights_use_exact_fallback(karate, karate_oracle):
     """return_weight >> 1 with explore tiny: acceptance ~1e-4, the rejection loop gives up after
     128 trials and the exact scan must still sample the right distribution."""
