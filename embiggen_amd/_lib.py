@@ -243,7 +243,7 @@ def lib():
     L.gn2v_graph_reserve_cus.argtypes = [vp, u32, vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),
                                   C.POINTER(BlockIO), u64, u64, f32, vp]
-    L.gn2v_block_auto_plan.argtypes = [u64, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.gn2v_block_auto_plan.argtypes = [u64, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
     L.gn2v_block_round_plan.argtypes = [u64, u64, u32, u32, u32, u32, u32, u32, C.POINTER(u64),
                                         C.POINTER(u32)]
     L.gn2v_train_blocks.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,

@@ -523,11 +523,39 @@ __device__ __forceinline__ void hot_hand_over(float *hb, float *dl, uint32_t *lo
 // One sample row against the register row u of its centre (a 16-lane group): v = row, var =
 // (label - sigmoid(clip(u.v))) * lr, g += var * v, row += var * u -- a read-modify-write of the
 // row in memory, or of the workgroup's LDS copy when the row is hot.
-template <int CH, int WMX>
+template <int CH, int WMX, bool RES = false>
 __device__ __forceinline__ void score_sample(const BlockArgs &a, const HotLds &h,
                                              const Row<CH> &u, Row<CH> &g, uint32_t row, float lab,
                                              float lrc, int q, uint32_t nchunks) {
     const bool valid = row != kSentinel;
+    if constexpr (RES) {
+        // resident cell (sgns_resident_kernel): `row` is the row inside the cell, every row of
+        // which lives in h.base -- read, scored and updated in LDS, nothing else holds a copy
+        float *rw = h.base + (valid ? row : 0u) * h.ld;
+        Row<CH> v;
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) {
+            const uint32_t ci = cc * 16 + q;
+            v.c[cc] = (valid && ci < nchunks) ? *reinterpret_cast<const float4 *>(rw + ci * 4)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float dot = dot_rows<CH>(u, v);
+        const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+        axpy<CH>(g, var, v);
+        if (valid) {
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc) {
+                const uint32_t ci = cc * 16 + q;
+                if (ci < nchunks) {
+                    lds_add_f32(rw + ci * 4 + 0, var * u.c[cc].x);
+                    lds_add_f32(rw + ci * 4 + 1, var * u.c[cc].y);
+                    lds_add_f32(rw + ci * 4 + 2, var * u.c[cc].z);
+                    lds_add_f32(rw + ci * 4 + 3, var * u.c[cc].w);
+                }
+            }
+        }
+        return;
+    }
     const bool hot = valid && (row & kHubBit) != 0;
     const bool cold = valid && !hot;
     float *base = sample_base(a, a.context, cold ? row : 0);
@@ -572,7 +600,7 @@ __device__ __forceinline__ void score_sample(const BlockArgs &a, const HotLds &h
 
 // the sample list of a run against the register row u (replicated in the four groups): a round
 // is the four sample rows t0 .. t0 + 3, one per group, with no check for a row named twice in it
-template <int CH, int WMX>
+template <int CH, int WMX, bool RES = false>
 __device__ __forceinline__ void score_run(const BlockArgs &a, const HotLds &h, const Row<CH> &u,
                                           Row<CH> &g, const uint32_t *s_rows, const float *s_lab,
                                           uint32_t n_samples, float lrc, int grp, int q) {
@@ -581,11 +609,11 @@ __device__ __forceinline__ void score_run(const BlockArgs &a, const HotLds &h, c
         const uint32_t t = t0 + grp;
         const uint32_t row = t < n_samples ? s_rows[t] : kSentinel;
         const float lab = t < n_samples ? s_lab[t] : 0.f;
-        score_sample<CH, WMX>(a, h, u, g, row, lab, lrc, q, nchunks);
+        score_sample<CH, WMX, RES>(a, h, u, g, row, lab, lrc, q, nchunks);
     }
 }
 
-template <int CH, int WMX, int WMC, bool DET>
+template <int CH, int WMX, int WMC, bool DET, bool RES = false>
 __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h, uint32_t cell,
                                              uint64_t lo, uint64_t hi, uint64_t p0, uint32_t n,
                                              uint64_t ckey, uint64_t cell_lo, uint64_t cell_n,
@@ -597,14 +625,15 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
     const uint32_t k = a.k, nchunks = a.ld >> 2;
     const uint32_t rowmask = a.p.row_bits >= 32 ? 0xFFFFFFFFu : ((1u << a.p.row_bits) - 1u);
     // hot rows are served from the LDS accumulators in the parallel store schedules only
-    const uint32_t hot_n = (DET || is_atomic(WMX)) ? 0u : h.n;
+    const uint32_t hot_n = (DET || RES || is_atomic(WMX)) ? 0u : h.n;
     wave_sync();
     if ((uint32_t)lane < n) {
         const unsigned long long word = a.pairs[p0 + lane];
         const uint32_t low = (uint32_t)word & ((1u << a.p.ctx_bits) - 1u);
         const uint32_t hub = low >> (a.p.ctx_bits - 1);
         const uint32_t local = low & ((1u << (a.p.ctx_bits - 1)) - 1u);
-        uint32_t val = slice + a.p.slices * local;  // row inside the part
+        // row inside the part (resident cells: inside the cell)
+        uint32_t val = RES ? local : slice + a.p.slices * local;
         uint32_t hs = kNoSlot;
         if (hub && hot_n) {
             hs = a.hot_slot[cell_lo + local];
@@ -640,9 +669,9 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
                     hub = (uint32_t)(e >> 63);
                 }
             }
-            row = slice + a.p.slices * local;
+            row = RES ? local : slice + a.p.slices * local;
             lab = 0.f;
-            const uint64_t ngid = (uint64_t)row * a.p.parts + a.part;
+            const uint64_t ngid = (uint64_t)(slice + a.p.slices * local) * a.p.parts + a.part;
             const uint64_t cgid = (uint64_t)s_key[pr] * a.p.world + a.p.rank;
             if (row == (xrow & ~kHubBit) || ngid == cgid) {
                 row = kSentinel;
@@ -690,7 +719,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
                 for (uint32_t sidx = 0; sidx < kk; ++sidx) {
                     const uint32_t t = (have ? pr : 0) * kk + sidx;
                     const uint32_t row = have ? s_rows[t] : kSentinel;
-                    score_sample<CH, WMX>(a, h, u, g, row, s_lab[t], lrc, q, nchunks);
+                    score_sample<CH, WMX, RES>(a, h, u, g, row, s_lab[t], lrc, q, nchunks);
                 }
                 // the pair's gradient goes to its central row: one store of row + gradient when
                 // the plan allows it and the pair's neighbours have other centres (a.central_store),
@@ -765,7 +794,7 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
             score_samples<CH, WMX, DET>(a, a.context, u, u, g, s_rows + r0 * (k + 1),
                                         s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
         } else if constexpr (!is_atomic(WMX)) {
-            score_run<CH, WMX>(a, h, u, g, s_rows + r0 * (k + 1), s_lab + r0 * (k + 1),
+            score_run<CH, WMX, RES>(a, h, u, g, s_rows + r0 * (k + 1), s_lab + r0 * (k + 1),
                                (r1 - r0) * (k + 1), lrc, grp, q);
         } else {  // atomics on every row: u in the lane-contiguous layout for the row updates
             Row<CH> u_upd;
@@ -967,6 +996,87 @@ __global__ __launch_bounds__(WG) void sgns_block_kernel(BlockArgs a) {
     if (a.counters && lane == 0 && pairs) {
         atomicAdd(&a.counters[0], pairs);
         atomicAdd(&a.counters[2], runs);  // "centres": runs of equal centre
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Resident cells: the plan of a small or mid-sized graph (gn2v_block_auto_plan: up to ~1.5 M nodes
+// at d = 128) makes cells whose rows fit ONE workgroup's LDS.  A launch covers a part, one
+// workgroup of sixteen waves per cell: it loads the cell's contextual rows into LDS, trains ALL
+// the cell's records (its waves take them from an LDS cursor), reads and updates the rows in
+// LDS -- ds_add_f32: every update of every row arrives, and each wave sees the others' at once --
+// and writes the rows back when the cell is done.  No other workgroup touches those rows during
+// the launch: nothing races, nothing is in limbo, no atomics on contextual rows.  (The XCD cells
+// of sgns_block_kernel lose what waves of different CUs write to an ordinary row at the same
+// moment: at 2 708 nodes 8 x 2 000 row updates are in flight on 2 708 rows and the contextual
+// table moved 0.69 x as far as the sequential schedule)  The central rows are
+// shared between the cells and take the run's gradient by f32 atomics, as in sgns_block_kernel.
+// LDS: per wave the staging of train_record, then rows[cell rows][ld] and the record cursor.
+// --------------------------------------------------------------------------------------------
+template <int CH, bool FULL = false>
+__global__ __launch_bounds__(1024) void sgns_resident_kernel(BlockArgs a) {
+    if constexpr (FULL) a.ld = CH * 64;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, q = lane & 15;
+    const uint32_t C = a.p.record, k = a.k;
+    const uint32_t per_wave = (a.ld + 3 * C + 2 * C * (k + 1) + 2 + 3) & ~3u;
+    float *s_tr = reinterpret_cast<float *>(smem + wave * per_wave);
+    uint32_t *s_key = smem + wave * per_wave + a.ld;
+    uint32_t *s_val = s_key + C;
+    uint32_t *s_hs = s_val + C;
+    uint32_t *s_rows = s_hs + C;
+    float *s_lab = reinterpret_cast<float *>(s_rows + C * (k + 1));
+    uint32_t *s_nb = s_rows + 2 * C * (k + 1);
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t slice = blockIdx.x;
+    const uint32_t cell = a.part * a.p.slices + slice;
+    const uint64_t lo = a.cell_offsets[cell], hi = a.cell_offsets[cell + 1];
+    if (hi == lo) return;  // the same for every wave of the workgroup
+    const uint64_t part_rows = stripe_count(a.n_nodes, a.part, a.p.parts);
+    const uint32_t cell_n = (uint32_t)stripe_count(part_rows, slice, a.p.slices);
+    HotLds h{};
+    h.base = reinterpret_cast<float *>(smem + n_waves * per_wave);
+    h.ld = a.ld;
+    h.n = cell_n;
+    uint32_t *s_cursor = smem + n_waves * per_wave + cell_n * a.ld;
+    for (uint32_t i = threadIdx.x; i < cell_n * (a.ld >> 2); i += blockDim.x) {
+        const uint32_t r = i / (a.ld >> 2), c4 = i - r * (a.ld >> 2);
+        reinterpret_cast<float4 *>(h.base + r * a.ld)[c4] = reinterpret_cast<const float4 *>(
+            sample_base(a, a.context, slice + a.p.slices * r))[c4];
+    }
+    if (threadIdx.x == 0) *s_cursor = 0;
+    __syncthreads();
+    unsigned long long pairs = 0, runs = 0;
+    const uint64_t R = (hi - lo + C - 1) / C;
+    const uint64_t A = record_stride(R);
+    const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kMaxCells + cell);
+    const uint64_t cell_lo = a.cell_rows ? a.cell_rows[cell] : 0;
+    const uint64_t start = mulhi64(ckey, R);
+    for (;;) {
+        uint32_t t0 = 0;
+        if (lane == 0)
+            t0 = __hip_atomic_fetch_add((lds_u32 *)s_cursor, 1u, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t t = __shfl(t0, 0);
+        if (t >= R) break;
+        const uint64_t rec = (t * A + start) % R;
+        const uint64_t p0 = lo + rec * C;
+        const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
+        train_record<CH, kWriteBack, kAtomic, false, true>(a, h, cell, lo, hi, p0, n, ckey, cell_lo,
+                                                           cell_n, slice, s_key, s_val, s_hs,
+                                                           s_rows, s_lab, s_nb, s_tr, lane, grp, q,
+                                                           pairs, runs);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cell_n * (a.ld >> 2); i += blockDim.x) {
+        const uint32_t r = i / (a.ld >> 2), c4 = i - r * (a.ld >> 2);
+        reinterpret_cast<float4 *>(sample_base(a, a.context, slice + a.p.slices * r))[c4] =
+            reinterpret_cast<const float4 *>(h.base + r * a.ld)[c4];
+    }
+    if (a.counters && lane == 0 && pairs) {
+        atomicAdd(&a.counters[0], pairs);
+        atomicAdd(&a.counters[2], runs);
     }
 }
 

@@ -20,6 +20,8 @@ using namespace gn2v_host;
 
 namespace {
 
+constexpr uint32_t kMaxSlices = GN2V_BLOCK_MAX_SLICES;
+
 uint32_t bits_for(uint64_t n) {  // smallest b with 2^b >= n
     uint32_t b = 0;
     while ((1ULL << b) < n) ++b;
@@ -33,8 +35,8 @@ int check_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     // (ranks that exchange parts need parts % world == 0: the host-side trainer checks that; the
     // centre stripes of one GPU -- gn2v_block_io.central_ld -- do not)
     if (p->parts < 1) return fail("parts must be positive");
-    if (p->slices < 1 || p->slices > gn2v_host::kCursorSlices)
-        return fail("slices must be in [1, 16]");
+    if (p->slices < 1 || p->slices > kMaxSlices)
+        return fail("slices must be in [1, " + std::to_string(kMaxSlices) + "]");
     if ((uint64_t)p->parts * p->slices > gn2v::kMaxCells) return fail("too many cells (parts x slices)");
     if (p->walk_length < 2 || p->window < 1) return fail("need walk_length >= 2, window_size >= 1");
     if (p->min_dist > p->window) return fail("min_dist must not exceed window_size");
@@ -74,6 +76,16 @@ size_t block_lds_words_per_wave(uint32_t ld, uint32_t record, uint32_t k) {
 // the extraction stages, per wave, the walk and three words per position, plus one counter per cell
 size_t extract_lds_bytes(uint32_t walk_length, uint32_t cells) {
     return ((size_t)(gn2v::kPrepBlock / 64) * 4 * walk_length + cells) * 4;
+}
+
+// Rows of a cell that one workgroup of sixteen waves holds in LDS next to its waves' staging
+// (sgns_resident_kernel); 0: rows too wide for that kernel (it is built for strides up to 128
+// floats) or nothing left beside the staging
+uint32_t resident_rows(uint32_t ld, uint32_t record, uint32_t k) {
+    if (ld == 0 || ld > 128) return 0;
+    const size_t staging = block_lds_words_per_wave(ld, record, k) * 4 * 16 + 64;
+    const size_t lds = 160 * 1024;
+    return staging >= lds ? 0 : (uint32_t)std::min<size_t>((lds - staging) / ((size_t)ld * 4), 4096);
 }
 
 size_t env_size(const char *name, size_t fallback) {
@@ -377,6 +389,19 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
 #undef GN2V_BLOCK
 #undef GN2V_BLOCK_WIDE
 }
+
+template <int CH>
+static void launch_resident_ch(dim3 grid, size_t lds, hipStream_t s, const gn2v::BlockArgs &a) {
+    if (a.ld == (uint32_t)CH * 64) {
+        auto kernel = gn2v::sgns_resident_kernel<CH, true>;
+        allow_lds(kernel, lds);
+        hipLaunchKernelGGL(kernel, grid, dim3(1024), lds, s, a);
+    } else {
+        auto kernel = gn2v::sgns_resident_kernel<CH, false>;
+        allow_lds(kernel, lds);
+        hipLaunchKernelGGL(kernel, grid, dim3(1024), lds, s, a);
+    }
+}
 }  // extern "C++"
 
 int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
@@ -466,6 +491,45 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     // when even T = 1 does not, the rows stay ordinary rows (plain stores lose updates on hub rows
     // -- which is also what keeps them stable at any learning rate).
     const bool stores = !det && wmx != gn2v::kAtomic;
+    // Resident cells (block_kernels.h sgns_resident_kernel): every cell of the plan fits one
+    // workgroup's LDS -- what gn2v_block_auto_plan arranges for graphs up to ~1.5 M nodes at
+    // d = 128.  One workgroup per cell, contextual rows read and updated in LDS: exact.
+    static const size_t resident_env = env_size("GN2V_BLOCK_RESIDENT", 1);  // 0: never (A/B)
+    const uint64_t max_cell_rows =
+        gn2v::stripe_count(gn2v::stripe_count(g->view.n_nodes, 0, d.parts), 0, d.slices);
+    const bool resident = stores && resident_env && wmc != gn2v::kWriteBack &&
+                          !(tp->flags & (GN2V_TRAIN_WRITE_THROUGH | GN2V_TRAIN_WRITE_BACK)) &&
+                          max_cell_rows <= resident_rows(tp->ld, d.record, tp->k);
+    if (d.slices > gn2v_host::kCursorSlices && !resident)
+        return fail("more than 16 slices need cells that fit a workgroup's LDS (default update "
+                    "mode, rows up to 128 floats)");
+    if (resident) {
+        const size_t lds = block_lds_words_per_wave(tp->ld, d.record, tp->k) * 4 * 16 +
+                           (size_t)max_cell_rows * tp->ld * 4 + 16;
+        std::lock_guard<std::mutex> lock(g->mu);
+        hipStream_t caller = s;
+        if (g->train_stream) {
+            HIP_TRY(hipEventRecord(g->ts_in, caller));
+            HIP_TRY(hipStreamWaitEvent(g->train_stream, g->ts_in, 0));
+            s = g->train_stream;
+        }
+        EventPair ev;
+        if (get_events(g, &ev)) return 1;
+        HIP_TRY(hipEventRecord(ev.a, s));
+        if (tp->ld <= 64)
+            launch_resident_ch<1>(dim3(d.slices), lds, s, a);
+        else
+            launch_resident_ch<2>(dim3(d.slices), lds, s, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev.b, s));
+        g->train_events.push_back(ev);
+        g->train_launches++;
+        if (g->train_stream) {
+            HIP_TRY(hipEventRecord(g->ts_out, s));
+            HIP_TRY(hipStreamWaitEvent(caller, g->ts_out, 0));
+        }
+        return 0;
+    }
     static const size_t wide_env = env_size("GN2V_BLOCK_WIDE", 1);  // 0: never (A/B)
     const size_t per_wave_words = block_lds_words_per_wave(tp->ld, d.record, tp->k);
     bool wide = stores && a.hot_list && d.hot_rows && wide_env && tp->ld <= 128 &&
@@ -551,9 +615,30 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
 }
 
 
-int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t *parts, uint32_t *slices) {
+int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
+                         uint32_t *parts, uint32_t *slices) {
     if (!parts || !slices || world < 1) return fail("bad arguments");
     constexpr uint64_t kMinRows = 32768, kXcds = 8;
+    // One GPU, rows up to 128 floats, a graph small enough for cells that fit a workgroup's LDS
+    // (8 192 cells x ~200 rows at d = 128: 1.6 M nodes): RESIDENT CELLS -- every contextual row
+    // is read and updated in the LDS of the one workgroup that owns its cell, exactly
+    // (sgns_resident_kernel).  As few cells as hold the rows, but 256 when the graph allows
+    // cells of 64 rows (a launch covers a part: one workgroup per cell and CU), up to 256
+    // slices per part.
+    const uint64_t fit = world == 1 && n_nodes >= GN2V_BLOCK_PATH_MIN_NODES
+                             ? resident_rows(ld, 32, k) : 0;
+    if (fit >= 16 && n_nodes <= fit * (gn2v::kMaxCells - 512)) {
+        uint64_t cells = (n_nodes + fit - 1) / fit;
+        if (cells < 256) cells = std::min<uint64_t>(256, std::max<uint64_t>(cells, n_nodes / 64));
+        uint64_t sl = std::min<uint64_t>(cells, kMaxSlices), p = (cells + sl - 1) / sl;
+        // striping rounds up twice: make sure the largest cell fits
+        while (gn2v::stripe_count(gn2v::stripe_count(n_nodes, 0, p), 0, sl) > fit) ++p;
+        if (p * sl <= gn2v::kMaxCells) {
+            *parts = (uint32_t)p;
+            *slices = (uint32_t)sl;
+            return 0;
+        }
+    }
     // Slices: one per XCD or none.  Only then is a contextual row exclusive to one XCD's L2 (plain
     // write-back stores, hub rows L2 resident); 2 or 4 slices would have several XCDs share a
     // slice and fall back to write-through stores without the locality.
@@ -638,7 +723,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     gn2v_block_plan plan{};
     plan.world = V;
     plan.rank = 0;
-    if (gn2v_block_auto_plan(n, 1, &plan.parts, &plan.slices)) return 1;
+    if (gn2v_block_auto_plan(n, 1, ld, tp->k, &plan.parts, &plan.slices)) return 1;
     plan.walk_length = L;
     plan.window = w;
     plan.min_dist = tp->min_dist ? tp->min_dist : 1;

@@ -67,9 +67,11 @@ def round_plan(free_bytes: int, n_nodes: int, walk_length: int, window: int, wor
     return walks.value, group.value
 
 
-def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:
+def auto_plan(n_nodes: int, world: int, ld: int = 0, k: int = 10) -> Tuple[int, int]:
     """(parts, slices) of the contextual table (``gn2v_block_auto_plan``: one rule for the C++
-    one-GPU fit and for this trainer).  Measured (scripts/quality_probe.py):
+    one-GPU fit and for this trainer).  One GPU, row stride ``ld`` <= 128 floats (0: unknown),
+    up to ~1.5 M nodes: resident cells -- cells that fit one workgroup's LDS, whose rows are
+    read and updated there, exactly.  Otherwise XCD cells.  Measured (scripts/quality_probe.py):
     the smaller a cell, the more of it lives in the XCD's L2 (BA 10 M nodes: 0.67 of the HBM
     roofline unsliced, 0.80 at 4 x 8 cells, 0.87 at 32 x 8) -- and the more often two waves
     read-modify-write the same row at once; link quality stays at or above the walk-ordered
@@ -81,7 +83,8 @@ def auto_plan(n_nodes: int, world: int) -> Tuple[int, int]:
     from . import _lib
 
     parts, slices = C.c_uint32(), C.c_uint32()
-    _lib.check(_lib.lib().gn2v_block_auto_plan(n_nodes, world, C.byref(parts), C.byref(slices)))
+    _lib.check(_lib.lib().gn2v_block_auto_plan(n_nodes, world, int(ld), int(k), C.byref(parts),
+                                               C.byref(slices)))
     return parts.value, slices.value
 
 
@@ -328,7 +331,7 @@ class BlockPartitionedTrainer:
         self.walk_length, self.window = walk_length, window
         rank, world = comm.rank, comm.world
         self.backend = backend if backend is not None else GpuBlockBackend(graph, device)
-        auto_parts, auto_slices = auto_plan(self.n_nodes, world)
+        auto_parts, auto_slices = auto_plan(self.n_nodes, world, ld, int(train_params.k))
         parts = auto_parts if parts is None else parts
         slices = auto_slices if slices is None else slices
         if world > 1 and (parts % world or parts < 2 * world):

@@ -51,6 +51,14 @@
 #define O_FLAG_SCALE_FREE 1u
 #define O_FLAG_DOWNSAMPLE 2u
 #define O_FLAG_NORM_LR 4u
+/* Variants of the two readings DESIGN.md 1.1 decides the other way, in the oracle's SkipGram
+ * trainer only (tests/test_ensmallen_hook.py prints what each changes; the device has neither):
+ * SKIP_CLIPPED: "clip" read as "skip the update when |dot| > clipping_value" (the [uncited] hint
+ * about ensmallen) instead of clamping the dot product; SHARED_NEGATIVES: the k negatives of a
+ * centre drawn once and reused for all its contexts (the docstring's "per batch" wording,
+ * node2vec_skipgram.py:48-50) instead of k fresh ones per pair. */
+#define O_FLAG_SKIP_CLIPPED 256u
+#define O_FLAG_SHARED_NEGATIVES 512u
 
 typedef struct {
     uint32_t walk_length;
@@ -555,7 +563,8 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const o_step_io *io
                     v = contextual + (uint64_t)wrow[j] * ld;
                     label = 1.0f;
                 } else {
-                    uint64_t q = ((uint64_t)i * 2 * w + slot) * k + (s - 1);
+                    uint32_t qslot = (tp->flags & O_FLAG_SHARED_NEGATIVES) ? 0 : slot;
+                    uint64_t q = ((uint64_t)i * 2 * w + qslot) * k + (s - 1);
                     uint32_t row = neg_override ? neg_override[q] : draw_negative(g, tp, io, nkey, q);
                     uint32_t gid = neg_global_id(io, row);
                     label = 0.0f;
@@ -564,6 +573,8 @@ void o_sgns_walk(const o_graph *g, const o_train_params *tp, const o_step_io *io
                 }
                 float dot = 0.0f;
                 for (uint32_t x = 0; x < d; ++x) dot += u[x] * v[x];
+                if ((tp->flags & O_FLAG_SKIP_CLIPPED) && (dot > tp->clip || dot < -tp->clip))
+                    continue;
                 if (dot > tp->clip) dot = tp->clip;
                 if (dot < -tp->clip) dot = -tp->clip;
                 float var = (label - sigmoidf(dot)) * lrc;

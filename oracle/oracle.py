@@ -19,6 +19,9 @@ SENTINEL = 0xFFFFFFFF
 FLAG_SCALE_FREE = 1
 FLAG_DOWNSAMPLE = 2
 FLAG_NORM_LR = 4
+# oracle-only variants of two semantic readings (gn2v_oracle.c O_FLAG_SKIP_CLIPPED / _SHARED_NEGATIVES)
+FLAG_SKIP_CLIPPED = 256
+FLAG_SHARED_NEGATIVES = 512
 
 
 class WalkParams(C.Structure):

@@ -85,6 +85,27 @@ def test_automatic_plan_of_the_block_path():
             assert world == 1 or parts >= 2 * world
             if parts > (1 if world == 1 else 2 * world) and parts * slices < 8192 - 8 * world:
                 assert 32768 <= n // (parts * slices) < 2 * 32768 * (world + 1)
+    # one GPU, the row width known (ld <= 128 floats): RESIDENT CELLS -- every cell fits one
+    # workgroup's LDS (160 KB minus the sixteen waves' staging) -- up to ~1.5 M nodes at d = 128
+    def rows(n, parts, slices):
+        return -(-(-(-n // parts)) // slices)  # the largest cell: ceil(ceil(n / parts) / slices)
+
+    assert auto_plan(2_559, 1, 128, 10) == (1, 1)  # below the block path's limit: atomics
+    assert auto_plan(2_708, 1, 128, 10) == (1, 42)       # config 2's shape: cells of 65 rows
+    assert auto_plan(169_343, 1, 128, 10) == (4, 256)    # config 3's shape: cells of 166 rows
+    assert auto_plan(2_449_029, 1, 128, 10) == (9, 8)    # too many rows for 8 192 cells: XCD cells
+    assert auto_plan(1_000_000, 1, 256, 10) == (3, 8)    # rows too wide for the resident kernel
+    assert auto_plan(1_000_000, 2, 128, 10) == auto_plan(1_000_000, 2)  # several ranks: XCD cells
+    for n in (2_560, 10_000, 100_000, 1_000_000, 1_500_000):
+        for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40)):
+            parts, slices = auto_plan(n, 1, ld, k)
+            staging = 16 * 4 * ((ld + 3 * 32 + 2 * 32 * (k + 1) + 2 + 3) // 4 * 4) + 64
+            fit = (160 * 1024 - staging) // (ld * 4)
+            if slices > 8:
+                assert parts * slices <= 8192 and slices <= 256
+                assert rows(n, parts, slices) <= fit, (n, ld, k, parts, slices)
+            else:
+                assert (parts, slices) == auto_plan(n, 1)  # did not fit: the XCD plan
 
 
 def test_round_size_and_groups_follow_the_free_memory():

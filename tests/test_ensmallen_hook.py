@@ -76,3 +76,56 @@ def test_embeddings_agree_statistically_with_ensmallen():
         assert hits > 0.8, hits
     overlap = np.mean([len(set(a) & set(b)) / 5 for a, b in zip(_topk(rc), _topk(mine[0]))])
     assert overlap > 0.5, overlap
+
+
+@pytest.mark.gpu
+def test_report_what_the_three_semantic_choices_change_against_ensmallen():
+    """DESIGN.md 1.1 decides three readings the reference's text leaves open.  With the wheel at
+    hand this PRINTS (it gates nothing) how far each alternative sits from ensmallen's own fit of
+    the same graph and kwargs -- what a maintainer should look at first:
+      * negatives drawn inside the context's cell (the block path, graphs >= 2 560 nodes) vs
+        over the whole graph (the walk-ordered kernels);
+      * dot product clamped at clipping_value vs the update skipped beyond it;
+      * k fresh negatives per pair vs one draw per centre reused for all its contexts.
+    The last two exist in the oracle only (O.FLAG_SKIP_CLIPPED / O.FLAG_SHARED_NEGATIVES)."""
+    import embiggen_amd as E
+    from oracle import oracle as O
+
+    src, dst, n = _ring_of_cliques(400, 8)  # 3 200 nodes: the default fit takes the block path
+    names = [str(i) for i in range(n)]
+    ref_graph = ensmallen.Graph.from_pd(
+        edges_df=__import__("pandas").DataFrame({"s": [names[i] for i in src],
+                                                 "d": [names[i] for i in dst]}),
+        edge_src_column="s", edge_dst_column="d", directed=False, name="ring_of_cliques")
+    ref = ensmallen.models.SkipGram(random_state=42, **KW).fit_transform(ref_graph)
+    order = np.argsort([int(x) for x in ref_graph.get_node_names()])
+    rc, rx = np.asarray(ref[0])[order], np.asarray(ref[1])[order]
+    g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=n)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    wp = O.WalkParams(KW["walk_length"], KW["iterations"], 1.0, 1.0, 100, 0)
+
+    def oracle_fit(extra):
+        tp = O.TrainParams(0, 32, 32, KW["epochs"], 5, 4, KW["learning_rate"], 0.9, 6.0,
+                           O.FLAG_SCALE_FREE | extra, 32 ** -0.5)
+        c, x, _ = O.fit(og, wp, tp, 42, threads=8)
+        return c, x
+
+    fits = {
+        "engine, block path (cell-local negatives)":
+            E.models.SkipGram(random_state=42, verbose=False, **KW).fit_transform(g),
+        "engine, walk-ordered (global negatives)":
+            E.models.SkipGram(random_state=42, verbose=False, update_mode="write_through",
+                              **KW).fit_transform(g),
+        "oracle as shipped (clamp, per-pair negatives)": oracle_fit(0),
+        "oracle, update skipped beyond the clipping value": oracle_fit(O.FLAG_SKIP_CLIPPED),
+        "oracle, one negative draw per centre": oracle_fit(O.FLAG_SHARED_NEGATIVES),
+    }
+    auc_ref = _auc((src, dst), n, rc, rx, np.random.RandomState(0))
+    print(f"ensmallen: link AUROC {auc_ref:.4f}")
+    ref_top = _topk(rc)
+    for name, (c, x) in fits.items():
+        auc = _auc((src, dst), n, c, x, np.random.RandomState(0))
+        overlap = np.mean([len(set(a) & set(b)) / 5 for a, b in zip(ref_top, _topk(c))])
+        norm = float(np.linalg.norm(c, axis=1).mean() / np.linalg.norm(rc, axis=1).mean())
+        print(f"{name}: link AUROC {auc:.4f}, top-5 neighbour overlap with ensmallen "
+              f"{overlap:.3f}, mean |central row| / ensmallen's {norm:.3f}")

@@ -77,7 +77,7 @@ def test_default_fit_agrees_with_the_oracles_hogwild_fit_on_the_same_walks(shape
               learning_rate=0.01, random_state=42, verbose=False)
     fast = models.SkipGram(**kw)
     c, _, st = fast.fit_transform_device(g)
-    assert fast.last_plan is not None and fast.last_plan["slices"] == 8  # the block path
+    assert fast.last_plan is not None and fast.last_plan["slices"] > 8  # resident cells
     og = O.OracleGraph(host.row_ptr, host.col_idx)
     threads = min(16, len(os.sched_getaffinity(0)))
     rc, _, pairs = O.fit(og, O.WalkParams(L, 1, rw, ew, 100, 0),
@@ -112,13 +112,13 @@ def test_default_schedule_against_the_sequential_restatement_of_the_same_schedul
             tp = ops.train_params(0, d, k, w, flags=1, ld=d)
             tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
                                          walk_length=L, window=w)
-            assert (tr.parts, tr.slices) == (1, 8)
+            assert (tr.parts, tr.slices) == (1, 42)  # resident cells of 65 rows
             tr.train_round(wk, 42, 0, lr, 0)
         else:
             tp = O.TrainParams(0, d, d, 1, k, w, lr, 0.9, 6.0, 1, d ** -0.5)
             tr = BlockPartitionedTrainer(host, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cpu",
                                          walk_length=L, window=w, backend=OracleBlockBackend(host),
-                                         parts=1, slices=8)
+                                         parts=1, slices=42)
             tr.train_round(wk.cpu(), 42, 0, lr, 0)
         c, x = tr.gather_full()
         tables[name] = (c.cpu().numpy(), x.cpu().numpy())

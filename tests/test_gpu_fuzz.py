@@ -218,7 +218,7 @@ def block_path_moves(g, kw):
     fast, strict = models.SkipGram(**kw), models.SkipGram(deterministic=True, **kw)
     c1, x1, st1 = fast.fit_transform_device(g)
     c0, x0, st0 = strict.fit_transform_device(g)
-    assert fast.last_plan is not None and fast.last_plan["slices"] == 8 and strict.last_plan is None
+    assert fast.last_plan is not None and fast.last_plan["slices"] >= 8 and strict.last_plan is None
     d, ld = kw["embedding_size"], fast.padded_size
     init_c = ops.init_table(n, d, kw["random_state"], 0, d ** -0.5, ld=ld)
     init_x = ops.init_table(n, d, kw["random_state"], 1, d ** -0.5, ld=ld)
