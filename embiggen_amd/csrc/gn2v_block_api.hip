@@ -85,7 +85,8 @@ uint32_t resident_rows(uint32_t ld, uint32_t record, uint32_t k) {
     if (ld == 0 || ld > 128) return 0;
     const size_t staging = block_lds_words_per_wave(ld, record, k) * 4 * 16 + 64;
     const size_t lds = 160 * 1024;
-    return staging >= lds ? 0 : (uint32_t)std::min<size_t>((lds - staging) / ((size_t)ld * 4), 4096);
+    return staging >= lds ? 0
+                          : (uint32_t)std::min<size_t>((lds - staging) / ((size_t)ld * 4), 4096);
 }
 
 size_t env_size(const char *name, size_t fallback) {
@@ -467,6 +468,17 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     // wavefronts meet on the same few rows: exclusive slices divide that crowd by the XCDs and
     // keep it inside one L2, which is why they need no atomics from GN2V_BLOCK_PATH_MIN_NODES up).
     const bool exclusive = slices_are_xcd_exclusive(g, d.slices);
+    // Resident cells (block_kernels.h sgns_resident_kernel): every cell of the plan fits one
+    // workgroup's LDS -- what gn2v_block_auto_plan arranges for graphs up to ~1.5 M nodes at
+    // d = 128.  One workgroup per cell, contextual rows read and updated in LDS: exact, whatever
+    // the size of the graph (no flavour of store or atomic is involved).
+    static const size_t resident_env = env_size("GN2V_BLOCK_RESIDENT", 1);  // 0: never (A/B)
+    const uint64_t max_cell_rows =
+        gn2v::stripe_count(gn2v::stripe_count(g->view.n_nodes, 0, d.parts), 0, d.slices);
+    const bool resident =
+        !det && resident_env &&
+        !(tp->flags & (GN2V_TRAIN_ATOMIC | GN2V_TRAIN_WRITE_THROUGH | GN2V_TRAIN_WRITE_BACK)) &&
+        max_cell_rows <= resident_rows(tp->ld, d.record, tp->k);
     int wmc = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
               : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
               : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
@@ -491,15 +503,6 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     // when even T = 1 does not, the rows stay ordinary rows (plain stores lose updates on hub rows
     // -- which is also what keeps them stable at any learning rate).
     const bool stores = !det && wmx != gn2v::kAtomic;
-    // Resident cells (block_kernels.h sgns_resident_kernel): every cell of the plan fits one
-    // workgroup's LDS -- what gn2v_block_auto_plan arranges for graphs up to ~1.5 M nodes at
-    // d = 128.  One workgroup per cell, contextual rows read and updated in LDS: exact.
-    static const size_t resident_env = env_size("GN2V_BLOCK_RESIDENT", 1);  // 0: never (A/B)
-    const uint64_t max_cell_rows =
-        gn2v::stripe_count(gn2v::stripe_count(g->view.n_nodes, 0, d.parts), 0, d.slices);
-    const bool resident = stores && resident_env && wmc != gn2v::kWriteBack &&
-                          !(tp->flags & (GN2V_TRAIN_WRITE_THROUGH | GN2V_TRAIN_WRITE_BACK)) &&
-                          max_cell_rows <= resident_rows(tp->ld, d.record, tp->k);
     if (d.slices > gn2v_host::kCursorSlices && !resident)
         return fail("more than 16 slices need cells that fit a workgroup's LDS (default update "
                     "mode, rows up to 128 floats)");
@@ -619,17 +622,19 @@ int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t
                          uint32_t *parts, uint32_t *slices) {
     if (!parts || !slices || world < 1) return fail("bad arguments");
     constexpr uint64_t kMinRows = 32768, kXcds = 8;
-    // One GPU, rows up to 128 floats, a graph small enough for cells that fit a workgroup's LDS
-    // (8 192 cells x ~200 rows at d = 128: 1.6 M nodes): RESIDENT CELLS -- every contextual row
-    // is read and updated in the LDS of the one workgroup that owns its cell, exactly
-    // (sgns_resident_kernel).  As few cells as hold the rows, but 256 when the graph allows
-    // cells of 64 rows (a launch covers a part: one workgroup per cell and CU), up to 256
-    // slices per part.
-    const uint64_t fit = world == 1 && n_nodes >= GN2V_BLOCK_PATH_MIN_NODES
+    // One GPU, rows up to 128 floats, a graph of GN2V_RESIDENT_MIN_NODES nodes or more that is
+    // small enough for cells that fit a workgroup's LDS (8 192 cells x ~200 rows at d = 128: 1.5 M
+    // nodes): RESIDENT CELLS -- every contextual row is read and updated in the LDS of the one
+    // workgroup that owns its cell (sgns_resident_kernel).  As few cells as hold the rows, up to
+    // 256 slices per part (a launch covers a part: one workgroup per cell and CU).  Smaller
+    // graphs keep the XCD cells: with cells of ~200 rows the cosine of the central vectors of a
+    // CONVERGED fit separates edges from random pairs less well (link AUROC 0.978 vs 0.996 at
+    // 2 708 nodes, 0.994 vs 0.998 at 20 k; equal from 200 k nodes, 0.956 vs 0.920 at 1 M after
+    // three epochs: DESIGN.md 7.3) -- the negatives of a pair come from its context's cell.
+    const uint64_t fit = world == 1 && n_nodes >= GN2V_RESIDENT_MIN_NODES
                              ? resident_rows(ld, 32, k) : 0;
     if (fit >= 16 && n_nodes <= fit * (gn2v::kMaxCells - 512)) {
-        uint64_t cells = (n_nodes + fit - 1) / fit;
-        if (cells < 256) cells = std::min<uint64_t>(256, std::max<uint64_t>(cells, n_nodes / 64));
+        const uint64_t cells = (n_nodes + fit - 1) / fit;
         uint64_t sl = std::min<uint64_t>(cells, kMaxSlices), p = (cells + sl - 1) / sl;
         // striping rounds up twice: make sure the largest cell fits
         while (gn2v::stripe_count(gn2v::stripe_count(n_nodes, 0, p), 0, sl) > fit) ++p;

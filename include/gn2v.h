@@ -348,16 +348,17 @@ int gn2v_graph_xcds(gn2v_graph *g);
 
 /* (parts, slices) of the contextual table for a graph of n_nodes on `world` ranks.
  * One GPU, row stride ld <= 128 floats (ld = 0: unknown, this rule is skipped), k negatives, a
- * graph of up to ~1.5 M nodes (d = 128): RESIDENT CELLS -- cells of at most the ~200 rows that fit
- * one workgroup's LDS beside its staging, up to GN2V_BLOCK_MAX_SLICES slices per part (a launch =
- * a part = one workgroup per cell), as many parts as needed (2 708 nodes: 1 x 42 cells of 65
- * rows; 169 k: 4 x 256; 1 M: 20 x 256).  gn2v_block_step then reads and updates every contextual
- * row in LDS: exact accumulation, nothing races.
+ * graph of GN2V_RESIDENT_MIN_NODES up to ~1.5 M nodes (d = 128): RESIDENT CELLS -- cells of at most
+ * the ~200 rows that fit one workgroup's LDS beside its staging, up to GN2V_BLOCK_MAX_SLICES
+ * slices per part (a launch = a part = one workgroup per cell), as many parts as needed (169 k
+ * nodes: 4 x 256 cells of 166 rows; 1 M: 20 x 256).  gn2v_block_step then reads and updates every
+ * contextual row in the LDS of the one workgroup that owns it: no other CU races for it.
  * Otherwise XCD CELLS: slices = 8 (one per XCD; 1 on graphs too small to keep 8 192 rows in a
  * cell) and as many parts (any count; a multiple of world, at least two per rank) as keep
  * >= 32 768 rows in a cell -- the size from which the link quality of racing stores is at or above
  * the walk-ordered schedule's: 10 M nodes -> 38 x 8, 100 M -> 381 x 8. */
 #define GN2V_BLOCK_MAX_SLICES 256u
+#define GN2V_RESIDENT_MIN_NODES 100000u
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
                          uint32_t *parts, uint32_t *slices);
 

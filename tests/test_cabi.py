@@ -91,12 +91,13 @@ def test_automatic_plan_of_the_block_path():
         return -(-(-(-n // parts)) // slices)  # the largest cell: ceil(ceil(n / parts) / slices)
 
     assert auto_plan(2_559, 1, 128, 10) == (1, 1)  # below the block path's limit: atomics
-    assert auto_plan(2_708, 1, 128, 10) == (1, 42)       # config 2's shape: cells of 65 rows
+    assert auto_plan(2_708, 1, 128, 10) == (1, 8)        # below GN2V_RESIDENT_MIN_NODES: XCD cells
+    assert auto_plan(99_999, 1, 128, 10) == (1, 8) and auto_plan(100_000, 1, 128, 10) == (2, 256)
     assert auto_plan(169_343, 1, 128, 10) == (4, 256)    # config 3's shape: cells of 166 rows
     assert auto_plan(2_449_029, 1, 128, 10) == (9, 8)    # too many rows for 8 192 cells: XCD cells
     assert auto_plan(1_000_000, 1, 256, 10) == (3, 8)    # rows too wide for the resident kernel
     assert auto_plan(1_000_000, 2, 128, 10) == auto_plan(1_000_000, 2)  # several ranks: XCD cells
-    for n in (2_560, 10_000, 100_000, 1_000_000, 1_500_000):
+    for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000):
         for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40)):
             parts, slices = auto_plan(n, 1, ld, k)
             staging = 16 * 4 * ((ld + 3 * 32 + 2 * 32 * (k + 1) + 2 + 3) // 4 * 4) + 64

@@ -574,7 +574,7 @@ def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
 
 def test_bad_plans_are_refused(karate):
     for kw in (dict(world=2, rank=2, parts=4), dict(world=2, rank=0, parts=0),
-               dict(world=1, rank=0, parts=1, slices=17), dict(world=1, rank=0, parts=9000),
+               dict(world=1, rank=0, parts=1, slices=257), dict(world=1, rank=0, parts=9000),
                dict(world=1, rank=0, parts=1, record=33), dict(world=1, rank=0, parts=1, hot_rows=193),
                dict(world=1, rank=0, parts=1, hot_rows=4, hot_flush=12)):
         args = dict(slices=1, walk_length=8, window=2)
@@ -930,8 +930,10 @@ def test_negatives_keep_their_degree_proportional_law_through_the_cells():
     n_walks = 1 << 20
     lr = 1e-9  # scores stay below 1e-4: sigmoid = 1/2 to 3e-5, the order of the updates is moot
     tp = ops.train_params(0, d, k, w, lr=lr, flags=1 | _lib.TRAIN_ATOMIC, ld=d)
+    # XCD cells named explicitly (rows of 8 floats would make resident cells of 4 096 rows; the
+    # exact counting below needs atomics on every row, which those do not offer)
     tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
-                                 walk_length=L, window=w)
+                                 walk_length=L, window=w, parts=3, slices=8)
     assert (tr.parts, tr.slices) == (3, 8)
     u = d ** -0.5
     tr.central.fill_(u)

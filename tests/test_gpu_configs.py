@@ -133,11 +133,11 @@ def block_path_properties(g, n_walks, plan, d=128, return_weight=0.25, explore_w
 
 
 def test_config3_arxiv_shaped_block_path_full_size_properties():
-    """BASELINE config 3's shape (169 343 nodes, p = 0.5 / q = 2): the plan is 1 part x 8 slices
-    -- one slice per XCD; round 2 shipped 1 x 4 here, with write-back stores on rows that two
-    XCDs shared."""
+    """BASELINE config 3's shape (169 343 nodes, p = 0.5 / q = 2): resident cells since round 4
+    -- 4 parts x 256 cells of 166 rows, each trained by one workgroup in its LDS (rounds 2-3: 1 x 8
+    XCD cells, racing stores)."""
     g = E.barabasi_albert(169_343, 7, 42, name="BA-shaped-like-ogbn-arxiv")
-    block_path_properties(g, 1 << 15, {"parts": 1, "slices": 8}, return_weight=2.0,
+    block_path_properties(g, 1 << 15, {"parts": 4, "slices": 256}, return_weight=2.0,
                           explore_weight=0.5)
 
 
@@ -250,7 +250,8 @@ def test_large_graphs_are_fitted_through_the_block_path_on_one_gpu():
     assert res[0].shape == (400_000, 32) and res[1].shape == (400_000, 32)
     assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
     plan = m._model.last_plan  # gn2v_train's own choice
-    assert (plan["world"], plan["parts"], plan["slices"], plan["stripes"]) == (1, 1, 8, 1)
+    # rows of 32 floats: 861 fit a workgroup's LDS -> resident cells, 2 parts x 256
+    assert (plan["world"], plan["parts"], plan["slices"], plan["stripes"]) == (1, 2, 256, 1)
     assert m.get_last_stats()["pairs"] == 400_000 * (2 * 3 * 32 - 3 * 4)
     init = ops.init_table(400_000, 32, 42, 0, 32 ** -0.5).cpu().numpy()
     assert np.abs(res[0] - init).max() > 1e-3

@@ -77,7 +77,9 @@ def test_default_fit_agrees_with_the_oracles_hogwild_fit_on_the_same_walks(shape
               learning_rate=0.01, random_state=42, verbose=False)
     fast = models.SkipGram(**kw)
     c, _, st = fast.fit_transform_device(g)
-    assert fast.last_plan is not None and fast.last_plan["slices"] > 8  # resident cells
+    # the block path: XCD cells at config 2's size, resident cells (LDS) at config 3's
+    assert fast.last_plan is not None
+    assert (fast.last_plan["slices"] > 8) == (nodes >= 100_000), fast.last_plan
     og = O.OracleGraph(host.row_ptr, host.col_idx)
     threads = min(16, len(os.sched_getaffinity(0)))
     rc, _, pairs = O.fit(og, O.WalkParams(L, 1, rw, ew, 100, 0),
@@ -96,12 +98,16 @@ def test_default_fit_agrees_with_the_oracles_hogwild_fit_on_the_same_walks(shape
 
 
 @pytest.mark.timeout(900)
-def test_default_schedule_against_the_sequential_restatement_of_the_same_schedule():
-    """Config 2's shape through the trainer: the GPU's parallel default and the oracle's
-    sequential restatement of the block schedule train the SAME pairs with the SAME negatives
-    (one round, 1 x 8 cells); they differ by what parallel execution does to the order of the
-    updates (and by nothing a lost update could hide: the tables must have moved equally far)."""
-    nodes, m, L, rw, ew = SHAPES["config2_cora_shape"]
+@pytest.mark.parametrize("cells,nodes,m,L,plan", [("xcd", 2_708, 2, 128, (1, 8)),
+                                                  ("resident", 20_000, 5, 32, (1, 99))])
+def test_default_schedule_against_the_sequential_restatement_of_the_same_schedule(cells, nodes, m,
+                                                                                  L, plan):
+    """The GPU's parallel default and the oracle's sequential restatement of the block schedule
+    train the SAME pairs with the SAME negatives (one round); they differ by what parallel
+    execution does to the order of the updates -- and by what racing stores lose.  XCD cells at
+    config 2's shape (1 x 8 cells of 338 rows, the 100 hottest of each in LDS copies); resident
+    cells (1 x 99 cells of 203 rows, each owned by one workgroup) on a 20 k-node graph."""
+    rw = ew = 1.0
     g = E.barabasi_albert(nodes, m, 42)
     host = g  # row_ptr / col_idx come to the host on first use
     d, w, k, lr = 128, 5, 10, 0.01
@@ -111,14 +117,13 @@ def test_default_schedule_against_the_sequential_restatement_of_the_same_schedul
         if name == "gpu":
             tp = ops.train_params(0, d, k, w, flags=1, ld=d)
             tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
-                                         walk_length=L, window=w)
-            assert (tr.parts, tr.slices) == (1, 42)  # resident cells of 65 rows
+                                         walk_length=L, window=w, parts=plan[0], slices=plan[1])
             tr.train_round(wk, 42, 0, lr, 0)
         else:
             tp = O.TrainParams(0, d, d, 1, k, w, lr, 0.9, 6.0, 1, d ** -0.5)
             tr = BlockPartitionedTrainer(host, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cpu",
                                          walk_length=L, window=w, backend=OracleBlockBackend(host),
-                                         parts=1, slices=42)
+                                         parts=plan[0], slices=plan[1])
             tr.train_round(wk.cpu(), 42, 0, lr, 0)
         c, x = tr.gather_full()
         tables[name] = (c.cpu().numpy(), x.cpu().numpy())
@@ -130,13 +135,18 @@ def test_default_schedule_against_the_sequential_restatement_of_the_same_schedul
         report[label] = dict(moved=float(np.linalg.norm(got - init) / np.linalg.norm(want - init)),
                              **_agreement(host, got, want, 50_000))
     print("parallel default vs sequential restatement of the block schedule:", report)
-    # measured (round 4): central moved 1.04 x / Spearman 0.94, contextual 0.69 x / 0.93: the
-    # 100 hottest rows of each cell are exact (LDS copies), the other rows of a 338-row cell lose
-    # updates to one another's racing stores
+    # measured (round 4).  XCD cells at 2 708 nodes: central moved 1.04 x / Spearman 0.94,
+    # contextual 0.69 x / 0.93 -- the 100 hottest rows of each cell are exact (LDS copies), the
+    # other rows of a 338-row cell lose updates to one another's racing stores (an exact
+    # accumulation in the same parallel order moves the contextual table 0.91 x: that is the
+    # order, not a loss).  Resident cells: contextual 0.85 x at 2 708 nodes in 42 cells
     assert 0.9 <= report["central"]["moved"] <= 1.1, report
-    assert 0.6 <= report["contextual"]["moved"] <= 1.1, report
+    assert (0.8 if cells == "resident" else 0.6) <= report["contextual"]["moved"] <= 1.1, report
+    # (the 20 k-node case trains walks of 32 nodes only: the cosines are still close to their
+    # random start -- mean |d cos| 0.02-0.04 -- and rank less alike: Spearman 0.87-0.90)
     for label, r in report.items():
-        assert r["spearman"] >= 0.9 and r["mean_abs"] <= 0.12, report
+        assert r["spearman"] >= (0.85 if cells == "resident" else 0.9), report
+        assert r["mean_abs"] <= 0.12, report
 
 
 def _central_store_losses(pairs_per_centre_and_cell, n_centres=60_000, d=128):
