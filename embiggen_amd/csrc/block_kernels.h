@@ -395,6 +395,7 @@ struct BlockArgs {
                              // adding the gradient with atomics (GN2V_TRAIN_CENTRAL_STORE)
     uint32_t hot_n;      // hot slots the LDS of this launch holds (0: hot rows are ordinary rows)
     uint32_t hot_mask;   // a slot's pending sum goes to its row after ~hot_mask + 1 updates (2^j - 1)
+    uint32_t reread;     // 1: a row is read a second time right before its stores (small graphs)
     uint32_t k, ld, flags;
     float lr, clip;
 };
@@ -603,7 +604,30 @@ __device__ __forceinline__ void score_sample(const BlockArgs &a, const HotLds &h
             hot_hand_over<CH, true>(hb, dl, h.lock + (row & 0xFFu),
                                     sample_base(a, a.context, h.grow[row & 0xFFu]), q, h.ld);
     } else if (cold) {
-        scatter_add<CH, WMX>(base, q, nchunks, var, u, v);
+        if (a.reread) {
+            // Small graphs (the tables live in the L2s): add var * u to the row AS IT IS NOW --
+            // read again past the CU's L1 right before the stores -- instead of to the copy that
+            // was scored: an update of another wave is lost only when it lands between that
+            // second read (an L2 hit) and the stores, not anywhere in the memory round trip and
+            // the scoring.  One more L2 read per sample row: nothing where HBM is not the bound.
+            Row<CH> w;
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc) {
+                const uint32_t ci = cc * 16 + q;
+                if (ci < nchunks) {
+                    f32x4 r;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(base + ci * 4)
+                                 : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory");
+                    w.c[cc] = make_float4(r.x, r.y, r.z, r.w);
+                } else {
+                    w.c[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            scatter_add<CH, WMX>(base, q, nchunks, var, u, w);
+        } else {
+            scatter_add<CH, WMX>(base, q, nchunks, var, u, v);
+        }
     }
 }
 

@@ -490,6 +490,12 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     if (wmc == gn2v::kWriteThrough && exclusive) wmx = gn2v::kWriteBack;
     a.xcds = (uint32_t)g->n_xcds;
     a.central_store = (tp->flags & GN2V_TRAIN_CENTRAL_STORE) ? 1u : 0u;
+    // graphs whose contextual table lives in the L2s (and in the Infinity Cache): the second read
+    // of a row right before its stores costs no HBM traffic and shrinks the window in which a
+    // racing store is lost (block_kernels.h score_sample); GN2V_BLOCK_REREAD=0 / 1 overrides
+    static const size_t reread_env = env_size("GN2V_BLOCK_REREAD", 2);
+    a.reread = reread_env == 2 ? ((uint64_t)g->view.n_nodes * tp->ld * 4 <= (64ull << 20) ? 1u : 0u)
+                               : (uint32_t)reread_env;
 
     // Hot rows (block_kernels.h "hot rows"): only with ONE workgroup of sixteen waves per CU --
     // rows up to 128 floats, store flavours, central rows by atomics -- whose waves share one set

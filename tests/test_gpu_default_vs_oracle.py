@@ -88,10 +88,11 @@ def test_default_fit_agrees_with_the_oracles_hogwild_fit_on_the_same_walks(shape
     assert st["pairs"] == pairs
     res = _agreement(host, c.cpu().numpy()[:, :128], rc[:, :128])
     print(f"{shape}: default GPU fit vs oracle Hogwild ({threads} threads), {pairs} pairs: {res}")
-    # measured (round 4): config 2's shape Spearman 0.96, mean |d cos| 0.086, AUROC 0.967 vs
+    # measured (round 4): config 2's shape Spearman 0.96, mean |d cos| 0.078, AUROC 0.968 vs
     # 0.987 -- after ONE walk per node the 2 708-node fit is behind the CPU's: 8 x 2 000 row
-    # updates in flight on 2 708 contextual rows lose what the rows outside the LDS copies
-    # receive at the same moment; config 3's shape agrees far better
+    # updates in flight on 2 708 contextual rows lose part of what the rows outside the LDS
+    # copies receive at the same moment (converged fits agree: 0.9950 vs 0.9961);
+    # config 3's shape (resident cells): mean |d cos| 0.034
     assert res["spearman"] >= 0.9, res
     assert res["mean_abs"] <= 0.12, res
     assert abs(res["auc_got"] - res["auc_want"]) <= 0.04, res
@@ -135,13 +136,14 @@ def test_default_schedule_against_the_sequential_restatement_of_the_same_schedul
         report[label] = dict(moved=float(np.linalg.norm(got - init) / np.linalg.norm(want - init)),
                              **_agreement(host, got, want, 50_000))
     print("parallel default vs sequential restatement of the block schedule:", report)
-    # measured (round 4).  XCD cells at 2 708 nodes: central moved 1.04 x / Spearman 0.94,
-    # contextual 0.69 x / 0.93 -- the 100 hottest rows of each cell are exact (LDS copies), the
-    # other rows of a 338-row cell lose updates to one another's racing stores (an exact
-    # accumulation in the same parallel order moves the contextual table 0.91 x: that is the
-    # order, not a loss).  Resident cells: contextual 0.85 x at 2 708 nodes in 42 cells
+    # measured (round 4).  XCD cells at 2 708 nodes: central moved 1.03 x / Spearman 0.94,
+    # contextual 0.83 x / 0.93 -- the 100 hottest rows of each cell are exact (LDS copies), the
+    # other rows of a 338-row cell lose some updates to one another's racing stores (0.69 x
+    # before a row was read again right before its stores; an exact accumulation in the same
+    # parallel order moves the contextual table 0.91 x: that is the order, not a loss).
+    # Resident cells: 0.87 x on the 20 k-node graph
     assert 0.9 <= report["central"]["moved"] <= 1.1, report
-    assert (0.8 if cells == "resident" else 0.6) <= report["contextual"]["moved"] <= 1.1, report
+    assert (0.8 if cells == "resident" else 0.75) <= report["contextual"]["moved"] <= 1.1, report
     # (the 20 k-node case trains walks of 32 nodes only: the cosines are still close to their
     # random start -- mean |d cos| 0.02-0.04 -- and rank less alike: Spearman 0.87-0.90)
     for label, r in report.items():

@@ -233,16 +233,18 @@ def test_random_default_fit_on_the_block_path_does_the_work_of_the_strict_one(ca
     the context's cell) against the strict walk-ordered schedule on the same random graph and
     parameters: the same number of training pairs, finite tables, a change from the initial
     tables of the same size (the samples differ, so the tables do not agree element by element;
-    measured ratios 0.79-0.94 for the central and 0.55-0.90 for the contextual table, whose racing
-    stores inside an XCD lose some updates), and rows of nodes no walk visits and no negative can
-    hit left exactly as initialised."""
+    measured ratios, round 4: 0.97-1.01 for the central and 0.94-1.00 for the contextual table --
+    rounds 2-3: 0.79-0.94 and 0.55-0.90, when the racing stores inside an XCD lost more: since
+    then the hot rows of a cell accumulate in LDS, every central update is an atomic add, and on
+    graphs this small a row is read again right before its stores), and rows of nodes no walk
+    visits and no negative can hit left exactly as initialised."""
     g, kw = block_path_case(case)
     n = g.get_number_of_nodes()
     pairs_fast, pairs_strict, moves, (c1, x1, init_c, init_x) = block_path_moves(g, kw)
     assert pairs_fast == pairs_strict  # 0 when min_distance exceeds what a walk of L nodes holds
     assert bool(torch.isfinite(c1).all()) and bool(torch.isfinite(x1).all())
     for moved, should in moves:
-        assert 0.4 * should <= moved <= 2.0 * should, (moved, should)
+        assert 0.8 * should <= moved <= 1.25 * should, (moved, should)
         assert (pairs_strict == 0) == (moved == 0.0)
     # nodes that start no walk and that no edge points to: never a centre, a context or a negative
     indeg = np.bincount(g.col_idx, minlength=n)
