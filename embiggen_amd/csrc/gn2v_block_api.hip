@@ -541,7 +541,11 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     }
     static const size_t wide_env = env_size("GN2V_BLOCK_WIDE", 1);  // 0: never (A/B)
     const size_t per_wave_words = block_lds_words_per_wave(tp->ld, d.record, tp->k);
-    bool wide = stores && a.hot_list && d.hot_rows && wide_env && tp->ld <= 128 &&
+    // Not on graphs whose tables live in the L2s (a.reread): there a sample costs ~30 ns of a
+    // wave's time, and a hand-over -- a returning atomic's round trip -- costs a hundred of them
+    // (BA 2 708 nodes, 100 of a cell's 338 rows hot: 1.06e8 instead of 8.4e8 pairs/s); such graphs
+    // get the second read before the store instead.
+    bool wide = stores && a.hot_list && d.hot_rows && wide_env && tp->ld <= 128 && !a.reread &&
                 wmc != gn2v::kWriteBack && per_wave_words * 4 * 16 <= 96 * 1024;
     const uint64_t cus = (uint64_t)g->n_cus - (uint64_t)g->reserved_cus * std::max(1, g->n_xcds);
     uint32_t hot_period = 0;
@@ -573,7 +577,15 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     if (!det) {
         // at most one concurrent wave per table row on average (staleness of the records of one
         // centre trained from the same copy of its row; binds on tiny graphs only)
-        const uint64_t rows = g->view.n_nodes / d.parts;
+        // Graphs whose tables live in the L2s (a.reread) are not bandwidth bound: every wave more
+        // is one more racer on the same few rows.  One wave per FOUR rows there -- BA 2 708 nodes,
+        // 10 epochs: cosine-of-central AUROC 0.9937 at 3.0e8 pairs/s, against 0.9845 at 9.0e8 with
+        // a wave per row (atomics on every row: 0.9961 at 5.8e7); the contextual table moves 0.82
+        // instead of 0.61 x as far as the sequential schedule, the central one 0.98 instead of
+        // 1.10 x (overshoot: several runs of a centre in flight add gradients of one stale row).
+        static const size_t rows_env = env_size("GN2V_BLOCK_ROWS_PER_WAVE", 0);  // A/B
+        const size_t rows_per_wave = rows_env ? rows_env : a.reread ? 4 : 1;
+        const uint64_t rows = g->view.n_nodes / d.parts / rows_per_wave;
         const uint64_t max_blocks = std::max<uint64_t>(d.slices, rows / waves_per_block);
         if (blocks > max_blocks) blocks = max_blocks;
     }
