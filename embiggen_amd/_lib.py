@@ -44,7 +44,7 @@ EXPORTS = [
     "gn2v_touch_rows",
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
     "gn2v_block_alias", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
-    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_auto_plan", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
+    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_round", "gn2v_block_auto_plan", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
     "gn2v_train_blocks",
     "gn2v_stats_reset",
     "gn2v_stats_read",
@@ -127,6 +127,33 @@ class BlockIO(C.Structure):
         ("context_ld", C.c_uint64),
     ]
 
+
+class BlockRoundIO(C.Structure):
+    """gn2v_block_round_io (include/gn2v.h)."""
+    _fields_ = [
+        ("d_walks", C.c_void_p),
+        ("d_alias", C.c_void_p),
+        ("d_cell_rows", C.c_void_p),
+        ("d_hub_bits", C.c_void_p),
+        ("d_hot_list", C.c_void_p),
+        ("d_hot_slot", C.c_void_p),
+        ("d_central", C.c_void_p),
+        ("context_parts", C.POINTER(C.c_void_p)),
+        ("context_ld", C.c_uint64),
+        ("d_work", C.c_void_p),
+        ("d_cell_offsets", C.c_void_p),
+        ("d_pairs", C.c_void_p),
+        ("pairs_capacity", C.c_uint64),
+        ("d_temp", C.c_void_p),
+        ("temp_bytes", C.c_uint64),
+        ("group_parts", C.c_uint32),
+        ("next_unit", C.c_uint32),
+        ("needed_pairs", C.c_uint64),
+        ("pairs_trained", C.c_uint64),
+    ]
+
+
+ROUND_GROW = 3  # GN2V_ROUND_GROW
 
 # include/gn2v_experimental.h: measured-and-rejected designs kept for their scripts and tests
 EXPERIMENTAL_EXPORTS = ["gn2v_step"]
@@ -243,6 +270,8 @@ def lib():
     L.gn2v_graph_reserve_cus.argtypes = [vp, u32, vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),
                                   C.POINTER(BlockIO), u64, u64, f32, vp]
+    L.gn2v_block_round.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan), u32,
+                                   C.POINTER(BlockRoundIO), u64, u64, u64, u64, f32, u64, vp]
     L.gn2v_block_auto_plan.argtypes = [u64, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
     L.gn2v_block_round_plan.argtypes = [u64, u64, u32, u32, u32, u32, u32, u32, C.POINTER(u64),
                                         C.POINTER(u32)]

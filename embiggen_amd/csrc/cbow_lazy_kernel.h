@@ -58,6 +58,22 @@
 
 namespace gn2v {
 
+// workgroups of 256 threads per CU the register cap of the instantiation for row stride ld
+// leaves room for (the __launch_bounds__ below)
+constexpr uint32_t lazy_min_blocks_ch(int ch, bool full) {
+    return ch <= 2   ? GN2V_CBOW_LAZY_MIN_BLOCKS
+           : ch == 4 ? (full ? GN2V_CBOW_LAZY_MIN_BLOCKS_CH4_FULL : GN2V_CBOW_LAZY_MIN_BLOCKS_CH4)
+           : ch == 8 ? GN2V_CBOW_LAZY_MIN_BLOCKS_CH8
+                     : GN2V_CBOW_LAZY_MIN_BLOCKS_CH16;
+}
+inline uint32_t lazy_min_blocks(uint32_t ld) {
+    const uint32_t nchunks = ld / 4;
+    const int ch = nchunks <= 16 ? 1 : nchunks <= 32 ? 2 : nchunks <= 64 ? 4 : nchunks <= 128 ? 8 : 16;
+    return lazy_min_blocks_ch(ch, ld == (uint32_t)ch * 64);
+}
+// the lazy window runs when a CU's LDS holds at least this many of its waves
+constexpr uint32_t kLazyMinWaves = 8;
+
 template <int CH>
 __device__ __forceinline__ void lds_load_row(Row<CH> &r, const float *base, int q,
                                              uint32_t nchunks) {
@@ -88,11 +104,7 @@ __device__ __forceinline__ void row_axpy(Row<CH> &acc, float s, const Row<CH> &x
 // FULL: the row stride is exactly CH * 64 floats (d = 128 -> CH = 2): ld becomes a compile-time
 // constant and the per-chunk bounds predicates fold away (fewer instructions, fewer SGPR masks).
 template <int CH, int WM, bool FULL = false>
-__global__ __launch_bounds__(kTrainBlock, (CH <= 2   ? GN2V_CBOW_LAZY_MIN_BLOCKS
-                                          : CH == 4 ? (FULL ? GN2V_CBOW_LAZY_MIN_BLOCKS_CH4_FULL
-                                                            : GN2V_CBOW_LAZY_MIN_BLOCKS_CH4)
-                                          : CH == 8 ? GN2V_CBOW_LAZY_MIN_BLOCKS_CH8
-                                                    : GN2V_CBOW_LAZY_MIN_BLOCKS_CH16)) void
+__global__ __launch_bounds__(kTrainBlock, lazy_min_blocks_ch(CH, FULL)) void
 cbow_lazy_kernel(TrainArgs a) {
     if constexpr (FULL) a.ld = CH * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];

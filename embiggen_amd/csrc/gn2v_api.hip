@@ -352,7 +352,37 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     const size_t lazy_words = ((size_t)(slots + 2) * tp->ld + L + 2 * (size_t)a.max_samples +
                                2 * tp->window + 3 * slots + 3) &
                               ~(size_t)3;
-    const size_t lazy_lds = (size_t)waves_per_block * lazy_words * 4;
+    // Its window takes (2 w + 3) rows of LDS per wave: wide rows and long windows leave a CU's
+    // 160 KB fewer waves than its registers would, and workgroups of four waves round that down
+    // once more (d = 128, w = 12: 59 KB per workgroup = 8 waves a CU; as single waves 10).  The
+    // workgroup is the 4 / 2 / 1 waves that put most waves on a CU; below kLazyMinWaves waves per
+    // CU the uncached kernel keeps the path (measured).
+    // GN2V_CBOW_LAZY_WAVES forces the workgroup, GN2V_CBOW_LAZY_MIN_WAVES the threshold (A/B).
+    static const long lazy_waves_env = [] {
+        const char *e = getenv("GN2V_CBOW_LAZY_WAVES");
+        return e ? atol(e) : 0L;
+    }();
+    static const long lazy_min_waves = [] {
+        const char *e = getenv("GN2V_CBOW_LAZY_MIN_WAVES");
+        return e ? atol(e) : (long)gn2v::kLazyMinWaves;
+    }();
+    uint32_t lazy_wpb = (uint32_t)waves_per_block, lazy_waves_cu = 0;
+    if (!det) {
+        // what the kernel's register cap allows (cbow_lazy_kernel.h, __launch_bounds__)
+        const uint32_t reg_waves = 4 * gn2v::lazy_min_blocks(tp->ld);
+        for (uint32_t wpb : {4u, 2u, 1u}) {
+            if (lazy_waves_env && (long)wpb != lazy_waves_env) continue;
+            const size_t wg = ((size_t)wpb * lazy_words * 4 + 1023) & ~(size_t)1023;
+            if (wg > 64 * 1024) continue;
+            const uint32_t waves =
+                std::min<uint32_t>((uint32_t)(160 * 1024 / wg) * wpb, reg_waves);
+            if (waves > lazy_waves_cu) {
+                lazy_waves_cu = waves;
+                lazy_wpb = wpb;
+            }
+        }
+    }
+    const size_t lazy_lds = (size_t)lazy_wpb * lazy_words * 4;
     // A/B switches, read once: GN2V_CBOW_LAZY=0 keeps cbow_cached_kernel, GN2V_BLOCK_NO_FULL=1 the
     // kernels that do not know the row stride at compile time
     static const bool lazy_off = [] {
@@ -360,8 +390,11 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
         return e && e[0] == '0';
     }();
     static const bool no_full = getenv("GN2V_BLOCK_NO_FULL") != nullptr;
-    const bool use_lazy =
-        cacheable && cbow && a.min_dist == 1 && lazy_lds <= lazy_budget && !lazy_off;
+    const bool use_lazy = cacheable && cbow && a.min_dist == 1 && lazy_lds <= lazy_budget &&
+                          (long)lazy_waves_cu >= lazy_min_waves && !lazy_off;
+    uint64_t lazy_blocks = (n_walks + lazy_wpb - 1) / lazy_wpb;
+    lazy_blocks = std::min<uint64_t>(lazy_blocks, (uint64_t)g->n_cus * 32 / lazy_wpb);
+    const dim3 lgrid((unsigned)std::max<uint64_t>(lazy_blocks, 1)), lblock(64 * lazy_wpb);
     const bool use_cache = use_lazy || (cacheable && cache_lds <= cache_budget);
     if (use_cache) {
         if (tp->flags & GN2V_TRAIN_CTX_CACHE_ALL) {
@@ -384,14 +417,14 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
 #define GN2V_CACHED(CH)                                                                        \
     do {                                                                                       \
         if (use_lazy && wm == gn2v::kWriteBack)                                                \
-            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteBack>), grid, block,    \
+            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteBack>), lgrid, lblock,  \
                                lazy_lds, s, a);                                                \
         else if (use_lazy && tp->ld == CH * 64 && !no_full)                                    \
-            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteThrough, true>), grid,  \
-                               block, lazy_lds, s, a);                                         \
+            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteThrough, true>), lgrid, \
+                               lblock, lazy_lds, s, a);                                        \
         else if (use_lazy)                                                                     \
-            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteThrough>), grid, block, \
-                               lazy_lds, s, a);                                                \
+            hipLaunchKernelGGL((gn2v::cbow_lazy_kernel<CH, gn2v::kWriteThrough>), lgrid,       \
+                               lblock, lazy_lds, s, a);                                        \
         else if (cbow && wm == gn2v::kWriteBack)                                               \
             hipLaunchKernelGGL((gn2v::cbow_cached_kernel<CH, gn2v::kWriteBack>), grid, block,  \
                                cache_lds, s, a);                                               \

@@ -716,6 +716,75 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     return 0;
 }
 
+int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plans,
+                     uint32_t stripes, gn2v_block_round_io *io, uint64_t n_walks, uint64_t seed,
+                     uint64_t epoch, uint64_t first_walk, float lr, uint64_t round_id,
+                     void *stream) {
+    if (!g || !tp || !plans || !io) return fail("NULL handle / params / plans / io");
+    if (stripes < 1 || stripes > 64) return fail("stripes must be in [1, 64]");
+    for (uint32_t j = 0; j < stripes; ++j) {
+        if (check_plan(g, &plans[j])) return 1;
+        if (plans[j].world != stripes || plans[j].rank != j || plans[j].parts != plans[0].parts ||
+            plans[j].slices != plans[0].slices)
+            return fail("plans[j] must be the plan of stripe j of `stripes` (world = stripes, "
+                        "rank = j, one geometry)");
+    }
+    if (!io->d_central || !io->context_parts || !io->d_work || !io->d_cell_offsets)
+        return fail("NULL pointer in the round's io");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t parts = plans[0].parts, cells = parts * plans[0].slices, ld = tp->ld;
+    const uint32_t gp = io->group_parts ? std::min(io->group_parts, parts) : parts;
+    const uint32_t groups = (parts + gp - 1) / gp;
+    if (io->next_unit > stripes * groups) return fail("next_unit beyond the round");
+    for (; io->next_unit < stripes * groups; ++io->next_unit) {
+        const uint32_t j = io->next_unit / groups, p0 = (io->next_unit % groups) * gp;
+        const uint32_t pn = std::min(gp, parts - p0);
+        const gn2v_block_plan *pj = &plans[j];
+        if (gn2v_block_count(g, pj, io->d_walks, n_walks, seed, epoch, first_walk, p0, pn,
+                             io->d_work, io->d_cell_offsets, s))
+            return 1;
+        uint64_t n_pairs = 0;  // the one host read of the group
+        HIP_TRY(hipMemcpyAsync(&n_pairs, io->d_cell_offsets + cells, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (n_pairs == 0) continue;
+        uint64_t need = 0;
+        gn2v_block_extract_temp_bytes(n_pairs, &need);
+        if (n_pairs > io->pairs_capacity || need > io->temp_bytes || !io->d_pairs || !io->d_temp) {
+            io->needed_pairs = n_pairs;
+            return GN2V_ROUND_GROW;
+        }
+        if (gn2v_block_extract(g, pj, io->d_walks, n_walks, seed, epoch, first_walk, p0, pn,
+                               io->d_work, io->d_hub_bits, n_pairs, io->d_pairs, io->d_temp,
+                               io->temp_bytes, s))
+            return 1;
+        for (uint32_t p = p0; p < p0 + pn; ++p) {
+            gn2v_block_io step{};
+            step.d_pairs = io->d_pairs;
+            step.d_cell_offsets = io->d_cell_offsets;
+            step.d_alias = io->d_alias;
+            step.d_cell_rows = io->d_cell_rows;
+            step.d_hot_list = io->d_hot_list;
+            step.d_hot_slot = io->d_hot_slot;
+            step.d_central = io->d_central + (size_t)j * ld;
+            step.central_ld = (uint64_t)stripes * ld;
+            step.d_context = io->context_parts[p];
+            step.context_ld = io->context_ld;
+            step.block_id = round_id * stripes + j;
+            step.part = p;
+            if (gn2v_block_step(g, tp, pj, &step, seed, epoch, lr, s)) return 1;
+        }
+        io->pairs_trained += n_pairs;
+        if (g->train_events.size() > 2048) {  // bound the event pool on long fits
+            HIP_TRY(hipStreamSynchronize(s));
+            gn2v_stats scratch;
+            if (gn2v_stats_read(g, &scratch, s)) return 1;
+        }
+    }
+    return 0;
+}
+
 // gn2v_train_blocks returns this (instead of 1) when it cannot run this fit -- device memory ran
 // out, or the walk / the sample list of a record does not fit the kernels' LDS plans -- before
 // anything was trained or initialised: gn2v_train then falls back to the walk-ordered schedule.
@@ -874,58 +943,50 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
                 return 1;
     }
 
+    std::vector<float *> part_rows(parts);
+    for (uint32_t p = 0; p < parts; ++p)
+        part_rows[p] = part_major ? d_contextual + first_row[p] * ld : d_contextual + (size_t)p * ld;
+    gn2v_block_round_io rio{};
+    rio.d_walks = walks;
+    rio.d_alias = alias;
+    rio.d_cell_rows = cell_rows;
+    rio.d_hub_bits = hub_bits;
+    rio.d_hot_list = hot_list;
+    rio.d_hot_slot = hot_slot;
+    rio.d_central = d_central;
+    rio.context_parts = part_rows.data();
+    rio.context_ld = part_major ? 0 : (uint64_t)parts * ld;
+    rio.d_work = work;
+    rio.d_cell_offsets = cell_offsets;
+    rio.d_pairs = pairs;
+    rio.pairs_capacity = cap;
+    rio.d_temp = tmp;
+    rio.temp_bytes = tb;
+    rio.group_parts = group_parts;
+
     float lr = tp->lr;
     uint64_t round_id = 0;
     for (uint32_t e = 0; e < tp->epochs; ++e) {
         for (uint64_t first = 0; first < walks_per_epoch; first += super_walks, ++round_id) {
             const uint64_t nw = std::min(super_walks, walks_per_epoch - first);
             if (gn2v_walks(g, wp, seed, e, first, nw, walks, s)) return 1;
-            for (uint32_t j = 0; j < V; ++j) {
-                const gn2v_block_plan *pj = &plans[j];
-                for (uint32_t p0 = 0; p0 < parts; p0 += group_parts) {
-                    const uint32_t pn = std::min(group_parts, parts - p0);
-                    if (gn2v_block_count(g, pj, walks, nw, seed, e, first, p0, pn, work,
-                                         cell_offsets, s))
-                        return 1;
-                    uint64_t n_pairs = 0;  // the one host read of the group
-                    HIP_TRY(hipMemcpyAsync(&n_pairs, cell_offsets + cells, 8,
-                                           hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    if (n_pairs == 0) continue;
-                    if (n_pairs > cap) {  // a group heavier than the head room allows: grow
-                        (void)hipFree(tmp);
-                        (void)hipFree(pairs);
-                        buf.ptrs.resize(buf.ptrs.size() - 2);
-                        cap = n_pairs + n_pairs / 16;
-                        gn2v_block_extract_temp_bytes(cap, &tb);
-                        if (buf.alloc(&pairs, cap * 8) || buf.alloc(&tmp, tb)) return 1;
-                    }
-                    if (gn2v_block_extract(g, pj, walks, nw, seed, e, first, p0, pn, work, hub_bits,
-                                           n_pairs, pairs, tmp, tb, s))
-                        return 1;
-                    for (uint32_t p = p0; p < p0 + pn; ++p) {
-                        gn2v_block_io io{};
-                        io.d_pairs = pairs;
-                        io.d_cell_offsets = cell_offsets;
-                        io.d_alias = alias;
-                        io.d_cell_rows = cell_rows;
-                        io.d_hot_list = hot_list;
-                        io.d_hot_slot = hot_slot;
-                        io.d_central = d_central + (size_t)j * ld;
-                        io.central_ld = (uint64_t)V * ld;
-                        io.d_context = part_major ? d_contextual + first_row[p] * ld
-                                                  : d_contextual + (size_t)p * ld;
-                        io.context_ld = part_major ? 0 : (uint64_t)parts * ld;
-                        io.block_id = round_id * V + j;
-                        io.part = p;
-                        if (gn2v_block_step(g, tp, pj, &io, seed, e, lr, s)) return 1;
-                    }
-                    if (g->train_events.size() > 2048) {  // bound the event pool on long fits
-                        HIP_TRY(hipStreamSynchronize(s));
-                        gn2v_stats scratch;
-                        if (gn2v_stats_read(g, &scratch, s)) return 1;
-                    }
-                }
+            rio.next_unit = 0;
+            for (;;) {
+                const int rc = gn2v_block_round(g, tp, plans.data(), V, &rio, nw, seed, e, first,
+                                                lr, round_id, s);
+                if (rc == 0) break;
+                if (rc != GN2V_ROUND_GROW) return 1;
+                // a group heavier than the head room allows: grow
+                (void)hipFree(tmp);
+                (void)hipFree(pairs);
+                buf.ptrs.resize(buf.ptrs.size() - 2);
+                cap = rio.needed_pairs + rio.needed_pairs / 16;
+                gn2v_block_extract_temp_bytes(cap, &tb);
+                if (buf.alloc(&pairs, cap * 8) || buf.alloc(&tmp, tb)) return 1;
+                rio.d_pairs = pairs;
+                rio.pairs_capacity = cap;
+                rio.d_temp = tmp;
+                rio.temp_bytes = tb;
             }
         }
         lr *= tp->lr_decay;

@@ -282,6 +282,68 @@ class GpuBlockBackend:
                   f"{torch.cuda.memory_reserved() / 1e9:.1f} GB", file=sys.stderr, flush=True)
         return pairs[:n_pairs], offsets, n_pairs
 
+    def round(self, tp, plans, walks, tables, central, part_rows, group_parts, capacity, seed,
+              epoch, first_walk, lr, round_id):
+        """A whole round on one GPU through the C round driver (``gn2v_block_round``: the loop
+        ``gn2v_train_blocks`` runs too -- one host loop orders the launches of a one-GPU fit):
+        every stripe in ``plans``, every group of ``group_parts`` parts: count, extract + sort,
+        one step per part.  ``tables``: (alias, cell_rows, hub_bits, hot_list, hot_slot) or
+        Nones; ``central``: the whole table; ``part_rows[p]``: the rows of part p.  Pairs in the
+        standing buffers of slot 0 (``capacity`` pairs to begin with, grown when the driver asks
+        for it).  Returns the pairs trained."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib, ops
+
+        dev = walks.device
+        plan = plans[0]
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        if getattr(self, "_work", None) is None:
+            self._work = torch.empty(_lib.BLOCK_WORK_WORDS, dtype=torch.int64, device=dev)
+        cells = plan.parts * plan.slices
+        if getattr(self, "_offsets", None) is None or self._offsets.numel() != cells + 1:
+            self._offsets = torch.empty(cells + 1, dtype=torch.int64, device=dev)
+
+        def rounded(n):  # in steps of 2^24 pairs
+            return max(1, -(-int(n) // PAIR_ROOM)) * PAIR_ROOM
+
+        def room_for(n_pairs):
+            pairs = self._slots.get(0)
+            if pairs is None or pairs.numel() < n_pairs:
+                self._slots[0] = pairs = None  # released before its successor is allocated
+                pairs = self._slots[0] = torch.empty(rounded(n_pairs * (1 + 1 / 64)),
+                                                     dtype=torch.int64, device=dev)
+            need = ops.block_extract_temp_bytes(pairs.numel())
+            if self._temp is None or self._temp.numel() < need:
+                self._temp = None
+                self._temp = torch.empty(need, dtype=torch.uint8, device=dev)
+            return pairs, self._temp
+
+        pairs, temp = room_for(max(1, capacity))
+        alias, cell_rows, hub_bits, hot_list, hot_slot = tables
+        assert walks.is_contiguous() and central.is_contiguous()
+        assert all(t.is_contiguous() and t.shape[1] == tp.ld for t in part_rows)
+        part_ptrs = (C.c_void_p * len(part_rows))(*[t.data_ptr() for t in part_rows])
+        plan_array = (_lib.BlockPlan * len(plans))(*plans)
+        io = _lib.BlockRoundIO(
+            ptr(walks), ptr(alias), ptr(cell_rows), ptr(hub_bits), ptr(hot_list), ptr(hot_slot),
+            ptr(central), C.cast(part_ptrs, C.POINTER(C.c_void_p)), 0, ptr(self._work),
+            ptr(self._offsets), ptr(pairs), pairs.numel(), ptr(temp), temp.numel(),
+            int(group_parts), 0, 0, 0)
+        dg = self.graph.device_graph(self.index)
+        while True:
+            rc = _lib.lib().gn2v_block_round(
+                dg.handle, C.byref(tp), plan_array, len(plans), C.byref(io), walks.shape[0],
+                seed, epoch, first_walk, lr, round_id, ops._stream(dev))
+            if rc != _lib.ROUND_GROW:
+                _lib.check(rc)
+                return int(io.pairs_trained)
+            pairs, temp = room_for(int(io.needed_pairs))
+            io.d_pairs, io.pairs_capacity = ptr(pairs), pairs.numel()
+            io.d_temp, io.temp_bytes = ptr(temp), temp.numel()
+
     def release(self):
         """Give the standing pair buffers back (before the result tables are assembled)."""
         import torch
@@ -533,6 +595,20 @@ class BlockPartitionedTrainer:
         return out
 
     def train_round(self, walks, seed: int, epoch: int, lr: float, first_walk: int, slot=None):
+        if self.comm.world == 1 and hasattr(self.backend, "round"):
+            # one GPU: the C round driver (what gn2v_train_blocks runs) orders the launches
+            assert self._round_episodes == 0, "a round driven in one piece starts at its beginning"
+            hot_list, hot_slot = self.hot if self.hot is not None else (None, None)
+            tables = (self.alias, self.cell_rows, self.hub_bits, hot_list, hot_slot)
+            part_rows = [self.held[p][: self.part_rows(p)] for p in range(self.parts)]
+            trained = self.backend.round(
+                self.tp, self.plans, walks, tables, self.central, part_rows, self.group_parts,
+                self.group_capacity(), seed, epoch, lr=lr, first_walk=first_walk,
+                round_id=self.rounds_done)
+            self.last_round = {"pairs_trained": trained}
+            self.episode += self.parts * self.stripes
+            self.rounds_done += 1
+            return
         walks_all = self.gather_walks(walks)
         for j in range(self.stripes):
             for group in self.groups():
@@ -554,8 +630,10 @@ class BlockPartitionedTrainer:
         if not rounds:
             return
         on_gpu = isinstance(self.backend, GpuBlockBackend)
-        # a single round too: one allocator pool for all rounds; centre stripes run in line
-        overlap = overlap and on_gpu and self.stripes == 1
+        # a single round too: one allocator pool for all rounds; centre stripes run in line, and
+        # so does one GPU by itself (train_round: the C round driver; the kernels of a part take
+        # 96 % of a round there, and the preparation has no exchange to hide)
+        overlap = overlap and on_gpu and self.stripes == 1 and self.comm.world > 1
         if not overlap:
             # one standing slot: the stream orders a group's training before the pairs of the
             # next are written

@@ -419,6 +419,36 @@ def test_centre_stripes_on_one_gpu_equal_the_oracle(stripes, nodes, parts, slice
     assert np.abs(gpu[0][0] - plain[0][0]).max() > 1e-4  # another order of the same pairs
 
 
+def test_round_driver_asks_for_room_and_resumes_where_it_stopped(monkeypatch):
+    """``gn2v_block_round`` (the host loop of a one-GPU round, shared by gn2v_train_blocks and the
+    Python trainer) with pair buffers too small for a group: it returns GN2V_ROUND_GROW before
+    anything of that group is trained, names the pairs it needs and, called again with room,
+    goes on at that group -- the tables of the round equal those of a round that had room from
+    the start, bit for bit (deterministic schedule), and every pair is trained once."""
+    import embiggen_amd.distributed as dist_mod
+
+    g = _ba(203)
+    calls = []
+    real_lib = E._lib.lib()
+    real = real_lib.gn2v_block_round
+
+    class Spy:
+        def __call__(self, *a):
+            rc = real(*a)
+            calls.append(rc)
+            return rc
+
+    want = _trainer_run(LoopbackComm(), g, False, 2, stripes=2, parts=4)
+    monkeypatch.setattr(dist_mod, "PAIR_ROOM", 64)
+    spy_lib = type("L", (), {"gn2v_block_round": Spy(),
+                             "__getattr__": lambda self, k: getattr(real_lib, k)})()
+    monkeypatch.setattr(E._lib, "lib", lambda: spy_lib)
+    got = _trainer_run(LoopbackComm(), g, False, 2, stripes=2, parts=4)
+    assert calls.count(E._lib.ROUND_GROW) >= 1 and calls.count(0) == 2, calls
+    assert np.array_equal(got[0][0], want[0][0]) and np.array_equal(got[0][1], want[0][1])
+    assert got[1] == want[1] == [11 * (2 * W * L - W * (W + 1))] * 2
+
+
 def test_centre_stripes_keep_the_quality_and_lengthen_the_runs():
     """BA 200 k nodes, production update mode: 8 centre stripes vs none on the same walks -- the
     link quality of the plain trainer, every pair trained once."""
