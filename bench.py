@@ -479,6 +479,8 @@ def main():
                                          slices=args.slices, record=args.record,
                                          hot_rows=args.hot_rows, hot_flush=args.hot_flush,
                                          stripes=stripes)
+        if overlap:  # --overlap on, one GPU: the several-rank loop with its side stream
+            blocks.round_driver = False
     else:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local, ld=ld)
@@ -740,7 +742,7 @@ def main():
                 # the host loop that drove the timed region
                 "entry": ("gn2v_train (C ABI, include/gn2v.h: one call = tables initialised + "
                           "alias tables + all rounds + node order restored)" if c_entry else
-                          "embiggen_amd.distributed.BlockPartitionedTrainer (Python host loop)"
+                          "embiggen_amd.distributed.BlockPartitionedTrainer (Python; on one GPU its rounds are gn2v_block_round calls, the loop gn2v_train_blocks runs)"
                           if blocks is not None else "per-launch step entry points"),
                 # what a committed PMC profile must share with this run to price its traffic
                 "traffic_key": (f"ba{n}x{args.m}:d{d}:{args.model}:{args.mode}:"

@@ -995,17 +995,40 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     release_round();
     if (part_major) {  // part-major -> natural order
         float *scratch = nullptr;
-        if (buf.alloc(&scratch, table_bytes))
-            return fail("out of device memory while restoring the row order of the contextual "
-                        "table (GN2V_BLOCK_LAYOUT=natural trains without that copy)");
-        HIP_TRY(hipMemcpyAsync(scratch, d_contextual, table_bytes, hipMemcpyDeviceToDevice, s));
-        const unsigned blocks =
-            (unsigned)std::min<uint64_t>((n * (ld >> 2) + 255) / 256, 256 * 32);
-        hipLaunchKernelGGL(gn2v::parts_to_natural_kernel, dim3(blocks), dim3(256), 0, s,
-                           d_contextual, scratch, (const unsigned long long *)part_first, n, ld,
-                           parts);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(s));
+        void *raw = nullptr;
+        if (!getenv("GN2V_BLOCK_RESTORE_ON_HOST") && hipMalloc(&raw, table_bytes) == hipSuccess) {
+            buf.ptrs.push_back(raw);
+            scratch = (float *)raw;
+            HIP_TRY(hipMemcpyAsync(scratch, d_contextual, table_bytes, hipMemcpyDeviceToDevice, s));
+            const unsigned blocks =
+                (unsigned)std::min<uint64_t>((n * (ld >> 2) + 255) / 256, 256 * 32);
+            hipLaunchKernelGGL(gn2v::parts_to_natural_kernel, dim3(blocks), dim3(256), 0, s,
+                               d_contextual, scratch, (const unsigned long long *)part_first, n,
+                               ld, parts);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            // somebody took the memory the copy was planned for while the fit ran: the trained
+            // table is not given up -- it goes through host memory, a part at a time coming back
+            // as a strided copy into its rows p, p + parts, ...
+            (void)hipGetLastError();
+            float *host = (float *)malloc(table_bytes);
+            if (!host)
+                return fail("out of device and host memory while restoring the row order of the "
+                            "contextual table (GN2V_BLOCK_LAYOUT=natural trains without that "
+                            "copy)");
+            hipError_t e = hipMemcpyAsync(host, d_contextual, table_bytes, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            for (uint32_t p = 0; p < parts && e == hipSuccess; ++p)
+                e = hipMemcpy2DAsync(d_contextual + (size_t)p * ld, (size_t)parts * ld * 4,
+                                     host + first_row[p] * ld, (size_t)ld * 4, (size_t)ld * 4,
+                                     first_row[p + 1] - first_row[p], hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            free(host);
+            if (e != hipSuccess)
+                return fail(std::string("restoring the row order through host memory: ") +
+                            hipGetErrorString(e));
+        }
     }
     if (stats) {
         if (gn2v_stats_read(g, stats, s)) return 1;

@@ -393,6 +393,10 @@ class BlockPartitionedTrainer:
         self.walk_length, self.window = walk_length, window
         rank, world = comm.rank, comm.world
         self.backend = backend if backend is not None else GpuBlockBackend(graph, device)
+        # one GPU: a round is one call of the library's round driver (gn2v_block_round, what
+        # gn2v_train_blocks runs); the per-group loop below, with its hops and its overlapped
+        # preparation, is for several ranks (tests switch this off to run that loop on one GPU)
+        self.round_driver = world == 1 and hasattr(self.backend, "round")
         auto_parts, auto_slices = auto_plan(self.n_nodes, world, ld, int(train_params.k))
         parts = auto_parts if parts is None else parts
         slices = auto_slices if slices is None else slices
@@ -595,7 +599,7 @@ class BlockPartitionedTrainer:
         return out
 
     def train_round(self, walks, seed: int, epoch: int, lr: float, first_walk: int, slot=None):
-        if self.comm.world == 1 and hasattr(self.backend, "round"):
+        if self.round_driver:
             # one GPU: the C round driver (what gn2v_train_blocks runs) orders the launches
             assert self._round_episodes == 0, "a round driven in one piece starts at its beginning"
             hot_list, hot_slot = self.hot if self.hot is not None else (None, None)
@@ -633,7 +637,7 @@ class BlockPartitionedTrainer:
         # a single round too: one allocator pool for all rounds; centre stripes run in line, and
         # so does one GPU by itself (train_round: the C round driver; the kernels of a part take
         # 96 % of a round there, and the preparation has no exchange to hide)
-        overlap = overlap and on_gpu and self.stripes == 1 and self.comm.world > 1
+        overlap = overlap and on_gpu and self.stripes == 1 and not self.round_driver
         if not overlap:
             # one standing slot: the stream orders a group's training before the pairs of the
             # next are written

@@ -64,7 +64,7 @@ class EdgeLabelPredictionTransformer:
         labels = (graph.get_directed_known_edge_type_ids() if whole
                   else graph.get_upper_triangular_known_edge_type_ids())
         if sum(c > 0 for c in counts.values()) == 2:
-            labels = labels == np.max(labels)
+            labels = labels == 1  # as the reference: the type of id 1 is the positive class
         if unknown and behaviour_for_unknown_edge_labels == "drop":
             x = x[graph.get_directed_edges_with_known_edge_types_mask() if whole
                   else graph.get_upper_triangular_known_edge_types_mask()]

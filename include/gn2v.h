@@ -333,7 +333,8 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
                     void *stream);
 
 /* Leave `cus_per_xcd` compute units of every XCD to other work: from now on the training kernels
- * of this handle (gn2v_block_step, gn2v_sgns_step, ...) run on a stream of the library's own
+ * of the multi-GPU path (gn2v_block_step; the walk-ordered gn2v_sgns_step / gn2v_cbow_step keep
+ * the caller's stream: they never run beside a transfer) run on a stream of the library's own
  * created with hipExtStreamCreateWithCUMask, ordered after the caller's stream at entry and before
  * it at exit (two events per call).  For multi-GPU jobs: the training kernel's workgroups stay
  * resident for a whole launch, and RCCL's transfer kernels must find a CU.  The

@@ -835,8 +835,8 @@ def test_run_with_standing_buffers_equals_round_by_round_training(overlap, group
     """``run`` (standing pair buffers, two slots alternating when the preparation overlaps, called
     twice like bench.py's warm-up and timed phases, a later round larger than the buffers were
     sized for; the round's pairs prepared at once or a group of parts at a time, the next group
-    prepared on the side stream while one trains) against ``train_round`` (fresh buffers per round,
-    all parts at once): the deterministic kernel makes the two bit-equal."""
+    prepared on the side stream while one trains) against ``train_round`` (the library's round
+    driver, all parts at once): the deterministic kernel makes the two bit-equal."""
     g = _ba(203)
     tp = ops.train_params(0, D, K, W, flags=1 | DET)
     wp = ops.walk_params(L, 1, 0.25, 4.0)
@@ -853,6 +853,9 @@ def test_run_with_standing_buffers_equals_round_by_round_training(overlap, group
     b = trainer()
     b.group_parts = group_parts or b.parts  # groups change the buffers, never the result
     b.round_capacity = 11
+    # overlap: the per-group loop of several ranks (next group prepared on the side stream) run
+    # on one GPU, against `a`, whose rounds go through the library's round driver
+    b.round_driver = not overlap
     rounds = [(lambda first=first, n=n: ops.walks(g, wp, 42, 0, first, n), 42, 0, 0.02, first)
               for first, n in zip(firsts, sizes)]
     b.run(rounds[:2], overlap=overlap)
