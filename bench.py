@@ -703,11 +703,15 @@ def main():
         scheduled = sched_bytes / (st["train_ms"] * 1e-3) / 1e9
         if cbow:
             # mirror of launch_train's choice (gn2v_api.hip): the lazy window needs its LDS --
-            # 4 waves x ((2w + 3) rows + walk + samples + bookkeeping) words -- within 64 KB
-            lazy_words = (13 * ld + 128 + 2 * 11 + 10 + 33 + 3) & ~3
+            # (2w + 3) rows + walk + samples + bookkeeping words per wave; workgroups of 4 / 2 / 1
+            # waves within 64 KB -- and runs while a CU's 160 KB hold kLazyMinWaves = 3 waves
+            lazy_bytes = 4 * ((13 * ld + 128 + 2 * 11 + 10 + 33 + 3) & ~3)
             store_mode = args.mode in ("write_through", "write_back") or (
                 args.mode == "auto" and n * ld >= (1 << 22))  # GN2V_CBOW_STORES_MIN_ELEMENTS
-            kernel = ("gn2v::cbow_lazy_kernel" if store_mode and 16 * lazy_words <= 64 * 1024
+            lazy_waves = max((160 * 1024 // ((wpb * lazy_bytes + 1023) & ~1023)) * wpb
+                             for wpb in (4, 2, 1) if wpb * lazy_bytes <= 64 * 1024) \
+                if lazy_bytes <= 64 * 1024 else 0
+            kernel = ("gn2v::cbow_lazy_kernel" if store_mode and lazy_waves >= 3
                       else "gn2v::cbow_kernel")
         elif blocks_view is not None:
             kernel = "gn2v::sgns_block_kernel"

@@ -31,6 +31,7 @@ BLOCK_PATH_MIN_NODES = 2560  # GN2V_BLOCK_PATH_MIN_NODES
 TRAIN_WALK_ORDERED = 1024
 TRAIN_BLOCK_PATH = 2048
 TRAIN_CENTRAL_STORE = 4096
+TRAIN_CTX_CACHE_NONE = 512
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 

@@ -22,10 +22,15 @@
 // node occurs twice in the window (all m = 1: the rule), the sum of the b's is slid along:
 //   B_{i+1} = B_i - b_{v(i-w)} + b_{v(i+w+1)} + b_{v(i)} - b_{v(i+1)},   S_i = B_i + Mc_i D_{i-1}
 // (Mc = cached positions in J(i)); a revisited node switches to the direct sum until the window
-// is free of duplicates again.  Rows of high-degree nodes are not cached (as in
-// cbow_cached_kernel: many waves would hold private copies): they are read from HBM for the sum
-// and receive delta_i in HBM at once.  Exact in exact arithmetic; in f32 the sliding sum drifts
-// by ~1e-6 over a walk (tests: 1e-5 against the oracle, return-heavy walks included).
+// is free of duplicates again.  Rows of high-degree nodes must not live in private copies (many
+// waves would hold one at once and the last write-back would win): their slots hold the PENDING
+// STEP only,
+//   x_v(t) = x_v(HBM, now) + b_v + m_v * D_t,   b_v = -D_{e-1} at entry,
+// the row itself is read from HBM for every window sum (so it is always everybody's latest) and
+// the pending step reaches it with f32 atomics when the position retires -- one row of atomics
+// per position instead of a read-modify-write per centre, and nobody's update is lost.  Exact in
+// exact arithmetic; in f32 the sliding sum drifts by ~1e-6 over a walk (tests: 1e-5 against the
+// oracle, return-heavy walks included).
 // min_dist == 1 only (Walklets scales keep cbow_cached_kernel).
 #pragma once
 #include "train_kernels.h"
@@ -71,8 +76,10 @@ inline uint32_t lazy_min_blocks(uint32_t ld) {
     const int ch = nchunks <= 16 ? 1 : nchunks <= 32 ? 2 : nchunks <= 64 ? 4 : nchunks <= 128 ? 8 : 16;
     return lazy_min_blocks_ch(ch, ld == (uint32_t)ch * 64);
 }
-// the lazy window runs when a CU's LDS holds at least this many of its waves
-constexpr uint32_t kLazyMinWaves = 8;
+// the lazy window runs when a CU's LDS holds at least this many of its waves (measured down to
+// three -- rows of 1 024 floats at w = 5: 0.62 of the roofline against the uncached kernel's
+// 0.52)
+constexpr uint32_t kLazyMinWaves = 3;
 
 template <int CH>
 __device__ __forceinline__ void lds_load_row(Row<CH> &r, const float *base, int q,
@@ -131,8 +138,12 @@ cbow_lazy_kernel(TrainArgs a) {
     const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
     unsigned long long pairs = 0, centres = 0;
 
+    // s_node: node id of the slot; bit 31 = the slot holds the pending step of a row that stays
+    // in HBM (node ids are below 2^30 here, launch_train)
+    constexpr uint32_t kPending = 0x80000000u;
     auto lookup = [&](uint32_t v) -> int {
-        const bool m = (uint32_t)lane < slots && s_ref[lane] != 0 && s_node[lane] == v;
+        const bool m =
+            (uint32_t)lane < slots && s_ref[lane] != 0 && (s_node[lane] & ~kPending) == v;
         const unsigned long long b = __ballot(m);
         return b ? __ffsll((long long)b) - 1 : -1;
     };
@@ -178,13 +189,10 @@ cbow_lazy_kernel(TrainArgs a) {
                 wave_sync();
                 return hit;
             }
+            bool pending = false;  // hot node: the row stays in HBM, the slot holds its step
             if (a.cache_max_degree != 0xFFFFFFFFu) {
                 const uint64_t deg = a.g.row_ptr[v + 1] - a.g.row_ptr[v];
-                if (deg >= a.cache_max_degree) {  // hot node: stays in HBM
-                    if (lane == 0) s_pos[entry] = kNoSlot;
-                    wave_sync();
-                    return -1;
-                }
+                pending = deg >= a.cache_max_degree;
             }
             int f = -1;
             {
@@ -200,11 +208,11 @@ cbow_lazy_kernel(TrainArgs a) {
                 return -1;
             }
             Row<CH> b;
-            load_row<CH>(b, a.contextual + (uint64_t)v * a.ld, q, nchunks, true);
+            load_row<CH>(b, a.contextual + (uint64_t)v * a.ld, q, nchunks, !pending);
             row_axpy<CH>(b, -1.0f, D);
             if (grp == 0) lds_store_row<CH>(rows + (uint32_t)f * a.ld, b, q, nchunks);
             if (lane == 0) {
-                s_node[f] = v;
+                s_node[f] = pending ? v | kPending : v;
                 s_ref[f] = 1;
                 s_pos[entry] = (uint32_t)f;
             }
@@ -246,8 +254,9 @@ cbow_lazy_kernel(TrainArgs a) {
                 uint32_t node_j = 0;
                 if ((uint32_t)lane < n_ctx) {
                     const uint32_t j = win.position(lane);
-                    cached = s_pos[j % slots] != kNoSlot;
-                    hub = !cached;
+                    const uint32_t sl = s_pos[j % slots];
+                    cached = sl != kNoSlot;
+                    hub = !cached || (s_node[sl] & kPending);  // the row is read from HBM
                     node_j = s_walk[j];
                 }
                 const unsigned long long hub_mask = __ballot(hub);
@@ -291,15 +300,18 @@ cbow_lazy_kernel(TrainArgs a) {
                     S = part;
                     row_axpy<CH>(S, m_sum, D);
                 }
-                if (n_hub) {
+                if (n_hub) {  // the rows that stay in HBM: eight in flight per wave
                     Row<CH> hs;
                     zero_row<CH>(hs);
-                    for (uint32_t r0 = 0; r0 < n_hub; r0 += 4) {
-                        const uint32_t rank = r0 + grp;
-                        Row<CH> v;
-                        load_row<CH>(v, a.contextual + (uint64_t)(rank < n_hub ? s_ctx[rank] : 0) * a.ld,
-                                     q, nchunks, rank < n_hub);
-                        row_axpy<CH>(hs, 1.0f, v);
+                    for (uint32_t r0 = 0; r0 < n_hub; r0 += 8) {
+                        const uint32_t ra = r0 + grp, rb = r0 + 4 + grp;
+                        Row<CH> va, vb;
+                        load_row<CH>(va, a.contextual + (uint64_t)(ra < n_hub ? s_ctx[ra] : 0) * a.ld,
+                                     q, nchunks, ra < n_hub);
+                        load_row<CH>(vb, a.contextual + (uint64_t)(rb < n_hub ? s_ctx[rb] : 0) * a.ld,
+                                     q, nchunks, rb < n_hub);
+                        row_axpy<CH>(hs, 1.0f, va);
+                        row_axpy<CH>(hs, 1.0f, vb);
                     }
                     reduce_groups<CH>(hs);
                     row_axpy<CH>(S, 1.0f, hs);
@@ -334,20 +346,9 @@ cbow_lazy_kernel(TrainArgs a) {
                     delta.c[cc].z = g.c[cc].z * invC;
                     delta.c[cc].w = g.c[cc].w * invC;
                 }
-                // the uncached context rows get their step in HBM at once
-                for (uint32_t r0 = 0; r0 < n_hub; r0 += 4) {
-                    const RoundIds ids(s_ctx, r0, n_hub);
-                    const uint32_t row = ids.row_of(grp);
-                    const bool valid = row != kSentinel;
-                    const int my_pass = ids.pass_of(grp);
-                    float *gbase = a.contextual + (uint64_t)(valid ? row : 0) * a.ld;
-                    for (int pass = 0; pass <= ids.last_pass; ++pass) {
-                        const bool mine = valid && my_pass == pass;
-                        Row<CH> v;
-                        load_row<CH>(v, gbase, q, nchunks, mine);
-                        if (mine) scatter_add<CH, WM>(gbase, q, nchunks, 1.0f, delta, v);
-                    }
-                }
+                // (a position without a slot cannot happen -- at most `slots` are live -- so
+                // every context row receives delta_i through its slot, the rows that stay in HBM
+                // too: their slots hold the pending step)
                 pairs += n_ctx;
                 ++centres;
                 // (a) the centre's own position receives no step: take it back
@@ -389,8 +390,14 @@ cbow_lazy_kernel(TrainArgs a) {
                     const uint32_t m = s_ref[h];
                     wave_sync();
                     if (m == 1) {
-                        if (grp == 0) {
-                            float *dst = a.contextual + (uint64_t)s_node[h] * a.ld;
+                        const uint32_t node = s_node[h];
+                        float *dst = a.contextual + (uint64_t)(node & ~kPending) * a.ld;
+                        if (node & kPending) {
+                            // b = the pending step: added to everybody's row, 256 B per instruction
+                            if (grp == 0) lds_store_row<CH>(row, b, q, nchunks);
+                            wave_sync();
+                            for (uint32_t f = lane; f < a.ld; f += 64) unsafeAtomicAdd(dst + f, row[f]);
+                        } else if (grp == 0) {
                             Row<CH> none;
                             zero_row<CH>(none);
                             // row = b: a plain (or write-through) store of the final value
@@ -443,12 +450,21 @@ cbow_lazy_kernel(TrainArgs a) {
                 const uint32_t m = s_ref[s];
                 if (m == 0) continue;
                 Row<CH> b, none;
-                lds_load_row<CH>(b, rows + s * a.ld, q, nchunks);
+                float *row = rows + s * a.ld;
+                lds_load_row<CH>(b, row, q, nchunks);
                 row_axpy<CH>(b, (float)m, D);
                 zero_row<CH>(none);
-                if (grp == 0)
+                const uint32_t node = s_node[s];
+                float *dst = a.contextual + (uint64_t)(node & ~kPending) * a.ld;
+                if (node & kPending) {
+                    wave_sync();
+                    if (grp == 0) lds_store_row<CH>(row, b, q, nchunks);
+                    wave_sync();
+                    for (uint32_t f = lane; f < a.ld; f += 64) unsafeAtomicAdd(dst + f, row[f]);
+                } else if (grp == 0) {
                     scatter_add<CH, WM == kWriteBack ? kWriteBack : kWriteThrough>(
-                        a.contextual + (uint64_t)s_node[s] * a.ld, q, nchunks, 1.0f, b, none);
+                        dst, q, nchunks, 1.0f, b, none);
+                }
             }
         }
         wave_sync();

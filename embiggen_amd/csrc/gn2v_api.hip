@@ -399,6 +399,8 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     if (use_cache) {
         if (tp->flags & GN2V_TRAIN_CTX_CACHE_ALL) {
             a.cache_max_degree = 0xFFFFFFFFu;
+        } else if (tp->flags & GN2V_TRAIN_CTX_CACHE_NONE) {
+            a.cache_max_degree = 0;
         } else {
             // a row is cached by ~(resident waves x window) positions at a time; keep the expected
             // number of waves holding the same row at once below 0.1

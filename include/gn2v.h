@@ -63,6 +63,8 @@ extern "C" {
  * left in HBM.  Switches: */
 #define GN2V_TRAIN_NO_CTX_CACHE 128u  /* always use the plain kernel                             */
 #define GN2V_TRAIN_CTX_CACHE_ALL 256u /* cache every row regardless of degree (tests)            */
+#define GN2V_TRAIN_CTX_CACHE_NONE 512u /* treat every row as a high-degree row: it stays in HBM
+                                          (CBOW: its window slot holds the pending step; tests)  */
 /* gn2v_train picks its schedule: SkipGram on graphs of >= GN2V_BLOCK_PATH_MIN_NODES nodes in the
  * default update mode runs the block path (gn2v_train_blocks; one part of 8 XCD slices up to 2^18
  * nodes), everything else the walk-ordered kernels.  The limit is where the link quality of the

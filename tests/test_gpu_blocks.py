@@ -702,6 +702,25 @@ def test_gn2v_train_blocks_with_stripes_equals_the_python_trainer(stripes, round
     assert float((c1 - c2).abs().max()) < 1e-5 and float((x1 - x2).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("on_host", [False, True])
+def test_parts_come_back_in_node_order_also_through_host_memory(on_host, monkeypatch):
+    """gn2v_train_blocks trains the contextual table part by part inside the caller's buffer and
+    restores the node order at the end through a scratch copy on the device -- or, when that
+    allocation fails after the fit (GN2V_BLOCK_RESTORE_ON_HOST forces the branch), through host
+    memory with one strided copy per part.  A learning rate of zero leaves the
+    initial tables: every row must be back at its node's place, bit for bit."""
+    if on_host:
+        monkeypatch.setenv("GN2V_BLOCK_RESTORE_ON_HOST", "1")
+    n, d = 120_000, 128
+    g = E.barabasi_albert(n, 5, 3)
+    m = E.models.SkipGram(embedding_size=d, epochs=1, iterations=1, walk_length=16, window_size=3,
+                          learning_rate=0.0, verbose=False)
+    c, x, st = m.fit_transform_device(g)
+    assert m.last_plan["parts"] > 1 and st["pairs"] == n * (2 * 3 * 16 - 3 * 4)
+    assert torch.equal(c[:, :d], ops.init_table(n, d, m.random_state, 0, m.init_scale()))
+    assert torch.equal(x[:, :d], ops.init_table(n, d, m.random_state, 1, m.init_scale()))
+
+
 def test_gn2v_train_takes_the_block_path_by_itself_from_2560_nodes():
     """GN2V_BLOCK_PATH_MIN_NODES: below it the walk-ordered kernel with atomics on every row, from
     it up one part of 8 XCD slices (plain stores on the XCD-exclusive contextual rows)."""

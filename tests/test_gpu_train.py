@@ -448,10 +448,14 @@ def test_context_cache_is_sequentially_exact_on_real_walks(karate, karate_oracle
                               flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_ALL)
     plain = ops.train_params(model, d, k, w,
                              flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_NO_CTX_CACHE)
+    # every row treated as a high-degree one: it stays in HBM; the lazy CBOW window keeps its
+    # pending step in the slot and adds it with atomics when the position retires
+    pending = ops.train_params(model, d, k, w,
+                               flags=1 | _lib.TRAIN_WRITE_THROUGH | _lib.TRAIN_CTX_CACHE_NONE)
     otp = O.TrainParams(model, d, ld, 1, k, w, 0.01, 0.9, 6.0, 1, d ** -0.5)
     step = ops.sgns_step if model == 0 else ops.cbow_step
     for b in range(34):
-        tp = cached if b % 3 else plain
+        tp = (plain, cached, pending, cached)[b % 4]
         step(karate, tp, wk[b:b + 1].contiguous(), 3, 0, b, 0.05, c, x)
     torch.cuda.synchronize()
     O.train_walks(karate_oracle, otp, wk_h, 3, 0, 0, 0.05, c_h, x_h)
