@@ -1157,9 +1157,12 @@ def test_pair_per_group_path_adds_shared_centres_with_atomics(d):
 def test_small_graph_through_the_block_path_learns_what_atomics_learn():
     """A graph the size of Cora (2 708 nodes: BASELINE config 1's shape) takes the block path by
     default since GN2V_BLOCK_PATH_MIN_NODES = 2 560: one part of 8 XCD slices, plain stores on the
-    contextual rows.  Same walks, 10 epochs: link AUROC (symmetrised c.x over all node pairs, and
-    cosine of the central vectors) within 0.004 of atomics on every row, which it replaces at
-    20 x the speed (profiles/r03_logs/r3_small_quality*.log)."""
+    contextual rows (one wave per four rows, rows re-read right before their stores: tables this
+    small live in the L2s).  Same walks, 10 epochs: link AUROC (symmetrised c.x over all node
+    pairs) within 0.004 and cosine of the central vectors within 0.008 of atomics on every row,
+    which it replaces at 5 x the speed.  The schedule races, so the numbers move from run to run:
+    measured over ten fits, cosine AUROC 0.9911-0.9969 against 0.9973-0.9976 for atomics, link
+    AUROC 0.9954-0.9958 against 0.9950-0.9957 (profiles/r04_logs/r4_run33_small_quality.log)."""
     from sklearn.metrics import roc_auc_score
 
     from helpers import adjacency, cosine_matrix, link_auc
@@ -1177,4 +1180,4 @@ def test_small_graph_through_the_block_path_learns_what_atomics_learn():
         iu = np.triu_indices(2708, 1)
         got[name] = (link_auc(g, c, x), float(roc_auc_score(adjacency(g)[iu], cosine_matrix(c)[iu])))
     assert got["atomic"][0] > 0.98 and got["atomic"][1] > 0.98
-    assert got["blocks"][0] > got["atomic"][0] - 0.004 and got["blocks"][1] > got["atomic"][1] - 0.004
+    assert got["blocks"][0] > got["atomic"][0] - 0.004 and got["blocks"][1] > got["atomic"][1] - 0.008
