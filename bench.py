@@ -714,7 +714,9 @@ def main():
             kernel = ("gn2v::cbow_lazy_kernel" if store_mode and lazy_waves >= 3
                       else "gn2v::cbow_kernel")
         elif blocks_view is not None:
-            kernel = "gn2v::sgns_block_kernel"
+            # more than one slice per XCD: resident cells (gn2v_block_step's own rule)
+            kernel = ("gn2v::sgns_resident_kernel" if blocks_view.slices > 8 and t_world == 1
+                      else "gn2v::sgns_block_kernel")
         elif n >= (1 << 16) and args.mode in ("auto", "write_through", "write_back"):
             kernel = "gn2v::sgns_cached_kernel"
         else:
@@ -759,7 +761,11 @@ def main():
                                "kernel" if replicas else "1 GPU, walk-ordered kernel"),
                     "blocks": f"{t_world} GPU(s), central table striped over the ranks, contextual "
                               f"table in {blocks_view.parts if blocks_view else 0} travelling parts x "
-                              f"{blocks_view.slices if blocks_view else 0} XCD slice(s) (no shared rows), rounds of "
+                              f"{blocks_view.slices if blocks_view else 0} "
+                              + ("resident cells (every contextual row in the LDS of the one "
+                                 "workgroup that owns its cell)"
+                                 if blocks_view is not None and blocks_view.slices > 8 and t_world == 1
+                                 else "XCD slice(s) (no shared rows)") + ", rounds of "
                               f"{min(args.round_walks, args.steps * args.walks)} walks per GPU "
                               f"prepared {blocks_view.group_parts if blocks_view else 0} parts at a time"
                               + (f" trained in {stripes} centre stripes" if stripes > 1 else "")

@@ -45,7 +45,7 @@ EXPORTS = [
     "gn2v_touch_rows",
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
     "gn2v_block_alias", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
-    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_round", "gn2v_block_auto_plan", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
+    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_round", "gn2v_block_auto_plan", "gn2v_block_auto_plan_graph", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
     "gn2v_train_blocks",
     "gn2v_stats_reset",
     "gn2v_stats_read",
@@ -159,7 +159,8 @@ ROUND_GROW = 3  # GN2V_ROUND_GROW
 # include/gn2v_experimental.h: measured-and-rejected designs kept for their scripts and tests
 EXPERIMENTAL_EXPORTS = ["gn2v_step"]
 
-BLOCK_WORK_WORDS = 16384
+BLOCK_WORK_WORDS = 73728    # GN2V_BLOCK_WORK_WORDS
+BLOCK_MAX_GROUP_CELLS = 8192  # GN2V_BLOCK_MAX_GROUP_CELLS
 BLOCK_HOT_MAX = 192      # GN2V_BLOCK_HOT_MAX
 BLOCK_HOT_DEFAULT = 192  # GN2V_BLOCK_HOT_DEFAULT
 
@@ -274,6 +275,7 @@ def lib():
     L.gn2v_block_round.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan), u32,
                                    C.POINTER(BlockRoundIO), u64, u64, u64, u64, f32, u64, vp]
     L.gn2v_block_auto_plan.argtypes = [u64, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.gn2v_block_auto_plan_graph.argtypes = [vp, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), vp]
     L.gn2v_block_round_plan.argtypes = [u64, u64, u32, u32, u32, u32, u32, u32, C.POINTER(u64),
                                         C.POINTER(u32)]
     L.gn2v_train_blocks.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,

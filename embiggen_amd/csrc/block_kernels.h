@@ -35,7 +35,13 @@ namespace gn2v {
 constexpr uint64_t kTagBlock = 0xB10C5EED0B10C5EDULL;
 constexpr int kPrepBlock = 256;
 constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
-constexpr uint32_t kMaxCells = 8192;    // parts x slices (100 M nodes: 381 x 8 cells of 32 k rows)
+constexpr uint32_t kMaxCells = GN2V_BLOCK_MAX_CELLS;   // parts x slices (resident cells at 10 M nodes: 200 x 256)
+constexpr uint32_t kMaxGroupCells = GN2V_BLOCK_MAX_GROUP_CELLS;  // one extraction group (LDS histogram)
+// negatives' stream of a cell: draw(key, block_id * kCellStreamStride + cell).  Plans of more
+// cells than the stride let (block, cell + stride) share its numbers with (block + 1, cell) --
+// another cell, another alias table, another round: harmless, and the plans of up to 8 192 cells
+// keep the streams the oracle restates.
+constexpr uint64_t kCellStreamStride = 8192;
 constexpr uint32_t kMaxRecord = 32;
 // A run -- consecutive pairs of one centre inside a record, trained against ONE copy of the central
 // row, their gradients summed -- is at most this long; a longer stretch of equal centres is cut
@@ -228,7 +234,8 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t waves_per_block = kPrepBlock / 64;
-    const uint32_t cells = a.p.parts * a.p.slices;
+    // cells of the group of parts being extracted, numbered (part - part_lo) mod parts, slice
+    const uint32_t cells = a.part_n * a.p.slices;
     const uint32_t L = a.p.L, w = a.p.window, w2 = 2 * a.p.window;
     // per wave: the walk, per position its context cell (kSentinel: not in this group of parts)
     // and its context row inside the cell (| hot flag), the compacted own positions
@@ -319,7 +326,12 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
                 if (valid) a.pairs[base + __popcll(mask & lt_mask)] = word;
                 base += __popcll(mask);
             } else {
-                if (valid) atomicAdd(&s_hist[cell], 1u);
+                if (valid) {
+                    const uint32_t part = cell / a.p.slices, sl = cell - part * a.p.slices;
+                    const uint32_t rel = part >= a.part_lo ? part - a.part_lo
+                                                           : part + a.p.parts - a.part_lo;
+                    atomicAdd(&s_hist[rel * a.p.slices + sl], 1u);
+                }
                 total += __popcll(mask);
             }
         }
@@ -328,7 +340,12 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
         if (lane == 0) a.wave_counts[gw] = total;
         __syncthreads();
         for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock)
-            if (s_hist[c]) atomicAdd(&a.cell_counts[c], (unsigned long long)s_hist[c]);
+            if (s_hist[c]) {
+                const uint32_t rel = c / a.p.slices, sl = c - rel * a.p.slices;
+                uint32_t part = a.part_lo + rel;
+                if (part >= a.p.parts) part -= a.p.parts;
+                atomicAdd(&a.cell_counts[part * a.p.slices + sl], (unsigned long long)s_hist[c]);
+            }
     }
 }
 
@@ -347,22 +364,32 @@ __global__ __launch_bounds__(1024) void block_scan_kernel(unsigned long long *wa
     }
     part[threadIdx.x] = sum;
     __syncthreads();
+    // the cells: thread t sums the cells [t * chunk, (t + 1) * chunk)
+    __shared__ unsigned long long cpart[1024];
+    const uint32_t chunk = (cells + 1023) / 1024;
+    const uint32_t c0 = min(cells, threadIdx.x * chunk), c1 = min(cells, c0 + chunk);
+    unsigned long long csum = 0;
+    for (uint32_t c = c0; c < c1; ++c) csum += cell_counts[c];
+    cpart[threadIdx.x] = csum;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long run = 0;
+        unsigned long long run = 0, off = 0;
         for (uint32_t i = 0; i < 1024; ++i) {
-            const unsigned long long v = part[i];
+            const unsigned long long v = part[i], cv = cpart[i];
             part[i] = run;
+            cpart[i] = off;
             run += v;
-        }
-        unsigned long long off = 0;
-        for (uint32_t c = 0; c < cells; ++c) {
-            cell_offsets[c] = off;
-            off += cell_counts[c];
+            off += cv;
         }
         cell_offsets[cells] = off;
     }
     __syncthreads();
     for (uint32_t e = 0; e < per; ++e) wave_counts[threadIdx.x * per + e] = part[threadIdx.x] + loc[e];
+    unsigned long long off = cpart[threadIdx.x];
+    for (uint32_t c = c0; c < c1; ++c) {
+        cell_offsets[c] = off;
+        off += cell_counts[c];
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -975,7 +1002,7 @@ __global__ __launch_bounds__(WG) void sgns_block_kernel(BlockArgs a) {
         if (work) {
             const uint64_t R = (hi - lo + C - 1) / C;
             const uint64_t A = record_stride(R);
-            const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kMaxCells + cell);
+            const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kCellStreamStride + cell);
             const uint64_t cell_lo = a.cell_rows ? a.cell_rows[cell] : 0;
             if constexpr (DET) {
                 for (uint64_t t = 0; t < R; ++t) {
@@ -1083,7 +1110,7 @@ __global__ __launch_bounds__(1024) void sgns_resident_kernel(BlockArgs a) {
     unsigned long long pairs = 0, runs = 0;
     const uint64_t R = (hi - lo + C - 1) / C;
     const uint64_t A = record_stride(R);
-    const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kMaxCells + cell);
+    const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kCellStreamStride + cell);
     const uint64_t cell_lo = a.cell_rows ? a.cell_rows[cell] : 0;
     const uint64_t start = mulhi64(ckey, R);
     for (;;) {

@@ -109,6 +109,9 @@ int check_group(const gn2v_block_plan *p, uint32_t part_lo, uint32_t *part_n) {
     if (*part_n == 0 && part_lo == 0) *part_n = p->parts;  // 0, 0 = every part
     if (part_lo >= p->parts || *part_n < 1 || *part_n > p->parts)
         return fail("group of parts out of range");
+    if ((uint64_t)*part_n * p->slices > gn2v::kMaxGroupCells)
+        return fail("a group of parts may hold at most " + std::to_string(gn2v::kMaxGroupCells) +
+                    " cells (parts of the group x slices): extract fewer parts at a time");
     return 0;
 }
 
@@ -262,8 +265,7 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     a.pairs = (unsigned long long *)pairs;
     a.part_lo = part_lo;
     a.part_n = part_n;
-    const uint32_t cells = d.parts * d.slices;
-    const size_t lds = extract_lds_bytes(d.L, cells);
+    const size_t lds = extract_lds_bytes(d.L, part_n * d.slices);
     if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
     const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
     if (write)
@@ -636,8 +638,51 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
 }
 
 
-int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
-                         uint32_t *parts, uint32_t *slices) {
+}  // extern "C"
+
+namespace {
+__global__ void max_u32_kernel(const uint32_t *__restrict__ v, uint64_t n,
+                               unsigned int *__restrict__ out) {
+    unsigned int m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        m = max(m, v[i]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// largest in-degree of the graph (computed once per handle): the most frequent context
+int max_in_degree(gn2v_graph *g, hipStream_t s, uint64_t *out) {
+    if (!g->max_in_degree_known) {
+        const uint64_t n = g->view.n_nodes, E = g->view.n_edges;
+        uint32_t *indeg = nullptr;
+        if (hipMalloc((void **)&indeg, (n + 1) * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail("out of device memory for the in-degrees");
+        }
+        hipError_t e = hipMemsetAsync(indeg, 0, (n + 1) * sizeof(uint32_t), s);
+        if (e == hipSuccess && E) {
+            const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(gn2v::indegree_kernel, dim3(blocks), dim3(256), 0, s,
+                               g->view.col_idx, E, indeg);
+            const unsigned nb = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(max_u32_kernel, dim3(nb), dim3(256), 0, s, indeg, n, indeg + n);
+            e = hipGetLastError();
+        }
+        unsigned int m = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&m, indeg + n, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(indeg);
+        if (e != hipSuccess) return fail(std::string("in-degrees: ") + hipGetErrorString(e));
+        g->max_in_degree = m;
+        g->max_in_degree_known = true;
+    }
+    *out = g->max_in_degree;
+    return 0;
+}
+
+int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool allow_resident,
+              uint32_t *parts, uint32_t *slices) {
     if (!parts || !slices || world < 1) return fail("bad arguments");
     constexpr uint64_t kMinRows = 32768, kXcds = 8;
     // One GPU, rows up to 128 floats, a graph of GN2V_RESIDENT_MIN_NODES nodes or more that is
@@ -649,7 +694,9 @@ int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t
     // CONVERGED fit separates edges from random pairs less well (link AUROC 0.978 vs 0.996 at
     // 2 708 nodes, 0.994 vs 0.998 at 20 k; equal from 200 k nodes, 0.956 vs 0.920 at 1 M after
     // three epochs: DESIGN.md 7.3) -- the negatives of a pair come from its context's cell.
-    const uint64_t fit = world == 1 && n_nodes >= GN2V_RESIDENT_MIN_NODES
+    const uint64_t max_nodes = env_size("GN2V_RESIDENT_MAX_NODES", GN2V_RESIDENT_MAX_NODES);
+    const uint64_t fit = allow_resident && world == 1 && n_nodes >= GN2V_RESIDENT_MIN_NODES &&
+                                 n_nodes <= max_nodes
                              ? resident_rows(ld, 32, k) : 0;
     if (fit >= 16 && n_nodes <= fit * (gn2v::kMaxCells - 512)) {
         const uint64_t cells = (n_nodes + fit - 1) / fit;
@@ -683,6 +730,35 @@ int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t
     *slices = (uint32_t)sl;
     return 0;
 }
+}  // namespace
+
+extern "C" {
+
+int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
+                         uint32_t *parts, uint32_t *slices) {
+    return auto_plan(n_nodes, world, ld, k, true, parts, slices);
+}
+
+int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint32_t k,
+                               uint32_t *parts, uint32_t *slices, void *stream) {
+    if (!g) return fail("NULL handle");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    if (auto_plan(g->view.n_nodes, world, ld, k, true, parts, slices)) return 1;
+    if (*slices <= 8) return 0;  // XCD cells
+    // Resident cells: a launch is one workgroup per cell, and it lasts as long as its heaviest
+    // cell.  The cell of the most frequent context receives in_degree / edges of all pairs on top
+    // of its 1 / cells; over a round that costs up to in_degree / edges x slices of the time
+    // (resident cells run at ~0.6 of the XCD cells' time, so they stop paying at ~0.65).  A graph
+    // with a hub beyond half of edges / slices keeps the XCD cells, whose records are handed out
+    // by tickets to every workgroup of the slice.
+    uint64_t hub = 0;
+    if (max_in_degree(g, (hipStream_t)stream, &hub)) return 1;
+    static const size_t skew_pct = env_size("GN2V_RESIDENT_MAX_SKEW_PCT", 50);
+    if ((double)hub * *slices * 100.0 > (double)skew_pct * (double)g->view.n_edges)
+        return auto_plan(g->view.n_nodes, world, ld, k, false, parts, slices);
+    return 0;
+}
 
 
 int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_length,
@@ -710,6 +786,12 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     };
     while (r > (1ull << 14) && walk_bytes(r) + group_bytes(r, 1) > budget) r /= 2;
     uint64_t gp = std::max<uint64_t>(1, (parts + 3) / 4);
+    // the extraction counts the cells of a group in LDS: kMaxGroupCells at most, and fewer when
+    // the walk's staging leaves less of the 64 KB
+    const uint64_t lds_cells =
+        std::min<uint64_t>(gn2v::kMaxGroupCells,
+                           (64 * 1024 - std::min<size_t>(extract_lds_bytes(walk_length, 0), 60 * 1024)) / 4);
+    gp = std::max<uint64_t>(1, std::min(gp, lds_cells / slices));
     while (gp > 1 && walk_bytes(r) + group_bytes(r, gp) > budget) --gp;
     *round_walks = r;
     *group_parts = (uint32_t)gp;
@@ -815,7 +897,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     gn2v_block_plan plan{};
     plan.world = V;
     plan.rank = 0;
-    if (gn2v_block_auto_plan(n, 1, ld, tp->k, &plan.parts, &plan.slices)) return 1;
+    if (gn2v_block_auto_plan_graph(g, 1, ld, tp->k, &plan.parts, &plan.slices, s)) return 1;
     plan.walk_length = L;
     plan.window = w;
     plan.min_dist = tp->min_dist ? tp->min_dist : 1;
@@ -826,7 +908,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     for (uint32_t r = 32; r >= 8 && !plan.record; r >>= 1)
         if (block_lds_words_per_wave(ld, r, tp->k) * 4 * (gn2v::kTrainBlock / 64) <= 64 * 1024)
             plan.record = r;
-    if (!plan.record || extract_lds_bytes(L, plan.parts * plan.slices) > 64 * 1024) {
+    if (!plan.record || extract_lds_bytes(L, plan.slices) > 64 * 1024) {  // a group of one part
         fail("walk_length / number_of_negative_samples beyond the block path's LDS plans");
         return kOutOfMemory;
     }

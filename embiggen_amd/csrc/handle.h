@@ -84,6 +84,9 @@ struct gn2v_graph {
     // the second-order sampler's edge set (GraphView.edge_set), built on the first biased walk
     unsigned long long *edge_set = nullptr, *edge_filter = nullptr;
     bool edge_set_tried = false;
+    // largest in-degree (the most frequent context), computed on the first automatic plan
+    uint64_t max_in_degree = 0;
+    bool max_in_degree_known = false;
     unsigned long long *counters = nullptr;  // device, 4 x u64
     unsigned long long *cursors = nullptr;   // device, ring of record-ticket arrays (block trainer)
     uint32_t cursor_slot = 0;

@@ -228,6 +228,23 @@ class GpuBlockBackend:
 
         return ops.block_plan(self.graph, device=self.index, **kw)
 
+    def auto_plan(self, world, ld, k):
+        """(parts, slices) by ``gn2v_block_auto_plan_graph``: the rule of ``auto_plan`` with the
+        graph at hand (resident cells only without a hub that would hold every launch up)."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+
+        parts, slices = C.c_uint32(), C.c_uint32()
+        dg = self.graph.device_graph(self.index)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().gn2v_block_auto_plan_graph(
+                dg.handle, world, int(ld), int(k), C.byref(parts), C.byref(slices), stream))
+        return parts.value, slices.value
+
     def alias_tables(self, plan):
         from . import ops
 
@@ -397,7 +414,10 @@ class BlockPartitionedTrainer:
         # gn2v_train_blocks runs); the per-group loop below, with its hops and its overlapped
         # preparation, is for several ranks (tests switch this off to run that loop on one GPU)
         self.round_driver = world == 1 and hasattr(self.backend, "round")
-        auto_parts, auto_slices = auto_plan(self.n_nodes, world, ld, int(train_params.k))
+        auto_parts, auto_slices = (
+            self.backend.auto_plan(world, ld, int(train_params.k))
+            if hasattr(self.backend, "auto_plan")
+            else auto_plan(self.n_nodes, world, ld, int(train_params.k)))
         parts = auto_parts if parts is None else parts
         slices = auto_slices if slices is None else slices
         if world > 1 and (parts % world or parts < 2 * world):
@@ -409,7 +429,11 @@ class BlockPartitionedTrainer:
             from . import _lib
 
             hot_rows = _lib.BLOCK_HOT_DEFAULT
-        self.group_parts = parts if not group_parts else max(1, min(int(group_parts), parts))
+        # the extraction counts the cells of a group in LDS: BLOCK_MAX_GROUP_CELLS at most
+        from . import _lib as _l
+
+        most = max(1, _l.BLOCK_MAX_GROUP_CELLS // slices)
+        self.group_parts = min(most, parts if not group_parts else max(1, min(int(group_parts), parts)))
         self.stripes = max(1, int(stripes))
         if self.stripes > 1 and world > 1:
             raise ValueError("Centre stripes are the one-GPU form of several ranks: stripes > 1 "

@@ -81,12 +81,13 @@ def test_automatic_plan_of_the_block_path():
     for n in (10 ** 5, 10 ** 6, 10 ** 7, 10 ** 8, 3 * 10 ** 9):
         for world in (1, 2, 3, 8):
             parts, slices = auto_plan(n, world)
-            assert parts % world == 0 and parts * slices <= 8192 and slices in (1, 8)
+            assert parts % world == 0 and parts * slices <= 65536 and slices in (1, 8)
             assert world == 1 or parts >= 2 * world
-            if parts > (1 if world == 1 else 2 * world) and parts * slices < 8192 - 8 * world:
+            if parts > (1 if world == 1 else 2 * world) and parts * slices < 65536 - 8 * world:
                 assert 32768 <= n // (parts * slices) < 2 * 32768 * (world + 1)
     # one GPU, the row width known (ld <= 128 floats): RESIDENT CELLS -- every cell fits one
-    # workgroup's LDS (160 KB minus the sixteen waves' staging) -- up to ~1.5 M nodes at d = 128
+    # workgroup's LDS (160 KB minus the sixteen waves' staging) -- up to GN2V_RESIDENT_MAX_NODES
+    # (13 M: 65 536 cells of ~200 rows at d = 128)
     def rows(n, parts, slices):
         return -(-(-(-n // parts)) // slices)  # the largest cell: ceil(ceil(n / parts) / slices)
 
@@ -94,16 +95,18 @@ def test_automatic_plan_of_the_block_path():
     assert auto_plan(2_708, 1, 128, 10) == (1, 8)        # below GN2V_RESIDENT_MIN_NODES: XCD cells
     assert auto_plan(99_999, 1, 128, 10) == (1, 8) and auto_plan(100_000, 1, 128, 10) == (2, 256)
     assert auto_plan(169_343, 1, 128, 10) == (4, 256)    # config 3's shape: cells of 166 rows
-    assert auto_plan(2_449_029, 1, 128, 10) == (9, 8)    # too many rows for 8 192 cells: XCD cells
+    assert auto_plan(2_449_029, 1, 128, 10) == (48, 256)  # config 4's shape
+    assert auto_plan(10_000_000, 1, 128, 10) == (193, 256)  # the bench graph: cells of 203 rows
+    assert auto_plan(13_000_001, 1, 128, 10) == (49, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
     assert auto_plan(1_000_000, 1, 256, 10) == (3, 8)    # rows too wide for the resident kernel
     assert auto_plan(1_000_000, 2, 128, 10) == auto_plan(1_000_000, 2)  # several ranks: XCD cells
-    for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000):
+    for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000):
         for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40)):
             parts, slices = auto_plan(n, 1, ld, k)
             staging = 16 * 4 * ((ld + 3 * 32 + 2 * 32 * (k + 1) + 2 + 3) // 4 * 4) + 64
             fit = (160 * 1024 - staging) // (ld * 4)
             if slices > 8:
-                assert parts * slices <= 8192 and slices <= 256
+                assert parts * slices <= 65536 and slices <= 256
                 assert rows(n, parts, slices) <= fit, (n, ld, k, parts, slices)
             else:
                 assert (parts, slices) == auto_plan(n, 1)  # did not fit: the XCD plan
@@ -119,6 +122,11 @@ def test_round_size_and_groups_follow_the_free_memory():
     GB = 10 ** 9
     # the bench graph on one GPU: 38 x 8 cells, rounds at the cap, four groups of <= 10 parts
     assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 38, 8, False) == (1 << 23, 10)
+    # the same graph in resident cells (193 x 256): a group is at most 8 192 cells = 32 parts --
+    # the extraction counts them in LDS -- and fewer when a long walk's staging leaves less room
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 193, 256, False) == (1 << 23, 32)
+    assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 193, 256, False)[1] == 32
+    assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 193, 256, False)[1] == 12
     # eight GPUs, a group in preparation while one trains
     assert round_plan(270 * GB, 10_000_000, 128, 5, 8, 32, 8, True) == (1 << 23, 8)
     # 100 M nodes on one GPU, 170 GB free beside the tables

@@ -142,8 +142,10 @@ def test_config3_arxiv_shaped_block_path_full_size_properties():
 
 
 def test_config4_products_shaped_block_path_full_size_properties():
+    """BASELINE config 4's shape on one GPU: resident cells, 48 parts x 256 cells of 200 rows
+    (up to round 4's cell limit of 8 192: 9 x 8 XCD cells)."""
     g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
-    block_path_properties(g, 1 << 16, {"parts": 9, "slices": 8})
+    block_path_properties(g, 1 << 16, {"parts": 48, "slices": 256})
 
 
 def test_config4_block_path_with_the_parts_trained_in_node_order(monkeypatch):
@@ -152,11 +154,23 @@ def test_config4_block_path_with_the_parts_trained_in_node_order(monkeypatch):
     falls back to when the scratch copy of the part-major layout would not fit.  Same properties."""
     monkeypatch.setenv("GN2V_BLOCK_LAYOUT", "natural")
     g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
-    block_path_properties(g, 1 << 16, {"parts": 9, "slices": 8})
+    block_path_properties(g, 1 << 16, {"parts": 48, "slices": 256})
 
 
 def test_config5a_bench_graph_block_path_full_size_properties():
-    """The roofline configuration (BA 10 M / 100 M) through the path the bench times."""
+    """The roofline configuration (BA 10 M / 100 M) through the path the bench times: resident
+    cells, 193 parts x 256 cells of 203 rows; the extraction counts a group's cells in LDS, so a
+    group holds 8 192 cells = 32 parts."""
+    g = E.barabasi_albert(10_000_000, 10, 42)
+    plan, _ = block_path_properties(g, 1 << 17, {"parts": 193, "slices": 256})
+    assert plan["group_parts"] == 32
+
+
+def test_config5a_bench_graph_with_xcd_cells(monkeypatch):
+    """The same graph with the resident cells switched off (GN2V_RESIDENT_MAX_NODES): the XCD
+    cells of rounds 2-4, 38 x 8 cells of 32.9 k rows -- what graphs beyond 13 M nodes, rows wider
+    than 128 floats and graphs with a dominating hub keep running."""
+    monkeypatch.setenv("GN2V_RESIDENT_MAX_NODES", "1500000")
     g = E.barabasi_albert(10_000_000, 10, 42)
     plan, _ = block_path_properties(g, 1 << 17, {"parts": 38, "slices": 8})
     assert plan["group_parts"] == 10  # four groups of parts per round
