@@ -126,7 +126,7 @@ def test_round_size_and_groups_follow_the_free_memory():
     # the extraction counts them in LDS -- and fewer when a long walk's staging leaves less room
     assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 193, 256, False) == (1 << 23, 32)
     assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 193, 256, False)[1] == 32
-    assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 193, 256, False)[1] == 12
+    assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 193, 256, False)[1] == 14
     # eight GPUs, a group in preparation while one trains
     assert round_plan(270 * GB, 10_000_000, 128, 5, 8, 32, 8, True) == (1 << 23, 8)
     # 100 M nodes on one GPU, 170 GB free beside the tables
