@@ -604,7 +604,7 @@ def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
 
 def test_bad_plans_are_refused(karate):
     for kw in (dict(world=2, rank=2, parts=4), dict(world=2, rank=0, parts=0),
-               dict(world=1, rank=0, parts=1, slices=257), dict(world=1, rank=0, parts=9000),
+               dict(world=1, rank=0, parts=1, slices=257), dict(world=1, rank=0, parts=70000),
                dict(world=1, rank=0, parts=1, record=33), dict(world=1, rank=0, parts=1, hot_rows=193),
                dict(world=1, rank=0, parts=1, hot_rows=4, hot_flush=12)):
         args = dict(slices=1, walk_length=8, window=2)
@@ -711,8 +711,8 @@ def test_parts_come_back_in_node_order_also_through_host_memory(on_host, monkeyp
     initial tables: every row must be back at its node's place, bit for bit."""
     if on_host:
         monkeypatch.setenv("GN2V_BLOCK_RESTORE_ON_HOST", "1")
-    n, d = 120_000, 128
-    g = E.barabasi_albert(n, 5, 3)
+    n, d = 200_000, 128
+    g = E.barabasi_albert(n, 8, 3)
     m = E.models.SkipGram(embedding_size=d, epochs=1, iterations=1, walk_length=16, window_size=3,
                           learning_rate=0.0, verbose=False)
     c, x, st = m.fit_transform_device(g)
