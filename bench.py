@@ -805,7 +805,11 @@ def main():
                         "workload) / time / peak: bandwidth, never above 1.  frac = SURVEY 8d's "
                         "schedule-independent bytes (every row of every pair read and written in "
                         "HBM) / time / peak: it prices work and may exceed 1 because the centre row "
-                        "of a run stays in registers and the XCD's L2 serves hub rows; "
+                        "of a run stays in registers and the XCD's L2 serves hub rows -- and, with "
+                        "resident cells (gn2v::sgns_resident_kernel), because every contextual row "
+                        "of a launch lives in the LDS of the workgroup that owns its cell: only the "
+                        "central rows and the pair words move through HBM, and the kernel is bound "
+                        "by LDS latency and instruction issue, not by HBM; "
                         "frac_scheduled counts the centre once per run",
             },
         }
