@@ -715,7 +715,7 @@ def main():
                       else "gn2v::cbow_kernel")
         elif blocks_view is not None:
             # more than one slice per XCD: resident cells (gn2v_block_step's own rule)
-            kernel = ("gn2v::sgns_resident_kernel" if blocks_view.slices > 8 and t_world == 1
+            kernel = ("gn2v::sgns_resident_kernel" if blocks_view.slices > 8
                       else "gn2v::sgns_block_kernel")
         elif n >= (1 << 16) and args.mode in ("auto", "write_through", "write_back"):
             kernel = "gn2v::sgns_cached_kernel"
@@ -764,7 +764,7 @@ def main():
                               f"{blocks_view.slices if blocks_view else 0} "
                               + ("resident cells (every contextual row in the LDS of the one "
                                  "workgroup that owns its cell)"
-                                 if blocks_view is not None and blocks_view.slices > 8 and t_world == 1
+                                 if blocks_view is not None and blocks_view.slices > 8
                                  else "XCD slice(s) (no shared rows)") + ", rounds of "
                               f"{min(args.round_walks, args.steps * args.walks)} walks per GPU "
                               f"prepared {blocks_view.group_parts if blocks_view else 0} parts at a time"

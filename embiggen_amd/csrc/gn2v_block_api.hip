@@ -695,15 +695,27 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
     // 2 708 nodes, 0.994 vs 0.998 at 20 k; equal from 200 k nodes, 0.956 vs 0.920 at 1 M after
     // three epochs: DESIGN.md 7.3) -- the negatives of a pair come from its context's cell.
     const uint64_t max_nodes = env_size("GN2V_RESIDENT_MAX_NODES", GN2V_RESIDENT_MAX_NODES);
-    const uint64_t fit = allow_resident && world == 1 && n_nodes >= GN2V_RESIDENT_MIN_NODES &&
+    const uint64_t fit = allow_resident && n_nodes >= GN2V_RESIDENT_MIN_NODES &&
                                  n_nodes <= max_nodes
                              ? resident_rows(ld, 32, k) : 0;
     if (fit >= 16 && n_nodes <= fit * (gn2v::kMaxCells - 512)) {
         const uint64_t cells = (n_nodes + fit - 1) / fit;
         uint64_t sl = std::min<uint64_t>(cells, kMaxSlices), p = (cells + sl - 1) / sl;
+        // several ranks: the parts travel -- a multiple of the ranks, at least two per rank, and
+        // no more slices than keep the cells full (a launch is one workgroup per slice: graphs
+        // too small for 64 of them per part keep the XCD cells)
+        if (world > 1) {
+            p = std::max<uint64_t>(2ull * world, (p + world - 1) / world * world);
+            sl = std::min<uint64_t>(kMaxSlices, (cells + p - 1) / p);
+        }
         // striping rounds up twice: make sure the largest cell fits
-        while (gn2v::stripe_count(gn2v::stripe_count(n_nodes, 0, p), 0, sl) > fit) ++p;
-        if (p * sl <= gn2v::kMaxCells) {
+        while (gn2v::stripe_count(gn2v::stripe_count(n_nodes, 0, p), 0, sl) > fit) {
+            if (world > 1 && sl < kMaxSlices)
+                ++sl;
+            else
+                p += world;
+        }
+        if (p * sl <= gn2v::kMaxCells && (world == 1 || sl >= 64)) {
             *parts = (uint32_t)p;
             *slices = (uint32_t)sl;
             return 0;
