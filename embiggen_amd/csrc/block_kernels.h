@@ -399,6 +399,8 @@ struct BlockArgs {
     GraphView g;
     BlockPlan p;
     const unsigned long long *pairs;  // sorted pair words (see the head of this file)
+    float *const *part_ptrs;  // resident cells, a group of parts per launch: the rows of part p
+                              // (blockIdx.y counts from `part`); nullptr: `context` is the part's
     const unsigned long long *cell_offsets;  // [cells + 1] into pairs
     const unsigned long long *alias;      // alias tables (threshold | alias << 32), or nullptr:
                                           // negatives uniform over the rows of the cell
@@ -1090,6 +1092,14 @@ __global__ __launch_bounds__(1024) void sgns_resident_kernel(BlockArgs a) {
     uint32_t *s_nb = s_rows + 2 * C * (k + 1);
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t slice = blockIdx.x;
+    // A launch covers a GROUP of parts (blockIdx.y) when the caller holds them all: a launch of
+    // one part lasts as long as its heaviest cell -- and the striping puts one of the graph's
+    // oldest hubs into every part -- while the workgroups of a group are handed to the CUs as
+    // they fall free (BA 10 M: a part's heaviest cell carries 1.5-9 x the average cell).
+    if (a.part_ptrs) {
+        a.part += blockIdx.y;
+        a.context = a.part_ptrs[a.part];
+    }
     const uint32_t cell = a.part * a.p.slices + slice;
     const uint64_t lo = a.cell_offsets[cell], hi = a.cell_offsets[cell + 1];
     if (hi == lo) return;  // the same for every wave of the workgroup

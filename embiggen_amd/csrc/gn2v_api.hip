@@ -682,6 +682,7 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->own_node_types) (void)hipFree(g->own_node_types);
     if (g->own_edge_types) (void)hipFree(g->own_edge_types);
     if (g->counters) (void)hipFree(g->counters);
+    if (g->part_ptrs_dev) (void)hipFree(g->part_ptrs_dev);
     if (g->cursors) (void)hipFree(g->cursors);
     if (g->edge_set) (void)hipFree(g->edge_set);
     if (g->edge_filter) (void)hipFree(g->edge_filter);

@@ -407,9 +407,12 @@ static void launch_resident_ch(dim3 grid, size_t lds, hipStream_t s, const gn2v:
 }
 }  // extern "C++"
 
-int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
-                    const gn2v_block_io *io, uint64_t seed, uint64_t epoch, float lr,
-                    void *stream) {
+// part_n > 1: the parts io->part .. io->part + part_n - 1 in ONE launch (resident cells only;
+// d_part_ptrs[p] = the rows of part p, on the device); *took_group says whether that happened
+// (false: the plan is not resident here and nothing was launched)
+static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
+                      const gn2v_block_io *io, uint64_t seed, uint64_t epoch, float lr,
+                      void *stream, uint32_t part_n, float *const *d_part_ptrs, bool *took_group) {
     if (check_plan(g, plan)) return 1;
     const gn2v::BlockPlan d = device_plan(g, plan);
     if (check_key_width(d)) return 1;
@@ -419,8 +422,9 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     if (tp->ld > 1024) return fail("embedding sizes above 1024 are not supported");
     if (!std::isfinite(lr) || !std::isfinite(tp->clip) || tp->clip <= 0.f)
         return fail("learning rate / clipping value must be finite, clipping value positive");
-    if (io->part >= plan->parts) return fail("part out of range");
-    if (!io->d_pairs || !io->d_cell_offsets || !io->d_central || !io->d_context)
+    if (io->part >= plan->parts || part_n < 1 || io->part + part_n > plan->parts)
+        return fail("part out of range");
+    if (!io->d_pairs || !io->d_cell_offsets || !io->d_central || (!io->d_context && part_n == 1))
         return fail("NULL pointer");
     if ((tp->flags & GN2V_TRAIN_SCALE_FREE) && (!io->d_alias || !io->d_cell_rows))
         return fail("degree-proportional negatives need the tables of gn2v_block_alias");
@@ -514,6 +518,11 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     if (d.slices > gn2v_host::kCursorSlices && !resident)
         return fail("more than 16 slices need cells that fit a workgroup's LDS (default update "
                     "mode, rows up to 128 floats)");
+    if (part_n > 1) {
+        *took_group = resident;
+        if (!resident) return 0;
+        a.part_ptrs = d_part_ptrs;
+    }
     if (resident) {
         const size_t lds = block_lds_words_per_wave(tp->ld, d.record, tp->k) * 4 * 16 +
                            (size_t)max_cell_rows * tp->ld * 4 + 16;
@@ -528,9 +537,9 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
         if (get_events(g, &ev)) return 1;
         HIP_TRY(hipEventRecord(ev.a, s));
         if (tp->ld <= 64)
-            launch_resident_ch<1>(dim3(d.slices), lds, s, a);
+            launch_resident_ch<1>(dim3(d.slices, part_n), lds, s, a);
         else
-            launch_resident_ch<2>(dim3(d.slices), lds, s, a);
+            launch_resident_ch<2>(dim3(d.slices, part_n), lds, s, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev.b, s));
         g->train_events.push_back(ev);
@@ -637,6 +646,11 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
     return 0;
 }
 
+int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plan,
+                    const gn2v_block_io *io, uint64_t seed, uint64_t epoch, float lr,
+                    void *stream) {
+    return block_step(g, tp, plan, io, seed, epoch, lr, stream, 1, nullptr, nullptr);
+}
 
 }  // extern "C"
 
@@ -853,7 +867,39 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
                                io->d_work, io->d_hub_bits, n_pairs, io->d_pairs, io->d_temp,
                                io->temp_bytes, s))
             return 1;
-        for (uint32_t p = p0; p < p0 + pn; ++p) {
+        // resident cells: the whole group in one launch (its workgroups are handed to the CUs
+        // as they fall free; a launch per part would wait for the part's heaviest cell)
+        bool took_group = false;
+        if (pn > 1 && !getenv("GN2V_RESIDENT_PART_LAUNCHES")) {
+            std::vector<float *> ptrs(io->context_parts, io->context_parts + parts);
+            if (!g->part_ptrs_dev || ptrs != g->part_ptrs_host) {
+                HIP_TRY(hipStreamSynchronize(s));  // no launch may still read the old pointers
+                if (g->part_ptrs_dev && g->part_ptrs_host.size() < parts) {
+                    (void)hipFree(g->part_ptrs_dev);
+                    g->part_ptrs_dev = nullptr;
+                }
+                if (!g->part_ptrs_dev) HIP_TRY(hipMalloc((void **)&g->part_ptrs_dev, parts * sizeof(float *)));
+                HIP_TRY(hipMemcpy(g->part_ptrs_dev, ptrs.data(), parts * sizeof(float *),
+                                  hipMemcpyHostToDevice));
+                g->part_ptrs_host = ptrs;
+            }
+            gn2v_block_io step{};
+            step.d_pairs = io->d_pairs;
+            step.d_cell_offsets = io->d_cell_offsets;
+            step.d_alias = io->d_alias;
+            step.d_cell_rows = io->d_cell_rows;
+            step.d_hot_list = io->d_hot_list;
+            step.d_hot_slot = io->d_hot_slot;
+            step.d_central = io->d_central + (size_t)j * ld;
+            step.central_ld = (uint64_t)stripes * ld;
+            step.d_context = nullptr;
+            step.context_ld = io->context_ld;
+            step.block_id = round_id * stripes + j;
+            step.part = p0;
+            if (block_step(g, tp, pj, &step, seed, epoch, lr, s, pn, g->part_ptrs_dev, &took_group))
+                return 1;
+        }
+        for (uint32_t p = p0; p < p0 + pn && !took_group; ++p) {
             gn2v_block_io step{};
             step.d_pairs = io->d_pairs;
             step.d_cell_offsets = io->d_cell_offsets;

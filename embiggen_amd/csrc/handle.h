@@ -84,6 +84,9 @@ struct gn2v_graph {
     // the second-order sampler's edge set (GraphView.edge_set), built on the first biased walk
     unsigned long long *edge_set = nullptr, *edge_filter = nullptr;
     bool edge_set_tried = false;
+    // resident cells, a group of parts per launch: the parts' row pointers on the device
+    std::vector<float *> part_ptrs_host;
+    float **part_ptrs_dev = nullptr;
     // largest in-degree (the most frequent context), computed on the first automatic plan
     uint64_t max_in_degree = 0;
     bool max_in_degree_known = false;
