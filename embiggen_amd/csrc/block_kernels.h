@@ -576,7 +576,7 @@ __device__ __forceinline__ void score_sample(const BlockArgs &a, const HotLds &h
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const float dot = dot_rows<CH>(u, v);
-        const float var = valid ? (lab - sigmoid_clipped(dot, a.clip)) * lrc : 0.f;
+        const float var = valid ? (lab - sigmoid_clipped_fast(dot, a.clip)) * lrc : 0.f;
         axpy<CH>(g, var, v);
         asm volatile("" ::: "memory");  // the second read is a read, not the first one's registers
         if (valid) {
@@ -656,6 +656,69 @@ __device__ __forceinline__ void score_sample(const BlockArgs &a, const HotLds &h
             scatter_add<CH, WMX>(base, q, nchunks, var, u, w);
         } else {
             scatter_add<CH, WMX>(base, q, nchunks, var, u, v);
+        }
+    }
+}
+
+// Resident cells, two samples of a pair side by side: the chain of a sample -- LDS read, dot,
+// reduction over the 16 lanes, sigmoid, second read, stores -- is serial, and four waves a SIMD do
+// not hide it; two independent chains do.  Exactly the sequential result while the two rows
+// differ (the caller takes them one after the other when they are the same row).
+// dot product over the 16 lanes of a group with two-wide accumulators (v_pk_fma_f32: half the
+// instructions of the element-by-element sum; the kernel is bound by instruction issue)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int CH>
+__device__ __forceinline__ float dot_rows_pk(const Row<CH> &a, const Row<CH> &b) {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        acc += f32x2{a.c[cc].x, a.c[cc].y} * f32x2{b.c[cc].x, b.c[cc].y};
+        acc += f32x2{a.c[cc].z, a.c[cc].w} * f32x2{b.c[cc].z, b.c[cc].w};
+    }
+    return group16_sum(acc.x + acc.y);
+}
+
+template <int CH>
+__device__ __forceinline__ void score_sample_pair(const BlockArgs &a, const HotLds &h,
+                                                  const Row<CH> &u, Row<CH> &g, uint32_t row_a,
+                                                  float lab_a, uint32_t row_b, float lab_b,
+                                                  float lrc, int q, uint32_t nchunks) {
+    // an invalid sample (a negative that fell on the context or the centre; the tail of a record)
+    // reads row 0 and contributes var = 0; only its stores are skipped -- a store of row + 0
+    // could undo another group's update of that row
+    const bool va = row_a != kSentinel, vb = row_b != kSentinel;
+    float *ra = h.base + (va ? row_a : 0u) * h.ld, *rb = h.base + (vb ? row_b : 0u) * h.ld;
+    Row<CH> xa, xb;
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        const uint32_t ci = cc * 16 + q;
+        xa.c[cc] = ci < nchunks ? *reinterpret_cast<const float4 *>(ra + ci * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        xb.c[cc] = ci < nchunks ? *reinterpret_cast<const float4 *>(rb + ci * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float dot_a = dot_rows_pk<CH>(u, xa), dot_b = dot_rows_pk<CH>(u, xb);
+    const float var_a = va ? (lab_a - sigmoid_clipped_fast(dot_a, a.clip)) * lrc : 0.f;
+    const float var_b = vb ? (lab_b - sigmoid_clipped_fast(dot_b, a.clip)) * lrc : 0.f;
+    axpy<CH>(g, var_a, xa);
+    axpy<CH>(g, var_b, xb);
+    asm volatile("" ::: "memory");  // the second reads are reads
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        const uint32_t ci = cc * 16 + q;
+        if (ci < nchunks) {
+            float4 oa = *reinterpret_cast<const float4 *>(ra + ci * 4);
+            float4 ob = *reinterpret_cast<const float4 *>(rb + ci * 4);
+            oa.x += var_a * u.c[cc].x;
+            oa.y += var_a * u.c[cc].y;
+            oa.z += var_a * u.c[cc].z;
+            oa.w += var_a * u.c[cc].w;
+            ob.x += var_b * u.c[cc].x;
+            ob.y += var_b * u.c[cc].y;
+            ob.z += var_b * u.c[cc].z;
+            ob.w += var_b * u.c[cc].w;
+            if (va) *reinterpret_cast<float4 *>(ra + ci * 4) = oa;
+            if (vb) *reinterpret_cast<float4 *>(rb + ci * 4) = ob;
         }
     }
 }
@@ -764,13 +827,28 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
         }
         if (n_runs * 100 >= n * kPpgMinPct) {
             const uint32_t kk = k + 1;
+            // the central rows of the NEXT four pairs are fetched while these four are scored (a
+            // memory round trip per pair otherwise); a pair whose centre one of these four also
+            // has then starts from the row before their gradients -- like a pair of another wave
+            // (resident cells only: the XCD cells' kernels sit on their register budget)
+            Row<CH> u_next;
+            if constexpr (RES)
+                load_row<CH>(u_next, a.central + (uint64_t)s_key[(uint32_t)grp < n ? grp : 0] * a.cld,
+                             q, nchunks, (uint32_t)grp < n);
             for (uint32_t p4 = 0; p4 < n; p4 += 4) {
                 const uint32_t pr = p4 + grp;
                 const bool have = pr < n;
                 const uint32_t crow_id = s_key[have ? pr : 0];
                 float *crow = a.central + (uint64_t)crow_id * a.cld;
                 Row<CH> u, g;
-                load_row<CH>(u, crow, q, nchunks, have);
+                if constexpr (RES) {
+                    u = u_next;
+                    const uint32_t nx = pr + 4;
+                    load_row<CH>(u_next, a.central + (uint64_t)s_key[nx < n ? nx : 0] * a.cld, q,
+                                 nchunks, nx < n);
+                } else {
+                    load_row<CH>(u, crow, q, nchunks, have);
+                }
                 zero_row<CH>(g);
                 float lrc = a.lr;
                 if (a.flags & kFlagNormLr) {
@@ -778,7 +856,23 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
                     const uint64_t deg = a.g.row_ptr[c + 1] - a.g.row_ptr[c];
                     if (deg) lrc = a.lr / (float)deg;
                 }
-                for (uint32_t sidx = 0; sidx < kk; ++sidx) {
+                uint32_t sidx = 0;
+                if constexpr (RES) {
+                    for (; sidx + 1 < kk; sidx += 2) {
+                        const uint32_t t = (have ? pr : 0) * kk + sidx;
+                        const uint32_t row_a = have ? s_rows[t] : kSentinel;
+                        const uint32_t row_b = have ? s_rows[t + 1] : kSentinel;
+                        if (__ballot(row_a == row_b && row_a != kSentinel)) {  // one row twice
+                            score_sample<CH, WMX, RES>(a, h, u, g, row_a, s_lab[t], lrc, q, nchunks);
+                            score_sample<CH, WMX, RES>(a, h, u, g, row_b, s_lab[t + 1], lrc, q,
+                                                       nchunks);
+                        } else {
+                            score_sample_pair<CH>(a, h, u, g, row_a, s_lab[t], row_b, s_lab[t + 1],
+                                                  lrc, q, nchunks);
+                        }
+                    }
+                }
+                for (; sidx < kk; ++sidx) {
                     const uint32_t t = (have ? pr : 0) * kk + sidx;
                     const uint32_t row = have ? s_rows[t] : kSentinel;
                     score_sample<CH, WMX, RES>(a, h, u, g, row, s_lab[t], lrc, q, nchunks);

@@ -9,6 +9,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -944,6 +945,17 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     hipStream_t s = (hipStream_t)stream;
     const uint64_t n = g->view.n_nodes;
     const uint32_t L = wp->walk_length, w = tp->window, ld = tp->ld;
+    // GN2V_TRAIN_TIMING=1: host-side phase times of this call on stderr (each mark synchronises)
+    const bool timing = getenv("GN2V_TRAIN_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gn2v_train_blocks] %-28s %9.2f ms\n", what,
+                std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
 
     // Centre stripes ("virtual ranks"): stripe j = the centres c with c % V == j is trained over
     // the pairs of ALL the round's walks before stripe j + 1 -- what V ranks do side by side.
@@ -981,6 +993,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     plan = plans[0];
     const uint32_t parts = plan.parts, cells = parts * plan.slices;
     const bool scale_free = tp->flags & GN2V_TRAIN_SCALE_FREE;
+    mark("plan");
 
     uint64_t walks_per_epoch = g->view.n_sources * (uint64_t)wp->iterations;
     if (max_walks_per_epoch && max_walks_per_epoch < walks_per_epoch)
@@ -1008,6 +1021,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         buf.ptrs.pop_back();
     }
 
+    mark("alias tables");
     // round size and groups of parts: `round_walks` = the walks one pass extracts from (a round is
     // V times that); the pairs of a round are extracted, sorted and trained a group at a time
     const bool automatic = round_walks == 0;
@@ -1056,6 +1070,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
             return kOutOfMemory;
     }
     const uint64_t super_walks = V * round_walks;
+    mark("round buffers");
 
     // The contextual table is trained in the caller's buffer -- no third table exists during the
     // fit -- stored part by part (the rows of part p one after the other from row first_row[p]: a
@@ -1104,6 +1119,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     rio.temp_bytes = tb;
     rio.group_parts = group_parts;
 
+    mark("tables initialised");
     float lr = tp->lr;
     uint64_t round_id = 0;
     for (uint32_t e = 0; e < tp->epochs; ++e) {
@@ -1132,7 +1148,9 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         lr *= tp->lr_decay;
     }
     HIP_TRY(hipStreamSynchronize(s));
+    mark("rounds");
     release_round();
+    mark("round buffers released");
     if (part_major) {  // part-major -> natural order
         float *scratch = nullptr;
         void *raw = nullptr;
@@ -1170,6 +1188,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
                             hipGetErrorString(e));
         }
     }
+    mark("node order restored");
     if (stats) {
         if (gn2v_stats_read(g, stats, s)) return 1;
         stats->block_parts = parts;
