@@ -350,12 +350,15 @@ int gn2v_graph_reserve_cus(gn2v_graph *g, uint32_t cus_per_xcd, uint32_t *active
 int gn2v_graph_xcds(gn2v_graph *g);
 
 /* (parts, slices) of the contextual table for a graph of n_nodes on `world` ranks.
- * One GPU, row stride ld <= 128 floats (ld = 0: unknown, this rule is skipped), k negatives, a
- * graph of GN2V_RESIDENT_MIN_NODES up to ~1.5 M nodes (d = 128): RESIDENT CELLS -- cells of at most
- * the ~200 rows that fit one workgroup's LDS beside its staging, up to GN2V_BLOCK_MAX_SLICES
- * slices per part (a launch = a part = one workgroup per cell), as many parts as needed (169 k
- * nodes: 4 x 256 cells of 166 rows; 1 M: 20 x 256).  gn2v_block_step then reads and updates every
- * contextual row in the LDS of the one workgroup that owns it: no other CU races for it.
+ * Row stride ld <= 128 floats (ld = 0: unknown, this rule is skipped), k negatives, a graph of
+ * GN2V_RESIDENT_MIN_NODES up to GN2V_RESIDENT_MAX_NODES nodes: RESIDENT CELLS -- cells of at
+ * most the ~200 rows that fit one workgroup's LDS beside its staging, up to
+ * GN2V_BLOCK_MAX_SLICES slices per part (one workgroup per cell), as many parts as needed (169 k
+ * nodes: 4 x 256 cells of 166 rows; 1 M: 20 x 256; 10 M: 193 x 256; several ranks: parts a
+ * multiple of the ranks, at least two per rank, slices to match while a part keeps 64 cells).
+ * gn2v_block_step then reads and updates every contextual row in the LDS of the one workgroup
+ * that owns it: no other CU races for it; gn2v_block_round launches a whole group of parts at
+ * once, so that no CU waits for a part's heaviest cell.
  * Otherwise XCD CELLS: slices = 8 (one per XCD; 1 on graphs too small to keep 8 192 rows in a
  * cell) and as many parts (any count; a multiple of world, at least two per rank) as keep
  * >= 32 768 rows in a cell -- the size from which the link quality of racing stores is at or above
