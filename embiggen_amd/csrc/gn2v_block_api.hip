@@ -773,15 +773,16 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     if (auto_plan(g->view.n_nodes, world, ld, k, true, parts, slices)) return 1;
     if (*slices <= 8) return 0;  // XCD cells
-    // Resident cells: a launch is one workgroup per cell, and it lasts as long as its heaviest
-    // cell.  The cell of the most frequent context receives in_degree / edges of all pairs on top
-    // of its 1 / cells; over a round that costs up to in_degree / edges x slices of the time
-    // (resident cells run at ~0.6 of the XCD cells' time, so they stop paying at ~0.65).  A graph
-    // with a hub beyond half of edges / slices keeps the XCD cells, whose records are handed out
-    // by tickets to every workgroup of the slice.
+    // Resident cells: one workgroup per cell, and a launch cannot end before its heaviest cell.
+    // The cell of the most frequent context receives in_degree / edges of ALL pairs on top of its
+    // 1 / cells; a launch covers a group of parts whose other cells keep the remaining CUs busy,
+    // but once that share exceeds the group's own (its cells / all cells / CUs) the round grows
+    // by about in_degree / edges x slices.  Resident cells run at a third of the XCD cells' time:
+    // a graph whose hub would cost more than one extra round's worth (x slices > 1) keeps the XCD
+    // cells, whose records are handed out by tickets to every workgroup of a slice.
     uint64_t hub = 0;
     if (max_in_degree(g, (hipStream_t)stream, &hub)) return 1;
-    static const size_t skew_pct = env_size("GN2V_RESIDENT_MAX_SKEW_PCT", 50);
+    static const size_t skew_pct = env_size("GN2V_RESIDENT_MAX_SKEW_PCT", 100);
     if ((double)hub * *slices * 100.0 > (double)skew_pct * (double)g->view.n_edges)
         return auto_plan(g->view.n_nodes, world, ld, k, false, parts, slices);
     return 0;

@@ -371,9 +371,9 @@ int gn2v_graph_xcds(gn2v_graph *g);
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
                          uint32_t *parts, uint32_t *slices);
 /* The same rule for a graph at hand (what gn2v_train_blocks and the Python trainer use): resident
- * cells only while the graph's largest in-degree (computed once per handle) stays below half
- * of n_edges / slices -- a launch of resident cells lasts as long as its heaviest cell, and the
- * cell of a context that frequent would hold every launch up; such graphs keep the XCD cells,
+ * cells only while the graph's largest in-degree (computed once per handle) stays below
+ * n_edges / slices -- a launch of resident cells cannot end before its heaviest cell, and the
+ * cell of a context that frequent would hold its launch up for a round's worth; such graphs keep the XCD cells,
  * whose records are handed out by tickets to all workgroups of a slice. */
 int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint32_t k,
                                uint32_t *parts, uint32_t *slices, void *stream);
