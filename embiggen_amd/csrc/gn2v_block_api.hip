@@ -715,17 +715,24 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
                              ? resident_rows(ld, 32, k) : 0;
     if (fit >= 16 && n_nodes <= fit * (gn2v::kMaxCells - 512)) {
         const uint64_t cells = (n_nodes + fit - 1) / fit;
-        uint64_t sl = std::min<uint64_t>(cells, kMaxSlices), p = (cells + sl - 1) / sl;
-        // several ranks: the parts travel -- a multiple of the ranks, at least two per rank, and
-        // no more slices than keep the cells full (a launch is one workgroup per slice: graphs
-        // too small for 64 of them per part keep the XCD cells)
+        // one GPU: 256 slices per part (gn2v_block_round launches a group of parts at once)
+        constexpr uint64_t kOneGpuSlices = 256;
+        uint64_t sl = std::min<uint64_t>(cells, kOneGpuSlices), p = (cells + sl - 1) / sl;
+        // Several ranks: the parts travel -- a multiple of the ranks, two per rank -- and a part is
+        // launched by itself (it leaves for the neighbour after its episode), so it brings as many
+        // cells as it can (up to 8 192 slices): a launch cannot end before its heaviest cell, and
+        // the striping puts one of the graph's oldest hubs into every part; with thousands of
+        // workgroups per launch the other cells keep the CUs busy meanwhile.  Graphs too small
+        // for 64 cells a part keep the XCD cells.
         if (world > 1) {
-            p = std::max<uint64_t>(2ull * world, (p + world - 1) / world * world);
+            p = std::max<uint64_t>(2ull * world,
+                                   ((cells + kMaxSlices - 1) / kMaxSlices + world - 1) / world * world);
             sl = std::min<uint64_t>(kMaxSlices, (cells + p - 1) / p);
         }
+        const uint64_t sl_max = world > 1 ? kMaxSlices : kOneGpuSlices;
         // striping rounds up twice: make sure the largest cell fits
         while (gn2v::stripe_count(gn2v::stripe_count(n_nodes, 0, p), 0, sl) > fit) {
-            if (world > 1 && sl < kMaxSlices)
+            if (world > 1 && sl < sl_max)
                 ++sl;
             else
                 p += world;
@@ -774,16 +781,16 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
     if (auto_plan(g->view.n_nodes, world, ld, k, true, parts, slices)) return 1;
     if (*slices <= 8) return 0;  // XCD cells
     // Resident cells: one workgroup per cell, and a launch cannot end before its heaviest cell.
-    // The cell of the most frequent context receives in_degree / edges of ALL pairs on top of its
-    // 1 / cells; a launch covers a group of parts whose other cells keep the remaining CUs busy,
-    // but once that share exceeds the group's own (its cells / all cells / CUs) the round grows
-    // by about in_degree / edges x slices.  Resident cells run at a third of the XCD cells' time:
-    // a graph whose hub would cost more than one extra round's worth (x slices > 1) keeps the XCD
-    // cells, whose records are handed out by tickets to every workgroup of a slice.
+    // The cell of the most frequent context receives h = in_degree / edges of ALL pairs on top of
+    // its 1 / cells, while a balanced round takes 1 / CUs of them per CU: the other cells of the
+    // launch (a group of parts, or a travelling part of thousands of cells) keep the CUs busy
+    // meanwhile, but a round cannot take less than h.  Resident cells run at a third of the XCD
+    // cells' time: a graph whose hub alone would cost a whole balanced round more (h x CUs > 1)
+    // keeps the XCD cells, whose records are handed out by tickets to every workgroup of a slice.
     uint64_t hub = 0;
     if (max_in_degree(g, (hipStream_t)stream, &hub)) return 1;
     static const size_t skew_pct = env_size("GN2V_RESIDENT_MAX_SKEW_PCT", 100);
-    if ((double)hub * *slices * 100.0 > (double)skew_pct * (double)g->view.n_edges)
+    if ((double)hub * g->n_cus * 100.0 > (double)skew_pct * (double)g->view.n_edges)
         return auto_plan(g->view.n_nodes, world, ld, k, false, parts, slices);
     return 0;
 }

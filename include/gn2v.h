@@ -354,8 +354,9 @@ int gn2v_graph_xcds(gn2v_graph *g);
  * GN2V_RESIDENT_MIN_NODES up to GN2V_RESIDENT_MAX_NODES nodes: RESIDENT CELLS -- cells of at
  * most the ~200 rows that fit one workgroup's LDS beside its staging, up to
  * GN2V_BLOCK_MAX_SLICES slices per part (one workgroup per cell), as many parts as needed (169 k
- * nodes: 4 x 256 cells of 166 rows; 1 M: 20 x 256; 10 M: 193 x 256; several ranks: parts a
- * multiple of the ranks, at least two per rank, slices to match while a part keeps 64 cells).
+ * nodes: 4 x 256 cells of 166 rows; 1 M: 20 x 256; 10 M: 193 x 256 -- 256 slices per part on
+ * one GPU; several ranks: two parts per rank with as many slices as hold the rows, 10 M nodes on
+ * 8 GPUs: 16 x 3 088, while a part keeps 64 cells).
  * gn2v_block_step then reads and updates every contextual row in the LDS of the one workgroup
  * that owns it: no other CU races for it; gn2v_block_round launches a whole group of parts at
  * once, so that no CU waits for a part's heaviest cell.
@@ -363,7 +364,7 @@ int gn2v_graph_xcds(gn2v_graph *g);
  * cell) and as many parts (any count; a multiple of world, at least two per rank) as keep
  * >= 32 768 rows in a cell -- the size from which the link quality of racing stores is at or above
  * the walk-ordered schedule's: 10 M nodes -> 38 x 8, 100 M -> 381 x 8. */
-#define GN2V_BLOCK_MAX_SLICES 256u
+#define GN2V_BLOCK_MAX_SLICES 8192u
 #define GN2V_BLOCK_MAX_CELLS 65536u       /* parts x slices of a plan                           */
 #define GN2V_BLOCK_MAX_GROUP_CELLS 8192u  /* parts of an extraction group x slices              */
 #define GN2V_RESIDENT_MIN_NODES 100000u
@@ -372,8 +373,9 @@ int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t
                          uint32_t *parts, uint32_t *slices);
 /* The same rule for a graph at hand (what gn2v_train_blocks and the Python trainer use): resident
  * cells only while the graph's largest in-degree (computed once per handle) stays below
- * n_edges / slices -- a launch of resident cells cannot end before its heaviest cell, and the
- * cell of a context that frequent would hold its launch up for a round's worth; such graphs keep the XCD cells,
+ * n_edges / CUs -- a launch of resident cells cannot end before its heaviest cell, and the cell
+ * of a context that frequent would hold its launch up for a round's worth; such graphs keep the
+ * XCD cells,
  * whose records are handed out by tickets to all workgroups of a slice. */
 int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint32_t k,
                                uint32_t *parts, uint32_t *slices, void *stream);

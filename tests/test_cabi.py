@@ -99,14 +99,14 @@ def test_automatic_plan_of_the_block_path():
     assert auto_plan(10_000_000, 1, 128, 10) == (193, 256)  # the bench graph: cells of 203 rows
     assert auto_plan(13_000_001, 1, 128, 10) == (49, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
     assert auto_plan(1_000_000, 1, 256, 10) == (3, 8)    # rows too wide for the resident kernel
-    # several ranks: the parts travel -- a multiple of the ranks, at least two per rank, slices to
-    # match -- while a part keeps 64 cells; smaller graphs travel as XCD cells
-    assert auto_plan(1_000_000, 2, 128, 10) == (20, 247) and auto_plan(1_000_000, 8, 128, 10) == (24, 206)
-    assert auto_plan(10_000_000, 8, 128, 10) == (200, 247)
+    # several ranks: the parts travel -- two per rank (more only beyond 8 192 slices), each launched
+    # by itself with all its cells -- while a part keeps 64 cells; smaller graphs travel as XCD cells
+    assert auto_plan(1_000_000, 2, 128, 10) == (4, 1232) and auto_plan(1_000_000, 8, 128, 10) == (16, 308)
+    assert auto_plan(10_000_000, 8, 128, 10) == (16, 3079) and auto_plan(10_000_000, 2, 128, 10) == (8, 6158)
     assert auto_plan(200_000, 8, 128, 10) == auto_plan(200_000, 8) == (16, 1)
     for n, world in ((1_000_000, 3), (2_449_029, 8), (10_000_000, 4), (13_000_000, 8)):
         parts, slices = auto_plan(n, world, 128, 10)
-        assert parts % world == 0 and parts >= 2 * world and 64 <= slices <= 256
+        assert parts % world == 0 and parts >= 2 * world and 64 <= slices <= 8192
         assert rows(n, parts, slices) <= 203 and parts * slices <= 65536
     for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000):
         for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40)):

@@ -226,8 +226,8 @@ def test_config4_block_trainer_with_eight_simulated_ranks_at_full_size():
     gen.manual_seed(1)
     auc_single = link_auc_device(g, c, x, gen)
     del c, x
-    # resident cells travel too: 48 parts (six per rank) x 252 cells of <= 203 rows
-    assert auto_plan(n, world, d, 10) == (48, 252) and auto_plan(n, world) == (16, 8)
+    # resident cells travel too: 16 parts (two per rank) x 755 cells of <= 203 rows
+    assert auto_plan(n, world, d, 10) == (16, 755) and auto_plan(n, world) == (16, 8)
 
     def rank_fn(comm):
         tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, comm, "cuda:0", walk_length=128,
@@ -247,7 +247,7 @@ def test_config4_block_trainer_with_eight_simulated_ranks_at_full_size():
     res = run_ranks(world, rank_fn)
     torch.cuda.synchronize()
     assert sum(r[0] for r in res) == total * PAIRS_PER_WALK == ops.stats_read(g)["pairs"]
-    assert sorted(p for r in res for p in r[1]) == list(range(48))
+    assert sorted(p for r in res for p in r[1]) == list(range(16))
     assert all(r[2] for r in res)
     bc, bx = res[0][3]
     gen.manual_seed(1)
