@@ -813,6 +813,13 @@ def main():
                         "frac_scheduled counts the centre once per run",
             },
         }
+        if kernel == "gn2v::sgns_resident_kernel":
+            # what bounds this kernel is not a byte count: say so next to the byte-based figures
+            line["roofline"]["limiter"] = (
+                "instruction issue: 196 VALU + 63 SALU + 32 LDS instructions per pair and wave, "
+                "vector pipes 64 % busy, LDS bank conflicts 0.8 % of the LDS cycles "
+                "(profiles/r04_resident_counters.json, rocprofv3 --pmc on this workload); the "
+                "contextual rows live in LDS, HBM carries the central rows and the pair words")
         if reserved is not None:
             line["config"]["reserved_cus_per_xcd"] = args.reserve_cus
             line["config"]["active_cus_per_xcd"] = reserved
