@@ -35,7 +35,7 @@ namespace gn2v {
 constexpr uint64_t kTagBlock = 0xB10C5EED0B10C5EDULL;
 constexpr int kPrepBlock = 256;
 constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
-constexpr uint32_t kMaxCells = GN2V_BLOCK_MAX_CELLS;   // parts x slices (resident cells at 10 M nodes: 200 x 256)
+constexpr uint32_t kMaxCells = GN2V_BLOCK_MAX_CELLS;   // parts x slices (resident cells at 100 M nodes: 1 925 x 256)
 constexpr uint32_t kMaxGroupCells = GN2V_BLOCK_MAX_GROUP_CELLS;  // one extraction group (LDS histogram)
 // negatives' stream of a cell: draw(key, block_id * kCellStreamStride + cell).  Plans of more
 // cells than the stride let (block, cell + stride) share its numbers with (block + 1, cell) --
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(WG) void sgns_block_kernel(BlockArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Resident cells: the plan of a small or mid-sized graph (gn2v_block_auto_plan: up to 13 M nodes
+// Resident cells: the plan of a small or mid-sized graph (gn2v_block_auto_plan: up to 106 M nodes
 // at d = 128) makes cells whose rows fit ONE workgroup's LDS.  A launch covers a part, one
 // workgroup of sixteen waves per cell: it loads the cell's contextual rows into LDS, trains ALL
 // the cell's records (its waves take them from an LDS cursor), reads and updates the rows in

@@ -476,7 +476,7 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     // keep it inside one L2, which is why they need no atomics from GN2V_BLOCK_PATH_MIN_NODES up).
     const bool exclusive = slices_are_xcd_exclusive(g, d.slices);
     // Resident cells (block_kernels.h sgns_resident_kernel): every cell of the plan fits one
-    // workgroup's LDS -- what gn2v_block_auto_plan arranges for graphs up to 13 M nodes at
+    // workgroup's LDS -- what gn2v_block_auto_plan arranges for graphs up to 106 M nodes at
     // d = 128.  One workgroup per cell, contextual rows read and updated in LDS: exact, whatever
     // the size of the graph (no flavour of store or atomic is involved).
     static const size_t resident_env = env_size("GN2V_BLOCK_RESIDENT", 1);  // 0: never (A/B)
@@ -701,7 +701,7 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
     if (!parts || !slices || world < 1) return fail("bad arguments");
     constexpr uint64_t kMinRows = 32768, kXcds = 8;
     // One GPU, rows up to 128 floats, a graph of GN2V_RESIDENT_MIN_NODES nodes or more that is
-    // small enough for cells that fit a workgroup's LDS (65 536 cells x ~200 rows at d = 128: 13 M
+    // small enough for cells that fit a workgroup's LDS (524 288 cells x ~200 rows at d = 128: 106 M
     // nodes): RESIDENT CELLS -- every contextual row is read and updated in the LDS of the one
     // workgroup that owns its cell (sgns_resident_kernel).  As few cells as hold the rows, up to
     // 256 slices per part (a launch covers a part: one workgroup per cell and CU).  Smaller

@@ -290,7 +290,7 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
  * grouped by cell and centre row, ties in walk / position / slot order (independent of the launch
  * geometry).  d_temp: gn2v_block_extract_temp_bytes(n_pairs) bytes (the unsorted words + the
  * sort's own storage). */
-#define GN2V_BLOCK_WORK_WORDS 73728 /* 8192 extraction waves + 65536 cells */
+#define GN2V_BLOCK_WORK_WORDS 532480 /* 8192 extraction waves + 524288 cells */
 int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
                      uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
                      uint32_t part_lo, uint32_t part_n, uint64_t *d_work,
@@ -365,10 +365,10 @@ int gn2v_graph_xcds(gn2v_graph *g);
  * >= 32 768 rows in a cell -- the size from which the link quality of racing stores is at or above
  * the walk-ordered schedule's: 10 M nodes -> 38 x 8, 100 M -> 381 x 8. */
 #define GN2V_BLOCK_MAX_SLICES 8192u
-#define GN2V_BLOCK_MAX_CELLS 65536u       /* parts x slices of a plan                           */
+#define GN2V_BLOCK_MAX_CELLS 524288u      /* parts x slices of a plan                           */
 #define GN2V_BLOCK_MAX_GROUP_CELLS 8192u  /* parts of an extraction group x slices              */
 #define GN2V_RESIDENT_MIN_NODES 100000u
-#define GN2V_RESIDENT_MAX_NODES 13000000u /* 65 024 cells of ~200 rows (d = 128, k = 10)        */
+#define GN2V_RESIDENT_MAX_NODES 106000000u /* 523 776 cells of ~200 rows (d = 128, k = 10)      */
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
                          uint32_t *parts, uint32_t *slices);
 /* The same rule for a graph at hand (what gn2v_train_blocks and the Python trainer use): resident

@@ -81,13 +81,13 @@ def test_automatic_plan_of_the_block_path():
     for n in (10 ** 5, 10 ** 6, 10 ** 7, 10 ** 8, 3 * 10 ** 9):
         for world in (1, 2, 3, 8):
             parts, slices = auto_plan(n, world)
-            assert parts % world == 0 and parts * slices <= 65536 and slices in (1, 8)
+            assert parts % world == 0 and parts * slices <= 524288 and slices in (1, 8)
             assert world == 1 or parts >= 2 * world
-            if parts > (1 if world == 1 else 2 * world) and parts * slices < 65536 - 8 * world:
+            if parts > (1 if world == 1 else 2 * world) and parts * slices < 524288 - 8 * world:
                 assert 32768 <= n // (parts * slices) < 2 * 32768 * (world + 1)
     # one GPU, the row width known (ld <= 128 floats): RESIDENT CELLS -- every cell fits one
     # workgroup's LDS (160 KB minus the sixteen waves' staging) -- up to GN2V_RESIDENT_MAX_NODES
-    # (13 M: 65 536 cells of ~200 rows at d = 128)
+    # (106 M: 524 288 cells of ~200 rows at d = 128)
     def rows(n, parts, slices):
         return -(-(-(-n // parts)) // slices)  # the largest cell: ceil(ceil(n / parts) / slices)
 
@@ -97,24 +97,25 @@ def test_automatic_plan_of_the_block_path():
     assert auto_plan(169_343, 1, 128, 10) == (4, 256)    # config 3's shape: cells of 166 rows
     assert auto_plan(2_449_029, 1, 128, 10) == (48, 256)  # config 4's shape
     assert auto_plan(10_000_000, 1, 128, 10) == (193, 256)  # the bench graph: cells of 203 rows
-    assert auto_plan(13_000_001, 1, 128, 10) == (49, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
+    assert auto_plan(100_000_000, 1, 128, 10) == (1925, 256)  # config 5: 492 800 cells
+    assert auto_plan(107_000_000, 1, 128, 10) == (408, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
     assert auto_plan(1_000_000, 1, 256, 10) == (3, 8)    # rows too wide for the resident kernel
     # several ranks: the parts travel -- two per rank (more only beyond 8 192 slices), each launched
     # by itself with all its cells -- while a part keeps 64 cells; smaller graphs travel as XCD cells
     assert auto_plan(1_000_000, 2, 128, 10) == (4, 1232) and auto_plan(1_000_000, 8, 128, 10) == (16, 308)
     assert auto_plan(10_000_000, 8, 128, 10) == (16, 3079) and auto_plan(10_000_000, 2, 128, 10) == (8, 6158)
     assert auto_plan(200_000, 8, 128, 10) == auto_plan(200_000, 8) == (16, 1)
-    for n, world in ((1_000_000, 3), (2_449_029, 8), (10_000_000, 4), (13_000_000, 8)):
+    for n, world in ((1_000_000, 3), (2_449_029, 8), (10_000_000, 4), (13_000_000, 8), (100_000_000, 8)):
         parts, slices = auto_plan(n, world, 128, 10)
         assert parts % world == 0 and parts >= 2 * world and 64 <= slices <= 8192
-        assert rows(n, parts, slices) <= 203 and parts * slices <= 65536
-    for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000):
+        assert rows(n, parts, slices) <= 203 and parts * slices <= 524288
+    for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000, 300_000_000):
         for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40)):
             parts, slices = auto_plan(n, 1, ld, k)
             staging = 16 * 4 * ((ld + 3 * 32 + 2 * 32 * (k + 1) + 2 + 3) // 4 * 4) + 64
             fit = (160 * 1024 - staging) // (ld * 4)
             if slices > 8:
-                assert parts * slices <= 65536 and slices <= 256
+                assert parts * slices <= 524288 and slices <= 256
                 assert rows(n, parts, slices) <= fit, (n, ld, k, parts, slices)
             else:
                 assert (parts, slices) == auto_plan(n, 1)  # did not fit: the XCD plan

@@ -604,7 +604,7 @@ def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
 
 def test_bad_plans_are_refused(karate):
     for kw in (dict(world=2, rank=2, parts=4), dict(world=2, rank=0, parts=0),
-               dict(world=1, rank=0, parts=1, slices=8193), dict(world=1, rank=0, parts=70000),
+               dict(world=1, rank=0, parts=1, slices=8193), dict(world=1, rank=0, parts=600000),
                dict(world=1, rank=0, parts=1, record=33), dict(world=1, rank=0, parts=1, hot_rows=193),
                dict(world=1, rank=0, parts=1, hot_rows=4, hot_flush=12)):
         args = dict(slices=1, walk_length=8, window=2)

@@ -177,9 +177,19 @@ def test_config5a_bench_graph_with_xcd_cells(monkeypatch):
 
 
 def test_config5_ba_100m_block_path_full_size_properties():
-    """BASELINE config 5 (BA 100 M / 1 B) on one GPU: 381 x 8 cells of 32.8 k rows, 56-bit pair
-    words (12 + 27 + 17), 100 M-row alias tables, the 51.2 GB contextual table trained part-major
-    in the caller's buffer and restored through one scratch copy."""
+    """BASELINE config 5 (BA 100 M / 1 B) on one GPU: resident cells, 1 925 parts x 256 cells of
+    203 rows (492 800 cells: 55-bit pair words, 19 + 27 + 9), extracted 32 parts at a time,
+    100 M-row alias tables, the 51.2 GB contextual table trained part-major in the caller's
+    buffer and restored through one scratch copy."""
+    g = E.barabasi_albert(100_000_000, 10, 42)
+    plan, _ = block_path_properties(g, 1 << 17, {"parts": 1925, "slices": 256})
+    assert plan["group_parts"] == 32
+
+
+def test_config5_ba_100m_with_xcd_cells(monkeypatch):
+    """The same graph with the resident cells switched off: 381 x 8 XCD cells of 32.8 k rows,
+    56-bit pair words (12 + 27 + 17) -- the plan of graphs beyond 106 M nodes."""
+    monkeypatch.setenv("GN2V_RESIDENT_MAX_NODES", "1500000")
     g = E.barabasi_albert(100_000_000, 10, 42)
     plan, _ = block_path_properties(g, 1 << 17, {"parts": 381, "slices": 8})
     assert plan["group_parts"] == 96
