@@ -349,6 +349,210 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
     }
 }
 
+// The same extraction for walks of at most 128 nodes and windows of at most 31 (the reference's
+// defaults: 128 and 5), without visiting every window slot of every centre.  The walk's
+// positions whose context cell lies in the group, and its own centres, are two 128-bit masks; a
+// centre's pairs are the set bits of (window of i) & in-group, so
+//   count(i)   = popc(window(i) & in_group)                      own centres only
+//   rank(i, j) = sum_{i' < i} count(i') + popc(window(i) & in_group & below(j))
+// is where the pair (i, j) stands among the walk's pairs in (centre position, context position)
+// order -- the order block_extract_kernel emits them in.  The count pass adds popc(window(j) &
+// own) to the cell of every in-group position j (one LDS atomic per position, not per pair); the
+// write pass runs over (in-group position, window offset) and stores every pair at its rank.
+// Work follows the pairs a group EMITS: a group is 1 / 6 of the parts on the bench graph, 1 / 61
+// at 100 M nodes, and the slot-by-slot kernel visited all 1 280 slots of a walk for each.
+struct Mask128 {
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ Mask128 window_mask(uint32_t p, uint32_t w, uint32_t md) {
+    Mask128 m{0, 0};
+    if (md > w) return m;
+    const uint64_t side = (1ull << (w - md + 1)) - 1;
+    const uint64_t pat = side | (side << (w + md));  // bit k: offset k - w, md <= |offset| <= w
+    if (p >= w) {
+        const uint32_t sh = p - w;
+        if (sh == 0) {
+            m.lo = pat;
+        } else if (sh < 64) {
+            m.lo = pat << sh;
+            m.hi = pat >> (64 - sh);
+        } else {
+            m.hi = pat << (sh - 64);
+        }
+    } else {
+        m.lo = pat >> (w - p);
+    }
+    return m;
+}
+__device__ __forceinline__ Mask128 below_mask(uint32_t j) {
+    Mask128 m;
+    m.lo = j < 64 ? (1ull << j) - 1 : ~0ull;
+    m.hi = j <= 64 ? 0 : (j >= 128 ? ~0ull : (1ull << (j - 64)) - 1);
+    return m;
+}
+__device__ __forceinline__ uint32_t popc_and(const Mask128 &a, const Mask128 &b) {
+    return (uint32_t)(__popcll(a.lo & b.lo) + __popcll(a.hi & b.hi));
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t waves_per_block = kPrepBlock / 64;
+    const uint32_t cells = a.part_n * a.p.slices;
+    const uint32_t L = a.p.L, w = a.p.window, w2 = 2 * a.p.window, md = a.p.min_dist;
+    uint32_t *s_walk = smem + wave * 5 * L;
+    uint32_t *s_cell = s_walk + L;
+    uint32_t *s_loc = s_cell + L;
+    uint32_t *s_pre = s_loc + L;   // pairs of the walk before centre position p
+    uint32_t *s_j = s_pre + L;     // the in-group positions, in walk order
+    unsigned int *s_hist = smem + waves_per_block * 5 * L;
+    const uint64_t gw = (uint64_t)blockIdx.x * waves_per_block + wave;
+    const uint64_t chunk = (a.n_walks + kPrepWaves - 1) / kPrepWaves;
+    const uint64_t b0 = gw * chunk;
+    const uint64_t b1 = b0 + chunk < a.n_walks ? b0 + chunk : a.n_walks;
+    if constexpr (!WRITE) {
+        for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock) s_hist[c] = 0;
+        __syncthreads();
+    }
+    unsigned long long base = 0;
+    if constexpr (WRITE) base = a.wave_counts[gw];
+    unsigned long long total = 0;
+    const uint64_t lt_mask = (1ULL << lane) - 1;
+    const uint32_t hub_shift = a.p.ctx_bits - 1;
+    for (uint64_t b = b0; b < b1; ++b) {
+        wave_sync();
+        uint32_t Le = L;
+        for (uint32_t t = lane; t < L; t += 64) {
+            const uint32_t x = a.walks[b * L + t];
+            s_walk[t] = x;
+            uint32_t cell = kSentinel, loc = 0;
+            if (x == kSentinel) {
+                Le = min(Le, t);
+            } else {
+                const uint32_t row = x / a.p.parts, part = x - row * a.p.parts;
+                const uint32_t rel = part >= a.part_lo ? part - a.part_lo
+                                                       : part + a.p.parts - a.part_lo;
+                if (rel < a.part_n) {
+                    loc = row / a.p.slices;
+                    cell = part * a.p.slices + (row - loc * a.p.slices);
+                    if (WRITE && a.hub_bits && ((a.hub_bits[x >> 5] >> (x & 31)) & 1u))
+                        loc |= 1u << hub_shift;
+                }
+            }
+            s_cell[t] = cell;
+            s_loc[t] = loc;
+        }
+        for (int off = 32; off > 0; off >>= 1) Le = min(Le, (uint32_t)__shfl_xor(Le, off));
+        wave_sync();
+        const uint64_t wkey = draw(a.ekey, a.first_walk + b);
+        // the two masks: lane l speaks for the positions l and l + 64
+        Mask128 in_group, own;
+        bool g0, g1, o0 = false, o1 = false;
+        {
+            const uint32_t p0 = lane, p1 = lane + 64;
+            g0 = p0 < Le && s_cell[p0] != kSentinel;
+            g1 = p1 < Le && s_cell[p1] != kSentinel;
+            if (p0 < Le) {
+                const uint32_t c = s_walk[p0];
+                o0 = c % a.p.world == a.p.rank &&
+                     (!(a.p.flags & kFlagDownsample) || keep_centre_at(a.g, wkey, p0, c));
+            }
+            if (p1 < Le) {
+                const uint32_t c = s_walk[p1];
+                o1 = c % a.p.world == a.p.rank &&
+                     (!(a.p.flags & kFlagDownsample) || keep_centre_at(a.g, wkey, p1, c));
+            }
+            in_group.lo = __ballot(g0);
+            in_group.hi = __ballot(g1);
+            own.lo = __ballot(o0);
+            own.hi = __ballot(o1);
+        }
+        if ((in_group.lo | in_group.hi) == 0 || (own.lo | own.hi) == 0) continue;
+        if constexpr (!WRITE) {
+            // per in-group position: the own centres that have it in their window
+            uint32_t n0 = 0, n1 = 0;
+            if (g0) n0 = popc_and(window_mask(lane, w, md), own);
+            if (g1) n1 = popc_and(window_mask(lane + 64, w, md), own);
+            if (n0 | n1) {
+                const uint32_t slices = a.p.slices;
+                auto gidx = [&](uint32_t cell) {
+                    const uint32_t part = cell / slices, sl = cell - part * slices;
+                    const uint32_t rel = part >= a.part_lo ? part - a.part_lo
+                                                           : part + a.p.parts - a.part_lo;
+                    return rel * slices + sl;
+                };
+                if (n0) atomicAdd(&s_hist[gidx(s_cell[lane])], n0);
+                if (n1) atomicAdd(&s_hist[gidx(s_cell[lane + 64])], n1);
+            }
+            uint32_t n = n0 + n1;
+            for (int off = 32; off > 0; off >>= 1) n += (uint32_t)__shfl_xor(n, off);
+            total += n;
+        } else {
+            // pairs before each centre position: an exclusive scan of count(p) over the walk
+            uint32_t c0 = o0 ? popc_and(window_mask(lane, w, md), in_group) : 0;
+            uint32_t c1 = o1 ? popc_and(window_mask(lane + 64, w, md), in_group) : 0;
+            uint32_t x0 = c0, x1 = c1;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y0 = (uint32_t)__shfl_up(x0, off), y1 = (uint32_t)__shfl_up(x1, off);
+                if (lane >= off) {
+                    x0 += y0;
+                    x1 += y1;
+                }
+            }
+            const uint32_t t0 = (uint32_t)__shfl(x0, 63), t1 = (uint32_t)__shfl(x1, 63);
+            if ((uint32_t)lane < L) s_pre[lane] = x0 - c0;
+            if ((uint32_t)lane + 64 < L) s_pre[lane + 64] = t0 + x1 - c1;
+            // the in-group positions in walk order
+            const uint32_t nj0 = (uint32_t)__popcll(in_group.lo);
+            if (g0) s_j[__popcll(in_group.lo & lt_mask)] = lane;
+            if (g1) s_j[nj0 + __popcll(in_group.hi & lt_mask)] = lane + 64;
+            const uint32_t nj = nj0 + (uint32_t)__popcll(in_group.hi);
+            wave_sync();
+            const uint32_t n_slots = nj * w2;
+            for (uint32_t s0 = 0; s0 < n_slots; s0 += 64) {
+                const uint32_t t = s0 + lane;
+                if (t < n_slots) {
+                    const uint32_t jx = t / w2, slot = t - jx * w2;
+                    const uint32_t j = s_j[jx];
+                    // the centre at offset -w .. -1, 1 .. w of j
+                    const int64_t i = slot < w ? (int64_t)j - w + slot : (int64_t)j + 1 + (slot - w);
+                    const uint32_t dist = slot < w ? w - slot : slot - w + 1;
+                    if (i >= 0 && i < (int64_t)Le && dist >= md) {
+                        const uint32_t iu = (uint32_t)i;
+                        const bool is_own = iu < 64 ? (own.lo >> iu) & 1 : (own.hi >> (iu - 64)) & 1;
+                        if (is_own) {
+                            Mask128 wi = window_mask(iu, w, md);
+                            const Mask128 bj = below_mask(j);
+                            wi.lo &= in_group.lo & bj.lo;
+                            wi.hi &= in_group.hi & bj.hi;
+                            const uint32_t rank =
+                                s_pre[iu] + (uint32_t)(__popcll(wi.lo) + __popcll(wi.hi));
+                            a.pairs[base + rank] =
+                                ((((unsigned long long)s_cell[j] << a.p.row_bits) |
+                                  (s_walk[iu] / a.p.world))
+                                 << a.p.ctx_bits) |
+                                s_loc[j];
+                        }
+                    }
+                }
+            }
+            base += t0 + t1;
+        }
+    }
+    if constexpr (!WRITE) {
+        if (lane == 0) a.wave_counts[gw] = total;
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock)
+            if (s_hist[c]) {
+                const uint32_t rel = c / a.p.slices, sl = c - rel * a.p.slices;
+                uint32_t part = a.part_lo + rel;
+                if (part >= a.p.parts) part -= a.p.parts;
+                atomicAdd(&a.cell_counts[part * a.p.slices + sl], (unsigned long long)s_hist[c]);
+            }
+    }
+}
+
 // wave_counts -> exclusive offsets in place, total -> total_out[0]; cell_counts -> cell_offsets
 __global__ __launch_bounds__(1024) void block_scan_kernel(unsigned long long *wave_counts,
                                                           const unsigned long long *cell_counts,

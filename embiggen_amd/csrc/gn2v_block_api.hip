@@ -75,8 +75,18 @@ size_t block_lds_words_per_wave(uint32_t ld, uint32_t record, uint32_t k) {
 }
 
 // the extraction stages, per wave, the walk and three words per position, plus one counter per cell
+// walks of at most 128 nodes and windows of at most 31 take block_extract_fast_kernel
+bool extract_fast(uint32_t walk_length, uint32_t window) {
+    static const size_t fast_env = []() {
+        const char *v = getenv("GN2V_EXTRACT_FAST");
+        return v && *v ? (size_t)strtoull(v, nullptr, 10) : (size_t)1;
+    }();  // 0: the slot-by-slot kernel always (A/B)
+    return fast_env && walk_length <= 128 && window <= 31;
+}
+
 size_t extract_lds_bytes(uint32_t walk_length, uint32_t cells) {
-    return ((size_t)(gn2v::kPrepBlock / 64) * 4 * walk_length + cells) * 4;
+    const size_t arrays = walk_length <= 128 ? 5 : 4;  // the fast kernel stages one array more
+    return ((size_t)(gn2v::kPrepBlock / 64) * arrays * walk_length + cells) * 4;
 }
 
 // Rows of a cell that one workgroup of sixteen waves holds in LDS next to its waves' staging
@@ -269,7 +279,12 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     const size_t lds = extract_lds_bytes(d.L, part_n * d.slices);
     if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
     const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
-    if (write)
+    if (extract_fast(d.L, d.window)) {
+        if (write)
+            hipLaunchKernelGGL((gn2v::block_extract_fast_kernel<true>), grid, block, lds, s, a);
+        else
+            hipLaunchKernelGGL((gn2v::block_extract_fast_kernel<false>), grid, block, lds, s, a);
+    } else if (write)
         hipLaunchKernelGGL((gn2v::block_extract_kernel<true>), grid, block, lds, s, a);
     else
         hipLaunchKernelGGL((gn2v::block_extract_kernel<false>), grid, block, lds, s, a);
