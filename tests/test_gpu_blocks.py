@@ -75,8 +75,11 @@ def test_init_table_rows_are_the_rows_of_the_whole_table():
 
 
 @pytest.mark.parametrize("world,rank,parts,slices,md", [
-    (1, 0, 1, 1, 1), (1, 0, 4, 8, 1), (2, 1, 4, 1, 1), (3, 2, 6, 2, 2), (8, 5, 16, 8, 1)])
+    (1, 0, 1, 1, 1), (1, 0, 4, 8, 1), (2, 1, 4, 1, 1), (3, 2, 6, 2, 2), (8, 5, 16, 8, 1),
+    (1, 0, 2, 32, 1), (2, 1, 4, 17, 2)])
 def test_extraction_and_sort_are_bit_exact(world, rank, parts, slices, md):
+    """Pair words of the device (count + extraction by rank + radix sort) against the oracle's,
+    word for word, plans of resident cells (more than 16 slices) included."""
     g = _ba(203)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     wk = ops.walks(g, ops.walk_params(24, 4, 0.5, 2.0), 5, 1, 100, 300)
