@@ -484,6 +484,9 @@ def main():
     else:
         central = ops.init_table(n, d, 42, 0, d ** -0.5, device=local, ld=ld)
         contextual = ops.init_table(n, d, 42, 1, d ** -0.5, device=local, ld=ld)
+        # gn2v_train allocates its round buffers with hipMalloc: what building the graph left in
+        # torch's caching allocator goes back to the driver first
+        torch.cuda.empty_cache()
 
     if blocks is not None:
         from embiggen_amd.distributed import round_plan
