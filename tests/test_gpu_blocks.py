@@ -149,6 +149,33 @@ def test_pair_words_of_a_graph_whose_cell_and_row_do_not_fit_32_bits():
     assert np.abs(c.cpu().numpy() - c_h).max() < 1e-5 and np.abs(c_h - ops.init_table(n, 8, 5, 0, 0.3).cpu().numpy()).max() > 1e-4
 
 
+@pytest.mark.parametrize("L,w,md", [(160, 4, 1), (40, 33, 1), (129, 7, 3), (128, 31, 2), (64, 5, 5)])
+def test_both_extraction_kernels_equal_the_oracle(L, w, md):
+    """Walks of at most 128 nodes with windows of at most 31 are extracted by rank
+    (block_extract_fast_kernel: two 128-bit masks per walk), everything else slot by slot
+    (block_extract_kernel); both must emit the oracle's pair words in the oracle's order --
+    long walks, windows wider than a mask's reach, the largest shapes the fast kernel takes,
+    min_dist = window."""
+    g = _ba(203)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    wk = ops.walks(g, ops.walk_params(L, 2, 0.5, 2.0), 5, 1, 100, 150)
+    wk[::4, L // 3:] = -1
+    plan = ops.block_plan(g, 2, 1, 4, 8, L, w, md, 4, hot_rows=3)
+    oplan = O.block_plan(203, 2, 1, 4, 8, L, w, md, 4, hot_rows=3)
+    hub_bits = ops.block_alias(g, plan)[2]
+    ohub = O.block_alias(og, 4, 8, 3)[2]
+    for lo, cnt in ((0, 0), (3, 2)):
+        work, offsets = ops.block_count(g, plan, wk, 5, 1, 100, part_lo=lo, part_n=cnt)
+        n = int(offsets[-1])
+        pairs = ops.block_extract(g, plan, wk, 5, 1, 100, work, n, hub_bits=hub_bits, part_lo=lo,
+                                  part_n=cnt)
+        rw, ro = O.block_extract(og, oplan, _u32(wk), 5, 1, 100, hub_bits=ohub, part_lo=lo,
+                                 part_n=cnt)
+        assert n == len(rw) and n > 0
+        assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), ro)
+        assert np.array_equal(_words(pairs), rw)
+
+
 def test_extraction_honours_centre_downsampling(karate, karate_oracle):
     wk = ops.walks(karate, ops.walk_params(16, 4, 1.0, 1.0), 3, 0, 0, 136)
     plan = ops.block_plan(karate, 2, 0, 4, 1, 16, 3, 1, 4, flags=_lib.TRAIN_DOWNSAMPLE)
