@@ -751,6 +751,27 @@ def test_parts_come_back_in_node_order_also_through_host_memory(on_host, monkeyp
     assert torch.equal(x[:, :d], ops.init_table(n, d, m.random_state, 1, m.init_scale()))
 
 
+def test_a_graph_with_a_dominating_hub_keeps_the_xcd_cells():
+    """gn2v_block_auto_plan_graph: resident cells -- one workgroup per cell -- cannot end a launch
+    before the cell of the most frequent context is done; a graph whose largest in-degree x CUs
+    exceeds its edges (here a star of 150 000 leaves on top of a ring: the centre is the context
+    of nearly every second pair) is planned into XCD cells, whose records are handed out by
+    tickets; the ring alone gets resident cells.  Both fits count every pair and stay finite."""
+    n = 150_001
+    ring_s, ring_d = np.arange(1, n), np.concatenate([np.arange(2, n), [1]])
+    star = E.CSRGraph.from_edge_list(np.concatenate([ring_s, np.zeros(n - 1, dtype=np.int64)]),
+                                     np.concatenate([ring_d, np.arange(1, n)]),
+                                     number_of_nodes=n)
+    ring = E.CSRGraph.from_edge_list(ring_s, ring_d, number_of_nodes=n)
+    kw = dict(embedding_size=128, epochs=1, iterations=1, walk_length=16, window_size=3,
+              verbose=False)
+    for g, slices in ((star, 8), (ring, 256)):
+        m = E.models.SkipGram(**kw)
+        c, x, st = m.fit_transform_device(g, max_walks_per_epoch=1 << 15)
+        assert m.last_plan["slices"] == slices, m.last_plan
+        assert st["pairs"] > 0 and bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+
+
 def test_gn2v_train_takes_the_block_path_by_itself_from_2560_nodes():
     """GN2V_BLOCK_PATH_MIN_NODES: below it the walk-ordered kernel with atomics on every row, from
     it up one part of 8 XCD slices (plain stores on the XCD-exclusive contextual rows)."""
