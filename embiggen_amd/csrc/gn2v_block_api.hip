@@ -93,7 +93,7 @@ size_t extract_lds_bytes(uint32_t walk_length, uint32_t cells) {
 // (sgns_resident_kernel); 0: rows too wide for that kernel (it is built for strides up to 128
 // floats) or nothing left beside the staging
 uint32_t resident_rows(uint32_t ld, uint32_t record, uint32_t k) {
-    if (ld == 0 || ld > 128) return 0;
+    if (ld == 0 || ld > 256) return 0;
     const size_t staging = block_lds_words_per_wave(ld, record, k) * 4 * 16 + 64;
     const size_t lds = 160 * 1024;
     return staging >= lds ? 0
@@ -533,7 +533,7 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     const bool stores = !det && wmx != gn2v::kAtomic;
     if (d.slices > gn2v_host::kCursorSlices && !resident)
         return fail("more than 16 slices need cells that fit a workgroup's LDS (default update "
-                    "mode, rows up to 128 floats)");
+                    "mode, rows up to 256 floats)");
     if (part_n > 1) {
         *took_group = resident;
         if (!resident) return 0;
@@ -554,8 +554,10 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         HIP_TRY(hipEventRecord(ev.a, s));
         if (tp->ld <= 64)
             launch_resident_ch<1>(dim3(d.slices, part_n), lds, s, a);
-        else
+        else if (tp->ld <= 128)
             launch_resident_ch<2>(dim3(d.slices, part_n), lds, s, a);
+        else
+            launch_resident_ch<4>(dim3(d.slices, part_n), lds, s, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev.b, s));
         g->train_events.push_back(ev);
@@ -715,7 +717,7 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
               uint32_t *parts, uint32_t *slices) {
     if (!parts || !slices || world < 1) return fail("bad arguments");
     constexpr uint64_t kMinRows = 32768, kXcds = 8;
-    // One GPU, rows up to 128 floats, a graph of GN2V_RESIDENT_MIN_NODES nodes or more that is
+    // Rows up to 256 floats, a graph of GN2V_RESIDENT_MIN_NODES nodes or more that is
     // small enough for cells that fit a workgroup's LDS (524 288 cells x ~200 rows at d = 128: 106 M
     // nodes): RESIDENT CELLS -- every contextual row is read and updated in the LDS of the one
     // workgroup that owns its cell (sgns_resident_kernel).  As few cells as hold the rows, up to

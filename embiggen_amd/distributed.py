@@ -69,7 +69,7 @@ def round_plan(free_bytes: int, n_nodes: int, walk_length: int, window: int, wor
 
 def auto_plan(n_nodes: int, world: int, ld: int = 0, k: int = 10) -> Tuple[int, int]:
     """(parts, slices) of the contextual table (``gn2v_block_auto_plan``: one rule for the C++
-    one-GPU fit and for this trainer).  One GPU, row stride ``ld`` <= 128 floats (0: unknown),
+    one-GPU fit and for this trainer).  Row stride ``ld`` <= 256 floats (0: unknown),
     up to 106 M nodes: resident cells -- cells that fit one workgroup's LDS, whose rows are
     read and updated there, exactly.  Otherwise XCD cells.  Measured (scripts/quality_probe.py):
     the smaller a cell, the more of it lives in the XCD's L2 (BA 10 M nodes: 0.67 of the HBM

@@ -99,7 +99,8 @@ def test_automatic_plan_of_the_block_path():
     assert auto_plan(10_000_000, 1, 128, 10) == (193, 256)  # the bench graph: cells of 203 rows
     assert auto_plan(100_000_000, 1, 128, 10) == (1925, 256)  # config 5: 492 800 cells
     assert auto_plan(107_000_000, 1, 128, 10) == (408, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
-    assert auto_plan(1_000_000, 1, 256, 10) == (3, 8)    # rows too wide for the resident kernel
+    assert auto_plan(1_000_000, 1, 256, 10) == (43, 256)  # rows of 256 floats: cells of 92 rows
+    assert auto_plan(1_000_000, 1, 260, 10) == (3, 8)    # rows too wide for the resident kernel
     # several ranks: the parts travel -- two per rank (more only beyond 8 192 slices), each launched
     # by itself with all its cells -- while a part keeps 64 cells; smaller graphs travel as XCD cells
     assert auto_plan(1_000_000, 2, 128, 10) == (4, 1232) and auto_plan(1_000_000, 8, 128, 10) == (16, 308)
@@ -110,7 +111,7 @@ def test_automatic_plan_of_the_block_path():
         assert parts % world == 0 and parts >= 2 * world and 64 <= slices <= 8192
         assert rows(n, parts, slices) <= 203 and parts * slices <= 524288
     for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000, 300_000_000):
-        for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40)):
+        for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40), (256, 10), (224, 5)):
             parts, slices = auto_plan(n, 1, ld, k)
             staging = 16 * 4 * ((ld + 3 * 32 + 2 * 32 * (k + 1) + 2 + 3) // 4 * 4) + 64
             fit = (160 * 1024 - staging) // (ld * 4)
