@@ -100,6 +100,29 @@ uint32_t resident_rows(uint32_t ld, uint32_t record, uint32_t k) {
                           : (uint32_t)std::min<size_t>((lds - staging) / ((size_t)ld * 4), 4096);
 }
 
+// The record length the resident kernel runs a cell of `rows` rows with: the plan's, or the
+// half or the quarter of it when the sixteen waves' staging of longer records (1 + k samples a
+// pair) would not leave the cell its room (k = 50 at d = 128: records of 8).  0: none fits.
+// The pairs, their order and their negatives do not depend on it (a record is only how many
+// pairs a wave takes from the cursor at a time).
+uint32_t resident_record(uint32_t ld, uint32_t record, uint32_t k, uint64_t rows) {
+    for (uint32_t r = record; r >= 8 && r * 4 >= record; r >>= 1)
+        if (rows <= resident_rows(ld, r, k)) return r;
+    return 0;
+}
+
+// rows a cell of the automatic plan gets: what records of 32 pairs leave, or -- when that is
+// fewer than 64 rows -- what records of 16, then 8 leave (gn2v_block_step picks the record to
+// match, resident_record)
+uint32_t resident_fit(uint32_t ld, uint32_t k) {
+    uint32_t fit = 0;
+    for (uint32_t r = 32; r >= 8; r >>= 1) {
+        fit = resident_rows(ld, r, k);
+        if (fit >= 64) break;
+    }
+    return fit;
+}
+
 size_t env_size(const char *name, size_t fallback) {
     const char *v = getenv(name);
     return v && *v ? (size_t)strtoull(v, nullptr, 10) : fallback;
@@ -497,10 +520,11 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     static const size_t resident_env = env_size("GN2V_BLOCK_RESIDENT", 1);  // 0: never (A/B)
     const uint64_t max_cell_rows =
         gn2v::stripe_count(gn2v::stripe_count(g->view.n_nodes, 0, d.parts), 0, d.slices);
+    const uint32_t res_record = resident_record(tp->ld, d.record, tp->k, max_cell_rows);
     const bool resident =
         !det && resident_env &&
         !(tp->flags & (GN2V_TRAIN_ATOMIC | GN2V_TRAIN_WRITE_THROUGH | GN2V_TRAIN_WRITE_BACK)) &&
-        max_cell_rows <= resident_rows(tp->ld, d.record, tp->k);
+        res_record != 0;
     int wmc = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
               : (tp->flags & GN2V_TRAIN_WRITE_BACK)    ? gn2v::kWriteBack
               : (tp->flags & GN2V_TRAIN_WRITE_THROUGH) ? gn2v::kWriteThrough
@@ -540,7 +564,8 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         a.part_ptrs = d_part_ptrs;
     }
     if (resident) {
-        const size_t lds = block_lds_words_per_wave(tp->ld, d.record, tp->k) * 4 * 16 +
+        a.p.record = res_record;
+        const size_t lds = block_lds_words_per_wave(tp->ld, res_record, tp->k) * 4 * 16 +
                            (size_t)max_cell_rows * tp->ld * 4 + 16;
         std::lock_guard<std::mutex> lock(g->mu);
         hipStream_t caller = s;
@@ -729,7 +754,7 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
     const uint64_t max_nodes = env_size("GN2V_RESIDENT_MAX_NODES", GN2V_RESIDENT_MAX_NODES);
     const uint64_t fit = allow_resident && n_nodes >= GN2V_RESIDENT_MIN_NODES &&
                                  n_nodes <= max_nodes
-                             ? resident_rows(ld, 32, k) : 0;
+                             ? resident_fit(ld, k) : 0;
     if (fit >= 16 && n_nodes <= fit * (gn2v::kMaxCells - 512)) {
         const uint64_t cells = (n_nodes + fit - 1) / fit;
         // one GPU: 256 slices per part (gn2v_block_round launches a group of parts at once)

@@ -101,6 +101,7 @@ def test_automatic_plan_of_the_block_path():
     assert auto_plan(107_000_000, 1, 128, 10) == (408, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
     assert auto_plan(1_000_000, 1, 256, 10) == (43, 256)  # rows of 256 floats: cells of 92 rows
     assert auto_plan(1_000_000, 1, 260, 10) == (3, 8)    # rows too wide for the resident kernel
+    assert auto_plan(1_000_000, 1, 128, 50) == (43, 256)  # 50 negatives: records of 16, cells of 92 rows
     # several ranks: the parts travel -- two per rank (more only beyond 8 192 slices), each launched
     # by itself with all its cells -- while a part keeps 64 cells; smaller graphs travel as XCD cells
     assert auto_plan(1_000_000, 2, 128, 10) == (4, 1232) and auto_plan(1_000_000, 8, 128, 10) == (16, 308)
@@ -113,8 +114,12 @@ def test_automatic_plan_of_the_block_path():
     for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000, 300_000_000):
         for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40), (256, 10), (224, 5)):
             parts, slices = auto_plan(n, 1, ld, k)
-            staging = 16 * 4 * ((ld + 3 * 32 + 2 * 32 * (k + 1) + 2 + 3) // 4 * 4) + 64
-            fit = (160 * 1024 - staging) // (ld * 4)
+            # records of 32 pairs, or of 16 / 8 when their staging would leave under 64 rows
+            for record in (32, 16, 8):
+                staging = 16 * 4 * ((ld + 3 * record + 2 * record * (k + 1) + 2 + 3) // 4 * 4) + 64
+                fit = max(0, 160 * 1024 - staging) // (ld * 4)
+                if fit >= 64:
+                    break
             if slices > 8:
                 assert parts * slices <= 524288 and slices <= 256
                 assert rows(n, parts, slices) <= fit, (n, ld, k, parts, slices)
