@@ -1,4 +1,5 @@
-"""Largest in-degree of the test graphs against their edges (the hub-skew rule of\ngn2v_block_auto_plan_graph) and the plans that follow."""
+"""Largest in-degree of the test graphs against their edges (the hub-skew rule of
+gn2v_block_auto_plan_graph) and the plans that follow."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
