@@ -44,7 +44,8 @@ EXPORTS = [
     "gn2v_cooc_slots", "gn2v_glove_step",
     "gn2v_touch_rows",
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
-    "gn2v_block_alias", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
+    "gn2v_block_alias", "gn2v_block_placement_temp_bytes", "gn2v_block_placement",
+    "gn2v_block_place_walks", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
     "gn2v_block_extract", "gn2v_block_step", "gn2v_block_round", "gn2v_block_auto_plan", "gn2v_block_auto_plan_graph", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
     "gn2v_train_blocks",
     "gn2v_stats_reset",
@@ -126,6 +127,8 @@ class BlockIO(C.Structure):
         ("part", C.c_uint32),
         ("central_ld", C.c_uint64),
         ("context_ld", C.c_uint64),
+        ("d_inv", C.c_void_p),
+        ("d_context_table", C.c_void_p),
     ]
 
 
@@ -133,6 +136,9 @@ class BlockRoundIO(C.Structure):
     """gn2v_block_round_io (include/gn2v.h)."""
     _fields_ = [
         ("d_walks", C.c_void_p),
+        ("d_placed_walks", C.c_void_p),
+        ("d_inv", C.c_void_p),
+        ("d_context_table", C.c_void_p),
         ("d_alias", C.c_void_p),
         ("d_cell_rows", C.c_void_p),
         ("d_hub_bits", C.c_void_p),
@@ -179,6 +185,8 @@ class Stats(C.Structure):
         ("block_stripes", C.c_uint32),
         ("block_group_parts", C.c_uint32),
         ("block_round_walks", C.c_uint64),
+        ("resident_launches", C.c_uint32),
+        ("resident_record", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -262,12 +270,15 @@ def lib():
     L.gn2v_block_plan_check.argtypes = [vp, C.POINTER(BlockPlan)]
     L.gn2v_init_table_rows.argtypes = [vp, u64, u32, u32, u64, u32, f32, u64, u64, vp]
     L.gn2v_block_alias_temp_bytes.argtypes = [u64, C.POINTER(u64)]
-    L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, vp, vp, vp, u64, vp]
-    L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, u32, u32, vp,
-                                   vp, vp]
+    L.gn2v_block_alias.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, vp, vp, vp, vp, vp, u64, vp]
+    L.gn2v_block_placement_temp_bytes.argtypes = [u64, C.POINTER(u64)]
+    L.gn2v_block_placement.argtypes = [vp, u32, u64, u64, vp, vp, vp, u64, vp]
+    L.gn2v_block_place_walks.argtypes = [vp, vp, u64, vp, vp]
+    L.gn2v_block_count.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, u64, u64, u64, u64, u32, u32,
+                                   vp, vp, vp]
     L.gn2v_block_extract_temp_bytes.argtypes = [u64, C.POINTER(u64)]
-    L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, u64, u64, u64, u64, u32, u32,
-                                     vp, vp, u64, vp, vp, u64, vp]
+    L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, u64, u64, u64, u64, u32,
+                                     u32, vp, vp, u64, vp, vp, u64, vp]
     L.gn2v_graph_xcds.argtypes = [vp]
     L.gn2v_graph_reserve_cus.argtypes = [vp, u32, vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),

@@ -37,11 +37,8 @@ constexpr int kPrepBlock = 256;
 constexpr uint32_t kPrepWaves = 8192;  // fixed: the extraction order does not depend on it
 constexpr uint32_t kMaxCells = GN2V_BLOCK_MAX_CELLS;   // parts x slices (resident cells at 100 M nodes: 1 925 x 256)
 constexpr uint32_t kMaxGroupCells = GN2V_BLOCK_MAX_GROUP_CELLS;  // one extraction group (LDS histogram)
-// negatives' stream of a cell: draw(key, block_id * kCellStreamStride + cell).  Plans of more
-// cells than the stride let (block, cell + stride) share its numbers with (block + 1, cell) --
-// another cell, another alias table, another round: harmless, and the plans of up to 8 192 cells
-// keep the streams the oracle restates.
-constexpr uint64_t kCellStreamStride = 8192;
+// negatives' stream of a cell: draw(draw(key, block_id), cell) -- one stream per (block, cell),
+// whatever the number of cells (cell_stream_key; the oracle restates it)
 constexpr uint32_t kMaxRecord = 32;
 // A run -- consecutive pairs of one centre inside a record, trained against ONE copy of the central
 // row, their gradients summed -- is at most this long; a longer stretch of equal centres is cut
@@ -135,17 +132,23 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
                                     uint32_t *__restrict__ stack,
                                     uint32_t *__restrict__ hub_bits, uint32_t hot_rows,
                                     uint32_t *__restrict__ hot_list,
-                                    uint8_t *__restrict__ hot_slot) {
+                                    uint8_t *__restrict__ hot_slot,
+                                    const uint32_t *__restrict__ inv) {
     const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= parts * slices) return;
     const uint32_t part = cell / slices, slice = cell - part * slices;
     const uint64_t lo = cell_rows[cell], n = cell_rows[cell + 1] - lo;
-    uint32_t *hl = hot_list + (size_t)cell * kHotMax;
-    for (uint32_t s = 0; s < kHotMax; ++s) hl[s] = kSentinel;
+    uint32_t *hl = hot_rows ? hot_list + (size_t)cell * kHotMax : nullptr;
+    if (hot_rows)
+        for (uint32_t s = 0; s < kHotMax; ++s) hl[s] = kSentinel;
     if (n == 0) return;
     unsigned long long *w = weight + lo, *t = table + lo;
     uint32_t *st = stack + lo;
-    auto node_of = [&](uint64_t i) { return (slice + (uint64_t)slices * i) * parts + part; };
+    // the node whose placed id is row i of this cell (inv: the round's placement, or identity)
+    auto node_of = [&](uint64_t i) -> uint64_t {
+        const uint64_t xp = (slice + (uint64_t)slices * i) * parts + part;
+        return inv ? (uint64_t)inv[xp] : xp;
+    };
     unsigned long long D = 0;
     uint32_t n_hot = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -167,7 +170,9 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
         atomicOr(&hub_bits[x >> 5], 1u << (x & 31));
     }
     uint64_t n_small = 0, n_large = 0;  // small stack grows from st[0], large from st[n - 1]
-    auto hot = [&](uint64_t i) -> unsigned long long { return hot_slot[lo + i] != kNoSlot; };
+    auto hot = [&](uint64_t i) -> unsigned long long {
+        return hot_rows != 0 && hot_slot[lo + i] != kNoSlot;
+    };
     for (uint64_t i = 0; i < n; ++i) {
         const unsigned long long p = (unsigned long long)indeg[node_of(i)] * n;
         w[i] = p;
@@ -199,6 +204,58 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
 }
 
 // --------------------------------------------------------------------------------------------
+// Placement of a round: WHERE a node's contextual row is trained changes from
+// round to round, so that over a fit the negatives a context meets -- drawn inside its cell --
+// range over the graph (node2vec_skipgram.py:101-102) instead of over one fixed set of ~200
+// cell-mates.  A seeded permutation of the node ids inside their residue classes modulo
+// `classes` (= parts when the parts travel between ranks: a row never changes its part; 1 on
+// one GPU): keys (class << 40 | hash(round key, x) >> 24) are sorted (stable radix sort: ties
+// in node order), and the j-th node of class c receives the placed id c + classes * j.
+// place[x] = x', inv[x'] = x.  Everything downstream works on placed ids (part = x' % parts,
+// row = x' / parts, slice = row % slices); the tables stay where they are and the resident
+// kernel reaches a row through inv.  The oracle restates it (o_block_placement): bit-equal.
+// --------------------------------------------------------------------------------------------
+constexpr uint64_t kTagPlace = 0x91ACE5EED5EED5EDULL;
+
+static __global__ void place_keys_kernel(uint64_t n_nodes, uint32_t classes, uint64_t pkey,
+                                         unsigned long long *__restrict__ keys,
+                                         uint32_t *__restrict__ vals) {
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_nodes;
+         x += (uint64_t)gridDim.x * blockDim.x) {
+        keys[x] = ((unsigned long long)(x % classes) << 40) | (draw(pkey, x) >> 24);
+        vals[x] = (uint32_t)x;
+    }
+}
+
+static __global__ void place_scatter_kernel(uint64_t n_nodes, uint32_t classes,
+                                            const uint32_t *__restrict__ sorted,
+                                            uint32_t *__restrict__ place,
+                                            uint32_t *__restrict__ inv) {
+    const uint64_t per = n_nodes / classes, extra = n_nodes % classes;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_nodes;
+         j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = sorted[j];
+        const uint64_t c = x % classes;
+        const uint64_t start = c * per + (c < extra ? c : extra);
+        const uint32_t xp = (uint32_t)(c + (uint64_t)classes * (j - start));
+        place[x] = xp;
+        inv[xp] = x;
+    }
+}
+
+// out[i] = place[walks[i]] (the walks with their nodes' placed ids: what the extraction reads
+// for the CONTEXT side -- one gather per walk position and round instead of one per pass)
+static __global__ void place_walks_kernel(const uint32_t *__restrict__ place,
+                                          const uint32_t *__restrict__ walks, uint64_t n,
+                                          uint32_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = walks[i];
+        out[i] = x == kSentinel ? kSentinel : place[x];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // Pair extraction.  Wave w owns the contiguous chunk of walks [w * chunk, (w + 1) * chunk) and
 // emits their pairs in walk / position / slot order; WRITE = false counts (per wave and per cell),
 // WRITE = true writes at the wave's scanned offset.
@@ -212,6 +269,8 @@ struct ExtractArgs {
     uint64_t first_walk;  // id of walks[0]
     unsigned long long *wave_counts;  // [kPrepWaves]: counts out (count pass), offsets in (write)
     unsigned long long *cell_counts;  // [cells] (count pass)
+    const uint32_t *placed;  // the walks with placed node ids (place_walks_kernel), or nullptr:
+                             // a context's cell follows from its node id itself
     const uint32_t *hub_bits;         // one bit per node (gn2v_block_alias), or nullptr
     unsigned long long *pairs;        // [n_pairs] pair words (write pass)
     uint32_t part_lo, part_n;         // only contexts in the parts part_lo, part_lo + 1, ...
@@ -267,7 +326,8 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
             if (x == kSentinel) {
                 Le = min(Le, t);
             } else {
-                const uint32_t row = x / a.p.parts, part = x - row * a.p.parts;
+                const uint32_t xp = a.placed ? a.placed[b * L + t] : x;
+                const uint32_t row = xp / a.p.parts, part = xp - row * a.p.parts;
                 const uint32_t rel = part >= a.part_lo ? part - a.part_lo
                                                        : part + a.p.parts - a.part_lo;
                 if (rel < a.part_n) {
@@ -430,7 +490,8 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractA
             if (x == kSentinel) {
                 Le = min(Le, t);
             } else {
-                const uint32_t row = x / a.p.parts, part = x - row * a.p.parts;
+                const uint32_t xp = a.placed ? a.placed[b * L + t] : x;
+                const uint32_t row = xp / a.p.parts, part = xp - row * a.p.parts;
                 const uint32_t rel = part >= a.part_lo ? part - a.part_lo
                                                        : part + a.p.parts - a.part_lo;
                 if (rel < a.part_n) {
@@ -615,6 +676,12 @@ struct BlockArgs {
     uint64_t cld;      // floats between its rows (ld, or world * ld inside the whole table)
     float *context;    // the resident context part      [rows][xld]
     uint64_t xld;      // floats between its rows (ld, or parts * ld inside the whole table)
+    // resident cells under a round's placement: row r of cell (part, slice) is
+    // the contextual row of node x = inv[(slice + slices r) parts + part] -- row x of ctx_table
+    // (the whole table in node order: one GPU) or, ctx_table == nullptr, row x / parts of
+    // `context` (placements that keep the classes modulo parts: x % parts == part)
+    const uint32_t *inv;
+    float *ctx_table;
     unsigned long long *cursors;  // record tickets of the part's cells, one per slice, kCursorStep
                                   // words apart (zeroed per launch)
     unsigned long long *counters;
@@ -635,6 +702,11 @@ struct BlockArgs {
 
 __device__ __forceinline__ float *sample_base(const BlockArgs &a, float *table, uint32_t row) {
     return table + (uint64_t)row * a.xld;
+}
+
+__device__ __forceinline__ uint64_t cell_stream_key(uint64_t ekey, uint64_t block_id,
+                                                    uint32_t cell) {
+    return draw(draw(mix64(ekey ^ kTagBlock), block_id), cell);
 }
 
 __device__ __forceinline__ uint64_t gcd64(uint64_t a, uint64_t b) {
@@ -1000,7 +1072,10 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
             }
             row = RES ? local : slice + a.p.slices * local;
             lab = 0.f;
-            const uint64_t ngid = (uint64_t)(slice + a.p.slices * local) * a.p.parts + a.part;
+            // the node behind the negative: staged with the cell's rows (resident cells; under a
+            // placement it is not a function of the row any more)
+            const uint64_t ngid = RES ? (uint64_t)h.grow[local]
+                                      : (uint64_t)(slice + a.p.slices * local) * a.p.parts + a.part;
             const uint64_t cgid = (uint64_t)s_key[pr] * a.p.world + a.p.rank;
             if (row == (xrow & ~kHubBit) || ngid == cgid) {
                 row = kSentinel;
@@ -1023,13 +1098,18 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
     // gradient with atomics (several groups, or waves, hold that row), a lone pair stores row +
     // gradient.  Runs proper (the bench graph: 3.4 pairs) keep the run-major loop below: there a
     // group-private centre would re-read the central row per pair.
-    if constexpr (!DET && !is_atomic(WMX) && WMC == kAtomic) {
+    // DET (resident cells only): the same code with the four groups taking TURNS -- one pair at a
+    // time, in record order -- taken when every run of the record is a single pair, where "a pair
+    // per group" and the oracle's "run of equal centre" are the same thing.  That is how the
+    // packed dot products, the v_rcp sigmoid, the side-by-side samples, the prefetched central
+    // rows and the transposed atomic hand-over are compared with the oracle element by element.
+    if constexpr ((!DET || RES) && !is_atomic(WMX) && WMC == kAtomic) {
         uint32_t n_runs = 0;
         {
             const bool starts = (uint32_t)lane < n && (lane == 0 || s_key[lane] != s_key[lane - 1]);
             n_runs = (uint32_t)__popcll(__ballot(starts));
         }
-        if (n_runs * 100 >= n * kPpgMinPct) {
+        if (DET ? n_runs == n : n_runs * 100 >= n * kPpgMinPct) {
             const uint32_t kk = k + 1;
             // the central rows of the NEXT four pairs are fetched while these four are scored (a
             // memory round trip per pair otherwise); a pair whose centre one of these four also
@@ -1041,8 +1121,8 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
                              q, nchunks, (uint32_t)grp < n);
             for (uint32_t p4 = 0; p4 < n; p4 += 4) {
                 const uint32_t pr = p4 + grp;
-                const bool have = pr < n;
-                const uint32_t crow_id = s_key[have ? pr : 0];
+                const bool in_rec = pr < n;
+                const uint32_t crow_id = s_key[in_rec ? pr : 0];
                 float *crow = a.central + (uint64_t)crow_id * a.cld;
                 Row<CH> u, g;
                 if constexpr (RES) {
@@ -1051,9 +1131,11 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
                     load_row<CH>(u_next, a.central + (uint64_t)s_key[nx < n ? nx : 0] * a.cld, q,
                                  nchunks, nx < n);
                 } else {
-                    load_row<CH>(u, crow, q, nchunks, have);
+                    load_row<CH>(u, crow, q, nchunks, in_rec);
                 }
                 zero_row<CH>(g);
+              for (int det_turn = 0; det_turn < (DET ? 4 : 1); ++det_turn) {
+                const bool have = in_rec && (!DET || grp == det_turn);
                 float lrc = a.lr;
                 if (a.flags & kFlagNormLr) {
                     const uint64_t c = (uint64_t)crow_id * a.p.world + a.p.rank;
@@ -1117,6 +1199,9 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
                         }
                     }
                 }
+                // the next pair of the record may name a row this one has just changed
+                if constexpr (DET) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+              }
             }
             pairs += n;
             runs += n;  // one central row read and one hand-over per pair
@@ -1150,7 +1235,12 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
                          r1 < n);
         }
         zero_row<CH>(g);
-        if constexpr (DET) {
+        if constexpr (DET && RES) {
+            // the cell's rows live in LDS: one sample after the other, group 0 alone
+            for (uint32_t t = r0 * (k + 1); t < r1 * (k + 1); ++t)
+                score_sample<CH, WMX, true>(a, h, u, g, grp == 0 ? s_rows[t] : kSentinel, s_lab[t],
+                                            lrc, q, nchunks);
+        } else if constexpr (DET) {
             score_samples<CH, WMX, DET>(a, a.context, u, u, g, s_rows + r0 * (k + 1),
                                         s_lab + r0 * (k + 1), (r1 - r0) * (k + 1), lrc, grp, q);
         } else if constexpr (!is_atomic(WMX)) {
@@ -1302,7 +1392,7 @@ __global__ __launch_bounds__(WG) void sgns_block_kernel(BlockArgs a) {
         if (work) {
             const uint64_t R = (hi - lo + C - 1) / C;
             const uint64_t A = record_stride(R);
-            const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kCellStreamStride + cell);
+            const uint64_t ckey = cell_stream_key(a.ekey, a.block_id, cell);
             const uint64_t cell_lo = a.cell_rows ? a.cell_rows[cell] : 0;
             if constexpr (DET) {
                 for (uint64_t t = 0; t < R; ++t) {
@@ -1360,23 +1450,34 @@ __global__ __launch_bounds__(WG) void sgns_block_kernel(BlockArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Resident cells: the plan of a small or mid-sized graph (gn2v_block_auto_plan: up to 106 M nodes
-// at d = 128) makes cells whose rows fit ONE workgroup's LDS.  A launch covers a part, one
-// workgroup of sixteen waves per cell: it loads the cell's contextual rows into LDS, trains ALL
-// the cell's records (its waves take them from an LDS cursor), reads and updates the rows in
-// LDS -- ds_add_f32: every update of every row arrives, and each wave sees the others' at once --
-// and writes the rows back when the cell is done.  No other workgroup touches those rows during
-// the launch: nothing races, nothing is in limbo, no atomics on contextual rows.  (The XCD cells
-// of sgns_block_kernel lose what waves of different CUs write to an ordinary row at the same
-// moment: at 2 708 nodes 8 x 2 000 row updates are in flight on 2 708 rows and the contextual
-// table moved 0.69 x as far as the sequential schedule)  The central rows are
-// shared between the cells and take the run's gradient by f32 atomics, as in sgns_block_kernel.
-// LDS: per wave the staging of train_record, then rows[cell rows][ld] and the record cursor.
+// Resident cells: the plan of a small or mid-sized graph (gn2v_block_auto_plan: up to 105 M nodes
+// at d = 128) makes cells whose rows fit ONE workgroup's LDS.  A launch covers a part (or a group
+// of parts), one workgroup of sixteen waves per cell: it loads the cell's contextual rows into
+// LDS, trains ALL the cell's records (its waves take them from an LDS cursor), reads and updates
+// the rows in LDS and writes them back when the cell is done.  No other workgroup touches those
+// rows during the launch, so no flavour of global store or atomic is involved and nothing is in
+// limbo between copies.  What still races is the workgroup with itself: a sample is a plain LDS
+// read -> score -> second read -> 16-byte stores by one of 64 concurrent 16-lane groups
+// (score_sample<RES>, score_sample_pair), so two groups that name the same row within the ~100
+// cycles between the second read and the stores keep one of the two updates -- always so for two
+// groups of one wave that name a row in the same instruction.  The hub rows of a cell (the
+// targets of the degree-proportional negatives) are hit that way regularly: the contextual table
+// moves 0.85-0.87 x as far as the sequential restatement of the same schedule, where an exact
+// accumulation in the same parallel order gives 0.905 (counted per row by
+// tests/test_gpu_resident.py).  (The XCD cells of sgns_block_kernel additionally lose what waves
+// of different CUs write to a row at the same moment: at 2 708 nodes the contextual table moved
+// 0.69 x as far as the sequential schedule)  The central rows are shared between
+// the cells and take the run's gradient by f32 atomics, as in sgns_block_kernel: exact.
+// DET: the deterministic instantiation (GN2V_TRAIN_DETERMINISTIC on a resident plan) -- ONE
+// workgroup walks the launch's cells one after the other, wave 0 trains a cell's records in the
+// stride order t * A mod R, samples in order, rows in LDS: the oracle's o_block_step, to 1e-5.
+// LDS: per wave the staging of train_record, then rows[cell rows][ld], the rows' node ids and
+// the record cursor.
 // --------------------------------------------------------------------------------------------
-template <int CH, bool FULL = false>
-__global__ __launch_bounds__(1024) void sgns_resident_kernel(BlockArgs a) {
-    if constexpr (FULL) a.ld = CH * 64;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+template <int CH, bool DET>
+__device__ __forceinline__ void resident_cell(BlockArgs &a, uint32_t *smem, uint32_t slice,
+                                              unsigned long long &pairs,
+                                              unsigned long long &runs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, q = lane & 15;
     const uint32_t C = a.p.record, k = a.k;
@@ -1389,15 +1490,6 @@ __global__ __launch_bounds__(1024) void sgns_resident_kernel(BlockArgs a) {
     float *s_lab = reinterpret_cast<float *>(s_rows + C * (k + 1));
     uint32_t *s_nb = s_rows + 2 * C * (k + 1);
     const uint32_t n_waves = blockDim.x >> 6;
-    const uint32_t slice = blockIdx.x;
-    // A launch covers a GROUP of parts (blockIdx.y) when the caller holds them all: a launch of
-    // one part lasts as long as its heaviest cell -- and the striping puts one of the graph's
-    // oldest hubs into every part -- while the workgroups of a group are handed to the CUs as
-    // they fall free (BA 10 M: a part's heaviest cell carries 1.5-9 x the average cell).
-    if (a.part_ptrs) {
-        a.part += blockIdx.y;
-        a.context = a.part_ptrs[a.part];
-    }
     const uint32_t cell = a.part * a.p.slices + slice;
     const uint64_t lo = a.cell_offsets[cell], hi = a.cell_offsets[cell + 1];
     if (hi == lo) return;  // the same for every wave of the workgroup
@@ -1407,42 +1499,96 @@ __global__ __launch_bounds__(1024) void sgns_resident_kernel(BlockArgs a) {
     h.base = reinterpret_cast<float *>(smem + n_waves * per_wave);
     h.ld = a.ld;
     h.n = cell_n;
-    uint32_t *s_cursor = smem + n_waves * per_wave + cell_n * a.ld;
-    for (uint32_t i = threadIdx.x; i < cell_n * (a.ld >> 2); i += blockDim.x) {
-        const uint32_t r = i / (a.ld >> 2), c4 = i - r * (a.ld >> 2);
-        reinterpret_cast<float4 *>(h.base + r * a.ld)[c4] = reinterpret_cast<const float4 *>(
-            sample_base(a, a.context, slice + a.p.slices * r))[c4];
+    // the node behind every row of the cell (for "is this negative the centre itself", and for
+    // where the row lies under a placement)
+    h.grow = smem + n_waves * per_wave + cell_n * a.ld;
+    uint32_t *s_cursor = h.grow + cell_n;
+    for (uint32_t r = threadIdx.x; r < cell_n; r += blockDim.x) {
+        const uint64_t xp = (uint64_t)(slice + a.p.slices * r) * a.p.parts + a.part;
+        h.grow[r] = a.inv ? a.inv[xp] : (uint32_t)xp;
     }
     if (threadIdx.x == 0) *s_cursor = 0;
     __syncthreads();
-    unsigned long long pairs = 0, runs = 0;
+    auto row_ptr = [&](uint32_t r) -> float * {
+        if (!a.inv) return sample_base(a, a.context, slice + a.p.slices * r);
+        const uint32_t x = h.grow[r];
+        return a.ctx_table ? a.ctx_table + (uint64_t)x * a.ld
+                           : a.context + (uint64_t)(x / a.p.parts) * a.xld;
+    };
+    for (uint32_t i = threadIdx.x; i < cell_n * (a.ld >> 2); i += blockDim.x) {
+        const uint32_t r = i / (a.ld >> 2), c4 = i - r * (a.ld >> 2);
+        reinterpret_cast<float4 *>(h.base + r * a.ld)[c4] =
+            reinterpret_cast<const float4 *>(row_ptr(r))[c4];
+    }
+    __syncthreads();
     const uint64_t R = (hi - lo + C - 1) / C;
     const uint64_t A = record_stride(R);
-    const uint64_t ckey = draw(mix64(a.ekey ^ kTagBlock), a.block_id * kCellStreamStride + cell);
+    const uint64_t ckey = cell_stream_key(a.ekey, a.block_id, cell);
     const uint64_t cell_lo = a.cell_rows ? a.cell_rows[cell] : 0;
-    const uint64_t start = mulhi64(ckey, R);
-    for (;;) {
-        uint32_t t0 = 0;
-        if (lane == 0)
-            t0 = __hip_atomic_fetch_add((lds_u32 *)s_cursor, 1u, __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint64_t t = __shfl(t0, 0);
-        if (t >= R) break;
-        const uint64_t rec = (t * A + start) % R;
-        const uint64_t p0 = lo + rec * C;
-        const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
-        train_record<CH, kWriteBack, kAtomic, false, true>(a, h, cell, lo, hi, p0, n, ckey, cell_lo,
-                                                           cell_n, slice, s_key, s_val, s_hs,
-                                                           s_rows, s_lab, s_nb, s_tr, lane, grp, q,
-                                                           pairs, runs);
+    if constexpr (DET) {
+        if (wave == 0)
+            for (uint64_t t = 0; t < R; ++t) {
+                const uint64_t rec = (t * A) % R;
+                const uint64_t p0 = lo + rec * C;
+                const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
+                train_record<CH, kWriteBack, kAtomic, true, true>(
+                    a, h, cell, lo, hi, p0, n, ckey, cell_lo, cell_n, slice, s_key, s_val, s_hs,
+                    s_rows, s_lab, s_nb, s_tr, lane, grp, q, pairs, runs);
+            }
+    } else {
+        const uint64_t start = mulhi64(ckey, R);
+        for (;;) {
+            uint32_t t0 = 0;
+            if (lane == 0)
+                t0 = __hip_atomic_fetch_add((lds_u32 *)s_cursor, 1u, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t t = __shfl(t0, 0);
+            if (t >= R) break;
+            const uint64_t rec = (t * A + start) % R;
+            const uint64_t p0 = lo + rec * C;
+            const uint32_t n = (uint32_t)min((uint64_t)C, hi - p0);
+            train_record<CH, kWriteBack, kAtomic, false, true>(
+                a, h, cell, lo, hi, p0, n, ckey, cell_lo, cell_n, slice, s_key, s_val, s_hs,
+                s_rows, s_lab, s_nb, s_tr, lane, grp, q, pairs, runs);
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < cell_n * (a.ld >> 2); i += blockDim.x) {
         const uint32_t r = i / (a.ld >> 2), c4 = i - r * (a.ld >> 2);
-        reinterpret_cast<float4 *>(sample_base(a, a.context, slice + a.p.slices * r))[c4] =
+        reinterpret_cast<float4 *>(row_ptr(r))[c4] =
             reinterpret_cast<const float4 *>(h.base + r * a.ld)[c4];
     }
-    if (a.counters && lane == 0 && pairs) {
+}
+
+template <int CH, bool FULL = false, bool DET = false>
+__global__ __launch_bounds__(1024) void sgns_resident_kernel(BlockArgs a) {
+    if constexpr (FULL) a.ld = CH * 64;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    unsigned long long pairs = 0, runs = 0;
+    if constexpr (DET) {
+        // one workgroup, the cells of the launch in order (parts, then slices): a.sweep carries
+        // the number of parts
+        const uint32_t part0 = a.part, part_n = a.sweep ? a.sweep : 1;
+        for (uint32_t p = 0; p < part_n; ++p) {
+            a.part = part0 + p;
+            if (a.part_ptrs) a.context = a.part_ptrs[a.part];
+            for (uint32_t slice = 0; slice < a.p.slices; ++slice) {
+                resident_cell<CH, true>(a, smem, slice, pairs, runs);
+                __syncthreads();  // the LDS is the next cell's
+            }
+        }
+    } else {
+        // A launch covers a GROUP of parts (blockIdx.y) when the caller holds them all: a launch
+        // of one part lasts as long as its heaviest cell -- and the striping puts one of the
+        // graph's oldest hubs into every part -- while the workgroups of a group are handed to
+        // the CUs as they fall free (BA 10 M: a part's heaviest cell carries 1.5-9 x the average).
+        if (a.part_ptrs) {
+            a.part += blockIdx.y;
+            a.context = a.part_ptrs[a.part];
+        }
+        resident_cell<CH, false>(a, smem, blockIdx.x, pairs, runs);
+    }
+    if (a.counters && (threadIdx.x & 63) == 0 && pairs) {
         atomicAdd(&a.counters[0], pairs);
         atomicAdd(&a.counters[2], runs);
     }

@@ -148,38 +148,55 @@ gn2v::WalkConsts walk_consts(const gn2v_graph *g, const gn2v_walk_params *wp) {
 // the free memory; GN2V_WALK_EDGE_SET=0 keeps the binary searches (same walks either way).
 int ensure_edge_set(gn2v_graph *g, hipStream_t s) {
     if (g->edge_set_tried) return 0;
-    g->edge_set_tried = true;
     const char *env = getenv("GN2V_WALK_EDGE_SET");
-    if (env && *env == '0') return 0;
     const uint64_t E = g->view.n_edges;
-    if (E == 0 || g->view.n_nodes >= 0xFFFFFFFFULL) return 0;
+    if ((env && *env == '0') || E == 0 || g->view.n_nodes >= 0xFFFFFFFFULL) {
+        g->edge_set_tried = true;  // never for this handle
+        return 0;
+    }
     uint64_t slots = 16;
     while (slots < 2 * E) slots <<= 1;
+    // no room now (a quarter of the free memory): the walks take the binary searches -- same
+    // walks -- and a later call, with more memory free, tries again
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || slots * 8 > free_b / 4) {
         (void)hipGetLastError();
         return 0;
     }
-    unsigned long long *table = nullptr;
+    unsigned long long *table = nullptr, *filter = nullptr;
     if (hipMalloc((void **)&table, slots * 8) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
-    HIP_TRY(hipMemsetAsync(table, 0xFF, slots * 8, s));
     // the filter in front of it: one word per 8 edges, rounded up to a power of two
     // (GN2V_WALK_EDGE_FILTER=0: the set alone)
     uint64_t words = 16;
     while (words * 8 < E) words <<= 1;
-    unsigned long long *filter = nullptr;
     const char *fenv = getenv("GN2V_WALK_EDGE_FILTER");
-    if (!(fenv && *fenv == '0') && hipMalloc((void **)&filter, words * 8) == hipSuccess)
-        HIP_TRY(hipMemsetAsync(filter, 0, words * 8, s));
-    else
+    if ((fenv && *fenv == '0') || hipMalloc((void **)&filter, words * 8) != hipSuccess) {
         (void)hipGetLastError();
-    const unsigned blocks = (unsigned)std::min<uint64_t>((g->view.n_nodes + 255) / 256, 1u << 20);
-    hipLaunchKernelGGL(gn2v::edge_set_kernel, dim3(blocks), dim3(256), 0, s, g->view.row_ptr,
-                       g->view.col_idx, g->view.n_nodes, table, slots - 1, filter, words - 1);
-    HIP_TRY(hipGetLastError());
+        filter = nullptr;
+    }
+    // Built on `s` and COMPLETE before it is published: a walk launched later on any other
+    // stream must never probe a table that is not memset yet (an unset, zero-filled table has no
+    // empty slot: the probe loop would not end) or half built (other walks, silently).
+    hipError_t e = hipMemsetAsync(table, 0xFF, slots * 8, s);
+    if (e == hipSuccess && filter) e = hipMemsetAsync(filter, 0, words * 8, s);
+    if (e == hipSuccess) {
+        const unsigned blocks =
+            (unsigned)std::min<uint64_t>((g->view.n_nodes + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(gn2v::edge_set_kernel, dim3(blocks), dim3(256), 0, s, g->view.row_ptr,
+                           g->view.col_idx, g->view.n_nodes, table, slots - 1, filter, words - 1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        (void)hipFree(table);
+        if (filter) (void)hipFree(filter);
+        return fail(std::string("building the edge set of the walk sampler: ") +
+                    hipGetErrorString(e));
+    }
+    g->edge_set_tried = true;
     g->edge_set = table;
     g->edge_filter = filter;
     g->view.edge_set = table;
@@ -470,6 +487,19 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
 
 }  // namespace
 
+namespace gn2v_host {
+// What the walks of `wp` need beyond the CSR (the second-order sampler's edge set), allocated and
+// built NOW: gn2v_train_blocks calls this before it sizes its rounds from the free memory, so
+// that the set's bytes (3.4 GB on the bench graph, 18 GB at 100 M nodes) are neither planned
+// twice nor found missing at the first walk.
+int prepare_walk_sampler(gn2v_graph *g, const gn2v_walk_params *wp, hipStream_t s) {
+    if (check_walk_params(wp)) return 1;
+    if (!walk_consts(g, wp).second_order) return 0;
+    std::lock_guard<std::mutex> lock(g->mu);
+    return ensure_edge_set(g, s);
+}
+}  // namespace gn2v_host
+
 extern "C" {
 
 int gn2v_version(void) { return GN2V_VERSION; }
@@ -683,6 +713,7 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->own_edge_types) (void)hipFree(g->own_edge_types);
     if (g->counters) (void)hipFree(g->counters);
     if (g->part_ptrs_dev) (void)hipFree(g->part_ptrs_dev);
+    if (g->indeg) (void)hipFree(g->indeg);
     if (g->cursors) (void)hipFree(g->cursors);
     if (g->edge_set) (void)hipFree(g->edge_set);
     if (g->edge_filter) (void)hipFree(g->edge_filter);
@@ -1015,6 +1046,7 @@ int gn2v_stats_reset(gn2v_graph *g, void *stream) {
     if (fold_events(g)) return 1;
     g->train_ms = g->walk_ms = 0.0;
     g->train_launches = g->walk_launches = 0;
+    g->resident_launches = g->resident_record = 0;
     HIP_TRY(hipMemsetAsync(g->counters, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return 0;
@@ -1036,6 +1068,8 @@ int gn2v_stats_read(gn2v_graph *g, gn2v_stats *stats, void *stream) {
     stats->walk_ms = g->walk_ms;
     stats->train_launches = g->train_launches;
     stats->walk_launches = g->walk_launches;
+    stats->resident_launches = g->resident_launches;
+    stats->resident_record = g->resident_record;
     return 0;
 }
 

@@ -11,7 +11,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "block_kernels.h"
@@ -96,8 +98,10 @@ uint32_t resident_rows(uint32_t ld, uint32_t record, uint32_t k) {
     if (ld == 0 || ld > 256) return 0;
     const size_t staging = block_lds_words_per_wave(ld, record, k) * 4 * 16 + 64;
     const size_t lds = 160 * 1024;
-    return staging >= lds ? 0
-                          : (uint32_t)std::min<size_t>((lds - staging) / ((size_t)ld * 4), 4096);
+    // a row and its node id
+    return staging >= lds
+               ? 0
+               : (uint32_t)std::min<size_t>((lds - staging) / ((size_t)ld * 4 + 4), 4096);
 }
 
 // The record length the resident kernel runs a cell of `rows` rows with: the plan's, or the
@@ -206,6 +210,58 @@ struct Buffers {
 };
 }  // namespace
 
+namespace {
+__global__ void max_u32_kernel(const uint32_t *__restrict__ v, uint64_t n,
+                               unsigned int *__restrict__ out) {
+    unsigned int m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        m = max(m, v[i]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// The in-degrees of the graph (how often a node is the endpoint of a uniform random directed
+// edge: the weights of the degree-proportional negatives) and the largest of them, computed once
+// per handle and kept (4 B per node): a placement rebuilds the alias tables every round, and
+// 2 x 10^9 atomic increments per rebuild were 2.3 % of the GPU time at 100 M nodes.  Returns 1
+// (no error recorded) when the handle cannot keep them: the caller counts into its own storage.
+int in_degrees(gn2v_graph *g, hipStream_t s, uint32_t **out) {
+    if (!g->indeg) {
+        if (g->indeg_failed) return 1;
+        const uint64_t n = g->view.n_nodes, E = g->view.n_edges;
+        uint32_t *indeg = nullptr;
+        if (hipMalloc((void **)&indeg, (n + 1) * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            g->indeg_failed = true;
+            return 1;
+        }
+        hipError_t e = hipMemsetAsync(indeg, 0, (n + 1) * sizeof(uint32_t), s);
+        if (e == hipSuccess && E) {
+            const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(gn2v::indegree_kernel, dim3(blocks), dim3(256), 0, s,
+                               g->view.col_idx, E, indeg);
+            const unsigned nb = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(max_u32_kernel, dim3(nb), dim3(256), 0, s, indeg, n, indeg + n);
+            e = hipGetLastError();
+        }
+        unsigned int m = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&m, indeg + n, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);  // complete before any other stream uses it
+        if (e != hipSuccess) {
+            (void)hipFree(indeg);
+            g->indeg_failed = true;
+            return 1;
+        }
+        g->indeg = indeg;
+        g->max_in_degree = m;
+        g->max_in_degree_known = true;
+    }
+    *out = g->indeg;
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int gn2v_block_plan_check(gn2v_graph *g, gn2v_block_plan *plan) {
@@ -244,10 +300,12 @@ int gn2v_block_alias_temp_bytes(uint64_t n_nodes, uint64_t *bytes) {
 
 int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_alias,
                      uint64_t *d_cell_rows, uint32_t *d_hub_bits, uint32_t *d_hot_list,
-                     uint8_t *d_hot_slot, void *d_temp, uint64_t temp_bytes, void *stream) {
+                     uint8_t *d_hot_slot, const uint32_t *d_inv, void *d_temp,
+                     uint64_t temp_bytes, void *stream) {
     if (check_plan(g, plan)) return 1;
-    if (!d_alias || !d_cell_rows || !d_hub_bits || !d_hot_list || !d_hot_slot || !d_temp)
-        return fail("NULL pointer");
+    if (!d_alias || !d_cell_rows || !d_temp) return fail("NULL pointer");
+    if (plan->hot_rows && (!d_hub_bits || !d_hot_list || !d_hot_slot))
+        return fail("a plan with hot rows needs d_hub_bits, d_hot_list and d_hot_slot");
     if ((g->view.n_nodes + plan->parts - 1) / plan->parts >= (1ULL << 31))
         return fail("a context part must have fewer than 2^31 rows");
     const uint64_t n = g->view.n_nodes;
@@ -259,17 +317,24 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
     char *t = (char *)d_temp;
-    uint32_t *indeg = (uint32_t *)t;
+    // the in-degrees: computed once per handle when it can keep them (a placement rebuilds the
+    // tables every round), else into the temporary storage
+    uint32_t *indeg = nullptr;
+    if (in_degrees(g, s, &indeg)) {
+        indeg = (uint32_t *)t;
+        HIP_TRY(hipMemsetAsync(indeg, 0, n * sizeof(uint32_t), s));
+        const uint64_t E = g->view.n_edges;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(gn2v::indegree_kernel, dim3(blocks), dim3(256), 0, s, g->view.col_idx,
+                           E, indeg);
+        HIP_TRY(hipGetLastError());
+    }
     uint32_t *stack = (uint32_t *)(t + align256(n * 4));
     unsigned long long *weight = (unsigned long long *)(t + 2 * align256(n * 4));
-    HIP_TRY(hipMemsetAsync(indeg, 0, n * sizeof(uint32_t), s));
-    HIP_TRY(hipMemsetAsync(d_hub_bits, 0, ((n + 31) / 32) * sizeof(uint32_t), s));
-    HIP_TRY(hipMemsetAsync(d_hot_slot, 0xFF, n, s));
-    const uint64_t E = g->view.n_edges;
-    const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(gn2v::indegree_kernel, dim3(blocks), dim3(256), 0, s, g->view.col_idx, E,
-                       indeg);
-    HIP_TRY(hipGetLastError());
+    if (plan->hot_rows) {
+        HIP_TRY(hipMemsetAsync(d_hub_bits, 0, ((n + 31) / 32) * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(d_hot_slot, 0xFF, n, s));
+    }
     hipLaunchKernelGGL(gn2v::cell_rows_kernel, dim3(1), dim3(64), 0, s, n, plan->parts,
                        plan->slices, (unsigned long long *)d_cell_rows);
     HIP_TRY(hipGetLastError());
@@ -277,19 +342,79 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
     hipLaunchKernelGGL(gn2v::alias_kernel, dim3((cells + 63) / 64), dim3(64), 0, s, indeg, n,
                        plan->parts, plan->slices, (const unsigned long long *)d_cell_rows,
                        (unsigned long long *)d_alias, weight, stack, d_hub_bits, plan->hot_rows,
-                       d_hot_list, d_hot_slot);
+                       d_hot_list, d_hot_slot, d_inv);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_block_placement_temp_bytes(uint64_t n_nodes, uint64_t *bytes) {
+    if (!bytes) return fail("bytes is NULL");
+    size_t sort = 0;
+    rocprim::double_buffer<unsigned long long> kb(nullptr, nullptr);
+    rocprim::double_buffer<uint32_t> vb(nullptr, nullptr);
+    if (rocprim::radix_sort_pairs(nullptr, sort, kb, vb, n_nodes ? n_nodes : 1, 0, 64,
+                                  (hipStream_t)0) != hipSuccess)
+        return fail("rocprim::radix_sort_pairs (size query)");
+    *bytes = 2 * align256(n_nodes * 8) + 2 * align256(n_nodes * 4) + align256(sort);
+    return 0;
+}
+
+int gn2v_block_placement(gn2v_graph *g, uint32_t classes, uint64_t seed, uint64_t round_id,
+                         uint32_t *d_place, uint32_t *d_inv, void *d_temp, uint64_t temp_bytes,
+                         void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    if (!d_place || !d_inv || !d_temp) return fail("NULL pointer");
+    const uint64_t n = g->view.n_nodes;
+    if (classes < 1 || classes > n || classes >= (1u << 23))
+        return fail("classes must be in [1, min(n_nodes, 2^23))");
+    uint64_t need = 0;
+    if (gn2v_block_placement_temp_bytes(n, &need)) return 1;
+    if (temp_bytes < need) return fail("temporary storage too small for the placement");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    hipStream_t s = (hipStream_t)stream;
+    char *t = (char *)d_temp;
+    unsigned long long *k0 = (unsigned long long *)t, *k1 = (unsigned long long *)(t + align256(n * 8));
+    uint32_t *v0 = (uint32_t *)(t + 2 * align256(n * 8));
+    uint32_t *v1 = (uint32_t *)(t + 2 * align256(n * 8) + align256(n * 4));
+    void *sort_tmp = t + 2 * align256(n * 8) + 2 * align256(n * 4);
+    size_t sort_bytes = temp_bytes - (2 * align256(n * 8) + 2 * align256(n * 4));
+    const uint64_t pkey = gn2v::draw(gn2v::mix64(seed ^ gn2v::kTagPlace), round_id);
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(gn2v::place_keys_kernel, dim3(blocks), dim3(256), 0, s, n, classes, pkey, k0,
+                       v0);
+    HIP_TRY(hipGetLastError());
+    rocprim::double_buffer<unsigned long long> kb(k0, k1);
+    rocprim::double_buffer<uint32_t> vb(v0, v1);
+    HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, kb, vb, n, 0, 40 + bits_for(classes), s));
+    hipLaunchKernelGGL(gn2v::place_scatter_kernel, dim3(blocks), dim3(256), 0, s, n, classes,
+                       vb.current(), d_place, d_inv);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_block_place_walks(const uint32_t *d_place, const uint32_t *d_walks, uint64_t n_entries,
+                           uint32_t *d_out, void *stream) {
+    if (n_entries == 0) return 0;
+    if (!d_place || !d_walks || !d_out) return fail("NULL pointer");
+    DeviceGuard guard(DeviceGuard::of_pointer(d_out));
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_entries + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(gn2v::place_walks_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       d_place, d_walks, n_entries, d_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
-                          const uint32_t *d_walks, uint64_t n_walks, uint64_t seed, uint64_t epoch,
+                          const uint32_t *d_walks, const uint32_t *d_placed, uint64_t n_walks,
+                          uint64_t seed, uint64_t epoch,
                           uint64_t first_walk, uint32_t part_lo, uint32_t part_n, uint64_t *d_work,
                           const uint32_t *d_hub_bits, uint64_t *pairs, hipStream_t s) {
     gn2v::ExtractArgs a{};
     a.g = g->view;
     a.p = d;
     a.walks = d_walks;
+    a.placed = d_placed;
     a.n_walks = n_walks;
     a.ekey = gn2v::epoch_key(seed, epoch);
     a.first_walk = first_walk;
@@ -316,7 +441,8 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
 }
 
 int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
-                     uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                     const uint32_t *d_placed_walks, uint64_t n_walks, uint64_t seed,
+                     uint64_t epoch, uint64_t first_walk,
                      uint32_t part_lo, uint32_t part_n, uint64_t *d_work,
                      uint64_t *d_cell_offsets, void *stream) {
     if (check_plan(g, plan)) return 1;
@@ -326,10 +452,13 @@ int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t 
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(d_work, 0, GN2V_BLOCK_WORK_WORDS * sizeof(uint64_t), s));
+    // the waves' counts and the counters of the plan's cells (the scan reads no more)
+    HIP_TRY(hipMemsetAsync(d_work, 0,
+                           ((size_t)gn2v::kPrepWaves + (size_t)d.parts * d.slices) * sizeof(uint64_t),
+                           s));
     if (n_walks &&
-        launch_extract(g, d, false, d_walks, n_walks, seed, epoch, first_walk, part_lo, part_n,
-                       d_work, nullptr, nullptr, s))
+        launch_extract(g, d, false, d_walks, d_placed_walks, n_walks, seed, epoch, first_walk,
+                       part_lo, part_n, d_work, nullptr, nullptr, s))
         return 1;
     hipLaunchKernelGGL(gn2v::block_scan_kernel, dim3(1), dim3(1024), 0, s,
                        (unsigned long long *)d_work,
@@ -346,7 +475,8 @@ int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes) {
 }
 
 int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
-                       uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                       const uint32_t *d_placed_walks, uint64_t n_walks, uint64_t seed,
+                       uint64_t epoch, uint64_t first_walk,
                        uint32_t part_lo, uint32_t part_n, const uint64_t *d_work,
                        const uint32_t *d_hub_bits, uint64_t n_pairs, uint64_t *d_pairs,
                        void *d_temp, uint64_t temp_bytes, void *stream) {
@@ -364,8 +494,9 @@ int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_
     char *t = (char *)d_temp;
     unsigned long long *unsorted = (unsigned long long *)t;
     const size_t head = align256(n_pairs * 8);
-    if (launch_extract(g, d, true, d_walks, n_walks, seed, epoch, first_walk, part_lo, part_n,
-                       const_cast<uint64_t *>(d_work), d_hub_bits, (uint64_t *)unsorted, s))
+    if (launch_extract(g, d, true, d_walks, d_placed_walks, n_walks, seed, epoch, first_walk,
+                       part_lo, part_n, const_cast<uint64_t *>(d_work), d_hub_bits,
+                       (uint64_t *)unsorted, s))
         return 1;
     const uint32_t end_bit = std::max(d.ctx_bits + 1, d.ctx_bits + d.row_bits + cell_bits(d));
     return sort_words(t + head, temp_bytes - head, unsorted, (unsigned long long *)d_pairs,
@@ -376,9 +507,23 @@ extern "C++" {
 // dynamic LDS beyond 64 KB has to be allowed per kernel, once
 template <class K>
 static void allow_lds(K kernel, size_t lds) {
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // per kernel instantiation (K) and device: the largest size allowed so far
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<const void *, int>, size_t>> allowed;
+    if (lds <= 64 * 1024) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const std::pair<const void *, int> key(reinterpret_cast<const void *>(kernel), dev);
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &e : allowed)
+        if (e.first == key) {
+            if (e.second >= lds) return;
+            e.second = lds;
+            (void)hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            return;
+        }
+    allowed.push_back({key, lds});
+    (void)hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 template <int CH>
@@ -433,8 +578,13 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
 }
 
 template <int CH>
-static void launch_resident_ch(dim3 grid, size_t lds, hipStream_t s, const gn2v::BlockArgs &a) {
-    if (a.ld == (uint32_t)CH * 64) {
+static void launch_resident_ch(bool det, dim3 grid, size_t lds, hipStream_t s,
+                               const gn2v::BlockArgs &a) {
+    if (det) {  // one workgroup walks the cells in order (block_kernels.h)
+        auto kernel = gn2v::sgns_resident_kernel<CH, false, true>;
+        allow_lds(kernel, lds);
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(1024), lds, s, a);
+    } else if (a.ld == (uint32_t)CH * 64) {
         auto kernel = gn2v::sgns_resident_kernel<CH, true>;
         allow_lds(kernel, lds);
         hipLaunchKernelGGL(kernel, grid, dim3(1024), lds, s, a);
@@ -463,7 +613,8 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         return fail("learning rate / clipping value must be finite, clipping value positive");
     if (io->part >= plan->parts || part_n < 1 || io->part + part_n > plan->parts)
         return fail("part out of range");
-    if (!io->d_pairs || !io->d_cell_offsets || !io->d_central || (!io->d_context && part_n == 1))
+    if (!io->d_pairs || !io->d_cell_offsets || !io->d_central ||
+        (!io->d_context && !io->d_context_table && part_n == 1))
         return fail("NULL pointer");
     if ((tp->flags & GN2V_TRAIN_SCALE_FREE) && (!io->d_alias || !io->d_cell_rows))
         return fail("degree-proportional negatives need the tables of gn2v_block_alias");
@@ -490,6 +641,9 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     a.context = io->d_context;
     a.xld = io->context_ld ? io->context_ld : tp->ld;
     if (a.xld < tp->ld || (a.xld & 3)) return fail("context_ld must be a multiple of 4 and >= ld");
+    a.inv = io->d_inv;
+    a.ctx_table = io->d_context_table;
+    if (a.ctx_table && !a.inv) return fail("d_context_table is for plans under a placement (d_inv)");
     a.counters = g->counters;
     a.n_nodes = g->view.n_nodes;
     a.ekey = gn2v::epoch_key(seed, epoch);
@@ -513,16 +667,21 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     // wavefronts meet on the same few rows: exclusive slices divide that crowd by the XCDs and
     // keep it inside one L2, which is why they need no atomics from GN2V_BLOCK_PATH_MIN_NODES up).
     const bool exclusive = slices_are_xcd_exclusive(g, d.slices);
-    // Resident cells (block_kernels.h sgns_resident_kernel): every cell of the plan fits one
-    // workgroup's LDS -- what gn2v_block_auto_plan arranges for graphs up to 106 M nodes at
-    // d = 128.  One workgroup per cell, contextual rows read and updated in LDS: exact, whatever
-    // the size of the graph (no flavour of store or atomic is involved).
+    // Resident cells (block_kernels.h sgns_resident_kernel): a plan of MORE THAN 16 SLICES whose
+    // every cell fits one workgroup's LDS -- what gn2v_block_auto_plan arranges for graphs up to
+    // 105 M nodes at d = 128 (its XCD-cell plans have 1 or 8 slices; an explicit plan of a few
+    // slices on a tiny graph keeps sgns_block_kernel although its cells would fit).  One
+    // workgroup per cell, contextual rows read and updated in LDS: no other CU touches them, no
+    // flavour of global store or atomic is involved.  Inside the workgroup the rows are plain
+    // read-modify-writes of its 64 concurrent 16-lane groups, so updates that meet on a row
+    // within ~100 cycles lose one (block_kernels.h; counted in tests/test_gpu_resident.py).
+    // GN2V_TRAIN_DETERMINISTIC runs the same kernel's deterministic instantiation.
     static const size_t resident_env = env_size("GN2V_BLOCK_RESIDENT", 1);  // 0: never (A/B)
     const uint64_t max_cell_rows =
         gn2v::stripe_count(gn2v::stripe_count(g->view.n_nodes, 0, d.parts), 0, d.slices);
     const uint32_t res_record = resident_record(tp->ld, d.record, tp->k, max_cell_rows);
     const bool resident =
-        !det && resident_env &&
+        resident_env && d.slices > gn2v_host::kCursorSlices &&
         !(tp->flags & (GN2V_TRAIN_ATOMIC | GN2V_TRAIN_WRITE_THROUGH | GN2V_TRAIN_WRITE_BACK)) &&
         res_record != 0;
     int wmc = (tp->flags & GN2V_TRAIN_ATOMIC)          ? gn2v::kAtomic
@@ -558,6 +717,9 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     if (d.slices > gn2v_host::kCursorSlices && !resident)
         return fail("more than 16 slices need cells that fit a workgroup's LDS (default update "
                     "mode, rows up to 256 floats)");
+    if (a.inv && !resident)
+        return fail("a placement (d_inv) needs resident cells: only their kernel reaches the rows "
+                    "through it");
     if (part_n > 1) {
         *took_group = resident;
         if (!resident) return 0;
@@ -566,7 +728,7 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     if (resident) {
         a.p.record = res_record;
         const size_t lds = block_lds_words_per_wave(tp->ld, res_record, tp->k) * 4 * 16 +
-                           (size_t)max_cell_rows * tp->ld * 4 + 16;
+                           (size_t)max_cell_rows * (tp->ld * 4 + 4) + 16;
         std::lock_guard<std::mutex> lock(g->mu);
         hipStream_t caller = s;
         if (g->train_stream) {
@@ -577,16 +739,19 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         EventPair ev;
         if (get_events(g, &ev)) return 1;
         HIP_TRY(hipEventRecord(ev.a, s));
+        if (det) a.sweep = part_n;  // the deterministic form walks the parts itself
         if (tp->ld <= 64)
-            launch_resident_ch<1>(dim3(d.slices, part_n), lds, s, a);
+            launch_resident_ch<1>(det, dim3(d.slices, part_n), lds, s, a);
         else if (tp->ld <= 128)
-            launch_resident_ch<2>(dim3(d.slices, part_n), lds, s, a);
+            launch_resident_ch<2>(det, dim3(d.slices, part_n), lds, s, a);
         else
-            launch_resident_ch<4>(dim3(d.slices, part_n), lds, s, a);
+            launch_resident_ch<4>(det, dim3(d.slices, part_n), lds, s, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev.b, s));
         g->train_events.push_back(ev);
         g->train_launches++;
+        g->resident_launches++;
+        g->resident_record = res_record;
         if (g->train_stream) {
             HIP_TRY(hipEventRecord(g->ts_out, s));
             HIP_TRY(hipStreamWaitEvent(caller, g->ts_out, 0));
@@ -698,41 +863,11 @@ int gn2v_block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block
 }  // extern "C"
 
 namespace {
-__global__ void max_u32_kernel(const uint32_t *__restrict__ v, uint64_t n,
-                               unsigned int *__restrict__ out) {
-    unsigned int m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (uint64_t)gridDim.x * blockDim.x)
-        m = max(m, v[i]);
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
-}
-
 // largest in-degree of the graph (computed once per handle): the most frequent context
 int max_in_degree(gn2v_graph *g, hipStream_t s, uint64_t *out) {
     if (!g->max_in_degree_known) {
-        const uint64_t n = g->view.n_nodes, E = g->view.n_edges;
         uint32_t *indeg = nullptr;
-        if (hipMalloc((void **)&indeg, (n + 1) * sizeof(uint32_t)) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail("out of device memory for the in-degrees");
-        }
-        hipError_t e = hipMemsetAsync(indeg, 0, (n + 1) * sizeof(uint32_t), s);
-        if (e == hipSuccess && E) {
-            const unsigned blocks = (unsigned)std::min<uint64_t>((E + 255) / 256, 256 * 16);
-            hipLaunchKernelGGL(gn2v::indegree_kernel, dim3(blocks), dim3(256), 0, s,
-                               g->view.col_idx, E, indeg);
-            const unsigned nb = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
-            hipLaunchKernelGGL(max_u32_kernel, dim3(nb), dim3(256), 0, s, indeg, n, indeg + n);
-            e = hipGetLastError();
-        }
-        unsigned int m = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&m, indeg + n, 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void)hipFree(indeg);
-        if (e != hipSuccess) return fail(std::string("in-degrees: ") + hipGetErrorString(e));
-        g->max_in_degree = m;
-        g->max_in_degree_known = true;
+        if (in_degrees(g, s, &indeg)) return fail("out of device memory for the in-degrees");
     }
     *out = g->max_in_degree;
     return 0;
@@ -743,7 +878,7 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
     if (!parts || !slices || world < 1) return fail("bad arguments");
     constexpr uint64_t kMinRows = 32768, kXcds = 8;
     // Rows up to 256 floats, a graph of GN2V_RESIDENT_MIN_NODES nodes or more that is
-    // small enough for cells that fit a workgroup's LDS (524 288 cells x ~200 rows at d = 128: 106 M
+    // small enough for cells that fit a workgroup's LDS (524 288 cells x ~200 rows at d = 128: 105 M
     // nodes): RESIDENT CELLS -- every contextual row is read and updated in the LDS of the one
     // workgroup that owns its cell (sgns_resident_kernel).  As few cells as hold the rows, up to
     // 256 slices per part (a launch covers a part: one workgroup per cell and CU).  Smaller
@@ -752,8 +887,8 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
     // 2 708 nodes, 0.994 vs 0.998 at 20 k; equal from 200 k nodes, 0.956 vs 0.920 at 1 M after
     // three epochs: DESIGN.md 7.3) -- the negatives of a pair come from its context's cell.
     const uint64_t max_nodes = env_size("GN2V_RESIDENT_MAX_NODES", GN2V_RESIDENT_MAX_NODES);
-    const uint64_t fit = allow_resident && n_nodes >= GN2V_RESIDENT_MIN_NODES &&
-                                 n_nodes <= max_nodes
+    const uint64_t min_nodes = env_size("GN2V_RESIDENT_MIN_NODES", GN2V_RESIDENT_MIN_NODES);
+    const uint64_t fit = allow_resident && n_nodes >= min_nodes && n_nodes <= max_nodes
                              ? resident_fit(ld, k) : 0;
     if (fit >= 16 && n_nodes <= fit * (gn2v::kMaxCells - 512)) {
         const uint64_t cells = (n_nodes + fit - 1) / fit;
@@ -779,7 +914,8 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
             else
                 p += world;
         }
-        if (p * sl <= gn2v::kMaxCells && (world == 1 || sl >= 64)) {
+        // (gn2v_block_step runs cells in LDS for plans of more than 16 slices only)
+        if (p * sl <= gn2v::kMaxCells && sl > gn2v_host::kCursorSlices && (world == 1 || sl >= 64)) {
             *parts = (uint32_t)p;
             *slices = (uint32_t)sl;
             return 0;
@@ -856,7 +992,10 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     // per round when there are that many parts, more when memory is short.
     const uint64_t budget = free_bytes / 4 * 3;
     const uint64_t copies = overlap ? 3 : 2;
-    auto walk_bytes = [&](uint64_t rw) { return 4 * L * rw * (world > 1 ? world + 1ull : 1ull); };
+    // (resident cells -- more than 16 slices -- are trained under a round's placement: the walks
+    // the extraction reads exist a second time, with placed node ids)
+    const uint64_t copies_of_walks = (world > 1 ? world + 1ull : 1ull) + (slices > 16 ? world : 0);
+    auto walk_bytes = [&](uint64_t rw) { return 4 * L * rw * copies_of_walks; };
     auto group_bytes = [&](uint64_t rw, uint64_t gp) {  // + 1/8: parts are not equally heavy
         const uint64_t per_part = rw * pairs / parts + 1;
         return copies * 8 * (per_part * gp + per_part * gp / 8);
@@ -890,6 +1029,8 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
     }
     if (!io->d_central || !io->context_parts || !io->d_work || !io->d_cell_offsets)
         return fail("NULL pointer in the round's io");
+    if ((io->d_inv != nullptr) != (io->d_placed_walks != nullptr))
+        return fail("a round under a placement needs d_inv and d_placed_walks together");
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     hipStream_t s = (hipStream_t)stream;
@@ -901,8 +1042,8 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
         const uint32_t j = io->next_unit / groups, p0 = (io->next_unit % groups) * gp;
         const uint32_t pn = std::min(gp, parts - p0);
         const gn2v_block_plan *pj = &plans[j];
-        if (gn2v_block_count(g, pj, io->d_walks, n_walks, seed, epoch, first_walk, p0, pn,
-                             io->d_work, io->d_cell_offsets, s))
+        if (gn2v_block_count(g, pj, io->d_walks, io->d_placed_walks, n_walks, seed, epoch,
+                             first_walk, p0, pn, io->d_work, io->d_cell_offsets, s))
             return 1;
         uint64_t n_pairs = 0;  // the one host read of the group
         HIP_TRY(hipMemcpyAsync(&n_pairs, io->d_cell_offsets + cells, 8, hipMemcpyDeviceToHost, s));
@@ -914,9 +1055,9 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
             io->needed_pairs = n_pairs;
             return GN2V_ROUND_GROW;
         }
-        if (gn2v_block_extract(g, pj, io->d_walks, n_walks, seed, epoch, first_walk, p0, pn,
-                               io->d_work, io->d_hub_bits, n_pairs, io->d_pairs, io->d_temp,
-                               io->temp_bytes, s))
+        if (gn2v_block_extract(g, pj, io->d_walks, io->d_placed_walks, n_walks, seed, epoch,
+                               first_walk, p0, pn, io->d_work, io->d_hub_bits, n_pairs,
+                               io->d_pairs, io->d_temp, io->temp_bytes, s))
             return 1;
         // resident cells: the whole group in one launch (its workgroups are handed to the CUs
         // as they fall free; a launch per part would wait for the part's heaviest cell)
@@ -945,6 +1086,8 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
             step.central_ld = (uint64_t)stripes * ld;
             step.d_context = nullptr;
             step.context_ld = io->context_ld;
+            step.d_inv = io->d_inv;
+            step.d_context_table = io->d_context_table;
             step.block_id = round_id * stripes + j;
             step.part = p0;
             if (block_step(g, tp, pj, &step, seed, epoch, lr, s, pn, g->part_ptrs_dev, &took_group))
@@ -962,6 +1105,8 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
             step.central_ld = (uint64_t)stripes * ld;
             step.d_context = io->context_parts[p];
             step.context_ld = io->context_ld;
+            step.d_inv = io->d_inv;
+            step.d_context_table = io->d_context_table;
             step.block_id = round_id * stripes + j;
             step.part = p;
             if (gn2v_block_step(g, tp, pj, &step, seed, epoch, lr, s)) return 1;
@@ -1014,6 +1159,9 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     uint32_t V = stripes ? stripes : 1;
     while (V > 1 && n / V < 2) V /= 2;
 
+    // the walk sampler's own memory first: everything below is sized from what is free
+    if (prepare_walk_sampler(g, wp, s)) return 1;
+
     gn2v_block_plan plan{};
     plan.world = V;
     plan.rank = 0;
@@ -1033,7 +1181,13 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         return kOutOfMemory;
     }
     plan.flags = tp->flags & GN2V_TRAIN_DOWNSAMPLE;
-    plan.hot_rows = (uint32_t)env_size("GN2V_HOT_ROWS", GN2V_BLOCK_HOT_DEFAULT);
+    // Resident cells (more than 16 slices): no hot rows -- every row of a cell lives in LDS -- and
+    // a PLACEMENT per round (block_kernels.h "Placement of a round"): the cell-mates of a node,
+    // among which the negatives of a pair are drawn, change from round to round.
+    // GN2V_BLOCK_PERMUTE=0: the fixed cells of round 4 (A/B).
+    const bool resident_plan = plan.slices > gn2v_host::kCursorSlices;
+    const bool permute = resident_plan && env_size("GN2V_BLOCK_PERMUTE", 1) != 0;
+    plan.hot_rows = resident_plan ? 0 : (uint32_t)env_size("GN2V_HOT_ROWS", GN2V_BLOCK_HOT_DEFAULT);
     plan.hot_flush = (uint32_t)env_size("GN2V_HOT_FLUSH", 0);
     std::vector<gn2v_block_plan> plans(V, plan);
     for (uint32_t j = 0; j < V; ++j) {
@@ -1055,20 +1209,32 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     uint64_t *alias = nullptr, *cell_rows = nullptr;
     uint32_t *hub_bits = nullptr, *hot_list = nullptr;
     uint8_t *hot_slot = nullptr;
+    // under a placement the alias tables are rebuilt every round: their temporary storage stays
+    uint32_t *place = nullptr, *inv = nullptr;
+    void *alias_tmp = nullptr, *place_tmp = nullptr;
+    uint64_t alias_tb = 0, place_tb = 0;
     if (scale_free || plan.hot_rows) {  // uniform negatives: the hot rows (frequent contexts) only
-        uint64_t tb = 0;
-        gn2v_block_alias_temp_bytes(n, &tb);
-        void *tmp = nullptr;
-        if (buf.alloc(&alias, n * 8) || buf.alloc(&cell_rows, (cells + 1) * 8) ||
-            buf.alloc(&hub_bits, ((n + 31) / 32) * 4) ||
-            buf.alloc(&hot_list, (size_t)cells * GN2V_BLOCK_HOT_MAX * 4) ||
-            buf.alloc(&hot_slot, n) || buf.alloc(&tmp, tb))
+        gn2v_block_alias_temp_bytes(n, &alias_tb);
+        if (buf.alloc(&alias, n * 8) || buf.alloc(&cell_rows, (cells + 1) * 8)) return kOutOfMemory;
+        if (plan.hot_rows &&
+            (buf.alloc(&hub_bits, ((n + 31) / 32) * 4) ||
+             buf.alloc(&hot_list, (size_t)cells * GN2V_BLOCK_HOT_MAX * 4) || buf.alloc(&hot_slot, n)))
             return kOutOfMemory;
-        if (gn2v_block_alias(g, &plan, alias, cell_rows, hub_bits, hot_list, hot_slot, tmp, tb, s))
-            return 1;
-        HIP_TRY(hipStreamSynchronize(s));
-        (void)hipFree(tmp);
-        buf.ptrs.pop_back();
+        if (buf.alloc(&alias_tmp, alias_tb)) return kOutOfMemory;
+        if (!permute) {
+            if (gn2v_block_alias(g, &plan, alias, cell_rows, hub_bits, hot_list, hot_slot, nullptr,
+                                 alias_tmp, alias_tb, s))
+                return 1;
+            HIP_TRY(hipStreamSynchronize(s));
+            (void)hipFree(alias_tmp);
+            buf.ptrs.pop_back();
+            alias_tmp = nullptr;
+        }
+    }
+    if (permute) {
+        if (gn2v_block_placement_temp_bytes(n, &place_tb)) return 1;
+        if (buf.alloc(&place, n * 4) || buf.alloc(&inv, n * 4) || buf.alloc(&place_tmp, place_tb))
+            return kOutOfMemory;
     }
 
     mark("alias tables");
@@ -1086,7 +1252,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         if (automatic) round_walks = auto_walks;
     }
     round_walks = std::max<uint64_t>(1, std::min(round_walks, (walks_per_epoch + V - 1) / V));
-    uint32_t *walks = nullptr;
+    uint32_t *walks = nullptr, *placed = nullptr;
     uint64_t *pairs = nullptr, *work = nullptr, *cell_offsets = nullptr, *part_first = nullptr;
     void *tmp = nullptr;
     uint64_t tb = 0, cap = 0;
@@ -1106,8 +1272,9 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         cap = round_walks * pairs_per_walk / parts * group_parts;
         cap += cap / 8 + 1024;
         gn2v_block_extract_temp_bytes(cap, &tb);
-        if (!(buf.alloc(&walks, V * round_walks * L * 4) || buf.alloc(&pairs, cap * 8) ||
-              buf.alloc(&tmp, tb)))
+        if (!(buf.alloc(&walks, V * round_walks * L * 4) ||
+              (permute && buf.alloc(&placed, V * round_walks * L * 4)) ||
+              buf.alloc(&pairs, cap * 8) || buf.alloc(&tmp, tb)))
             break;
         // somebody else took the memory between the query and here: smaller groups, then an
         // automatic round halves
@@ -1130,7 +1297,9 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     // they belong and part p is the rows p, p + parts, ... (gn2v_block_io.context_ld).
     const size_t table_bytes = (size_t)n * ld * sizeof(float);
     const char *layout = getenv("GN2V_BLOCK_LAYOUT");
-    const bool part_major = parts > 1 && !(layout && !strcmp(layout, "natural")) &&
+    // (under a placement the kernel reaches every row through the placement's inverse: the
+    // table simply stays in node order)
+    const bool part_major = !permute && parts > 1 && !(layout && !strcmp(layout, "natural")) &&
                             (free_b > table_bytes + ((size_t)1 << 28) ||
                              (layout && !strcmp(layout, "parts")));
     std::vector<uint64_t> first_row(parts + 1, 0);
@@ -1153,6 +1322,9 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         part_rows[p] = part_major ? d_contextual + first_row[p] * ld : d_contextual + (size_t)p * ld;
     gn2v_block_round_io rio{};
     rio.d_walks = walks;
+    rio.d_placed_walks = placed;
+    rio.d_inv = inv;
+    rio.d_context_table = permute ? d_contextual : nullptr;
     rio.d_alias = alias;
     rio.d_cell_rows = cell_rows;
     rio.d_hub_bits = hub_bits;
@@ -1176,6 +1348,14 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         for (uint64_t first = 0; first < walks_per_epoch; first += super_walks, ++round_id) {
             const uint64_t nw = std::min(super_walks, walks_per_epoch - first);
             if (gn2v_walks(g, wp, seed, e, first, nw, walks, s)) return 1;
+            if (permute) {  // this round's cells
+                if (gn2v_block_placement(g, 1, seed, round_id, place, inv, place_tmp, place_tb, s))
+                    return 1;
+                if (alias && gn2v_block_alias(g, &plan, alias, cell_rows, nullptr, nullptr, nullptr,
+                                              inv, alias_tmp, alias_tb, s))
+                    return 1;
+                if (gn2v_block_place_walks(place, walks, nw * L, placed, s)) return 1;
+            }
             rio.next_unit = 0;
             for (;;) {
                 const int rc = gn2v_block_round(g, tp, plans.data(), V, &rio, nw, seed, e, first,

@@ -90,15 +90,19 @@ struct gn2v_graph {
     // largest in-degree (the most frequent context), computed on the first automatic plan
     uint64_t max_in_degree = 0;
     bool max_in_degree_known = false;
+    uint32_t *indeg = nullptr;  // u32[n_nodes + 1] (the last word: their maximum), kept once computed
+    bool indeg_failed = false;
     unsigned long long *counters = nullptr;  // device, 4 x u64
     unsigned long long *cursors = nullptr;   // device, ring of record-ticket arrays (block trainer)
     uint32_t cursor_slot = 0;
     std::vector<gn2v_host::EventPair> train_events, walk_events, free_events;
     double train_ms = 0.0, walk_ms = 0.0;
     uint32_t train_launches = 0, walk_launches = 0;
+    uint32_t resident_launches = 0, resident_record = 0;  // sgns_resident_kernel (gn2v_stats)
     std::mutex mu;  // guards the event / timing bookkeeping (launches themselves are stream ordered)
 };
 
 namespace gn2v_host {
 int get_events(gn2v_graph *g, EventPair *ev);
+int prepare_walk_sampler(gn2v_graph *g, const gn2v_walk_params *wp, hipStream_t s);
 }

@@ -25,6 +25,13 @@ ever held by two GPUs.
   crosses the fabric.
 * Training: ``gn2v_block_step`` per part, negatives drawn degree-proportionally inside the
   cell of the pair's context (one alias table per cell).
+* Placement (resident cells, i.e. plans of more than 16 slices): which cell a node's contextual
+  row is trained in changes every round -- ``gn2v_block_placement``, a seeded permutation of the
+  node ids inside their classes modulo ``parts`` (several ranks: a row never leaves its part) or
+  over the whole graph (one GPU: the table stays in node order and the kernel reaches the rows
+  through the placement's inverse) -- so that the negatives a context meets over a fit range
+  over the part / the graph, not over one fixed set of ~200 cell-mates
+  (node2vec_skipgram.py:101-102).  The alias tables follow the placement, round by round.
 
 Preparation of the next group (for the first group of a round: walk generation and all-gather;
 then extraction and sort) runs on a second stream while the current group trains.
@@ -70,8 +77,10 @@ def round_plan(free_bytes: int, n_nodes: int, walk_length: int, window: int, wor
 def auto_plan(n_nodes: int, world: int, ld: int = 0, k: int = 10) -> Tuple[int, int]:
     """(parts, slices) of the contextual table (``gn2v_block_auto_plan``: one rule for the C++
     one-GPU fit and for this trainer).  Row stride ``ld`` <= 256 floats (0: unknown),
-    up to 106 M nodes: resident cells -- cells that fit one workgroup's LDS, whose rows are
-    read and updated there, exactly.  Otherwise XCD cells.  Measured (scripts/quality_probe.py):
+    up to 105 M nodes: resident cells -- cells that fit one workgroup's LDS, whose rows are
+    read and updated there by that workgroup alone (plain read-modify-writes of its sixteen
+    waves: no other CU races for a row, the workgroup's own groups still can).  Otherwise XCD
+    cells.  Measured (scripts/quality_probe.py):
     the smaller a cell, the more of it lives in the XCD's L2 (BA 10 M nodes: 0.67 of the HBM
     roofline unsliced, 0.80 at 4 x 8 cells, 0.87 at 32 x 8) -- and the more often two waves
     read-modify-write the same row at once; link quality stays at or above the walk-ordered
@@ -245,13 +254,24 @@ class GpuBlockBackend:
                 dg.handle, world, int(ld), int(k), C.byref(parts), C.byref(slices), stream))
         return parts.value, slices.value
 
-    def alias_tables(self, plan):
+    def alias_tables(self, plan, inv=None, out=None):
         from . import ops
 
-        return ops.block_alias(self.graph, plan, device=self.index)
+        return ops.block_alias(self.graph, plan, device=self.index, inv=inv, out=out)
+
+    def placement(self, classes, seed, round_id, out=None):
+        """(place, inv) of the round (``gn2v_block_placement``)."""
+        from . import ops
+
+        return ops.block_placement(self.graph, classes, seed, round_id, device=self.index, out=out)
+
+    def place_walks(self, place, walks_all):
+        from . import ops
+
+        return ops.block_place_walks(place, walks_all)
 
     def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None, part_lo=0,
-                part_n=0, capacity=0, slot=None):
+                part_n=0, capacity=0, slot=None, placed=None):
         """-> (pairs, cell_offsets, n_pairs): the sorted pair words of the group of parts
         ``part_lo, part_lo + 1, ...`` (``part_n`` of them, cyclic; 0, 0 = every part); one host
         read (the pair count).
@@ -266,7 +286,7 @@ class GpuBlockBackend:
         import torch
 
         work, offsets = ops.block_count(self.graph, plan, walks_all, seed, epoch, first_walk,
-                                        part_lo=part_lo, part_n=part_n)
+                                        part_lo=part_lo, part_n=part_n, placed=placed)
         n_pairs = int(offsets[-1])
         dev = walks_all.device
 
@@ -291,7 +311,7 @@ class GpuBlockBackend:
             temp = self._temp
         ops.block_extract(self.graph, plan, walks_all, seed, epoch, first_walk, work, n_pairs,
                           pairs=pairs, temp=temp, hub_bits=hub_bits, part_lo=part_lo,
-                          part_n=part_n)
+                          part_n=part_n, placed=placed)
         if os.environ.get("GN2V_BENCH_MEMLOG"):
             print(f"[mem] prepare: parts {part_lo}+{part_n}: {n_pairs} pairs, room "
                   f"{pairs.numel()}, slot {slot}, allocated "
@@ -300,14 +320,15 @@ class GpuBlockBackend:
         return pairs[:n_pairs], offsets, n_pairs
 
     def round(self, tp, plans, walks, tables, central, part_rows, group_parts, capacity, seed,
-              epoch, first_walk, lr, round_id):
+              epoch, first_walk, lr, round_id, placed=None, inv=None, context_table=None):
         """A whole round on one GPU through the C round driver (``gn2v_block_round``: the loop
         ``gn2v_train_blocks`` runs too -- one host loop orders the launches of a one-GPU fit):
         every stripe in ``plans``, every group of ``group_parts`` parts: count, extract + sort,
         one step per part.  ``tables``: (alias, cell_rows, hub_bits, hot_list, hot_slot) or
-        Nones; ``central``: the whole table; ``part_rows[p]``: the rows of part p.  Pairs in the
-        standing buffers of slot 0 (``capacity`` pairs to begin with, grown when the driver asks
-        for it).  Returns the pairs trained."""
+        Nones; ``central``: the whole table; ``part_rows[p]``: the rows of part p -- or, under
+        a placement (``placed``: the walks with placed ids, ``inv``), ``context_table``: the whole
+        contextual table in node order.  Pairs in the standing buffers of slot 0 (``capacity``
+        pairs to begin with, grown when the driver asks for it).  Returns the pairs trained."""
         import ctypes as C
 
         import torch
@@ -341,12 +362,20 @@ class GpuBlockBackend:
         pairs, temp = room_for(max(1, capacity))
         alias, cell_rows, hub_bits, hot_list, hot_slot = tables
         assert walks.is_contiguous() and central.is_contiguous()
-        assert all(t.is_contiguous() and t.shape[1] == tp.ld for t in part_rows)
-        part_ptrs = (C.c_void_p * len(part_rows))(*[t.data_ptr() for t in part_rows])
+        context_ld = 0
+        if context_table is not None:  # parts = the rows p, p + parts, ... of the one table
+            assert context_table.is_contiguous() and context_table.shape[1] == tp.ld
+            part_ptrs = (C.c_void_p * plan.parts)(
+                *[context_table.data_ptr() + p * tp.ld * 4 for p in range(plan.parts)])
+            context_ld = plan.parts * tp.ld
+        else:
+            assert all(t.is_contiguous() and t.shape[1] == tp.ld for t in part_rows)
+            part_ptrs = (C.c_void_p * len(part_rows))(*[t.data_ptr() for t in part_rows])
         plan_array = (_lib.BlockPlan * len(plans))(*plans)
         io = _lib.BlockRoundIO(
-            ptr(walks), ptr(alias), ptr(cell_rows), ptr(hub_bits), ptr(hot_list), ptr(hot_slot),
-            ptr(central), C.cast(part_ptrs, C.POINTER(C.c_void_p)), 0, ptr(self._work),
+            ptr(walks), ptr(placed), ptr(inv), ptr(context_table),
+            ptr(alias), ptr(cell_rows), ptr(hub_bits), ptr(hot_list), ptr(hot_slot),
+            ptr(central), C.cast(part_ptrs, C.POINTER(C.c_void_p)), context_ld, ptr(self._work),
             ptr(self._offsets), ptr(pairs), pairs.numel(), ptr(temp), temp.numel(),
             int(group_parts), 0, 0, 0)
         dg = self.graph.device_graph(self.index)
@@ -370,7 +399,7 @@ class GpuBlockBackend:
             self._slots, self._temp = {}, None
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
-             epoch, lr, whole_central=False, hot=None):
+             epoch, lr, whole_central=False, hot=None, inv=None, context_table=None):
         from . import ops
 
         pairs, offsets, n_pairs = prepared[:3]
@@ -378,7 +407,7 @@ class GpuBlockBackend:
             return
         ops.block_step(self.graph, tp, plan, pairs, offsets, alias, cell_rows, central,
                        context, block_id, part, seed, epoch, lr, whole_central=whole_central,
-                       hot=hot)
+                       hot=hot, inv=inv, context_table=context_table)
 
 
 class BlockPartitionedTrainer:
@@ -425,10 +454,22 @@ class BlockPartitionedTrainer:
                              "of the number of ranks, at least two per rank.")
         self.parts, self.slices = parts, slices
         self.per_rank = parts // world
+        # Resident cells (more than 16 slices; gn2v_block_step's rule): no hot rows -- every row
+        # of a cell lives in LDS -- and a PLACEMENT per round (module docstring): inside the
+        # classes modulo `parts` when the parts travel, over the whole graph on one GPU, where
+        # the contextual table then stays ONE table in node order.  GN2V_BLOCK_PERMUTE=0: the
+        # fixed cells of round 4 (A/B; every rank alike).
+        resident_plan = slices > 16
+        self.permute = (resident_plan and os.environ.get("GN2V_BLOCK_PERMUTE", "1") != "0"
+                        and hasattr(self.backend, "placement"))
+        self.classes = parts if world > 1 else 1
+        self.natural = self.permute and world == 1
         if hot_rows is None:
             from . import _lib
 
-            hot_rows = _lib.BLOCK_HOT_DEFAULT
+            hot_rows = 0 if resident_plan else _lib.BLOCK_HOT_DEFAULT
+        if self.permute:
+            hot_rows = 0
         # the extraction counts the cells of a group in LDS: BLOCK_MAX_GROUP_CELLS at most
         from . import _lib as _l
 
@@ -451,11 +492,14 @@ class BlockPartitionedTrainer:
         # per-cell alias tables for the negatives + the hot rows of every cell (flags, slots)
         # (with uniform negatives the alias tables are not used: the hot rows, the most frequent
         # contexts, still are)
+        # (under a placement the tables follow it round by round: _round_state)
         self.alias, self.cell_rows, self.hub_bits, hot_list, hot_slot = (
-            self.backend.alias_tables(self.plan) if scale_free or hot_rows else (None,) * 5)
+            self.backend.alias_tables(self.plan)
+            if (scale_free or hot_rows) and not self.permute else (None,) * 5)
         self.hot = (hot_list, hot_slot) if hot_list is not None and hot_rows else None
         if not scale_free:
             self.alias = None
+        self._rstates = [None, None]  # placement, alias tables, placed walks of two rounds
         for p in range(parts):
             if stripe_rows(self.n_nodes, p, parts) == 0:
                 raise ValueError("A context part owns no node: graph too small to split this far.")
@@ -465,7 +509,15 @@ class BlockPartitionedTrainer:
         # context parts held now: {part id: tensor}
         self.max_part_rows = stripe_rows(self.n_nodes, 0, parts)
         self.held = {}
+        self.context_table = None
         mine = range(self.per_rank * rank, self.per_rank * (rank + 1))
+        if self.natural:
+            # one table in node order; part p = its rows p, p + parts, ... (views)
+            self.context_table = self.backend.init_rows(self.n_nodes, d, ld, seed, 1, init_scale,
+                                                        0, 1)
+            for p in mine:
+                self.held[p] = self.context_table[p::parts]
+            mine = ()
         for p in mine:
             buf = self.backend.empty_rows(self.max_part_rows, ld)
             rows = stripe_rows(self.n_nodes, p, parts)
@@ -513,8 +565,29 @@ class BlockPartitionedTrainer:
         walks pad with sentinel rows)."""
         return self.comm.all_gather(walks)
 
+    def round_state(self, walks_all, seed: int, round_id: int):
+        """What a round under a placement needs beside its walks: the placement itself, the
+        alias tables that follow it and the walks with placed ids (None without a placement).
+        Two sets alternate, so that the preparation of round r + 1 never touches what the
+        training of round r still reads."""
+        if not self.permute:
+            return None
+        turn = round_id & 1
+        st = self._rstates[turn]
+        if st is None:
+            st = self._rstates[turn] = {"placement": None, "alias": None}
+        st["placement"] = self.backend.placement(self.classes, seed, round_id,
+                                                 out=st["placement"])
+        place, inv = st["placement"]
+        if self.scale_free:
+            tables = self.backend.alias_tables(self.plan, inv=inv, out=st["alias"])
+            st["alias"] = tables[:2]
+        st["placed"] = self.backend.place_walks(place, walks_all)
+        st["round_id"] = round_id
+        return st
+
     def prepare(self, walks_all, seed: int, epoch: int, first_walk: int, group=None, slot=None,
-                stripe: int = 0):
+                stripe: int = 0, rstate=None):
         """Extract + sort this rank's pairs of one group of parts (``group`` = (first part,
         number of parts), None = the whole round) from the round's gathered walks.  ``slot``:
         which of the backend's standing buffers receives the pairs (``run`` alternates two when it
@@ -523,10 +596,12 @@ class BlockPartitionedTrainer:
         kw = {}
         if slot is not None and isinstance(self.backend, GpuBlockBackend):
             kw = {"capacity": self.group_capacity(), "slot": slot}
+        if rstate is not None:
+            kw["placed"] = rstate["placed"]
         pairs, offsets, n_pairs = self.backend.prepare(
             self.plans[stripe], walks_all, seed, epoch, first_walk, self.hub_bits, part_lo=lo,
             part_n=n, **kw)
-        return pairs, offsets, n_pairs, lo, n
+        return pairs, offsets, n_pairs, lo, n, rstate
 
     def train_prepared(self, prepared, seed: int, epoch: int, lr: float, stripe: int = 0,
                        timed: bool = False):
@@ -553,10 +628,19 @@ class BlockPartitionedTrainer:
                                               (comm.rank - 1) % world,
                                               recv_buf[: self.part_rows(nxt)],
                                               (comm.rank + 1) % world)
-            ctx = self.held[part]
-            self.backend.step(self.tp, self.plans[stripe], prepared, self.alias, self.cell_rows,
-                              self.central, ctx[: self.part_rows(part)], block_id, part, seed,
-                              epoch, lr, whole_central=striped, hot=self.hot)
+            rstate = prepared[5] if len(prepared) > 5 else None
+            if rstate is None:
+                self.backend.step(self.tp, self.plans[stripe], prepared, self.alias,
+                                  self.cell_rows, self.central,
+                                  self.held[part][: self.part_rows(part)], block_id, part, seed,
+                                  epoch, lr, whole_central=striped, hot=self.hot)
+            else:
+                alias, cell_rows = rstate["alias"] if rstate["alias"] is not None else (None, None)
+                self.backend.step(self.tp, self.plans[stripe], prepared, alias, cell_rows,
+                                  self.central,
+                                  None if self.natural else self.held[part][: self.part_rows(part)],
+                                  block_id, part, seed, epoch, lr, whole_central=striped,
+                                  inv=rstate["placement"][1], context_table=self.context_table)
             if pending is not None:
                 if timed:
                     self._timed_wait(pending)
@@ -628,21 +712,34 @@ class BlockPartitionedTrainer:
             assert self._round_episodes == 0, "a round driven in one piece starts at its beginning"
             hot_list, hot_slot = self.hot if self.hot is not None else (None, None)
             tables = (self.alias, self.cell_rows, self.hub_bits, hot_list, hot_slot)
-            part_rows = [self.held[p][: self.part_rows(p)] for p in range(self.parts)]
+            kw = {}
+            rstate = self.round_state(walks, seed, self.rounds_done)
+            if rstate is not None:
+                alias, cell_rows = rstate["alias"] if rstate["alias"] is not None else (None, None)
+                tables = (alias, cell_rows, None, None, None)
+                kw = {"placed": rstate["placed"], "inv": rstate["placement"][1],
+                      "context_table": self.context_table}
+            part_rows = (None if self.natural
+                         else [self.held[p][: self.part_rows(p)] for p in range(self.parts)])
             trained = self.backend.round(
                 self.tp, self.plans, walks, tables, self.central, part_rows, self.group_parts,
                 self.group_capacity(), seed, epoch, lr=lr, first_walk=first_walk,
-                round_id=self.rounds_done)
+                round_id=self.rounds_done, **kw)
+            if rstate is not None:
+                rstate["placed"] = None
             self.last_round = {"pairs_trained": trained}
             self.episode += self.parts * self.stripes
             self.rounds_done += 1
             return
         walks_all = self.gather_walks(walks)
+        rstate = self.round_state(walks_all, seed, self.rounds_done)
         for j in range(self.stripes):
             for group in self.groups():
                 self.train_prepared(
                     self.prepare(walks_all, seed, epoch, first_walk, group=group, slot=slot,
-                                 stripe=j), seed, epoch, lr, stripe=j)
+                                 stripe=j, rstate=rstate), seed, epoch, lr, stripe=j)
+        if rstate is not None:
+            rstate["placed"] = None
 
     def run(self, rounds, overlap: bool = True, timed: bool = False):
         """Train a sequence of rounds; ``rounds`` is a list of ``(make_walks, seed, epoch, lr,
@@ -675,7 +772,9 @@ class BlockPartitionedTrainer:
         side = self._side
         groups = self.groups()
         units = [(r, gi) for r in range(len(rounds)) for gi in range(len(groups))]
-        state = {"walks_all": None}
+        state = {"walks_all": None, "rstate": None}
+        assert self._round_episodes == 0, "run() starts at the beginning of a round"
+        first_round = self.rounds_done
 
         def prep(unit, turn):
             r, gi = unit
@@ -694,12 +793,16 @@ class BlockPartitionedTrainer:
                         del mine
                     else:
                         state["walks_all"] = self.gather_walks(make())
+                    # the round's placement, alias tables and placed walks (resident cells)
+                    if state["rstate"] is not None:
+                        state["rstate"]["placed"] = None
+                    state["rstate"] = self.round_state(state["walks_all"], seed, first_round + r)
                 if timed:
                     with self._span("extract_and_sort"):
                         return self.prepare(state["walks_all"], seed, epoch, first,
-                                            group=groups[gi], slot=turn)
+                                            group=groups[gi], slot=turn, rstate=state["rstate"])
                 return self.prepare(state["walks_all"], seed, epoch, first, group=groups[gi],
-                                    slot=turn)
+                                    slot=turn, rstate=state["rstate"])
 
         def wait_for_preparation():
             # what the compute stream really waits for the preparation stream: exposed time
@@ -732,6 +835,8 @@ class BlockPartitionedTrainer:
                 wait_for_preparation()
             before, prepared = done, nxt
         state["walks_all"] = None
+        if state["rstate"] is not None:
+            state["rstate"]["placed"] = None
         self._turn = turn ^ 1
 
     # ------------------------------------------------------------------ results
@@ -745,6 +850,8 @@ class BlockPartitionedTrainer:
             self.backend.release()
         if world == 1:
             # the central partition of the only rank IS the table; parts are released one by one
+            if self.natural:
+                return self.central, self.context_table
             if self.parts == 1:
                 return self.central, self.held[0]
             context = self.backend.empty_rows(n, ld)

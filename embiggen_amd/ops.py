@@ -144,12 +144,62 @@ def block_plan(graph: CSRGraph, world: int, rank: int, parts: int, slices: int, 
     return plan
 
 
-def block_alias(graph: CSRGraph, plan, device: int = 0):
+def block_placement(graph: CSRGraph, classes: int, seed: int, round_id: int, device: int = 0,
+                    out=None):
+    """(place int32 [n_nodes], inv int32 [n_nodes]) of round ``round_id``
+    (``gn2v_block_placement``): the seeded permutation of the node ids inside their residue
+    classes modulo ``classes`` that decides in which cell a node's contextual row is trained this
+    round (place[x] = x', inv[x'] = x).  ``out``: (place, inv) tensors to fill."""
+    torch = _torch()
+    dg = graph.device_graph(device)
+    dev = torch.device("cuda", device)
+    n = graph.get_number_of_nodes()
+    need = C.c_uint64()
+    _lib.check(_lib.lib().gn2v_block_placement_temp_bytes(n, C.byref(need)))
+    temp = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    place, inv = out if out is not None else (torch.empty(n, dtype=torch.int32, device=dev),
+                                              torch.empty(n, dtype=torch.int32, device=dev))
+    _lib.check(_lib.lib().gn2v_block_placement(dg.handle, classes, seed, round_id,
+                                               place.data_ptr(), inv.data_ptr(), temp.data_ptr(),
+                                               need.value, _stream(dev)))
+    return place, inv
+
+
+def block_place_walks(place, walks_tensor, out=None):
+    """The walks with placed node ids (``gn2v_block_place_walks``): what ``block_count`` /
+    ``block_extract`` read for the context side under a placement."""
+    torch = _torch()
+    assert walks_tensor.is_contiguous() and place.is_contiguous()
+    if out is None:
+        out = torch.empty_like(walks_tensor)
+    _lib.check(_lib.lib().gn2v_block_place_walks(place.data_ptr(), walks_tensor.data_ptr(),
+                                                 walks_tensor.numel(), out.data_ptr(),
+                                                 _stream(walks_tensor.device)))
+    return out
+
+
+def block_alias(graph: CSRGraph, plan, device: int = 0, inv=None, out=None):
     """(alias int64 [n_nodes], cell_rows int64 [cells + 1], hub_bits int32 [(n_nodes + 31) // 32],
     hot_list int32 [cells, BLOCK_HOT_MAX], hot_slot uint8 [n_nodes]): per-cell alias tables for
     degree-proportional negatives, the hot-row flags and the hot rows' slots
-    (``gn2v_block_alias``)."""
+    (``gn2v_block_alias``).  ``inv``: the round's placement; ``out``: (alias, cell_rows) of an
+    earlier call to refill (plans without hot rows: the other three come back as None)."""
     torch = _torch()
+    if out is not None or (inv is not None and not plan.hot_rows):
+        dg = graph.device_graph(device)
+        dev = torch.device("cuda", device)
+        n = graph.get_number_of_nodes()
+        need = C.c_uint64()
+        _lib.check(_lib.lib().gn2v_block_alias_temp_bytes(n, C.byref(need)))
+        temp = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        alias, cell_rows = out if out is not None else (
+            torch.empty(n, dtype=torch.int64, device=dev),
+            torch.empty(plan.parts * plan.slices + 1, dtype=torch.int64, device=dev))
+        assert not plan.hot_rows
+        _lib.check(_lib.lib().gn2v_block_alias(
+            dg.handle, C.byref(plan), alias.data_ptr(), cell_rows.data_ptr(), None, None, None,
+            None if inv is None else inv.data_ptr(), temp.data_ptr(), need.value, _stream(dev)))
+        return alias, cell_rows, None, None, None
     dg = graph.device_graph(device)
     dev = torch.device("cuda", device)
     n = graph.get_number_of_nodes()
@@ -165,15 +215,17 @@ def block_alias(graph: CSRGraph, plan, device: int = 0):
     _lib.check(_lib.lib().gn2v_block_alias(dg.handle, C.byref(plan), alias.data_ptr(),
                                            cell_rows.data_ptr(), hub_bits.data_ptr(),
                                            hot_list.data_ptr(), hot_slot.data_ptr(),
+                                           None if inv is None else inv.data_ptr(),
                                            temp.data_ptr(), need.value, _stream(dev)))
     return alias, cell_rows, hub_bits, hot_list, hot_slot
 
 
 def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
-                work=None, cell_offsets=None, part_lo: int = 0, part_n: int = 0):
+                work=None, cell_offsets=None, part_lo: int = 0, part_n: int = 0, placed=None):
     """Pass 1 of the pair extraction: (work, cell_offsets int64 [cells + 1]); the last offset is
     the number of pairs this rank trains in the group of parts ``part_lo, part_lo + 1, ...``
-    (``part_n`` of them, cyclic; 0, 0 = every part)."""
+    (``part_n`` of them, cyclic; 0, 0 = every part).  ``placed``: the walks with placed node ids
+    (``block_place_walks``) of a round under a placement."""
     torch = _torch()
     dev = walks_tensor.device
     dg = graph.device_graph(dev.index or 0)
@@ -182,8 +234,10 @@ def block_count(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, firs
     if cell_offsets is None:
         cell_offsets = torch.empty(plan.parts * plan.slices + 1, dtype=torch.int64, device=dev)
     assert walks_tensor.is_contiguous()
+    assert placed is None or (placed.is_contiguous() and placed.shape == walks_tensor.shape)
     _lib.check(_lib.lib().gn2v_block_count(
-        dg.handle, C.byref(plan), walks_tensor.data_ptr(), walks_tensor.shape[0], seed, epoch,
+        dg.handle, C.byref(plan), walks_tensor.data_ptr(),
+        None if placed is None else placed.data_ptr(), walks_tensor.shape[0], seed, epoch,
         first_walk, part_lo, part_n, work.data_ptr(), cell_offsets.data_ptr(), _stream(dev)))
     return work, cell_offsets
 
@@ -196,7 +250,7 @@ def block_extract_temp_bytes(n_pairs: int) -> int:
 
 def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, first_walk: int,
                   work, n_pairs: int, pairs=None, temp=None, hub_bits=None, part_lo: int = 0,
-                  part_n: int = 0):
+                  part_n: int = 0, placed=None):
     """Pass 2 + sort: the pair words int64 [n_pairs] (``cell << (row_bits + ctx_bits) | centre
     row << ctx_bits | hot << (ctx_bits - 1) | context row inside its cell``) grouped by cell and
     centre row."""
@@ -211,7 +265,8 @@ def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, fi
         temp = torch.empty(need, dtype=torch.uint8, device=dev)
     assert pairs.numel() >= n_pairs and temp.numel() >= need
     _lib.check(_lib.lib().gn2v_block_extract(
-        dg.handle, C.byref(plan), walks_tensor.data_ptr(), walks_tensor.shape[0], seed, epoch,
+        dg.handle, C.byref(plan), walks_tensor.data_ptr(),
+        None if placed is None else placed.data_ptr(), walks_tensor.shape[0], seed, epoch,
         first_walk, part_lo, part_n, work.data_ptr(),
         None if hub_bits is None else hub_bits.data_ptr(), n_pairs, pairs.data_ptr(),
         temp.data_ptr(), temp.numel(), _stream(dev)))
@@ -220,18 +275,24 @@ def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, fi
 
 def block_step(graph: CSRGraph, tp, plan, pairs, cell_offsets, alias, cell_rows, central,
                context, block_id: int, part: int, seed: int, epoch: int, lr: float,
-               whole_central: bool = False, whole_context: bool = False, hot=None):
+               whole_central: bool = False, whole_context: bool = False, hot=None, inv=None,
+               context_table=None):
     """Train the pairs of one context part (``gn2v_block_step``; tables updated in place).
     ``hot``: (hot_list, hot_slot) of ``block_alias`` -- with them (and ``cell_rows``) the rows the
     plan flags as hot accumulate their updates in LDS; without, they are ordinary rows.
     ``whole_central``: ``central`` is the whole table [n_nodes, ld] and the plan's rank one of its
     ``world`` centre stripes (one GPU training the stripes one after the other);
     ``whole_context``: ``context`` is the whole contextual table and the part its rows
-    ``part, part + parts, ...``."""
+    ``part, part + parts, ...``.  ``inv``: the round's placement (resident cells only): the rows
+    of a cell are reached through it -- in ``context_table``, the whole contextual table in node
+    order (``context`` may then be None), or, without, in the part's rows ``context`` (placements
+    that keep the classes modulo ``parts``)."""
     dev = central.device
     dg = graph.device_graph(dev.index or 0)
-    assert central.is_contiguous() and context.is_contiguous()
-    assert central.shape[1] == tp.ld and context.shape[1] == tp.ld
+    assert central.is_contiguous() and (context is None or context.is_contiguous())
+    assert central.shape[1] == tp.ld and (context is None or context.shape[1] == tp.ld)
+    assert context_table is None or (context_table.is_contiguous()
+                                     and context_table.shape == (graph.get_number_of_nodes(), tp.ld))
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     c_ptr, c_ld, x_ptr, x_ld = ptr(central), 0, ptr(context), 0
     if whole_central:
@@ -242,7 +303,8 @@ def block_step(graph: CSRGraph, tp, plan, pairs, cell_offsets, alias, cell_rows,
         x_ptr, x_ld = x_ptr + part * tp.ld * 4, plan.parts * tp.ld
     hot_list, hot_slot = hot if hot is not None else (None, None)
     io = _lib.BlockIO(ptr(pairs), ptr(cell_offsets), ptr(alias), ptr(cell_rows), ptr(hot_list),
-                      ptr(hot_slot), c_ptr, x_ptr, block_id, part, c_ld, x_ld)
+                      ptr(hot_slot), c_ptr, x_ptr, block_id, part, c_ld, x_ld, ptr(inv),
+                      ptr(context_table))
     _lib.check(_lib.lib().gn2v_block_step(dg.handle, C.byref(tp), C.byref(plan), C.byref(io),
                                           seed, epoch, lr, _stream(dev)))
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GN2V_VERSION 300 /* 0.3.0: hot rows of a cell accumulate in LDS (plan.hot_rows) */
+#define GN2V_VERSION 310 /* 0.3.1: per-round placement of the contextual rows (gn2v_block_placement) */
 
 #define GN2V_SENTINEL 0xFFFFFFFFu /* walk positions after a trap node */
 
@@ -134,6 +134,8 @@ typedef struct {
     uint32_t block_stripes; /* centre stripes of that fit (gn2v_train_blocks), else 0   */
     uint32_t block_group_parts; /* parts whose pairs were extracted + sorted at a time, else 0 */
     uint64_t block_round_walks; /* walks per round of that fit, else 0                   */
+    uint32_t resident_launches; /* training launches that ran sgns_resident_kernel (cells in LDS) */
+    uint32_t resident_record;   /* pairs a wave of that kernel took per record (last launch), else 0 */
 } gn2v_stats;
 
 typedef struct gn2v_graph gn2v_graph;
@@ -272,9 +274,34 @@ int gn2v_init_table_rows(float *d_table, uint64_t n_rows, uint32_t d, uint32_t l
 #define GN2V_BLOCK_HOT_MAX 192u
 #define GN2V_BLOCK_HOT_DEFAULT 192u /* what gn2v_train_blocks and the Python trainer flag */
 int gn2v_block_alias_temp_bytes(uint64_t n_nodes, uint64_t *bytes);
+/* d_inv (or NULL): the round's placement (gn2v_block_placement) -- row i of cell (part, slice) is
+ * then node d_inv[(slice + slices * i) * parts + part].  A plan without hot rows may pass NULL
+ * for d_hub_bits, d_hot_list and d_hot_slot. */
 int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_alias,
                      uint64_t *d_cell_rows, uint32_t *d_hub_bits, uint32_t *d_hot_list,
-                     uint8_t *d_hot_slot, void *d_temp, uint64_t temp_bytes, void *stream);
+                     uint8_t *d_hot_slot, const uint32_t *d_inv, void *d_temp,
+                     uint64_t temp_bytes, void *stream);
+
+/* Placement of a round.  The negatives of a pair are drawn -- proportionally to the in-degree,
+ * node2vec_skipgram.py:101-102 -- among the nodes of its context's CELL; with resident cells
+ * (~200 rows) a fixed cell would confine a context's negatives to the same 200 nodes for a whole
+ * fit.  So WHERE a node's contextual row is trained changes every round: a seeded permutation of
+ * the node ids (seed, round_id; splitmix64-keyed, sorted with ties in node order: the oracle's
+ * o_block_placement is bit-equal) inside their residue classes modulo `classes` -- `parts` when
+ * the parts travel between ranks (a row never leaves its part: x' % parts == x % parts), 1 on one
+ * GPU (the whole graph is shuffled).  d_place u32[n_nodes]: node -> placed id; d_inv: placed id
+ * -> node.  Everything downstream works on placed ids (part = x' % parts, row = x' / parts,
+ * slice = row % slices: the pair words, the alias tables); the tables stay where they are and
+ * the resident kernel reaches a row through d_inv (gn2v_block_io).  Plans of XCD cells (<= 16
+ * slices) keep their fixed cells of >= 32 k rows.
+ * gn2v_block_place_walks: d_out[i] = d_place[d_walks[i]] (GN2V_SENTINEL kept): the walks as the
+ * extraction reads them for the context side (gn2v_block_count / _extract: d_placed_walks). */
+int gn2v_block_placement_temp_bytes(uint64_t n_nodes, uint64_t *bytes);
+int gn2v_block_placement(gn2v_graph *g, uint32_t classes, uint64_t seed, uint64_t round_id,
+                         uint32_t *d_place, uint32_t *d_inv, void *d_temp, uint64_t temp_bytes,
+                         void *stream);
+int gn2v_block_place_walks(const uint32_t *d_place, const uint32_t *d_walks, uint64_t n_entries,
+                           uint32_t *d_out, void *stream);
 
 /* Pairs of a round.  d_walks holds the walks of ALL ranks for the round (ids first_walk,
  * first_walk + 1, ...; all-gathered); this rank keeps the pairs whose centre it owns and whose
@@ -291,13 +318,16 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
  * geometry).  d_temp: gn2v_block_extract_temp_bytes(n_pairs) bytes (the unsorted words + the
  * sort's own storage). */
 #define GN2V_BLOCK_WORK_WORDS 532480 /* 8192 extraction waves + 524288 cells */
+/* d_placed_walks (or NULL): the same walks with placed node ids (gn2v_block_place_walks): the
+ * cell and row of a CONTEXT follow from its placed id, the centres keep their node ids. */
 int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
-                     uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
-                     uint32_t part_lo, uint32_t part_n, uint64_t *d_work,
-                     uint64_t *d_cell_offsets, void *stream);
+                     const uint32_t *d_placed_walks, uint64_t n_walks, uint64_t seed,
+                     uint64_t epoch, uint64_t first_walk, uint32_t part_lo, uint32_t part_n,
+                     uint64_t *d_work, uint64_t *d_cell_offsets, void *stream);
 int gn2v_block_extract_temp_bytes(uint64_t n_pairs, uint64_t *bytes);
 int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t *d_walks,
-                       uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
+                       const uint32_t *d_placed_walks, uint64_t n_walks, uint64_t seed,
+                       uint64_t epoch, uint64_t first_walk,
                        uint32_t part_lo, uint32_t part_n, const uint64_t *d_work,
                        const uint32_t *d_hub_bits, uint64_t n_pairs, uint64_t *d_pairs,
                        void *d_temp, uint64_t temp_bytes, void *stream);
@@ -322,6 +352,13 @@ typedef struct {
     uint64_t context_ld;             /* the same for the context part; 0 = ld.  A part trained in
                                         place inside the whole contextual table f32[n_nodes][ld]:
                                         d_context = table + part * ld, context_ld = parts * ld   */
+    const uint32_t *d_inv;           /* the round's placement (gn2v_block_placement), or NULL.
+                                        Resident cells only: row r of cell (part, slice) is the
+                                        contextual row of node x = d_inv[(slice + slices * r) *
+                                        parts + part], found at d_context_table + x * ld, or --
+                                        d_context_table NULL, placements with classes = parts --
+                                        at d_context + (x / parts) * context_ld                   */
+    float *d_context_table;          /* the whole contextual table f32[n_nodes][ld] in node order */
 } gn2v_block_io;
 
 /* The fused gather -> dot -> sigmoid -> scatter-add step over the pairs of one part: a wavefront
@@ -354,9 +391,9 @@ int gn2v_graph_xcds(gn2v_graph *g);
  * GN2V_RESIDENT_MIN_NODES up to GN2V_RESIDENT_MAX_NODES nodes: RESIDENT CELLS -- cells of at
  * most the rows that fit one workgroup's LDS beside its staging (~200 at d = 128, 92 at 256), up to
  * GN2V_BLOCK_MAX_SLICES slices per part (one workgroup per cell), as many parts as needed (169 k
- * nodes: 4 x 256 cells of 166 rows; 1 M: 20 x 256; 10 M: 193 x 256 -- 256 slices per part on
+ * nodes: 4 x 256 cells of 166 rows; 1 M: 20 x 256; 10 M: 195 x 256 -- 256 slices per part on
  * one GPU; several ranks: two parts per rank with as many slices as hold the rows, 10 M nodes on
- * 8 GPUs: 16 x 3 088, while a part keeps 64 cells).
+ * 8 GPUs: 16 x 3 110, while a part keeps 64 cells).
  * gn2v_block_step then reads and updates every contextual row in the LDS of the one workgroup
  * that owns it: no other CU races for it; gn2v_block_round launches a whole group of parts at
  * once, so that no CU waits for a part's heaviest cell.
@@ -368,7 +405,7 @@ int gn2v_graph_xcds(gn2v_graph *g);
 #define GN2V_BLOCK_MAX_CELLS 524288u      /* parts x slices of a plan                           */
 #define GN2V_BLOCK_MAX_GROUP_CELLS 8192u  /* parts of an extraction group x slices              */
 #define GN2V_RESIDENT_MIN_NODES 100000u
-#define GN2V_RESIDENT_MAX_NODES 106000000u /* 523 776 cells of ~200 rows (d = 128, k = 10)      */
+#define GN2V_RESIDENT_MAX_NODES 105000000u /* 523 776 cells of 201 rows (d = 128, k = 10)       */
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
                          uint32_t *parts, uint32_t *slices);
 /* The same rule for a graph at hand (what gn2v_train_blocks and the Python trainer use): resident
@@ -412,6 +449,9 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
 #define GN2V_ROUND_GROW 3
 typedef struct {
     const uint32_t *d_walks;        /* u32[n_walks][walk_length]                                */
+    const uint32_t *d_placed_walks; /* a round under a placement: the walks with placed ids,    */
+    const uint32_t *d_inv;          /* the placement's inverse (both or neither) and, one table */
+    float *d_context_table;         /* in node order, the contextual table (else NULL: parts)   */
     const uint64_t *d_alias;        /* the five tables of gn2v_block_alias (NULL where          */
     const uint64_t *d_cell_rows;    /* gn2v_block_io / gn2v_block_extract allow it)             */
     const uint32_t *d_hub_bits;

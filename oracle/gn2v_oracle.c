@@ -1021,11 +1021,10 @@ double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *log
  * centre (at most O_MAX_RUN pairs) is one "centre" of Semantic S (copy of the central row, samples [context, k negatives]
  * applied one after the other, gradient added at the end of the run).  Negative n of the pair at
  * position p of its cell: a row of the cell, degree-proportional through the cell's alias table
- * (or uniform), picked by draw(cell_key, p * k + n), cell_key = draw(mix64(epoch_key ^ TAG_BLOCK), block_id * O_MAX_CELLS + cell);
+ * (or uniform), picked by draw(cell_key, p * k + n), cell_key = draw(draw(mix64(epoch_key ^ TAG_BLOCK), block_id), cell);
  * skipped when it is the context or the centre itself. */
 
 #define O_TAG_BLOCK 0xB10C5EED0B10C5EDULL
-#define O_MAX_CELLS 8192ULL /* parts x slices of a plan, at most */
 #define O_MAX_RUN 16u       /* pairs trained against one copy of the central row, at most */
 
 typedef struct {
@@ -1062,12 +1061,58 @@ uint32_t o_block_cell_bits(uint32_t parts, uint32_t slices) {
     return bits_for((uint64_t)parts * slices);
 }
 
+/* Placement of a round: WHERE a node's contextual row is trained changes from round to round, so
+ * that over a fit the negatives a context meets -- drawn inside its cell -- range over the graph
+ * (node2vec_skipgram.py:101-102: "proportionally to their degree", over the graph), not over
+ * one fixed set of cell-mates.  A seeded permutation of the node ids that keeps every node in
+ * its residue class modulo `classes` (classes = parts when the parts travel between ranks: a
+ * row never changes its part; 1 on one GPU: the whole graph is shuffled): the nodes of class c
+ * in the order of (hash(round key, x), x) receive the placed ids c, c + classes, c + 2 classes,
+ * ...; place[x] = x' and inv[x'] = x.  Everything downstream (part = x' % parts, row = x' /
+ * parts, slice = row % slices, the pair words, the alias tables) works on placed ids; the
+ * tables stay where they are and are addressed through inv. */
+#define O_TAG_PLACE 0x91ACE5EED5EED5EDULL
+
+typedef struct {
+    uint64_t key;
+    uint32_t x;
+} place_kv;
+
+static int cmp_place_kv(const void *a, const void *b) {
+    const place_kv *p = (const place_kv *)a, *q = (const place_kv *)b;
+    if (p->key != q->key) return p->key < q->key ? -1 : 1;
+    return p->x < q->x ? -1 : (p->x > q->x ? 1 : 0);
+}
+
+void o_block_placement(uint64_t n_nodes, uint32_t classes, uint64_t seed, uint64_t round_id,
+                       uint32_t *place, uint32_t *inv) {
+    uint64_t pkey = o_draw(o_mix64(seed ^ O_TAG_PLACE), round_id);
+    place_kv *kv = (place_kv *)malloc(sizeof(place_kv) * (n_nodes ? n_nodes : 1));
+    if (classes < 1) classes = 1;
+    for (uint64_t x = 0; x < n_nodes; ++x) {
+        kv[x].key = ((uint64_t)(x % classes) << 40) | (o_draw(pkey, x) >> 24);
+        kv[x].x = (uint32_t)x;
+    }
+    qsort(kv, n_nodes, sizeof(place_kv), cmp_place_kv);
+    /* class c starts at sorted position c * (n / classes) + min(c, n % classes) */
+    for (uint64_t j = 0; j < n_nodes; ++j) {
+        uint64_t c = kv[j].x % classes;
+        uint64_t start = c * (n_nodes / classes) + (c < n_nodes % classes ? c : n_nodes % classes);
+        uint32_t xp = (uint32_t)(c + (uint64_t)classes * (j - start));
+        place[kv[j].x] = xp;
+        inv[xp] = kv[j].x;
+    }
+    free(kv);
+}
+
 /* pair words of this rank in walk / position / slot order, contexts in the parts part_lo,
- * part_lo + 1, ... (part_n of them, cyclic; 0, 0 = every part); words may be NULL (count only) */
+ * part_lo + 1, ... (part_n of them, cyclic; 0, 0 = every part); words may be NULL (count only);
+ * place (or NULL: identity): the round's placement of the CONTEXT nodes (the centres keep their
+ * ids: the central table is not placed) */
 uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t *walks,
                          uint64_t n_walks, uint64_t seed, uint64_t epoch, uint64_t first_walk,
                          uint32_t part_lo, uint32_t part_n, const uint32_t *hub_bits,
-                         uint64_t *words) {
+                         uint64_t *words, const uint32_t *place) {
     uint64_t n = 0, ekey = o_epoch_key(seed, epoch);
     uint32_t L = p->walk_length, w = p->window, md = p->min_dist ? p->min_dist : 1;
     o_train_params tp;
@@ -1087,7 +1132,8 @@ uint64_t o_block_extract(const o_graph *g, const o_block_plan *p, const uint32_t
                 if (j < 0 || j >= (int64_t)Le) continue;
                 if (!is_context(i, (uint32_t)j, md)) continue;
                 uint32_t x = wk[j];
-                uint32_t row = x / p->parts, part = x % p->parts;
+                uint32_t xp = place ? place[x] : x;
+                uint32_t row = xp / p->parts, part = xp % p->parts;
                 if ((part + p->parts - part_lo) % p->parts >= part_n) continue;
                 uint32_t cell = part * p->slices + row % p->slices;
                 if (words) {
@@ -1161,7 +1207,7 @@ static inline uint64_t scaled_threshold(uint64_t w, uint64_t D) {
 #define O_HOT_MAX 192u
 void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t hot_rows,
                    uint64_t *table, uint64_t *cell_rows, uint32_t *hub_bits, uint32_t *hot_list,
-                   uint8_t *hot_slot) {
+                   uint8_t *hot_slot, const uint32_t *inv) {
     uint32_t *indeg = (uint32_t *)calloc(g->n_nodes, sizeof(uint32_t));
     for (uint64_t e = 0; e < g->n_edges; ++e) indeg[g->col_idx[e]]++;
     memset(hub_bits, 0, sizeof(uint32_t) * ((g->n_nodes + 31) / 32));
@@ -1185,7 +1231,9 @@ void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t h
         uint32_t *hl = hot_list + (size_t)cell * O_HOT_MAX, n_hot = 0;
         for (uint32_t s = 0; s < O_HOT_MAX; ++s) hl[s] = 0xFFFFFFFFu;
         if (n == 0) continue;
-#define O_NODE_OF(i) ((slice + (uint64_t)slices * (i)) * parts + part)
+/* the node whose placed id is row i of this cell (inv: the round's placement, or identity) */
+#define O_PLACED(i) ((slice + (uint64_t)slices * (i)) * parts + part)
+#define O_NODE_OF(i) (inv ? (uint64_t)inv[O_PLACED(i)] : O_PLACED(i))
         for (uint64_t i = 0; i < n; ++i) {
             uint32_t d = indeg[O_NODE_OF(i)];
             D += d;
@@ -1235,6 +1283,7 @@ void o_block_alias(const o_graph *g, uint32_t parts, uint32_t slices, uint32_t h
             t[i] = (O_HOT(i) << 63) | ((uint64_t)i << 32) | 0xFFFFFFFEull | O_HOT(i);
         }
 #undef O_NODE_OF
+#undef O_PLACED
 #undef O_HOT
     }
     free(indeg);
@@ -1260,11 +1309,15 @@ uint64_t o_block_record_stride(uint64_t R) {
 }
 
 /* one part of one round, strictly sequential; returns the pairs trained */
+/* inv (or NULL: identity): the round's placement; row `local` of cell (part, slice) is then the
+ * contextual row of node x = inv[(slice + slices * local) * parts + part], found at row x of
+ * `context` when `natural` (context = the whole table in node order), else at row x / parts
+ * (context = the rows of part x % parts == part: placements that keep the classes mod parts) */
 uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_plan *p,
                       const uint64_t *words, const uint64_t *cell_offsets,
                       const uint64_t *alias, const uint64_t *cell_rows, float *central,
                       float *context, uint64_t block_id, uint32_t part, uint64_t seed,
-                      uint64_t epoch, float lr) {
+                      uint64_t epoch, float lr, const uint32_t *inv, uint32_t natural) {
     uint32_t d = tp->d, ld = tp->ld, k = tp->k, C = p->record ? p->record : 16;
     uint64_t rowmask = (1ull << p->row_bits) - 1ull;
     uint64_t ekey = o_epoch_key(seed, epoch), trained = 0;
@@ -1275,7 +1328,7 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
         uint64_t lo = cell_offsets[cell], hi = cell_offsets[cell + 1];
         if (hi == lo) continue;
         uint64_t R = (hi - lo + C - 1) / C, A = o_block_record_stride(R);
-        uint64_t ckey = o_draw(o_mix64(ekey ^ O_TAG_BLOCK), block_id * O_MAX_CELLS + cell);
+        uint64_t ckey = o_draw(o_draw(o_mix64(ekey ^ O_TAG_BLOCK), block_id), cell);
         int use_alias = (tp->flags & O_FLAG_SCALE_FREE) && alias;
         uint64_t alias_lo = use_alias ? cell_rows[cell] : 0;
         uint64_t cell_n = stripe_count(part_rows, slice, p->slices);
@@ -1312,9 +1365,12 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
                             }
                             row = slice + p->slices * local;
                             label = 0.0f;
-                            if (row == xrow || (uint64_t)row * p->parts + part == cgid) continue;
+                            if (row == xrow) continue;
                         }
-                        float *v = context + (uint64_t)row * ld;
+                        /* the node behind the row, and where its contextual row lies */
+                        uint64_t xp = (uint64_t)row * p->parts + part, xn = inv ? inv[xp] : xp;
+                        if (s && xn == cgid) continue;
+                        float *v = context + (natural ? xn : xn / p->parts) * ld;
                         float dot = 0.0f;
                         for (uint32_t x = 0; x < d; ++x) dot += u[x] * v[x];
                         if (dot > tp->clip) dot = tp->clip;

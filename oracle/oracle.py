@@ -361,9 +361,19 @@ def block_plan(n_nodes: int, world: int, rank: int, parts: int, slices: int, wal
                      flags, hot_rows, 0, cell_bits + row_bits + ctx_bits, ctx_bits)
 
 
+def block_placement(n_nodes: int, classes: int, seed: int, round_id: int):
+    """(place u32[n_nodes], inv u32[n_nodes]): the round's seeded permutation of the node ids
+    inside their residue classes modulo ``classes`` (place[x] = x', inv[x'] = x)."""
+    place = np.empty(n_nodes, dtype=np.uint32)
+    inv = np.empty(n_nodes, dtype=np.uint32)
+    lib().o_block_placement(C.c_uint64(n_nodes), C.c_uint32(classes), C.c_uint64(seed),
+                            C.c_uint64(round_id), _ptr(place), _ptr(inv))
+    return place, inv
+
+
 def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: int,
                   first_walk: int, sort: bool = True, hub_bits=None, part_lo: int = 0,
-                  part_n: int = 0):
+                  part_n: int = 0, place=None):
     """(words u64, cell_offsets): the pairs of the walks whose centre `plan.rank` owns (contexts
     in the parts part_lo, part_lo + 1, ... cyclic; 0, 0 = all) as pair words
     ``cell << (row_bits + ctx_bits) | centre row << ctx_bits | hot << (ctx_bits - 1) | context
@@ -375,10 +385,12 @@ def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: 
     L.o_block_extract.restype = C.c_uint64
     args = (C.byref(g.c), C.byref(plan), _ptr(walks_arr), C.c_uint64(n_walks), C.c_uint64(seed),
             C.c_uint64(epoch), C.c_uint64(first_walk), C.c_uint32(part_lo), C.c_uint32(part_n))
-    n = int(L.o_block_extract(*args, None, None))
+    if place is not None:
+        assert place.dtype == np.uint32 and place.flags.c_contiguous
+    n = int(L.o_block_extract(*args, None, None, _ptr(place)))
     words = np.empty(n, dtype=np.uint64)
     if n:
-        L.o_block_extract(*args, _ptr(hub_bits), _ptr(words))
+        L.o_block_extract(*args, _ptr(hub_bits), _ptr(words), _ptr(place))
         if sort:
             L.o_block_sort(_ptr(words), C.c_uint64(n), C.c_uint32(plan.ctx_bits))
     cells = plan.parts * plan.slices
@@ -418,7 +430,7 @@ def block_pack(cell, centre_row, part_row, plan: BlockPlan, hot=None):
 HOT_MAX = 192  # O_HOT_MAX / GN2V_BLOCK_HOT_MAX
 
 
-def block_alias(g: OracleGraph, parts: int, slices: int, hot_rows: int = 0):
+def block_alias(g: OracleGraph, parts: int, slices: int, hot_rows: int = 0, inv=None):
     """(alias tables u64[n_nodes], cell_rows u64[cells + 1], hub_bits u32[(n_nodes + 31) // 32],
     hot_list u32[cells, HOT_MAX], hot_slot u8[n_nodes]):
     entry = hot(row) | threshold (31 bits) | alias row << 32 | hot(alias row) << 63; the hot rows
@@ -431,14 +443,18 @@ def block_alias(g: OracleGraph, parts: int, slices: int, hot_rows: int = 0):
     hot_slot = np.empty(g.n_nodes, dtype=np.uint8)
     lib().o_block_alias(C.byref(g.c), C.c_uint32(parts), C.c_uint32(slices), C.c_uint32(hot_rows),
                         _ptr(table), _ptr(cell_rows), _ptr(hub_bits), _ptr(hot_list),
-                        _ptr(hot_slot))
+                        _ptr(hot_slot), _ptr(inv))
     return table, cell_rows, hub_bits, hot_list, hot_slot
 
 
 def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, words, cell_offsets, alias,
                cell_rows, central, context, block_id: int, part: int, seed: int, epoch: int,
-               lr: float) -> int:
-    """Sequential training of one part (in place on ``central`` / ``context``)."""
+               lr: float, inv=None, natural: bool = False) -> int:
+    """Sequential training of one part (in place on ``central`` / ``context``).  ``inv``: the
+    round's placement (``block_placement``); ``natural``: ``context`` is the whole contextual
+    table in node order instead of the rows of the part."""
+    if inv is not None:
+        assert inv.dtype == np.uint32 and inv.flags.c_contiguous
     for a, t in ((words, np.uint64), (cell_offsets, np.uint64), (central, np.float32),
                  (context, np.float32)):
         assert a.dtype == t and a.flags.c_contiguous
@@ -446,7 +462,8 @@ def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, words, cell_off
     return int(lib().o_block_step(
         C.byref(g.c), C.byref(tp), C.byref(plan), _ptr(words), _ptr(cell_offsets),
         _ptr(alias), _ptr(cell_rows), _ptr(central), _ptr(context), C.c_uint64(block_id),
-        C.c_uint32(part), C.c_uint64(seed), C.c_uint64(epoch), C.c_float(lr)))
+        C.c_uint32(part), C.c_uint64(seed), C.c_uint64(epoch), C.c_float(lr), _ptr(inv),
+        C.c_uint32(1 if natural else 0)))
 
 
 def init_table_rows(n_rows: int, d: int, ld: int, seed: int, table_id: int, scale: float,

@@ -102,13 +102,13 @@ int main(void) {
         uint64_t *alias = malloc(sizeof(uint64_t) * N), poff[13];
         uint32_t *hot_list = malloc(sizeof(uint32_t) * 12 * 192);
         uint8_t *hot_slot = malloc(N);
-        o_block_alias(&g, 6, 2, bp.hot_rows, alias, poff, hub, hot_list, hot_slot);
+        o_block_alias(&g, 6, 2, bp.hot_rows, alias, poff, hub, hot_list, hot_slot, NULL);
         free(hot_list);
         free(hot_slot);
         /* two groups of parts (the second wraps round), then the whole round */
-        uint64_t n_a = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 4, 3, hub, bk);
-        uint64_t n_b = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 1, 3, hub, bk);
-        uint64_t nb = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 0, 0, hub, bk);
+        uint64_t n_a = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 4, 3, hub, bk, NULL);
+        uint64_t n_b = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 1, 3, hub, bk, NULL);
+        uint64_t nb = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 0, 0, hub, bk, NULL);
         if (n_a + n_b != nb) return 1;
         o_block_sort(bk, nb, bp.ctx_bits);
         uint64_t off[13];
@@ -119,9 +119,36 @@ int main(void) {
         for (uint32_t part = 0; part < 6; ++part) {
             o_init_table_rows(bx, (N - part + 5) / 6, 10, 12, 5, 1, 0.3f, part, 6);
             trained += o_block_step(&g, &tp, &bp, bk, off, alias, poff, bc, bx, 2, part, 7, 1,
-                                    0.02f);
+                                    0.02f, NULL, 0);
         }
         if (trained != nb) return 1;
+        /* the same round under a placement: inside the classes mod 6 (part buffers), then over
+         * the whole graph (one natural table) */
+        uint32_t *place = malloc(sizeof(uint32_t) * N), *inv = malloc(sizeof(uint32_t) * N);
+        float *whole = malloc(sizeof(float) * N * 12);
+        hot_list = malloc(sizeof(uint32_t) * 12 * 192);
+        hot_slot = malloc(N);
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t classes = pass ? 1 : 6;
+            o_block_placement(N, classes, 7, 3, place, inv);
+            for (uint32_t x = 0; x < N; ++x)
+                if (inv[place[x]] != x || place[x] % classes != x % classes) return 1;
+            o_block_alias(&g, 6, 2, 0, alias, poff, hub, hot_list, hot_slot, inv);
+            uint64_t np2 = o_block_extract(&g, &bp, walks, nw, 7, 1, 0, 0, 0, NULL, bk, place);
+            if (np2 != nb) return 1;
+            o_block_sort(bk, np2, bp.ctx_bits);
+            o_block_cell_offsets(bk, np2, bp.row_bits + bp.ctx_bits, 12, off);
+            o_init_table(whole, N, 10, 12, 5, 1, 0.3f);
+            trained = 0;
+            for (uint32_t part = 0; part < 6; ++part) {
+                o_init_table_rows(bx, (N - part + 5) / 6, 10, 12, 5, 1, 0.3f, part, 6);
+                trained += o_block_step(&g, &tp, &bp, bk, off, alias, poff, bc,
+                                        classes == 1 ? whole : bx, 2, part, 7, 1, 0.02f, inv,
+                                        classes == 1);
+            }
+            if (trained != nb) return 1;
+        }
+        free(place); free(inv); free(whole); free(hot_list); free(hot_slot);
         free(bk); free(alias); free(bc); free(bx);
     }
 

@@ -43,5 +43,17 @@ if __name__ == "__main__":
         parts.append(x)
     blk.update(words=words, offsets=offsets, alias=alias, cell_rows=cell_rows,
                hub_bits=hub_bits, hot_list=hot_list, hot_slot=hot_slot, central=central, **{f"part{p}": x for p, x in enumerate(parts)})
+    # round 5: the same walks under the placement of round 3 (whole graph: classes = 1), a plan
+    # of resident cells (1 part x 17 slices: two rows a cell), the contextual table in node order
+    place, inv = O.block_placement(34, 1, 42, 3)
+    rplan = O.block_plan(34, 1, 0, 1, 17, 16, 3, 1, 8)
+    ralias, rcell_rows = O.block_alias(og, 1, 17, 0, inv=inv)[:2]
+    rwords, roffsets = O.block_extract(og, rplan, out["walks"], 42, 0, 0, place=place)
+    rc = O.init_table(34, 8, 8, 42, 0, 8 ** -0.5)
+    rx = O.init_table(34, 8, 8, 42, 1, 8 ** -0.5)
+    O.block_step(og, tp, rplan, rwords, roffsets, ralias, rcell_rows, rc, rx, 3, 0, 42, 0, 0.05,
+                 inv=inv, natural=True)
+    blk.update(placed_place=place, placed_inv=inv, placed_words=rwords, placed_offsets=roffsets,
+               placed_alias=ralias, placed_central=rc, placed_contextual=rx)
     np.savez_compressed(os.path.join(HERE, "oracle_blocks.npz"), **blk)
     print("written", {k: np.shape(v) for k, v in blk.items()})

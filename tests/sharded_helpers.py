@@ -121,29 +121,39 @@ class OracleBlockBackend:
         return O.block_plan(self.graph.get_number_of_nodes(), world, rank, parts, slices,
                             walk_length, window, min_dist, record, flags, hot_rows)
 
-    def alias_tables(self, plan):
-        return O.block_alias(self.og, plan.parts, plan.slices, plan.hot_rows)
+    def alias_tables(self, plan, inv=None, out=None):
+        return O.block_alias(self.og, plan.parts, plan.slices, plan.hot_rows, inv=inv)
+
+    def placement(self, classes, seed, round_id, out=None):
+        return O.block_placement(self.graph.get_number_of_nodes(), classes, seed, round_id)
+
+    def place_walks(self, place, walks_all):
+        # o_block_extract maps the node ids itself: what `prepare` receives as "the placed
+        # walks" is the placement
+        return place
 
     def prepare(self, plan, walks_all, seed, epoch, first_walk, hub_bits=None, part_lo=0,
-                part_n=0):
+                part_n=0, placed=None):
         walks = walks_all.cpu().numpy().view(np.uint32)
         words, offsets = O.block_extract(self.og, plan, walks, seed, epoch, first_walk,
-                                         hub_bits=hub_bits, part_lo=part_lo, part_n=part_n)
+                                         hub_bits=hub_bits, part_lo=part_lo, part_n=part_n,
+                                         place=placed)
         return words, offsets, len(words)
 
     def step(self, tp, plan, prepared, alias, cell_rows, central, context, block_id, part, seed,
-             epoch, lr, whole_central=False, hot=None):
+             epoch, lr, whole_central=False, hot=None, inv=None, context_table=None):
         words, offsets, n_pairs = prepared[:3]
         if n_pairs == 0:
             return
         # a centre stripe of the whole table is handed to the oracle as the partition it is
         mine = central[plan.rank::plan.world] if whole_central else central
         c = np.ascontiguousarray(mine.numpy())
-        x = np.ascontiguousarray(context.numpy())
+        rows = context_table if context_table is not None else context
+        x = np.ascontiguousarray(rows.numpy())
         O.block_step(self.og, tp, plan, words, offsets, alias, cell_rows, c, x, block_id,
-                     part, seed, epoch, lr)
+                     part, seed, epoch, lr, inv=inv, natural=context_table is not None)
         mine.copy_(torch.from_numpy(c))
-        context.copy_(torch.from_numpy(x))
+        rows.copy_(torch.from_numpy(x))
 
 
 def link_auc_device(g, c, x, gen, n_eval=100000):

@@ -354,3 +354,115 @@ def test_gloo_ranks_gather_to_one_rank_and_train_in_groups(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["c1.npy", "x1.npy"]
     assert np.array_equal(np.load(tmp_path / "c1.npy"), sim[1][0][0])
     assert np.array_equal(np.load(tmp_path / "x1.npy"), sim[1][0][1])
+
+
+# ------------------------------------------------------------------ placement of a round (round 5)
+@pytest.mark.parametrize("n,classes", [(34, 1), (97, 1), (97, 4), (203, 6), (1000, 16)])
+def test_placement_is_a_seeded_permutation_inside_its_classes(n, classes):
+    """o_block_placement: a bijection of the node ids that keeps every node in its residue class
+    modulo `classes` (several ranks: a row never leaves its part), reproducible, different for
+    every round and seed."""
+    place, inv = O.block_placement(n, classes, 42, 3)
+    assert sorted(place.tolist()) == list(range(n))
+    assert np.array_equal(inv[place], np.arange(n, dtype=np.uint32))
+    assert np.array_equal(place % classes, np.arange(n) % classes)
+    again = O.block_placement(n, classes, 42, 3)
+    assert np.array_equal(place, again[0]) and np.array_equal(inv, again[1])
+    for seed, rnd in ((42, 4), (43, 3)):
+        assert not np.array_equal(place, O.block_placement(n, classes, seed, rnd)[0])
+
+
+def test_cell_mates_change_from_round_to_round():
+    """What the placement is for: under the fixed striping a node shares its cell with the same
+    nodes for a whole fit (x = y modulo parts x slices); under the placement of round r the
+    cell-mates of a node are another random set every round -- over 64 rounds a node of a
+    1 000-node graph in cells of ~20 rows meets most of the graph, every other node about
+    equally often."""
+    n, parts, slices = 1000, 2, 25
+    cells = parts * slices
+    met = np.zeros((n, n), dtype=np.int32)
+    rounds = 64
+    for r in range(rounds):
+        place = O.block_placement(n, 1, 7, r)[0].astype(np.int64)
+        cell = (place % parts) * slices + (place // parts) % slices
+        met += (cell[:, None] == cell[None, :])
+    np.fill_diagonal(met, 0)
+    per_node = (met > 0).sum(1)
+    # 64 rounds x 19 mates = 1 216 draws from 999 nodes: ~70 % of the graph met at least once
+    assert per_node.min() > 0.6 * n and per_node.mean() > 0.68 * n
+    # and nobody is a mate much more often than chance (64 * 19 / 999 = 1.2 rounds)
+    assert met.max() <= 9
+    # the fixed striping, for contrast: always the same 19 mates
+    ids = np.arange(n)
+    fixed = (ids % parts) * slices + (ids // parts) % slices
+    assert ((fixed[:, None] == fixed[None, :]).sum(1) - 1).max() == n // cells - 1 + (n % cells > 0)
+    # classes = parts (several ranks): a node only ever meets nodes of its own part
+    place = O.block_placement(n, parts, 7, 5)[0].astype(np.int64)
+    assert np.array_equal(place % parts, ids % parts)
+
+
+@pytest.mark.parametrize("world,parts,slices,group_parts", [(1, 2, 24, None), (1, 3, 17, 2),
+                                                            (2, 4, 24, None), (3, 6, 20, 4)])
+def test_trainer_under_a_placement_equals_the_restated_schedule(world, parts, slices, group_parts):
+    """Plans of more than 16 slices (resident cells) are trained under a placement per round:
+    over the whole graph on one rank (the contextual table stays one table in node order),
+    inside the classes modulo `parts` with several ranks (the parts travel as before).  The
+    trainer -- threads as ranks -- against the schedule restated call by call: placement,
+    alias tables and extraction of the round, then every (rank, part) block once."""
+    nodes, rounds, wpr = 203, 2, 9
+    g = _graph(nodes)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    sims = run_ranks(world, lambda comm: _train(comm, rounds=rounds, walks_per_round=wpr,
+                                                nodes=nodes, parts=parts, slices=slices,
+                                                group_parts=group_parts, record=8))
+    for s in sims[1:]:
+        assert np.array_equal(s[0][0], sims[0][0][0]) and np.array_equal(s[0][1], sims[0][0][1])
+    assert sum(s[1] for s in sims) == rounds * world * wpr * (2 * W * L - W * (W + 1))
+    # the restatement
+    rc = O.init_table(nodes, D, D, 42, 0, D ** -0.5)
+    rx = O.init_table(nodes, D, D, 42, 1, D ** -0.5)
+    classes = parts if world > 1 else 1
+    wp = O.WalkParams(L, 1, 0.25, 4.0, 100, 0)
+    per_rank = parts // world
+    for r in range(rounds):
+        walks = O.walks(og, wp, 42, 0, r * world * wpr, world * wpr)
+        place, inv = O.block_placement(nodes, classes, 42, r)
+        alias, cell_rows = O.block_alias(og, parts, slices, 0, inv=inv)[:2]
+        plans = [O.block_plan(nodes, world, rank, parts, slices, L, W, 1, 8)
+                 for rank in range(world)]
+        prepared = [O.block_extract(og, plans[rank], walks, 42, 0, r * world * wpr, place=place)
+                    for rank in range(world)]
+        mine = [np.ascontiguousarray(rc[rank::world]) for rank in range(world)]
+        for e in range(parts):  # episode by episode: a part visits the ranks one after the other
+            for rank in range(world):
+                p = (per_rank * rank + e) % parts
+                O.block_step(og, _otp(), plans[rank], prepared[rank][0], prepared[rank][1], alias,
+                             cell_rows, mine[rank], rx, r * world + rank, p, 42, 0, 0.02, inv=inv,
+                             natural=True)
+        for rank in range(world):
+            rc[rank::world] = mine[rank]
+    assert np.array_equal(sims[0][0][0], rc) and np.array_equal(sims[0][0][1], rx)
+    assert np.abs(rx - O.init_table(nodes, D, D, 42, 1, D ** -0.5)).max() > 1e-3
+
+
+def test_gloo_ranks_under_a_placement_equal_the_in_process_simulation(tmp_path):
+    """2 gloo ranks, 4 parts x 24 slices (resident cells: a placement per round inside the
+    classes modulo 4, the alias tables rebuilt per round on every rank alike)."""
+    mp.spawn(_gloo_worker_placed, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    sim = run_ranks(2, lambda comm: _train(comm, nodes=97, parts=4, slices=24, record=8))
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), sim[r][0][0])
+        assert np.array_equal(np.load(tmp_path / f"x{r}.npy"), sim[r][0][1])
+
+
+def _gloo_worker_placed(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    (c, x), _, _ = _train(TorchComm(), nodes=97, parts=4, slices=24, record=8)
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), c)
+    np.save(os.path.join(out_dir, f"x{rank}.npy"), x)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -842,6 +842,24 @@ def test_block_path_against_the_committed_golden_fixture(karate):
                        0, 0.05)
         assert np.abs(x.cpu().numpy() - gold[f"part{part}"]).max() < 1e-5
     assert np.abs(c.cpu().numpy() - gold["central"]).max() < 1e-5
+    # the same walks under the placement of round 3, resident cells, the table in node order
+    place, inv = ops.block_placement(karate, 1, 42, 3)
+    assert np.array_equal(place.cpu().numpy().view(np.uint32), gold["placed_place"])
+    assert np.array_equal(inv.cpu().numpy().view(np.uint32), gold["placed_inv"])
+    rplan = ops.block_plan(karate, 1, 0, 1, 17, 16, 3, 1, 8)
+    ralias, rcell_rows = ops.block_alias(karate, rplan, inv=inv)[:2]
+    assert np.array_equal(ralias.cpu().numpy().view(np.uint64), gold["placed_alias"])
+    placed = ops.block_place_walks(place, wk)
+    work, roffsets = ops.block_count(karate, rplan, wk, 42, 0, 0, placed=placed)
+    rpairs = ops.block_extract(karate, rplan, wk, 42, 0, 0, work, int(roffsets[-1]), placed=placed)
+    assert np.array_equal(_words(rpairs), gold["placed_words"])
+    assert np.array_equal(roffsets.cpu().numpy().astype(np.uint64), gold["placed_offsets"])
+    rc = ops.init_table(34, 8, 42, 0, 8 ** -0.5)
+    rx = ops.init_table(34, 8, 42, 1, 8 ** -0.5)
+    ops.block_step(karate, tp, rplan, rpairs, roffsets, ralias, rcell_rows, rc, None, 3, 0, 42, 0,
+                   0.05, inv=inv, context_table=rx)
+    assert np.abs(rc.cpu().numpy() - gold["placed_central"]).max() < 1e-5
+    assert np.abs(rx.cpu().numpy() - gold["placed_contextual"]).max() < 1e-5
 
 
 def test_gn2v_train_block_path_honours_the_model_options():

@@ -188,7 +188,7 @@ def test_config5_ba_100m_block_path_full_size_properties():
 
 def test_config5_ba_100m_with_xcd_cells(monkeypatch):
     """The same graph with the resident cells switched off: 381 x 8 XCD cells of 32.8 k rows,
-    56-bit pair words (12 + 27 + 17) -- the plan of graphs beyond 106 M nodes."""
+    56-bit pair words (12 + 27 + 17) -- the plan of graphs beyond 105 M nodes."""
     monkeypatch.setenv("GN2V_RESIDENT_MAX_NODES", "1500000")
     g = E.barabasi_albert(100_000_000, 10, 42)
     plan, _ = block_path_properties(g, 1 << 17, {"parts": 381, "slices": 8})

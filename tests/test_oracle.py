@@ -318,6 +318,20 @@ def test_self_golden_of_the_block_schedule(karate_oracle):
                      part, 42, 0, 0.05)
         assert np.allclose(x, gold[f"part{part}"], atol=1e-6)
     assert np.allclose(central, gold["central"], atol=1e-6)
+    # the same walks under the placement of round 3 (round 5: cells change every round)
+    place, inv = O.block_placement(34, 1, 42, 3)
+    rplan = O.block_plan(34, 1, 0, 1, 17, 16, 3, 1, 8)
+    ralias, rcell_rows = O.block_alias(karate_oracle, 1, 17, 0, inv=inv)[:2]
+    rwords, roffsets = O.block_extract(karate_oracle, rplan, walks, 42, 0, 0, place=place)
+    for name, got in (("placed_place", place), ("placed_inv", inv), ("placed_words", rwords),
+                      ("placed_offsets", roffsets), ("placed_alias", ralias)):
+        assert np.array_equal(got, gold[name]), name
+    rc = O.init_table(34, 8, 8, 42, 0, 8 ** -0.5)
+    rx = O.init_table(34, 8, 8, 42, 1, 8 ** -0.5)
+    O.block_step(karate_oracle, tp, rplan, rwords, roffsets, ralias, rcell_rows, rc, rx, 3, 0, 42,
+                 0, 0.05, inv=inv, natural=True)
+    assert np.allclose(rc, gold["placed_central"], atol=1e-6)
+    assert np.allclose(rx, gold["placed_contextual"], atol=1e-6)
 
 
 def test_oracle_is_clean_under_address_and_ub_sanitizers():
