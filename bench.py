@@ -47,6 +47,20 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_PAIR = 12288  # 2 * (k + 2) * d * 4 with k = 10, d = 128
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# the same guide: 256 CUs x 4 SIMDs, 2 400 MHz max clock, a wave64 VALU instruction occupies its
+# SIMD for 4 cycles: 614.4 G wave-instructions/s is all the vector pipes can issue
+VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4e9 / 4 / 1e9
+
+
+def valu_floor_per_pair(ld, k):
+    """Vector instructions (per wave) the arithmetic of ONE training pair needs at the very
+    least in the resident kernel's layout: a wave scores four samples at a time
+    (one per 16-lane group, 4 row floats x ld / 64 per lane), and a sample is: dot product
+    2 ld / 64 packed FMAs + 4 DPP adds of the 16-lane reduction; clamp, exp2 scale, exp, + 1,
+    reciprocal, label - sigma, x learning rate = 6; gradient 2 ld / 64 packed FMAs; row update
+    2 ld / 64 packed FMAs.  (k + 1) samples per pair, four pairs side by side."""
+    ch = ld // 64
+    return (k + 1) * (6 * ch + 10) / 4.0
 
 
 def parse():
@@ -717,8 +731,10 @@ def main():
             kernel = ("gn2v::cbow_lazy_kernel" if store_mode and lazy_waves >= 3
                       else "gn2v::cbow_kernel")
         elif blocks_view is not None:
-            # more than one slice per XCD: resident cells (gn2v_block_step's own rule)
-            kernel = ("gn2v::sgns_resident_kernel" if blocks_view.slices > 8
+            # what the library launched (gn2v_stats.resident_launches), not a mirror of its rule
+            resident_launches = (c_stats.resident_launches if c_entry
+                                 else st.get("resident_launches", 0))
+            kernel = ("gn2v::sgns_resident_v2_kernel" if resident_launches
                       else "gn2v::sgns_block_kernel")
         elif n >= (1 << 16) and args.mode in ("auto", "write_through", "write_back"):
             kernel = "gn2v::sgns_cached_kernel"
@@ -767,7 +783,7 @@ def main():
                               f"{blocks_view.slices if blocks_view else 0} "
                               + ("resident cells (every contextual row in the LDS of the one "
                                  "workgroup that owns its cell)"
-                                 if blocks_view is not None and blocks_view.slices > 8
+                                 if blocks_view is not None and blocks_view.slices > 16
                                  else "XCD slice(s) (no shared rows)") + ", rounds of "
                               f"{min(args.round_walks, args.steps * args.walks)} walks per GPU "
                               f"prepared {blocks_view.group_parts if blocks_view else 0} parts at a time"
@@ -816,13 +832,36 @@ def main():
                         "frac_scheduled counts the centre once per run",
             },
         }
-        if kernel == "gn2v::sgns_resident_kernel":
-            # what bounds this kernel is not a byte count: say so next to the byte-based figures
-            line["roofline"]["limiter"] = (
-                "instruction issue: 196 VALU + 63 SALU + 32 LDS instructions per pair and wave, "
-                "vector pipes 64 % busy, LDS bank conflicts 0.8 % of the LDS cycles "
-                "(profiles/r04_resident_counters.json, rocprofv3 --pmc on this workload); the "
-                "contextual rows live in LDS, HBM carries the central rows and the pair words")
+        if kernel == "gn2v::sgns_resident_v2_kernel":
+            # Resident cells: the contextual rows of a launch live in LDS, HBM carries the central
+            # rows and the pair words only -- the byte model of SURVEY 8d does not bound this
+            # kernel (its "fraction" came out at 3).  What bounds it is the issue rate
+            # of the vector pipes: frac = the arithmetic's floor of vector instructions per
+            # second / what the 1 024 SIMDs can issue at the maximum clock.  The byte figures stay
+            # beside it under explicit names.
+            roof = line["roofline"]
+            floor = valu_floor_per_pair(ld, 10)
+            kernel_pairs_per_s = st["pairs"] / (st["train_ms"] * 1e-3)
+            roof["work_over_hbm_peak"] = roof["frac"]
+            roof["work_bytes_per_s_gb"] = roof["achieved"]
+            roof["bound"] = "valu_issue"
+            roof["unit"] = "G wave-instructions/s"
+            roof["peak"] = VALU_ISSUE_PEAK_GIPS
+            roof["achieved"] = floor * kernel_pairs_per_s / 1e9
+            roof["frac"] = roof["achieved"] / VALU_ISSUE_PEAK_GIPS
+            roof["valu_floor_per_pair"] = floor
+            roof["kernel_pairs_per_s"] = kernel_pairs_per_s
+            roof["note"] = (
+                "bound = valu_issue: frac = (arithmetic floor of vector instructions per pair, "
+                f"{floor:.1f} at ld {ld}, k 10: bench.py valu_floor_per_pair) x kernel pairs/s / "
+                "(256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles).  The counter pass behind it "
+                "(profiles/r05_resident_counters.json: SQ_INSTS_VALU, SQ_INSTS_SALU, "
+                "SQ_ACTIVE_INST_LDS, SQ_WAIT_INST_LDS, GRBM_GUI_ACTIVE per launch) gives the "
+                "issued instructions per pair and the busy share: frac = floor / issued x busy x "
+                "(effective / maximum clock).  work_over_hbm_peak = SURVEY 8d's 12 288 B per pair "
+                "/ time / 8 TB/s: it prices work, exceeds 1 because the sample rows never move "
+                "through HBM, and is not a roofline fraction; frac_hbm = bytes that really leave "
+                "L2 (committed PMC profile) / time / 8 TB/s")
         if reserved is not None:
             line["config"]["reserved_cus_per_xcd"] = args.reserve_cus
             line["config"]["active_cus_per_xcd"] = reserved

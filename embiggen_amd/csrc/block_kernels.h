@@ -138,9 +138,11 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
     if (cell >= parts * slices) return;
     const uint32_t part = cell / slices, slice = cell - part * slices;
     const uint64_t lo = cell_rows[cell], n = cell_rows[cell + 1] - lo;
-    uint32_t *hl = hot_rows ? hot_list + (size_t)cell * kHotMax : nullptr;
-    if (hot_rows)
+    // (the hot tables are optional for plans without hot rows: resident cells)
+    uint32_t *hl = hot_list ? hot_list + (size_t)cell * kHotMax : nullptr;
+    if (hl)
         for (uint32_t s = 0; s < kHotMax; ++s) hl[s] = kSentinel;
+    if (!hl || !hot_slot || !hub_bits) hot_rows = 0;
     if (n == 0) return;
     unsigned long long *w = weight + lo, *t = table + lo;
     uint32_t *st = stack + lo;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "block_kernels.h"
+#include "resident_kernels.h"
 #include "handle.h"
 
 using namespace gn2v_host;
@@ -91,13 +92,35 @@ size_t extract_lds_bytes(uint32_t walk_length, uint32_t cells) {
     return ((size_t)(gn2v::kPrepBlock / 64) * arrays * walk_length + cells) * 4;
 }
 
+size_t env_size(const char *name, size_t fallback) {
+    const char *v = getenv(name);
+    return v && *v ? (size_t)strtoull(v, nullptr, 10) : fallback;
+}
+
+// The resident kernel's second form (resident_kernels.h; GN2V_RESIDENT_V2=0: round 4's, for A/Bs)
+bool resident_v2() {
+    static const size_t v = env_size("GN2V_RESIDENT_V2", 1);
+    return v != 0;
+}
+
 // Rows of a cell that one workgroup of sixteen waves holds in LDS next to its waves' staging
-// (sgns_resident_kernel); 0: rows too wide for that kernel (it is built for strides up to 128
+// (sgns_resident_kernel); 0: rows too wide for that kernel (it is built for strides up to 256
 // floats) or nothing left beside the staging
 uint32_t resident_rows(uint32_t ld, uint32_t record, uint32_t k) {
     if (ld == 0 || ld > 256) return 0;
-    const size_t staging = block_lds_words_per_wave(ld, record, k) * 4 * 16 + 64;
     const size_t lds = 160 * 1024;
+    if (resident_v2()) {
+        // per wave: four transposition rows + the record's centres and 16-bit samples; shared:
+        // the dummy row, then per cell row the row, its alias entry and its node id
+        const size_t staging = (size_t)gn2v::res_words_per_wave(ld, record, k) * 4 * 16 + 64 +
+                               (size_t)ld * 4;
+        // (a staged sample names its row in 12 bits, the dummy row included)
+        static const size_t cap = env_size("GN2V_RESIDENT_FIT_ROWS", 4095);  // A/B: pin the cells
+        return staging >= lds
+                   ? 0
+                   : (uint32_t)std::min<size_t>((lds - staging) / gn2v::res_bytes_per_row(ld), cap);
+    }
+    const size_t staging = block_lds_words_per_wave(ld, record, k) * 4 * 16 + 64;
     // a row and its node id
     return staging >= lds
                ? 0
@@ -125,11 +148,6 @@ uint32_t resident_fit(uint32_t ld, uint32_t k) {
         if (fit >= 64) break;
     }
     return fit;
-}
-
-size_t env_size(const char *name, size_t fallback) {
-    const char *v = getenv(name);
-    return v && *v ? (size_t)strtoull(v, nullptr, 10) : fallback;
 }
 
 uint32_t cell_bits(const gn2v::BlockPlan &d) { return bits_for((uint64_t)d.parts * d.slices); }
@@ -331,10 +349,8 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
     }
     uint32_t *stack = (uint32_t *)(t + align256(n * 4));
     unsigned long long *weight = (unsigned long long *)(t + 2 * align256(n * 4));
-    if (plan->hot_rows) {
-        HIP_TRY(hipMemsetAsync(d_hub_bits, 0, ((n + 31) / 32) * sizeof(uint32_t), s));
-        HIP_TRY(hipMemsetAsync(d_hot_slot, 0xFF, n, s));
-    }
+    if (d_hub_bits) HIP_TRY(hipMemsetAsync(d_hub_bits, 0, ((n + 31) / 32) * sizeof(uint32_t), s));
+    if (d_hot_slot) HIP_TRY(hipMemsetAsync(d_hot_slot, 0xFF, n, s));
     hipLaunchKernelGGL(gn2v::cell_rows_kernel, dim3(1), dim3(64), 0, s, n, plan->parts,
                        plan->slices, (unsigned long long *)d_cell_rows);
     HIP_TRY(hipGetLastError());
@@ -578,6 +594,24 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
 }
 
 template <int CH>
+static void launch_resident_v2_ch(bool det, dim3 grid, size_t lds, hipStream_t s,
+                                  const gn2v::BlockArgs &a) {
+    if (det) {  // one workgroup walks the cells in order
+        auto kernel = gn2v::sgns_resident_v2_kernel<CH, false, true>;
+        allow_lds(kernel, lds);
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(1024), lds, s, a);
+    } else if (a.ld == (uint32_t)CH * 64) {
+        auto kernel = gn2v::sgns_resident_v2_kernel<CH, true>;
+        allow_lds(kernel, lds);
+        hipLaunchKernelGGL(kernel, grid, dim3(1024), lds, s, a);
+    } else {
+        auto kernel = gn2v::sgns_resident_v2_kernel<CH, false>;
+        allow_lds(kernel, lds);
+        hipLaunchKernelGGL(kernel, grid, dim3(1024), lds, s, a);
+    }
+}
+
+template <int CH>
 static void launch_resident_ch(bool det, dim3 grid, size_t lds, hipStream_t s,
                                const gn2v::BlockArgs &a) {
     if (det) {  // one workgroup walks the cells in order (block_kernels.h)
@@ -727,8 +761,13 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     }
     if (resident) {
         a.p.record = res_record;
-        const size_t lds = block_lds_words_per_wave(tp->ld, res_record, tp->k) * 4 * 16 +
-                           (size_t)max_cell_rows * (tp->ld * 4 + 4) + 16;
+        const bool v2 = resident_v2();
+        const size_t lds =
+            v2 ? (size_t)gn2v::res_words_per_wave(tp->ld, res_record, tp->k) * 4 * 16 +
+                     (size_t)(max_cell_rows + 1) * tp->ld * 4 + (size_t)max_cell_rows * 12 + 16
+               : block_lds_words_per_wave(tp->ld, res_record, tp->k) * 4 * 16 +
+                     (size_t)max_cell_rows * (tp->ld * 4 + 4) + 16;
+        a.hot_n = (uint32_t)max_cell_rows;  // the rows the LDS plan is made for
         std::lock_guard<std::mutex> lock(g->mu);
         hipStream_t caller = s;
         if (g->train_stream) {
@@ -740,12 +779,20 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         if (get_events(g, &ev)) return 1;
         HIP_TRY(hipEventRecord(ev.a, s));
         if (det) a.sweep = part_n;  // the deterministic form walks the parts itself
-        if (tp->ld <= 64)
-            launch_resident_ch<1>(det, dim3(d.slices, part_n), lds, s, a);
+        const dim3 grid(d.slices, part_n);
+        if (v2) {
+            if (tp->ld <= 64)
+                launch_resident_v2_ch<1>(det, grid, lds, s, a);
+            else if (tp->ld <= 128)
+                launch_resident_v2_ch<2>(det, grid, lds, s, a);
+            else
+                launch_resident_v2_ch<4>(det, grid, lds, s, a);
+        } else if (tp->ld <= 64)
+            launch_resident_ch<1>(det, grid, lds, s, a);
         else if (tp->ld <= 128)
-            launch_resident_ch<2>(det, dim3(d.slices, part_n), lds, s, a);
+            launch_resident_ch<2>(det, grid, lds, s, a);
         else
-            launch_resident_ch<4>(det, dim3(d.slices, part_n), lds, s, a);
+            launch_resident_ch<4>(det, grid, lds, s, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev.b, s));
         g->train_events.push_back(ev);
@@ -967,7 +1014,7 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
     // keeps the XCD cells, whose records are handed out by tickets to every workgroup of a slice.
     uint64_t hub = 0;
     if (max_in_degree(g, (hipStream_t)stream, &hub)) return 1;
-    static const size_t skew_pct = env_size("GN2V_RESIDENT_MAX_SKEW_PCT", 100);
+    const size_t skew_pct = env_size("GN2V_RESIDENT_MAX_SKEW_PCT", 100);
     if ((double)hub * g->n_cus * 100.0 > (double)skew_pct * (double)g->view.n_edges)
         return auto_plan(g->view.n_nodes, world, ld, k, false, parts, slices);
     return 0;

@@ -405,7 +405,7 @@ int gn2v_graph_xcds(gn2v_graph *g);
 #define GN2V_BLOCK_MAX_CELLS 524288u      /* parts x slices of a plan                           */
 #define GN2V_BLOCK_MAX_GROUP_CELLS 8192u  /* parts of an extraction group x slices              */
 #define GN2V_RESIDENT_MIN_NODES 100000u
-#define GN2V_RESIDENT_MAX_NODES 105000000u /* 523 776 cells of 201 rows (d = 128, k = 10)       */
+#define GN2V_RESIDENT_MAX_NODES 115000000u /* 523 776 cells of 221 rows (d = 128, k = 10)       */
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
                          uint32_t *parts, uint32_t *slices);
 /* The same rule for a graph at hand (what gn2v_train_blocks and the Python trainer use): resident
