@@ -50,6 +50,12 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # the same guide: 256 CUs x 4 SIMDs, 2 400 MHz max clock, a wave64 VALU instruction occupies its
 # SIMD for 4 cycles: 614.4 G wave-instructions/s is all the vector pipes can issue
 VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4e9 / 4 / 1e9
+# f32 atomic adds the chip's L2 / memory-side atomic units retire per second, whatever the shape
+# of the instruction and whether the rows live in L2 or in HBM: scripts/atomic_probe.hip measured
+# 3.13e11 (5 GB table) and 3.31e11 (51 MB table) dword adds/s on an MI355X
+# (profiles/r05_logs/r5_atomic_probe.log) -- one dword per clock for each of 128 L2 channels at
+# 2.4-2.6 GHz; the guide quotes no figure for atomics.  The higher one is the ceiling.
+L2_ATOMIC_PEAK_GDWORDS = 331.0
 
 
 def valu_floor_per_pair(ld, k):
@@ -835,33 +841,38 @@ def main():
         if kernel == "gn2v::sgns_resident_v2_kernel":
             # Resident cells: the contextual rows of a launch live in LDS, HBM carries the central
             # rows and the pair words only -- the byte model of SURVEY 8d does not bound this
-            # kernel (its "fraction" came out at 3).  What bounds it is the issue rate
-            # of the vector pipes: frac = the arithmetic's floor of vector instructions per
-            # second / what the 1 024 SIMDs can issue at the maximum clock.  The byte figures stay
-            # beside it under explicit names.
+            # kernel (its "fraction" came out at 3).  What does: every pair hands its
+            # gradient to its central row with `ld` f32 atomic adds, and the L2 atomic units
+            # retire 3.3e11 of them per second (round 5: without the hand-over the same kernel
+            # runs at 3.5e9 pairs/s, with it at 2.2e9; profiles/r05_logs/).  frac = atomic dwords
+            # per second / that ceiling.  The byte figures stay beside it under explicit names,
+            # and so does the share of the vector pipes' issue rate the arithmetic needs.
             roof = line["roofline"]
             floor = valu_floor_per_pair(ld, 10)
             kernel_pairs_per_s = st["pairs"] / (st["train_ms"] * 1e-3)
             roof["work_over_hbm_peak"] = roof["frac"]
             roof["work_bytes_per_s_gb"] = roof["achieved"]
-            roof["bound"] = "valu_issue"
-            roof["unit"] = "G wave-instructions/s"
-            roof["peak"] = VALU_ISSUE_PEAK_GIPS
-            roof["achieved"] = floor * kernel_pairs_per_s / 1e9
-            roof["frac"] = roof["achieved"] / VALU_ISSUE_PEAK_GIPS
-            roof["valu_floor_per_pair"] = floor
+            roof["bound"] = "l2_atomic"
+            roof["unit"] = "G f32 atomic adds/s"
+            roof["peak"] = L2_ATOMIC_PEAK_GDWORDS
+            roof["achieved"] = ld * kernel_pairs_per_s / 1e9
+            roof["frac"] = roof["achieved"] / L2_ATOMIC_PEAK_GDWORDS
+            roof["atomic_dwords_per_pair"] = ld
             roof["kernel_pairs_per_s"] = kernel_pairs_per_s
+            roof["valu_floor_per_pair"] = floor
+            roof["valu_issue_frac"] = floor * kernel_pairs_per_s / 1e9 / VALU_ISSUE_PEAK_GIPS
             roof["note"] = (
-                "bound = valu_issue: frac = (arithmetic floor of vector instructions per pair, "
-                f"{floor:.1f} at ld {ld}, k 10: bench.py valu_floor_per_pair) x kernel pairs/s / "
-                "(256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles).  The counter pass behind it "
-                "(profiles/r05_resident_counters.json: SQ_INSTS_VALU, SQ_INSTS_SALU, "
-                "SQ_ACTIVE_INST_LDS, SQ_WAIT_INST_LDS, GRBM_GUI_ACTIVE per launch) gives the "
-                "issued instructions per pair and the busy share: frac = floor / issued x busy x "
-                "(effective / maximum clock).  work_over_hbm_peak = SURVEY 8d's 12 288 B per pair "
-                "/ time / 8 TB/s: it prices work, exceeds 1 because the sample rows never move "
-                "through HBM, and is not a roofline fraction; frac_hbm = bytes that really leave "
-                "L2 (committed PMC profile) / time / 8 TB/s")
+                "bound = l2_atomic: frac = (ld f32 atomic adds per pair: the gradient of the "
+                "central row, exact) x kernel pairs/s / 3.31e11 dword adds/s (what "
+                "scripts/atomic_probe.hip measures on this chip for any instruction shape; "
+                "profiles/r05_logs/r5_atomic_probe.log).  valu_issue_frac = the arithmetic's "
+                f"floor of vector instructions per pair ({floor:.1f}: bench.py "
+                "valu_floor_per_pair) x kernel pairs/s / (1 024 SIMDs x 2.4 GHz / 4 cycles): the "
+                "counter pass profiles/r05_resident_counters.json gives the instructions really "
+                "issued.  work_over_hbm_peak = SURVEY 8d's 12 288 B per pair / time / 8 TB/s: it "
+                "prices work, exceeds 1 because the sample rows never move through HBM, and is "
+                "not a roofline fraction; frac_hbm = bytes that really leave L2 (committed PMC "
+                "profile) / time / 8 TB/s")
         if reserved is not None:
             line["config"]["reserved_cus_per_xcd"] = args.reserve_cus
             line["config"]["active_cus_per_xcd"] = reserved

@@ -1452,7 +1452,7 @@ __global__ __launch_bounds__(WG) void sgns_block_kernel(BlockArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Resident cells: the plan of a small or mid-sized graph (gn2v_block_auto_plan: up to 105 M nodes
+// Resident cells: the plan of a small or mid-sized graph (gn2v_block_auto_plan: up to 115 M nodes
 // at d = 128) makes cells whose rows fit ONE workgroup's LDS.  A launch covers a part (or a group
 // of parts), one workgroup of sixteen waves per cell: it loads the cell's contextual rows into
 // LDS, trains ALL the cell's records (its waves take them from an LDS cursor), reads and updates

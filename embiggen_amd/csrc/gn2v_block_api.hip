@@ -703,7 +703,7 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     const bool exclusive = slices_are_xcd_exclusive(g, d.slices);
     // Resident cells (block_kernels.h sgns_resident_kernel): a plan of MORE THAN 16 SLICES whose
     // every cell fits one workgroup's LDS -- what gn2v_block_auto_plan arranges for graphs up to
-    // 105 M nodes at d = 128 (its XCD-cell plans have 1 or 8 slices; an explicit plan of a few
+    // 115 M nodes at d = 128 (its XCD-cell plans have 1 or 8 slices; an explicit plan of a few
     // slices on a tiny graph keeps sgns_block_kernel although its cells would fit).  One
     // workgroup per cell, contextual rows read and updated in LDS: no other CU touches them, no
     // flavour of global store or atomic is involved.  Inside the workgroup the rows are plain
@@ -925,7 +925,7 @@ int auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k, bool al
     if (!parts || !slices || world < 1) return fail("bad arguments");
     constexpr uint64_t kMinRows = 32768, kXcds = 8;
     // Rows up to 256 floats, a graph of GN2V_RESIDENT_MIN_NODES nodes or more that is
-    // small enough for cells that fit a workgroup's LDS (524 288 cells x ~200 rows at d = 128: 105 M
+    // small enough for cells that fit a workgroup's LDS (524 288 cells x ~200 rows at d = 128: 115 M
     // nodes): RESIDENT CELLS -- every contextual row is read and updated in the LDS of the one
     // workgroup that owns its cell (sgns_resident_kernel).  As few cells as hold the rows, up to
     // 256 slices per part (a launch covers a part: one workgroup per cell and CU).  Smaller

@@ -389,11 +389,11 @@ int gn2v_graph_xcds(gn2v_graph *g);
 /* (parts, slices) of the contextual table for a graph of n_nodes on `world` ranks.
  * Row stride ld <= 256 floats (ld = 0: unknown, this rule is skipped), k negatives, a graph of
  * GN2V_RESIDENT_MIN_NODES up to GN2V_RESIDENT_MAX_NODES nodes: RESIDENT CELLS -- cells of at
- * most the rows that fit one workgroup's LDS beside its staging (~200 at d = 128, 92 at 256), up to
+ * most the rows that fit one workgroup's LDS beside its staging (220 at d = 128, 109 at 256), up to
  * GN2V_BLOCK_MAX_SLICES slices per part (one workgroup per cell), as many parts as needed (169 k
- * nodes: 4 x 256 cells of 166 rows; 1 M: 20 x 256; 10 M: 195 x 256 -- 256 slices per part on
+ * nodes: 4 x 256 cells of 166 rows; 1 M: 18 x 256; 10 M: 178 x 256 -- 256 slices per part on
  * one GPU; several ranks: two parts per rank with as many slices as hold the rows, 10 M nodes on
- * 8 GPUs: 16 x 3 110, while a part keeps 64 cells).
+ * 8 GPUs: 16 x 2 841, while a part keeps 64 cells).
  * gn2v_block_step then reads and updates every contextual row in the LDS of the one workgroup
  * that owns it: no other CU races for it; gn2v_block_round launches a whole group of parts at
  * once, so that no CU waits for a part's heaviest cell.
@@ -405,7 +405,7 @@ int gn2v_graph_xcds(gn2v_graph *g);
 #define GN2V_BLOCK_MAX_CELLS 524288u      /* parts x slices of a plan                           */
 #define GN2V_BLOCK_MAX_GROUP_CELLS 8192u  /* parts of an extraction group x slices              */
 #define GN2V_RESIDENT_MIN_NODES 100000u
-#define GN2V_RESIDENT_MAX_NODES 115000000u /* 523 776 cells of 221 rows (d = 128, k = 10)       */
+#define GN2V_RESIDENT_MAX_NODES 115000000u /* 523 776 cells of 220 rows (d = 128, k = 10)       */
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
                          uint32_t *parts, uint32_t *slices);
 /* The same rule for a graph at hand (what gn2v_train_blocks and the Python trainer use): resident

@@ -9,7 +9,7 @@
 int main(void) {
     if (gn2v_version() < 200) return 1;
     uint32_t parts = 0, slices = 0, group = 0;
-    if (gn2v_block_auto_plan(10000000, 8, 128, 10, &parts, &slices) || parts != 16 || slices != 3110) return 2;
+    if (gn2v_block_auto_plan(10000000, 8, 128, 10, &parts, &slices) || parts != 16 || slices != 2841) return 2;
     if (gn2v_block_auto_plan(10000000, 8, 0, 10, &parts, &slices) || parts != 32 || slices != 8) return 2;
     uint64_t walks = 0;
     if (gn2v_block_round_plan(270000000000ull, 10000000, 128, 5, 1, 38, 8, 0, &walks, &group) ||

@@ -87,7 +87,7 @@ def test_automatic_plan_of_the_block_path():
                 assert 32768 <= n // (parts * slices) < 2 * 32768 * (world + 1)
     # one GPU, the row width known (ld <= 128 floats): RESIDENT CELLS -- every cell fits one
     # workgroup's LDS (160 KB minus the sixteen waves' staging) -- up to GN2V_RESIDENT_MAX_NODES
-    # (105 M: 524 288 cells of ~200 rows at d = 128)
+    # (115 M: 524 288 cells of 220 rows at d = 128)
     def rows(n, parts, slices):
         return -(-(-(-n // parts)) // slices)  # the largest cell: ceil(ceil(n / parts) / slices)
 
@@ -95,29 +95,34 @@ def test_automatic_plan_of_the_block_path():
     assert auto_plan(2_708, 1, 128, 10) == (1, 8)        # below GN2V_RESIDENT_MIN_NODES: XCD cells
     assert auto_plan(99_999, 1, 128, 10) == (1, 8) and auto_plan(100_000, 1, 128, 10) == (2, 256)
     assert auto_plan(169_343, 1, 128, 10) == (4, 256)    # config 3's shape: cells of 166 rows
-    assert auto_plan(2_449_029, 1, 128, 10) == (48, 256)  # config 4's shape
-    assert auto_plan(10_000_000, 1, 128, 10) == (195, 256)  # the bench graph: cells of 201 rows
-    assert auto_plan(100_000_000, 1, 128, 10) == (1944, 256)  # config 5: 497 664 cells
-    assert auto_plan(107_000_000, 1, 128, 10) == (408, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
-    assert auto_plan(1_000_000, 1, 256, 10) == (43, 256)  # rows of 256 floats: cells of 91 rows
+    assert auto_plan(2_449_029, 1, 128, 10) == (44, 256)  # config 4's shape
+    assert auto_plan(10_000_000, 1, 128, 10) == (178, 256)  # the bench graph: cells of 220 rows
+    assert auto_plan(100_000_000, 1, 128, 10) == (1776, 256)  # config 5: 454 656 cells
+    assert auto_plan(116_000_000, 1, 128, 10) == (442, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
+    assert auto_plan(1_000_000, 1, 256, 10) == (36, 256)  # rows of 256 floats: cells of 109 rows
     assert auto_plan(1_000_000, 1, 260, 10) == (3, 8)    # rows too wide for the resident kernel
-    assert auto_plan(1_000_000, 1, 128, 50) == (43, 256)  # 50 negatives: records of 16, cells of 91 rows
+    assert auto_plan(1_000_000, 1, 128, 50) == (28, 256)  # 50 negatives: cells of 140 rows
     # several ranks: the parts travel -- two per rank (more only beyond 8 192 slices), each launched
     # by itself with all its cells -- while a part keeps 64 cells; smaller graphs travel as XCD cells
-    assert auto_plan(1_000_000, 2, 128, 10) == (4, 1244) and auto_plan(1_000_000, 8, 128, 10) == (16, 311)
-    assert auto_plan(10_000_000, 8, 128, 10) == (16, 3110) and auto_plan(10_000_000, 2, 128, 10) == (8, 6219)
+    assert auto_plan(1_000_000, 2, 128, 10) == (4, 1137) and auto_plan(1_000_000, 8, 128, 10) == (16, 285)
+    assert auto_plan(10_000_000, 8, 128, 10) == (16, 2841) and auto_plan(10_000_000, 2, 128, 10) == (6, 7576)
     assert auto_plan(200_000, 8, 128, 10) == auto_plan(200_000, 8) == (16, 1)
     for n, world in ((1_000_000, 3), (2_449_029, 8), (10_000_000, 4), (13_000_000, 8), (100_000_000, 8)):
         parts, slices = auto_plan(n, world, 128, 10)
         assert parts % world == 0 and parts >= 2 * world and 64 <= slices <= 8192
-        assert rows(n, parts, slices) <= 201 and parts * slices <= 524288
+        assert rows(n, parts, slices) <= 220 and parts * slices <= 524288
     for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000, 300_000_000):
         for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40), (256, 10), (224, 5)):
             parts, slices = auto_plan(n, 1, ld, k)
             # records of 32 pairs, or of 16 / 8 when their staging would leave under 64 rows
             for record in (32, 16, 8):
-                staging = 16 * 4 * ((ld + 3 * record + 2 * record * (k + 1) + 2 + 3) // 4 * 4) + 64
-                fit = max(0, 160 * 1024 - staging) // (ld * 4 + 4)  # a row and its node id
+                # per wave: four transposition rows (128 floats at most), the centres and the
+                # 16-bit sample lists ((k + 1) padded to 4, record + 1 of them); shared: the dummy
+                # row; per row: the row, its alias entry, its node id
+                stride = (k + 1 + 3) // 4 * 4
+                words = (4 * min(ld, 128) + record + (record + 1) * stride // 2 + 2 + 3) // 4 * 4
+                staging = 16 * 4 * words + 64 + ld * 4
+                fit = min(4095, max(0, 160 * 1024 - staging) // (ld * 4 + 12))
                 if fit >= 64:
                     break
             if slices > 8:
@@ -137,11 +142,11 @@ def test_round_size_and_groups_follow_the_free_memory():
     GB = 10 ** 9
     # the bench graph on one GPU: 38 x 8 cells, rounds at the cap, four groups of <= 10 parts
     assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 38, 8, False) == (1 << 23, 10)
-    # the same graph in resident cells (195 x 256): a group is at most 8 192 cells = 32 parts --
+    # the same graph in resident cells (178 x 256): a group is at most 8 192 cells = 32 parts --
     # the extraction counts them in LDS -- and fewer when a long walk's staging leaves less room
-    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 195, 256, False) == (1 << 23, 32)
-    assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 195, 256, False)[1] == 32
-    assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 195, 256, False)[1] == 14
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, False) == (1 << 23, 32)
+    assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False)[1] == 32
+    assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 178, 256, False)[1] == 14
     # eight GPUs, a group in preparation while one trains
     assert round_plan(270 * GB, 10_000_000, 128, 5, 8, 32, 8, True) == (1 << 23, 8)
     # 100 M nodes on one GPU, 170 GB free beside the tables

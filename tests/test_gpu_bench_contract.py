@@ -31,14 +31,14 @@ def test_single_gpu_line():
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["value"] > 0 and d["finite"] is True
     r = d["roofline"]
-    # the bench graph is trained in resident cells: its kernel is bound by the issue rate of the
-    # vector pipes, and `frac` is a fraction of THAT ceiling (never above 1); SURVEY 8d's byte
-    # model is reported beside it under its own name
-    assert r["kernel"] == "gn2v::sgns_resident_v2_kernel" and r["bound"] == "valu_issue"
-    assert r["unit"] == "G wave-instructions/s" and abs(r["peak"] - 614.4) < 1e-9
+    # the bench graph is trained in resident cells: its kernel is bound by the L2 atomic units
+    # (the central rows' gradients), and `frac` is a fraction of THAT ceiling (never above 1);
+    # SURVEY 8d's byte model is reported beside it under its own name
+    assert r["kernel"] == "gn2v::sgns_resident_v2_kernel" and r["bound"] == "l2_atomic"
+    assert r["unit"] == "G f32 atomic adds/s" and r["peak"] == 331.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
-    assert abs(r["achieved"] - r["valu_floor_per_pair"] * r["kernel_pairs_per_s"] / 1e9) < 1e-6
-    assert r["valu_floor_per_pair"] == 60.5 and "traffic" in r
+    assert abs(r["achieved"] - 128 * r["kernel_pairs_per_s"] / 1e9) < 1e-6
+    assert r["valu_floor_per_pair"] == 60.5 and 0 < r["valu_issue_frac"] < 1 and "traffic" in r
     assert r["work_over_hbm_peak"] > 0 and abs(r["work_over_hbm_peak"] - r["work_bytes_per_s_gb"] / 8000.0) < 1e-12
     # bandwidth as bandwidth: either the PMC-based figure or the reason it is missing (this
     # tiny workload has no committed profile)

@@ -142,10 +142,10 @@ def test_config3_arxiv_shaped_block_path_full_size_properties():
 
 
 def test_config4_products_shaped_block_path_full_size_properties():
-    """BASELINE config 4's shape on one GPU: resident cells, 48 parts x 256 cells of 200 rows
+    """BASELINE config 4's shape on one GPU: resident cells, 44 parts x 256 cells of 218 rows
     (up to round 4's cell limit of 8 192: 9 x 8 XCD cells)."""
     g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
-    block_path_properties(g, 1 << 16, {"parts": 48, "slices": 256})
+    block_path_properties(g, 1 << 16, {"parts": 44, "slices": 256})
 
 
 def test_config4_block_path_with_the_parts_trained_in_node_order(monkeypatch):
@@ -154,15 +154,15 @@ def test_config4_block_path_with_the_parts_trained_in_node_order(monkeypatch):
     falls back to when the scratch copy of the part-major layout would not fit.  Same properties."""
     monkeypatch.setenv("GN2V_BLOCK_LAYOUT", "natural")
     g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
-    block_path_properties(g, 1 << 16, {"parts": 48, "slices": 256})
+    block_path_properties(g, 1 << 16, {"parts": 44, "slices": 256})
 
 
 def test_config5a_bench_graph_block_path_full_size_properties():
     """The roofline configuration (BA 10 M / 100 M) through the path the bench times: resident
-    cells, 193 parts x 256 cells of 203 rows; the extraction counts a group's cells in LDS, so a
+    cells, 178 parts x 256 cells of 220 rows; the extraction counts a group's cells in LDS, so a
     group holds 8 192 cells = 32 parts."""
     g = E.barabasi_albert(10_000_000, 10, 42)
-    plan, _ = block_path_properties(g, 1 << 17, {"parts": 193, "slices": 256})
+    plan, _ = block_path_properties(g, 1 << 17, {"parts": 178, "slices": 256})
     assert plan["group_parts"] == 32
 
 
@@ -177,18 +177,18 @@ def test_config5a_bench_graph_with_xcd_cells(monkeypatch):
 
 
 def test_config5_ba_100m_block_path_full_size_properties():
-    """BASELINE config 5 (BA 100 M / 1 B) on one GPU: resident cells, 1 925 parts x 256 cells of
-    203 rows (492 800 cells: 55-bit pair words, 19 + 27 + 9), extracted 32 parts at a time,
-    100 M-row alias tables, the 51.2 GB contextual table trained part-major in the caller's
-    buffer and restored through one scratch copy."""
+    """BASELINE config 5 (BA 100 M / 1 B) on one GPU: resident cells, 1 776 parts x 256 cells of
+    220 rows (454 656 cells: 55-bit pair words, 19 + 27 + 9), extracted 32 parts at a time,
+    100 M-row alias tables rebuilt with every round's placement, the 51.2 GB contextual table
+    trained where it lies, in node order."""
     g = E.barabasi_albert(100_000_000, 10, 42)
-    plan, _ = block_path_properties(g, 1 << 17, {"parts": 1925, "slices": 256})
+    plan, _ = block_path_properties(g, 1 << 17, {"parts": 1776, "slices": 256})
     assert plan["group_parts"] == 32
 
 
 def test_config5_ba_100m_with_xcd_cells(monkeypatch):
     """The same graph with the resident cells switched off: 381 x 8 XCD cells of 32.8 k rows,
-    56-bit pair words (12 + 27 + 17) -- the plan of graphs beyond 105 M nodes."""
+    56-bit pair words (12 + 27 + 17) -- the plan of graphs beyond 115 M nodes."""
     monkeypatch.setenv("GN2V_RESIDENT_MAX_NODES", "1500000")
     g = E.barabasi_albert(100_000_000, 10, 42)
     plan, _ = block_path_properties(g, 1 << 17, {"parts": 381, "slices": 8})
@@ -236,8 +236,8 @@ def test_config4_block_trainer_with_eight_simulated_ranks_at_full_size():
     gen.manual_seed(1)
     auc_single = link_auc_device(g, c, x, gen)
     del c, x
-    # resident cells travel too: 16 parts (two per rank) x 755 cells of <= 203 rows
-    assert auto_plan(n, world, d, 10) == (16, 755) and auto_plan(n, world) == (16, 8)
+    # resident cells travel too: 16 parts (two per rank) x 696 cells of <= 220 rows
+    assert auto_plan(n, world, d, 10) == (16, 696) and auto_plan(n, world) == (16, 8)
 
     def rank_fn(comm):
         tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, comm, "cuda:0", walk_length=128,

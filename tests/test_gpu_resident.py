@@ -1,4 +1,4 @@
-"""GPU: `sgns_resident_kernel` -- the default training kernel of every graph from 100 k to 105 M
+"""GPU: `sgns_resident_kernel` -- the default training kernel of every graph from 100 k to 115 M
 nodes (BASELINE configs 3, 4, 5a, 5; nine tenths of the bench's GPU time) -- against the oracle's
 restatement of the block schedule (`oracle/gn2v_oracle.c` o_block_step), element by element:
 
