@@ -99,36 +99,40 @@ def test_default_fit_agrees_with_the_oracles_hogwild_fit_on_the_same_walks(shape
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("cells,nodes,m,L,plan", [("xcd", 2_708, 2, 128, (1, 8)),
-                                                  ("resident", 100_000, 5, 24, (2, 256))])
+@pytest.mark.parametrize("cells,nodes,m,L,plan,rounds", [("xcd", 2_708, 2, 128, (1, 8), 1),
+                                                         ("resident", 100_000, 5, 24, (2, 256), 4)])
 def test_default_schedule_against_the_sequential_restatement_of_the_same_schedule(cells, nodes, m,
-                                                                                  L, plan):
+                                                                                  L, plan, rounds):
     """The GPU's parallel default and the oracle's sequential restatement of the block schedule
     train the SAME pairs with the SAME negatives (one round); they differ by what parallel
     execution does to the order of the updates -- and by what racing stores lose.  XCD cells at
     config 2's shape (1 x 8 cells of 338 rows; one wave per four rows, a row read again right
     before its stores); resident cells at the smallest size that gets them (100 k nodes: 2 x 256
-    cells of 196 rows, each owned by one workgroup; short walks, so that the sequential oracle
-    finishes: the cosines are still near their random start there and only their distance and
-    the tables' displacement are gated)."""
+    cells of 196 rows, each owned by one workgroup, under the rounds' placements; short walks,
+    so that the sequential oracle finishes, but four rounds of them -- four walks a node, the
+    cells reshuffled in between -- so that the cosines leave their random start and their rank
+    correlation means something: gated)."""
     rw = ew = 1.0
     g = E.barabasi_albert(nodes, m, 42)
     host = g  # row_ptr / col_idx come to the host on first use
     d, w, k, lr = 128, 5, 10, 0.01
-    wk = ops.walks(g, ops.walk_params(L, 1, rw, ew), 42, 0, 0, nodes)
+    wks = [ops.walks(g, ops.walk_params(L, 1, rw, ew), 42, 0, r * nodes, nodes)
+           for r in range(rounds)]
     tables = {}
     for name in ("gpu", "oracle"):
         if name == "gpu":
             tp = ops.train_params(0, d, k, w, flags=1, ld=d)
             tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
                                          walk_length=L, window=w, parts=plan[0], slices=plan[1])
-            tr.train_round(wk, 42, 0, lr, 0)
+            for r, wk in enumerate(wks):
+                tr.train_round(wk, 42, 0, lr, r * nodes)
         else:
             tp = O.TrainParams(0, d, d, 1, k, w, lr, 0.9, 6.0, 1, d ** -0.5)
             tr = BlockPartitionedTrainer(host, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cpu",
                                          walk_length=L, window=w, backend=OracleBlockBackend(host),
                                          parts=plan[0], slices=plan[1])
-            tr.train_round(wk.cpu(), 42, 0, lr, 0)
+            for r, wk in enumerate(wks):
+                tr.train_round(wk.cpu(), 42, 0, lr, r * nodes)
         c, x = tr.gather_full()
         tables[name] = (c.cpu().numpy(), x.cpu().numpy())
     init_c = ops.init_table(nodes, d, 42, 0, d ** -0.5).cpu().numpy()
@@ -143,11 +147,13 @@ def test_default_schedule_against_the_sequential_restatement_of_the_same_schedul
     # contextual 0.82 x / 0.93 -- racing stores on a 338-row cell lose some updates (0.61 x with
     # a wave per row, 0.69 x before a row was read again right before its stores; an exact
     # accumulation in the same parallel order moves the contextual table 0.91 x: that is the
-    # order, not a loss).  Resident cells: 0.85-0.87 x
+    # order, not a loss).  Resident cells, round 5 (four rounds under their placements, lockstep
+    # phases): central 0.955 x / Spearman 0.971, contextual 0.954 x / 0.949, mean |d cos| 0.034 /
+    # 0.043 (round 4's kernel moved the contextual table 0.85-0.87 x)
     assert 0.9 <= report["central"]["moved"] <= 1.1, report
-    assert (0.8 if cells == "resident" else 0.75) <= report["contextual"]["moved"] <= 1.1, report
+    assert (0.9 if cells == "resident" else 0.75) <= report["contextual"]["moved"] <= 1.1, report
     for label, r in report.items():
-        assert r["spearman"] >= 0.9 or cells == "resident", report
+        assert r["spearman"] >= 0.9, report
         assert r["mean_abs"] <= 0.12, report
 
 

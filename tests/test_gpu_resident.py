@@ -551,3 +551,98 @@ def test_gn2v_train_takes_resident_cells_under_a_placement_and_equals_the_python
     assert float((c1 - c3).abs().max()) < 1e-5 and float((x1 - x3).abs().max()) < 1e-5
     init = ops.init_table(6000, 100, 42, 1, 100 ** -0.5, ld=128)
     assert float((x1[:, :100] - init[:, :100]).abs().max()) > 1e-3
+
+
+def test_negatives_met_by_a_context_over_the_rounds():
+    """What the placement is for, measured on the device.  One fixed context
+    x0; every round it is placed in another cell of 200 rows, and 300 pairs (c_i, x0) draw
+    k = 5 negatives each there -- deterministic form, central rows = one constant vector,
+    contextual rows = 0, a tiny learning rate: row y ends at -(times y was drawn) lr / 2 u.
+    (a) GIVEN the cell-mates of every round the counts follow in-degree / cell total (chi-square,
+        the skip rule for negative == context included);
+    (b) over the rounds x0 meets negatives from the whole graph: after 96 rounds ~60 % of all
+        nodes have been cell-mates, every one about equally often, where fixed cells would have
+        offered the same 199 nodes 96 times;
+    (c) per degree class the counts stay within 6 % of in-degree / total for the classes that
+        hold 90 % of the in-degree (measured 0.98-1.02); the class of the hubs gets 0.97 here
+        -- a cell normalises by its OWN total, so a hub that is a mate crowds the very draw it
+        is in (a node whose in-degree is a tenth of a cell's total is drawn 9 % less often than
+        the law over the graph says): printed, and bounded."""
+    from scipy import stats
+
+    n, d, k, slices, rounds, n_pairs = 20_000, 8, 5, 100, 96, 300
+    g = E.barabasi_albert(n, 5, 42)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    indeg = np.bincount(g.col_idx, minlength=n).astype(np.float64)
+    plan = ops.block_plan(g, 1, 0, 1, slices, 8, 2, 1, 16)
+    oplan = O.block_plan(n, 1, 0, 1, slices, 8, 2, 1, 16)
+    x0 = 12_345
+    centres = np.arange(1, n_pairs + 1) * 17 % n
+    centres = centres[centres != x0]
+    lr, u = 1e-6, d ** -0.5
+    tp = ops.train_params(0, d, k, 2, flags=1 | DET, ld=d)
+    c = torch.full((n, d), u, device="cuda")
+    x = torch.zeros((n, d), device="cuda")
+    expected = np.zeros(n)
+    met = np.zeros(n, dtype=np.int64)
+    for r in range(rounds):
+        place, inv = ops.block_placement(g, 1, 42, r)
+        alias, cell_rows = ops.block_alias(g, plan, inv=inv)[:2]
+        xp = int(place[x0])  # parts = 1: row = x', slice = row % slices, local = row // slices
+        cell, local = xp % slices, xp // slices
+        words = O.block_pack(np.full(len(centres), cell), centres, np.full(len(centres), xp), oplan)
+        off = np.zeros(slices + 1, dtype=np.uint64)
+        off[cell + 1:] = len(centres)
+        ops.block_step(g, tp, plan, _dev_words(np.sort(words)), torch.from_numpy(off.astype(np.int64)).cuda(),
+                       alias, cell_rows, c, None, r, 0, 42, 0, lr, inv=inv, context_table=x)
+        inv_h = inv.cpu().numpy().view(np.uint32)
+        rows_in_cell = -(-(n - cell) // slices)
+        mates = inv_h[cell + slices * np.arange(rows_in_cell)].astype(np.int64)
+        assert x0 in mates and mates[local] == x0
+        w = indeg[mates]
+        # a draw of x0 itself is skipped; a draw of the pair's own centre too (one pair in 299)
+        share = w / w.sum()
+        share[local] = 0.0
+        expected[mates] += len(centres) * k * share
+        met[mates] += 1
+    torch.cuda.synchronize()
+    got = (-x.double().mean(1) / (0.5 * lr * u)).cpu().numpy()
+    got[x0] = 0.0
+    counts = np.rint(got)
+    # (a row that was drawn 500 times has moved far enough for its sigmoid to leave 1 / 2 a little)
+    assert (np.abs(got - counts) <= 0.05 + 2e-3 * counts).all() and counts.min() >= 0
+    assert abs(counts.sum() / expected.sum() - 1) < 0.01
+    # (a) given the mates: chi-square over the nodes ever met, pooled to >= 40 expected draws
+    order = np.argsort(-expected)
+    order = order[expected[order] > 0]
+    bins_o, bins_e, acc_o, acc_e = [], [], 0.0, 0.0
+    for y in order:
+        acc_o += counts[y]
+        acc_e += expected[y]
+        if acc_e >= 40:
+            bins_o.append(acc_o)
+            bins_e.append(acc_e)
+            acc_o = acc_e = 0.0
+    o, e = np.array(bins_o), np.array(bins_e)
+    p = stats.chisquare(o, e * o.sum() / e.sum()).pvalue
+    assert len(o) > 100 and p > 1e-4, p
+    # (b) the mates over the rounds
+    others = np.delete(np.arange(n), x0)
+    assert (met[others] > 0).mean() > 0.55 and met[others].max() <= 8
+    assert abs(met[others].mean() - rounds * 199 / (n - 1)) < 0.05
+    # (c) against the law over the whole graph, by degree class (equal shares of the in-degree)
+    by_deg = np.argsort(indeg)
+    cum = np.cumsum(indeg[by_deg]) / indeg.sum()
+    report = []
+    for lo, hi in ((0.0, 0.3), (0.3, 0.6), (0.6, 0.9), (0.9, 1.0)):
+        cls = by_deg[(cum > lo) & (cum <= hi)]
+        cls = cls[cls != x0]
+        report.append((float(indeg[cls].min()), float(indeg[cls].max()),
+                       float(counts[cls].sum() / counts.sum()), float(indeg[cls].sum() / indeg[others].sum())))
+    print("degree class (min, max in-degree): share of the negatives met / share of the in-degree")
+    for lo_d, hi_d, got_s, want_s in report:
+        print(f"  {lo_d:6.0f} .. {hi_d:6.0f}: {got_s:.4f} / {want_s:.4f} = {got_s / want_s:.3f}")
+    # measured: 0.983, 1.009, 1.018, 0.969
+    for lo_d, hi_d, got_s, want_s in report[:3]:
+        assert abs(got_s / want_s - 1) < 0.06, report
+    assert 0.88 < report[3][2] / report[3][3] < 1.08, report
