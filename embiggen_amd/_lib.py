@@ -157,6 +157,9 @@ class BlockRoundIO(C.Structure):
         ("next_unit", C.c_uint32),
         ("needed_pairs", C.c_uint64),
         ("pairs_trained", C.c_uint64),
+        ("d_pairs2", C.c_void_p),
+        ("d_cell_offsets2", C.c_void_p),
+        ("d_work2", C.c_void_p),
     ]
 
 

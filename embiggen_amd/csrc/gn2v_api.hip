@@ -714,6 +714,13 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->counters) (void)hipFree(g->counters);
     if (g->part_ptrs_dev) (void)hipFree(g->part_ptrs_dev);
     if (g->indeg) (void)hipFree(g->indeg);
+    if (g->prep_stream) {
+        (void)hipStreamDestroy(g->prep_stream);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(g->prep_done[i]);
+            (void)hipEventDestroy(g->train_done[i]);
+        }
+    }
     if (g->cursors) (void)hipFree(g->cursors);
     if (g->edge_set) (void)hipFree(g->edge_set);
     if (g->edge_filter) (void)hipFree(g->edge_filter);

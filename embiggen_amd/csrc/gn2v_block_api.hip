@@ -1085,27 +1085,75 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
     const uint32_t gp = io->group_parts ? std::min(io->group_parts, parts) : parts;
     const uint32_t groups = (parts + gp - 1) / gp;
     if (io->next_unit > stripes * groups) return fail("next_unit beyond the round");
-    for (; io->next_unit < stripes * groups; ++io->next_unit) {
-        const uint32_t j = io->next_unit / groups, p0 = (io->next_unit % groups) * gp;
-        const uint32_t pn = std::min(gp, parts - p0);
+
+    // Two sets of (pair words, cell offsets, work): unit u + 1 is counted, extracted and sorted
+    // on a stream of the handle's own WHILE unit u trains -- the training kernel of resident
+    // cells is bound by the L2 atomic units, the preparation by HBM, so they overlap (the
+    // kernel's workgroups hold their CUs' LDS: gn2v_graph_reserve_cus leaves the preparation
+    // CUs of its own).  One set: everything in line on the caller's stream.
+    const bool overlapped = io->d_pairs2 && io->d_cell_offsets2 && io->d_work2;
+    uint64_t *const pairs_of[2] = {io->d_pairs, overlapped ? io->d_pairs2 : io->d_pairs};
+    uint64_t *const offsets_of[2] = {io->d_cell_offsets,
+                                     overlapped ? io->d_cell_offsets2 : io->d_cell_offsets};
+    uint64_t *const work_of[2] = {io->d_work, overlapped ? io->d_work2 : io->d_work};
+    hipStream_t side = s;
+    if (overlapped) {
+        if (!g->prep_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&g->prep_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipEventCreateWithFlags(&g->prep_done[i], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&g->train_done[i], hipEventDisableTiming));
+            }
+        }
+        side = g->prep_stream;
+        // whatever the caller put on its stream (the walks, the placement, the alias tables)
+        // comes before the first preparation
+        HIP_TRY(hipEventRecord(g->train_done[0], s));
+        HIP_TRY(hipStreamWaitEvent(side, g->train_done[0], 0));
+        HIP_TRY(hipEventRecord(g->train_done[1], s));
+    }
+
+    // count + one host read + extract + sort of unit u into set `slot`; *n_pairs = 0: nothing
+    // to train; returns GN2V_ROUND_GROW when the unit needs larger buffers
+    auto prepare = [&](uint32_t u, int slot, uint64_t *n_pairs) -> int {
+        const uint32_t j = u / groups, p0 = (u % groups) * gp, pn = std::min(gp, parts - p0);
         const gn2v_block_plan *pj = &plans[j];
         if (gn2v_block_count(g, pj, io->d_walks, io->d_placed_walks, n_walks, seed, epoch,
-                             first_walk, p0, pn, io->d_work, io->d_cell_offsets, s))
+                             first_walk, p0, pn, work_of[slot], offsets_of[slot], side))
             return 1;
-        uint64_t n_pairs = 0;  // the one host read of the group
-        HIP_TRY(hipMemcpyAsync(&n_pairs, io->d_cell_offsets + cells, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (n_pairs == 0) continue;
+        HIP_TRY(hipMemcpyAsync(n_pairs, offsets_of[slot] + cells, 8, hipMemcpyDeviceToHost, side));
+        HIP_TRY(hipStreamSynchronize(side));  // the one host read of the group
+        if (*n_pairs == 0) return 0;
         uint64_t need = 0;
-        gn2v_block_extract_temp_bytes(n_pairs, &need);
-        if (n_pairs > io->pairs_capacity || need > io->temp_bytes || !io->d_pairs || !io->d_temp) {
-            io->needed_pairs = n_pairs;
+        gn2v_block_extract_temp_bytes(*n_pairs, &need);
+        if (*n_pairs > io->pairs_capacity || need > io->temp_bytes || !io->d_pairs || !io->d_temp) {
+            io->needed_pairs = *n_pairs;
             return GN2V_ROUND_GROW;
         }
         if (gn2v_block_extract(g, pj, io->d_walks, io->d_placed_walks, n_walks, seed, epoch,
-                               first_walk, p0, pn, io->d_work, io->d_hub_bits, n_pairs,
-                               io->d_pairs, io->d_temp, io->temp_bytes, s))
+                               first_walk, p0, pn, work_of[slot], io->d_hub_bits, *n_pairs,
+                               pairs_of[slot], io->d_temp, io->temp_bytes, side))
             return 1;
+        if (overlapped) HIP_TRY(hipEventRecord(g->prep_done[slot], side));
+        return 0;
+    };
+    auto train = [&](uint32_t u, int slot) -> int {
+        const uint32_t j = u / groups, p0 = (u % groups) * gp, pn = std::min(gp, parts - p0);
+        const gn2v_block_plan *pj = &plans[j];
+        if (overlapped) HIP_TRY(hipStreamWaitEvent(s, g->prep_done[slot], 0));
+        gn2v_block_io step{};
+        step.d_pairs = pairs_of[slot];
+        step.d_cell_offsets = offsets_of[slot];
+        step.d_alias = io->d_alias;
+        step.d_cell_rows = io->d_cell_rows;
+        step.d_hot_list = io->d_hot_list;
+        step.d_hot_slot = io->d_hot_slot;
+        step.d_central = io->d_central + (size_t)j * ld;
+        step.central_ld = (uint64_t)stripes * ld;
+        step.context_ld = io->context_ld;
+        step.d_inv = io->d_inv;
+        step.d_context_table = io->d_context_table;
+        step.block_id = round_id * stripes + j;
         // resident cells: the whole group in one launch (its workgroups are handed to the CUs
         // as they fall free; a launch per part would wait for the part's heaviest cell)
         bool took_group = false;
@@ -1117,53 +1165,66 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
                     (void)hipFree(g->part_ptrs_dev);
                     g->part_ptrs_dev = nullptr;
                 }
-                if (!g->part_ptrs_dev) HIP_TRY(hipMalloc((void **)&g->part_ptrs_dev, parts * sizeof(float *)));
+                if (!g->part_ptrs_dev)
+                    HIP_TRY(hipMalloc((void **)&g->part_ptrs_dev, parts * sizeof(float *)));
                 HIP_TRY(hipMemcpy(g->part_ptrs_dev, ptrs.data(), parts * sizeof(float *),
                                   hipMemcpyHostToDevice));
                 g->part_ptrs_host = ptrs;
             }
-            gn2v_block_io step{};
-            step.d_pairs = io->d_pairs;
-            step.d_cell_offsets = io->d_cell_offsets;
-            step.d_alias = io->d_alias;
-            step.d_cell_rows = io->d_cell_rows;
-            step.d_hot_list = io->d_hot_list;
-            step.d_hot_slot = io->d_hot_slot;
-            step.d_central = io->d_central + (size_t)j * ld;
-            step.central_ld = (uint64_t)stripes * ld;
             step.d_context = nullptr;
-            step.context_ld = io->context_ld;
-            step.d_inv = io->d_inv;
-            step.d_context_table = io->d_context_table;
-            step.block_id = round_id * stripes + j;
             step.part = p0;
             if (block_step(g, tp, pj, &step, seed, epoch, lr, s, pn, g->part_ptrs_dev, &took_group))
                 return 1;
         }
         for (uint32_t p = p0; p < p0 + pn && !took_group; ++p) {
-            gn2v_block_io step{};
-            step.d_pairs = io->d_pairs;
-            step.d_cell_offsets = io->d_cell_offsets;
-            step.d_alias = io->d_alias;
-            step.d_cell_rows = io->d_cell_rows;
-            step.d_hot_list = io->d_hot_list;
-            step.d_hot_slot = io->d_hot_slot;
-            step.d_central = io->d_central + (size_t)j * ld;
-            step.central_ld = (uint64_t)stripes * ld;
             step.d_context = io->context_parts[p];
-            step.context_ld = io->context_ld;
-            step.d_inv = io->d_inv;
-            step.d_context_table = io->d_context_table;
-            step.block_id = round_id * stripes + j;
             step.part = p;
             if (gn2v_block_step(g, tp, pj, &step, seed, epoch, lr, s)) return 1;
         }
-        io->pairs_trained += n_pairs;
+        if (overlapped) HIP_TRY(hipEventRecord(g->train_done[slot], s));
+        return 0;
+    };
+
+    const uint32_t n_units = stripes * groups;
+    int slot = 0;
+    uint64_t n_pairs = 0;
+    bool prepared = false;  // unit io->next_unit sits in `slot`, ready to train
+    while (io->next_unit < n_units) {
+        if (!prepared) {
+            const int rc = prepare(io->next_unit, slot, &n_pairs);
+            if (rc) {
+                if (rc == GN2V_ROUND_GROW && overlapped) HIP_TRY(hipStreamSynchronize(s));
+                return rc;
+            }
+        }
+        prepared = false;
+        const uint32_t u = io->next_unit;
+        if (n_pairs) {
+            if (train(u, slot)) return 1;
+            io->pairs_trained += n_pairs;
+        }
+        io->next_unit = u + 1;
+        if (overlapped && u + 1 < n_units) {
+            // the next unit's preparation beside this unit's training: its set was last read by
+            // the training of unit u - 1
+            slot ^= 1;
+            HIP_TRY(hipStreamWaitEvent(side, g->train_done[slot], 0));
+            const int rc = prepare(u + 1, slot, &n_pairs);
+            if (rc) {
+                if (rc == GN2V_ROUND_GROW) HIP_TRY(hipStreamSynchronize(s));
+                return rc;
+            }
+            prepared = true;
+        }
         if (g->train_events.size() > 2048) {  // bound the event pool on long fits
             HIP_TRY(hipStreamSynchronize(s));
             gn2v_stats scratch;
             if (gn2v_stats_read(g, &scratch, s)) return 1;
         }
+    }
+    if (overlapped) {  // the caller's stream ends after everything the side stream did
+        HIP_TRY(hipEventRecord(g->prep_done[0], side));
+        HIP_TRY(hipStreamWaitEvent(s, g->prep_done[0], 0));
     }
     return 0;
 }
@@ -1286,25 +1347,32 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
 
     mark("alias tables");
     // round size and groups of parts: `round_walks` = the walks one pass extracts from (a round is
-    // V times that); the pairs of a round are extracted, sorted and trained a group at a time
+    // V times that); the pairs of a round are extracted, sorted and trained a group at a time.
+    // Resident cells: the next group is prepared on a second stream while this one trains (a
+    // second set of pair words; gn2v_block_round) -- GN2V_BLOCK_OVERLAP=0: in line (A/B).
+    const bool overlap = resident_plan && env_size("GN2V_BLOCK_OVERLAP", 1) != 0;
     const bool automatic = round_walks == 0;
     uint32_t group_parts = 0;
     size_t free_b = 0, total_b = 0;
     {
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         uint64_t auto_walks = 0;
-        if (gn2v_block_round_plan(free_b, n, L, w, V, parts, plan.slices, 0, &auto_walks,
-                                  &group_parts))
+        if (gn2v_block_round_plan(free_b, n, L, w, V, parts, plan.slices, overlap ? 1 : 0,
+                                  &auto_walks, &group_parts))
             return 1;
         if (automatic) round_walks = auto_walks;
     }
     round_walks = std::max<uint64_t>(1, std::min(round_walks, (walks_per_epoch + V - 1) / V));
     uint32_t *walks = nullptr, *placed = nullptr;
-    uint64_t *pairs = nullptr, *work = nullptr, *cell_offsets = nullptr, *part_first = nullptr;
+    uint64_t *pairs = nullptr, *pairs2 = nullptr, *work = nullptr, *work2 = nullptr,
+             *cell_offsets = nullptr, *cell_offsets2 = nullptr, *part_first = nullptr;
     void *tmp = nullptr;
     uint64_t tb = 0, cap = 0;
     if (buf.alloc(&work, GN2V_BLOCK_WORK_WORDS * 8) || buf.alloc(&cell_offsets, (cells + 1) * 8) ||
         buf.alloc(&part_first, (parts + 1) * 8))
+        return kOutOfMemory;
+    if (overlap && (buf.alloc(&work2, GN2V_BLOCK_WORK_WORDS * 8) ||
+                    buf.alloc(&cell_offsets2, (cells + 1) * 8)))
         return kOutOfMemory;
     const size_t held = buf.ptrs.size();
     auto release_round = [&]() {
@@ -1321,7 +1389,8 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         gn2v_block_extract_temp_bytes(cap, &tb);
         if (!(buf.alloc(&walks, V * round_walks * L * 4) ||
               (permute && buf.alloc(&placed, V * round_walks * L * 4)) ||
-              buf.alloc(&pairs, cap * 8) || buf.alloc(&tmp, tb)))
+              (overlap && buf.alloc(&pairs2, cap * 8)) || buf.alloc(&pairs, cap * 8) ||
+              buf.alloc(&tmp, tb)))
             break;
         // somebody else took the memory between the query and here: smaller groups, then an
         // automatic round halves
@@ -1387,6 +1456,9 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     rio.d_temp = tmp;
     rio.temp_bytes = tb;
     rio.group_parts = group_parts;
+    rio.d_pairs2 = pairs2;
+    rio.d_cell_offsets2 = cell_offsets2;
+    rio.d_work2 = work2;
 
     mark("tables initialised");
     float lr = tp->lr;
@@ -1409,13 +1481,21 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
                                                 lr, round_id, s);
                 if (rc == 0) break;
                 if (rc != GN2V_ROUND_GROW) return 1;
-                // a group heavier than the head room allows: grow
+                // a group heavier than the head room allows: grow (the driver has waited for
+                // whatever still trained from these buffers)
                 (void)hipFree(tmp);
                 (void)hipFree(pairs);
                 buf.ptrs.resize(buf.ptrs.size() - 2);
+                if (pairs2) {
+                    (void)hipFree(pairs2);
+                    buf.ptrs.pop_back();
+                }
                 cap = rio.needed_pairs + rio.needed_pairs / 16;
                 gn2v_block_extract_temp_bytes(cap, &tb);
-                if (buf.alloc(&pairs, cap * 8) || buf.alloc(&tmp, tb)) return 1;
+                if ((pairs2 && buf.alloc(&pairs2, cap * 8)) || buf.alloc(&pairs, cap * 8) ||
+                    buf.alloc(&tmp, tb))
+                    return 1;
+                rio.d_pairs2 = pairs2;
                 rio.d_pairs = pairs;
                 rio.pairs_capacity = cap;
                 rio.d_temp = tmp;

@@ -84,6 +84,10 @@ struct gn2v_graph {
     // the second-order sampler's edge set (GraphView.edge_set), built on the first biased walk
     unsigned long long *edge_set = nullptr, *edge_filter = nullptr;
     bool edge_set_tried = false;
+    // gn2v_block_round with two sets of pair buffers: the preparation's own stream and the
+    // events that order it against the training (created on first use)
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t prep_done[2] = {nullptr, nullptr}, train_done[2] = {nullptr, nullptr};
     // resident cells, a group of parts per launch: the parts' row pointers on the device
     std::vector<float *> part_ptrs_host;
     float **part_ptrs_dev = nullptr;

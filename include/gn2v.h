@@ -470,6 +470,12 @@ typedef struct {
     uint32_t next_unit;             /* in / out                                                 */
     uint64_t needed_pairs;          /* out, with GN2V_ROUND_GROW                                */
     uint64_t pairs_trained;         /* out: pairs of the units this call trained are ADDED      */
+    /* a second set (all three or none; d_pairs2 of pairs_capacity words): the next unit is
+     * counted, extracted and sorted on a stream of the library's own while this one trains --
+     * the resident kernel is bound by the L2 atomic units, the preparation by HBM            */
+    uint64_t *d_pairs2;
+    uint64_t *d_cell_offsets2;
+    uint64_t *d_work2;
 } gn2v_block_round_io;
 int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plans,
                      uint32_t stripes, gn2v_block_round_io *io, uint64_t n_walks, uint64_t seed,

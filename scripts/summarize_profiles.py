@@ -145,6 +145,28 @@ def main(tag):
                 f"calibration on `touch_rows_kernel` (known bytes): fetch x{fetch_factor:.3f}, write x{write_factor:.3f} -> "
                 f"HBM traffic {out['hbm_traffic_bytes_per_launch'] / 1e9:.1f} GB per launch = {out['hbm_traffic_GBps']:.0f} GB/s "
                 f"({out['traffic_over_algorithmic']:.3f} x the algorithmic bytes).\n")
+    roof = bench.get("roofline", {})
+    if roof.get("bound") == "l2_atomic":
+        # the resident kernel's own ceiling: f32 atomic adds of the central rows' gradients
+        dwords = roof["atomic_dwords_per_pair"] * pairs_per_launch
+        out["l2_atomic"] = {
+            "atomic_dwords_per_launch": dwords,
+            "G_atomic_adds_per_s": dwords / (avg_ms * 1e-3) / 1e9,
+            "G_atomic_adds_per_s_timed_launches": dwords * len(timed) / len(timed)
+            / (timed_ms * 1e-3) / 1e9 if timed else None,
+            "peak_G_atomic_adds_per_s": roof["peak"],
+            "frac": dwords / (avg_ms * 1e-3) / 1e9 / roof["peak"],
+            "peak_source": "scripts/atomic_probe.hip -> profiles/r05_logs/r5_atomic_probe.log",
+        }
+        with open(os.path.join(dst, f"{tag}_pmc.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        with open(os.path.join(dst, f"{tag}_summary.md"), "a") as f:
+            f.write(f"\nWhat bounds this kernel is not HBM (0.25 of 8 TB/s above) but the L2 atomic units: every "
+                    f"pair adds its gradient to its central row with {roof['atomic_dwords_per_pair']} f32 atomics = "
+                    f"{dwords / 1e9:.1f} G adds per launch, {out['l2_atomic']['G_atomic_adds_per_s']:.1f} G adds/s over "
+                    f"all launches = {out['l2_atomic']['frac']:.3f} of the {roof['peak']:.0f} G adds/s the chip "
+                    f"retires (`scripts/atomic_probe.hip`, `profiles/r05_logs/r5_atomic_probe.log`); bench.py "
+                    f"reports this as `roofline.frac` ({roof['frac']:.3f} over the timed launches of this run).\n")
     print(json.dumps(out, indent=1))
 
 
