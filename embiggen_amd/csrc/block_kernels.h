@@ -62,8 +62,31 @@ constexpr uint32_t kTicket = 4;       // records a wave takes per ticket (one re
 constexpr uint32_t kHubBit = 0x80000000u;
 constexpr uint32_t kHotMax = GN2V_BLOCK_HOT_MAX;
 
+// Division by a number that is the same for a whole launch (parts, slices, world): a 32-bit
+// integer division costs ~35 vector instructions on gfx950, and the extraction does three per
+// walk position and pass.  Granlund-Montgomery: q = (mulhi(x, m) + x) >> s for every 32-bit x
+// (the sum in 33 bits: t + ((x - t) >> 1) >> (s - 1)); set up on the host (FastDiv::of).
+struct FastDiv {
+    uint32_t m, s, d;
+    static FastDiv of(uint32_t d) {
+        FastDiv f{0, 0, d};
+        if (d <= 1) return f;  // s == 0: q = x (d == 1)
+        uint32_t l = 0;
+        while ((1ull << l) < d) ++l;
+        f.s = l;
+        f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+        return f;
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t x) const {
+        if (s == 0) return x;
+        const uint32_t t = __umulhi(x, m);
+        return (t + ((x - t) >> 1)) >> (s - 1);
+    }
+};
+
 struct BlockPlan {
     uint32_t world, rank, parts, slices;
+    FastDiv dparts, dslices, dworld;
     uint32_t L, window, min_dist, record;
     uint32_t row_bits;  // bits of the centre row in a pair word
     uint32_t ctx_bits;  // bits below it: the context row inside its cell + the hot flag on top
@@ -329,11 +352,11 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
                 Le = min(Le, t);
             } else {
                 const uint32_t xp = a.placed ? a.placed[b * L + t] : x;
-                const uint32_t row = xp / a.p.parts, part = xp - row * a.p.parts;
+                const uint32_t row = a.p.dparts.div(xp), part = xp - row * a.p.parts;
                 const uint32_t rel = part >= a.part_lo ? part - a.part_lo
                                                        : part + a.p.parts - a.part_lo;
                 if (rel < a.part_n) {
-                    loc = row / a.p.slices;
+                    loc = a.p.dslices.div(row);
                     cell = part * a.p.slices + (row - loc * a.p.slices);
                     if (WRITE && a.hub_bits && ((a.hub_bits[x >> 5] >> (x & 31)) & 1u))
                         loc |= 1u << hub_shift;
@@ -352,7 +375,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
             bool own = false;
             if (i < Le) {
                 const uint32_t c = s_walk[i];
-                own = c % a.p.world == a.p.rank &&
+                own = c - a.p.dworld.div(c) * a.p.world == a.p.rank &&
                       (!(a.p.flags & kFlagDownsample) || keep_centre_at(a.g, wkey, i, c));
             }
             const uint64_t m = __ballot(own);
@@ -376,7 +399,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
                     if (dist >= a.p.min_dist && cell != kSentinel) {
                         if constexpr (WRITE)
                             word = ((((unsigned long long)cell << a.p.row_bits) |
-                                     (s_walk[i] / a.p.world))
+                                     a.p.dworld.div(s_walk[i]))
                                     << a.p.ctx_bits) |
                                    s_loc[j];
                         valid = true;
@@ -389,7 +412,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
                 base += __popcll(mask);
             } else {
                 if (valid) {
-                    const uint32_t part = cell / a.p.slices, sl = cell - part * a.p.slices;
+                    const uint32_t part = a.p.dslices.div(cell), sl = cell - part * a.p.slices;
                     const uint32_t rel = part >= a.part_lo ? part - a.part_lo
                                                            : part + a.p.parts - a.part_lo;
                     atomicAdd(&s_hist[rel * a.p.slices + sl], 1u);
@@ -493,11 +516,11 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractA
                 Le = min(Le, t);
             } else {
                 const uint32_t xp = a.placed ? a.placed[b * L + t] : x;
-                const uint32_t row = xp / a.p.parts, part = xp - row * a.p.parts;
+                const uint32_t row = a.p.dparts.div(xp), part = xp - row * a.p.parts;
                 const uint32_t rel = part >= a.part_lo ? part - a.part_lo
                                                        : part + a.p.parts - a.part_lo;
                 if (rel < a.part_n) {
-                    loc = row / a.p.slices;
+                    loc = a.p.dslices.div(row);
                     cell = part * a.p.slices + (row - loc * a.p.slices);
                     if (WRITE && a.hub_bits && ((a.hub_bits[x >> 5] >> (x & 31)) & 1u))
                         loc |= 1u << hub_shift;
@@ -518,12 +541,12 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractA
             g1 = p1 < Le && s_cell[p1] != kSentinel;
             if (p0 < Le) {
                 const uint32_t c = s_walk[p0];
-                o0 = c % a.p.world == a.p.rank &&
+                o0 = c - a.p.dworld.div(c) * a.p.world == a.p.rank &&
                      (!(a.p.flags & kFlagDownsample) || keep_centre_at(a.g, wkey, p0, c));
             }
             if (p1 < Le) {
                 const uint32_t c = s_walk[p1];
-                o1 = c % a.p.world == a.p.rank &&
+                o1 = c - a.p.dworld.div(c) * a.p.world == a.p.rank &&
                      (!(a.p.flags & kFlagDownsample) || keep_centre_at(a.g, wkey, p1, c));
             }
             in_group.lo = __ballot(g0);
@@ -540,7 +563,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractA
             if (n0 | n1) {
                 const uint32_t slices = a.p.slices;
                 auto gidx = [&](uint32_t cell) {
-                    const uint32_t part = cell / slices, sl = cell - part * slices;
+                    const uint32_t part = a.p.dslices.div(cell), sl = cell - part * slices;
                     const uint32_t rel = part >= a.part_lo ? part - a.part_lo
                                                            : part + a.p.parts - a.part_lo;
                     return rel * slices + sl;
@@ -593,7 +616,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractA
                                 s_pre[iu] + (uint32_t)(__popcll(wi.lo) + __popcll(wi.hi));
                             a.pairs[base + rank] =
                                 ((((unsigned long long)s_cell[j] << a.p.row_bits) |
-                                  (s_walk[iu] / a.p.world))
+                                  a.p.dworld.div(s_walk[iu]))
                                  << a.p.ctx_bits) |
                                 s_loc[j];
                         }

@@ -488,6 +488,12 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
 }  // namespace
 
 namespace gn2v_host {
+void release_kept_buffers(gn2v_graph *g) {
+    for (auto &b : g->kept_buffers) (void)hipFree(b.first);
+    g->kept_buffers.clear();
+    g->kept_bytes = 0;
+}
+
 // What the walks of `wp` need beyond the CSR (the second-order sampler's edge set), allocated and
 // built NOW: gn2v_train_blocks calls this before it sizes its rounds from the free memory, so
 // that the set's bytes (3.4 GB on the bench graph, 18 GB at 100 M nodes) are neither planned
@@ -714,6 +720,7 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->counters) (void)hipFree(g->counters);
     if (g->part_ptrs_dev) (void)hipFree(g->part_ptrs_dev);
     if (g->indeg) (void)hipFree(g->indeg);
+    release_kept_buffers(g);
     if (g->prep_stream) {
         (void)hipStreamDestroy(g->prep_stream);
         for (int i = 0; i < 2; ++i) {
@@ -1041,6 +1048,16 @@ int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t
         GN2V_TOUCH(16);
 #undef GN2V_TOUCH
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_graph_release_buffers(gn2v_graph *g) {
+    if (!g) return fail("graph handle is NULL");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g->mu);
+    release_kept_buffers(g);
     return 0;
 }
 

@@ -69,6 +69,9 @@ gn2v::BlockPlan device_plan(const gn2v_graph *g, const gn2v_block_plan *p) {
     d.ctx_bits = bits_for(gn2v::stripe_count(part_rows, 0, p->slices)) + 1;  // + the hot flag
     d.flags = p->flags & gn2v::kFlagDownsample;
     d.hot_rows = p->hot_rows;
+    d.dparts = gn2v::FastDiv::of(d.parts);
+    d.dslices = gn2v::FastDiv::of(d.slices);
+    d.dworld = gn2v::FastDiv::of(d.world);
     return d;
 }
 
@@ -206,24 +209,71 @@ bool slices_are_xcd_exclusive(const gn2v_graph *g, uint32_t slices) {
 }  // namespace
 
 namespace {
-// device buffers of one gn2v_train_blocks call, released on every exit path
+// Device buffers of one gn2v_train_blocks call, given back on every exit path -- to the graph
+// handle, which keeps them for its next fit (up to a third of the device's memory;
+// gn2v_graph_release_buffers or gn2v_graph_destroy frees them; GN2V_KEEP_BUFFERS=0: freed at
+// once).  A second fit on the same handle found its 65 GB of round buffers only after the driver
+// had cleared them again: 1.6-2.0 s of a 15 s call (profiles/r05_logs/r5_var.log).
 struct Buffers {
-    std::vector<void *> ptrs;
+    gn2v_graph *g;
+    std::vector<std::pair<void *, size_t>> ptrs;
+    explicit Buffers(gn2v_graph *graph) : g(graph) {}
     ~Buffers() {
-        for (void *p : ptrs) (void)hipFree(p);
+        while (!ptrs.empty()) release_last();
     }
     template <class T>
     int alloc(T **out, size_t bytes) {
         *out = nullptr;
+        bytes = bytes ? bytes : 4;
         void *p = nullptr;
-        if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail("out of device memory in gn2v_train_blocks (" + std::to_string(bytes >> 20) +
-                        " MiB)");
+        // the smallest kept block that holds it without wasting more than a quarter
+        size_t best = g->kept_buffers.size();
+        for (size_t i = 0; i < g->kept_buffers.size(); ++i) {
+            const size_t have = g->kept_buffers[i].second;
+            if (have >= bytes && have - bytes <= bytes / 4 &&
+                (best == g->kept_buffers.size() || have < g->kept_buffers[best].second))
+                best = i;
         }
-        ptrs.push_back(p);
+        size_t size = bytes;
+        if (best != g->kept_buffers.size()) {
+            p = g->kept_buffers[best].first;
+            size = g->kept_buffers[best].second;
+            g->kept_bytes -= size;
+            g->kept_buffers.erase(g->kept_buffers.begin() + (long)best);
+        } else if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            // what the handle still keeps may be exactly what is missing
+            if (!g->kept_buffers.empty()) {
+                gn2v_host::release_kept_buffers(g);
+                if (hipMalloc(&p, bytes) != hipSuccess) p = nullptr;
+            }
+            if (!p) {
+                (void)hipGetLastError();
+                return fail("out of device memory in gn2v_train_blocks (" +
+                            std::to_string(bytes >> 20) + " MiB)");
+            }
+        }
+        ptrs.push_back({p, size});
         *out = (T *)p;
         return 0;
+    }
+    // the most recent allocation goes back (to the handle, or to the driver)
+    void release_last() {
+        static const size_t keep = env_size("GN2V_KEEP_BUFFERS", 1);
+        const auto b = ptrs.back();
+        ptrs.pop_back();
+        size_t total = 0, free_b = 0;
+        if (keep && b.second >= ((size_t)1 << 20) && hipMemGetInfo(&free_b, &total) == hipSuccess &&
+            g->kept_bytes + b.second <= total / 3) {
+            g->kept_buffers.push_back(b);
+            g->kept_bytes += b.second;
+        } else {
+            (void)hipFree(b.first);
+        }
+    }
+    void free_last() {  // to the driver, whatever its size (room for another allocation)
+        (void)hipFree(ptrs.back().first);
+        ptrs.pop_back();
     }
 };
 }  // namespace
@@ -1312,7 +1362,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         walks_per_epoch = max_walks_per_epoch;
     const uint64_t pairs_per_walk = 2ull * w * L;  // upper bound (window untrimmed)
 
-    Buffers buf;
+    Buffers buf(g);
     // alias tables + the hot rows of every cell (flags for the extraction, slot tables)
     uint64_t *alias = nullptr, *cell_rows = nullptr;
     uint32_t *hub_bits = nullptr, *hot_list = nullptr;
@@ -1334,8 +1384,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
                                  alias_tmp, alias_tb, s))
                 return 1;
             HIP_TRY(hipStreamSynchronize(s));
-            (void)hipFree(alias_tmp);
-            buf.ptrs.pop_back();
+            buf.release_last();
             alias_tmp = nullptr;
         }
     }
@@ -1376,10 +1425,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         return kOutOfMemory;
     const size_t held = buf.ptrs.size();
     auto release_round = [&]() {
-        while (buf.ptrs.size() > held) {
-            (void)hipFree(buf.ptrs.back());
-            buf.ptrs.pop_back();
-        }
+        while (buf.ptrs.size() > held) buf.release_last();
     };
     for (;;) {
         // a group's share of the round's pairs by its parts, 1 / 8 of head room on the
@@ -1483,13 +1529,9 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
                 if (rc != GN2V_ROUND_GROW) return 1;
                 // a group heavier than the head room allows: grow (the driver has waited for
                 // whatever still trained from these buffers)
-                (void)hipFree(tmp);
-                (void)hipFree(pairs);
-                buf.ptrs.resize(buf.ptrs.size() - 2);
-                if (pairs2) {
-                    (void)hipFree(pairs2);
-                    buf.ptrs.pop_back();
-                }
+                buf.free_last();  // tmp
+                buf.free_last();  // pairs
+                if (pairs2) buf.free_last();
                 cap = rio.needed_pairs + rio.needed_pairs / 16;
                 gn2v_block_extract_temp_bytes(cap, &tb);
                 if ((pairs2 && buf.alloc(&pairs2, cap * 8)) || buf.alloc(&pairs, cap * 8) ||
@@ -1510,10 +1552,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     mark("round buffers released");
     if (part_major) {  // part-major -> natural order
         float *scratch = nullptr;
-        void *raw = nullptr;
-        if (!getenv("GN2V_BLOCK_RESTORE_ON_HOST") && hipMalloc(&raw, table_bytes) == hipSuccess) {
-            buf.ptrs.push_back(raw);
-            scratch = (float *)raw;
+        if (!getenv("GN2V_BLOCK_RESTORE_ON_HOST") && buf.alloc(&scratch, table_bytes) == 0) {
             HIP_TRY(hipMemcpyAsync(scratch, d_contextual, table_bytes, hipMemcpyDeviceToDevice, s));
             const unsigned blocks =
                 (unsigned)std::min<uint64_t>((n * (ld >> 2) + 255) / 256, 256 * 32);

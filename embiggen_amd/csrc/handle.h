@@ -5,6 +5,7 @@
 
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gn2v.h"
@@ -96,6 +97,9 @@ struct gn2v_graph {
     bool max_in_degree_known = false;
     uint32_t *indeg = nullptr;  // u32[n_nodes + 1] (the last word: their maximum), kept once computed
     bool indeg_failed = false;
+    // round buffers of the last block fit, kept for the next one (gn2v_block_api.hip Buffers)
+    std::vector<std::pair<void *, size_t>> kept_buffers;
+    size_t kept_bytes = 0;
     unsigned long long *counters = nullptr;  // device, 4 x u64
     unsigned long long *cursors = nullptr;   // device, ring of record-ticket arrays (block trainer)
     uint32_t cursor_slot = 0;
@@ -109,4 +113,5 @@ struct gn2v_graph {
 namespace gn2v_host {
 int get_events(gn2v_graph *g, EventPair *ev);
 int prepare_walk_sampler(gn2v_graph *g, const gn2v_walk_params *wp, hipStream_t s);
+void release_kept_buffers(gn2v_graph *g);
 }

@@ -208,6 +208,11 @@ class _WalkBasedModel:
                                     max_walks_per_epoch, central.data_ptr(),
                                     contextual.data_ptr(), C.byref(stats), stream))
             self.last_seconds = time.perf_counter() - start
+            # the library keeps the round buffers of a block fit (tens of GB) on the graph handle
+            # for the handle's next fit; a model gives them back unless told otherwise
+            # (model.keep_buffers = True: repeated fits on one graph skip 1.5-2 s of allocation)
+            if not getattr(self, "keep_buffers", False):
+                _lib.check(L.gn2v_graph_release_buffers(dgraph.handle))
         self.last_stats = stats.as_dict()
         self.last_plan = ({"world": 1, "parts": stats.block_parts, "slices": stats.block_slices,
                            "stripes": stats.block_stripes,

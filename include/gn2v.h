@@ -552,6 +552,14 @@ int gn2v_edge_embedding(const float *d_src_table, const float *d_dst_table, uint
 int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t n, uint32_t flags,
                     void *stream);
 
+/* A block fit (gn2v_train on graphs of >= GN2V_BLOCK_PATH_MIN_NODES nodes, gn2v_train_blocks)
+ * hands its round buffers -- walks, pair words, sort storage: tens of GB on large graphs -- back
+ * to the graph handle, which keeps up to a third of the device's memory for the handle's next
+ * fit (a second fit otherwise waits 1.5-2 s for the driver to clear the same 65 GB again).  This
+ * frees them now; gn2v_graph_destroy does too; GN2V_KEEP_BUFFERS=0 in the environment never
+ * keeps any.  The Python classes call it after every fit unless told to keep the buffers. */
+int gn2v_graph_release_buffers(gn2v_graph *g);
+
 /* counters accumulated on the handle by the step / walk entry points since the last reset */
 int gn2v_stats_reset(gn2v_graph *g, void *stream);
 int gn2v_stats_read(gn2v_graph *g, gn2v_stats *stats, void *stream); /* synchronises */
