@@ -794,7 +794,11 @@ def main():
                               f"{min(args.round_walks, args.steps * args.walks)} walks per GPU "
                               f"prepared {blocks_view.group_parts if blocks_view else 0} parts at a time"
                               + (f" trained in {stripes} centre stripes" if stripes > 1 else "")
-                              + f", preparation {'overlapped' if overlap and stripes == 1 else 'in line'}",
+                              + (", the next group prepared beside the training (second pair "
+                                 "buffer, own stream)"
+                                 if c_entry and os.environ.get("GN2V_BLOCK_OVERLAP", "1") != "0"
+                                 else f", preparation "
+                                      f"{'overlapped' if overlap and stripes == 1 else 'in line'}"),
                 }[mode],
             },
             "pairs_per_s": total_pairs / elapsed,

@@ -47,7 +47,7 @@ EXPORTS = [
     "gn2v_block_alias", "gn2v_block_placement_temp_bytes", "gn2v_block_placement",
     "gn2v_block_place_walks", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
     "gn2v_block_extract", "gn2v_block_step", "gn2v_block_round", "gn2v_block_auto_plan", "gn2v_block_auto_plan_graph", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
-    "gn2v_train_blocks", "gn2v_graph_release_buffers",
+    "gn2v_train_blocks", "gn2v_graph_release_buffers", "gn2v_graph_walk_accel",
     "gn2v_stats_reset",
     "gn2v_stats_read",
 ]
@@ -295,6 +295,7 @@ def lib():
     L.gn2v_train_blocks.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,
                                     u64, u32, vp, vp, C.POINTER(Stats), vp]
     L.gn2v_graph_release_buffers.argtypes = [vp]
+    L.gn2v_graph_walk_accel.argtypes = [vp]
     L.gn2v_stats_reset.argtypes = [vp, vp]
     L.gn2v_stats_read.argtypes = [vp, C.POINTER(Stats), vp]
     for name in EXPORTS + EXPERIMENTAL_EXPORTS:

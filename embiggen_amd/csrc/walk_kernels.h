@@ -44,6 +44,10 @@ struct GraphView {
     // once the binary searches are gone.
     const unsigned long long *edge_filter;
     uint64_t filter_mask;  // words - 1 (a power of two)
+    // Edge records (see walk_rec_kernel): per directed edge, the destination with its row and the
+    // signature of its neighbourhood; per node, that signature.  nullptr: not built.
+    const uint4 *edge_rec;
+    const uint32_t *node_sig;
 };
 
 constexpr unsigned long long kNoEdge = ~0ULL;
@@ -462,6 +466,254 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
     }
     if (counters) {
         // one atomic per wave
+        uint32_t s = steps;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) atomicAdd(&counters[1], (unsigned long long)s);
+    }
+}
+
+// ---- edge records -------------------------------------------------------------------------------
+// The CSR walk pays three dependent memory round trips per step: row_ptr[cur] (one 64 B sector for
+// 16 B), col_idx[start + i] (one sector for 4 B) and the adjacency test of the candidate against
+// the previous node (filter word, sometimes the set).  An edge record carries, beside the
+// destination x of edge e, everything the NEXT step needs to know about x:
+//   .x = x   .y = signature of N(x)   .z/.w = row start of x (40 bits) | degree of x (24 bits)
+// 16 B, four to a sector, so a step of an unweighted untyped walk reads ONE sector for the
+// candidate and already holds the row of the node it moves to.  The signature is a 32-bit Bloom
+// word of the node's out-neighbours (bit sig_slot(y) for every y in N(x)): "x adjacent to prev"
+// is answered "no" for certain from registers when prev's signature lacks x's bit -- the typical
+// case on a sparse graph -- and goes to the filter / set / binary search only otherwise.  An
+// accelerator only: every decision, hence every walk, is the same as on the CSR arrays.
+__device__ __forceinline__ uint32_t sig_slot(uint32_t x) { return (x * 0x9E3779B1u) >> 27; }
+
+constexpr uint64_t kRecMaxDegree = (1ULL << 24) - 1;
+constexpr uint64_t kRecMaxEdges = 1ULL << 40;
+
+// flag[0] |= 1 when a row is too long for a record
+static __global__ void node_sig_kernel(const uint64_t *__restrict__ row_ptr,
+                                       const uint32_t *__restrict__ col, uint64_t n_nodes,
+                                       uint32_t *__restrict__ sig, uint32_t *__restrict__ flag) {
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_nodes;
+         u += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lo = row_ptr[u], hi = row_ptr[u + 1];
+        if (hi - lo > kRecMaxDegree) atomicOr(flag, 1u);
+        uint32_t s = 0;
+        for (uint64_t e = lo; e < hi && s != 0xFFFFFFFFu; ++e) s |= 1u << sig_slot(col[e]);
+        sig[u] = s;
+    }
+}
+
+static __global__ void edge_rec_kernel(const uint64_t *__restrict__ row_ptr,
+                                       const uint32_t *__restrict__ col,
+                                       const uint32_t *__restrict__ sig, uint64_t n_edges,
+                                       uint4 *__restrict__ rec) {
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = col[e];
+        const uint64_t lo = row_ptr[x], deg = row_ptr[x + 1] - lo;
+        rec[e] = make_uint4(x, sig[x], (uint32_t)lo, (uint32_t)(lo >> 32) | (uint32_t)(deg << 8));
+    }
+}
+
+// what a walker knows about a node it stands on (or came from)
+struct NodeRow {
+    uint32_t id;
+    uint32_t sig;
+    uint64_t start;
+    uint32_t deg;
+};
+
+__device__ __forceinline__ NodeRow row_of_record(const uint4 r) {
+    return NodeRow{r.x, r.y, (uint64_t)r.z | ((uint64_t)(r.w & 0xFFu) << 32), r.w >> 8};
+}
+
+// is_common_neighbour with prev's signature in front
+__device__ __forceinline__ bool rec_maybe_common(const NodeRow &prev, uint32_t x) {
+    return (prev.sig >> sig_slot(x)) & 1u;
+}
+
+// The walk of walk_kernel<false> on an unweighted graph, candidate by candidate the same draws and
+// the same decisions, read from the edge records.
+static __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphView g, WalkConsts c,
+                                                              uint64_t ekey, uint64_t first_walk,
+                                                              uint64_t n_walks,
+                                                              uint32_t *__restrict__ out,
+                                                              unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t tile[kWalkBlock / 64][64][kTileSteps + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint64_t wave_base = ((uint64_t)blockIdx.x * kWalkBlock + (uint64_t)wave * 64);
+    if (wave_base >= n_walks) return;
+    const uint64_t b = wave_base + lane;
+    const bool live = b < n_walks;
+    const uint32_t L = c.walk_length;
+    const uint4 *__restrict__ rec = g.edge_rec;
+
+    uint64_t wkey = 0, ctr = 0;
+    NodeRow cur{kSentinel, 0, 0, 0}, prev{kSentinel, 0, 0, 0};
+    if (live) {
+        const uint64_t wid = first_walk + b;
+        const uint64_t si = wid % g.n_sources;
+        cur.id = g.sources ? g.sources[si] : (uint32_t)si;
+        cur.start = g.row_ptr[cur.id];
+        cur.deg = (uint32_t)(g.row_ptr[cur.id + 1] - cur.start);
+        cur.sig = g.node_sig[cur.id];
+        wkey = draw(ekey, wid);
+    }
+    bool dead = !live;
+    uint32_t steps = 0;
+
+    for (uint32_t t0 = 0; t0 < L; t0 += kTileSteps) {
+        const uint32_t tn = min((uint32_t)kTileSteps, L - t0);
+        for (uint32_t tt = 0; tt < tn; ++tt) {
+            const uint32_t t = t0 + tt;
+            uint32_t val = kSentinel;
+            if (t == 0) {
+                val = cur.id;
+            } else if (!dead) {
+                const uint64_t deg = cur.deg;
+                if (deg == 0) {
+                    dead = true;
+                } else {
+                    // the node moved to: a record, or prev itself (return apart)
+                    NodeRow nxt;
+                    bool back = false;  // the accepted candidate is prev, proposed on its own
+                    uint4 got = make_uint4(0, 0, 0, 0);
+                    const bool biased = prev.id != kSentinel && c.second_order;
+                    if (!biased || deg == 1) {
+                        const uint64_t r = draw(wkey, ctr++);
+                        got = rec[cur.start + (((r >> 32) * deg) >> 32)];
+                    } else if (c.apart) {
+                        // same trial sequence as walk_kernel's "return apart" branch
+                        bool accepted = false;
+                        uint32_t trial = 0;
+                        const uint64_t z = c.rq + deg * c.mq;
+                        bool direct = mulhi64(draw(wkey, ctr), z) < c.rq;
+                        uint64_t r2 = direct ? 0 : draw(wkey, ctr + 1);
+                        uint4 x = make_uint4(0, 0, 0, 0);
+                        if (!direct) x = rec[cur.start + (((r2 >> 32) * deg) >> 32)];
+                        while (trial < c.max_trials) {
+                            const uint64_t used = direct ? 1 : 2;
+                            const bool n_direct = mulhi64(draw(wkey, ctr + used), z) < c.rq;
+                            const uint64_t n_r2 = n_direct ? 0 : draw(wkey, ctr + used + 1);
+                            uint4 n_x = make_uint4(0, 0, 0, 0);
+                            if (!n_direct && trial + 1 < c.max_trials)
+                                n_x = rec[cur.start + (((n_r2 >> 32) * deg) >> 32)];
+                            ++trial;
+                            ctr += used;
+                            if (direct) {
+                                // prev is a neighbour of cur on a symmetric graph; otherwise look
+                                // for the edge cur -> prev in the row
+                                if (g.symmetric ||
+                                    adj_contains(g.col_idx, cur.start, cur.start + deg, prev.id)) {
+                                    accepted = true;
+                                    back = true;
+                                }
+                            } else if (x.x != prev.id) {
+                                const uint64_t r32 = r2 & 0xFFFFFFFFULL;
+                                if (r32 < c.s_min)
+                                    accepted = true;
+                                else if (r32 < c.s_max)
+                                    accepted =
+                                        r32 < ((rec_maybe_common(prev, x.x) &&
+                                                is_common_neighbour(g, x.x, prev.id, prev.start,
+                                                                    prev.start + prev.deg))
+                                                   ? c.s_common
+                                                   : c.s_explore);
+                                if (accepted) got = x;
+                            }
+                            if (accepted) break;
+                            direct = n_direct;
+                            r2 = n_r2;
+                            x = n_x;
+                        }
+                        if (!accepted) {
+                            const uint64_t r = draw(wkey, ctr++);
+                            got = rec[cur.start +
+                                      exact_scan<false>(g, c, r, cur.id, cur.start, deg, prev.id,
+                                                        prev.start, prev.start + prev.deg, 0)];
+                        }
+                    } else {
+                        // one envelope for all classes: a candidate whose bit is missing from
+                        // prev's signature is of class "other" for certain and is decided at
+                        // once; the exact test runs only for the rest, in lock step (phase B)
+                        bool accepted = false;
+                        uint32_t trial = 0;
+                        while (trial < c.max_trials) {
+                            uint64_t r32 = 0;
+                            uint4 x = make_uint4(0, 0, 0, 0);
+                            bool pending = false;
+                            while (trial < c.max_trials) {
+                                const uint64_t r = draw(wkey, ctr++);
+                                x = rec[cur.start + (((r >> 32) * deg) >> 32)];
+                                ++trial;
+                                r32 = r & 0xFFFFFFFFULL;
+                                if (x.x == prev.id) {
+                                    if (r32 < c.t_ret) {
+                                        accepted = true;
+                                        break;
+                                    }
+                                    continue;
+                                }
+                                if (r32 < c.t_min) {
+                                    accepted = true;
+                                    break;
+                                }
+                                if (r32 >= c.t_max) continue;
+                                if (!rec_maybe_common(prev, x.x)) {
+                                    if (r32 < c.t_explore) {
+                                        accepted = true;
+                                        break;
+                                    }
+                                    continue;
+                                }
+                                pending = true;
+                                break;
+                            }
+                            if (pending)
+                                accepted = r32 < (is_common_neighbour(g, x.x, prev.id, prev.start,
+                                                                      prev.start + prev.deg)
+                                                      ? c.t_common
+                                                      : c.t_explore);
+                            if (accepted) {
+                                got = x;
+                                break;
+                            }
+                            if (!pending) break;  // trials exhausted
+                        }
+                        if (!accepted) {
+                            const uint64_t r = draw(wkey, ctr++);
+                            got = rec[cur.start +
+                                      exact_scan<false>(g, c, r, cur.id, cur.start, deg, prev.id,
+                                                        prev.start, prev.start + prev.deg, 0)];
+                        }
+                    }
+                    nxt = back ? prev : row_of_record(got);
+                    val = nxt.id;
+                    prev = cur;
+                    cur = nxt;
+                    ++steps;
+                }
+            }
+            tile[wave][lane][tt] = val;
+        }
+        // flush: 64 walks x tn steps; lane -> (walk = lane/4 + 16*pass, 4-step quarter = lane%4)
+        __builtin_amdgcn_wave_barrier();
+        for (int pass = 0; pass < 4; ++pass) {
+            const int wrow = (lane >> 2) + 16 * pass;
+            const uint64_t wb = wave_base + wrow;
+            const int q = lane & 3;
+            if (wb < n_walks) {
+                uint32_t *dst = out + wb * L + t0 + q * 4;
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t tt = q * 4 + e;
+                    if (tt < tn) dst[e] = tile[wave][wrow][tt];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (counters) {
         uint32_t s = steps;
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
         if (lane == 0) atomicAdd(&counters[1], (unsigned long long)s);

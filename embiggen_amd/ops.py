@@ -55,6 +55,18 @@ def walks(graph: CSRGraph, wp, seed: int, epoch: int, first_walk: int, n_walks: 
     return out
 
 
+WALK_ACCEL_EDGE_SET, WALK_ACCEL_FILTER, WALK_ACCEL_RECORDS = 1, 2, 4
+
+
+def walk_accel(graph: CSRGraph, device: int = 0) -> int:
+    """Bit set of the sampler's accelerators the handle holds now (gn2v_graph_walk_accel): edge
+    set, its filter, edge records.  They never change a walk."""
+    rc = _lib.lib().gn2v_graph_walk_accel(graph.device_graph(device).handle)
+    if rc < 0:
+        _lib.check(1)
+    return rc
+
+
 def window_batch(walks_tensor, window: int):
     """(contexts int32 [n, 2w], words int32 [n]) for every full-window walk position."""
     torch = _torch()

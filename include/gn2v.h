@@ -560,6 +560,15 @@ int gn2v_touch_rows(float *d_table, uint32_t ld, const uint32_t *d_ids, uint64_t
  * keeps any.  The Python classes call it after every fit unless told to keep the buffers. */
 int gn2v_graph_release_buffers(gn2v_graph *g);
 
+/* Which accelerators of the walk sampler the handle holds right now (they are built on the first
+ * walk that can use them and when memory allows; the walks are the same with or without them):
+ * bit 0 the hashed edge set, bit 1 the filter in front of it, bit 2 the edge records
+ * (csrc/walk_kernels.h).  Negative on a NULL handle. */
+#define GN2V_WALK_ACCEL_EDGE_SET 1
+#define GN2V_WALK_ACCEL_FILTER 2
+#define GN2V_WALK_ACCEL_RECORDS 4
+int gn2v_graph_walk_accel(gn2v_graph *g);
+
 /* counters accumulated on the handle by the step / walk entry points since the last reset */
 int gn2v_stats_reset(gn2v_graph *g, void *stream);
 int gn2v_stats_read(gn2v_graph *g, gn2v_stats *stats, void *stream); /* synchronises */

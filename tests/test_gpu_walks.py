@@ -57,16 +57,48 @@ def test_edge_set_and_filter_only_accelerate_the_adjacency_test(monkeypatch, rw,
     s, d = O.ba_edges(5000, 4, 11)
     owp = O.WalkParams(40, 2, rw, ew, 100, 0)
     ref = None
-    for env in ({}, {"GN2V_WALK_EDGE_FILTER": "0"}, {"GN2V_WALK_EDGE_SET": "0"}):
-        for k in ("GN2V_WALK_EDGE_FILTER", "GN2V_WALK_EDGE_SET"):
+    for env, accel in (({}, 7), ({"GN2V_WALK_EDGE_FILTER": "0"}, 5),
+                       ({"GN2V_WALK_EDGE_SET": "0"}, 4), ({"GN2V_WALK_EDGE_RECORDS": "0"}, 3),
+                       ({"GN2V_WALK_EDGE_RECORDS": "0", "GN2V_WALK_EDGE_SET": "0"}, 0)):
+        for k in ("GN2V_WALK_EDGE_FILTER", "GN2V_WALK_EDGE_SET", "GN2V_WALK_EDGE_RECORDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=5000)  # a handle of its own
         got = _u32(ops.walks(g, ops.walk_params(40, 2, rw, ew), 7, 1, 0, 10_000))
+        assert ops.walk_accel(g) == accel, env
         if ref is None:
             ref = O.walks(O.OracleGraph(g.row_ptr, g.col_idx), owp, 7, 1, 0, 10_000)
         assert np.array_equal(got, ref), env
+
+
+@pytest.mark.parametrize("directed", [False, True])
+@pytest.mark.parametrize("rw,ew", [(1.0, 1.0), (0.25, 4.0), (2.0, 0.5), (4.0, 0.25), (1e-3, 1e-3)])
+def test_edge_records_only_accelerate_the_reads(monkeypatch, rw, ew, directed):
+    """An unweighted walk without type factors reads one 16 B edge record per candidate
+    (destination, its row, the signature of its neighbourhood) instead of row_ptr + col_idx + the
+    adjacency probe (walk_kernels.h walk_rec_kernel): the same walks with the records switched
+    off and in the oracle -- on a symmetric graph (prev is a neighbour for certain when it is
+    proposed on its own) and on a directed one with traps (it is looked up), hubs whose signature
+    is full, first and second order, both envelopes."""
+    rng = np.random.RandomState(5)
+    if directed:
+        src, dst = rng.randint(0, 2000, size=12_000), rng.randint(0, 2000, size=12_000)
+        make = lambda: E.CSRGraph.from_edge_list(src, dst, number_of_nodes=2100, directed=True)
+    else:
+        s, d = O.ba_edges(4000, 6, 3)
+        make = lambda: E.CSRGraph.from_edge_list(s, d, number_of_nodes=4000)
+    owp = O.WalkParams(48, 2, rw, ew, 100, 0)
+    walks = {}
+    for records in ("1", "0"):
+        monkeypatch.setenv("GN2V_WALK_EDGE_RECORDS", records)
+        g = make()
+        n = 2 * g.get_number_of_unique_source_nodes() + 37
+        walks[records] = _u32(ops.walks(g, ops.walk_params(48, 2, rw, ew), 11, 2, 5, n))
+        assert bool(ops.walk_accel(g) & ops.WALK_ACCEL_RECORDS) == (records == "1")
+    assert np.array_equal(walks["1"], walks["0"])
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    assert np.array_equal(walks["1"], O.walks(og, owp, 11, 2, 5, n, sources=g.sources))
 
 
 def test_weighted_walks_bit_exact():
