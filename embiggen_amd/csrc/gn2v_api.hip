@@ -206,61 +206,84 @@ int ensure_edge_set(gn2v_graph *g, hipStream_t s) {
     return 0;
 }
 
-// The edge records of the walk sampler (walk_kernels.h): 16 B per directed edge + 4 B per node --
-// 3.2 GB for the 10 M / 100 M bench graph.  Built once per handle, on the first unweighted untyped
-// walk, when they fit an eighth of the free memory (a fit of a 100 M-node graph keeps that memory
-// for its tables and pair buffers: the walks are 1 % of its time); GN2V_WALK_EDGE_RECORDS=0 keeps
-// the CSR reads (same walks either way).
-int ensure_edge_records(gn2v_graph *g, hipStream_t s) {
-    if (g->edge_rec_tried) return 0;
+// The edge records of the walk sampler (walk_kernels.h): 16 B per directed edge (32 B in the typed
+// form, for walks with type factors) + 4 B per node -- 3.2 GB (6.4 GB) for the 10 M / 100 M bench
+// graph.  Each form is built once per handle, on the first unweighted walk that reads it, when it
+// fits an eighth of the free memory (a fit of a 100 M-node graph keeps that memory for its tables
+// and pair buffers: the walks are 1 % of its time); GN2V_WALK_EDGE_RECORDS=0 keeps the CSR reads
+// (same walks either way).
+int ensure_edge_records(gn2v_graph *g, hipStream_t s, bool typed) {
+    bool &tried = typed ? g->edge_rec_typed_tried : g->edge_rec_tried;
+    if (tried) return 0;
     const char *env = getenv("GN2V_WALK_EDGE_RECORDS");
     const uint64_t E = g->view.n_edges, N = g->view.n_nodes;
     if ((env && *env == '0') || E == 0 || E >= gn2v::kRecMaxEdges || N >= 0xFFFFFFFFULL ||
         g->view.cumw != nullptr) {
-        g->edge_rec_tried = true;  // never for this handle
+        tried = true;  // never for this handle
         return 0;
     }
+    const size_t rec_bytes = (size_t)E * (typed ? 32 : 16);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || E * 16 + N * 4 > free_b / 8) {
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+        rec_bytes + (g->node_sig ? 0 : (N + 1) * 4) > free_b / 8) {
         (void)hipGetLastError();
         return 0;  // a later call, with more memory free, tries again
     }
     uint4 *rec = nullptr;
-    uint32_t *sig = nullptr;  // u32[N] signatures, then one flag word
-    if (hipMalloc((void **)&sig, (N + 1) * 4) != hipSuccess ||
-        hipMalloc((void **)&rec, E * 16) != hipSuccess) {
+    uint32_t *sig = g->node_sig;  // u32[N] signatures, then one flag word
+    const bool own_sig = sig == nullptr;
+    if ((own_sig && hipMalloc((void **)&sig, (N + 1) * 4) != hipSuccess) ||
+        hipMalloc((void **)&rec, rec_bytes) != hipSuccess) {
         (void)hipGetLastError();
-        if (sig) (void)hipFree(sig);
+        if (own_sig && sig) (void)hipFree(sig);
         return 0;
     }
     // complete before it is published, as the edge set is
     uint32_t flag = 0;
-    hipError_t e = hipMemsetAsync(sig + N, 0, 4, s);
-    if (e == hipSuccess) {
-        const unsigned nb = (unsigned)std::min<uint64_t>((N + 255) / 256, 1u << 20);
-        hipLaunchKernelGGL(gn2v::node_sig_kernel, dim3(nb), dim3(256), 0, s, g->view.row_ptr,
-                           g->view.col_idx, N, sig, sig + N);
-        const unsigned eb = (unsigned)std::min<uint64_t>((E + 255) / 256, 1u << 20);
-        hipLaunchKernelGGL(gn2v::edge_rec_kernel, dim3(eb), dim3(256), 0, s, g->view.row_ptr,
-                           g->view.col_idx, sig, E, rec);
-        e = hipGetLastError();
+    hipError_t e = hipSuccess;
+    if (own_sig) {
+        e = hipMemsetAsync(sig + N, 0, 4, s);
+        if (e == hipSuccess) {
+            const unsigned nb = (unsigned)std::min<uint64_t>((N + 255) / 256, 1u << 20);
+            hipLaunchKernelGGL(gn2v::node_sig_kernel, dim3(nb), dim3(256), 0, s, g->view.row_ptr,
+                               g->view.col_idx, N, sig, sig + N);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&flag, sig + N, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&flag, sig + N, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && !flag) {
+        const unsigned eb = (unsigned)std::min<uint64_t>((E + 255) / 256, 1u << 20);
+        if (typed)
+            hipLaunchKernelGGL(gn2v::edge_rec_typed_kernel, dim3(eb), dim3(256), 0, s,
+                               g->view.row_ptr, g->view.col_idx, sig, g->view.node_types,
+                               g->view.edge_types, E, rec);
+        else
+            hipLaunchKernelGGL(gn2v::edge_rec_kernel, dim3(eb), dim3(256), 0, s, g->view.row_ptr,
+                               g->view.col_idx, sig, E, rec);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
     if (e != hipSuccess || flag) {
         (void)hipFree(rec);
-        (void)hipFree(sig);
+        if (own_sig) (void)hipFree(sig);
         if (e != hipSuccess)
             return fail(std::string("building the edge records of the walk sampler: ") +
                         hipGetErrorString(e));
-        g->edge_rec_tried = true;  // a row longer than a record can say
+        // a row longer than a record can say: neither form, ever
+        g->edge_rec_tried = g->edge_rec_typed_tried = true;
         return 0;
     }
-    g->edge_rec_tried = true;
-    g->edge_rec = rec;
+    tried = true;
     g->node_sig = sig;
-    g->view.edge_rec = rec;
     g->view.node_sig = sig;
+    if (typed) {
+        g->edge_rec_typed = rec;
+        g->view.edge_rec_typed = rec;
+    } else {
+        g->edge_rec = rec;
+        g->view.edge_rec = rec;
+    }
     return 0;
 }
 
@@ -272,7 +295,7 @@ int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint6
     {
         std::lock_guard<std::mutex> lock(g->mu);
         if (c.second_order && ensure_edge_set(g, s)) return 1;
-        if (!typed && ensure_edge_records(g, s)) return 1;
+        if (ensure_edge_records(g, s, typed)) return 1;
     }
     const uint64_t blocks = (n_walks + gn2v::kWalkBlock - 1) / gn2v::kWalkBlock;
     if (blocks > 0x7FFFFFFFULL) return fail("too many walks in one launch");
@@ -280,12 +303,16 @@ int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint6
     EventPair ev;
     if (get_events(g, &ev)) return 1;
     HIP_TRY(hipEventRecord(ev.a, s));
-    if (typed)
+    if (typed && g->view.edge_rec_typed)
+        hipLaunchKernelGGL(gn2v::walk_rec_kernel<true>, dim3((unsigned)blocks),
+                           dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
+                           first_walk, n_walks, d_out, g->counters);
+    else if (typed)
         hipLaunchKernelGGL(gn2v::walk_kernel<true>, dim3((unsigned)blocks),
                            dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
                            first_walk, n_walks, d_out, g->counters);
     else if (g->view.edge_rec)
-        hipLaunchKernelGGL(gn2v::walk_rec_kernel, dim3((unsigned)blocks),
+        hipLaunchKernelGGL(gn2v::walk_rec_kernel<false>, dim3((unsigned)blocks),
                            dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
                            first_walk, n_walks, d_out, g->counters);
     else
@@ -567,7 +594,7 @@ int prepare_walk_sampler(gn2v_graph *g, const gn2v_walk_params *wp, hipStream_t 
     const gn2v::WalkConsts c = walk_consts(g, wp);
     std::lock_guard<std::mutex> lock(g->mu);
     if (c.second_order && ensure_edge_set(g, s)) return 1;
-    if (!c.node_bias && !c.edge_bias && ensure_edge_records(g, s)) return 1;
+    if (ensure_edge_records(g, s, c.node_bias || c.edge_bias)) return 1;
     return 0;
 }
 }  // namespace gn2v_host
@@ -744,6 +771,11 @@ int gn2v_graph_set_types(gn2v_graph *g, const uint32_t *node_types,
     std::lock_guard<std::mutex> lock(g->mu);
     // walks already queued may still read the old arrays
     HIP_TRY(hipDeviceSynchronize());
+    // the typed edge records carry the old types: the next typed walk builds them again
+    if (g->edge_rec_typed) (void)hipFree(g->edge_rec_typed);
+    g->edge_rec_typed = nullptr;
+    g->view.edge_rec_typed = nullptr;
+    g->edge_rec_typed_tried = false;
     if (!g->owns) {
         g->view.node_types = node_types;
         g->view.edge_types = edge_types;
@@ -798,6 +830,7 @@ int gn2v_graph_destroy(gn2v_graph *g) {
     if (g->edge_set) (void)hipFree(g->edge_set);
     if (g->edge_filter) (void)hipFree(g->edge_filter);
     if (g->edge_rec) (void)hipFree(g->edge_rec);
+    if (g->edge_rec_typed) (void)hipFree(g->edge_rec_typed);
     if (g->node_sig) (void)hipFree(g->node_sig);
     if (g->train_stream) (void)hipStreamDestroy(g->train_stream);
     if (g->ts_in) (void)hipEventDestroy(g->ts_in);
@@ -1134,7 +1167,8 @@ int gn2v_graph_walk_accel(gn2v_graph *g) {
     std::lock_guard<std::mutex> lock(g->mu);
     return (g->edge_set ? GN2V_WALK_ACCEL_EDGE_SET : 0) |
            (g->edge_filter ? GN2V_WALK_ACCEL_FILTER : 0) |
-           (g->edge_rec ? GN2V_WALK_ACCEL_RECORDS : 0);
+           (g->edge_rec ? GN2V_WALK_ACCEL_RECORDS : 0) |
+           (g->edge_rec_typed ? GN2V_WALK_ACCEL_TYPED_RECORDS : 0);
 }
 
 int gn2v_stats_reset(gn2v_graph *g, void *stream) {

@@ -86,9 +86,9 @@ struct gn2v_graph {
     unsigned long long *edge_set = nullptr, *edge_filter = nullptr;
     bool edge_set_tried = false;
     // the sampler's edge records (GraphView.edge_rec / node_sig), built on the first unweighted walk
-    uint4 *edge_rec = nullptr;
+    uint4 *edge_rec = nullptr, *edge_rec_typed = nullptr;
     uint32_t *node_sig = nullptr;
-    bool edge_rec_tried = false;
+    bool edge_rec_tried = false, edge_rec_typed_tried = false;
     // gn2v_block_round with two sets of pair buffers: the preparation's own stream and the
     // events that order it against the training (created on first use)
     hipStream_t prep_stream = nullptr;

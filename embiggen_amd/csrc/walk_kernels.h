@@ -48,6 +48,7 @@ struct GraphView {
     // signature of its neighbourhood; per node, that signature.  nullptr: not built.
     const uint4 *edge_rec;
     const uint32_t *node_sig;
+    const uint4 *edge_rec_typed;  // two uint4 per edge: the record, then (node type, edge type)
 };
 
 constexpr unsigned long long kNoEdge = ~0ULL;
@@ -532,13 +533,55 @@ __device__ __forceinline__ bool rec_maybe_common(const NodeRow &prev, uint32_t x
     return (prev.sig >> sig_slot(x)) & 1u;
 }
 
-// The walk of walk_kernel<false> on an unweighted graph, candidate by candidate the same draws and
+// The typed form of a record, 32 B (two to a sector): the 16 B above, then the node type of x and
+// the type of edge e -- the two reads a type factor costs per candidate on the CSR arrays.
+static __global__ void edge_rec_typed_kernel(const uint64_t *__restrict__ row_ptr,
+                                             const uint32_t *__restrict__ col,
+                                             const uint32_t *__restrict__ sig,
+                                             const uint32_t *__restrict__ node_types,
+                                             const uint32_t *__restrict__ edge_types,
+                                             uint64_t n_edges, uint4 *__restrict__ rec) {
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = col[e];
+        const uint64_t lo = row_ptr[x], deg = row_ptr[x + 1] - lo;
+        rec[2 * e] = make_uint4(x, sig[x], (uint32_t)lo, (uint32_t)(lo >> 32) | (uint32_t)(deg << 8));
+        rec[2 * e + 1] =
+            make_uint4(node_types ? node_types[x] : 0u, edge_types ? edge_types[e] : 0u, 0u, 0u);
+    }
+}
+
+// a candidate: the record of edge cur -> x (TYPED: with the types of x and of the edge)
+template <bool TYPED>
+struct Candidate {
+    uint4 a;
+    uint32_t ntype, etype;
+};
+
+template <bool TYPED>
+__device__ __forceinline__ Candidate<TYPED> fetch_candidate(const uint4 *__restrict__ rec,
+                                                            uint64_t e) {
+    Candidate<TYPED> k;
+    if constexpr (TYPED) {
+        k.a = rec[2 * e];
+        const uint2 ty = *reinterpret_cast<const uint2 *>(rec + 2 * e + 1);
+        k.ntype = ty.x;
+        k.etype = ty.y;
+    } else {
+        k.a = rec[e];
+        k.ntype = k.etype = 0;
+    }
+    return k;
+}
+
+// The walk of walk_kernel<TYPED> on an unweighted graph, candidate by candidate the same draws and
 // the same decisions, read from the edge records.
-static __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphView g, WalkConsts c,
-                                                              uint64_t ekey, uint64_t first_walk,
-                                                              uint64_t n_walks,
-                                                              uint32_t *__restrict__ out,
-                                                              unsigned long long *__restrict__ counters) {
+template <bool TYPED>
+__global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphView g, WalkConsts c,
+                                                                 uint64_t ekey, uint64_t first_walk,
+                                                                 uint64_t n_walks,
+                                                                 uint32_t *__restrict__ out,
+                                                                 unsigned long long *__restrict__ counters) {
     __shared__ uint32_t tile[kWalkBlock / 64][64][kTileSteps + 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -547,10 +590,11 @@ static __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphVie
     const uint64_t b = wave_base + lane;
     const bool live = b < n_walks;
     const uint32_t L = c.walk_length;
-    const uint4 *__restrict__ rec = g.edge_rec;
+    const uint4 *__restrict__ rec = TYPED ? g.edge_rec_typed : g.edge_rec;
 
     uint64_t wkey = 0, ctr = 0;
     NodeRow cur{kSentinel, 0, 0, 0}, prev{kSentinel, 0, 0, 0};
+    uint32_t cur_ntype = 0, ptype = 0;  // TYPED: node type of cur, type of the edge that led to it
     if (live) {
         const uint64_t wid = first_walk + b;
         const uint64_t si = wid % g.n_sources;
@@ -558,6 +602,8 @@ static __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphVie
         cur.start = g.row_ptr[cur.id];
         cur.deg = (uint32_t)(g.row_ptr[cur.id + 1] - cur.start);
         cur.sig = g.node_sig[cur.id];
+        if constexpr (TYPED)
+            if (g.node_types) cur_ntype = g.node_types[cur.id];
         wkey = draw(ekey, wid);
     }
     bool dead = !live;
@@ -575,30 +621,33 @@ static __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphVie
                 if (deg == 0) {
                     dead = true;
                 } else {
-                    // the node moved to: a record, or prev itself (return apart)
-                    NodeRow nxt;
                     bool back = false;  // the accepted candidate is prev, proposed on its own
-                    uint4 got = make_uint4(0, 0, 0, 0);
-                    const bool biased = prev.id != kSentinel && c.second_order;
+                    Candidate<TYPED> got{};
+                    const bool walked = prev.id != kSentinel;
+                    const bool second = c.second_order && walked;
+                    const bool biased = (TYPED && c.node_bias) || second ||
+                                        (TYPED && c.edge_bias && walked);
                     if (!biased || deg == 1) {
                         const uint64_t r = draw(wkey, ctr++);
-                        got = rec[cur.start + (((r >> 32) * deg) >> 32)];
-                    } else if (c.apart) {
+                        got = fetch_candidate<TYPED>(rec, cur.start + (((r >> 32) * deg) >> 32));
+                    } else if (!TYPED && c.apart) {
                         // same trial sequence as walk_kernel's "return apart" branch
                         bool accepted = false;
                         uint32_t trial = 0;
                         const uint64_t z = c.rq + deg * c.mq;
                         bool direct = mulhi64(draw(wkey, ctr), z) < c.rq;
                         uint64_t r2 = direct ? 0 : draw(wkey, ctr + 1);
-                        uint4 x = make_uint4(0, 0, 0, 0);
-                        if (!direct) x = rec[cur.start + (((r2 >> 32) * deg) >> 32)];
+                        Candidate<TYPED> x{};
+                        if (!direct)
+                            x = fetch_candidate<TYPED>(rec, cur.start + (((r2 >> 32) * deg) >> 32));
                         while (trial < c.max_trials) {
                             const uint64_t used = direct ? 1 : 2;
                             const bool n_direct = mulhi64(draw(wkey, ctr + used), z) < c.rq;
                             const uint64_t n_r2 = n_direct ? 0 : draw(wkey, ctr + used + 1);
-                            uint4 n_x = make_uint4(0, 0, 0, 0);
+                            Candidate<TYPED> n_x{};
                             if (!n_direct && trial + 1 < c.max_trials)
-                                n_x = rec[cur.start + (((n_r2 >> 32) * deg) >> 32)];
+                                n_x = fetch_candidate<TYPED>(
+                                    rec, cur.start + (((n_r2 >> 32) * deg) >> 32));
                             ++trial;
                             ctr += used;
                             if (direct) {
@@ -609,14 +658,14 @@ static __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphVie
                                     accepted = true;
                                     back = true;
                                 }
-                            } else if (x.x != prev.id) {
+                            } else if (x.a.x != prev.id) {
                                 const uint64_t r32 = r2 & 0xFFFFFFFFULL;
                                 if (r32 < c.s_min)
                                     accepted = true;
                                 else if (r32 < c.s_max)
                                     accepted =
-                                        r32 < ((rec_maybe_common(prev, x.x) &&
-                                                is_common_neighbour(g, x.x, prev.id, prev.start,
+                                        r32 < ((rec_maybe_common(prev, x.a.x) &&
+                                                is_common_neighbour(g, x.a.x, prev.id, prev.start,
                                                                     prev.start + prev.deg))
                                                    ? c.s_common
                                                    : c.s_explore);
@@ -629,52 +678,72 @@ static __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphVie
                         }
                         if (!accepted) {
                             const uint64_t r = draw(wkey, ctr++);
-                            got = rec[cur.start +
-                                      exact_scan<false>(g, c, r, cur.id, cur.start, deg, prev.id,
-                                                        prev.start, prev.start + prev.deg, 0)];
+                            got = fetch_candidate<TYPED>(
+                                rec, cur.start + exact_scan<TYPED>(g, c, r, cur.id, cur.start, deg,
+                                                                   prev.id, prev.start,
+                                                                   prev.start + prev.deg, ptype));
                         }
                     } else {
-                        // one envelope for all classes: a candidate whose bit is missing from
-                        // prev's signature is of class "other" for certain and is decided at
-                        // once; the exact test runs only for the rest, in lock step (phase B)
+                        // One envelope for all classes (walk_kernel's two phases).  A candidate
+                        // whose bit is missing from prev's signature is of class "other" for
+                        // certain: its bounds meet and it is decided at once; the exact test runs
+                        // only for the rest, in lock step (phase B).
                         bool accepted = false;
                         uint32_t trial = 0;
                         while (trial < c.max_trials) {
-                            uint64_t r32 = 0;
-                            uint4 x = make_uint4(0, 0, 0, 0);
+                            uint64_t r32 = 0, fac_n = 1ULL << 32, fac_e = 1ULL << 32;
+                            Candidate<TYPED> x{};
                             bool pending = false;
                             while (trial < c.max_trials) {
                                 const uint64_t r = draw(wkey, ctr++);
-                                x = rec[cur.start + (((r >> 32) * deg) >> 32)];
+                                x = fetch_candidate<TYPED>(rec,
+                                                           cur.start + (((r >> 32) * deg) >> 32));
                                 ++trial;
                                 r32 = r & 0xFFFFFFFFULL;
-                                if (x.x == prev.id) {
-                                    if (r32 < c.t_ret) {
-                                        accepted = true;
-                                        break;
+                                uint64_t lo = 1ULL << 32, hi = 1ULL << 32;
+                                if (second) {
+                                    if (x.a.x == prev.id) {
+                                        lo = hi = c.t_ret;
+                                    } else if (!rec_maybe_common(prev, x.a.x)) {
+                                        lo = hi = c.t_explore;
+                                    } else {
+                                        lo = c.t_min;
+                                        hi = c.t_max;
                                     }
-                                    continue;
                                 }
-                                if (r32 < c.t_min) {
+                                if constexpr (TYPED) {
+                                    if (c.node_bias) {
+                                        fac_n = cur_ntype != x.ntype ? c.fn_diff : c.fn_same;
+                                        lo = scale32(lo, fac_n);
+                                        hi = scale32(hi, fac_n);
+                                    }
+                                    if (c.edge_bias && walked) {
+                                        fac_e = x.etype != ptype ? c.fe_diff : c.fe_same;
+                                        lo = scale32(lo, fac_e);
+                                        hi = scale32(hi, fac_e);
+                                    }
+                                }
+                                if (r32 < lo) {
                                     accepted = true;
                                     break;
                                 }
-                                if (r32 >= c.t_max) continue;
-                                if (!rec_maybe_common(prev, x.x)) {
-                                    if (r32 < c.t_explore) {
-                                        accepted = true;
-                                        break;
-                                    }
-                                    continue;
+                                if (r32 < hi) {
+                                    pending = true;
+                                    break;
                                 }
-                                pending = true;
-                                break;
                             }
-                            if (pending)
-                                accepted = r32 < (is_common_neighbour(g, x.x, prev.id, prev.start,
-                                                                      prev.start + prev.deg)
-                                                      ? c.t_common
-                                                      : c.t_explore);
+                            if (pending) {
+                                // x is not prev here (its bounds meet)
+                                uint64_t thr = is_common_neighbour(g, x.a.x, prev.id, prev.start,
+                                                                   prev.start + prev.deg)
+                                                   ? c.t_common
+                                                   : c.t_explore;
+                                if constexpr (TYPED) {
+                                    if (c.node_bias) thr = scale32(thr, fac_n);
+                                    if (c.edge_bias && walked) thr = scale32(thr, fac_e);
+                                }
+                                accepted = r32 < thr;
+                            }
                             if (accepted) {
                                 got = x;
                                 break;
@@ -683,12 +752,17 @@ static __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphVie
                         }
                         if (!accepted) {
                             const uint64_t r = draw(wkey, ctr++);
-                            got = rec[cur.start +
-                                      exact_scan<false>(g, c, r, cur.id, cur.start, deg, prev.id,
-                                                        prev.start, prev.start + prev.deg, 0)];
+                            got = fetch_candidate<TYPED>(
+                                rec, cur.start + exact_scan<TYPED>(g, c, r, cur.id, cur.start, deg,
+                                                                   prev.id, prev.start,
+                                                                   prev.start + prev.deg, ptype));
                         }
                     }
-                    nxt = back ? prev : row_of_record(got);
+                    const NodeRow nxt = back ? prev : row_of_record(got.a);
+                    if constexpr (TYPED) {
+                        cur_ntype = got.ntype;
+                        ptype = got.etype;
+                    }
                     val = nxt.id;
                     prev = cur;
                     cur = nxt;

@@ -55,7 +55,7 @@ def walks(graph: CSRGraph, wp, seed: int, epoch: int, first_walk: int, n_walks: 
     return out
 
 
-WALK_ACCEL_EDGE_SET, WALK_ACCEL_FILTER, WALK_ACCEL_RECORDS = 1, 2, 4
+WALK_ACCEL_EDGE_SET, WALK_ACCEL_FILTER, WALK_ACCEL_RECORDS, WALK_ACCEL_TYPED_RECORDS = 1, 2, 4, 8
 
 
 def walk_accel(graph: CSRGraph, device: int = 0) -> int:

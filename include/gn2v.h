@@ -562,11 +562,12 @@ int gn2v_graph_release_buffers(gn2v_graph *g);
 
 /* Which accelerators of the walk sampler the handle holds right now (they are built on the first
  * walk that can use them and when memory allows; the walks are the same with or without them):
- * bit 0 the hashed edge set, bit 1 the filter in front of it, bit 2 the edge records
- * (csrc/walk_kernels.h).  Negative on a NULL handle. */
+ * bit 0 the hashed edge set, bit 1 the filter in front of it, bit 2 the edge records, bit 3 their
+ * typed form (csrc/walk_kernels.h).  Negative on a NULL handle. */
 #define GN2V_WALK_ACCEL_EDGE_SET 1
 #define GN2V_WALK_ACCEL_FILTER 2
 #define GN2V_WALK_ACCEL_RECORDS 4
+#define GN2V_WALK_ACCEL_TYPED_RECORDS 8 /* the 32 B form read by walks with type factors */
 int gn2v_graph_walk_accel(gn2v_graph *g);
 
 /* counters accumulated on the handle by the step / walk entry points since the last reset */

@@ -153,3 +153,53 @@ def test_set_types_through_the_c_abi():
     assert b"change_node_type_weight" in L.gn2v_last_error()
     assert L.gn2v_graph_set_types(None, None, None) != 0
     L.gn2v_graph_destroy(handle)
+
+
+@pytest.mark.parametrize("rw,ew,cn,ce", [(1.0, 1.0, 4.0, 1.0), (1.0, 1.0, 1.0, 0.2),
+                                         (0.25, 4.0, 2.0, 0.5), (2.0, 0.5, 2.0, 0.5),
+                                         (1e-3, 1e-3, 1e-3, 1e-3)])
+def test_typed_edge_records_only_accelerate_the_reads(monkeypatch, rw, ew, cn, ce):
+    """Walks with type factors read 32 B edge records (the 16 B record, then the node type of the
+    destination and the type of the edge; walk_kernels.h walk_rec_kernel<true>): the same walks
+    with the records off and in the oracle, on a multigraph whose parallel edges differ in type."""
+    rng = np.random.RandomState(8)
+    s, d = O.ba_edges(3000, 5, 4)
+    extra = rng.randint(0, len(s), size=2000)
+    src, dst = np.concatenate([s, s[extra]]), np.concatenate([d, d[extra]])
+    et = np.concatenate([rng.randint(0, 3, size=len(s)), rng.randint(3, 5, size=len(extra))])
+    nt = rng.randint(0, 4, size=3000)
+    walks = {}
+    for records in ("1", "0"):
+        monkeypatch.setenv("GN2V_WALK_EDGE_RECORDS", records)
+        g = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=3000, node_types=nt.tolist(),
+                                      edge_types=et.tolist())
+        walks[records] = _u32(ops.walks(g, ops.walk_params(40, 2, rw, ew, 100, cn, ce), 3, 1, 7, 6100))
+        assert ops.walk_accel(g) & 12 == (ops.WALK_ACCEL_TYPED_RECORDS if records == "1" else 0)
+    assert np.array_equal(walks["1"], walks["0"])
+    assert np.array_equal(walks["1"], O.walks(oracle_graph(g), O.WalkParams(40, 2, rw, ew, 100, 0, cn, ce),
+                                              3, 1, 7, 6100))
+
+
+def test_new_types_rebuild_the_typed_records():
+    import ctypes as C
+
+    g = typed_karate()
+    L = _lib.lib()
+    handle = C.c_void_p()
+    _lib.check(L.gn2v_graph_create(g.row_ptr.ctypes.data, g.col_idx.ctypes.data, None, None, 34,
+                                   len(g.col_idx), 34, 0, 0, C.byref(handle)))
+    out = torch.empty((340, 20), dtype=torch.int32, device="cuda")
+    wp = _lib.WalkParams(20, 2, 0.5, 2.0, 100, 0, 5.0, 0.2)
+    owp = O.WalkParams(20, 2, 0.5, 2.0, 100, 0, 5.0, 0.2)
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.RandomState(2)
+    for trial in range(3):
+        nt = rng.randint(0, 3, size=34).astype(np.uint32)
+        et = rng.randint(0, 4, size=len(g.col_idx)).astype(np.uint32)
+        _lib.check(L.gn2v_graph_set_types(handle, nt.ctypes.data, et.ctypes.data))
+        assert L.gn2v_graph_walk_accel(handle) & ops.WALK_ACCEL_TYPED_RECORDS == 0
+        _lib.check(L.gn2v_walks(handle, C.byref(wp), 3, trial, 0, 340, out.data_ptr(), stream))
+        assert L.gn2v_graph_walk_accel(handle) & ops.WALK_ACCEL_TYPED_RECORDS
+        og = O.OracleGraph(g.row_ptr, g.col_idx, None, nt, et)
+        assert np.array_equal(_u32(out), O.walks(og, owp, 3, trial, 0, 340))
+    L.gn2v_graph_destroy(handle)
