@@ -44,7 +44,7 @@ struct GraphView {
     // once the binary searches are gone.
     const unsigned long long *edge_filter;
     uint64_t filter_mask;  // words - 1 (a power of two)
-    // Edge records (see walk_rec_kernel): per directed edge, the destination with its row and the
+    // Edge records (walk_rec_kernel): per directed edge, the destination with its row and the
     // signature of its neighbourhood; per node, that signature.  nullptr: not built.
     const uint4 *edge_rec;
     const uint32_t *node_sig;
@@ -574,14 +574,21 @@ __device__ __forceinline__ Candidate<TYPED> fetch_candidate(const uint4 *__restr
     return k;
 }
 
-// The walk of walk_kernel<TYPED> on an unweighted graph, candidate by candidate the same draws and
-// the same decisions, read from the edge records.
+// The walk of walk_kernel<TYPED> on an unweighted graph read from the edge records: per walk the
+// same draws in the same order and the same decisions, hence the same walks -- with the lanes of a
+// wave out of lock step.  In walk_kernel a step lasts as long as the slowest lane's trials (the
+// maximum of 64 geometric variables: 7 round trips at acceptance 1/2 where the mean is 2).  Here a
+// lane runs ONE trial per pass of the wave and moves on to its next step as soon as a trial is
+// accepted; the lanes meet again only where a tile of 16 steps is flushed.  The adjacency test of a
+// candidate that needs one is a pass of its own ("pending": the filter word is loaded beside the
+// other lanes' candidates, one wait for both).  Draws are counter based per walk, so the order in
+// which lanes run changes no walk.
 template <bool TYPED>
-__global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphView g, WalkConsts c,
-                                                                 uint64_t ekey, uint64_t first_walk,
-                                                                 uint64_t n_walks,
-                                                                 uint32_t *__restrict__ out,
-                                                                 unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, WalkConsts c,
+                                                                  uint64_t ekey, uint64_t first_walk,
+                                                                  uint64_t n_walks,
+                                                                  uint32_t *__restrict__ out,
+                                                                  unsigned long long *__restrict__ counters) {
     __shared__ uint32_t tile[kWalkBlock / 64][64][kTileSteps + 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -591,10 +598,16 @@ __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphView g, Wa
     const bool live = b < n_walks;
     const uint32_t L = c.walk_length;
     const uint4 *__restrict__ rec = TYPED ? g.edge_rec_typed : g.edge_rec;
+    // the envelope in use: "return apart" proposes prev on its own and never through a neighbour
+    const bool apart = !TYPED && c.apart;
+    const uint64_t k_ret = apart ? 0 : c.t_ret;
+    const uint64_t k_common = apart ? c.s_common : c.t_common;
+    const uint64_t k_explore = apart ? c.s_explore : c.t_explore;
+    const uint64_t k_min = apart ? c.s_min : c.t_min, k_max = apart ? c.s_max : c.t_max;
 
     uint64_t wkey = 0, ctr = 0;
     NodeRow cur{kSentinel, 0, 0, 0}, prev{kSentinel, 0, 0, 0};
-    uint32_t cur_ntype = 0, ptype = 0;  // TYPED: node type of cur, type of the edge that led to it
+    uint32_t cur_ntype = 0, ptype = 0;
     if (live) {
         const uint64_t wid = first_walk + b;
         const uint64_t si = wid % g.n_sources;
@@ -608,170 +621,151 @@ __global__ __launch_bounds__(kWalkBlock, 4) void walk_rec_kernel(GraphView g, Wa
     }
     bool dead = !live;
     uint32_t steps = 0;
+    // the step in hand: trials so far; a candidate waiting for its adjacency test
+    uint32_t trial = 0;
+    bool pend = false;
+    Candidate<TYPED> held{};
+    uint32_t held_r32 = 0;
+    bool ntype_differs = false, etype_differs = false;  // of the held candidate (TYPED)
 
     for (uint32_t t0 = 0; t0 < L; t0 += kTileSteps) {
-        const uint32_t tn = min((uint32_t)kTileSteps, L - t0);
-        for (uint32_t tt = 0; tt < tn; ++tt) {
-            const uint32_t t = t0 + tt;
-            uint32_t val = kSentinel;
-            if (t == 0) {
-                val = cur.id;
-            } else if (!dead) {
-                const uint64_t deg = cur.deg;
-                if (deg == 0) {
-                    dead = true;
+        const uint32_t tend = min(t0 + (uint32_t)kTileSteps, L);
+        uint32_t t = t0;
+        if (dead) {
+            for (; t < tend; ++t) tile[wave][lane][t - t0] = kSentinel;
+        } else if (t == 0) {
+            tile[wave][lane][0] = cur.id;
+            t = 1;
+        }
+        while (__any(t < tend)) {
+            const bool active = t < tend;
+            const uint64_t deg = cur.deg;
+            const bool walked = prev.id != kSentinel;
+            const bool second = c.second_order && walked;
+            const bool biased =
+                ((TYPED && c.node_bias) || second || (TYPED && c.edge_bias && walked)) && deg != 1;
+            // ---- what this pass loads: a candidate's record, or a held candidate's filter word
+            bool do_trial = active && !pend && deg != 0, direct = false;
+            const bool do_pend = active && pend;
+            uint64_t r32 = 0;
+            Candidate<TYPED> x{};
+            if (do_trial) {
+                uint64_t r = draw(wkey, ctr++);
+                if (apart && biased) {
+                    direct = mulhi64(r, c.rq + deg * c.mq) < c.rq;
+                    if (!direct) r = draw(wkey, ctr++);
+                }
+                ++trial;
+                r32 = r & 0xFFFFFFFFULL;
+                if (!direct) x = fetch_candidate<TYPED>(rec, cur.start + (((r >> 32) * deg) >> 32));
+            }
+            unsigned long long fword = ~0ULL, fbits = 0;
+            if (do_pend && g.edge_filter) {
+                uint64_t word;
+                fbits = filter_bits(((unsigned long long)prev.id << 32) | held.a.x, g.filter_mask,
+                                    &word);
+                fword = g.edge_filter[word];
+            }
+            // ---- decisions
+            bool accepted = false, back = false;
+            if (active && !pend && deg == 0) {
+                dead = true;
+                for (; t < tend; ++t) tile[wave][lane][t - t0] = kSentinel;
+            }
+            if (do_trial) {
+                if (!biased) {
+                    accepted = true;
+                } else if (direct) {
+                    // prev is a neighbour of cur on a symmetric graph; otherwise look for the
+                    // edge cur -> prev in the row
+                    accepted = back = g.symmetric || adj_contains(g.col_idx, cur.start,
+                                                                  cur.start + deg, prev.id);
                 } else {
-                    bool back = false;  // the accepted candidate is prev, proposed on its own
-                    Candidate<TYPED> got{};
-                    const bool walked = prev.id != kSentinel;
-                    const bool second = c.second_order && walked;
-                    const bool biased = (TYPED && c.node_bias) || second ||
-                                        (TYPED && c.edge_bias && walked);
-                    if (!biased || deg == 1) {
-                        const uint64_t r = draw(wkey, ctr++);
-                        got = fetch_candidate<TYPED>(rec, cur.start + (((r >> 32) * deg) >> 32));
-                    } else if (!TYPED && c.apart) {
-                        // same trial sequence as walk_kernel's "return apart" branch
-                        bool accepted = false;
-                        uint32_t trial = 0;
-                        const uint64_t z = c.rq + deg * c.mq;
-                        bool direct = mulhi64(draw(wkey, ctr), z) < c.rq;
-                        uint64_t r2 = direct ? 0 : draw(wkey, ctr + 1);
-                        Candidate<TYPED> x{};
-                        if (!direct)
-                            x = fetch_candidate<TYPED>(rec, cur.start + (((r2 >> 32) * deg) >> 32));
-                        while (trial < c.max_trials) {
-                            const uint64_t used = direct ? 1 : 2;
-                            const bool n_direct = mulhi64(draw(wkey, ctr + used), z) < c.rq;
-                            const uint64_t n_r2 = n_direct ? 0 : draw(wkey, ctr + used + 1);
-                            Candidate<TYPED> n_x{};
-                            if (!n_direct && trial + 1 < c.max_trials)
-                                n_x = fetch_candidate<TYPED>(
-                                    rec, cur.start + (((n_r2 >> 32) * deg) >> 32));
-                            ++trial;
-                            ctr += used;
-                            if (direct) {
-                                // prev is a neighbour of cur on a symmetric graph; otherwise look
-                                // for the edge cur -> prev in the row
-                                if (g.symmetric ||
-                                    adj_contains(g.col_idx, cur.start, cur.start + deg, prev.id)) {
-                                    accepted = true;
-                                    back = true;
-                                }
-                            } else if (x.a.x != prev.id) {
-                                const uint64_t r32 = r2 & 0xFFFFFFFFULL;
-                                if (r32 < c.s_min)
-                                    accepted = true;
-                                else if (r32 < c.s_max)
-                                    accepted =
-                                        r32 < ((rec_maybe_common(prev, x.a.x) &&
-                                                is_common_neighbour(g, x.a.x, prev.id, prev.start,
-                                                                    prev.start + prev.deg))
-                                                   ? c.s_common
-                                                   : c.s_explore);
-                                if (accepted) got = x;
-                            }
-                            if (accepted) break;
-                            direct = n_direct;
-                            r2 = n_r2;
-                            x = n_x;
+                    uint64_t lo = 1ULL << 32, hi = 1ULL << 32;
+                    if (second) {
+                        if (x.a.x == prev.id) {
+                            lo = hi = k_ret;
+                        } else if (!rec_maybe_common(prev, x.a.x)) {
+                            lo = hi = k_explore;
+                        } else {
+                            lo = k_min;
+                            hi = k_max;
                         }
-                        if (!accepted) {
-                            const uint64_t r = draw(wkey, ctr++);
-                            got = fetch_candidate<TYPED>(
-                                rec, cur.start + exact_scan<TYPED>(g, c, r, cur.id, cur.start, deg,
-                                                                   prev.id, prev.start,
-                                                                   prev.start + prev.deg, ptype));
+                    }
+                    if constexpr (TYPED) {
+                        if (c.node_bias) {
+                            ntype_differs = cur_ntype != x.ntype;
+                            const uint64_t f = ntype_differs ? c.fn_diff : c.fn_same;
+                            lo = scale32(lo, f);
+                            hi = scale32(hi, f);
+                        }
+                        if (c.edge_bias && walked) {
+                            etype_differs = x.etype != ptype;
+                            const uint64_t f = etype_differs ? c.fe_diff : c.fe_same;
+                            lo = scale32(lo, f);
+                            hi = scale32(hi, f);
+                        }
+                    }
+                    if (r32 < lo) {
+                        accepted = true;
+                    } else if (r32 < hi) {
+                        pend = true;
+                        held = x;
+                        held_r32 = (uint32_t)r32;
+                    }
+                }
+            } else if (do_pend) {
+                pend = false;
+                x = held;
+                r32 = held_r32;
+                bool common = (fword & fbits) == fbits;  // no filter: always "maybe"
+                if (common) {
+                    if (g.edge_set) {
+                        const unsigned long long key = ((unsigned long long)prev.id << 32) | x.a.x;
+                        uint64_t slot = edge_slot(key, g.edge_mask);
+                        for (;;) {
+                            const unsigned long long k = g.edge_set[slot];
+                            common = k == key;
+                            if (k == key || k == kNoEdge) break;
+                            slot = (slot + 1) & g.edge_mask;
                         }
                     } else {
-                        // One envelope for all classes (walk_kernel's two phases).  A candidate
-                        // whose bit is missing from prev's signature is of class "other" for
-                        // certain: its bounds meet and it is decided at once; the exact test runs
-                        // only for the rest, in lock step (phase B).
-                        bool accepted = false;
-                        uint32_t trial = 0;
-                        while (trial < c.max_trials) {
-                            uint64_t r32 = 0, fac_n = 1ULL << 32, fac_e = 1ULL << 32;
-                            Candidate<TYPED> x{};
-                            bool pending = false;
-                            while (trial < c.max_trials) {
-                                const uint64_t r = draw(wkey, ctr++);
-                                x = fetch_candidate<TYPED>(rec,
-                                                           cur.start + (((r >> 32) * deg) >> 32));
-                                ++trial;
-                                r32 = r & 0xFFFFFFFFULL;
-                                uint64_t lo = 1ULL << 32, hi = 1ULL << 32;
-                                if (second) {
-                                    if (x.a.x == prev.id) {
-                                        lo = hi = c.t_ret;
-                                    } else if (!rec_maybe_common(prev, x.a.x)) {
-                                        lo = hi = c.t_explore;
-                                    } else {
-                                        lo = c.t_min;
-                                        hi = c.t_max;
-                                    }
-                                }
-                                if constexpr (TYPED) {
-                                    if (c.node_bias) {
-                                        fac_n = cur_ntype != x.ntype ? c.fn_diff : c.fn_same;
-                                        lo = scale32(lo, fac_n);
-                                        hi = scale32(hi, fac_n);
-                                    }
-                                    if (c.edge_bias && walked) {
-                                        fac_e = x.etype != ptype ? c.fe_diff : c.fe_same;
-                                        lo = scale32(lo, fac_e);
-                                        hi = scale32(hi, fac_e);
-                                    }
-                                }
-                                if (r32 < lo) {
-                                    accepted = true;
-                                    break;
-                                }
-                                if (r32 < hi) {
-                                    pending = true;
-                                    break;
-                                }
-                            }
-                            if (pending) {
-                                // x is not prev here (its bounds meet)
-                                uint64_t thr = is_common_neighbour(g, x.a.x, prev.id, prev.start,
-                                                                   prev.start + prev.deg)
-                                                   ? c.t_common
-                                                   : c.t_explore;
-                                if constexpr (TYPED) {
-                                    if (c.node_bias) thr = scale32(thr, fac_n);
-                                    if (c.edge_bias && walked) thr = scale32(thr, fac_e);
-                                }
-                                accepted = r32 < thr;
-                            }
-                            if (accepted) {
-                                got = x;
-                                break;
-                            }
-                            if (!pending) break;  // trials exhausted
-                        }
-                        if (!accepted) {
-                            const uint64_t r = draw(wkey, ctr++);
-                            got = fetch_candidate<TYPED>(
-                                rec, cur.start + exact_scan<TYPED>(g, c, r, cur.id, cur.start, deg,
-                                                                   prev.id, prev.start,
-                                                                   prev.start + prev.deg, ptype));
-                        }
+                        common = is_common_neighbour(g, x.a.x, prev.id, prev.start,
+                                                     prev.start + prev.deg);
                     }
-                    const NodeRow nxt = back ? prev : row_of_record(got.a);
-                    if constexpr (TYPED) {
-                        cur_ntype = got.ntype;
-                        ptype = got.etype;
-                    }
-                    val = nxt.id;
-                    prev = cur;
-                    cur = nxt;
-                    ++steps;
                 }
+                uint64_t thr = common ? k_common : k_explore;
+                if constexpr (TYPED) {
+                    if (c.node_bias) thr = scale32(thr, ntype_differs ? c.fn_diff : c.fn_same);
+                    if (c.edge_bias && walked)
+                        thr = scale32(thr, etype_differs ? c.fe_diff : c.fe_same);
+                }
+                accepted = r32 < thr;
             }
-            tile[wave][lane][tt] = val;
+            if ((do_trial || do_pend) && !accepted && !pend && trial >= c.max_trials) {
+                // rare: the exact scan of the row
+                const uint64_t r = draw(wkey, ctr++);
+                x = fetch_candidate<TYPED>(
+                    rec, cur.start + exact_scan<TYPED>(g, c, r, cur.id, cur.start, deg, prev.id,
+                                                       prev.start, prev.start + prev.deg, ptype));
+                accepted = true;
+            }
+            if (accepted) {
+                const NodeRow nxt = back ? prev : row_of_record(x.a);
+                if constexpr (TYPED) {
+                    cur_ntype = x.ntype;
+                    ptype = x.etype;
+                }
+                tile[wave][lane][t - t0] = nxt.id;
+                prev = cur;
+                cur = nxt;
+                ++steps;
+                ++t;
+                trial = 0;
+            }
         }
         // flush: 64 walks x tn steps; lane -> (walk = lane/4 + 16*pass, 4-step quarter = lane%4)
+        const uint32_t tn = tend - t0;
         __builtin_amdgcn_wave_barrier();
         for (int pass = 0; pass < 4; ++pass) {
             const int wrow = (lane >> 2) + 16 * pass;

@@ -61,7 +61,7 @@ def main(tag):
                         r["Percentage"], r["MinNs"], r["MaxNs"]])
     needle = "cbow_" if any("cbow_" in r["Name"] for r in stats[:3]) else "sgns_"
     sg = next(r for r in stats if needle in r["Name"])
-    wk = next(r for r in stats if "walk_kernel" in r["Name"])
+    wk = next(r for r in stats if "walk_kernel" in r["Name"] or "walk_rec_kernel" in r["Name"])
     avg_ms = float(sg["AverageNs"]) / 1e6
     # like for like with bench.py's HIP events: the timed launches are the last `launches` ones
     # of that kernel in the trace (the warm-up's come first and may be smaller)

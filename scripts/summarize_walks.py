@@ -15,6 +15,11 @@ CONFIGS = ["untyped rw.25/ew4", "typed graph unit weights", "first order", "firs
 STEPS = (1 << 19) * 127
 
 
+def is_walk(name):
+    """walk_kernel (CSR reads) or walk_rec_kernel (edge records)"""
+    return "walk_kernel" in name or "walk_rec_kernel" in name
+
+
 def one(pattern):
     files = glob.glob(pattern, recursive=True)
     if not files:
@@ -26,9 +31,9 @@ def main(tag):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     trace = [r for r in csv.DictReader(open(one(f"{src}/stats/**/*kernel_trace.csv")))
-             if "walk_kernel" in r["Kernel_Name"]]
+             if is_walk(r["Kernel_Name"])]
     fetch = [r for r in csv.DictReader(open(one(f"{src}/fetch/**/*counter_collection.csv")))
-             if "walk_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+             if is_walk(r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE"]
     assert len(trace) == 4 * len(CONFIGS) == len(fetch), (len(trace), len(fetch))
     stats = list(csv.DictReader(open(one(f"{src}/stats/**/*kernel_stats.csv"))))
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -37,12 +42,12 @@ def main(tag):
         for r in stats[:8]:
             w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                         r["Percentage"]])
-    lines = [f"# {tag}: `gn2v::walk_kernel` (BA 10 M / 100 M, 2^19 walks of 128 nodes per launch)",
+    lines = [f"# {tag}: the walk sampler, `gn2v::walk_rec_kernel` / `gn2v::walk_kernel` (BA 10 M / 100 M, 2^19 walks of 128 nodes per launch)",
              "",
              "`rocprofv3 --kernel-trace --stats` and a separate `--pmc FETCH_SIZE` pass of "
              "`python3 scripts/typed_walk_probe.py` (3 timed launches per configuration after a "
              "warm-up; `scripts/profile_walks.sh`, digest by `scripts/summarize_walks.py`).  "
-             "FETCH_SIZE raw (KiB x 1024): the sampler's reads are 4-8 B wide.",
+             "FETCH_SIZE raw (KiB x 1024): the sampler's reads are 4-32 B wide.",
              "",
              "| configuration | kernel | ms / launch | steps/s | FETCH B / step | fetch GB/s | 64 B sectors / s |",
              "|---|---|---|---|---|---|---|"]

@@ -13,7 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "embiggen_amd", "csrc")
 
 
+_CACHE = {}
+
+
 def resources(unit, tmp_path):
+    if unit not in _CACHE:
+        _CACHE[unit] = _resources(unit, tmp_path)
+    return _CACHE[unit]
+
+
+def _resources(unit, tmp_path):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     res = subprocess.run(
         [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c",
@@ -78,3 +87,24 @@ def test_block_kernel_keeps_its_occupancy(tmp_path):
     for name, r in table.items():
         if re.search(r"sgns_block_kernelILi[1248]E", name):
             assert r["scratch"] <= 64, (name, r)
+
+
+@pytest.mark.timeout(1200)
+def test_resident_kernel_keeps_its_occupancy(tmp_path):
+    """sgns_resident_v2_kernel<CH = 2>: sixteen waves per workgroup, one workgroup per CU -- four
+    waves per SIMD means at most 128 registers, and the bench's kernel spills none."""
+    table = resources("gn2v_block_api.hip", tmp_path)
+    for name, r in pick(table, "sgns_resident_v2_kernelILi2E").items():
+        if name.endswith("Lb0EEEvNS_9BlockArgsE"):  # the parallel form (not the in-order one)
+            assert r["vgprs"] <= 128 and r["waves"] >= 4 and r["scratch"] == 0, (name, r)
+
+
+@pytest.mark.timeout(1200)
+def test_walk_kernels_keep_their_occupancy(tmp_path):
+    """The record sampler runs three waves per SIMD (measured: as fast as four, which costs
+    spills); its scratch is the frame of the rare exact scan, not spills of the trial loop."""
+    table = resources("gn2v_api.hip", tmp_path)
+    for name, r in pick(table, "walk_rec_kernel").items():
+        assert r["waves"] >= 3 and r["scratch"] <= 352, (name, r)
+    for name, r in pick(table, "walk_kernelILb").items():
+        assert r["waves"] >= 3 and r["scratch"] <= 320, (name, r)
