@@ -169,7 +169,7 @@ ROUND_GROW = 3  # GN2V_ROUND_GROW
 EXPERIMENTAL_EXPORTS = ["gn2v_step"]
 
 BLOCK_WORK_WORDS = 532480   # GN2V_BLOCK_WORK_WORDS
-BLOCK_MAX_GROUP_CELLS = 8192  # GN2V_BLOCK_MAX_GROUP_CELLS
+BLOCK_MAX_GROUP_CELLS = 16384  # GN2V_BLOCK_MAX_GROUP_CELLS
 BLOCK_HOT_MAX = 192      # GN2V_BLOCK_HOT_MAX
 BLOCK_HOT_DEFAULT = 192  # GN2V_BLOCK_HOT_DEFAULT
 

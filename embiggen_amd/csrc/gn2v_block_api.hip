@@ -490,7 +490,9 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     a.pairs = (unsigned long long *)pairs;
     a.part_lo = part_lo;
     a.part_n = part_n;
-    const size_t lds = extract_lds_bytes(d.L, part_n * d.slices);
+    // the counting pass keeps one LDS counter per cell of the group; the writing pass needs the
+    // walk staging only (and runs twice as many waves per CU without the counters)
+    const size_t lds = extract_lds_bytes(d.L, write ? 0 : part_n * d.slices);
     if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
     const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
     if (extract_fast(d.L, d.window)) {
@@ -1098,7 +1100,11 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
         return copies * 8 * (per_part * gp + per_part * gp / 8);
     };
     while (r > (1ull << 14) && walk_bytes(r) + group_bytes(r, 1) > budget) r /= 2;
-    uint64_t gp = std::max<uint64_t>(1, (parts + 3) / 4);
+    // (six on one GPU in resident cells: the first group of a round is prepared in line, and the
+    // pair buffers of a quarter of a round -- two sets -- are more than a handle keeps between
+    // two fits: the second fit of the bench waited 1.8 s for the driver to clear them again)
+    const uint64_t min_groups = world == 1 && slices > 16 ? 6 : 4;
+    uint64_t gp = std::max<uint64_t>(1, (parts + min_groups - 1) / min_groups);
     // the extraction counts the cells of a group in LDS: kMaxGroupCells at most, and fewer when
     // the walk's staging leaves less of the 64 KB
     const uint64_t lds_cells =

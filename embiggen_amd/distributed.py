@@ -473,7 +473,10 @@ class BlockPartitionedTrainer:
         # the extraction counts the cells of a group in LDS: BLOCK_MAX_GROUP_CELLS at most
         from . import _lib as _l
 
-        most = max(1, _l.BLOCK_MAX_GROUP_CELLS // slices)
+        # (and fewer when the walk's staging leaves less of the 64 KB: gn2v_block_round_plan)
+        staging = 4 * (5 if walk_length <= 128 else 4) * walk_length * 4
+        most = max(1, min(_l.BLOCK_MAX_GROUP_CELLS, (64 * 1024 - min(staging, 60 * 1024)) // 4)
+                   // slices)
         self.group_parts = min(most, parts if not group_parts else max(1, min(int(group_parts), parts)))
         self.stripes = max(1, int(stripes))
         if self.stripes > 1 and world > 1:

@@ -403,7 +403,8 @@ int gn2v_graph_xcds(gn2v_graph *g);
  * the walk-ordered schedule's: 10 M nodes -> 38 x 8, 100 M -> 381 x 8. */
 #define GN2V_BLOCK_MAX_SLICES 8192u
 #define GN2V_BLOCK_MAX_CELLS 524288u      /* parts x slices of a plan                           */
-#define GN2V_BLOCK_MAX_GROUP_CELLS 8192u  /* parts of an extraction group x slices              */
+#define GN2V_BLOCK_MAX_GROUP_CELLS 16384u /* parts of an extraction group x slices (less when the
+                                            * walk staging leaves less than 64 KB of LDS)      */
 #define GN2V_RESIDENT_MIN_NODES 100000u
 #define GN2V_RESIDENT_MAX_NODES 115000000u /* 523 776 cells of 220 rows (d = 128, k = 10)       */
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,
@@ -421,8 +422,8 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
  * once tables and graph are resident).  The longer a round, the more pairs of a centre meet in a
  * cell (its row is read once per such run: kernel 0.82 / 0.92 / 0.96 of the roofline at 2^20 /
  * 2^22 / 2^23 walks on the bench graph): the power of two in [2^20, 2^23] that gives 64 pairs per
- * (cell, centre), less when memory is short (>= 2^14).  group_parts: at least four groups per
- * round when there are that many parts, more (smaller groups) when three quarters of free_bytes
+ * (cell, centre), less when memory is short (>= 2^14).  group_parts: at least four groups (six on
+ * one GPU in resident cells) per round when there are that many parts, more (smaller groups) when three quarters of free_bytes
  * do not hold the walks plus, per group, its pair words once sorted (twice with `overlap`: the
  * next group is prepared while this one trains) and once unsorted, 8 B per pair.  Pure host
  * function; every rank of a job must use the same values (take the minimum). */

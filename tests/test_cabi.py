@@ -142,10 +142,13 @@ def test_round_size_and_groups_follow_the_free_memory():
     GB = 10 ** 9
     # the bench graph on one GPU: 38 x 8 cells, rounds at the cap, four groups of <= 10 parts
     assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 38, 8, False) == (1 << 23, 10)
-    # the same graph in resident cells (178 x 256): a group is at most 8 192 cells = 32 parts --
-    # the extraction counts them in LDS -- and fewer when a long walk's staging leaves less room
-    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, False) == (1 << 23, 32)
-    assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False)[1] == 32
+    # the same graph in resident cells (178 x 256): six groups on one GPU; the extraction counts
+    # the cells of a group in LDS, 13 824 of them beside the staging of a walk of 128 (16 384 at
+    # most), and fewer when a long walk's staging leaves less room
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, False) == (1 << 23, 30)
+    assert round_plan(150 * GB, 100_000_000, 128, 5, 1, 1776, 256, False) == (1 << 23, 54)
+    assert round_plan(250 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 4)
+    assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False)[1] == 30
     assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 178, 256, False)[1] == 14
     # eight GPUs, a group in preparation while one trains
     assert round_plan(270 * GB, 10_000_000, 128, 5, 8, 32, 8, True) == (1 << 23, 8)
