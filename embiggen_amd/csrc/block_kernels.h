@@ -242,6 +242,17 @@ static __global__ void alias_kernel(const uint32_t *__restrict__ indeg, uint64_t
 // --------------------------------------------------------------------------------------------
 constexpr uint64_t kTagPlace = 0x91ACE5EED5EED5EDULL;
 
+// LPT order of a resident launch: key = ~pairs of the cell (ascending sort = heaviest first)
+static __global__ void cell_order_keys_kernel(const unsigned long long *__restrict__ cell_offsets,
+                                              uint32_t first_cell, uint32_t n, uint32_t *keys,
+                                              uint32_t *vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long sz = cell_offsets[first_cell + i + 1] - cell_offsets[first_cell + i];
+    keys[i] = ~(uint32_t)(sz > 0xFFFFFFFFull ? 0xFFFFFFFFull : sz);
+    vals[i] = i;
+}
+
 static __global__ void place_keys_kernel(uint64_t n_nodes, uint32_t classes, uint64_t pkey,
                                          unsigned long long *__restrict__ keys,
                                          uint32_t *__restrict__ vals) {
@@ -707,6 +718,10 @@ struct BlockArgs {
     // `context` (placements that keep the classes modulo parts: x % parts == part)
     const uint32_t *inv;
     float *ctx_table;
+    // resident cells: the launch's workgroups take its cells heaviest first -- workgroup i (in
+    // dispatch order) trains cell order[i] of the launch (part offset * slices + slice); nullptr:
+    // in index order.  The last workgroups of a launch then finish light cells, not a hub's.
+    const uint32_t *order;
     unsigned long long *cursors;  // record tickets of the part's cells, one per slice, kCursorStep
                                   // words apart (zeroed per launch)
     unsigned long long *counters;

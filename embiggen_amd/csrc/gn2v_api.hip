@@ -827,6 +827,8 @@ int gn2v_graph_destroy(gn2v_graph *g) {
         }
     }
     if (g->cursors) (void)hipFree(g->cursors);
+    if (g->lpt) (void)hipFree(g->lpt);
+    if (g->lpt_temp) (void)hipFree(g->lpt_temp);
     if (g->edge_set) (void)hipFree(g->edge_set);
     if (g->edge_filter) (void)hipFree(g->edge_filter);
     if (g->edge_rec) (void)hipFree(g->edge_rec);

@@ -645,6 +645,48 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
 #undef GN2V_BLOCK_WIDE
 }
 
+// Heaviest cell first (BlockArgs.order): the cells of a launch sorted by their pairs, on the
+// launch's stream, in a ring of slots owned by the handle (a slot is rewritten kLptRing launches
+// later).  Launches of fewer than two cells per CU, or of more cells than an extraction group
+// may hold, keep the index order.  GN2V_RESIDENT_LPT=0: never (A/B).
+constexpr uint32_t kLptRing = 8, kLptCells = GN2V_BLOCK_MAX_GROUP_CELLS;
+static int lpt_order(gn2v_graph *g, uint32_t n, uint32_t first_cell,
+                     const unsigned long long *d_cell_offsets, const uint32_t **order,
+                     hipStream_t s) {
+    static const size_t on = env_size("GN2V_RESIDENT_LPT", 1);
+    *order = nullptr;
+    if (!on || n > kLptCells || n < 2u * (uint32_t)g->n_cus) return 0;
+    if (!g->lpt) {
+        uint32_t *kb = nullptr, *vb = nullptr;
+        size_t need = 0;
+        if (rocprim::radix_sort_pairs(nullptr, need, kb, kb, vb, vb, kLptCells, 0, 32,
+                                      (hipStream_t)0) != hipSuccess)
+            return fail("rocprim::radix_sort_pairs (size query)");
+        void *temp = nullptr;
+        uint32_t *buf = nullptr;
+        if (hipMalloc((void **)&buf, (size_t)kLptRing * 4 * kLptCells * 4) != hipSuccess ||
+            hipMalloc(&temp, need ? need : 16) != hipSuccess) {
+            (void)hipGetLastError();
+            if (buf) (void)hipFree(buf);
+            return 0;  // no room: index order
+        }
+        g->lpt = buf;
+        g->lpt_temp = temp;
+        g->lpt_temp_bytes = need;
+    }
+    uint32_t *slot = g->lpt + (size_t)(g->lpt_slot++ % kLptRing) * 4 * kLptCells;
+    uint32_t *keys_in = slot, *keys_out = slot + kLptCells, *vals_in = slot + 2 * kLptCells,
+             *vals_out = slot + 3 * kLptCells;
+    hipLaunchKernelGGL(gn2v::cell_order_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+                       d_cell_offsets, first_cell, n, keys_in, vals_in);
+    HIP_TRY(hipGetLastError());
+    size_t bytes = g->lpt_temp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(g->lpt_temp, bytes, keys_in, keys_out, vals_in, vals_out, n,
+                                      0, 32, s));
+    *order = vals_out;
+    return 0;
+}
+
 template <int CH>
 static void launch_resident_v2_ch(bool det, dim3 grid, size_t lds, hipStream_t s,
                                   const gn2v::BlockArgs &a) {
@@ -832,6 +874,9 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         HIP_TRY(hipEventRecord(ev.a, s));
         if (det) a.sweep = part_n;  // the deterministic form walks the parts itself
         const dim3 grid(d.slices, part_n);
+        if (v2 && !det && lpt_order(g, d.slices * part_n, io->part * d.slices,
+                                    (const unsigned long long *)io->d_cell_offsets, &a.order, s))
+            return 1;
         if (v2) {
             if (tp->ld <= 64)
                 launch_resident_v2_ch<1>(det, grid, lds, s, a);

@@ -104,6 +104,11 @@ struct gn2v_graph {
     // round buffers of the last block fit, kept for the next one (gn2v_block_api.hip Buffers)
     std::vector<std::pair<void *, size_t>> kept_buffers;
     size_t kept_bytes = 0;
+    // resident launches, heaviest cell first: ring of (keys, values) x (in, out) + sort storage
+    uint32_t *lpt = nullptr;
+    void *lpt_temp = nullptr;
+    size_t lpt_temp_bytes = 0;
+    uint32_t lpt_slot = 0;
     unsigned long long *counters = nullptr;  // device, 4 x u64
     unsigned long long *cursors = nullptr;   // device, ring of record-ticket arrays (block trainer)
     uint32_t cursor_slot = 0;

@@ -530,11 +530,17 @@ __global__ __launch_bounds__(1024) void sgns_resident_v2_kernel(BlockArgs a) {
             }
         }
     } else {
+        uint32_t part_off = blockIdx.y, slice = blockIdx.x;
+        if (a.order) {  // heaviest cells first (BlockArgs.order)
+            const uint32_t id = a.order[blockIdx.y * gridDim.x + blockIdx.x];
+            part_off = a.p.dslices.div(id);
+            slice = id - part_off * a.p.slices;
+        }
         if (a.part_ptrs) {
-            a.part += blockIdx.y;
+            a.part += part_off;
             a.context = a.part_ptrs[a.part];
         }
-        resident_cell_v2<CH, false>(a, smem, blockIdx.x, a.hot_n, pairs, runs);
+        resident_cell_v2<CH, false>(a, smem, slice, a.hot_n, pairs, runs);
     }
     if (a.counters && (threadIdx.x & 63) == 0 && pairs) {
         atomicAdd(&a.counters[0], pairs);
