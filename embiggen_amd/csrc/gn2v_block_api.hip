@@ -653,7 +653,8 @@ constexpr uint32_t kLptRing = 8, kLptCells = GN2V_BLOCK_MAX_GROUP_CELLS;
 static int lpt_order(gn2v_graph *g, uint32_t n, uint32_t first_cell,
                      const unsigned long long *d_cell_offsets, const uint32_t **order,
                      hipStream_t s) {
-    static const size_t on = env_size("GN2V_RESIDENT_LPT", 1);
+    const char *env = getenv("GN2V_RESIDENT_LPT");  // read per launch: tests switch it
+    const bool on = !(env && *env == '0');
     *order = nullptr;
     if (!on || n > kLptCells || n < 2u * (uint32_t)g->n_cus) return 0;
     if (!g->lpt) {

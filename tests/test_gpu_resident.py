@@ -220,6 +220,49 @@ def test_parallel_resident_step_on_collision_free_pairs(d, per_cell, slices):
     assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5
 
 
+@pytest.mark.parametrize("lpt", ["1", "0"])
+def test_cells_taken_heaviest_first_train_the_same_pairs(monkeypatch, lpt):
+    """A resident launch of at least two cells per CU hands its cells to the workgroups by
+    descending number of pairs (gn2v_block_api.hip lpt_order, GN2V_RESIDENT_LPT=0: index order):
+    cells of very different sizes, some empty, collision-free pairs -- every pair trained once,
+    tables equal to the sequential oracle either way."""
+    monkeypatch.setenv("GN2V_RESIDENT_LPT", lpt)
+    parts, slices, record, d = 2, 640, 16, 64
+    n = 160_005
+    g = _ba(n)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, 1, record)
+    oplan = O.block_plan(n, 1, 0, parts, slices, 8, 2, 1, record)
+    rng = np.random.RandomState(11)
+    words_l, offsets, centre = [], [0], 0
+    for cell in range(parts * slices):
+        part, slc = divmod(cell, slices)
+        rows = stripe_rows(stripe_rows(n, part, parts), slc, slices)
+        per_cell = 0 if cell % 7 == 3 else int(rng.randint(1, min(rows, 120)))
+        ctx = slc + slices * rng.permutation(rows)[:per_cell]
+        words_l.append(O.block_pack(np.full(per_cell, cell), centre + np.arange(per_cell), ctx, oplan))
+        centre += per_cell
+        offsets.append(offsets[-1] + per_cell)
+    words_h = np.concatenate(words_l).astype(np.uint64)
+    off_h = np.asarray(offsets, dtype=np.uint64)
+    pairs, offs = _dev_words(words_h), torch.from_numpy(off_h.astype(np.int64)).cuda()
+    tp = ops.train_params(0, d, 0, 2, flags=0, ld=d)
+    otp = O.TrainParams(0, d, d, 1, 0, 2, 0.01, 0.9, 6.0, 0, d ** -0.5)
+    c = ops.init_table(n, d, 5, 0, 0.5, ld=d)
+    c_h = c.cpu().numpy().copy()
+    ops.stats_reset(g)
+    for part in range(parts):
+        x = ops.init_table_rows(stripe_rows(n, part, parts), d, 5, 1, 0.5, part, parts, ld=d)
+        x_h = x.cpu().numpy().copy()
+        ops.block_step(g, tp, plan, pairs, offs, None, None, c, x, 0, part, 5, 0, 0.05)
+        O.block_step(og, otp, oplan, words_h, off_h, None, None, c_h, x_h, 0, part, 5, 0, 0.05)
+        torch.cuda.synchronize()
+        assert np.abs(x.cpu().numpy() - x_h).max() < 2e-5
+    st = ops.stats_read(g)
+    assert st["resident_launches"] == parts and st["pairs"] == len(words_h)
+    assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5
+
+
 @pytest.mark.parametrize("d", [16, 128, 256])
 def test_parallel_pair_per_group_adds_shared_centres_with_atomics_in_resident_cells(d):
     """Every fourth pair shares its centre with its neighbour (three runs per four pairs: the
