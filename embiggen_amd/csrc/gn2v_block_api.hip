@@ -106,17 +106,20 @@ bool resident_v2() {
     return v != 0;
 }
 
-// Rows of a cell that one workgroup of sixteen waves holds in LDS next to its waves' staging
-// (sgns_resident_kernel); 0: rows too wide for that kernel (it is built for strides up to 256
-// floats) or nothing left beside the staging
+// Waves of a resident workgroup: sixteen for rows up to 128 floats, eight for wider rows (the
+// second form only: resident_kernels.h sgns_resident_v2_kernel WAVES)
+uint32_t resident_waves(uint32_t ld) { return resident_v2() && ld > 128 ? 8 : 16; }
+
+// Rows of a cell that one workgroup holds in LDS next to its waves' staging; 0: rows too wide for
+// the kernel (strides up to 512 floats; round 4's form: 256) or nothing left beside the staging
 uint32_t resident_rows(uint32_t ld, uint32_t record, uint32_t k) {
-    if (ld == 0 || ld > 256) return 0;
+    if (ld == 0 || ld > (resident_v2() ? 512u : 256u)) return 0;
     const size_t lds = 160 * 1024;
     if (resident_v2()) {
         // per wave: four transposition rows + the record's centres and 16-bit samples; shared:
         // the dummy row, then per cell row the row, its alias entry and its node id
-        const size_t staging = (size_t)gn2v::res_words_per_wave(ld, record, k) * 4 * 16 + 64 +
-                               (size_t)ld * 4;
+        const size_t staging = (size_t)gn2v::res_words_per_wave(ld, record, k) * 4 *
+                                   resident_waves(ld) + 64 + (size_t)ld * 4;
         // (a staged sample names its row in 12 bits, the dummy row included)
         static const size_t cap = env_size("GN2V_RESIDENT_FIT_ROWS", 4095);  // A/B: pin the cells
         return staging >= lds
@@ -691,18 +694,19 @@ static int lpt_order(gn2v_graph *g, uint32_t n, uint32_t first_cell,
 template <int CH>
 static void launch_resident_v2_ch(bool det, dim3 grid, size_t lds, hipStream_t s,
                                   const gn2v::BlockArgs &a) {
+    constexpr int W = CH > 2 ? 8 : 16;  // resident_waves()
     if (det) {  // one workgroup walks the cells in order
-        auto kernel = gn2v::sgns_resident_v2_kernel<CH, false, true>;
+        auto kernel = gn2v::sgns_resident_v2_kernel<CH, false, true, W>;
         allow_lds(kernel, lds);
-        hipLaunchKernelGGL(kernel, dim3(1), dim3(1024), lds, s, a);
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(W * 64), lds, s, a);
     } else if (a.ld == (uint32_t)CH * 64) {
-        auto kernel = gn2v::sgns_resident_v2_kernel<CH, true>;
+        auto kernel = gn2v::sgns_resident_v2_kernel<CH, true, false, W>;
         allow_lds(kernel, lds);
-        hipLaunchKernelGGL(kernel, grid, dim3(1024), lds, s, a);
+        hipLaunchKernelGGL(kernel, grid, dim3(W * 64), lds, s, a);
     } else {
-        auto kernel = gn2v::sgns_resident_v2_kernel<CH, false>;
+        auto kernel = gn2v::sgns_resident_v2_kernel<CH, false, false, W>;
         allow_lds(kernel, lds);
-        hipLaunchKernelGGL(kernel, grid, dim3(1024), lds, s, a);
+        hipLaunchKernelGGL(kernel, grid, dim3(W * 64), lds, s, a);
     }
 }
 
@@ -858,7 +862,8 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         a.p.record = res_record;
         const bool v2 = resident_v2();
         const size_t lds =
-            v2 ? (size_t)gn2v::res_words_per_wave(tp->ld, res_record, tp->k) * 4 * 16 +
+            v2 ? (size_t)gn2v::res_words_per_wave(tp->ld, res_record, tp->k) * 4 *
+                         resident_waves(tp->ld) +
                      (size_t)(max_cell_rows + 1) * tp->ld * 4 + (size_t)max_cell_rows * 12 + 16
                : block_lds_words_per_wave(tp->ld, res_record, tp->k) * 4 * 16 +
                      (size_t)max_cell_rows * (tp->ld * 4 + 4) + 16;
@@ -883,8 +888,10 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
                 launch_resident_v2_ch<1>(det, grid, lds, s, a);
             else if (tp->ld <= 128)
                 launch_resident_v2_ch<2>(det, grid, lds, s, a);
-            else
+            else if (tp->ld <= 256)
                 launch_resident_v2_ch<4>(det, grid, lds, s, a);
+            else
+                launch_resident_v2_ch<8>(det, grid, lds, s, a);
         } else if (tp->ld <= 64)
             launch_resident_ch<1>(det, grid, lds, s, a);
         else if (tp->ld <= 128)

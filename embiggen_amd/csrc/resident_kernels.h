@@ -188,6 +188,14 @@ __device__ __forceinline__ void res_step(const ResCell &c, const Row<CH> &u, Row
                                          uint32_t w, float lrc, float clip, int q,
                                          uint32_t nchunks) {
     const uint32_t pa = w & 0xFFFFu, pb = w >> 16;
+    if constexpr (!SEQ && !ONE && CH >= 8) {
+        // rows of 512 floats: two samples side by side do not fit the 256 registers of a lane
+        // next to u, g and the prefetched central row -- one after the other (their phases, counted
+        // over both samples of the earlier groups, serialise each half at least as strictly)
+        res_step<CH, SEQ, true>(c, u, g, pa, lrc, clip, q, nchunks);
+        res_step<CH, SEQ, true>(c, u, g, pb, lrc, clip, q, nchunks);
+        return;
+    }
     if constexpr (SEQ) {  // deterministic form: no phases are staged
         if constexpr (ONE)
             res_step1<CH>(c, u, g, pa, lrc, clip, q, nchunks);
@@ -514,8 +522,11 @@ __device__ __forceinline__ void resident_cell_v2(BlockArgs &a, uint32_t *smem, u
 }
 
 // a.hot_n carries the rows the launch's LDS plan was made for (the largest cell of the plan)
-template <int CH, bool FULL = false, bool DET = false>
-__global__ __launch_bounds__(1024) void sgns_resident_v2_kernel(BlockArgs a) {
+// WAVES: sixteen waves per workgroup for rows up to 128 floats (four per SIMD: 128 registers);
+// eight for wider rows (two per SIMD, 256 registers: a row of 256 floats is 16 registers a lane,
+// of 512 floats 32, and a step holds five of them)
+template <int CH, bool FULL = false, bool DET = false, int WAVES = 16>
+__global__ __launch_bounds__(WAVES * 64) void sgns_resident_v2_kernel(BlockArgs a) {
     if constexpr (FULL) a.ld = CH * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     unsigned long long pairs = 0, runs = 0;

@@ -76,7 +76,7 @@ def round_plan(free_bytes: int, n_nodes: int, walk_length: int, window: int, wor
 
 def auto_plan(n_nodes: int, world: int, ld: int = 0, k: int = 10) -> Tuple[int, int]:
     """(parts, slices) of the contextual table (``gn2v_block_auto_plan``: one rule for the C++
-    one-GPU fit and for this trainer).  Row stride ``ld`` <= 256 floats (0: unknown),
+    one-GPU fit and for this trainer).  Row stride ``ld`` <= 512 floats (0: unknown),
     up to 115 M nodes: resident cells -- cells that fit one workgroup's LDS, whose rows are
     read and updated there by that workgroup alone (plain read-modify-writes of its sixteen
     waves: no other CU races for a row, the workgroup's own groups still can).  Otherwise XCD

@@ -387,9 +387,10 @@ int gn2v_graph_reserve_cus(gn2v_graph *g, uint32_t cus_per_xcd, uint32_t *active
 int gn2v_graph_xcds(gn2v_graph *g);
 
 /* (parts, slices) of the contextual table for a graph of n_nodes on `world` ranks.
- * Row stride ld <= 256 floats (ld = 0: unknown, this rule is skipped), k negatives, a graph of
+ * Row stride ld <= 512 floats (ld = 0: unknown, this rule is skipped), k negatives, a graph of
  * GN2V_RESIDENT_MIN_NODES up to GN2V_RESIDENT_MAX_NODES nodes: RESIDENT CELLS -- cells of at
- * most the rows that fit one workgroup's LDS beside its staging (220 at d = 128, 109 at 256), up to
+ * most the rows that fit one workgroup's LDS beside its staging (220 at d = 128; rows wider than 128
+ * floats run workgroups of eight waves instead of sixteen: 134 at 256, 66 at 512), up to
  * GN2V_BLOCK_MAX_SLICES slices per part (one workgroup per cell), as many parts as needed (169 k
  * nodes: 4 x 256 cells of 166 rows; 1 M: 18 x 256; 10 M: 178 x 256 -- 256 slices per part on
  * one GPU; several ranks: two parts per rank with as many slices as hold the rows, 10 M nodes on

@@ -99,8 +99,11 @@ def test_automatic_plan_of_the_block_path():
     assert auto_plan(10_000_000, 1, 128, 10) == (178, 256)  # the bench graph: cells of 220 rows
     assert auto_plan(100_000_000, 1, 128, 10) == (1776, 256)  # config 5: 454 656 cells
     assert auto_plan(116_000_000, 1, 128, 10) == (442, 8)  # beyond GN2V_RESIDENT_MAX_NODES: XCD cells
-    assert auto_plan(1_000_000, 1, 256, 10) == (36, 256)  # rows of 256 floats: cells of 109 rows
-    assert auto_plan(1_000_000, 1, 260, 10) == (3, 8)    # rows too wide for the resident kernel
+    # rows wider than 128 floats: workgroups of eight waves (half the staging) -- cells of 134 rows
+    # at 256 floats, of 66 at 512; wider rows keep the XCD cells
+    assert auto_plan(1_000_000, 1, 256, 10) == (30, 256)
+    assert auto_plan(1_000_000, 1, 512, 10) == (60, 256)
+    assert auto_plan(1_000_000, 1, 516, 10) == (3, 8)
     assert auto_plan(1_000_000, 1, 128, 50) == (28, 256)  # 50 negatives: cells of 140 rows
     # several ranks: the parts travel -- two per rank (more only beyond 8 192 slices), each launched
     # by itself with all its cells -- while a part keeps 64 cells; smaller graphs travel as XCD cells
@@ -112,7 +115,8 @@ def test_automatic_plan_of_the_block_path():
         assert parts % world == 0 and parts >= 2 * world and 64 <= slices <= 8192
         assert rows(n, parts, slices) <= 220 and parts * slices <= 524288
     for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000, 300_000_000):
-        for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40), (256, 10), (224, 5)):
+        for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40), (256, 10), (224, 5), (384, 10),
+                      (512, 5)):
             parts, slices = auto_plan(n, 1, ld, k)
             # records of 32 pairs, or of 16 / 8 when their staging would leave under 64 rows
             for record in (32, 16, 8):
@@ -121,7 +125,7 @@ def test_automatic_plan_of_the_block_path():
                 # row; per row: the row, its alias entry, its node id
                 stride = (k + 1 + 3) // 4 * 4
                 words = (4 * min(ld, 128) + record + (record + 1) * stride // 2 + 2 + 3) // 4 * 4
-                staging = 16 * 4 * words + 64 + ld * 4
+                staging = (16 if ld <= 128 else 8) * 4 * words + 64 + ld * 4
                 fit = min(4095, max(0, 160 * 1024 - staging) // (ld * 4 + 12))
                 if fit >= 64:
                     break

@@ -82,7 +82,7 @@ def _step_real_walks(g, og, d, k, parts, slices, record, flags, lr=0.05, n_walks
 
 @pytest.mark.parametrize("d,k,parts,slices,record", [
     (16, 4, 2, 32, 16), (100, 5, 2, 32, 32), (128, 10, 2, 64, 32), (128, 3, 3, 17, 8),
-    (256, 5, 2, 32, 16), (64, 0, 1, 40, 32)])
+    (256, 5, 2, 32, 16), (64, 0, 1, 40, 32), (320, 4, 2, 40, 16), (512, 5, 2, 32, 32)])
 def test_deterministic_resident_step_matches_oracle(d, k, parts, slices, record):
     """Real walks (runs of equal centre, k > 0 negatives from the cell's alias table, negatives
     that fall on the context or the centre, cells of 8-30 rows in LDS): <= 1e-5 per element."""
@@ -137,7 +137,8 @@ def _unique_centre_pairs(n_nodes, parts, slices, oplan, per_cell, seed=3):
     return np.concatenate(words_l).astype(np.uint64), np.asarray(offsets, dtype=np.uint64)
 
 
-@pytest.mark.parametrize("d,k", [(16, 4), (100, 5), (128, 10), (128, 1), (256, 6)])
+@pytest.mark.parametrize("d,k", [(16, 4), (100, 5), (128, 10), (128, 1), (256, 6), (400, 5),
+                                 (512, 10), (512, 2)])
 def test_deterministic_pair_per_group_loop_matches_oracle(d, k):
     """Records of unique centres take the pair-per-group loop -- in the deterministic
     instantiation with the four groups taking turns: score_sample_pair (two samples side by
@@ -175,7 +176,7 @@ def test_deterministic_pair_per_group_loop_matches_oracle(d, k):
 
 
 @pytest.mark.parametrize("d,per_cell,slices", [(8, 150, 512), (128, 150, 512), (100, 120, 512),
-                                               (256, 70, 1024)])
+                                               (256, 70, 1024), (512, 36, 2048), (330, 36, 2048)])
 def test_parallel_resident_step_on_collision_free_pairs(d, per_cell, slices):
     """The kernel as it ships (default flags, sixteen waves per cell, LDS cursor, stride order
     with a start offset, pair per group, central rows by atomics) on 1 024 cells of <= 157 rows
@@ -263,7 +264,7 @@ def test_cells_taken_heaviest_first_train_the_same_pairs(monkeypatch, lpt):
     assert np.abs(c.cpu().numpy() - c_h).max() < 2e-5
 
 
-@pytest.mark.parametrize("d", [16, 128, 256])
+@pytest.mark.parametrize("d", [16, 128, 256, 384])
 def test_parallel_pair_per_group_adds_shared_centres_with_atomics_in_resident_cells(d):
     """Every fourth pair shares its centre with its neighbour (three runs per four pairs: the
     pair-per-group loop) -- both inside one step of four, so both groups read the row before
