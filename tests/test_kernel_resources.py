@@ -94,9 +94,19 @@ def test_resident_kernel_keeps_its_occupancy(tmp_path):
     """sgns_resident_v2_kernel<CH = 2>: sixteen waves per workgroup, one workgroup per CU -- four
     waves per SIMD means at most 128 registers, and the bench's kernel spills none."""
     table = resources("gn2v_block_api.hip", tmp_path)
+    seen = 0
     for name, r in pick(table, "sgns_resident_v2_kernelILi2E").items():
-        if name.endswith("Lb0EEEvNS_9BlockArgsE"):  # the parallel form (not the in-order one)
+        if "Lb0ELi16EEE" in name:  # the parallel form (not the in-order one), sixteen waves
             assert r["vgprs"] <= 128 and r["waves"] >= 4 and r["scratch"] == 0, (name, r)
+            seen += 1
+    assert seen == 2  # row stride a compile-time constant, or not
+    # rows of 129-512 floats: eight waves per workgroup, 256 registers a lane; no spills where the
+    # stride is the template's (256 and 512 floats)
+    for ch in (4, 8):
+        full = pick(table, f"sgns_resident_v2_kernelILi{ch}ELb1ELb0ELi8EEE")
+        assert len(full) == 1
+        for name, r in full.items():
+            assert r["waves"] >= 2 and r["scratch"] == 0, (name, r)
 
 
 @pytest.mark.timeout(1200)
