@@ -932,6 +932,16 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         if (flush_override) hot_period = (uint32_t)flush_override;
         if (!hot_period) wide = false;
     }
+    // A graph whose hub alone is more than a CU's share of all pairs (max in-degree x CUs > edges:
+    // a star of 120 k leaves on BA 1 M) DIVERGES with hot rows at lr = 0.01 -- |x| 2e8 after
+    // three epochs, link AUROC 0.45; the hand-over period above is derived for hubs that are a
+    // small part of a cell's samples -- and trains to 0.993 without them, faster
+    // (profiles/r05_logs/r5_skew_ab*.log): its rows stay ordinary rows.  (The in-degrees are
+    // known here: the hot list was made from them.)
+    if (wide && g->max_in_degree_known &&
+        (double)g->max_in_degree * g->n_cus > (double)g->view.n_edges &&
+        !getenv("GN2V_HOT_ROWS_ON_HUB_GRAPHS"))  // (set: round 4's behaviour, for A/Bs)
+        wide = false;
     const int waves_per_block = det ? 1 : wide ? 16 : gn2v::kTrainBlock / 64;
     size_t lds = (size_t)waves_per_block * per_wave_words * 4;
     if (lds > 64 * 1024 && !wide) return fail("record / negatives too large for the LDS plan");
@@ -1113,13 +1123,15 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
     // Resident cells: one workgroup per cell, and a launch cannot end before its heaviest cell.
     // The cell of the most frequent context receives h = in_degree / edges of ALL pairs on top of
     // its 1 / cells, while a balanced round takes 1 / CUs of them per CU: the other cells of the
-    // launch (a group of parts, or a travelling part of thousands of cells) keep the CUs busy
-    // meanwhile, but a round cannot take less than h.  Resident cells run at a third of the XCD
-    // cells' time: a graph whose hub alone would cost a whole balanced round more (h x CUs > 1)
-    // keeps the XCD cells, whose records are handed out by tickets to every workgroup of a slice.
+    // launch keep the CUs busy meanwhile (the heaviest cell is started first, lpt_order), but a
+    // round cannot take less than h.  Round 4 sent graphs with h x CUs > 1 to the XCD cells;
+    // measured since (BA 1 M + a star of 120 k / 300 k leaves, h x CUs = 1.6 / 3.8,
+    // profiles/r05_logs/r5_skew_ab.log): resident cells 1.48e9 / 7.5e8 pairs/s against 7.0 /
+    // 5.9e8, and the same link AUROC as the atomic modes -- so the rule now only applies from
+    // h x CUs = 8 (where a round is all hub cell), GN2V_RESIDENT_MAX_SKEW_PCT = 100 restores it.
     uint64_t hub = 0;
     if (max_in_degree(g, (hipStream_t)stream, &hub)) return 1;
-    const size_t skew_pct = env_size("GN2V_RESIDENT_MAX_SKEW_PCT", 100);
+    const size_t skew_pct = env_size("GN2V_RESIDENT_MAX_SKEW_PCT", 800);
     if ((double)hub * g->n_cus * 100.0 > (double)skew_pct * (double)g->view.n_edges)
         return auto_plan(g->view.n_nodes, world, ld, k, false, parts, slices);
     return 0;

@@ -27,6 +27,11 @@ def auc(pos, neg):
 
 def evaluate(g, c, x, n_eval, gen):
     t = g._device_tensors
+    if t is None:  # a graph built on the host
+        import numpy as np
+
+        t = {"row_ptr": torch.from_numpy(np.asarray(g.row_ptr).astype(np.int64)).cuda(),
+             "col_idx": torch.from_numpy(np.asarray(g.col_idx).astype(np.int64)).cuda()}
     n = g.get_number_of_nodes()
     e = torch.randint(0, t["col_idx"].numel(), (n_eval,), device="cuda", generator=gen)
     dst = t["col_idx"][e].long()
@@ -61,8 +66,24 @@ if __name__ == "__main__":
     ap.add_argument("--central-store", action="store_true",
                     help="blocks modes: single-run centres by a store instead of atomics")
     ap.add_argument("--group-parts", type=int, default=0, help="blocks modes: parts per group")
+    ap.add_argument("--star", type=int, default=0,
+                    help="join node 0 to this many random nodes: a hub that dominates its cell "
+                         "(the hub-skew rule of gn2v_block_auto_plan_graph)")
     a = ap.parse_args()
     g = E.barabasi_albert(a.nodes, a.m, 42)
+    if a.star:
+        import numpy as np
+
+        t = g._device_tensors
+        rp, ci = t["row_ptr"].cpu().numpy().astype(np.int64), t["col_idx"].cpu().numpy().astype(np.int64)
+        src = np.repeat(np.arange(a.nodes, dtype=np.int64), np.diff(rp))
+        keep = src < ci
+        far = np.random.RandomState(7).choice(np.arange(1, a.nodes), size=a.star, replace=False)
+        g = E.CSRGraph.from_edge_list(np.concatenate([src[keep], np.zeros(a.star, dtype=np.int64)]),
+                                      np.concatenate([ci[keep], far]), number_of_nodes=a.nodes)
+        deg = np.diff(g.row_ptr)
+        print(f"star of {a.star}: max degree {int(deg.max())}, directed edges {len(g.col_idx)}, "
+              f"hub x 256 / edges = {deg.max() * 256 / len(g.col_idx):.2f}", flush=True)
     n, d = g.get_number_of_nodes(), a.d
     wp = ops.walk_params(128, 10, 0.25, 4.0)
     flagmap = {"write_through": _lib.TRAIN_WRITE_THROUGH, "write_back": _lib.TRAIN_WRITE_BACK,

@@ -754,9 +754,10 @@ def test_parts_come_back_in_node_order_also_through_host_memory(on_host, monkeyp
 def test_a_graph_with_a_dominating_hub_keeps_the_xcd_cells():
     """gn2v_block_auto_plan_graph: resident cells -- one workgroup per cell -- cannot end a launch
     before the cell of the most frequent context is done; a graph whose largest in-degree x CUs
-    exceeds its edges (here a star of 150 000 leaves on top of a ring: the centre is the context
-    of nearly every second pair) is planned into XCD cells, whose records are handed out by
-    tickets; the ring alone gets resident cells.  Both fits count every pair and stay finite."""
+    is more than eight times its edges (here a star of 150 000 leaves on top of a ring: the
+    centre is the context of nearly every second pair, 64 x) is planned into XCD cells, whose
+    records are handed out by tickets; the ring alone gets resident cells.  Both fits count every
+    pair and stay finite."""
     n = 150_001
     ring_s, ring_d = np.arange(1, n), np.concatenate([np.arange(2, n), [1]])
     star = E.CSRGraph.from_edge_list(np.concatenate([ring_s, np.zeros(n - 1, dtype=np.int64)]),
@@ -770,6 +771,49 @@ def test_a_graph_with_a_dominating_hub_keeps_the_xcd_cells():
         c, x, st = m.fit_transform_device(g, max_walks_per_epoch=1 << 15)
         assert m.last_plan["slices"] == slices, m.last_plan
         assert st["pairs"] > 0 and bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+
+
+def _link_auroc(g, c, x, n_eval=100_000, seed=1):
+    """AUROC of c[u].x[v] + c[v].x[u]: edges against random pairs"""
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    row_ptr = torch.from_numpy(np.asarray(g.row_ptr).astype(np.int64)).cuda()
+    col = torch.from_numpy(np.asarray(g.col_idx).astype(np.int64)).cuda()
+    e = torch.randint(0, col.numel(), (n_eval,), device="cuda", generator=gen)
+    src, dst = torch.searchsorted(row_ptr, e, right=True) - 1, col[e]
+    n = g.get_number_of_nodes()
+    ru = torch.randint(0, n, (n_eval,), device="cuda", generator=gen)
+    rv = torch.randint(0, n, (n_eval,), device="cuda", generator=gen)
+    score = lambda u, v: (c[u] * x[v]).sum(1) + (c[v] * x[u]).sum(1)
+    s = torch.cat([score(src, dst), score(ru, rv)])
+    ranks = torch.empty_like(s)
+    ranks[torch.argsort(s)] = torch.arange(1, s.numel() + 1, device="cuda", dtype=s.dtype)
+    return float((ranks[:n_eval].sum() - n_eval * (n_eval + 1) / 2) / (n_eval * n_eval))
+
+
+@pytest.mark.parametrize("skew_pct,slices", [(None, 256), ("100", 8)])
+def test_a_hub_with_more_than_a_cus_share_of_the_pairs_trains_in_both_kinds_of_cells(
+        monkeypatch, skew_pct, slices):
+    """BA 1 M + a star of 120 k leaves on node 0 (largest in-degree x CUs = 1.6 x the edges).
+    Round 4 planned such graphs into XCD cells, where the hot rows' hand-over then DIVERGED within
+    three epochs (profiles/r05_logs/r5_skew_ab.log: |x| 2e8, AUROC 0.45).  Now: resident cells
+    (the hub's cell is started first; faster than the XCD cells up to several times that skew),
+    and XCD cells -- here forced by GN2V_RESIDENT_MAX_SKEW_PCT=100 -- keep such a hub's rows
+    ordinary rows: both fits stay small and separate edges from random pairs."""
+    if skew_pct:
+        monkeypatch.setenv("GN2V_RESIDENT_MAX_SKEW_PCT", skew_pct)
+    n, leaves = 1_000_000, 120_000
+    s, d = O.ba_edges(n, 10, 5)
+    far = np.random.RandomState(7).choice(np.arange(1, n), size=leaves, replace=False)
+    g = E.CSRGraph.from_edge_list(np.concatenate([s, np.zeros(leaves, dtype=np.int64)]),
+                                  np.concatenate([d, far]), number_of_nodes=n)
+    deg = np.diff(g.row_ptr)
+    assert 1.4 < deg.max() * 256 / len(g.col_idx) < 2.0
+    m = E.models.SkipGram(embedding_size=128, epochs=3, iterations=1, walk_length=128, window_size=5,
+                          verbose=False)
+    c, x, st = m.fit_transform_device(g)
+    assert m.last_plan["slices"] == slices, m.last_plan
+    assert float(c.abs().max()) < 10 and float(x.abs().max()) < 10
+    assert _link_auroc(g, c[:, :128], x[:, :128]) > 0.9
 
 
 def test_gn2v_train_takes_the_block_path_by_itself_from_2560_nodes():
