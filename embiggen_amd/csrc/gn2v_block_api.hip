@@ -119,7 +119,7 @@ uint32_t resident_rows(uint32_t ld, uint32_t record, uint32_t k) {
         // per wave: four transposition rows + the record's centres and 16-bit samples; shared:
         // the dummy row, then per cell row the row, its alias entry and its node id
         const size_t staging = (size_t)gn2v::res_words_per_wave(ld, record, k) * 4 *
-                                   resident_waves(ld) + 64 + (size_t)ld * 4;
+                                   resident_waves(ld) + 64 + (size_t)gn2v::res_lds_stride(ld) * 4;
         // (a staged sample names its row in 12 bits, the dummy row included)
         static const size_t cap = env_size("GN2V_RESIDENT_FIT_ROWS", 4095);  // A/B: pin the cells
         return staging >= lds
@@ -864,7 +864,8 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
         const size_t lds =
             v2 ? (size_t)gn2v::res_words_per_wave(tp->ld, res_record, tp->k) * 4 *
                          resident_waves(tp->ld) +
-                     (size_t)(max_cell_rows + 1) * tp->ld * 4 + (size_t)max_cell_rows * 12 + 16
+                     (size_t)(max_cell_rows + 1) * gn2v::res_lds_stride(tp->ld) * 4 +
+                     (size_t)max_cell_rows * 12 + 16
                : block_lds_words_per_wave(tp->ld, res_record, tp->k) * 4 * 16 +
                      (size_t)max_cell_rows * (tp->ld * 4 + 4) + 16;
         a.hot_n = (uint32_t)max_cell_rows;  // the rows the LDS plan is made for

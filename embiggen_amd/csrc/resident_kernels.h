@@ -45,8 +45,19 @@ __host__ __device__ __forceinline__ uint32_t res_tr_floats(uint32_t ld) { return
 __host__ __device__ __forceinline__ uint32_t res_words_per_wave(uint32_t ld, uint32_t C, uint32_t k) {
     return (4 * res_tr_floats(ld) + C + (C + 1) * res_list_stride(k) / 2 + 2 + 3) & ~3u;
 }
+// Stride of a cell's rows IN LDS: rows wider than 64 floats are padded with zeros to the width of
+// their instantiation (128, 256 or 512 floats), so that the scoring loops -- all the kernel does
+// between loading a cell and writing it back -- run without a per-chunk predicate whatever the
+// stride of the tables (a row of 224 floats ran at 0.50 of the atomic ceiling with the predicates,
+// one of 256 at 0.83).  The padding columns stay zero: a row's update is coefficient x central row,
+// whose padding is zero.
+__host__ __device__ __forceinline__ uint32_t res_lds_stride(uint32_t ld) {
+    return ld <= 64 ? ld : ld <= 128 ? 128u : ld <= 256 ? 256u : 512u;
+}
 // bytes of LDS a cell row costs: the row, its alias entry, its node id
-__host__ __device__ __forceinline__ uint32_t res_bytes_per_row(uint32_t ld) { return ld * 4 + 8 + 4; }
+__host__ __device__ __forceinline__ uint32_t res_bytes_per_row(uint32_t ld) {
+    return res_lds_stride(ld) * 4 + 8 + 4;
+}
 
 struct ResCell {
     float *rows;                      // [cell_n + 1][ld]: the cell's rows, then the dummy row
@@ -257,6 +268,8 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
                                                  unsigned long long &pairs,
                                                  unsigned long long &runs) {
     const uint32_t k = a.k, kk = k + 1, stride = res_list_stride(k), nchunks = a.ld >> 2;
+    // chunks of a row in LDS (res_lds_stride): the whole width of the instantiation from CH = 2
+    const uint32_t lchunks = CH >= 2 ? CH * 16u : (c.ld >> 2);
     const uint32_t rowmask = a.p.row_bits >= 32 ? 0xFFFFFFFFu : ((1u << a.p.row_bits) - 1u);
     unsigned short *pk16 = reinterpret_cast<unsigned short *>(s_pk);
     wave_sync();
@@ -365,7 +378,7 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
                 // (a group without a pair scores the null list: it stores nothing but the dummy
                 // row -- a stale copy of a real row written back could undo another group's update)
                 res_score_list<CH, DET>(c, u, g, have ? s_pk + pr * (stride >> 1) : null_list, kk,
-                                        lrc, a.clip, q, nchunks);
+                                        lrc, a.clip, q, lchunks);
                 // Hand-over: every group writes its gradient to its own transposition row; then
                 // the WHOLE wave adds one pair's gradient after the other to its central row --
                 // 64 lanes on 256 contiguous bytes of ONE row per atomic instruction.  (Measured,
@@ -424,7 +437,7 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
             for (uint32_t pr = r0; pr < r1; ++pr)
                 res_score_list<CH, true>(
                     c, u, g, s_pk + (grp == 0 ? pr : a.p.record) * (stride >> 1), kk, lrc, a.clip,
-                    q, nchunks);
+                    q, lchunks);
             if (grp == 0) scatter_add<CH, kWriteBack>(crow, q, nchunks, 1.0f, g, u);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             r0 = r1;
@@ -435,7 +448,7 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
 }
 
 // LDS (32-bit words): per wave res_words_per_wave(ld, C, k); then, shared by the workgroup,
-// rows [(cell rows + 1) ld] | alias [2 x cell rows] | node ids [cell rows] | cursor.
+// rows [(cell rows + 1) res_lds_stride(ld)] | alias [2 x cell rows] | node ids [cell rows] | cursor.
 template <int CH, bool DET>
 __device__ __forceinline__ void resident_cell_v2(BlockArgs &a, uint32_t *smem, uint32_t slice,
                                                  uint32_t max_rows, unsigned long long &pairs,
@@ -457,9 +470,10 @@ __device__ __forceinline__ void resident_cell_v2(BlockArgs &a, uint32_t *smem, u
     ResCell c{};
     c.rows = reinterpret_cast<float *>(shared);
     c.n = cell_n;
-    c.ld = a.ld;
+    // res_lds_stride(a.ld); the host picks CH = 1 for strides up to 64 floats, then 2, 4, 8
+    c.ld = CH >= 2 ? CH * 64u : a.ld;
     unsigned long long *s_alias =
-        reinterpret_cast<unsigned long long *>(shared + (size_t)(max_rows + 1) * a.ld);
+        reinterpret_cast<unsigned long long *>(shared + (size_t)(max_rows + 1) * c.ld);
     uint32_t *s_node = reinterpret_cast<uint32_t *>(s_alias + max_rows);
     uint32_t *s_cursor = s_node + max_rows;
     c.node = s_node;
@@ -478,11 +492,11 @@ __device__ __forceinline__ void resident_cell_v2(BlockArgs &a, uint32_t *smem, u
         return a.ctx_table ? a.ctx_table + (uint64_t)x * a.ld
                            : a.context + (uint64_t)(x / a.p.parts) * a.xld;
     };
-    for (uint32_t i = threadIdx.x; i < (cell_n + 1) * (a.ld >> 2); i += blockDim.x) {
-        const uint32_t r = i / (a.ld >> 2), c4 = i - r * (a.ld >> 2);
-        reinterpret_cast<float4 *>(c.rows + r * a.ld)[c4] =
-            r < cell_n ? reinterpret_cast<const float4 *>(row_ptr(r))[c4]
-                       : make_float4(0.f, 0.f, 0.f, 0.f);  // the dummy row
+    for (uint32_t i = threadIdx.x; i < (cell_n + 1) * (c.ld >> 2); i += blockDim.x) {
+        const uint32_t r = i / (c.ld >> 2), c4 = i - r * (c.ld >> 2);
+        reinterpret_cast<float4 *>(c.rows + r * c.ld)[c4] =
+            r < cell_n && c4 < (a.ld >> 2) ? reinterpret_cast<const float4 *>(row_ptr(r))[c4]
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);  // padding, dummy row
     }
     __syncthreads();
     const uint64_t R = (hi - lo + C - 1) / C;
@@ -517,7 +531,7 @@ __device__ __forceinline__ void resident_cell_v2(BlockArgs &a, uint32_t *smem, u
     for (uint32_t i = threadIdx.x; i < cell_n * (a.ld >> 2); i += blockDim.x) {
         const uint32_t r = i / (a.ld >> 2), c4 = i - r * (a.ld >> 2);
         reinterpret_cast<float4 *>(row_ptr(r))[c4] =
-            reinterpret_cast<const float4 *>(c.rows + r * a.ld)[c4];
+            reinterpret_cast<const float4 *>(c.rows + r * c.ld)[c4];
     }
 }
 

@@ -116,7 +116,7 @@ def test_automatic_plan_of_the_block_path():
         assert rows(n, parts, slices) <= 220 and parts * slices <= 524288
     for n in (100_000, 250_000, 1_000_000, 1_500_000, 3_000_000, 12_999_999, 30_000_000, 300_000_000):
         for ld, k in ((128, 10), (64, 5), (32, 10), (128, 40), (256, 10), (224, 5), (384, 10),
-                      (512, 5)):
+                      (512, 5), (96, 10), (160, 10)):
             parts, slices = auto_plan(n, 1, ld, k)
             # records of 32 pairs, or of 16 / 8 when their staging would leave under 64 rows
             for record in (32, 16, 8):
@@ -125,8 +125,10 @@ def test_automatic_plan_of_the_block_path():
                 # row; per row: the row, its alias entry, its node id
                 stride = (k + 1 + 3) // 4 * 4
                 words = (4 * min(ld, 128) + record + (record + 1) * stride // 2 + 2 + 3) // 4 * 4
-                staging = (16 if ld <= 128 else 8) * 4 * words + 64 + ld * 4
-                fit = min(4095, max(0, 160 * 1024 - staging) // (ld * 4 + 12))
+                # (in LDS a row wider than 64 floats is padded to 128, 256 or 512 floats)
+                lds_ld = ld if ld <= 64 else 128 if ld <= 128 else 256 if ld <= 256 else 512
+                staging = (16 if ld <= 128 else 8) * 4 * words + 64 + lds_ld * 4
+                fit = min(4095, max(0, 160 * 1024 - staging) // (lds_ld * 4 + 12))
                 if fit >= 64:
                     break
             if slices > 8:

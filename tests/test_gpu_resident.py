@@ -270,7 +270,7 @@ def test_parallel_pair_per_group_adds_shared_centres_with_atomics_in_resident_ce
     pair-per-group loop) -- both inside one step of four, so both groups read the row before
     either adds its gradient, exactly the oracle's run of two -- unique context rows, k = 0:
     the two gradients must both arrive (f32 atomics through the transposition row)."""
-    parts, slices, record = 2, 1024, 32
+    parts, slices, record = 2, 1024 if d <= 256 else 2048, 32  # (66-row cells at 512 floats)
     n = 160_005
     g = _ba(n)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
@@ -278,7 +278,7 @@ def test_parallel_pair_per_group_adds_shared_centres_with_atomics_in_resident_ce
     plan = ops.block_plan(g, 1, 0, parts, slices, 8, 2, 1, record)
     oplan = O.block_plan(n, 1, 0, parts, slices, 8, 2, 1, record)
     rng = np.random.RandomState(8)
-    per_cell = 64
+    per_cell = 64 if d <= 256 else 36
     words_l, offsets, centre = [], [0], 0
     for cell in range(parts * slices):
         part, slc = divmod(cell, slices)
