@@ -430,7 +430,8 @@ def main():
     graph = E.barabasi_albert(args.nodes, args.m, 42, device=local)
     n, d = graph.get_number_of_nodes(), args.d
     reserved = ops.graph_reserve_cus(graph, args.reserve_cus, local) if args.reserve_cus else None
-    ld = (d + 3) // 4 * 4 if d <= 16 else (d + 31) // 32 * 32  # the engine's padded row stride
+    # the engine's padded row stride (models.SkipGram.padded_size)
+    ld = (d + 3) // 4 * 4 if d <= 16 else (d + 31) // 32 * 32 if d <= 128 else (d + 63) // 64 * 64
     flags = _lib.TRAIN_SCALE_FREE | {
         "auto": 0, "write_through": _lib.TRAIN_WRITE_THROUGH,
         "write_back": _lib.TRAIN_WRITE_BACK, "atomic": _lib.TRAIN_ATOMIC}[args.mode]

@@ -691,23 +691,42 @@ static int lpt_order(gn2v_graph *g, uint32_t n, uint32_t first_cell,
     return 0;
 }
 
+template <int CH, int LDQ, bool DET>
+static void launch_resident_v2_one(dim3 grid, size_t lds, hipStream_t s, const gn2v::BlockArgs &a) {
+    constexpr int W = CH > 2 ? 8 : 16;  // resident_waves()
+    auto kernel = gn2v::sgns_resident_v2_kernel<CH, LDQ, DET, W>;
+    allow_lds(kernel, lds);
+    hipLaunchKernelGGL(kernel, DET ? dim3(1) : grid, dim3(W * 64), lds, s, a);
+}
+
+// The strides the Python classes use (models.SkipGram.padded_size: multiples of 32 floats up to
+// 128, of 64 beyond) get an instantiation with the stride as a constant; any other stride -- and
+// the deterministic form, where one workgroup walks the cells in order -- reads it from the
+// arguments.
 template <int CH>
 static void launch_resident_v2_ch(bool det, dim3 grid, size_t lds, hipStream_t s,
                                   const gn2v::BlockArgs &a) {
-    constexpr int W = CH > 2 ? 8 : 16;  // resident_waves()
-    if (det) {  // one workgroup walks the cells in order
-        auto kernel = gn2v::sgns_resident_v2_kernel<CH, false, true, W>;
-        allow_lds(kernel, lds);
-        hipLaunchKernelGGL(kernel, dim3(1), dim3(W * 64), lds, s, a);
-    } else if (a.ld == (uint32_t)CH * 64) {
-        auto kernel = gn2v::sgns_resident_v2_kernel<CH, true, false, W>;
-        allow_lds(kernel, lds);
-        hipLaunchKernelGGL(kernel, grid, dim3(W * 64), lds, s, a);
+    if (det) return launch_resident_v2_one<CH, 0, true>(grid, lds, s, a);
+    const uint32_t ldq = a.ld % 32 == 0 ? a.ld / 32 : 0;
+#define GN2V_LDQ(Q) \
+    if (ldq == Q) return launch_resident_v2_one<CH, Q, false>(grid, lds, s, a)
+    if constexpr (CH == 1) {
+        GN2V_LDQ(1);
+        GN2V_LDQ(2);
+    } else if constexpr (CH == 2) {
+        GN2V_LDQ(3);
+        GN2V_LDQ(4);
+    } else if constexpr (CH == 4) {
+        GN2V_LDQ(6);
+        GN2V_LDQ(8);
     } else {
-        auto kernel = gn2v::sgns_resident_v2_kernel<CH, false, false, W>;
-        allow_lds(kernel, lds);
-        hipLaunchKernelGGL(kernel, grid, dim3(W * 64), lds, s, a);
+        GN2V_LDQ(10);
+        GN2V_LDQ(12);
+        GN2V_LDQ(14);
+        GN2V_LDQ(16);
     }
+#undef GN2V_LDQ
+    launch_resident_v2_one<CH, 0, false>(grid, lds, s, a);
 }
 
 template <int CH>

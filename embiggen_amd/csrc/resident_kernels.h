@@ -539,9 +539,14 @@ __device__ __forceinline__ void resident_cell_v2(BlockArgs &a, uint32_t *smem, u
 // WAVES: sixteen waves per workgroup for rows up to 128 floats (four per SIMD: 128 registers);
 // eight for wider rows (two per SIMD, 256 registers: a row of 256 floats is 16 registers a lane,
 // of 512 floats 32, and a step holds five of them)
-template <int CH, bool FULL = false, bool DET = false, int WAVES = 16>
+// LDQ: the tables' row stride in units of 32 floats as a compile-time constant (0: read from the
+// arguments).  Not a nicety: with a run-time stride the per-chunk predicates of the central rows'
+// loads and of the hand-over make the compiler wait for the prefetched central row inside the
+// scoring loop and before every atomic (s_waitcnt vmcnt(0)): strides of 192 and 320 floats ran at
+// 0.51 of their atomic ceiling where 256 and 512 reached 0.83-0.91.
+template <int CH, int LDQ = 0, bool DET = false, int WAVES = 16>
 __global__ __launch_bounds__(WAVES * 64) void sgns_resident_v2_kernel(BlockArgs a) {
-    if constexpr (FULL) a.ld = CH * 64;
+    if constexpr (LDQ != 0) a.ld = LDQ * 32;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     unsigned long long pairs = 0, runs = 0;
     if constexpr (DET) {

@@ -99,14 +99,15 @@ def test_resident_kernel_keeps_its_occupancy(tmp_path):
         if "Lb0ELi16EEE" in name:  # the parallel form (not the in-order one), sixteen waves
             assert r["vgprs"] <= 128 and r["waves"] >= 4 and r["scratch"] == 0, (name, r)
             seen += 1
-    assert seen == 2  # row stride a compile-time constant, or not
+    assert seen == 3  # strides of 96 and 128 floats as constants, and the run-time stride
     # rows of 129-512 floats: eight waves per workgroup, 256 registers a lane; no spills where the
-    # stride is the template's (256 and 512 floats)
-    for ch in (4, 8):
-        full = pick(table, f"sgns_resident_v2_kernelILi{ch}ELb1ELb0ELi8EEE")
-        assert len(full) == 1
-        for name, r in full.items():
-            assert r["waves"] >= 2 and r["scratch"] == 0, (name, r)
+    # stride is a compile-time constant (multiples of 64 floats)
+    for ch, ldqs in ((4, (6, 8)), (8, (10, 12, 14, 16))):
+        for ldq in ldqs:
+            one = pick(table, f"sgns_resident_v2_kernelILi{ch}ELi{ldq}ELb0ELi8EEE")
+            assert len(one) == 1
+            for name, r in one.items():
+                assert r["waves"] >= 2 and r["scratch"] == 0, (name, r)
 
 
 @pytest.mark.timeout(1200)
