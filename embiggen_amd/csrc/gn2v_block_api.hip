@@ -1195,6 +1195,28 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     const uint64_t lds_cells =
         std::min<uint64_t>(gn2v::kMaxGroupCells,
                            (64 * 1024 - std::min<size_t>(extract_lds_bytes(walk_length, 0), 60 * 1024)) / 4);
+    // Resident cells on one GPU: a group is ONE launch, one workgroup per cell, and a launch of
+    // few cells ends on its heaviest ones -- BA 1 M (18 parts x 256 cells), kernel pairs/s by
+    // cells per launch: 768 1.79e9, 1 280 2.01e9, 2 304 2.15e9, 4 608 2.25e9
+    // (profiles/r05_logs/r5_n1m_ab.log).  So a group takes at least 4 096 cells when the plan has
+    // them (in equal groups), and when the pair words of such a group do not fit -- or exceed the
+    // third of the memory a handle keeps between fits -- the ROUND gets shorter (down to 2^20
+    // walks) before the group gets smaller.
+    if (world == 1 && slices > 16) {
+        const uint64_t min_gp = std::min<uint64_t>(parts, (4096 + slices - 1) / slices);
+        if (gp < min_gp) {
+            uint64_t groups = (parts + min_gp - 1) / min_gp;
+            // (two groups of a round twice as long hold what one group of the whole round holds:
+            // the larger launch wins -- 2.07e9 against 2.00e9 pairs/s on BA 1 M)
+            if (groups == 2 && parts * slices <= lds_cells) groups = 1;
+            gp = (parts + groups - 1) / groups;
+        }
+        gp = std::max<uint64_t>(1, std::min(gp, lds_cells / slices));
+        const uint64_t keep = std::min<uint64_t>(budget, free_bytes / 3);
+        while (r > (1ull << 20) &&
+               (walk_bytes(r) + group_bytes(r, gp) > budget || group_bytes(r, gp) > keep))
+            r /= 2;
+    }
     gp = std::max<uint64_t>(1, std::min(gp, lds_cells / slices));
     while (gp > 1 && walk_bytes(r) + group_bytes(r, gp) > budget) --gp;
     *round_walks = r;

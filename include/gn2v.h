@@ -424,7 +424,9 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
  * cell (its row is read once per such run: kernel 0.82 / 0.92 / 0.96 of the roofline at 2^20 /
  * 2^22 / 2^23 walks on the bench graph): the power of two in [2^20, 2^23] that gives 64 pairs per
  * (cell, centre), less when memory is short (>= 2^14).  group_parts: at least four groups (six on
- * one GPU in resident cells) per round when there are that many parts, more (smaller groups) when three quarters of free_bytes
+ * one GPU in resident cells, where a group is one launch and holds at least 4 096 cells when the
+ * plan has them -- the round is shortened down to 2^20 walks before such a group is cut) per
+ * round when there are that many parts, more (smaller groups) when three quarters of free_bytes
  * do not hold the walks plus, per group, its pair words once sorted (twice with `overlap`: the
  * next group is prepared while this one trains) and once unsorted, 8 B per pair.  Pure host
  * function; every rank of a job must use the same values (take the minimum). */

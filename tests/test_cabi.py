@@ -153,6 +153,12 @@ def test_round_size_and_groups_follow_the_free_memory():
     # most), and fewer when a long walk's staging leaves less room
     assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, False) == (1 << 23, 30)
     assert round_plan(150 * GB, 100_000_000, 128, 5, 1, 1776, 256, False) == (1 << 23, 54)
+    # a group is one launch: at least 4 096 cells when the plan has them, the round shortened (not
+    # the group) until the pair words fit a third of the memory -- 1 M nodes: the whole round of
+    # 2^21 walks in one launch of 4 608 cells; 2.4 M: three groups of 15 parts, rounds of 2^22
+    assert round_plan(270 * GB, 1_000_000, 128, 5, 1, 18, 256, True) == (1 << 21, 18)
+    assert round_plan(270 * GB, 2_449_029, 128, 5, 1, 44, 256, True) == (1 << 22, 15)
+    assert round_plan(270 * GB, 169_343, 128, 5, 1, 4, 256, True) == (1 << 21, 4)
     assert round_plan(250 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 4)
     assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False)[1] == 30
     assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 178, 256, False)[1] == 14
