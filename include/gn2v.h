@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GN2V_VERSION 310 /* 0.3.1: per-round placement of the contextual rows (gn2v_block_placement) */
+#define GN2V_VERSION 320 /* 0.3.2: gn2v_graph_walk_accel; resident cells for rows of up to 512 floats */
 
 #define GN2V_SENTINEL 0xFFFFFFFFu /* walk positions after a trap node */
 

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_lib.build())
     for name in declared_symbols() + declared_symbols(EXPERIMENTAL):
         assert hasattr(L, name), name
-    assert _lib.lib().gn2v_version() == 310
+    assert _lib.lib().gn2v_version() == 320
 
 
 def test_struct_layouts_match_header():
