@@ -570,8 +570,12 @@ int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_
                        (uint64_t *)unsorted, s))
         return 1;
     const uint32_t end_bit = std::max(d.ctx_bits + 1, d.ctx_bits + d.row_bits + cell_bits(d));
+    // resident plans: (cell, the centre's highest bits) -- GN2V_RESIDENT_CENTRE_SORT_BITS
+    uint32_t begin_bit = d.ctx_bits;
+    if (d.slices > gn2v_host::kCursorSlices && d.row_bits > GN2V_RESIDENT_CENTRE_SORT_BITS)
+        begin_bit += d.row_bits - GN2V_RESIDENT_CENTRE_SORT_BITS;
     return sort_words(t + head, temp_bytes - head, unsorted, (unsigned long long *)d_pairs,
-                      n_pairs, d.ctx_bits, end_bit, s);
+                      n_pairs, begin_bit, end_bit, s);
 }
 
 extern "C++" {

@@ -344,8 +344,13 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
     }
     bool ppg = true;
     if constexpr (DET) {
-        const bool starts = (uint32_t)lane < n && (lane == 0 || s_key[lane] != s_key[lane - 1]);
-        ppg = (uint32_t)__popcll(__ballot(starts)) == n;
+        // only records whose centres are ALL different (a resident plan's pairs are sorted by the
+        // centre's highest bits: equal centres need not be neighbours, and the pair-per-group
+        // loop reads the central rows of four -- with the prefetch, eight -- pairs ahead)
+        bool dup = false;
+        if ((uint32_t)lane < n)
+            for (int j = 0; j < lane; ++j) dup |= s_key[j] == s_key[lane];
+        ppg = __ballot(dup) == 0;
     }
     if (ppg) {
         // ---- pair per group: four pairs side by side; the central rows of the NEXT four are

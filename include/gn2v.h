@@ -406,6 +406,14 @@ int gn2v_graph_xcds(gn2v_graph *g);
 #define GN2V_BLOCK_MAX_CELLS 524288u      /* parts x slices of a plan                           */
 #define GN2V_BLOCK_MAX_GROUP_CELLS 16384u /* parts of an extraction group x slices (less when the
                                             * walk staging leaves less than 64 KB of LDS)      */
+/* Resident plans (more than 16 slices) sort a group's pair words by (cell, the HIGHEST
+ * GN2V_RESIDENT_CENTRE_SORT_BITS bits of the centre row), ties in extraction order: three radix
+ * passes instead of five.  What their kernel needs of the order inside a cell is that the pairs of
+ * one walk position -- up to 2 w pairs of ONE context, which four groups of a wave would otherwise
+ * update side by side -- are scattered, and that is what any bits of the centre do; pairs per
+ * (cell, centre) are one or two there, so nothing is gained from equal centres being adjacent.
+ * XCD plans keep the full (cell, centre) order: their kernel trains runs of equal centres. */
+#define GN2V_RESIDENT_CENTRE_SORT_BITS 8u
 #define GN2V_RESIDENT_MIN_NODES 100000u
 #define GN2V_RESIDENT_MAX_NODES 115000000u /* 523 776 cells of 220 rows (d = 128, k = 10)       */
 int gn2v_block_auto_plan(uint64_t n_nodes, uint32_t world, uint32_t ld, uint32_t k,

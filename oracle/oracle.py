@@ -371,14 +371,26 @@ def block_placement(n_nodes: int, classes: int, seed: int, round_id: int):
     return place, inv
 
 
+RESIDENT_CENTRE_SORT_BITS = 8  # GN2V_RESIDENT_CENTRE_SORT_BITS (include/gn2v.h)
+
+
+def block_sort_shift(plan: BlockPlan) -> int:
+    """The pair words of a group are sorted stably on the bits from here up: (cell, centre row)
+    for XCD plans, (cell, the centre row's highest RESIDENT_CENTRE_SORT_BITS bits) for resident
+    plans (more than 16 slices) -- include/gn2v.h GN2V_RESIDENT_CENTRE_SORT_BITS."""
+    if plan.slices > 16 and plan.row_bits > RESIDENT_CENTRE_SORT_BITS:
+        return plan.ctx_bits + plan.row_bits - RESIDENT_CENTRE_SORT_BITS
+    return plan.ctx_bits
+
+
 def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: int,
                   first_walk: int, sort: bool = True, hub_bits=None, part_lo: int = 0,
                   part_n: int = 0, place=None):
     """(words u64, cell_offsets): the pairs of the walks whose centre `plan.rank` owns (contexts
     in the parts part_lo, part_lo + 1, ... cyclic; 0, 0 = all) as pair words
     ``cell << (row_bits + ctx_bits) | centre row << ctx_bits | hot << (ctx_bits - 1) | context
-    row inside its cell``, sorted stably on the bits above ctx_bits (``sort=False``: extraction
-    order)."""
+    row inside its cell``, sorted stably on the bits from block_sort_shift(plan) up
+    (``sort=False``: extraction order)."""
     walks_arr = np.ascontiguousarray(walks_arr, dtype=np.uint32)
     n_walks = walks_arr.shape[0]
     L = lib()
@@ -392,7 +404,7 @@ def block_extract(g: OracleGraph, plan: BlockPlan, walks_arr, seed: int, epoch: 
     if n:
         L.o_block_extract(*args, _ptr(hub_bits), _ptr(words), _ptr(place))
         if sort:
-            L.o_block_sort(_ptr(words), C.c_uint64(n), C.c_uint32(plan.ctx_bits))
+            L.o_block_sort(_ptr(words), C.c_uint64(n), C.c_uint32(block_sort_shift(plan)))
     cells = plan.parts * plan.slices
     offsets = np.zeros(cells + 1, dtype=np.uint64)
     if sort:

@@ -67,10 +67,12 @@ def test_extraction_partitions_the_pairs_of_the_walks(world, parts, slices):
         plan = O.block_plan(97, world, rank, parts, slices, L, W, 1, 4)
         words, offsets = O.block_extract(og, plan, walks, 3, 0, 0)
         raw, _ = O.block_extract(og, plan, walks, 3, 0, 0, sort=False)
-        keys = words >> np.uint64(plan.ctx_bits)
+        shift = O.block_sort_shift(plan)  # (cell, centre); resident plans: the centre's top bits
+        assert shift == plan.ctx_bits + (max(0, plan.row_bits - 8) if slices > 16 else 0)
+        keys = words >> np.uint64(shift)
         assert (np.diff(keys.astype(np.int64)) >= 0).all()
-        # stable: pairs with equal (cell, centre) keep the extraction (walk / position / slot) order
-        order = np.argsort(raw >> np.uint64(plan.ctx_bits), kind="stable")
+        # stable: pairs with equal keys keep the extraction (walk / position / slot) order
+        order = np.argsort(raw >> np.uint64(shift), kind="stable")
         assert np.array_equal(words, raw[order])
         assert plan.key_bits <= 64 and not (words >> np.uint64(plan.key_bits)).any()
         cell, crow, vals, hot = O.block_unpack(words, plan)
