@@ -100,7 +100,8 @@ size_t env_size(const char *name, size_t fallback) {
     return v && *v ? (size_t)strtoull(v, nullptr, 10) : fallback;
 }
 
-// The resident kernel's second form (resident_kernels.h; GN2V_RESIDENT_V2=0: round 4's, for A/Bs)
+// The resident kernel's second form (resident_kernels.h; GN2V_RESIDENT_V2=0: round 4's, for speed
+// A/Bs of the parallel form only)
 bool resident_v2() {
     static const size_t v = env_size("GN2V_RESIDENT_V2", 1);
     return v != 0;
@@ -884,6 +885,10 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     if (resident) {
         a.p.record = res_record;
         const bool v2 = resident_v2();
+        if (!v2 && det)
+            return fail("GN2V_RESIDENT_V2=0 (round 4's resident kernel) is a speed A/B only: its "
+                        "deterministic form assumes that pairs of equal centre are neighbours, "
+                        "which the sort key of resident plans no longer guarantees");
         const size_t lds =
             v2 ? (size_t)gn2v::res_words_per_wave(tp->ld, res_record, tp->k) * 4 *
                          resident_waves(tp->ld) +
