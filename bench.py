@@ -557,6 +557,9 @@ def main():
 
             if n_steps == 0:
                 return
+            # the warm-up sizes the handle's round buffers for the timed call too (the handle keeps
+            # them between fits): no memory is touched for the first time inside the timed region
+            os.environ["GN2V_ROUND_BUFFERS_FOR"] = str(args.steps * args.walks)
             handle = graph.device_graph(local).handle
             stream = torch.cuda.current_stream().cuda_stream
             L = _lib.lib()
