@@ -654,10 +654,12 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
 }
 
 // Heaviest cell first (BlockArgs.order): the cells of a launch sorted by their pairs, on the
-// launch's stream, in a ring of slots owned by the handle (a slot is rewritten kLptRing launches
-// later).  Launches of fewer than two cells per CU, or of more cells than an extraction group
+// launch's stream, in a ring of slots owned by the handle -- keys, values and the sort's storage
+// of a slot are rewritten kLptRing launches later, long after the launch that read them (the
+// launches of a handle are issued stream-ordered by its callers; 64 of them are minutes of
+// training).  Launches of fewer than two cells per CU, or of more cells than an extraction group
 // may hold, keep the index order.  GN2V_RESIDENT_LPT=0: never (A/B).
-constexpr uint32_t kLptRing = 8, kLptCells = GN2V_BLOCK_MAX_GROUP_CELLS;
+constexpr uint32_t kLptRing = 64, kLptCells = GN2V_BLOCK_MAX_GROUP_CELLS;
 static int lpt_order(gn2v_graph *g, uint32_t n, uint32_t first_cell,
                      const unsigned long long *d_cell_offsets, const uint32_t **order,
                      hipStream_t s) {
@@ -673,25 +675,28 @@ static int lpt_order(gn2v_graph *g, uint32_t n, uint32_t first_cell,
             return fail("rocprim::radix_sort_pairs (size query)");
         void *temp = nullptr;
         uint32_t *buf = nullptr;
+        need = (need + 255) & ~(size_t)255;
         if (hipMalloc((void **)&buf, (size_t)kLptRing * 4 * kLptCells * 4) != hipSuccess ||
-            hipMalloc(&temp, need ? need : 16) != hipSuccess) {
+            hipMalloc(&temp, (size_t)kLptRing * (need ? need : 256)) != hipSuccess) {
             (void)hipGetLastError();
             if (buf) (void)hipFree(buf);
             return 0;  // no room: index order
         }
         g->lpt = buf;
         g->lpt_temp = temp;
-        g->lpt_temp_bytes = need;
+        g->lpt_temp_bytes = need ? need : 256;
     }
-    uint32_t *slot = g->lpt + (size_t)(g->lpt_slot++ % kLptRing) * 4 * kLptCells;
+    const uint32_t turn = g->lpt_slot++ % kLptRing;
+    uint32_t *slot = g->lpt + (size_t)turn * 4 * kLptCells;
+    void *temp = (char *)g->lpt_temp + (size_t)turn * g->lpt_temp_bytes;
     uint32_t *keys_in = slot, *keys_out = slot + kLptCells, *vals_in = slot + 2 * kLptCells,
              *vals_out = slot + 3 * kLptCells;
     hipLaunchKernelGGL(gn2v::cell_order_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
                        d_cell_offsets, first_cell, n, keys_in, vals_in);
     HIP_TRY(hipGetLastError());
     size_t bytes = g->lpt_temp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(g->lpt_temp, bytes, keys_in, keys_out, vals_in, vals_out, n,
-                                      0, 32, s));
+    HIP_TRY(rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 32,
+                                      s));
     *order = vals_out;
     return 0;
 }
