@@ -208,7 +208,7 @@ int ensure_edge_set(gn2v_graph *g, hipStream_t s) {
 
 // The edge records of the walk sampler (walk_kernels.h): 16 B per directed edge (32 B in the typed
 // form, for walks with type factors) + 4 B per node -- 3.2 GB (6.4 GB) for the 10 M / 100 M bench
-// graph.  Each form is built once per handle, on the first unweighted walk that reads it, when it
+// graph.  Each form is built once per handle, on the first walk that reads it, when it
 // fits an eighth of the free memory (a fit of a 100 M-node graph keeps that memory for its tables
 // and pair buffers: the walks are 1 % of its time); GN2V_WALK_EDGE_RECORDS=0 keeps the CSR reads
 // (same walks either way).
@@ -217,8 +217,7 @@ int ensure_edge_records(gn2v_graph *g, hipStream_t s, bool typed) {
     if (tried) return 0;
     const char *env = getenv("GN2V_WALK_EDGE_RECORDS");
     const uint64_t E = g->view.n_edges, N = g->view.n_nodes;
-    if ((env && *env == '0') || E == 0 || E >= gn2v::kRecMaxEdges || N >= 0xFFFFFFFFULL ||
-        g->view.cumw != nullptr) {
+    if ((env && *env == '0') || E == 0 || E >= gn2v::kRecMaxEdges || N >= 0xFFFFFFFFULL) {
         tried = true;  // never for this handle
         return 0;
     }

@@ -574,7 +574,8 @@ __device__ __forceinline__ Candidate<TYPED> fetch_candidate(const uint4 *__restr
     return k;
 }
 
-// The walk of walk_kernel<TYPED> on an unweighted graph read from the edge records: per walk the
+// The walk of walk_kernel<TYPED> read from the edge records (weighted graphs too: the candidate's
+// index comes from the row's cumulative weights, its record from here): per walk the
 // same draws in the same order and the same decisions, hence the same walks -- with the lanes of a
 // wave out of lock step.  In walk_kernel a step lasts as long as the slowest lane's trials (the
 // maximum of 64 geometric variables: 7 round trips at acceptance 1/2 where the mean is 2).  Here a
@@ -657,7 +658,9 @@ __global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, Wa
                 }
                 ++trial;
                 r32 = r & 0xFFFFFFFFULL;
-                if (!direct) x = fetch_candidate<TYPED>(rec, cur.start + (((r >> 32) * deg) >> 32));
+                // (weighted graphs: the candidate is found in the row's cumulative weights, as in
+                // walk_kernel; its record then saves the row_ptr read and most adjacency tests)
+                if (!direct) x = fetch_candidate<TYPED>(rec, cur.start + pick_index(g, cur.start, deg, r));
             }
             unsigned long long fword = ~0ULL, fbits = 0;
             if (do_pend && g.edge_filter) {

@@ -101,6 +101,25 @@ def test_edge_records_only_accelerate_the_reads(monkeypatch, rw, ew, directed):
     assert np.array_equal(walks["1"], O.walks(og, owp, 11, 2, 5, n, sources=g.sources))
 
 
+@pytest.mark.parametrize("rw,ew", [(1.0, 1.0), (0.25, 4.0), (2.0, 0.5)])
+def test_edge_records_on_a_weighted_graph(monkeypatch, rw, ew):
+    """Weighted graphs find the candidate in the row's cumulative weights and read its edge record
+    (the row of the node moved to, the signature for the adjacency test): the same walks with the
+    records off and in the oracle."""
+    rng = np.random.RandomState(4)
+    s, d = O.ba_edges(3000, 5, 6)
+    w = rng.uniform(0.05, 6.0, size=len(s))
+    walks = {}
+    for records in ("1", "0"):
+        monkeypatch.setenv("GN2V_WALK_EDGE_RECORDS", records)
+        g = E.CSRGraph.from_edge_list(s, d, w, number_of_nodes=3000)
+        walks[records] = _u32(ops.walks(g, ops.walk_params(40, 2, rw, ew), 9, 1, 3, 6100))
+        assert bool(ops.walk_accel(g) & ops.WALK_ACCEL_RECORDS) == (records == "1")
+    assert np.array_equal(walks["1"], walks["0"])
+    og = O.OracleGraph(g.row_ptr, g.col_idx, g.cumw)
+    assert np.array_equal(walks["1"], O.walks(og, O.WalkParams(40, 2, rw, ew, 100, 0), 9, 1, 3, 6100))
+
+
 def test_weighted_walks_bit_exact():
     rng = np.random.RandomState(3)
     s, d = O.ba_edges(800, 3, 5)
