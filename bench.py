@@ -852,7 +852,8 @@ def main():
             # kernel (its "fraction" came out at 3).  What does: every pair hands its
             # gradient to its central row with `ld` f32 atomic adds, and the L2 atomic units
             # retire 3.3e11 of them per second (round 5: without the hand-over the same kernel
-            # runs at 3.5e9 pairs/s, with it at 2.2e9; profiles/r05_logs/).  frac = atomic dwords
+            # ran at 3.5e9 pairs/s, with it at 2.2e9; the kernel of the round's end 2.5e9 against
+            # 2.3e9: profiles/r05_logs/r5_cold_centre_stores.log).  frac = atomic dwords
             # per second / that ceiling.  The byte figures stay beside it under explicit names,
             # and so does the share of the vector pipes' issue rate the arithmetic needs.
             roof = line["roofline"]
