@@ -605,6 +605,28 @@ def main():
     phase("warmup")
     run_steps(0, args.warmup)
     fence()
+    if blocks is not None and not c_entry and getattr(blocks, "_side", None) is not None:
+        # The Python trainer takes a round's walks (its own, the gathered ones, the placed ones)
+        # from torch's caching allocator, on its preparation stream; a warm-up shorter than a
+        # round leaves blocks of the wrong size there and the timed rounds would call hipMalloc
+        # for tens of GB (1-2 s, longest on a box whose memory was never touched).  As the C
+        # entry's warm-up sizes the handle's buffers for the timed call (GN2V_ROUND_BUFFERS_FOR),
+        # this fills the allocator's pool with a full round's blocks before the timed region.
+        full = min(args.round_walks, args.steps * args.walks)
+        if full > args.warmup * args.walks:
+            torch.cuda.empty_cache()
+            with torch.cuda.stream(blocks._side):
+                if phantom:
+                    hold = [torch.empty((t_world * full, 128), dtype=torch.int32, device="cuda")
+                            for _ in range(2 if blocks.permute else 1)]
+                else:
+                    hold = [torch.empty((full, 128), dtype=torch.int32, device="cuda")]
+                    hold += [torch.empty((t_world * full, 128), dtype=torch.int32, device="cuda")
+                             for _ in range((2 if blocks.permute else 1) if t_world > 1 else 0)]
+                for t in hold:
+                    t.zero_()  # touched, not only mapped
+                del hold
+            fence()
     memlog("after warm-up")
     ops.stats_reset(graph, local)
     phase("timed")
