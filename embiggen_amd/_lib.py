@@ -46,7 +46,7 @@ EXPORTS = [
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
     "gn2v_block_alias", "gn2v_block_placement_temp_bytes", "gn2v_block_placement",
     "gn2v_block_place_walks", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
-    "gn2v_block_extract", "gn2v_block_step", "gn2v_block_round", "gn2v_block_auto_plan", "gn2v_block_auto_plan_graph", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
+    "gn2v_block_extract", "gn2v_block_cell_offsets", "gn2v_block_step", "gn2v_block_round", "gn2v_block_auto_plan", "gn2v_block_auto_plan_graph", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
     "gn2v_train_blocks", "gn2v_graph_release_buffers", "gn2v_graph_walk_accel",
     "gn2v_stats_reset",
     "gn2v_stats_read",
@@ -170,6 +170,7 @@ EXPERIMENTAL_EXPORTS = ["gn2v_step"]
 
 BLOCK_WORK_WORDS = 532480   # GN2V_BLOCK_WORK_WORDS
 BLOCK_MAX_GROUP_CELLS = 16384  # GN2V_BLOCK_MAX_GROUP_CELLS
+BLOCK_MAX_WIDE_GROUP_CELLS = 65536  # GN2V_BLOCK_MAX_WIDE_GROUP_CELLS
 BLOCK_HOT_MAX = 192      # GN2V_BLOCK_HOT_MAX
 BLOCK_HOT_DEFAULT = 192  # GN2V_BLOCK_HOT_DEFAULT
 
@@ -282,6 +283,7 @@ def lib():
     L.gn2v_block_extract_temp_bytes.argtypes = [u64, C.POINTER(u64)]
     L.gn2v_block_extract.argtypes = [vp, C.POINTER(BlockPlan), vp, vp, u64, u64, u64, u64, u32,
                                      u32, vp, vp, u64, vp, vp, u64, vp]
+    L.gn2v_block_cell_offsets.argtypes = [vp, C.POINTER(BlockPlan), u32, vp, u64, vp, vp]
     L.gn2v_graph_xcds.argtypes = [vp]
     L.gn2v_graph_reserve_cus.argtypes = [vp, u32, vp]
     L.gn2v_block_step.argtypes = [vp, C.POINTER(TrainParams), C.POINTER(BlockPlan),

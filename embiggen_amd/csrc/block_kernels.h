@@ -304,7 +304,10 @@ struct ExtractArgs {
     uint64_t ekey;        // for the centre down-sampling draws (same as the walk-ordered kernels)
     uint64_t first_walk;  // id of walks[0]
     unsigned long long *wave_counts;  // [kPrepWaves]: counts out (count pass), offsets in (write)
-    unsigned long long *cell_counts;  // [cells] (count pass)
+    unsigned long long *cell_counts;  // [cells] (count pass); nullptr: the group has more cells than
+                                      // LDS counters -- only the waves' totals are counted, and
+                                      // the cell offsets are read off the sorted words afterwards
+                                      // (cell_offsets_from_sorted_kernel)
     const uint32_t *placed;  // the walks with placed node ids (place_walks_kernel), or nullptr:
                              // a context's cell follows from its node id itself
     const uint32_t *hub_bits;         // one bit per node (gn2v_block_alias), or nullptr
@@ -344,7 +347,8 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
     const uint64_t b0 = gw * chunk;
     const uint64_t b1 = b0 + chunk < a.n_walks ? b0 + chunk : a.n_walks;
     if constexpr (!WRITE) {
-        for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock) s_hist[c] = 0;
+        if (a.cell_counts)
+            for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock) s_hist[c] = 0;
         __syncthreads();
     }
     unsigned long long base = 0;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
                 if (valid) a.pairs[base + __popcll(mask & lt_mask)] = word;
                 base += __popcll(mask);
             } else {
-                if (valid) {
+                if (valid && a.cell_counts) {
                     const uint32_t part = a.p.dslices.div(cell), sl = cell - part * a.p.slices;
                     const uint32_t rel = part >= a.part_lo ? part - a.part_lo
                                                            : part + a.p.parts - a.part_lo;
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_kernel(ExtractArgs a
     if constexpr (!WRITE) {
         if (lane == 0) a.wave_counts[gw] = total;
         __syncthreads();
-        for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock)
+        for (uint32_t c = threadIdx.x; a.cell_counts && c < cells; c += kPrepBlock)
             if (s_hist[c]) {
                 const uint32_t rel = c / a.p.slices, sl = c - rel * a.p.slices;
                 uint32_t part = a.part_lo + rel;
@@ -508,7 +512,8 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractA
     const uint64_t b0 = gw * chunk;
     const uint64_t b1 = b0 + chunk < a.n_walks ? b0 + chunk : a.n_walks;
     if constexpr (!WRITE) {
-        for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock) s_hist[c] = 0;
+        if (a.cell_counts)
+            for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock) s_hist[c] = 0;
         __syncthreads();
     }
     unsigned long long base = 0;
@@ -571,7 +576,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractA
             uint32_t n0 = 0, n1 = 0;
             if (g0) n0 = popc_and(window_mask(lane, w, md), own);
             if (g1) n1 = popc_and(window_mask(lane + 64, w, md), own);
-            if (n0 | n1) {
+            if ((n0 | n1) && a.cell_counts) {
                 const uint32_t slices = a.p.slices;
                 auto gidx = [&](uint32_t cell) {
                     const uint32_t part = a.p.dslices.div(cell), sl = cell - part * slices;
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(kPrepBlock) void block_extract_fast_kernel(ExtractA
     if constexpr (!WRITE) {
         if (lane == 0) a.wave_counts[gw] = total;
         __syncthreads();
-        for (uint32_t c = threadIdx.x; c < cells; c += kPrepBlock)
+        for (uint32_t c = threadIdx.x; a.cell_counts && c < cells; c += kPrepBlock)
             if (s_hist[c]) {
                 const uint32_t rel = c / a.p.slices, sl = c - rel * a.p.slices;
                 uint32_t part = a.part_lo + rel;
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(1024) void block_scan_kernel(unsigned long long *wa
     const uint32_t chunk = (cells + 1023) / 1024;
     const uint32_t c0 = min(cells, threadIdx.x * chunk), c1 = min(cells, c0 + chunk);
     unsigned long long csum = 0;
-    for (uint32_t c = c0; c < c1; ++c) csum += cell_counts[c];
+    for (uint32_t c = c0; cell_counts && c < c1; ++c) csum += cell_counts[c];
     cpart[threadIdx.x] = csum;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -682,15 +687,35 @@ __global__ __launch_bounds__(1024) void block_scan_kernel(unsigned long long *wa
             run += v;
             off += cv;
         }
-        cell_offsets[cells] = off;
+        // (no cell counters: the total of the waves; the other offsets follow the sort)
+        cell_offsets[cells] = cell_counts ? off : run;
     }
     __syncthreads();
     for (uint32_t e = 0; e < per; ++e) wave_counts[threadIdx.x * per + e] = part[threadIdx.x] + loc[e];
     unsigned long long off = cpart[threadIdx.x];
-    for (uint32_t c = c0; c < c1; ++c) {
+    for (uint32_t c = c0; cell_counts && c < c1; ++c) {
         cell_offsets[c] = off;
         off += cell_counts[c];
     }
+}
+
+// cell_offsets[c] = first sorted pair word whose cell is >= c, c = 0 .. cells (the oracle's
+// o_block_cell_offsets): what the counters of the counting pass give for groups that have them
+static __global__ void cell_offsets_from_sorted_kernel(const unsigned long long *__restrict__ words,
+                                                       unsigned long long n, uint32_t cell_shift,
+                                                       uint32_t cells,
+                                                       unsigned long long *__restrict__ cell_offsets) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > cells) return;
+    unsigned long long lo = 0, hi = n;
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        if ((words[mid] >> cell_shift) < c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    cell_offsets[c] = lo;
 }
 
 // --------------------------------------------------------------------------------------------

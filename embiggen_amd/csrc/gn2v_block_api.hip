@@ -172,10 +172,17 @@ int check_group(const gn2v_block_plan *p, uint32_t part_lo, uint32_t *part_n) {
     if (*part_n == 0 && part_lo == 0) *part_n = p->parts;  // 0, 0 = every part
     if (part_lo >= p->parts || *part_n < 1 || *part_n > p->parts)
         return fail("group of parts out of range");
-    if ((uint64_t)*part_n * p->slices > gn2v::kMaxGroupCells)
-        return fail("a group of parts may hold at most " + std::to_string(gn2v::kMaxGroupCells) +
+    if ((uint64_t)*part_n * p->slices > GN2V_BLOCK_MAX_WIDE_GROUP_CELLS)
+        return fail("a group of parts may hold at most " +
+                    std::to_string(GN2V_BLOCK_MAX_WIDE_GROUP_CELLS) +
                     " cells (parts of the group x slices): extract fewer parts at a time");
     return 0;
+}
+
+// a group with more cells than the counting pass has LDS counters for (include/gn2v.h)
+bool wide_group(const gn2v::BlockPlan &d, uint32_t part_n) {
+    const uint64_t cells = (uint64_t)part_n * d.slices;
+    return cells > gn2v::kMaxGroupCells || extract_lds_bytes(d.L, (uint32_t)cells) > 64 * 1024;
 }
 
 // Stable radix sort of the pair words on the bits [begin_bit, end_bit) between two buffers of the
@@ -488,15 +495,16 @@ static int launch_extract(gn2v_graph *g, const gn2v::BlockPlan &d, bool write,
     a.n_walks = n_walks;
     a.ekey = gn2v::epoch_key(seed, epoch);
     a.first_walk = first_walk;
+    const bool wide = wide_group(d, part_n);
     a.wave_counts = (unsigned long long *)d_work;
-    a.cell_counts = (unsigned long long *)d_work + gn2v::kPrepWaves;
+    a.cell_counts = wide ? nullptr : (unsigned long long *)d_work + gn2v::kPrepWaves;
     a.hub_bits = d_hub_bits;
     a.pairs = (unsigned long long *)pairs;
     a.part_lo = part_lo;
     a.part_n = part_n;
     // the counting pass keeps one LDS counter per cell of the group; the writing pass needs the
     // walk staging only (and runs twice as many waves per CU without the counters)
-    const size_t lds = extract_lds_bytes(d.L, write ? 0 : part_n * d.slices);
+    const size_t lds = extract_lds_bytes(d.L, write || wide ? 0 : part_n * d.slices);
     if (lds > 64 * 1024) return fail("walk_length too large for the extraction's LDS plan");
     const dim3 grid(gn2v::kPrepWaves / (gn2v::kPrepBlock / 64)), block(gn2v::kPrepBlock);
     if (extract_fast(d.L, d.window)) {
@@ -532,9 +540,32 @@ int gn2v_block_count(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_t 
         launch_extract(g, d, false, d_walks, d_placed_walks, n_walks, seed, epoch, first_walk,
                        part_lo, part_n, d_work, nullptr, nullptr, s))
         return 1;
+    // (a wide group: no counters -- only d_cell_offsets[cells], the number of pairs, is written)
     hipLaunchKernelGGL(gn2v::block_scan_kernel, dim3(1), dim3(1024), 0, s,
                        (unsigned long long *)d_work,
-                       (const unsigned long long *)d_work + gn2v::kPrepWaves, d.parts * d.slices,
+                       wide_group(d, part_n)
+                           ? (const unsigned long long *)nullptr
+                           : (const unsigned long long *)d_work + gn2v::kPrepWaves,
+                       d.parts * d.slices, (unsigned long long *)d_cell_offsets);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int gn2v_block_cell_offsets(gn2v_graph *g, const gn2v_block_plan *plan, uint32_t part_n,
+                            const uint64_t *d_pairs, uint64_t n_pairs, uint64_t *d_cell_offsets,
+                            void *stream) {
+    if (check_plan(g, plan)) return 1;
+    const gn2v::BlockPlan d = device_plan(g, plan);
+    uint32_t lo = 0;
+    if (check_key_width(d) || check_group(plan, lo, &part_n)) return 1;
+    if (!wide_group(d, part_n)) return 0;  // counted: gn2v_block_count wrote them
+    if (!d_cell_offsets || (n_pairs && !d_pairs)) return fail("NULL pointer");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    const uint32_t cells = d.parts * d.slices;
+    hipLaunchKernelGGL(gn2v::cell_offsets_from_sorted_kernel, dim3((cells + 1 + 255) / 256),
+                       dim3(256), 0, (hipStream_t)stream, (const unsigned long long *)d_pairs,
+                       (unsigned long long)n_pairs, d.row_bits + d.ctx_bits, cells,
                        (unsigned long long *)d_cell_offsets);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -659,7 +690,7 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
 // launches of a handle are issued stream-ordered by its callers; 64 of them are minutes of
 // training).  Launches of fewer than two cells per CU, or of more cells than an extraction group
 // may hold, keep the index order.  GN2V_RESIDENT_LPT=0: never (A/B).
-constexpr uint32_t kLptRing = 64, kLptCells = GN2V_BLOCK_MAX_GROUP_CELLS;
+constexpr uint32_t kLptRing = 64, kLptCells = 16384;
 static int lpt_order(gn2v_graph *g, uint32_t n, uint32_t first_cell,
                      const unsigned long long *d_cell_offsets, const uint32_t **order,
                      hipStream_t s) {
@@ -1202,7 +1233,9 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     // (six on one GPU in resident cells: the first group of a round is prepared in line, and the
     // pair buffers of a quarter of a round -- two sets -- are more than a handle keeps between
     // two fits: the second fit of the bench waited 1.8 s for the driver to clear them again)
-    const uint64_t min_groups = world == 1 && slices > 16 ? 6 : 4;
+    // (several ranks in resident cells: two -- every scan of a group reads the walks of ALL ranks,
+    // and a group may be wide there: more cells than the counting pass has LDS counters)
+    const uint64_t min_groups = slices > 16 ? (world == 1 ? 6 : 2) : 4;
     uint64_t gp = std::max<uint64_t>(1, (parts + min_groups - 1) / min_groups);
     // the extraction counts the cells of a group in LDS: kMaxGroupCells at most, and fewer when
     // the walk's staging leaves less of the 64 KB
@@ -1231,8 +1264,12 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
                (walk_bytes(r) + group_bytes(r, gp) > budget || group_bytes(r, gp) > keep))
             r /= 2;
     }
-    gp = std::max<uint64_t>(1, std::min(gp, lds_cells / slices));
+    const uint64_t cap_cells =
+        world > 1 && slices > 16 ? (uint64_t)GN2V_BLOCK_MAX_WIDE_GROUP_CELLS : lds_cells;
+    gp = std::max<uint64_t>(1, std::min(gp, cap_cells / slices));
     while (gp > 1 && walk_bytes(r) + group_bytes(r, gp) > budget) --gp;
+    // equal groups: as many as that size needs, none of them a remainder of a part or two
+    gp = (parts + (parts + gp - 1) / gp - 1) / ((parts + gp - 1) / gp);
     *round_walks = r;
     *group_parts = (uint32_t)gp;
     return 0;
@@ -1310,6 +1347,8 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
         if (gn2v_block_extract(g, pj, io->d_walks, io->d_placed_walks, n_walks, seed, epoch,
                                first_walk, p0, pn, work_of[slot], io->d_hub_bits, *n_pairs,
                                pairs_of[slot], io->d_temp, io->temp_bytes, side))
+            return 1;
+        if (gn2v_block_cell_offsets(g, pj, pn, pairs_of[slot], *n_pairs, offsets_of[slot], side))
             return 1;
         if (overlapped) HIP_TRY(hipEventRecord(g->prep_done[slot], side));
         return 0;

@@ -312,6 +312,9 @@ class GpuBlockBackend:
         ops.block_extract(self.graph, plan, walks_all, seed, epoch, first_walk, work, n_pairs,
                           pairs=pairs, temp=temp, hub_bits=hub_bits, part_lo=part_lo,
                           part_n=part_n, placed=placed)
+        # (a wide group -- more cells than the counting pass counts in LDS -- gets its cell
+        # offsets from the sorted words; a counted group has them already)
+        ops.block_cell_offsets(self.graph, plan, part_n, pairs, n_pairs, offsets)
         if os.environ.get("GN2V_BENCH_MEMLOG"):
             print(f"[mem] prepare: parts {part_lo}+{part_n}: {n_pairs} pairs, room "
                   f"{pairs.numel()}, slot {slot}, allocated "
@@ -477,6 +480,8 @@ class BlockPartitionedTrainer:
         staging = 4 * (5 if walk_length <= 128 else 4) * walk_length * 4
         most = max(1, min(_l.BLOCK_MAX_GROUP_CELLS, (64 * 1024 - min(staging, 60 * 1024)) // 4)
                    // slices)
+        if world > 1 and slices > 16:  # wide groups: their offsets follow the sort
+            most = max(1, _l.BLOCK_MAX_WIDE_GROUP_CELLS // slices)
         self.group_parts = min(most, parts if not group_parts else max(1, min(int(group_parts), parts)))
         self.stripes = max(1, int(stripes))
         if self.stripes > 1 and world > 1:

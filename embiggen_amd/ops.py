@@ -285,6 +285,18 @@ def block_extract(graph: CSRGraph, plan, walks_tensor, seed: int, epoch: int, fi
     return pairs
 
 
+def block_cell_offsets(graph: CSRGraph, plan, part_n: int, pairs, n_pairs: int, cell_offsets):
+    """After ``block_extract``: the cell offsets of a WIDE group (more cells than the counting
+    pass has LDS counters: ``gn2v_block_count`` wrote only their last entry, the number of
+    pairs) read off the sorted words; does nothing for a group that was counted."""
+    dev = pairs.device
+    dg = graph.device_graph(dev.index or 0)
+    _lib.check(_lib.lib().gn2v_block_cell_offsets(
+        dg.handle, C.byref(plan), part_n, pairs.data_ptr(), n_pairs, cell_offsets.data_ptr(),
+        _stream(dev)))
+    return cell_offsets
+
+
 def block_step(graph: CSRGraph, tp, plan, pairs, cell_offsets, alias, cell_rows, central,
                context, block_id: int, part: int, seed: int, epoch: int, lr: float,
                whole_central: bool = False, whole_context: bool = False, hot=None, inv=None,

@@ -332,6 +332,14 @@ int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_
                        const uint32_t *d_hub_bits, uint64_t n_pairs, uint64_t *d_pairs,
                        void *d_temp, uint64_t temp_bytes, void *stream);
 
+/* The cell offsets of a group's SORTED pair words (d_cell_offsets[c] = first word whose cell is
+ * >= c, c = 0 .. parts x slices): what gn2v_block_count wrote for a group whose cells it counted,
+ * and the only source for a wide group (GN2V_BLOCK_MAX_WIDE_GROUP_CELLS).  Does nothing for a
+ * group that was counted (part_n x slices within the LDS counters). */
+int gn2v_block_cell_offsets(gn2v_graph *g, const gn2v_block_plan *plan, uint32_t part_n,
+                            const uint64_t *d_pairs, uint64_t n_pairs, uint64_t *d_cell_offsets,
+                            void *stream);
+
 typedef struct {
     const uint64_t *d_pairs;         /* sorted pair words of the group (gn2v_block_extract)    */
     const uint64_t *d_cell_offsets;  /* [cells + 1] (gn2v_block_count)                         */
@@ -404,8 +412,13 @@ int gn2v_graph_xcds(gn2v_graph *g);
  * the walk-ordered schedule's: 10 M nodes -> 38 x 8, 100 M -> 381 x 8. */
 #define GN2V_BLOCK_MAX_SLICES 8192u
 #define GN2V_BLOCK_MAX_CELLS 524288u      /* parts x slices of a plan                           */
-#define GN2V_BLOCK_MAX_GROUP_CELLS 16384u /* parts of an extraction group x slices (less when the
-                                            * walk staging leaves less than 64 KB of LDS)      */
+#define GN2V_BLOCK_MAX_GROUP_CELLS 16384u /* cells of an extraction group that are COUNTED in LDS
+                                            * (less when the walk staging leaves less than 64 KB) */
+/* A group may hold more cells than that ("wide": several ranks, where every scan of a group reads
+ * the walks of all ranks and fewer, larger groups pay): gn2v_block_count then counts the pairs
+ * only (d_cell_offsets[cells] = their number, the other entries are not written) and the caller
+ * asks for the offsets after the sort -- gn2v_block_cell_offsets. */
+#define GN2V_BLOCK_MAX_WIDE_GROUP_CELLS 65536u
 /* Resident plans (more than 16 slices) sort a group's pair words by (cell, the HIGHEST
  * GN2V_RESIDENT_CENTRE_SORT_BITS bits of the centre row), ties in extraction order: three radix
  * passes instead of five.  What their kernel needs of the order inside a cell is that the pairs of

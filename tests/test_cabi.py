@@ -159,7 +159,12 @@ def test_round_size_and_groups_follow_the_free_memory():
     assert round_plan(270 * GB, 1_000_000, 128, 5, 1, 18, 256, True) == (1 << 21, 18)
     assert round_plan(270 * GB, 2_449_029, 128, 5, 1, 44, 256, True) == (1 << 22, 15)
     assert round_plan(270 * GB, 169_343, 128, 5, 1, 4, 256, True) == (1 << 21, 4)
-    assert round_plan(250 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 4)
+    # several ranks: every scan of a group reads the walks of ALL ranks -- two groups a round when
+    # memory allows (wide groups: their cell offsets follow the sort), more when it does not
+    # (equal groups: 6 + 6 + 4, never 7 + 7 + 2)
+    assert round_plan(300 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 8)
+    assert round_plan(285 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 6)
+    assert round_plan(250 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 6)
     assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False)[1] == 30
     assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 178, 256, False)[1] == 14
     # eight GPUs, a group in preparation while one trains

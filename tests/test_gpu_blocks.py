@@ -112,6 +112,40 @@ def test_extraction_and_sort_are_bit_exact(world, rank, parts, slices, md):
     assert int(off0.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("world,rank", [(1, 0), (4, 3)])
+def test_a_wide_group_gets_its_cell_offsets_from_the_sorted_words(world, rank):
+    """A group of more cells than the counting pass has LDS counters (here 3 parts x 6 000 = 18 000
+    of a plan of 4 x 6 000; the counters end at 13 824 beside the staging of a walk of 128):
+    gn2v_block_count counts the pairs only, gn2v_block_cell_offsets reads the offsets off the
+    sorted words -- pair words and offsets equal the oracle's, and the same group extracted as
+    three counted groups of one part gives the same words part by part."""
+    n, parts, slices = 60_001, 4, 6000
+    g = _ba(n)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    wk = ops.walks(g, ops.walk_params(128, 4, 0.5, 2.0), 5, 1, 100, 3000)
+    wk[::5, 90:] = -1
+    plan = ops.block_plan(g, world, rank, parts, slices, 128, 4, 1, 16)
+    oplan = O.block_plan(n, world, rank, parts, slices, 128, 4, 1, 16)
+    lo, cnt = 2, 3  # cyclic: parts 2, 3, 0
+    work, goff = ops.block_count(g, plan, wk, 5, 1, 100, part_lo=lo, part_n=cnt)
+    m = int(goff[-1])
+    grp = ops.block_extract(g, plan, wk, 5, 1, 100, work, m, part_lo=lo, part_n=cnt)
+    ops.block_cell_offsets(g, plan, cnt, grp, m, goff)
+    gw, go = O.block_extract(og, oplan, _u32(wk), 5, 1, 100, part_lo=lo, part_n=cnt)
+    assert m == len(gw) > 0
+    assert np.array_equal(_words(grp), gw)
+    assert np.array_equal(goff.cpu().numpy().astype(np.uint64), go)
+    pieces = []
+    for p in (0, 2, 3):  # in cell order
+        w1, o1 = ops.block_count(g, plan, wk, 5, 1, 100, part_lo=p, part_n=1)
+        one = ops.block_extract(g, plan, wk, 5, 1, 100, w1, int(o1[-1]), part_lo=p, part_n=1)
+        before = o1.clone()
+        ops.block_cell_offsets(g, plan, 1, one, int(o1[-1]), o1)  # a counted group: untouched
+        assert torch.equal(before, o1)
+        pieces.append(_words(one))
+    assert np.array_equal(np.concatenate(pieces), gw)
+
+
 def test_pair_words_of_a_graph_whose_cell_and_row_do_not_fit_32_bits():
     """2^23 nodes on one rank (23 row bits) x 1 024 cells (10 bits) + 11 context bits: the pair
     word uses 47 of its 64 bits; extraction + sort stay bit-exact and a deterministic step still
