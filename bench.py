@@ -524,6 +524,12 @@ def main():
             auto_walks, auto_group = int(agreed[0]), int(agreed[1])
         if not args.round_walks:
             args.round_walks = stripes * auto_walks
+            # equal rounds (as gn2v_train_blocks cuts an epoch): 20 steps of 2^20 walks are three
+            # rounds of 6.99 M, not two of 2^23 and a half one
+            total = args.steps * args.walks
+            if total > args.round_walks:
+                n_rounds = -(-total // args.round_walks)
+                args.round_walks = -(-total // n_rounds)
         blocks.group_parts = max(1, min(args.group_parts or auto_group, blocks.parts))
         # warm-up and timed rounds share their buffers (a phantom rank is handed all ranks' walks)
         blocks.round_capacity = (min(args.round_walks, (args.warmup + args.steps) * args.walks)

@@ -1579,6 +1579,14 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     }
     const uint64_t planned_walks = round_walks;
     round_walks = std::max<uint64_t>(1, std::min(round_walks, (walks_per_epoch + V - 1) / V));
+    if (automatic) {
+        // equal rounds: an epoch of 2.5 planned rounds is trained as three of 5 / 6 of the size,
+        // not as two and a half (the half round pays a whole round's placement, alias tables and
+        // first preparation for half the pairs)
+        const uint64_t per_pass = (walks_per_epoch + V - 1) / V;
+        const uint64_t n_rounds = (per_pass + round_walks - 1) / round_walks;
+        round_walks = std::max<uint64_t>(1, (per_pass + n_rounds - 1) / n_rounds);
+    }
     // GN2V_ROUND_BUFFERS_FOR=<walks per epoch>: a caller that will come back to this handle with
     // that many walks (bench.py's warm-up before its timed call) has the round buffers sized for
     // it now, so that the later call finds them kept -- memory touched for the first time inside
