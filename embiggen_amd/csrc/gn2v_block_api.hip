@@ -690,7 +690,7 @@ static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, s
 // launches of a handle are issued stream-ordered by its callers; 64 of them are minutes of
 // training).  Launches of fewer than two cells per CU, or of more cells than an extraction group
 // may hold, keep the index order.  GN2V_RESIDENT_LPT=0: never (A/B).
-constexpr uint32_t kLptRing = 64, kLptCells = 16384;
+constexpr uint32_t kLptRing = 32, kLptCells = GN2V_BLOCK_MAX_WIDE_GROUP_CELLS;
 static int lpt_order(gn2v_graph *g, uint32_t n, uint32_t first_cell,
                      const unsigned long long *d_cell_offsets, const uint32_t **order,
                      hipStream_t s) {
@@ -1251,21 +1251,31 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     // walks) before the group gets smaller.
     if (world == 1 && slices > 16) {
         const uint64_t min_gp = std::min<uint64_t>(parts, (4096 + slices - 1) / slices);
+        uint64_t floor_gp = gp;
         if (gp < min_gp) {
             uint64_t groups = (parts + min_gp - 1) / min_gp;
             // (two groups of a round twice as long hold what one group of the whole round holds:
             // the larger launch wins -- 2.07e9 against 2.00e9 pairs/s on BA 1 M)
-            if (groups == 2 && parts * slices <= lds_cells) groups = 1;
-            gp = (parts + groups - 1) / groups;
+            if (groups == 2 && parts * slices <= GN2V_BLOCK_MAX_WIDE_GROUP_CELLS) groups = 1;
+            floor_gp = gp = (parts + groups - 1) / groups;
+        } else {
+            floor_gp = min_gp;
         }
-        gp = std::max<uint64_t>(1, std::min(gp, lds_cells / slices));
+        const uint64_t wide_gp = std::max<uint64_t>(1, GN2V_BLOCK_MAX_WIDE_GROUP_CELLS / slices);
+        gp = std::min(gp, wide_gp);
+        floor_gp = std::min(floor_gp, gp);
         const uint64_t keep = std::min<uint64_t>(budget, free_bytes / 3);
-        while (r > (1ull << 20) &&
-               (walk_bytes(r) + group_bytes(r, gp) > budget || group_bytes(r, gp) > keep))
-            r /= 2;
+        auto too_big = [&](uint64_t rw, uint64_t g_) {
+            return walk_bytes(rw) + group_bytes(rw, g_) > budget || group_bytes(rw, g_) > keep;
+        };
+        // the round is shortened for the sake of the floor only; a group larger than the floor
+        // (a wide group: BA 100 M) is cut down to what the handle keeps instead
+        while (r > (1ull << 20) && too_big(r, floor_gp)) r /= 2;
+        while (gp > floor_gp && too_big(r, gp)) --gp;
     }
-    const uint64_t cap_cells =
-        world > 1 && slices > 16 ? (uint64_t)GN2V_BLOCK_MAX_WIDE_GROUP_CELLS : lds_cells;
+    // (resident plans: a group may be wide -- gn2v_block_cell_offsets; BA 100 M then takes 7 groups
+    // of 254 parts a round instead of 33 of 54)
+    const uint64_t cap_cells = slices > 16 ? (uint64_t)GN2V_BLOCK_MAX_WIDE_GROUP_CELLS : lds_cells;
     gp = std::max<uint64_t>(1, std::min(gp, cap_cells / slices));
     while (gp > 1 && walk_bytes(r) + group_bytes(r, gp) > budget) --gp;
     // equal groups: as many as that size needs, none of them a remainder of a part or two

@@ -152,7 +152,8 @@ def test_round_size_and_groups_follow_the_free_memory():
     # the cells of a group in LDS, 13 824 of them beside the staging of a walk of 128 (16 384 at
     # most), and fewer when a long walk's staging leaves less room
     assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, False) == (1 << 23, 30)
-    assert round_plan(150 * GB, 100_000_000, 128, 5, 1, 1776, 256, False) == (1 << 23, 54)
+    # (a wide group: more cells than LDS counters -- 7 groups a round where 13 824 counters gave 33)
+    assert round_plan(150 * GB, 100_000_000, 128, 5, 1, 1776, 256, False) == (1 << 23, 254)
     # a group is one launch: at least 4 096 cells when the plan has them, the round shortened (not
     # the group) until the pair words fit a third of the memory -- 1 M nodes: the whole round of
     # 2^21 walks in one launch of 4 608 cells; 2.4 M: three groups of 15 parts, rounds of 2^22
@@ -165,8 +166,10 @@ def test_round_size_and_groups_follow_the_free_memory():
     assert round_plan(300 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 8)
     assert round_plan(285 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 6)
     assert round_plan(250 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 6)
-    assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False)[1] == 30
-    assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 178, 256, False)[1] == 14
+    # (longer walks: four to six times the pairs per walk -- the groups above the floor of 16
+    # parts are cut to what a handle keeps, then the round is shortened)
+    assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False) == (8388608, 20)
+    assert round_plan(270 * GB, 10_000_000, 800, 5, 1, 178, 256, False) == (4194304, 26)
     # eight GPUs, a group in preparation while one trains
     assert round_plan(270 * GB, 10_000_000, 128, 5, 8, 32, 8, True) == (1 << 23, 8)
     # 100 M nodes on one GPU, 170 GB free beside the tables

@@ -177,13 +177,13 @@ def test_config5a_bench_graph_with_xcd_cells(monkeypatch):
 
 def test_config5_ba_100m_block_path_full_size_properties():
     """BASELINE config 5 (BA 100 M / 1 B) on one GPU: resident cells, 1 776 parts x 256 cells of
-    220 rows (454 656 cells: 55-bit pair words, 19 + 27 + 9), extracted 54 parts at a time (the
-    extraction counts a group's cells in LDS: 13 824 beside the staging of a walk of 128),
+    220 rows (454 656 cells: 55-bit pair words, 19 + 27 + 9), extracted in wide groups of some 200
+    parts (more cells than the counting pass has LDS counters: their offsets follow the sort),
     100 M-row alias tables rebuilt with every round's placement, the 51.2 GB contextual table
     trained where it lies, in node order."""
     g = E.barabasi_albert(100_000_000, 10, 42)
     plan, _ = block_path_properties(g, 1 << 17, {"parts": 1776, "slices": 256})
-    assert plan["group_parts"] == 54
+    assert 54 < plan["group_parts"] <= 256
 
 
 def test_config5_ba_100m_with_xcd_cells(monkeypatch):
