@@ -60,7 +60,8 @@ def round_plan(free_bytes: int, n_nodes: int, walk_length: int, window: int, wor
                parts: int, slices: int, overlap: bool) -> Tuple[int, int]:
     """(walks per rank and round, parts per extraction group) for ``free_bytes`` of HBM
     (``gn2v_block_round_plan``: a round long enough for 64 pairs per (cell, centre) within
-    [2^20, 2^23] walks; groups of parts -- at least four per round -- whose pair words, held once
+    [2^20, 2^23] walks; equal groups of parts -- at least four per round (resident cells: six on
+    one GPU, two with several ranks; include/gn2v.h) -- whose pair words, held once
     sorted (twice when the next group is prepared meanwhile) and once unsorted, fit three quarters
     of it beside the walks).  Every rank must use the same values."""
     import ctypes as C

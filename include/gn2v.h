@@ -444,13 +444,17 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
  * once tables and graph are resident).  The longer a round, the more pairs of a centre meet in a
  * cell (its row is read once per such run: kernel 0.82 / 0.92 / 0.96 of the roofline at 2^20 /
  * 2^22 / 2^23 walks on the bench graph): the power of two in [2^20, 2^23] that gives 64 pairs per
- * (cell, centre), less when memory is short (>= 2^14).  group_parts: at least four groups (six on
- * one GPU in resident cells, where a group is one launch and holds at least 4 096 cells when the
- * plan has them -- the round is shortened down to 2^20 walks before such a group is cut) per
- * round when there are that many parts, more (smaller groups) when three quarters of free_bytes
- * do not hold the walks plus, per group, its pair words once sorted (twice with `overlap`: the
- * next group is prepared while this one trains) and once unsorted, 8 B per pair.  Pure host
- * function; every rank of a job must use the same values (take the minimum). */
+ * (cell, centre), less when memory is short (>= 2^14).  group_parts, in equal groups: XCD plans
+ * at least four groups a round; resident plans on one GPU at least six, where a group is one launch
+ * and holds at least 4 096 cells when the plan has them (the round is shortened down to 2^20 walks
+ * before such a group is cut; groups above that floor are cut to a third of free_bytes, what a
+ * handle keeps between fits); resident plans on several ranks at least two (every scan of a group
+ * reads the walks of ALL ranks).  Resident groups may be wide (GN2V_BLOCK_MAX_WIDE_GROUP_CELLS).
+ * More, smaller groups when three quarters of free_bytes do not hold the walks plus, per group,
+ * its pair words once sorted (twice with `overlap`: the next group is prepared while this one
+ * trains) and once unsorted, 8 B per pair.  Pure host function; every rank of a job must use the
+ * same values (take the minimum).  gn2v_train_blocks cuts an epoch into EQUAL rounds of at most
+ * round_walks. */
 int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_length,
                           uint32_t window, uint32_t world, uint32_t parts, uint32_t slices,
                           uint32_t overlap, uint64_t *round_walks, uint32_t *group_parts);
