@@ -621,17 +621,18 @@ def main():
         full = min(args.round_walks, args.steps * args.walks)
         if full > args.warmup * args.walks:
             torch.cuda.empty_cache()
-            with torch.cuda.stream(blocks._side):
-                if phantom:
-                    hold = [torch.empty((t_world * full, 128), dtype=torch.int32, device="cuda")
-                            for _ in range(2 if blocks.permute else 1)]
-                else:
-                    hold = [torch.empty((full, 128), dtype=torch.int32, device="cuda")]
+            try:
+                with torch.cuda.stream(blocks._side):
+                    shared = (2 if blocks.permute else 1) if (phantom or t_world > 1) else 0
+                    hold = [] if phantom else [torch.empty((full, 128), dtype=torch.int32,
+                                                           device="cuda")]
                     hold += [torch.empty((t_world * full, 128), dtype=torch.int32, device="cuda")
-                             for _ in range((2 if blocks.permute else 1) if t_world > 1 else 0)]
-                for t in hold:
-                    t.zero_()  # touched, not only mapped
-                del hold
+                             for _ in range(shared)]
+                    for t in hold:
+                        t.zero_()  # touched, not only mapped
+                    del hold
+            except torch.cuda.OutOfMemoryError:  # no room to spare: the timed rounds allocate as they go
+                torch.cuda.empty_cache()
             fence()
     memlog("after warm-up")
     ops.stats_reset(graph, local)
