@@ -65,7 +65,7 @@ def valu_floor_per_pair(ld, k):
     2 ld / 64 packed FMAs + 4 DPP adds of the 16-lane reduction; clamp, exp2 scale, exp, + 1,
     reciprocal, label - sigma, x learning rate = 6; gradient 2 ld / 64 packed FMAs; row update
     2 ld / 64 packed FMAs.  (k + 1) samples per pair, four pairs side by side."""
-    ch = ld // 64
+    ch = max(1, -(-ld // 64))
     return (k + 1) * (6 * ch + 10) / 4.0
 
 
@@ -86,6 +86,10 @@ def parse():
                     choices=["auto", "write_through", "write_back", "atomic"])
     ap.add_argument("--return-weight", type=float, default=0.25)
     ap.add_argument("--explore-weight", type=float, default=4.0)
+    ap.add_argument("--max-neighbours", type=int, default=100,
+                    help="the reference's default (node2vec_skipgram.py:22): steps out of nodes of "
+                         "higher degree choose among a per-visit sub-sample of that many edges; "
+                         "0 = None = exact walks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calibrate", action="store_true",
                     help="run the traffic-calibration kernel instead of training (for rocprofv3 "
@@ -131,7 +135,7 @@ def parse():
                     help="blocks on one GPU: centre stripes trained one after the other over the "
                          "pairs of a round of `stripes` x as many walks -- the memory of a round "
                          "of --round-walks / stripes walks, centre runs `stripes` times as long; "
-                         "faster (8 stripes: +7 %) but the stripes of a round are trained one "
+                         "faster (8 stripes: +7 %%) but the stripes of a round are trained one "
                          "after the other, which costs link quality: 0 = 1 = off, what ships")
     ap.add_argument("--job-timeout", type=float, default=1500.0,
                     help="--gpus N > 1 started from a plain shell: seconds after which the parent "
@@ -267,7 +271,7 @@ def cpu_baseline(graph, args, central, contextual, seconds):
     d = args.d
     c = central[:, :d].contiguous().cpu().numpy()
     x = contextual[:, :d].contiguous().cpu().numpy()
-    wp = O.WalkParams(128, 10, args.return_weight, args.explore_weight, 100, 0)
+    wp = O.WalkParams(128, 10, args.return_weight, args.explore_weight, args.max_neighbours, 0)
     cbow = args.model == "cbow"
     tp = O.TrainParams(1 if cbow else 0, d, d, 1, 10, 5, 0.01, 0.9, 6.0, O.FLAG_SCALE_FREE,
                        d ** -0.5)
@@ -457,7 +461,8 @@ def main():
         return
     model_id = _lib.MODEL_CBOW if cbow else _lib.MODEL_SKIPGRAM
     tp = ops.train_params(model_id, d, 10, 5, lr=0.01, flags=flags, ld=ld)
-    wp = ops.walk_params(128, 10, args.return_weight, args.explore_weight)
+    wp = ops.walk_params(128, 10, args.return_weight, args.explore_weight,
+                         args.max_neighbours or None)
     from embiggen_amd.distributed import (BlockPartitionedTrainer, LoopbackComm, TorchComm,
                                           walk_slice)
 
@@ -523,6 +528,11 @@ def main():
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
             auto_walks, auto_group = int(agreed[0]), int(agreed[1])
         if not args.round_walks:
+            if getattr(blocks, "permute", False):
+                # resident cells: at least 16 rounds per epoch of the graph (10 walks a node),
+                # the rule of gn2v_train_blocks / models.fit_transform_blocks
+                rounds = max(1, int(os.environ.get("GN2V_ROUNDS_PER_EPOCH", "16") or 16))
+                auto_walks = min(auto_walks, max(1 << 16, -(-n * 10 // (rounds * max(t_world, stripes)))))
             args.round_walks = stripes * auto_walks
             # equal rounds (as gn2v_train_blocks cuts an epoch): 20 steps of 2^20 walks are three
             # rounds of 6.99 M, not two of 2^23 and a half one
@@ -609,8 +619,11 @@ def main():
 
     memlog("before warm-up")
     phase("warmup")
+    fence()
+    t_cold = time.perf_counter()
     run_steps(0, args.warmup)
     fence()
+    cold_seconds = time.perf_counter() - t_cold
     if blocks is not None and not c_entry and getattr(blocks, "_side", None) is not None:
         # The Python trainer takes a round's walks (its own, the gathered ones, the placed ones)
         # from torch's caching allocator, on its preparation stream; a warm-up shorter than a
@@ -773,8 +786,11 @@ def main():
             # what the library launched (gn2v_stats.resident_launches), not a mirror of its rule
             resident_launches = (c_stats.resident_launches if c_entry
                                  else st.get("resident_launches", 0))
-            kernel = ("gn2v::sgns_resident_v2_kernel" if resident_launches
-                      else "gn2v::sgns_block_kernel")
+            # (GN2V_RESIDENT_V2=0 launches round 4's form of the resident kernel: named as such)
+            resident_name = ("gn2v::sgns_resident_v2_kernel"
+                             if os.environ.get("GN2V_RESIDENT_V2", "1") != "0"
+                             else "gn2v::sgns_resident_kernel")
+            kernel = resident_name if resident_launches else "gn2v::sgns_block_kernel"
         elif n >= (1 << 16) and args.mode in ("auto", "write_through", "write_back"):
             kernel = "gn2v::sgns_cached_kernel"
         else:
@@ -800,7 +816,8 @@ def main():
                             f" edges (seed 42), Node2Vec {'CBOW' if cbow else 'SkipGram'} d={d}, "
                             f"walk_length 128, window 5,"
                             f" 10 negatives, return_weight {args.return_weight}, explore_weight "
-                            f"{args.explore_weight}, {args.walks} walks per step per GPU",
+                            f"{args.explore_weight}, max_neighbours "
+                            f"{args.max_neighbours or None}, {args.walks} walks per step per GPU",
                 "update_mode": args.mode,
                 "walks_per_launch": args.batch if blocks_view is None else None,
                 # the host loop that drove the timed region
@@ -911,6 +928,17 @@ def main():
                 "prices work, exceeds 1 because the sample rows never move through HBM, and is "
                 "not a roofline fraction; frac_hbm = bytes that really leave L2 (committed PMC "
                 "profile) / time / 8 TB/s")
+        # What `value` leaves out: the FIRST fit on a fresh handle also builds the walk sampler's
+        # edge records and allocates the round buffers (tens of GB the driver has to clear); the
+        # warm-up is that call here -- and it sizes the buffers for the timed call
+        # (GN2V_ROUND_BUFFERS_FOR), which therefore touches no memory for the first time.
+        # first_fit_s = the warm-up call, cold; overhead_s = that minus its steps at the timed rate.
+        line["first_fit_s"] = cold_seconds
+        line["first_fit"] = {
+            "seconds": cold_seconds, "steps": args.warmup,
+            "overhead_s": cold_seconds - args.warmup * elapsed / max(args.steps, 1),
+            "note": "the warm-up call on a fresh graph handle (sampler set-up + round-buffer "
+                    "allocation included); `value` is the steady state of a handle's later fits"}
         if reserved is not None:
             line["config"]["reserved_cus_per_xcd"] = args.reserve_cus
             line["config"]["active_cus_per_xcd"] = reserved

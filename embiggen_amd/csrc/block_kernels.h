@@ -47,6 +47,8 @@ constexpr uint32_t kMaxRecord = 32;
 // graph fills every record with one centre -- link AUROC 0.985 -> 0.93 with 8 centre stripes on
 // BA 200 k.)  The oracle restates it (O_MAX_RUN).
 constexpr uint32_t kMaxRun = 16;
+// draws of a cell-local negative before it is given up (the context or the centre every time)
+constexpr uint32_t kNegAttempts = 8;
 // records whose runs are at least this many per 100 pairs are trained pair per group
 constexpr uint32_t kPpgMinPct = 75;
 constexpr uint32_t kCursorStep = 64;  // u64 words between the ticket cursors of two slices
@@ -1125,28 +1127,36 @@ __device__ __forceinline__ void train_record(const BlockArgs &a, const HotLds &h
         if (s == 0) {
             if (xrow & kHubBit) row = kHubBit | s_hs[pr];
         } else {
-            const uint64_t r = draw(ckey, (p0 - lo + pr) * k + (s - 1));
-            uint32_t local = (uint32_t)mulhi64(r, cell_n), hub = 0;
-            if (a.alias) {
-                const unsigned long long e = a.alias[cell_lo + local];
-                hub = (uint32_t)e & 1u;
-                if ((uint32_t)r >= ((uint32_t)e & ~1u)) {
-                    local = (uint32_t)(e >> 32) & ~kHubBit;
-                    hub = (uint32_t)(e >> 63);
-                }
-            }
-            row = RES ? local : slice + a.p.slices * local;
-            lab = 0.f;
-            // the node behind the negative: staged with the cell's rows (resident cells; under a
-            // placement it is not a function of the row any more)
-            const uint64_t ngid = RES ? (uint64_t)h.grow[local]
-                                      : (uint64_t)(slice + a.p.slices * local) * a.p.parts + a.part;
+            // a negative that falls on the pair's context or centre is drawn again: attempt
+            // j + 1 = mix64(attempt j + golden), kNegAttempts draws at most (the oracle's
+            // O_NEG_ATTEMPTS), then the sample is given up (cells of one or two rows)
+            uint64_t r = draw(ckey, (p0 - lo + pr) * k + (s - 1));
             const uint64_t cgid = (uint64_t)s_key[pr] * a.p.world + a.p.rank;
-            if (row == (xrow & ~kHubBit) || ngid == cgid) {
-                row = kSentinel;
-            } else if (hub && hot_n) {
-                const uint32_t slot = a.hot_slot[cell_lo + local];
-                if (slot < hot_n) row = kHubBit | slot;
+            row = kSentinel;
+            lab = 0.f;
+            for (uint32_t att = 0; att < kNegAttempts; ++att, r = mix64(r + kGolden)) {
+                uint32_t local = (uint32_t)mulhi64(r, cell_n), hub = 0;
+                if (a.alias) {
+                    const unsigned long long e = a.alias[cell_lo + local];
+                    hub = (uint32_t)e & 1u;
+                    if ((uint32_t)r >= ((uint32_t)e & ~1u)) {
+                        local = (uint32_t)(e >> 32) & ~kHubBit;
+                        hub = (uint32_t)(e >> 63);
+                    }
+                }
+                const uint32_t cand = RES ? local : slice + a.p.slices * local;
+                // the node behind the negative: staged with the cell's rows (resident cells; under
+                // a placement it is not a function of the row any more)
+                const uint64_t ngid =
+                    RES ? (uint64_t)h.grow[local]
+                        : (uint64_t)(slice + a.p.slices * local) * a.p.parts + a.part;
+                if (cand == (xrow & ~kHubBit) || ngid == cgid) continue;
+                row = cand;
+                if (hub && hot_n) {
+                    const uint32_t slot = a.hot_slot[cell_lo + local];
+                    if (slot < hot_n) row = kHubBit | slot;
+                }
+                break;
             }
         }
         s_rows[t] = row;

@@ -97,6 +97,7 @@ gn2v::WalkConsts walk_consts(const gn2v_graph *g, const gn2v_walk_params *wp) {
     c.node_bias = g->view.node_types != nullptr && c.fn_same != c.fn_diff;
     c.edge_bias = g->view.edge_types != nullptr && c.fe_same != c.fe_diff;
     c.walk_length = wp->walk_length;
+    c.max_neighbours = wp->max_neighbours;  // 0: exact walks
     c.second_order = !(wp->return_weight == 1.0f && wp->explore_weight == 1.0f);
     const double rw = wp->return_weight, ew = wp->explore_weight;
     double mx = rw > ew ? rw : ew;
@@ -286,6 +287,37 @@ int ensure_edge_records(gn2v_graph *g, hipStream_t s, bool typed) {
     return 0;
 }
 
+__global__ void max_degree_kernel(const uint64_t *__restrict__ row_ptr, uint64_t n,
+                                  unsigned long long *__restrict__ out) {
+    unsigned long long m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        m = max(m, (unsigned long long)(row_ptr[i + 1] - row_ptr[i]));
+    for (int off = 32; off > 0; off >>= 1)
+        m = max(m, (unsigned long long)__shfl_xor((long long)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// the largest out-degree of the graph (one pass over row_ptr, one host read; cached by the caller)
+int max_out_degree(gn2v_graph *g, hipStream_t s, uint64_t *out) {
+    unsigned long long *d = nullptr, h = 0;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(h)));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(h), s);
+    if (e == hipSuccess) {
+        const uint64_t n = g->view.n_nodes;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(max_degree_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s,
+                           g->view.row_ptr, n, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(std::string("largest degree: ") + hipGetErrorString(e));
+    *out = h;
+    return 0;
+}
+
 int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
                  uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, hipStream_t s) {
     if (n_walks == 0) return 0;
@@ -299,25 +331,35 @@ int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint6
     const uint64_t blocks = (n_walks + gn2v::kWalkBlock - 1) / gn2v::kWalkBlock;
     if (blocks > 0x7FFFFFFFULL) return fail("too many walks in one launch");
     std::lock_guard<std::mutex> lock(g->mu);
+    // max_neighbours acts on rows longer than it: the largest out-degree, once per handle
+    bool sub = false;
+    if (c.max_neighbours) {
+        if (!g->max_out_degree_known) {
+            if (max_out_degree(g, s, &g->max_out_degree)) return 1;
+            g->max_out_degree_known = true;
+        }
+        sub = g->max_out_degree > c.max_neighbours;
+    }
     EventPair ev;
     if (get_events(g, &ev)) return 1;
     HIP_TRY(hipEventRecord(ev.a, s));
-    if (typed && g->view.edge_rec_typed)
-        hipLaunchKernelGGL(gn2v::walk_rec_kernel<true>, dim3((unsigned)blocks),
-                           dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
-                           first_walk, n_walks, d_out, g->counters);
-    else if (typed)
-        hipLaunchKernelGGL(gn2v::walk_kernel<true>, dim3((unsigned)blocks),
-                           dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
-                           first_walk, n_walks, d_out, g->counters);
-    else if (g->view.edge_rec)
-        hipLaunchKernelGGL(gn2v::walk_rec_kernel<false>, dim3((unsigned)blocks),
-                           dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
-                           first_walk, n_walks, d_out, g->counters);
-    else
-        hipLaunchKernelGGL(gn2v::walk_kernel<false>, dim3((unsigned)blocks),
-                           dim3(gn2v::kWalkBlock), 0, s, g->view, c, gn2v::epoch_key(seed, epoch),
-                           first_walk, n_walks, d_out, g->counters);
+    // (SUB: rows longer than max_neighbours exist -- see walk_kernels.h)
+    const bool rec = typed ? g->view.edge_rec_typed != nullptr : g->view.edge_rec != nullptr;
+#define GN2V_LAUNCH_WALK(KERNEL, TYPED, SUB)                                                       \
+    hipLaunchKernelGGL((gn2v::KERNEL<TYPED, SUB>), dim3((unsigned)blocks), dim3(gn2v::kWalkBlock), \
+                       0, s, g->view, c, gn2v::epoch_key(seed, epoch), first_walk, n_walks, d_out, \
+                       g->counters)
+    switch ((typed ? 4 : 0) | (rec ? 2 : 0) | (sub ? 1 : 0)) {
+        case 0: GN2V_LAUNCH_WALK(walk_kernel, false, false); break;
+        case 1: GN2V_LAUNCH_WALK(walk_kernel, false, true); break;
+        case 2: GN2V_LAUNCH_WALK(walk_rec_kernel, false, false); break;
+        case 3: GN2V_LAUNCH_WALK(walk_rec_kernel, false, true); break;
+        case 4: GN2V_LAUNCH_WALK(walk_kernel, true, false); break;
+        case 5: GN2V_LAUNCH_WALK(walk_kernel, true, true); break;
+        case 6: GN2V_LAUNCH_WALK(walk_rec_kernel, true, false); break;
+        default: GN2V_LAUNCH_WALK(walk_rec_kernel, true, true); break;
+    }
+#undef GN2V_LAUNCH_WALK
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.b, s));
     g->walk_events.push_back(ev);
@@ -579,6 +621,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
 
 namespace gn2v_host {
 void release_kept_buffers(gn2v_graph *g) {
+    std::lock_guard<std::mutex> lock(g->kept_mu);
     for (auto &b : g->kept_buffers) (void)hipFree(b.first);
     g->kept_buffers.clear();
     g->kept_bytes = 0;
@@ -1158,7 +1201,6 @@ int gn2v_graph_release_buffers(gn2v_graph *g) {
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     HIP_TRY(hipDeviceSynchronize());
-    std::lock_guard<std::mutex> lock(g->mu);
     release_kept_buffers(g);
     return 0;
 }

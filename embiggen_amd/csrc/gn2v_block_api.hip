@@ -228,36 +228,50 @@ namespace {
 struct Buffers {
     gn2v_graph *g;
     std::vector<std::pair<void *, size_t>> ptrs;
+    // set once the call has succeeded and its streams are drained: until then an exit is an error
+    // exit -- the side stream of the round driver (or a launch on the caller's) may still write
+    // the buffers, so the device is drained and they go back to the driver, not to the handle,
+    // where the next fit would reuse them at once
+    bool done = false;
     explicit Buffers(gn2v_graph *graph) : g(graph) {}
     ~Buffers() {
-        while (!ptrs.empty()) release_last();
+        if (!done && !ptrs.empty()) (void)hipDeviceSynchronize();
+        while (!ptrs.empty()) {
+            if (done)
+                release_last();
+            else
+                free_last();
+        }
     }
     template <class T>
     int alloc(T **out, size_t bytes) {
         *out = nullptr;
         bytes = bytes ? bytes : 4;
         void *p = nullptr;
-        // the smallest kept block that holds it without wasting more than a quarter
-        size_t best = g->kept_buffers.size();
-        for (size_t i = 0; i < g->kept_buffers.size(); ++i) {
-            const size_t have = g->kept_buffers[i].second;
-            if (have >= bytes && have - bytes <= bytes / 4 &&
-                (best == g->kept_buffers.size() || have < g->kept_buffers[best].second))
-                best = i;
-        }
         size_t size = bytes;
-        if (best != g->kept_buffers.size()) {
-            p = g->kept_buffers[best].first;
-            size = g->kept_buffers[best].second;
-            g->kept_bytes -= size;
-            g->kept_buffers.erase(g->kept_buffers.begin() + (long)best);
-        } else if (hipMalloc(&p, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            // what the handle still keeps may be exactly what is missing
-            if (!g->kept_buffers.empty()) {
-                gn2v_host::release_kept_buffers(g);
-                if (hipMalloc(&p, bytes) != hipSuccess) p = nullptr;
+        {
+            // the smallest kept block that holds it without wasting more than a quarter
+            std::lock_guard<std::mutex> lock(g->kept_mu);
+            size_t best = g->kept_buffers.size();
+            for (size_t i = 0; i < g->kept_buffers.size(); ++i) {
+                const size_t have = g->kept_buffers[i].second;
+                if (have >= bytes && have - bytes <= bytes / 4 &&
+                    (best == g->kept_buffers.size() || have < g->kept_buffers[best].second))
+                    best = i;
             }
+            if (best != g->kept_buffers.size()) {
+                p = g->kept_buffers[best].first;
+                size = g->kept_buffers[best].second;
+                g->kept_bytes -= size;
+                g->kept_buffers.erase(g->kept_buffers.begin() + (long)best);
+            }
+        }
+        if (!p && hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            // what the handle still keeps may be exactly what is missing
+            gn2v_host::release_kept_buffers(g);
+            if (hipMalloc(&p, bytes) != hipSuccess) p = nullptr;
             if (!p) {
                 (void)hipGetLastError();
                 return fail("out of device memory in gn2v_train_blocks (" +
@@ -274,13 +288,15 @@ struct Buffers {
         const auto b = ptrs.back();
         ptrs.pop_back();
         size_t total = 0, free_b = 0;
-        if (keep && b.second >= ((size_t)1 << 20) && hipMemGetInfo(&free_b, &total) == hipSuccess &&
-            g->kept_bytes + b.second <= total / 3) {
-            g->kept_buffers.push_back(b);
-            g->kept_bytes += b.second;
-        } else {
-            (void)hipFree(b.first);
+        if (keep && b.second >= ((size_t)1 << 20) && hipMemGetInfo(&free_b, &total) == hipSuccess) {
+            std::lock_guard<std::mutex> lock(g->kept_mu);
+            if (g->kept_bytes + b.second <= total / 3) {
+                g->kept_buffers.push_back(b);
+                g->kept_bytes += b.second;
+                return;
+            }
         }
+        (void)hipFree(b.first);
     }
     void free_last() {  // to the driver, whatever its size (room for another allocation)
         (void)hipFree(ptrs.back().first);
@@ -909,7 +925,7 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     const bool stores = !det && wmx != gn2v::kAtomic;
     if (d.slices > gn2v_host::kCursorSlices && !resident)
         return fail("more than 16 slices need cells that fit a workgroup's LDS (default update "
-                    "mode, rows up to 256 floats)");
+                    "mode, rows up to 512 floats)");
     if (a.inv && !resident)
         return fail("a placement (d_inv) needs resident cells: only their kernel reaches the rows "
                     "through it");
@@ -1581,11 +1597,33 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     size_t free_b = 0, total_b = 0;
     {
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        {
+            // what the handle keeps from its last fit is this fit's to reuse: a second fit must
+            // plan from the same budget as the first (the same rounds, groups and -- the round ids
+            // and placements depend on them -- the same embeddings for a seed)
+            std::lock_guard<std::mutex> lock(g->kept_mu);
+            free_b += g->kept_bytes;
+        }
         uint64_t auto_walks = 0;
         if (gn2v_block_round_plan(free_b, n, L, w, V, parts, plan.slices, overlap ? 1 : 0,
                                   &auto_walks, &group_parts))
             return 1;
         if (automatic) round_walks = auto_walks;
+    }
+    if (automatic && permute) {
+        // Resident cells draw a pair's negatives among the ~220 cell-mates its context has THIS
+        // round: an epoch trained as one or two rounds shows every context two or three sets of
+        // mates, and the cosine of the central rows pays for it -- config 3's shape (169 k
+        // nodes, three epochs of ten walks a node), cos-central AUROC by rounds per epoch:
+        // 1 0.9893, 4 0.9946, 8 0.9958, 16 0.9964 (walk-ordered kernel with graph-wide
+        // negatives: 0.9972) at the same kernel speed (profiles/r06_logs/r6_rounds_quality.log).
+        // So an epoch of the graph -- iterations x sources walks, whatever the caller's walk
+        // budget -- is cut into at least GN2V_ROUNDS_PER_EPOCH (16) rounds, none shorter than
+        // 2^16 walks.
+        const uint64_t rounds = std::max<uint64_t>(1, env_size("GN2V_ROUNDS_PER_EPOCH", 16));
+        const uint64_t epoch = g->view.n_sources * (uint64_t)wp->iterations;
+        const uint64_t mixed = std::max<uint64_t>(1ull << 16, (epoch + rounds * V - 1) / (rounds * V));
+        round_walks = std::min(round_walks, mixed);
     }
     const uint64_t planned_walks = round_walks;
     round_walks = std::max<uint64_t>(1, std::min(round_walks, (walks_per_epoch + V - 1) / V));
@@ -1787,6 +1825,7 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         stats->block_group_parts = group_parts;
         stats->block_round_walks = round_walks;
     }
+    buf.done = true;  // streams drained above: what is left goes back to the handle
     return 0;
 }
 

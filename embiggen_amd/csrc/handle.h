@@ -99,11 +99,15 @@ struct gn2v_graph {
     // largest in-degree (the most frequent context), computed on the first automatic plan
     uint64_t max_in_degree = 0;
     bool max_in_degree_known = false;
+    // largest out-degree (max_neighbours acts on longer rows only), on the first such walk
+    uint64_t max_out_degree = 0;
+    bool max_out_degree_known = false;
     uint32_t *indeg = nullptr;  // u32[n_nodes + 1] (the last word: their maximum), kept once computed
     bool indeg_failed = false;
     // round buffers of the last block fit, kept for the next one (gn2v_block_api.hip Buffers)
     std::vector<std::pair<void *, size_t>> kept_buffers;
     size_t kept_bytes = 0;
+    std::mutex kept_mu;  // guards kept_buffers / kept_bytes (never taken together with `mu`)
     // resident launches, heaviest cell first: ring of (keys, values) x (in, out) + sort storage
     uint32_t *lpt = nullptr;
     void *lpt_temp = nullptr;

@@ -15,7 +15,7 @@
 //     group's OWN transposition row: the four groups of a wave hand over at once, not in turns.
 // Semantics as before (block_kernels.h train_record<RES>; the oracle's o_block_step): negative n of
 // the pair at position p of its cell = draw(cell key, p k + n) through the cell's alias table,
-// skipped when it is the context or the centre; dot product clamped at +-clip; two samples of a
+// drawn again (kNegAttempts draws at most) when it is the context or the centre; dot product clamped at +-clip; two samples of a
 // pair that name the same row are applied one after the other (deterministic form) or as one
 // update with the summed coefficient (parallel form).  The deterministic instantiation (DET)
 // runs the same code with the four groups taking turns when every run of the record is a single
@@ -294,13 +294,24 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
         for (uint32_t s = first; s < last; ++s, arg += kGolden) {
             uint32_t row = xrow | kPkPositive;
             if (s != 0) {
-                const uint64_t r = mix64(arg);
-                uint32_t local = (uint32_t)mulhi64(r, (uint64_t)c.n);
-                if (c.alias) {
-                    const unsigned long long e = c.alias[local];
-                    if ((uint32_t)r >= ((uint32_t)e & ~1u)) local = (uint32_t)(e >> 32) & ~kHubBit;
+                // a negative that falls on the context or the centre is drawn again (attempt
+                // j + 1 = mix64(attempt j + golden), kNegAttempts draws at most -- the oracle's
+                // O_NEG_ATTEMPTS), so that a pair trains k negatives as under the reference's
+                // graph-wide draw; only cells of one or two rows still give a sample up
+                uint64_t r = mix64(arg);
+                row = c.n;
+                for (uint32_t att = 0; att < kNegAttempts; ++att, r = mix64(r + kGolden)) {
+                    uint32_t local = (uint32_t)mulhi64(r, (uint64_t)c.n);
+                    if (c.alias) {
+                        const unsigned long long e = c.alias[local];
+                        if ((uint32_t)r >= ((uint32_t)e & ~1u))
+                            local = (uint32_t)(e >> 32) & ~kHubBit;
+                    }
+                    if (local != xrow && c.node[local] != cgid) {
+                        row = local;
+                        break;
+                    }
                 }
-                row = (local == xrow || c.node[local] == cgid) ? c.n : local;
             }
             if (have) out[s] = (unsigned short)row;
         }
@@ -309,7 +320,8 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
             for (uint32_t s = kk; s < stride; ++s) out[s] = (unsigned short)c.n;
         // the null list: what a group without a pair (the tail of a record; a group that waits
         // for its turn in the deterministic form) scores -- the dummy row, coefficient 0
-        if ((uint32_t)lane < stride) pk16[a.p.record * stride + lane] = (unsigned short)c.n;
+        for (uint32_t s = (uint32_t)lane; s < stride; s += 64)
+            pk16[a.p.record * stride + s] = (unsigned short)c.n;
     }
     wave_sync();
     if constexpr (!DET) {

@@ -123,7 +123,59 @@ struct WalkConsts {
     uint64_t rq, mq;                      // R and M on a 2^20 scale
     uint64_t s_common, s_explore;         // 1 / M and explore_weight / M on a 2^32 scale
     uint64_t s_min, s_max;
+    // max_neighbours (0: exact walks): a step out of a node of higher degree is taken over a
+    // sub-sample of that many of its edges (RowView)
+    uint32_t max_neighbours;
 };
+
+// The row a step chooses from: all `deg` edges of the node, or -- degree > max_neighbours -- this
+// visit's SUB-SAMPLE of max_neighbours of them (node2vec_skipgram.py:78-81; the oracle's row_view
+// states the algorithm and its source): the row is cut into n buckets of step + (j < rem) edges,
+// element j = bucket j's first edge + (hash32(vkey, j) x its size >> 32), vkey = the first draw of
+// the step.  Counter based: a candidate costs one hash, nothing is enumerated.
+struct RowView {
+    uint64_t start, n, vkey;
+    uint32_t step, rem;  // step == 0: the whole row (n = degree)
+};
+
+__device__ __forceinline__ RowView whole_row(uint64_t start, uint64_t deg) {
+    return RowView{start, deg, 0, 0, 0};
+}
+
+// this visit's view of a row of `deg` > max_nb edges
+__device__ __forceinline__ RowView sub_sampled_row(uint64_t start, uint64_t deg, uint32_t max_nb,
+                                                   uint64_t vkey) {
+    const uint32_t step = (uint32_t)(deg / max_nb);
+    return RowView{start, max_nb, vkey, step, (uint32_t)(deg - (uint64_t)step * max_nb)};
+}
+
+// the draw of bucket j (32 bits are plenty for an offset inside a bucket, and a 64-bit splitmix
+// per candidate was the dearest part of the step: 16 % of the sampler's rate on the bench graph)
+__device__ __forceinline__ uint32_t view_hash(uint64_t vkey, uint64_t j) {
+    uint32_t h = (uint32_t)(vkey >> 32) + ((uint32_t)j + 1u) * 0x9E3779B1u;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// element j of the view -> edge id
+__device__ __forceinline__ uint64_t view_edge(const RowView &v, uint64_t j) {
+    if (v.step == 0) return v.start + j;
+    const uint64_t lo = j * v.step + (j < v.rem ? j : v.rem);
+    return v.start + lo +
+           (((uint64_t)view_hash(v.vkey, j) * ((uint64_t)v.step + (j < v.rem ? 1u : 0u))) >> 32);
+}
+
+// is edge index i of the row (counted from its start) an element of the sub-sample?
+__device__ __forceinline__ bool view_holds(const RowView &v, uint64_t i) {
+    if (v.step == 0) return true;
+    const uint64_t big = (uint64_t)v.rem * (v.step + 1u);
+    const uint64_t b = i < big ? i / (v.step + 1u) : v.rem + (i - big) / v.step;
+    return view_edge(v, b) == v.start + i;
+}
 
 __device__ __forceinline__ bool adj_contains(const uint32_t *__restrict__ col, uint64_t lo,
                                              uint64_t hi, uint32_t x) {
@@ -232,48 +284,49 @@ __device__ __forceinline__ ThresholdBounds threshold_bounds(const GraphView &g,
     return b;
 }
 
-// exact fallback after max_trials rejections (rare: only for extreme weights on low-weight rows);
-// returns the index of the chosen edge inside the row
+// exact fallback after max_trials rejections (rare: only for extreme weights on low-weight rows;
+// the one step of a weighted row under a sub-sample); returns the chosen edge
 template <bool TYPED>
 __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts &c, uint64_t r,
-                                            uint32_t cur, uint64_t start, uint64_t deg,
-                                            uint32_t prev, uint64_t pstart, uint64_t pend,
-                                            uint32_t ptype) {
+                                            uint32_t cur, const RowView &v, uint32_t prev,
+                                            uint64_t pstart, uint64_t pend, uint32_t ptype) {
+    const uint64_t n = v.n;
     if (g.cumw == nullptr) {
         uint64_t total = 0;
-        for (uint64_t i = 0; i < deg; ++i)
-            total += accept_threshold<TYPED>(g, c, cur, g.col_idx[start + i], start + i, prev, pstart,
-                                      pend, ptype);
-        if (total == 0) return ((r >> 32) * deg) >> 32;
+        for (uint64_t j = 0; j < n; ++j) {
+            const uint64_t e = view_edge(v, j);
+            total += accept_threshold<TYPED>(g, c, cur, g.col_idx[e], e, prev, pstart, pend, ptype);
+        }
+        if (total == 0) return view_edge(v, ((r >> 32) * n) >> 32);
         const uint64_t target = mulhi64(r, total);
         uint64_t acc = 0;
-        for (uint64_t i = 0; i < deg; ++i) {
-            acc += accept_threshold<TYPED>(g, c, cur, g.col_idx[start + i], start + i, prev, pstart,
-                                    pend, ptype);
-            if (acc > target) return i;
+        for (uint64_t j = 0; j < n; ++j) {
+            const uint64_t e = view_edge(v, j);
+            acc += accept_threshold<TYPED>(g, c, cur, g.col_idx[e], e, prev, pstart, pend, ptype);
+            if (acc > target) return e;
         }
-        return deg - 1;
+        return view_edge(v, n - 1);
     }
     double total = 0.0;
-    for (uint64_t i = 0; i < deg; ++i) {
-        const double w = __dsub_rn((double)g.cumw[start + i],
-                                   i ? (double)g.cumw[start + i - 1] : 0.0);
-        const uint64_t thr = accept_threshold<TYPED>(g, c, cur, g.col_idx[start + i], start + i, prev,
-                                              pstart, pend, ptype);
+    for (uint64_t j = 0; j < n; ++j) {
+        const uint64_t e = view_edge(v, j);
+        const double w = __dsub_rn((double)g.cumw[e], e > v.start ? (double)g.cumw[e - 1] : 0.0);
+        const uint64_t thr =
+            accept_threshold<TYPED>(g, c, cur, g.col_idx[e], e, prev, pstart, pend, ptype);
         total = __dadd_rn(total, __dmul_rn(w, (double)thr));
     }
     const double target =
         __dmul_rn(__dmul_rn((double)(r >> 11), 1.0 / 9007199254740992.0), total);
     double acc = 0.0;
-    for (uint64_t i = 0; i < deg; ++i) {
-        const double w = __dsub_rn((double)g.cumw[start + i],
-                                   i ? (double)g.cumw[start + i - 1] : 0.0);
-        const uint64_t thr = accept_threshold<TYPED>(g, c, cur, g.col_idx[start + i], start + i, prev,
-                                              pstart, pend, ptype);
+    for (uint64_t j = 0; j < n; ++j) {
+        const uint64_t e = view_edge(v, j);
+        const double w = __dsub_rn((double)g.cumw[e], e > v.start ? (double)g.cumw[e - 1] : 0.0);
+        const uint64_t thr =
+            accept_threshold<TYPED>(g, c, cur, g.col_idx[e], e, prev, pstart, pend, ptype);
         acc = __dadd_rn(acc, __dmul_rn(w, (double)thr));
-        if (acc > target) return i;
+        if (acc > target) return e;
     }
-    return deg - 1;
+    return view_edge(v, n - 1);
 }
 
 // One lane = one walker.  Output row-major u32[n_walks][walk_length]; every 16 steps a wave
@@ -281,7 +334,9 @@ __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts
 constexpr int kWalkBlock = 256;
 constexpr int kTileSteps = 16;
 
-template <bool TYPED>
+// SUB: some row of the graph is longer than max_neighbours (the host knows the largest degree):
+// only then is the sub-sampling code compiled in -- exact walks keep their instruction count.
+template <bool TYPED, bool SUB>
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConsts c, uint64_t ekey,
                                                           uint64_t first_walk, uint64_t n_walks,
                                                           uint32_t *__restrict__ out,
@@ -321,13 +376,27 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                 if (deg == 0) {
                     dead = true;
                 } else {
-                    uint64_t idx;
+                    uint64_t edge;  // the edge the step takes
                     const bool biased =
                         (TYPED && c.node_bias) ||
                         (prev != kSentinel && (c.second_order || (TYPED && c.edge_bias)));
-                    if (!biased || deg == 1) {
+                    // degree > max_neighbours: this visit's sub-sample (RowView)
+                    RowView v = whole_row(start, deg);
+                    if constexpr (SUB)
+                        if (deg > c.max_neighbours)
+                            v = sub_sampled_row(start, deg, c.max_neighbours, draw(wkey, ctr++));
+                    // candidate j of the view: uniform, or weight proportional on a whole row
+                    auto pick = [&](uint64_t r) -> uint64_t {
+                        return SUB && v.step ? view_edge(v, ((r >> 32) * v.n) >> 32)
+                                             : start + pick_index(g, start, deg, r);
+                    };
+                    if (SUB && g.cumw != nullptr && v.step) {
+                        // weights on a sub-sample: the scan over its elements (oracle: the same)
                         const uint64_t r = draw(wkey, ctr++);
-                        idx = pick_index(g, start, deg, r);
+                        edge = exact_scan<TYPED>(g, c, r, cur, v, biased ? prev : kSentinel, pstart,
+                                                 pend, ptype);
+                    } else if (!biased || deg == 1) {
+                        edge = pick(draw(wkey, ctr++));
                     } else {
                         if (!TYPED && c.apart) {
                             // The previous node proposed on its own (WalkConsts.apart).  Trial j
@@ -338,23 +407,23 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                             // for the adjacency test -- one memory round trip per trial instead
                             // of two; the look-ahead of an accepted trial is simply not consumed.
                             bool accepted = false;
-                            idx = 0;
+                            edge = start;
                             uint32_t trial = 0;
-                            const uint64_t z = c.rq + deg * c.mq;
-                            // the trial in hand: direct (prev) or a neighbour i = x with draw r32
+                            const uint64_t z = c.rq + v.n * c.mq;
+                            // the trial in hand: direct (prev) or a neighbour e -> x with draw r32
                             bool direct = mulhi64(draw(wkey, ctr), z) < c.rq;
                             uint64_t r2 = direct ? 0 : draw(wkey, ctr + 1);
-                            uint64_t i = ((r2 >> 32) * deg) >> 32;
-                            uint32_t x = direct ? 0u : g.col_idx[start + i];
+                            uint64_t e = direct ? start : view_edge(v, ((r2 >> 32) * v.n) >> 32);
+                            uint32_t x = direct ? 0u : g.col_idx[e];
                             while (trial < c.max_trials) {
                                 const uint64_t used = direct ? 1 : 2;
                                 // look ahead: the next trial's candidate
                                 const bool n_direct = mulhi64(draw(wkey, ctr + used), z) < c.rq;
                                 const uint64_t n_r2 = n_direct ? 0 : draw(wkey, ctr + used + 1);
-                                const uint64_t n_i = ((n_r2 >> 32) * deg) >> 32;
-                                const uint32_t n_x = (n_direct || trial + 1 >= c.max_trials)
-                                                         ? 0u
-                                                         : g.col_idx[start + n_i];
+                                const bool n_fetch = !n_direct && trial + 1 < c.max_trials;
+                                const uint64_t n_e =
+                                    n_fetch ? view_edge(v, ((n_r2 >> 32) * v.n) >> 32) : start;
+                                const uint32_t n_x = n_fetch ? g.col_idx[n_e] : 0u;
                                 ++trial;
                                 ctr += used;
                                 if (direct) {
@@ -366,8 +435,9 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                                         else
                                             hi = mid;
                                     }
-                                    if (lo < end && g.col_idx[lo] == prev) {
-                                        idx = lo - start;
+                                    // (of a sub-sample only when its bucket drew it)
+                                    if (lo < end && g.col_idx[lo] == prev && view_holds(v, lo - start)) {
+                                        edge = lo;
                                         accepted = true;
                                     }
                                 } else if (x != prev) {
@@ -378,18 +448,17 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                                         accepted = r32 < (is_common_neighbour(g, x, prev, pstart, pend)
                                                               ? c.s_common
                                                               : c.s_explore);
-                                    if (accepted) idx = i;
+                                    if (accepted) edge = e;
                                 }
                                 if (accepted) break;
                                 direct = n_direct;
                                 r2 = n_r2;
-                                i = n_i;
+                                e = n_e;
                                 x = n_x;
                             }
                             if (!accepted) {
                                 const uint64_t r = draw(wkey, ctr++);
-                                idx = exact_scan<TYPED>(g, c, r, cur, start, deg, prev, pstart,
-                                                        pend, ptype);
+                                edge = exact_scan<TYPED>(g, c, r, cur, v, prev, pstart, pend, ptype);
                             }
                         } else {
                         // Trials in two phases so that the wave pays for an adjacency search
@@ -397,17 +466,17 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                         // runs trials until one is decided without the search (accept) or needs
                         // it; phase B searches for the lanes that need it, in lock step.
                         bool accepted = false;
-                        idx = 0;
+                        edge = start;
                         uint32_t trial = 0;
                         while (trial < c.max_trials) {
-                            uint64_t r = 0, i = 0;
+                            uint64_t r = 0, e = start;
                             bool pending = false;
                             while (trial < c.max_trials) {
                                 r = draw(wkey, ctr++);
-                                i = pick_index(g, start, deg, r);
+                                e = pick(r);
                                 ++trial;
                                 const ThresholdBounds b = threshold_bounds<TYPED>(
-                                    g, c, cur, g.col_idx[start + i], start + i, prev, ptype);
+                                    g, c, cur, g.col_idx[e], e, prev, ptype);
                                 const uint64_t r32 = r & 0xFFFFFFFFULL;
                                 if (r32 < b.lo) {
                                     accepted = true;
@@ -420,25 +489,24 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
                             }
                             if (pending) {
                                 const uint64_t thr = accept_threshold<TYPED>(
-                                    g, c, cur, g.col_idx[start + i], start + i, prev, pstart, pend, ptype);
+                                    g, c, cur, g.col_idx[e], e, prev, pstart, pend, ptype);
                                 accepted = (r & 0xFFFFFFFFULL) < thr;
                             }
                             if (accepted) {
-                                idx = i;
+                                edge = e;
                                 break;
                             }
                             if (!pending) break;  // trials exhausted
                         }
                         if (!accepted) {
                             const uint64_t r = draw(wkey, ctr++);
-                            idx = exact_scan<TYPED>(g, c, r, cur, start, deg, prev, pstart, pend,
-                                                    ptype);
+                            edge = exact_scan<TYPED>(g, c, r, cur, v, prev, pstart, pend, ptype);
                         }
                         }
                     }
-                    const uint32_t nxt = g.col_idx[start + idx];
+                    const uint32_t nxt = g.col_idx[edge];
                     if constexpr (TYPED)
-                        if (c.edge_bias) ptype = g.edge_types[start + idx];
+                        if (c.edge_bias) ptype = g.edge_types[edge];
                     val = nxt;
                     prev = cur;
                     pstart = start;
@@ -584,7 +652,7 @@ __device__ __forceinline__ Candidate<TYPED> fetch_candidate(const uint4 *__restr
 // candidate that needs one is a pass of its own ("pending": the filter word is loaded beside the
 // other lanes' candidates, one wait for both).  Draws are counter based per walk, so the order in
 // which lanes run changes no walk.
-template <bool TYPED>
+template <bool TYPED, bool SUB>
 __global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, WalkConsts c,
                                                                   uint64_t ekey, uint64_t first_walk,
                                                                   uint64_t n_walks,
@@ -622,9 +690,11 @@ __global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, Wa
     }
     bool dead = !live;
     uint32_t steps = 0;
-    // the step in hand: trials so far; a candidate waiting for its adjacency test
+    // the step in hand: trials so far; a candidate waiting for its adjacency test; the visit's
+    // sub-sample when the row is longer than max_neighbours (set at the step's first trial)
     uint32_t trial = 0;
     bool pend = false;
+    RowView v = whole_row(0, 0);
     Candidate<TYPED> held{};
     uint32_t held_r32 = 0;
     bool ntype_differs = false, etype_differs = false;  // of the held candidate (TYPED)
@@ -650,17 +720,40 @@ __global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, Wa
             const bool do_pend = active && pend;
             uint64_t r32 = 0;
             Candidate<TYPED> x{};
+            bool scanned = false;  // the candidate came out of an exact scan: accepted as it is
             if (do_trial) {
+                if constexpr (SUB) {
+                    if (trial == 0) {  // the row this step chooses from (RowView)
+                        v = whole_row(cur.start, deg);
+                        if (deg > c.max_neighbours)
+                            v = sub_sampled_row(cur.start, deg, c.max_neighbours,
+                                                draw(wkey, ctr++));
+                    }
+                } else {
+                    v = whole_row(cur.start, deg);
+                }
                 uint64_t r = draw(wkey, ctr++);
-                if (apart && biased) {
-                    direct = mulhi64(r, c.rq + deg * c.mq) < c.rq;
-                    if (!direct) r = draw(wkey, ctr++);
+                if (SUB && g.cumw != nullptr && v.step) {
+                    // weights on a sub-sample: the scan over its elements (walk_kernel, oracle)
+                    x = fetch_candidate<TYPED>(
+                        rec, exact_scan<TYPED>(g, c, r, cur.id, v, biased ? prev.id : kSentinel,
+                                               prev.start, prev.start + prev.deg, ptype));
+                    scanned = true;
+                } else {
+                    if (apart && biased) {
+                        direct = mulhi64(r, c.rq + v.n * c.mq) < c.rq;
+                        if (!direct) r = draw(wkey, ctr++);
+                    }
+                    r32 = r & 0xFFFFFFFFULL;
+                    // (weighted graphs: the candidate is found in the row's cumulative weights, as
+                    // in walk_kernel; its record then saves the row_ptr read and most adjacency
+                    // tests)
+                    if (!direct)
+                        x = fetch_candidate<TYPED>(
+                            rec, SUB && v.step ? view_edge(v, ((r >> 32) * v.n) >> 32)
+                                               : cur.start + pick_index(g, cur.start, deg, r));
                 }
                 ++trial;
-                r32 = r & 0xFFFFFFFFULL;
-                // (weighted graphs: the candidate is found in the row's cumulative weights, as in
-                // walk_kernel; its record then saves the row_ptr read and most adjacency tests)
-                if (!direct) x = fetch_candidate<TYPED>(rec, cur.start + pick_index(g, cur.start, deg, r));
             }
             unsigned long long fword = ~0ULL, fbits = 0;
             if (do_pend && g.edge_filter) {
@@ -676,13 +769,27 @@ __global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, Wa
                 for (; t < tend; ++t) tile[wave][lane][t - t0] = kSentinel;
             }
             if (do_trial) {
-                if (!biased) {
+                if (!biased || scanned) {
                     accepted = true;
                 } else if (direct) {
                     // prev is a neighbour of cur on a symmetric graph; otherwise look for the
-                    // edge cur -> prev in the row
-                    accepted = back = g.symmetric || adj_contains(g.col_idx, cur.start,
-                                                                  cur.start + deg, prev.id);
+                    // edge cur -> prev in the row.  Under a sub-sample the edge must be found in
+                    // any case: it counts only when its bucket drew it.
+                    if (SUB && v.step) {
+                        uint64_t lo = cur.start, hi = cur.start + deg;
+                        while (lo < hi) {
+                            const uint64_t mid = lo + ((hi - lo) >> 1);
+                            if (g.col_idx[mid] < prev.id)
+                                lo = mid + 1;
+                            else
+                                hi = mid;
+                        }
+                        accepted = back = lo < cur.start + deg && g.col_idx[lo] == prev.id &&
+                                          view_holds(v, lo - cur.start);
+                    } else {
+                        accepted = back = g.symmetric || adj_contains(g.col_idx, cur.start,
+                                                                      cur.start + deg, prev.id);
+                    }
                 } else {
                     uint64_t lo = 1ULL << 32, hi = 1ULL << 32;
                     if (second) {
@@ -749,8 +856,8 @@ __global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, Wa
                 // rare: the exact scan of the row
                 const uint64_t r = draw(wkey, ctr++);
                 x = fetch_candidate<TYPED>(
-                    rec, cur.start + exact_scan<TYPED>(g, c, r, cur.id, cur.start, deg, prev.id,
-                                                       prev.start, prev.start + prev.deg, ptype));
+                    rec, exact_scan<TYPED>(g, c, r, cur.id, v, prev.id, prev.start,
+                                           prev.start + prev.deg, ptype));
                 accepted = true;
             }
             if (accepted) {

@@ -170,9 +170,21 @@ class _WalkBasedModel:
             flags |= _lib.TRAIN_WRITE_BACK
         elif self.update_mode == "write_through":
             flags |= _lib.TRAIN_WRITE_THROUGH
-        if self.block_path is True and self.MODEL_ID == _lib.MODEL_SKIPGRAM:
+        # GN2V_NEGATIVES=global: the reference-semantic schedule for models that did not choose
+        # themselves -- walk-ordered kernels, every negative the endpoint of a uniform random
+        # edge of the WHOLE graph (node2vec_skipgram.py:101-102) -- instead of the block path's
+        # cell-local draw; reachable from the drop-in classes (which have no such kwarg) through
+        # the environment.  "cell" (or unset): the engine decides.
+        block_path = self.block_path
+        if block_path is None:
+            law = os.environ.get("GN2V_NEGATIVES", "").strip().lower()
+            if law == "global":
+                block_path = False
+            elif law not in ("", "cell", "auto"):
+                raise ValueError(f"GN2V_NEGATIVES must be 'global' or 'cell', got {law!r}.")
+        if block_path is True and self.MODEL_ID == _lib.MODEL_SKIPGRAM:
             flags |= _lib.TRAIN_BLOCK_PATH
-        elif self.block_path is False:
+        elif block_path is False:
             flags |= _lib.TRAIN_WALK_ORDERED
         return _lib.TrainParams(
             self.MODEL_ID, self.embedding_size, self.padded_size, self.epochs,
@@ -303,6 +315,14 @@ class _WalkBasedModel:
                     mine = torch.tensor([auto_walks, auto_group], dtype=torch.int64, device=dev)
                     agreed = comm.all_gather(mine).view(-1, 2).min(0).values
                     auto_walks, auto_group = int(agreed[0]), int(agreed[1])
+                if round_walks is None and getattr(trainer, "permute", False):
+                    # resident cells: at least 16 rounds -- 16 sets of cell-mates -- per epoch of
+                    # the graph, none shorter than 2^16 walks (gn2v_train_blocks: the same rule
+                    # and the measurement behind it)
+                    rounds = max(1, int(os.environ.get("GN2V_ROUNDS_PER_EPOCH", "16") or 16))
+                    epoch_walks = csr.get_number_of_unique_source_nodes() * self.iterations
+                    auto_walks = min(auto_walks,
+                                     max(1 << 16, -(-epoch_walks // (rounds * lanes))))
                 round_walks = auto_walks if round_walks is None else round_walks
                 group_parts = auto_group if group_parts is None else group_parts
             trainer.group_parts = max(1, min(int(group_parts), trainer.parts))

@@ -92,8 +92,10 @@ typedef struct {
     uint32_t iterations;     /* walks per source node per epoch                   */
     float return_weight;     /* 1/p                                                */
     float explore_weight;    /* 1/q                                                */
-    uint32_t max_neighbours; /* accepted; walks are exact for every value: the law the
-                                reference's sub-sampled walks approximate */
+    uint32_t max_neighbours; /* node2vec_skipgram.py:22,78-81.  0 (the classes' None): exact
+                                walks.  Else a step out of a node of higher degree chooses among
+                                a per-visit sub-sample of this many of its edges (one per bucket
+                                of the row; csrc/walk_kernels.h RowView)          */
     uint32_t flags;          /* reserved                                           */
     /* node2vec_skipgram.py:72-77, node2vec_sequence.py:57-66.  0 = unset = 1.0.  "Only applies
      * to colored graphs / multigraphs, otherwise it has no impact": they act only when the

@@ -65,7 +65,8 @@ typedef struct {
     uint32_t iterations;
     float return_weight;
     float explore_weight;
-    uint32_t max_neighbours; /* accepted for API parity; walks are always exact */
+    uint32_t max_neighbours; /* 0 = exact; else rows longer than this are walked over a sub-sample
+                              * of this many edges per visit (row_view below) */
     uint32_t flags;
     float change_node_type_weight; /* 0 = unset = 1.0; only acts on graphs with node types */
     float change_edge_type_weight; /* 0 = unset = 1.0; only acts on graphs with edge types */
@@ -297,43 +298,94 @@ static inline uint64_t pick_index(const o_graph *g, uint64_t start, uint64_t deg
     return lo < deg ? lo : deg - 1;
 }
 
-/* exact fallback after max_trials rejections: integer-weighted scan over the whole row
+/* max_neighbours (node2vec_skipgram.py:78-81: "Number of maximum neighbours to consider when using
+ * approximated walks ... mainly useful for graphs containing nodes with high degrees"; default 100
+ * at :22, None = exact): a step that leaves a node of degree > max_neighbours is taken over a
+ * SUB-SAMPLE of max_neighbours of its edges, drawn afresh at every visit.  The reference's
+ * implementation lives in the absent ensmallen wheel; what is restated here is the algorithm its
+ * authors published for it (GRAPE, Cappelletti et al. 2023, "sorted unique sub-sampling"): the
+ * row's edge range is cut into max_neighbours buckets of (almost) equal length and ONE edge is
+ * drawn uniformly in every bucket -- sorted, distinct, O(1) per element.  Here bucket j of a row
+ * of `deg` edges holds step + (j < rem) edges (step = deg / M, rem = deg % M: every edge lies in
+ * exactly one bucket) and its element is lo_j + (hash32(vkey, j) * size_j >> 32), vkey = the FIRST
+ * draw of the step from the walk's stream -- counter based, so a candidate costs O(1) and the
+ * device draws the same sub-sample.  The step then follows the exact node2vec law ON the sub-sample
+ * (rejection on the same thresholds, the exact scan over its M elements as fall-back).
+ * [unpinned: a fourth reading, DESIGN.md 1.1] */
+typedef struct {
+    uint64_t start; /* first edge of the row */
+    uint64_t n;     /* elements of the view: the degree, or max_neighbours */
+    uint64_t step, rem, vkey;
+    int on; /* the view is a sub-sample */
+} row_view;
+
+/* the draw of bucket j: murmur3's 32-bit finaliser of (upper half of vkey) + (j + 1) golden32 --
+ * a sub-sample needs one per candidate, and a 64-bit splitmix each would be the dearest part of
+ * the device's step */
+static inline uint32_t view_hash(uint64_t vkey, uint64_t j) {
+    uint32_t h = (uint32_t)(vkey >> 32) + ((uint32_t)j + 1u) * 0x9E3779B1u;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+/* element j of the view -> edge id (buckets shorter than 2^32 edges) */
+static inline uint64_t view_edge(const row_view *v, uint64_t j) {
+    if (!v->on) return v->start + j;
+    uint64_t lo = j * v->step + (j < v->rem ? j : v->rem);
+    return v->start + lo + (((uint64_t)view_hash(v->vkey, j) * (v->step + (j < v->rem ? 1 : 0))) >> 32);
+}
+
+/* the bucket whose range holds the row's edge index i */
+static inline uint64_t view_bucket(const row_view *v, uint64_t i) {
+    uint64_t big = v->rem * (v->step + 1);
+    return i < big ? i / (v->step + 1) : v->rem + (i - big) / v->step;
+}
+
+static inline double edge_weight(const o_graph *g, uint64_t start, uint64_t e) {
+    return (double)g->cumw[e] - (e > start ? (double)g->cumw[e - 1] : 0.0);
+}
+
+/* exact fallback after max_trials rejections: integer-weighted scan over the view of the row
  * (unweighted graphs); weighted graphs scale each threshold by the edge weight in double.
- * Returns the index of the chosen edge inside the row. */
+ * Returns the chosen edge. */
 static uint64_t exact_scan(const o_graph *g, const walk_consts *c, uint64_t r, uint32_t cur,
-                           uint64_t start, uint64_t deg, uint32_t prev, uint64_t pstart,
-                           uint64_t pend, uint32_t ptype) {
+                           const row_view *v, uint32_t prev, uint64_t pstart, uint64_t pend,
+                           uint32_t ptype) {
+    uint64_t n = v->n;
     if (g->cumw == NULL) {
         uint64_t total = 0;
-        for (uint64_t i = 0; i < deg; ++i)
-            total += accept_threshold(g, c, cur, g->col_idx[start + i], start + i, prev, pstart,
-                                      pend, ptype);
-        if (total == 0) return ((r >> 32) * deg) >> 32;
-        uint64_t target = mulhi64(r, total), acc = 0;
-        for (uint64_t i = 0; i < deg; ++i) {
-            acc += accept_threshold(g, c, cur, g->col_idx[start + i], start + i, prev, pstart,
-                                    pend, ptype);
-            if (acc > target) return i;
+        for (uint64_t j = 0; j < n; ++j) {
+            uint64_t e = view_edge(v, j);
+            total += accept_threshold(g, c, cur, g->col_idx[e], e, prev, pstart, pend, ptype);
         }
-        return deg - 1;
+        if (total == 0) return view_edge(v, ((r >> 32) * n) >> 32);
+        uint64_t target = mulhi64(r, total), acc = 0;
+        for (uint64_t j = 0; j < n; ++j) {
+            uint64_t e = view_edge(v, j);
+            acc += accept_threshold(g, c, cur, g->col_idx[e], e, prev, pstart, pend, ptype);
+            if (acc > target) return e;
+        }
+        return view_edge(v, n - 1);
     }
     double total = 0.0;
-    for (uint64_t i = 0; i < deg; ++i) {
-        double w = (double)g->cumw[start + i] - (i ? (double)g->cumw[start + i - 1] : 0.0);
-        uint64_t thr = accept_threshold(g, c, cur, g->col_idx[start + i], start + i, prev,
-                                        pstart, pend, ptype);
-        total += w * (double)thr;
+    for (uint64_t j = 0; j < n; ++j) {
+        uint64_t e = view_edge(v, j);
+        uint64_t thr = accept_threshold(g, c, cur, g->col_idx[e], e, prev, pstart, pend, ptype);
+        total += edge_weight(g, v->start, e) * (double)thr;
     }
     double target = (double)(r >> 11) * (1.0 / 9007199254740992.0) * total;
     double acc = 0.0;
-    for (uint64_t i = 0; i < deg; ++i) {
-        double w = (double)g->cumw[start + i] - (i ? (double)g->cumw[start + i - 1] : 0.0);
-        uint64_t thr = accept_threshold(g, c, cur, g->col_idx[start + i], start + i, prev,
-                                        pstart, pend, ptype);
-        acc += w * (double)thr;
-        if (acc > target) return i;
+    for (uint64_t j = 0; j < n; ++j) {
+        uint64_t e = view_edge(v, j);
+        uint64_t thr = accept_threshold(g, c, cur, g->col_idx[e], e, prev, pstart, pend, ptype);
+        acc += edge_weight(g, v->start, e) * (double)thr;
+        if (acc > target) return e;
     }
-    return deg - 1;
+    return view_edge(v, n - 1);
 }
 
 void o_walk_one(const o_graph *g, const o_walk_params *wp, uint64_t wkey, uint32_t start_node,
@@ -349,17 +401,31 @@ void o_walk_one(const o_graph *g, const o_walk_params *wp, uint64_t wkey, uint32
         uint64_t start = g->row_ptr[cur], end = g->row_ptr[cur + 1];
         uint64_t deg = end - start;
         if (deg == 0) break;
-        uint64_t idx;
+        row_view v = {start, deg, 0, 0, 0, 0};
+        if (wp->max_neighbours && deg > wp->max_neighbours) { /* this visit's sub-sample */
+            v.on = 1;
+            v.n = wp->max_neighbours;
+            v.step = deg / v.n;
+            v.rem = deg % v.n;
+            v.vkey = o_draw(wkey, ctr++);
+        }
+        uint64_t edge;
         int biased = c.node_bias || (prev != O_SENTINEL && (c.second || c.edge_bias));
-        if (!biased || deg == 1) {
+        if (g->cumw != NULL && v.on) {
+            /* weights on a sub-sample: no cumulative sums to search -- the scan over its
+             * elements (thresholds all equal when the step is not biased) */
             uint64_t r = o_draw(wkey, ctr++);
-            idx = pick_index(g, start, deg, r);
+            edge = exact_scan(g, &c, r, cur, &v, biased ? prev : O_SENTINEL, pstart, pend, ptype);
+        } else if (!biased || deg == 1) {
+            uint64_t r = o_draw(wkey, ctr++);
+            edge = v.on ? view_edge(&v, ((r >> 32) * v.n) >> 32)
+                        : start + pick_index(g, start, deg, r);
         } else if (c.apart) {
             int accepted = 0;
-            idx = 0;
+            edge = start;
             for (uint32_t trial = 0; trial < c.max_trials; ++trial) {
                 uint64_t r1 = o_draw(wkey, ctr++);
-                if (mulhi64(r1, c.rq + deg * c.mq) < c.rq) { /* the previous node, if an edge */
+                if (mulhi64(r1, c.rq + v.n * c.mq) < c.rq) { /* the previous node, if an edge */
                     uint64_t lo = start, hi = end;
                     while (lo < hi) {
                         uint64_t mid = lo + ((hi - lo) >> 1);
@@ -368,49 +434,52 @@ void o_walk_one(const o_graph *g, const o_walk_params *wp, uint64_t wkey, uint32
                         else
                             hi = mid;
                     }
-                    if (lo < end && g->col_idx[lo] == prev) {
-                        idx = lo - start;
+                    /* ... of the view: a sub-sample holds it when its bucket drew it */
+                    if (lo < end && g->col_idx[lo] == prev &&
+                        (!v.on || view_edge(&v, view_bucket(&v, lo - start)) == lo)) {
+                        edge = lo;
                         accepted = 1;
                         break;
                     }
                     continue;
                 }
                 uint64_t r2 = o_draw(wkey, ctr++);
-                uint64_t i = ((r2 >> 32) * deg) >> 32;
-                uint32_t x = g->col_idx[start + i];
+                uint64_t e = view_edge(&v, ((r2 >> 32) * v.n) >> 32);
+                uint32_t x = g->col_idx[e];
                 if (x == prev) continue;
                 uint64_t thr = adj_contains(g->col_idx, pstart, pend, x) ? c.s_common : c.s_explore;
                 if ((r2 & 0xFFFFFFFFULL) < thr) {
-                    idx = i;
+                    edge = e;
                     accepted = 1;
                     break;
                 }
             }
             if (!accepted) {
                 uint64_t r = o_draw(wkey, ctr++);
-                idx = exact_scan(g, &c, r, cur, start, deg, prev, pstart, pend, ptype);
+                edge = exact_scan(g, &c, r, cur, &v, prev, pstart, pend, ptype);
             }
         } else {
             int accepted = 0;
-            idx = 0;
+            edge = start;
             for (uint32_t trial = 0; trial < c.max_trials; ++trial) {
                 uint64_t r = o_draw(wkey, ctr++);
-                uint64_t i = pick_index(g, start, deg, r);
-                uint64_t thr = accept_threshold(g, &c, cur, g->col_idx[start + i], start + i,
-                                                prev, pstart, pend, ptype);
+                uint64_t e = v.on ? view_edge(&v, ((r >> 32) * v.n) >> 32)
+                                  : start + pick_index(g, start, deg, r);
+                uint64_t thr = accept_threshold(g, &c, cur, g->col_idx[e], e, prev, pstart, pend,
+                                                ptype);
                 if ((r & 0xFFFFFFFFULL) < thr) {
-                    idx = i;
+                    edge = e;
                     accepted = 1;
                     break;
                 }
             }
             if (!accepted) {
                 uint64_t r = o_draw(wkey, ctr++);
-                idx = exact_scan(g, &c, r, cur, start, deg, prev, pstart, pend, ptype);
+                edge = exact_scan(g, &c, r, cur, &v, prev, pstart, pend, ptype);
             }
         }
-        uint32_t nxt = g->col_idx[start + idx];
-        if (c.edge_bias) ptype = g->edge_types[start + idx];
+        uint32_t nxt = g->col_idx[edge];
+        if (c.edge_bias) ptype = g->edge_types[edge];
         out[t] = nxt;
         prev = cur;
         pstart = start;
@@ -1025,6 +1094,7 @@ double o_glove_loss(const uint32_t *rows, const uint32_t *cols, const float *log
  * skipped when it is the context or the centre itself. */
 
 #define O_TAG_BLOCK 0xB10C5EED0B10C5EDULL
+#define O_NEG_ATTEMPTS 8u /* draws of a cell-local negative before it is given up */
 #define O_MAX_RUN 16u       /* pairs trained against one copy of the central row, at most */
 
 typedef struct {
@@ -1308,6 +1378,65 @@ uint64_t o_block_record_stride(uint64_t R) {
     return s % R;
 }
 
+/* Negative t of a cell's stream: a row inside the part (slice + slices * local), or 0xFFFFFFFF when
+ * every attempt fell on the pair's context (row xrow) or centre (node cgid).
+ * A cell-local negative that falls on the context or the centre is DRAWN AGAIN (the reference
+ * draws over the whole graph, node2vec_skipgram.py:101-102: there the event has probability
+ * ~ degree / edges and every pair trains k negatives; in a cell of ~220 rows a hub context would
+ * lose its own share of the cell's in-degree): attempt j + 1 = mix64(attempt j + golden), at most
+ * O_NEG_ATTEMPTS draws, then the sample is given up (cells of one or two rows). */
+static uint32_t block_negative(const o_block_plan *p, uint64_t ckey, uint64_t t, uint64_t cell_n,
+                               const uint64_t *cell_alias, uint32_t slice, uint32_t part,
+                               uint32_t xrow, uint64_t cgid, const uint32_t *inv) {
+    uint64_t r = o_draw(ckey, t);
+    for (uint32_t att = 0; att < O_NEG_ATTEMPTS; ++att, r = o_mix64(r + O_GOLDEN)) {
+        uint32_t local = (uint32_t)mulhi64(r, cell_n);
+        if (cell_alias) {
+            uint64_t e = cell_alias[local];
+            if ((uint32_t)r >= ((uint32_t)e & ~1u)) local = (uint32_t)(e >> 32) & 0x7FFFFFFFu;
+        }
+        uint32_t row = slice + p->slices * local;
+        uint64_t xp = (uint64_t)row * p->parts + part, xn = inv ? inv[xp] : xp;
+        if (row != xrow && xn != cgid) return row;
+    }
+    return 0xFFFFFFFFu;
+}
+
+/* test hook: the negatives o_block_step trains for the pairs of `part`, as node ids
+ * (0xFFFFFFFF: given up), out[(position in the sorted words - cell_offsets[part * slices]) * k + n] */
+uint64_t o_block_negatives(const o_graph *g, const o_train_params *tp, const o_block_plan *p,
+                           const uint64_t *words, const uint64_t *cell_offsets,
+                           const uint64_t *alias, const uint64_t *cell_rows, uint64_t block_id,
+                           uint32_t part, uint64_t seed, uint64_t epoch, const uint32_t *inv,
+                           uint32_t *out) {
+    uint32_t k = tp->k;
+    uint64_t rowmask = (1ull << p->row_bits) - 1ull;
+    uint64_t ekey = o_epoch_key(seed, epoch), n = 0;
+    uint64_t part_rows = stripe_count(g->n_nodes, part, p->parts);
+    uint64_t base = cell_offsets[part * p->slices];
+    for (uint32_t slice = 0; slice < p->slices; ++slice) {
+        uint32_t cell = part * p->slices + slice;
+        uint64_t lo = cell_offsets[cell], hi = cell_offsets[cell + 1];
+        uint64_t ckey = o_draw(o_draw(o_mix64(ekey ^ O_TAG_BLOCK), block_id), cell);
+        int use_alias = (tp->flags & O_FLAG_SCALE_FREE) && alias;
+        uint64_t cell_n = stripe_count(part_rows, slice, p->slices);
+        if (cell_n == 0) continue;
+        for (uint64_t q = lo; q < hi; ++q, ++n) {
+            uint64_t cgid = ((words[q] >> p->ctx_bits) & rowmask) * p->world + p->rank;
+            uint32_t xrow = slice + p->slices * (uint32_t)(words[q] & ((1ULL << (p->ctx_bits - 1)) - 1));
+            for (uint32_t s = 0; s < k; ++s) {
+                uint32_t row = block_negative(p, ckey, (q - lo) * k + s, cell_n,
+                                              use_alias ? alias + cell_rows[cell] : NULL, slice,
+                                              part, xrow, cgid, inv);
+                uint64_t xp = (uint64_t)row * p->parts + part;
+                out[(q - base) * k + s] =
+                    row == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)(inv ? inv[xp] : xp);
+            }
+        }
+    }
+    return n;
+}
+
 /* one part of one round, strictly sequential; returns the pairs trained */
 /* inv (or NULL: identity): the round's placement; row `local` of cell (part, slice) is then the
  * contextual row of node x = inv[(slice + slices * local) * parts + part], found at row x of
@@ -1355,21 +1484,17 @@ uint64_t o_block_step(const o_graph *g, const o_train_params *tp, const o_block_
                     for (uint32_t s = 0; s <= k; ++s) {
                         uint32_t row = xrow;
                         float label = 1.0f;
+                        uint64_t xp, xn;
                         if (s) {
-                            uint64_t r = o_draw(ckey, (p0 - lo + pr) * k + (s - 1));
-                            uint32_t local = (uint32_t)mulhi64(r, cell_n);
-                            if (use_alias) {
-                                uint64_t e = alias[alias_lo + local];
-                                if ((uint32_t)r >= ((uint32_t)e & ~1u))
-                                    local = (uint32_t)(e >> 32) & 0x7FFFFFFFu;
-                            }
-                            row = slice + p->slices * local;
+                            row = block_negative(p, ckey, (p0 - lo + pr) * k + (s - 1), cell_n,
+                                                 use_alias ? alias + alias_lo : NULL, slice, part,
+                                                 xrow, cgid, inv);
                             label = 0.0f;
-                            if (row == xrow) continue;
+                            if (row == 0xFFFFFFFFu) continue;
                         }
                         /* the node behind the row, and where its contextual row lies */
-                        uint64_t xp = (uint64_t)row * p->parts + part, xn = inv ? inv[xp] : xp;
-                        if (s && xn == cgid) continue;
+                        xp = (uint64_t)row * p->parts + part;
+                        xn = inv ? inv[xp] : xp;
                         float *v = context + (natural ? xn : xn / p->parts) * ld;
                         float dot = 0.0f;
                         for (uint32_t x = 0; x < d; ++x) dot += u[x] * v[x];

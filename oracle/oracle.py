@@ -478,6 +478,23 @@ def block_step(g: OracleGraph, tp: TrainParams, plan: BlockPlan, words, cell_off
         C.c_uint32(1 if natural else 0)))
 
 
+def block_negatives(g: OracleGraph, tp: TrainParams, plan: BlockPlan, words, cell_offsets, alias,
+                    cell_rows, block_id: int, part: int, seed: int, epoch: int, inv=None):
+    """Test hook: the negatives ``block_step`` trains for the pairs of ``part`` -- node ids
+    [pairs of the part, k], 0xFFFFFFFF where a sample was given up -- in the sorted order of
+    ``words``."""
+    lo = int(cell_offsets[part * plan.slices])
+    hi = int(cell_offsets[(part + 1) * plan.slices])
+    out = np.full((hi - lo, max(1, tp.k)), 0xFFFFFFFF, dtype=np.uint32)
+    lib().o_block_negatives.restype = C.c_uint64
+    n = int(lib().o_block_negatives(
+        C.byref(g.c), C.byref(tp), C.byref(plan), _ptr(words), _ptr(cell_offsets), _ptr(alias),
+        _ptr(cell_rows), C.c_uint64(block_id), C.c_uint32(part), C.c_uint64(seed),
+        C.c_uint64(epoch), _ptr(inv), _ptr(out)))
+    assert n == hi - lo
+    return out[:, :tp.k]
+
+
 def init_table_rows(n_rows: int, d: int, ld: int, seed: int, table_id: int, scale: float,
                     first_row: int, row_stride: int):
     t = np.empty((n_rows, ld), dtype=np.float32)

@@ -25,14 +25,15 @@ for k, record, extra, tag in ((10, 16, 0, "default"), (2, 16, 0, "default"), (0,
     tr = BlockPartitionedTrainer(g, tp, d, d, 42, d ** -0.5, LoopbackComm(), "cuda:0",
                                  walk_length=128, window=5, record=record)
     wk = ops.walks(g, wp, 42, 0, 0, 1 << 19)
-    prepared = tr.prepare(wk, 42, 0, 0)
+    # (resident cells: the round's placement, its alias tables and the placed walks)
+    prepared = tr.prepare(wk, 42, 0, 0, rstate=tr.round_state(wk, 42, 0))
     tr.train_prepared(prepared, 42, 0, 0.01)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tr.train_prepared(prepared, 42, 0, 0.01)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
-    pairs = prepared[3]
+    pairs = prepared[2]
     rows = pairs * (k + 1) + pairs / record
     print(f"k={k:2d} record={record} {tag}: {ms:8.1f} ms  {ms * 1e6 / pairs:6.2f} ns/pair  "
           f"{rows * 1024 / ms / 1e9:6.2f} TB/s of row traffic", flush=True)

@@ -17,7 +17,9 @@ tp = ops.train_params(0, 128, 10, 5, flags=1, ld=128)
 tr = BlockPartitionedTrainer(g, tp, 128, 128, 42, 128 ** -0.5, LoopbackComm(), "cuda:0",
                              walk_length=128, window=5)
 wp = ops.walk_params(128, 10, 0.25, 4.0)
-_, offsets, n, _, _ = tr.prepare(ops.walks(g, wp, 42, 0, 0, walks), 42, 0, 0)
+wk = ops.walks(g, wp, 42, 0, 0, walks)
+# (a trainer of resident cells extracts under the round's placement: round_state)
+_, offsets, n, _, _, _ = tr.prepare(wk, 42, 0, 0, rstate=tr.round_state(wk, 42, 0))
 sizes = (offsets[1:] - offsets[:-1]).to(torch.float64).reshape(tr.parts, tr.slices)
 ratio = sizes.max(dim=1).values / sizes.mean(dim=1)
 print(f"{nodes} nodes, {walks} walks: {n} pairs, {tr.parts} parts x {tr.slices} slices; fullest "

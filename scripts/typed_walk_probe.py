@@ -46,3 +46,12 @@ rate(g, ops.walk_params(128, 10, 2.0, 0.5), "untyped rw2/ew.5")
 rate(typed, ops.walk_params(128, 10, 2.0, 0.5, 100, 2.0, 0.5), "rw2/ew.5 + node x2 + edge x0.5")
 rate(g, ops.walk_params(128, 10, 4.0, 0.25), "untyped rw4/ew.25")
 rate(g, ops.walk_params(128, 10, 0.5, 2.0), "untyped rw.5/ew2")
+# round 6: max_neighbours (node2vec_skipgram.py:22,78-81) -- every line above ran at the
+# reference's default of 100 (steps out of hubs choose among a per-visit sub-sample of 100 edges);
+# the exact walks (None) and the smoke configuration's 10 beside it
+for mn in (None, 10):
+    rate(g, ops.walk_params(128, 10, 0.25, 4.0, mn), f"untyped rw.25/ew4, max_neighbours {mn}")
+    rate(g, ops.walk_params(128, 10, 1.0, 1.0, mn), f"untyped first order, max_neighbours {mn}")
+    rate(g, ops.walk_params(128, 10, 2.0, 0.5, mn), f"untyped rw2/ew.5, max_neighbours {mn}")
+    rate(typed, ops.walk_params(128, 10, 0.25, 4.0, mn, 2.0, 0.5),
+         f"rw.25/ew4 + node x2 + edge x0.5, max_neighbours {mn}")

@@ -137,6 +137,34 @@ def exact_second_order_probs(graph, prev: int, cur: int, return_weight: float,
     return neigh, w / w.sum()
 
 
+def exact_sub_sampled_probs(graph, prev: int, cur: int, return_weight: float,
+                            explore_weight: float, max_neighbours: int):
+    """Transition distribution out of `cur` (degree > max_neighbours) under the sub-sampled walk
+    (oracle/gn2v_oracle.c row_view: the row cut into max_neighbours buckets of step + (j < rem)
+    edges, one edge drawn uniformly in every bucket, the exact node2vec law on those), by
+    ENUMERATION of every sub-sample: P(x) = sum_S P(S) w_x [x in S] / W_S.  Independent of the
+    oracle's code; feasible while the product of the bucket sizes is small."""
+    import itertools
+
+    neigh, exact = exact_second_order_probs(graph, prev, cur, return_weight, explore_weight)
+    deg, m = len(neigh), max_neighbours
+    assert deg > m
+    step, rem = divmod(deg, m)
+    buckets, lo = [], 0
+    for j in range(m):
+        size = step + (1 if j < rem else 0)
+        buckets.append(range(lo, lo + size))
+        lo += size
+    assert lo == deg and np.prod([len(b) for b in buckets], dtype=np.float64) <= 1 << 16
+    p = np.zeros(deg)
+    p_s = 1.0 / np.prod([len(b) for b in buckets], dtype=np.float64)
+    for chosen in itertools.product(*buckets):
+        idx = np.fromiter(chosen, dtype=np.int64)
+        p[idx] += p_s * exact[idx] / exact[idx].sum()
+    assert abs(p.sum() - 1.0) < 1e-9
+    return neigh, p
+
+
 def typed_karate():
     """Karate Club with two node types (one multi-label, a few unknown) and three edge types
     (symmetric: both directions of an edge carry the same type; some unknown)."""

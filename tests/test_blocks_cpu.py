@@ -156,6 +156,73 @@ def test_alias_tables_are_degree_proportional_inside_a_cell():
     assert stats.chisquare(counts[sel], want[sel] / want[sel].sum() * counts[sel].sum()).pvalue > 1e-4
 
 
+def test_a_negative_on_the_context_or_centre_is_drawn_again():
+    """o_block_step's negatives (oracle/gn2v_oracle.c block_negative; the device kernels follow
+    it draw for draw): a cell-local negative that equals the pair's context or centre is drawn
+    again, so (i) no negative ever IS the context or the centre, (ii) every pair of a cell with
+    three rows or more trains its k negatives (the reference's graph-wide draw,
+    node2vec_skipgram.py:101-102, loses ~degree / edges of them: nothing), (iii) given the
+    context x and centre c the law is in-degree restricted to the cell's other rows --
+    chi-square on the heaviest context of a cell, where the old skip rule dropped the largest
+    share -- and (iv) cells of two rows (context + one mate) give up after O_NEG_ATTEMPTS draws
+    only when that mate is the centre."""
+    from scipy import stats
+
+    g = _graph(97)
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    indeg = np.bincount(og.col_idx, minlength=97).astype(np.float64)
+    walks = O.walks(og, O.WalkParams(L, 1, 1.0, 1.0, 100, 0), 5, 0, 0, 97 * 30)
+    parts, slices, k = 2, 2, 16
+    plan = O.block_plan(97, 1, 0, parts, slices, L, W, 1, 4)
+    words, offsets = O.block_extract(og, plan, walks, 5, 0, 0)
+    alias, cell_rows = O.block_alias(og, parts, slices)[:2]
+    tp = O.TrainParams(0, D, D, 1, k, W, 0.02, 0.9, 6.0, 1, D ** -0.5)
+    cell, crow, vals, _ = O.block_unpack(words, plan)
+    for part in range(parts):
+        neg = O.block_negatives(og, tp, plan, words, offsets, alias, cell_rows, 0, part, 5, 0)
+        lo, hi = int(offsets[part * slices]), int(offsets[(part + 1) * slices])
+        ctx = vals[lo:hi].astype(np.int64) * parts + part
+        centre = crow[lo:hi].astype(np.int64)
+        # (ii) a sample is given up with probability (share of context + centre) ^ 8 only
+        gone = neg == 0xFFFFFFFF
+        assert neg.shape == (hi - lo, k) and gone.mean() < 2e-4, gone.mean()
+        assert (neg != ctx[:, None]).all() and (neg != centre[:, None]).all()  # (i)
+        slc = (neg.astype(np.int64) // parts) % slices
+        assert ((neg % parts == part) | gone).all()
+        assert ((slc == (ctx[:, None] // parts) % slices) | gone).all()
+        # (iii) the context that carries the most pairs of the part, centres outside its cell
+        x = np.bincount(ctx).argmax()
+        in_cell = lambda v: (v % parts == part) & ((v // parts) % slices == (x // parts) % slices)  # noqa: E731
+        sel = (ctx == x) & ~in_cell(centre)
+        mates = np.array([v for v in range(97) if in_cell(np.int64(v)) and v != x])
+        want = indeg[mates] / indeg[mates].sum()
+        drawn = neg[sel].ravel()
+        counts = np.bincount(drawn[drawn != 0xFFFFFFFF], minlength=97)[mates].astype(np.float64)
+        keep = want * counts.sum() >= 5
+        assert counts.sum() >= 0.999 * sel.sum() * k and counts[~keep].sum() <= 0.02 * counts.sum()
+        pv = stats.chisquare(counts[keep], want[keep] / want[keep].sum() * counts[keep].sum()).pvalue
+        assert pv > 1e-4, (part, x, pv)
+        # ... under the old rule this context would have lost its own share of the cell's draws
+        assert indeg[x] / (indeg[x] + indeg[mates].sum()) > 0.05
+    # (iv) two-row cells: 4 nodes, 1 part x 2 slices; path 0 - 1 - 2 - 3 (cells {0, 2}, {1, 3})
+    g4 = E.CSRGraph.from_edge_list(np.array([0, 1, 2]), np.array([1, 2, 3]), number_of_nodes=4)
+    og4 = O.OracleGraph(g4.row_ptr, g4.col_idx)
+    plan4 = O.block_plan(4, 1, 0, 1, 2, 2, 1, 1, 4)
+    w4 = np.array([[0, 2], [1, 2], [0, 1]], dtype=np.uint32)  # (centre 0, ctx 2): the mate IS the centre
+    words4, off4 = O.block_extract(og4, plan4, w4, 5, 0, 0)
+    alias4, rows4 = O.block_alias(og4, 1, 2)[:2]
+    tp4 = O.TrainParams(0, D, D, 1, 3, 1, 0.02, 0.9, 6.0, 1, D ** -0.5)
+    neg4 = O.block_negatives(og4, tp4, plan4, words4, off4, alias4, rows4, 0, 0, 5, 0)
+    _, crow4, vals4, _ = O.block_unpack(words4, plan4)
+    for (c, x), row in zip(zip(crow4.astype(int), vals4.astype(int)), neg4):
+        mate = {0: 2, 2: 0, 1: 3, 3: 1}[x]
+        # (the context of in-degree 2 beside a mate of in-degree 1 is drawn 8 times in a row
+        # with probability (2 / 3) ^ 8: such a sample is given up as well)
+        assert ((row == 0xFFFFFFFF) if mate == c else np.isin(row, (mate, 0xFFFFFFFF))).all(), \
+            (c, x, row)
+    assert (neg4 != 0xFFFFFFFF).sum() >= neg4.size // 2
+
+
 def test_record_visiting_order_is_a_permutation():
     for R in (1, 2, 3, 10, 97, 1000, 4096, 65537):
         A = O.block_record_stride(R)

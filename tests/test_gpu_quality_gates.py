@@ -1,0 +1,196 @@
+"""The schedule that SHIPS against the reference-semantic schedule, gated.
+
+The default SkipGram fit from 100 k nodes (resident cells: the k negatives of a pair drawn among
+the ~220 cell-mates its context has this round, racing read-modify-writes inside a cell) against
+``block_path=False`` -- the walk-ordered kernels, every negative the endpoint of a uniform random
+edge of the WHOLE graph (the reference's ``use_scale_free_distribution``,
+embedders/ensmallen_embedders/node2vec_skipgram.py:101-102) -- on the SAME seeded walks, at
+BASELINE's shapes: config 3 (169 343 nodes, p = 0.5, q = 2), config 4 (2.45 M / 62 M) and the
+bench graph (10 M / 100 M).  What is compared is the north star's parity metric, the cosine
+similarity of learned embeddings (embedding_transformers/edge_transformer.py:242-267):
+
+* cos-central AUROC (edges against random pairs) of both fits: within 0.003 of each other;
+* rank correlation of the cosines of 10^5 edges + 10^5 random pairs under the two fits;
+* their mean absolute difference.
+
+ensmallen itself is not available (oracle: parity unpinned); the walk-ordered schedule with
+atomics is the closest runnable form of what its documentation describes."""
+import numpy as np
+import pytest
+import torch
+
+import embiggen_amd as E
+from embiggen_amd import models
+
+pytestmark = pytest.mark.gpu
+
+
+def _auc(pos, neg):
+    s = torch.cat([pos, neg]).double()
+    ranks = torch.empty_like(s)
+    ranks[torch.argsort(s)] = torch.arange(1, s.numel() + 1, device=s.device, dtype=s.dtype)
+    n1, n0 = pos.numel(), neg.numel()
+    return float((ranks[:n1].sum() - n1 * (n1 + 1) / 2) / (n1 * n0))
+
+
+def _spearman(a, b):
+    def rank(v):
+        r = torch.empty_like(v, dtype=torch.float64)
+        r[torch.argsort(v)] = torch.arange(v.numel(), device=v.device, dtype=torch.float64)
+        return r
+
+    ra, rb = rank(a), rank(b)
+    ra, rb = ra - ra.mean(), rb - rb.mean()
+    return float((ra * rb).sum() / (ra.norm() * rb.norm()))
+
+
+def _pairs(g, n_each, seed):
+    t = g._device_tensors
+    if t is None:
+        t = {"row_ptr": torch.from_numpy(np.asarray(g.row_ptr).astype(np.int64)).cuda(),
+             "col_idx": torch.from_numpy(np.asarray(g.col_idx).astype(np.int64)).cuda()}
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    n = g.get_number_of_nodes()
+    e = torch.randint(0, t["col_idx"].numel(), (n_each,), device="cuda", generator=gen)
+    src = torch.searchsorted(t["row_ptr"].long(), e, right=True) - 1
+    dst = t["col_idx"][e].long()
+    ru = torch.randint(0, n, (n_each,), device="cuda", generator=gen)
+    rv = torch.randint(0, n, (n_each,), device="cuda", generator=gen)
+    return torch.cat([src, ru]), torch.cat([dst, rv])
+
+
+def _cos(table, u, v):
+    a, b = table[u], table[v]
+    return (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1)).clamp_min(1e-6)
+
+
+def _reference_fit_with_other_negatives(g, kw, mode_flags, seed_of_negatives):
+    """The walk-ordered schedule as gn2v_train runs it (walks 2^19 at a time, launches of 2^16,
+    the learning rate decayed per epoch) on the walks of ``random_state`` but with the negatives
+    of another seed: what the reference-semantic fit differs from ITSELF by when only its
+    negatives change -- the floor under every comparison of two fits."""
+    from embiggen_amd import _lib, ops
+
+    n, d = g.get_number_of_nodes(), kw["embedding_size"]
+    seed = kw["random_state"]
+    wp = ops.walk_params(kw["walk_length"], kw["iterations"], kw["return_weight"],
+                         kw["explore_weight"])
+    tp = ops.train_params(0, d, kw["number_of_negative_samples"], kw["window_size"],
+                          flags=_lib.TRAIN_SCALE_FREE | mode_flags, ld=d)
+    c = ops.init_table(n, d, seed, 0, d ** -0.5)
+    x = ops.init_table(n, d, seed, 1, d ** -0.5)
+    walks_per_epoch = g.get_number_of_unique_source_nodes() * kw["iterations"]
+    lr = np.float32(kw["learning_rate"])
+    for e in range(kw["epochs"]):
+        for first in range(0, walks_per_epoch, 1 << 19):
+            nw = min(1 << 19, walks_per_epoch - first)
+            wk = ops.walks(g, wp, seed, e, first, nw)
+            for off in range(0, nw, 1 << 16):
+                nb = min(1 << 16, nw - off)
+                ops.sgns_step(g, tp, wk[off:off + nb], seed_of_negatives, e, first + off,
+                              float(lr), c, x)
+        lr = np.float32(lr * np.float32(0.9))
+    torch.cuda.synchronize()
+    del x
+    return c
+
+
+def compare(g, kw, reference_mode, n_each=100_000, floor=False):
+    """Both fits on the same walks; returns the figures and what ran.  ``floor``: also the
+    reference-semantic fit against itself under other negatives (same walks)."""
+    from embiggen_amd import _lib
+
+    fast = models.SkipGram(**kw)
+    c_fast, _, st_fast = fast.fit_transform_device(g)
+    assert fast.last_plan is not None and fast.last_plan["slices"] > 16, fast.last_plan
+    assert st_fast["resident_launches"] > 0, st_fast
+    u, v = _pairs(g, n_each, 7)
+    cos_fast = _cos(c_fast, u, v)
+    del c_fast
+    torch.cuda.empty_cache()
+    ref = models.SkipGram(block_path=False, update_mode=reference_mode, **kw)
+    c_ref, _, st_ref = ref.fit_transform_device(g)
+    assert ref.last_plan is None and st_ref["pairs"] == st_fast["pairs"]
+    cos_ref = _cos(c_ref, u, v)
+    del c_ref
+    torch.cuda.empty_cache()
+    res = dict(auc_default=_auc(cos_fast[:n_each], cos_fast[n_each:]),
+               auc_reference=_auc(cos_ref[:n_each], cos_ref[n_each:]),
+               spearman=_spearman(cos_fast, cos_ref),
+               mean_abs=float((cos_fast - cos_ref).abs().mean()),
+               pairs=st_fast["pairs"], seconds_default=fast.last_seconds,
+               seconds_reference=ref.last_seconds, plan=fast.last_plan)
+    if floor:
+        flags = {"atomic": _lib.TRAIN_ATOMIC, "auto": 0}[reference_mode]
+        c_other = _reference_fit_with_other_negatives(g, kw, flags, kw["random_state"] + 1)
+        cos_other = _cos(c_other, u, v)
+        del c_other
+        torch.cuda.empty_cache()
+        res.update(floor_spearman=_spearman(cos_ref, cos_other),
+                   floor_mean_abs=float((cos_ref - cos_other).abs().mean()),
+                   auc_reference_other_negatives=_auc(cos_other[:n_each], cos_other[n_each:]))
+    return res
+
+
+SHAPES = {
+    # name: (nodes, m, return_weight, explore_weight, iterations, epochs, reference update mode)
+    # config 3 (ogbn-arxiv's shape; p = 0.5, q = 2): the reference's ten walks a node, three epochs;
+    # the reference-semantic fit with exact atomic adds on every row
+    "config3_arxiv_shape": (169_343, 7, 2.0, 0.5, 10, 3, "atomic"),
+    # config 4 (ogbn-products' shape): two walks a node, three epochs; the walk-ordered schedule in
+    # its own default mode (stores: atomics would take minutes here)
+    "config4_products_shape": (2_449_029, 25, 0.25, 4.0, 2, 3, "auto"),
+}
+
+
+def _gate(name, res):
+    """The default's cosines must separate edges from random pairs as well as the
+    reference-semantic fit's (AUROC not more than 0.003 below it -- above is fine), and agree with
+    them about as well as that fit agrees with itself when only its negatives change (where the
+    floor was measured), else within the measured figures + margin."""
+    gate = GATES[name]
+    assert res["auc_default"] >= res["auc_reference"] - gate["auc"], res
+    if "floor_spearman" in res:
+        assert res["spearman"] >= res["floor_spearman"] - gate["below_floor"], res
+        assert res["mean_abs"] <= res["floor_mean_abs"] + gate["above_floor"], res
+    assert res["spearman"] >= gate["spearman"], res
+    assert res["mean_abs"] <= gate["mean_abs"], res
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_default_schedule_against_walk_ordered_global_negatives(shape):
+    nodes, m, rw, ew, iterations, epochs, ref_mode = SHAPES[shape]
+    g = E.barabasi_albert(nodes, m, 42)
+    kw = dict(embedding_size=128, epochs=epochs, walk_length=128, iterations=iterations,
+              window_size=5, number_of_negative_samples=10, return_weight=rw, explore_weight=ew,
+              learning_rate=0.01, random_state=42, verbose=False)
+    res = compare(g, kw, ref_mode, floor=shape == "config3_arxiv_shape")
+    print(f"{shape}: default (resident cells) vs walk-ordered / global negatives ({ref_mode}): {res}")
+    _gate(shape, res)
+
+
+@pytest.mark.timeout(1500)
+def test_default_schedule_at_the_bench_size():
+    """BA 10 M / 100 M (BASELINE config 5a, the bench graph), two epochs of 10^7 walks, reference
+    defaults: both schedules on the same walks.  (Two walks a node: both fits have barely left
+    their random start -- AUROC 0.59 -- what is gated is that they left it the same way.)"""
+    g = E.barabasi_albert(10_000_000, 10, 42)
+    kw = dict(embedding_size=128, epochs=2, walk_length=128, iterations=1, window_size=5,
+              number_of_negative_samples=10, return_weight=0.25, explore_weight=4.0,
+              learning_rate=0.01, random_state=42, verbose=False)
+    res = compare(g, kw, "auto")
+    print(f"bench graph: default (resident cells) vs walk-ordered / global negatives: {res}")
+    _gate("bench", res)
+
+
+# auc: VERDICT r5's 0.003 (one-sided); spearman / mean_abs: measured - / + margin
+# (profiles/r06_logs/r6_quality_gates.log: config 3 0.936 / 0.051 with a floor of ... ; config 4
+# 0.888 / 0.063 and the default 0.019 ABOVE the walk-ordered stores; bench graph 0.946 / 0.036)
+GATES = {
+    "config3_arxiv_shape": dict(auc=0.003, spearman=0.92, mean_abs=0.06, below_floor=0.03,
+                                above_floor=0.02),
+    "config4_products_shape": dict(auc=0.003, spearman=0.86, mean_abs=0.075),
+    "bench": dict(auc=0.003, spearman=0.92, mean_abs=0.05),
+}

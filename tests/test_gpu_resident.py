@@ -82,16 +82,22 @@ def _step_real_walks(g, og, d, k, parts, slices, record, flags, lr=0.05, n_walks
 
 @pytest.mark.parametrize("d,k,parts,slices,record", [
     (16, 4, 2, 32, 16), (100, 5, 2, 32, 32), (128, 10, 2, 64, 32), (128, 3, 3, 17, 8),
-    (256, 5, 2, 32, 16), (64, 0, 1, 40, 32), (320, 4, 2, 40, 16), (512, 5, 2, 32, 32)])
+    (256, 5, 2, 32, 16), (64, 0, 1, 40, 32), (320, 4, 2, 40, 16), (512, 5, 2, 32, 32),
+    (32, 70, 2, 32, 8), (128, 64, 1, 40, 8)])
 def test_deterministic_resident_step_matches_oracle(d, k, parts, slices, record):
     """Real walks (runs of equal centre, k > 0 negatives from the cell's alias table, negatives
-    that fall on the context or the centre, cells of 8-30 rows in LDS): <= 1e-5 per element."""
+    that fall on the context or the centre and are drawn again, cells of 8-30 rows in LDS):
+    <= 1e-5 per element.  k >= 64: sample lists longer than a wave (the null list -- what a
+    group without a pair scores -- has more than 64 entries)."""
     g = _ba(1999)
     og = O.OracleGraph(g.row_ptr, g.col_idx)
     c, xs, c_h, xs_h = _step_real_walks(g, og, d, k, parts, slices, record, DET)
-    assert np.abs(c - c_h).max() < 1e-5
+    # (k >= 64: 70 negatives a pair at this learning rate grow the rows to |2|: the bound is
+    # relative to the largest element)
+    tol = 1e-5 * max(1.0, float(np.abs(c_h).max()), max(float(np.abs(x).max()) for x in xs_h))
+    assert np.abs(c - c_h).max() < tol
     for x, x_h in zip(xs, xs_h):
-        assert np.abs(x - x_h).max() < 1e-5
+        assert np.abs(x - x_h).max() < tol
 
 
 def test_deterministic_resident_step_with_uniform_negatives_and_degree_normalised_rate():
@@ -138,7 +144,7 @@ def _unique_centre_pairs(n_nodes, parts, slices, oplan, per_cell, seed=3):
 
 
 @pytest.mark.parametrize("d,k", [(16, 4), (100, 5), (128, 10), (128, 1), (256, 6), (400, 5),
-                                 (512, 10), (512, 2)])
+                                 (512, 10), (512, 2), (64, 66), (128, 65)])
 def test_deterministic_pair_per_group_loop_matches_oracle(d, k):
     """Records of unique centres take the pair-per-group loop -- in the deterministic
     instantiation with the four groups taking turns: score_sample_pair (two samples side by

@@ -218,20 +218,89 @@ def test_normalize_by_degree_walks_and_fit(karate):
     assert not np.array_equal(res[0], plain.get_all_node_embedding()[0])
 
 
-def test_max_neighbours_of_the_smoke_configuration_is_accepted_and_walks_stay_exact(karate,
-                                                                                    karate_oracle):
+def test_max_neighbours_of_the_smoke_configuration_reaches_the_sampler(karate, karate_oracle):
     """The smoke configuration of the reference sets ``max_neighbours=10``
-    (embedders/ensmallen_embedders/node2vec.py:79-87; meaning: node2vec_skipgram.py:78-81).  The
-    engine's walks are exact for every value (tests/test_oracle.py::
-    test_max_neighbours_never_changes_the_walks states why that is the law the approximation
-    approximates): same walks on the GPU, through the C ABI, for 10, 100 and "unset"."""
+    (embedders/ensmallen_embedders/node2vec.py:79-87; meaning: node2vec_skipgram.py:78-81).
+    Karate's hubs have 12-17 neighbours: with 10 (and 3) their steps are taken over a sub-sample,
+    with 100 and None the walks are exact -- on the GPU, through the C ABI, as in the oracle."""
     import embiggen_amd as E
 
     smoke = E.Node2VecSkipGramEnsmallen().into_smoke_test()
     assert smoke.parameters()["max_neighbours"] == 10
     res = smoke.fit_transform(karate, return_dataframe=False).get_all_node_embedding()
     assert res[0].shape == (34, 5) and np.isfinite(res[0]).all()
-    ref = O.walks(karate_oracle, O.WalkParams(16, 2, 0.25, 4.0, 100, 0), 9, 0, 0, 68)
+    exact = O.walks(karate_oracle, O.WalkParams(16, 2, 0.25, 4.0, 0, 0), 9, 0, 0, 68)
     for mn in (10, 100, None, 3):
         wk = ops.walks(karate, ops.walk_params(16, 2, 0.25, 4.0, max_neighbours=mn), 9, 0, 0, 68)
+        ref = O.walks(karate_oracle, O.WalkParams(16, 2, 0.25, 4.0, mn or 0, 0), 9, 0, 0, 68)
         assert np.array_equal(wk.cpu().numpy().view(np.uint32), ref)
+        assert np.array_equal(ref, exact) == (mn in (100, None))
+
+
+# ---------------------------------------------------------------------- max_neighbours
+@pytest.mark.parametrize("records", ["1", "0"])
+@pytest.mark.parametrize("max_neighbours", [3, 10, 100, None])
+@pytest.mark.parametrize("rw,ew", [(1.0, 1.0), (0.25, 4.0), (2.0, 0.5), (4.0, 0.25)])
+def test_max_neighbours_sub_sampled_walks_bit_exact(monkeypatch, rw, ew, max_neighbours, records):
+    """``max_neighbours`` (node2vec_skipgram.py:22,78-81): steps out of nodes of higher degree
+    choose among a per-visit sub-sample of that many edges (walk_kernels.h RowView; the oracle's
+    row_view, whose law tests/test_oracle.py checks against an enumeration of every sub-sample).
+    Bit-exact against the oracle for 3, 10, 100 (the default) and None (exact walks), on a
+    scale-free graph whose hubs exceed 100 neighbours and on a directed graph with traps, through
+    the CSR kernel and the edge records, first and second order, both envelopes of the rejection
+    sampler (return apart: the previous node counts only when its bucket drew it)."""
+    monkeypatch.setenv("GN2V_WALK_EDGE_RECORDS", records)
+    m = 0 if max_neighbours is None else max_neighbours
+    s, d = O.ba_edges(4000, 6, 3)
+    g = E.CSRGraph.from_edge_list(s, d, number_of_nodes=4000)
+    deg = np.diff(g.row_ptr.astype(np.int64))
+    assert deg.max() > 100 and (deg > 10).sum() > 200
+    og = O.OracleGraph(g.row_ptr, g.col_idx)
+    got = _u32(ops.walks(g, ops.walk_params(48, 2, rw, ew, max_neighbours), 11, 2, 5, 8100))
+    ref = O.walks(og, O.WalkParams(48, 2, rw, ew, m, 0), 11, 2, 5, 8100)
+    assert np.array_equal(got, ref)
+    if max_neighbours is not None:  # the sub-sample acts: other walks than the exact ones
+        assert not np.array_equal(ref, O.walks(og, O.WalkParams(48, 2, rw, ew, 0, 0), 11, 2, 5, 8100))
+    rng = np.random.RandomState(5)
+    src, dst = rng.randint(0, 500, size=12_000), rng.randint(0, 500, size=12_000)
+    gd = E.CSRGraph.from_edge_list(src, dst, number_of_nodes=520, directed=True)
+    n = 2 * gd.get_number_of_unique_source_nodes() + 37
+    got = _u32(ops.walks(gd, ops.walk_params(40, 2, rw, ew, max_neighbours), 3, 1, 0, n))
+    assert np.array_equal(got, O.walks(O.OracleGraph(gd.row_ptr, gd.col_idx),
+                                       O.WalkParams(40, 2, rw, ew, m, 0), 3, 1, 0, n,
+                                       sources=gd.sources))
+
+
+@pytest.mark.parametrize("records", ["1", "0"])
+@pytest.mark.parametrize("max_neighbours", [4, 100])
+def test_max_neighbours_on_weighted_and_typed_graphs(monkeypatch, max_neighbours, records):
+    """Weights on a sub-sample have no cumulative sums to search: the step is the exact scan over
+    the sub-sample's elements (weight x threshold) -- unbiased steps included; typed graphs draw
+    their candidates from the sub-sample and apply the type factors as before."""
+    monkeypatch.setenv("GN2V_WALK_EDGE_RECORDS", records)
+    rng = np.random.RandomState(4)
+    s, d = O.ba_edges(3000, 5, 6)
+    w = rng.uniform(0.05, 6.0, size=len(s))
+    g = E.CSRGraph.from_edge_list(s, d, w, number_of_nodes=3000)
+    og = O.OracleGraph(g.row_ptr, g.col_idx, g.cumw)
+    for rw, ew in ((1.0, 1.0), (0.25, 4.0), (2.0, 0.5)):
+        got = _u32(ops.walks(g, ops.walk_params(32, 2, rw, ew, max_neighbours), 9, 1, 3, 6100))
+        assert np.array_equal(got, O.walks(og, O.WalkParams(32, 2, rw, ew, max_neighbours, 0),
+                                           9, 1, 3, 6100)), (rw, ew)
+    gt = E.CSRGraph.from_edge_list(s, d, number_of_nodes=3000,
+                                   node_types=rng.randint(0, 4, size=3000).tolist(),
+                                   edge_types=rng.randint(0, 3, size=len(s)).tolist())
+    ogt = O.OracleGraph(gt.row_ptr, gt.col_idx, gt.cumw, gt.node_type_ids, gt.edge_type_ids)
+    for rw, ew, cn, ce in ((0.25, 4.0, 2.0, 0.5), (1.0, 1.0, 0.1, 10.0), (2.0, 0.5, 1.0, 3.0)):
+        got = _u32(ops.walks(gt, ops.walk_params(32, 2, rw, ew, max_neighbours, cn, ce), 5, 1, 0,
+                             6000))
+        assert np.array_equal(got, O.walks(ogt, O.WalkParams(32, 2, rw, ew, max_neighbours, 0, cn,
+                                                             ce), 5, 1, 0, 6000)), (rw, ew, cn, ce)
+    gw = E.CSRGraph.from_edge_list(s, d, w, number_of_nodes=3000,
+                                   node_types=rng.randint(0, 3, size=3000).tolist(),
+                                   edge_types=rng.randint(0, 3, size=len(s)).tolist())
+    ogw = O.OracleGraph(gw.row_ptr, gw.col_idx, gw.cumw, gw.node_type_ids, gw.edge_type_ids)
+    got = _u32(ops.walks(gw, ops.walk_params(32, 2, 0.25, 4.0, max_neighbours, 0.5, 2.0), 5, 1, 0,
+                         6000))
+    assert np.array_equal(got, O.walks(ogw, O.WalkParams(32, 2, 0.25, 4.0, max_neighbours, 0, 0.5,
+                                                         2.0), 5, 1, 0, 6000))

@@ -363,43 +363,72 @@ def test_normalize_by_degree_is_a_destination_degree_weighting(karate):
         assert stats.chisquare(counts, p / p.sum() * counts.sum()).pvalue > 1e-4
 
 
-@pytest.mark.parametrize("max_neighbours", [10, 3, 100, 0])
-def test_max_neighbours_never_changes_the_walks(karate, karate_oracle, max_neighbours):
-    """``max_neighbours`` (node2vec_skipgram.py:22,78-81: "Number of maximum neighbours to
-    consider when using approximated walks ... mainly useful for graphs containing nodes with high
-    degrees"; the smoke configuration sets it to 10, node2vec.py:79-87) is the reference's CPU-cost
-    approximation of the exact walk: candidates are drawn from a uniform sub-sample of the
-    neighbours of a hub.  The engine never needs the approximation (rejection sampling costs O(1)
-    per step whatever the degree), so the kwarg is accepted and walks are EXACT for every value:
+@pytest.mark.parametrize("rw,ew", [(0.25, 4.0), (2.0, 0.5), (1.0, 1.0)])
+def test_max_neighbours_above_every_degree_or_none_walks_exactly(karate_oracle, rw, ew):
+    """``max_neighbours`` (node2vec_skipgram.py:22,78-81; None = exact) acts on rows LONGER than
+    it only: Karate's largest degree is 17, so 100 (the default), 17 and 0 (= None at the C
+    boundary) give the same walks -- and the default on a graph without hubs is the exact walk."""
+    ref = O.walks(karate_oracle, O.WalkParams(12, 1, rw, ew, 0, 0), 7, 0, 0, 34 * 40)
+    for m in (100, 17):
+        assert np.array_equal(O.walks(karate_oracle, O.WalkParams(12, 1, rw, ew, m, 0), 7, 0, 0,
+                                      34 * 40), ref)
+    assert not np.array_equal(O.walks(karate_oracle, O.WalkParams(12, 1, rw, ew, 16, 0), 7, 0, 0,
+                                      34 * 40), ref)
 
-    * first-order walks on unweighted graphs: a uniform pick from a uniform sub-sample IS a
-      uniform pick from all neighbours, so exact and sub-sampled walks have the same law;
-    * second-order / weighted walks: the exact transition law is what the sub-sampled walk
-      approximates (its limit for max_neighbours -> infinity).
 
-    Karate's hubs have 16-17 neighbours (> 10): with max_neighbours = 10 the transition
-    frequencies still match the exact node2vec law, and the walks are identical for any value."""
-    rw, ew = 0.25, 4.0
-    assert max(np.diff(karate.row_ptr.astype(np.int64))) > 10
-    ref = O.walks(karate_oracle, O.WalkParams(12, 1, rw, ew, 100, 0), 7, 0, 0, 34 * 1500)
-    w = O.walks(karate_oracle, O.WalkParams(12, 1, rw, ew, max_neighbours, 0), 7, 0, 0, 34 * 1500)
-    assert np.array_equal(w, ref)
-    w = w.astype(np.int64)
+@pytest.mark.parametrize("rw,ew", [(0.25, 4.0), (2.0, 0.5), (1.0, 1.0)])
+@pytest.mark.parametrize("max_neighbours", [10, 3])
+def test_max_neighbours_walks_hubs_over_a_sub_sample(karate, karate_oracle, max_neighbours, rw, ew):
+    """"Number of maximum neighbours to consider when using approximated walks ... mainly useful
+    for graphs containing nodes with high degrees" (node2vec_skipgram.py:78-81; the smoke
+    configuration sets 10, node2vec.py:79-87).  Restated (oracle row_view): a step out of a node
+    of degree > max_neighbours chooses among a sub-sample of max_neighbours of its edges -- one
+    per bucket of the row, drawn afresh at every visit -- by the exact node2vec law on them.
+    Checked against an independent ENUMERATION of every possible sub-sample
+    (helpers.exact_sub_sampled_probs): chi-square of the (prev, cur) -> next frequencies for the
+    hubs, the exact law for every other node; both envelopes of the rejection sampler (return
+    apart and not) and first-order walks."""
+    from helpers import exact_sub_sampled_probs
+
+    deg = np.diff(karate.row_ptr.astype(np.int64))
+    assert deg.max() > max_neighbours
+    w = O.walks(karate_oracle, O.WalkParams(12, 1, rw, ew, max_neighbours, 0), 7, 0, 0,
+                34 * 3000).astype(np.int64)
     prev, cur, nxt = w[:, :-2].ravel(), w[:, 1:-1].ravel(), w[:, 2:].ravel()
     key = prev * 34 + cur
-    hubs = [v for v in range(34) if karate.row_ptr[v + 1] - karate.row_ptr[v] > 10]
-    pvals = []
+    pvals = {True: [], False: []}
     for k in np.unique(key):
         p, c = divmod(int(k), 34)
         sel = key == k
-        if c not in hubs or sel.sum() < 1500:
-            continue
-        neigh, probs = exact_second_order_probs(karate, p, c, rw, ew)
+        hub = deg[c] > max_neighbours
+        if sel.sum() < 2000 or (hub and max_neighbours == 3 and deg[c] > 12):
+            continue  # (3 buckets of a row of 16-17 edges: 200 sub-samples: fine; keep it quick)
+        neigh, probs = (exact_sub_sampled_probs(karate, p, c, rw, ew, max_neighbours) if hub
+                        else exact_second_order_probs(karate, p, c, rw, ew))
         counts = np.array([(nxt[sel] == x).sum() for x in neigh], dtype=np.float64)
-        if (probs * counts.sum() < 5).any():
+        assert counts.sum() == sel.sum()
+        keep = probs * counts.sum() >= 5
+        if keep.sum() < 2:
             continue
-        pvals.append(stats.chisquare(counts, probs * counts.sum()).pvalue)
-    assert len(pvals) >= 5 and min(pvals) > 1e-3 / len(pvals), (pvals,)
+        pvals[bool(hub)].append(stats.chisquare(
+            counts[keep], probs[keep] / probs[keep].sum() * counts[keep].sum()).pvalue)
+    n = len(pvals[True]) + len(pvals[False])
+    assert len(pvals[True]) >= 5 and len(pvals[False]) >= 5, {k: len(v) for k, v in pvals.items()}
+    assert min(pvals[True] + pvals[False]) > 1e-3 / n, (pvals,)
+    # and the sub-sampled law is NOT the exact one (the test can tell them apart) when the
+    # weights differ inside a row
+    if (rw, ew) != (1.0, 1.0) and max_neighbours == 3:
+        far = []
+        for k in np.unique(key):
+            p, c = divmod(int(k), 34)
+            sel = key == k
+            if deg[c] <= 12 and deg[c] > 3 and sel.sum() >= 4000:
+                neigh, probs = exact_second_order_probs(karate, p, c, rw, ew)
+                counts = np.array([(nxt[sel] == x).sum() for x in neigh], dtype=np.float64)
+                keep = probs * counts.sum() >= 5
+                far.append(stats.chisquare(counts[keep], probs[keep] / probs[keep].sum()
+                                           * counts[keep].sum()).pvalue)
+        assert far and min(far) < 1e-6, far
 
 
 def test_tuned_oracle_build_is_the_same_algorithm(karate_oracle):
