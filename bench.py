@@ -257,6 +257,42 @@ def committed_traffic(traffic_key):
                   f"(run scripts/profile_bench.sh on this command line); found: {seen}")
 
 
+def committed_counters(kernel, ld, kernel_pairs_per_s):
+    """What the committed rocprofv3 counter passes of the resident kernel say about its two
+    bounds (profiles/r06_atomic_counters.json: TCC counters of the kernel and of the atomic probe;
+    profiles/r06_resident_counters.json: SQ instruction counters): `atomic_unit_busy` -- the
+    TCCs' busy share and the atomic sectors they retire per channel-cycle next to the probe's --
+    and `valu_issued_frac`, the vector instructions REALLY issued per pair x this run's kernel
+    pairs/s over the chip's issue rate (valu_issue_frac prices the arithmetic's floor only)."""
+    out = {}
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r06_atomic_counters.json")))
+        mine = next(v for k, v in rec["bench"].items() if kernel.split("::")[-1] in k)
+        probe = max(v["atomic_sectors_per_channel_cycle"]
+                    for k, v in rec["atomic_probe_10000000_rows"].items()
+                    if v.get("atomic_sectors_per_channel_cycle"))
+        out["atomic_unit_busy"] = {
+            "tcc_busy": mine["tcc_busy"],
+            "atomic_sectors_per_channel_cycle": mine["atomic_sectors_per_channel_cycle"],
+            "probe_atomic_sectors_per_channel_cycle": probe,
+            "of_probe_per_cycle": mine["atomic_sectors_per_channel_cycle"] / probe,
+            "source": "profiles/r06_atomic_counters.json (rocprofv3 --pmc TCC_ATOMIC_SECTORS_sum "
+                      "TCC_BUSY_sum TCC_CYCLE_sum of this kernel and of scripts/atomic_probe.hip; "
+                      "profiles/r06_atomic_summary.md)"}
+    except (OSError, ValueError, KeyError, StopIteration):
+        out["atomic_unit_busy"] = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r06_resident_counters.json")))
+        if rec["bench"]["kernel"] == kernel and ld == 128:
+            issued = rec["per_pair"]["SQ_INSTS_VALU"]
+            out["valu_issued_per_pair"] = issued
+            out["valu_issued_frac"] = issued * kernel_pairs_per_s / 1e9 / VALU_ISSUE_PEAK_GIPS
+            out["valu_issued_source"] = "profiles/r06_resident_counters.json (SQ_INSTS_VALU per pair)"
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
 def cpu_baseline(graph, args, central, contextual, seconds):
     """The oracle's OpenMP Hogwild restatement timed on this box's host cores, on a bounded
     sample of the same workload (same graph, same parameters, walk ids past the GPU's)."""
@@ -531,8 +567,10 @@ def main():
             if getattr(blocks, "permute", False):
                 # resident cells: at least 16 rounds per epoch of the graph (10 walks a node),
                 # the rule of gn2v_train_blocks / models.fit_transform_blocks
-                rounds = max(1, int(os.environ.get("GN2V_ROUNDS_PER_EPOCH", "16") or 16))
-                auto_walks = min(auto_walks, max(1 << 16, -(-n * 10 // (rounds * max(t_world, stripes)))))
+                from embiggen_amd.distributed import rounds_per_epoch
+
+                shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "") or 1 << 14)
+                auto_walks = min(auto_walks, max(shortest, -(-n * 10 // (rounds_per_epoch(1) * max(t_world, stripes)))))
             args.round_walks = stripes * auto_walks
             # equal rounds (as gn2v_train_blocks cuts an epoch): 20 steps of 2^20 walks are three
             # rounds of 6.99 M, not two of 2^23 and a half one
@@ -916,15 +954,20 @@ def main():
             roof["kernel_pairs_per_s"] = kernel_pairs_per_s
             roof["valu_floor_per_pair"] = floor
             roof["valu_issue_frac"] = floor * kernel_pairs_per_s / 1e9 / VALU_ISSUE_PEAK_GIPS
+            # counters behind the two figures above, from the committed passes of this kernel
+            # (scripts/atomic_counters.sh, scripts/resident_counters.sh): how busy the L2 atomic
+            # units really are, and the vector instructions really issued per pair
+            roof.update(committed_counters(kernel, ld, kernel_pairs_per_s))
             roof["note"] = (
                 "bound = l2_atomic: frac = (ld f32 atomic adds per pair: the gradient of the "
                 "central row, exact) x kernel pairs/s / 3.31e11 dword adds/s (what "
                 "scripts/atomic_probe.hip measures on this chip for any instruction shape; "
-                "profiles/r05_logs/r5_atomic_probe.log).  valu_issue_frac = the arithmetic's "
+                "profiles/r05_logs/r5_atomic_probe.log, counters profiles/r06_atomic_summary.md).  valu_issue_frac = the arithmetic's "
                 f"floor of vector instructions per pair ({floor:.1f}: bench.py "
                 "valu_floor_per_pair) x kernel pairs/s / (1 024 SIMDs x 2.4 GHz / 4 cycles): the "
-                "counter pass profiles/r05_resident_counters.json gives the instructions really "
-                "issued.  work_over_hbm_peak = SURVEY 8d's 12 288 B per pair / time / 8 TB/s: it "
+                "counter pass profiles/r06_resident_counters.json gives the instructions really "
+                "issued (valu_issued_frac); atomic_unit_busy = the TCC counters of this kernel "
+                "next to the probe's (profiles/r06_atomic_summary.md).  work_over_hbm_peak = SURVEY 8d's 12 288 B per pair / time / 8 TB/s: it "
                 "prices work, exceeds 1 because the sample rows never move through HBM, and is "
                 "not a roofline fraction; frac_hbm = bytes that really leave L2 (committed PMC "
                 "profile) / time / 8 TB/s")

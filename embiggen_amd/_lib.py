@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_CSRC, "libgn2v.so")
 _UNITS = ["gn2v_api.hip", "gn2v_block_api.hip"]  # translation units of libgn2v.so
 _HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v.h")
 _HEADER_EXPERIMENTAL = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v_experimental.h")
+_HEADER_INTERNAL = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v_internal.h")
 
 SENTINEL = 0xFFFFFFFF
 GRAPH_DEVICE_PTRS = 1
@@ -35,22 +36,26 @@ TRAIN_CTX_CACHE_NONE = 512
 MODEL_SKIPGRAM = 0
 MODEL_CBOW = 1
 
-# every symbol include/gn2v.h declares (checked by tests/test_cabi.py)
-EXPORTS = [
+# every symbol include/gn2v.h declares -- the drop-in boundary (checked by tests/test_cabi.py)
+BOUNDARY_EXPORTS = [
     "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
-    "gn2v_graph_destroy", "gn2v_graph_set_types", "gn2v_ba_edges", "gn2v_walks", "gn2v_window_batch", "gn2v_walk_pairs",
-    "gn2v_init_table",
-    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_train", "gn2v_edge_embedding",
-    "gn2v_cooc_slots", "gn2v_glove_step",
-    "gn2v_touch_rows",
+    "gn2v_graph_destroy", "gn2v_graph_set_types", "gn2v_ba_edges", "gn2v_walks",
+    "gn2v_window_batch", "gn2v_walk_pairs", "gn2v_init_table",
+    "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_train", "gn2v_train_blocks", "gn2v_train_world",
+    "gn2v_edge_embedding", "gn2v_cooc_slots", "gn2v_glove_step",
+    "gn2v_graph_release_buffers", "gn2v_graph_walk_accel", "gn2v_stats_reset", "gn2v_stats_read",
+]
+# include/gn2v_internal.h: the steps gn2v_train_blocks is made of (the multi-process trainer and
+# the parity tests drive them one at a time) and the measurement utilities
+INTERNAL_EXPORTS = [
     "gn2v_block_plan_check", "gn2v_init_table_rows", "gn2v_block_alias_temp_bytes",
     "gn2v_block_alias", "gn2v_block_placement_temp_bytes", "gn2v_block_placement",
     "gn2v_block_place_walks", "gn2v_block_count", "gn2v_block_extract_temp_bytes",
-    "gn2v_block_extract", "gn2v_block_cell_offsets", "gn2v_block_step", "gn2v_block_round", "gn2v_block_auto_plan", "gn2v_block_auto_plan_graph", "gn2v_block_round_plan", "gn2v_graph_xcds", "gn2v_graph_reserve_cus",
-    "gn2v_train_blocks", "gn2v_graph_release_buffers", "gn2v_graph_walk_accel",
-    "gn2v_stats_reset",
-    "gn2v_stats_read",
+    "gn2v_block_extract", "gn2v_block_cell_offsets", "gn2v_block_step", "gn2v_block_round",
+    "gn2v_block_auto_plan", "gn2v_block_auto_plan_graph", "gn2v_block_round_plan",
+    "gn2v_graph_xcds", "gn2v_graph_reserve_cus", "gn2v_touch_rows",
 ]
+EXPORTS = BOUNDARY_EXPORTS + INTERNAL_EXPORTS
 
 
 class WalkParams(C.Structure):
@@ -133,7 +138,7 @@ class BlockIO(C.Structure):
 
 
 class BlockRoundIO(C.Structure):
-    """gn2v_block_round_io (include/gn2v.h)."""
+    """gn2v_block_round_io (include/gn2v_internal.h)."""
     _fields_ = [
         ("d_walks", C.c_void_p),
         ("d_placed_walks", C.c_void_p),
@@ -164,6 +169,27 @@ class BlockRoundIO(C.Structure):
 
 
 ROUND_GROW = 3  # GN2V_ROUND_GROW
+
+# gn2v_comm (include/gn2v.h): the communicator a host fills for gn2v_train_world
+COMM_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+COMM_SENDRECV_START = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                  C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                  C.POINTER(C.c_void_p))
+COMM_SENDRECV_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+COMM_BROADCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p)
+
+
+class Comm(C.Structure):
+    _fields_ = [
+        ("ctx", C.c_void_p),
+        ("rank", C.c_uint32),
+        ("world", C.c_uint32),
+        ("all_gather", COMM_ALL_GATHER),
+        ("sendrecv_start", COMM_SENDRECV_START),
+        ("sendrecv_wait", COMM_SENDRECV_WAIT),
+        ("broadcast", COMM_BROADCAST),
+    ]
+
 
 # include/gn2v_experimental.h: measured-and-rejected designs kept for their scripts and tests
 EXPERIMENTAL_EXPORTS = ["gn2v_step"]
@@ -207,7 +233,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     # every header and unit in csrc/ is a dependency: a stale library must never survive an edit
     srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip")))
-    srcs += [_HEADER, _HEADER_EXPERIMENTAL]
+    srcs += [_HEADER, _HEADER_EXPERIMENTAL, _HEADER_INTERNAL]
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(s) for s in srcs)
         if os.path.getmtime(LIB_PATH) >= newest:
@@ -294,6 +320,8 @@ def lib():
     L.gn2v_block_auto_plan_graph.argtypes = [vp, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), vp]
     L.gn2v_block_round_plan.argtypes = [u64, u64, u32, u32, u32, u32, u32, u32, C.POINTER(u64),
                                         C.POINTER(u32)]
+    L.gn2v_train_world.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,
+                                   u64, C.POINTER(Comm), vp, vp, C.POINTER(Stats), vp]
     L.gn2v_train_blocks.argtypes = [vp, C.POINTER(WalkParams), C.POINTER(TrainParams), u64, u64,
                                     u64, u32, vp, vp, C.POINTER(Stats), vp]
     L.gn2v_graph_release_buffers.argtypes = [vp]

@@ -27,7 +27,7 @@
 // 12 + 27 + 17 bits); a round's pairs are extracted and sorted a group of parts at a time, so the
 // buffers hold 1 / groups of the round.
 #pragma once
-#include "../../include/gn2v.h"
+#include "../../include/gn2v_internal.h"
 #include "train_kernels.h"
 
 namespace gn2v {

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/gn2v.h"
+#include "../../include/gn2v_internal.h"
 #include "../../include/gn2v_experimental.h"
 #include "rng.h"
 #include "edge_kernels.h"

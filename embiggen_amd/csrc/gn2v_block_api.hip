@@ -1616,13 +1616,18 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         // mates, and the cosine of the central rows pays for it -- config 3's shape (169 k
         // nodes, three epochs of ten walks a node), cos-central AUROC by rounds per epoch:
         // 1 0.9893, 4 0.9946, 8 0.9958, 16 0.9964 (walk-ordered kernel with graph-wide
-        // negatives: 0.9972) at the same kernel speed (profiles/r06_logs/r6_rounds_quality.log).
-        // So an epoch of the graph -- iterations x sources walks, whatever the caller's walk
-        // budget -- is cut into at least GN2V_ROUNDS_PER_EPOCH (16) rounds, none shorter than
-        // 2^16 walks.
-        const uint64_t rounds = std::max<uint64_t>(1, env_size("GN2V_ROUNDS_PER_EPOCH", 16));
+        // negatives: 0.9972) at the same kernel speed (profiles/r06_logs/r6_rounds_quality.log);
+        // rank correlation of the cosines with that kernel's: 16 0.936, 26 0.946, 64 0.955,
+        // 128 0.958 where it agrees with ITSELF under other negatives to 0.969
+        // (r6_quality_gates_*.log).  What counts is how many sets of mates a context meets
+        // while its row forms -- rounds over the whole fit -- so an epoch of the graph
+        // (iterations x sources walks, whatever the caller's walk budget) is cut into
+        // 192 / epochs rounds, at least 16 and at most 64 (rounds_per_epoch), none shorter than
+        // 2^14 walks.  Cost of 64 against 16: 1.6 % on the bench graph, 12 % at 169 k nodes.
+        const uint64_t rounds = gn2v_host::rounds_per_epoch(tp->epochs);
         const uint64_t epoch = g->view.n_sources * (uint64_t)wp->iterations;
-        const uint64_t mixed = std::max<uint64_t>(1ull << 16, (epoch + rounds * V - 1) / (rounds * V));
+        const uint64_t shortest = std::max<uint64_t>(1, env_size("GN2V_ROUND_MIN_WALKS", 1ull << 14));
+        const uint64_t mixed = std::max<uint64_t>(shortest, (epoch + rounds * V - 1) / (rounds * V));
         round_walks = std::min(round_walks, mixed);
     }
     const uint64_t planned_walks = round_walks;
@@ -1830,3 +1835,5 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
 }
 
 }  // extern "C"
+
+#include "world_driver.h"

@@ -3,12 +3,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
 
-#include "../../include/gn2v.h"
+#include "../../include/gn2v_internal.h"
 #include "walk_kernels.h"
 
 namespace gn2v_host {
@@ -124,6 +126,14 @@ struct gn2v_graph {
 };
 
 namespace gn2v_host {
+// Rounds an epoch of the graph is cut into under a placement (resident cells): 192 over the
+// whole fit, at least 16 and at most 64 an epoch; GN2V_ROUNDS_PER_EPOCH pins it (A/B).
+inline uint64_t rounds_per_epoch(uint32_t epochs) {
+    if (const char *v = getenv("GN2V_ROUNDS_PER_EPOCH"))
+        if (*v) return std::max<uint64_t>(1, strtoull(v, nullptr, 10));
+    const uint64_t e = epochs ? epochs : 1;
+    return std::min<uint64_t>(64, std::max<uint64_t>(16, (192 + e - 1) / e));
+}
 int get_events(gn2v_graph *g, EventPair *ev);
 int prepare_walk_sampler(gn2v_graph *g, const gn2v_walk_params *wp, hipStream_t s);
 void release_kept_buffers(gn2v_graph *g);

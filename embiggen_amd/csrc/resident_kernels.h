@@ -403,7 +403,12 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
                 // different rows runs the kernel at 1.35e9 pairs/s, one row per instruction at
                 // 2.26e9, no hand-over at all at 3.5e9 -- the L2 atomic units, 3.1e11 dword adds/s
                 // in scripts/atomic_probe.hip, are what bounds this kernel: 128 dwords per pair,
-                // 2.45e9 pairs/s at most.)
+                // 2.45e9 pairs/s at most.  Round 6: the TCC counters confirm it per cycle
+                // (profiles/r06_atomic_summary.md) -- and folding the gradients of neighbouring
+                // pairs of one centre in these rows before the atomics, with the pairs sorted by
+                // the whole centre, took 17 % of the atomic rows away and left the kernel where it
+                // was (2.32 against 2.31e9: profiles/r06_logs/r6_fold_ab.log): instruction issue
+                // and LDS waits stand right behind the atomic units.  Not kept.)
 #pragma unroll
                 for (int pass = 0; pass < (CH + 1) / 2; ++pass) {
                     wave_sync();
@@ -418,9 +423,9 @@ __device__ __forceinline__ void res_train_record(const BlockArgs &a, const ResCe
                         const uint32_t tw = res_tr_floats(a.ld);
                         for (uint32_t gi = DET ? (uint32_t)turn : 0u; gi < (DET ? turn + 1u : 4u); ++gi) {
                             if (p4 + gi >= n) break;  // uniform
-                            float *row = a.central + (uint64_t)s_key[p4 + gi] * a.cld + 128 * pass;
                             const float *src = s_tr + gi * tw;
                             const uint32_t f = 128 * pass + lane;
+                            float *row = a.central + (uint64_t)s_key[p4 + gi] * a.cld + 128 * pass;
                             if (f < a.ld) unsafeAtomicAdd(row + lane, src[lane]);
                             if (f + 64 < a.ld && lane + 64 < tw) unsafeAtomicAdd(row + 64 + lane, src[64 + lane]);
                         }

@@ -52,6 +52,16 @@ def stripe_rows(n: int, first: int, stride: int) -> int:
     return (n - first + stride - 1) // stride if n > first else 0
 
 
+def rounds_per_epoch(epochs: int) -> int:
+    """Rounds an epoch of the graph is cut into under a placement (csrc/handle.h
+    ``rounds_per_epoch``: 192 over the fit, 16 to 64 an epoch; GN2V_ROUNDS_PER_EPOCH pins it)."""
+    pinned = os.environ.get("GN2V_ROUNDS_PER_EPOCH", "")
+    if pinned:
+        return max(1, int(pinned))
+    e = max(1, int(epochs))
+    return min(64, max(16, -(-192 // e)))
+
+
 PAIR_ROOM = 1 << 24  # pair buffers are sized in steps of this many pairs
 MIN_ROWS_PER_CELL = 32768
 
@@ -210,6 +220,68 @@ class TorchComm:
                 dist.recv(buffer, src, group=self._group)
             return buffer
         return None
+
+
+class _DeviceBytes:
+    """A raw device range as an object torch.as_tensor understands (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+class CComm:
+    """``gn2v_comm`` (include/gn2v.h) over one of this module's communicators: what the host hands
+    to ``gn2v_train_world`` so that the C loop moves its walks and parts through
+    torch.distributed (RCCL: ``TorchComm``), through the threads of a test, or not at all
+    (``LoopbackComm``).  The callbacks see raw device pointers and byte counts and wrap them as
+    uint8 tensors without a copy; they run on the calling thread with the GIL held.  Keep the
+    object alive for as long as the C call runs (it owns the ctypes callbacks)."""
+
+    def __init__(self, comm, device):
+        import torch
+
+        from . import _lib
+
+        self.comm, self.device = comm, torch.device(device)
+        self._pending, self._next, self.error = {}, 1, None
+
+        def view(ptr, nbytes):
+            return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=self.device)
+
+        def guarded(fn):
+            def call(*args):
+                try:
+                    with torch.cuda.device(self.device):
+                        fn(*args)
+                    return 0
+                except Exception as e:  # noqa: BLE001 -- a Python error must not cross the C frame
+                    self.error = e
+                    return 1
+            return call
+
+        def all_gather(_ctx, send, recv, nbytes, _stream):
+            out = comm.all_gather(view(send, nbytes))
+            view(recv, nbytes * comm.world).copy_(out.reshape(-1))
+
+        def sendrecv_start(_ctx, send, send_bytes, dst, recv, recv_bytes, src, _stream, handle):
+            pending = comm.sendrecv_start(view(send, send_bytes), int(dst), view(recv, recv_bytes),
+                                          int(src))
+            key, self._next = self._next, self._next + 1
+            self._pending[key] = pending
+            handle[0] = key
+
+        def sendrecv_wait(_ctx, handle, _stream):
+            self._pending.pop(int(handle)).wait()
+
+        def broadcast(_ctx, buf, nbytes, root, _stream):
+            comm.broadcast(view(buf, nbytes), int(root))
+
+        self._callbacks = (_lib.COMM_ALL_GATHER(guarded(all_gather)),
+                           _lib.COMM_SENDRECV_START(guarded(sendrecv_start)),
+                           _lib.COMM_SENDRECV_WAIT(guarded(sendrecv_wait)),
+                           _lib.COMM_BROADCAST(guarded(broadcast)))
+        self.struct = _lib.Comm(None, comm.rank, comm.world, *self._callbacks)
 
 
 class GpuBlockBackend:

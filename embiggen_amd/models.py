@@ -316,13 +316,16 @@ class _WalkBasedModel:
                     agreed = comm.all_gather(mine).view(-1, 2).min(0).values
                     auto_walks, auto_group = int(agreed[0]), int(agreed[1])
                 if round_walks is None and getattr(trainer, "permute", False):
-                    # resident cells: at least 16 rounds -- 16 sets of cell-mates -- per epoch of
-                    # the graph, none shorter than 2^16 walks (gn2v_train_blocks: the same rule
-                    # and the measurement behind it)
-                    rounds = max(1, int(os.environ.get("GN2V_ROUNDS_PER_EPOCH", "16") or 16))
+                    # resident cells: 192 rounds -- sets of cell-mates -- over the fit, 16 to 64
+                    # per epoch of the graph, none shorter than 2^14 walks (gn2v_train_blocks:
+                    # the same rule and the measurement behind it)
+                    from .distributed import rounds_per_epoch
+
+                    rounds = rounds_per_epoch(self.epochs)
+                    shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "") or 1 << 14)
                     epoch_walks = csr.get_number_of_unique_source_nodes() * self.iterations
                     auto_walks = min(auto_walks,
-                                     max(1 << 16, -(-epoch_walks // (rounds * lanes))))
+                                     max(shortest, -(-epoch_walks // (rounds * lanes))))
                 round_walks = auto_walks if round_walks is None else round_walks
                 group_parts = auto_group if group_parts is None else group_parts
             trainer.group_parts = max(1, min(int(group_parts), trainer.parts))
@@ -373,6 +376,52 @@ class _WalkBasedModel:
             )
         return central, contextual
 
+    def fit_transform_world(self, graph, comm, round_walks: int = 0, max_walks_per_epoch: int = 0):
+        """SkipGram over several GPUs through the C loop (``gn2v_train_world``, include/gn2v.h):
+        the schedule of ``fit_transform_blocks`` without Python between the launches -- what a
+        non-Python binding of node2vec.py:99 calls on every rank.  ``comm``: one of
+        ``distributed``'s communicators (wrapped as a ``gn2v_comm`` of callbacks; a C host hands
+        over RCCL calls instead).  Every rank returns the full ``(central, contextual)`` device
+        tensors [N, padded_size]."""
+        import torch
+
+        from .distributed import CComm
+
+        if self.MODEL_ID != _lib.MODEL_SKIPGRAM:
+            raise NotImplementedError("Multi-GPU training is available for SkipGram only.")
+        csr = _as_csr(graph, self.normalize_by_degree)
+        _lib.require_device()
+        device = torch.cuda.current_device() if comm.world > 1 else self.device
+        dev = torch.device("cuda", device)
+        dgraph = csr.device_graph(device)
+        n, ld = csr.get_number_of_nodes(), self.padded_size
+        with torch.cuda.device(dev):
+            central = torch.empty((n, ld), dtype=torch.float32, device=dev)
+            contextual = torch.empty((n, ld), dtype=torch.float32, device=dev)
+            torch.cuda.empty_cache()
+            stream = torch.cuda.current_stream().cuda_stream
+            wp, tp, stats = self.walk_params(), self.train_params(), _lib.Stats()
+            c_comm = CComm(comm, dev)
+            L = _lib.lib()
+            _lib.check(L.gn2v_stats_reset(dgraph.handle, stream))
+            start = time.perf_counter()
+            rc = L.gn2v_train_world(dgraph.handle, C.byref(wp), C.byref(tp), self.random_state,
+                                    max_walks_per_epoch, int(round_walks),
+                                    C.byref(c_comm.struct), central.data_ptr(),
+                                    contextual.data_ptr(), C.byref(stats), stream)
+            if rc and c_comm.error is not None:
+                raise c_comm.error
+            _lib.check(rc)
+            self.last_seconds = time.perf_counter() - start
+            if not getattr(self, "keep_buffers", False):
+                _lib.check(L.gn2v_graph_release_buffers(dgraph.handle))
+        self.last_stats = stats.as_dict()
+        self.last_plan = {"world": comm.world, "parts": stats.block_parts,
+                          "slices": stats.block_slices, "stripes": 1,
+                          "group_parts": stats.block_group_parts,
+                          "round_walks": stats.block_round_walks}
+        return central, contextual
+
     def fit_transform(self, graph) -> List[np.ndarray]:
         """``[central, contextual]`` as freshly allocated C-contiguous float32 [N, d] arrays
         (or ``np.memmap``s when the ``*_embedding_path`` arguments are given).
@@ -395,7 +444,11 @@ class _WalkBasedModel:
             # ranks return None -- 1 / world of the result traffic and no full tables beside
             # their shards; default (None): every rank returns them, like the reference's call
             root = getattr(self, "gather_root", None)
-            central, contextual = self.fit_transform_blocks(graph, comm, root=root)
+            if os.environ.get("GN2V_WORLD_LOOP", "python") == "c":
+                # the rounds of every rank driven by gn2v_train_world, the communicator as callbacks
+                central, contextual = self.fit_transform_world(graph, comm)
+            else:
+                central, contextual = self.fit_transform_blocks(graph, comm, root=root)
             if central is None:
                 return None
         if central is None:

@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "gn2v.h"
+#include "gn2v_internal.h" /* the host-only planning entry points live there */
 
 int main(void) {
     if (gn2v_version() < 200) return 1;

@@ -132,6 +132,68 @@ def block_path_properties(g, n_walks, plan, d=128, return_weight=0.25, explore_w
     return m.last_plan, st
 
 
+def cbow_full_size_properties(g, n_walks, d=128):
+    """CBOW (embedders/ensmallen_embedders/node2vec_cbow.py:9-146) at full size: the mirror image
+    of SkipGram's properties -- the mean of a window's CONTEXTUAL rows is scored against the
+    central rows of the centre and of k negatives, every context row receives the shared
+    gradient: contextual rows move only for walk nodes, central rows also for the negatives.
+    First one launch (``gn2v_cbow_step``), then the whole fit through ``gn2v_train`` -- the call
+    ``Node2VecCBOWEnsmallen.fit_transform`` makes -- on a budget of ``n_walks`` walks."""
+    n = g.get_number_of_nodes()
+    wp = ops.walk_params(128, 10, 0.25, 4.0)
+    wk = ops.walks(g, wp, 42, 0, 0, n_walks)
+    c = ops.init_table(n, d, 42, 0, d ** -0.5)
+    x = ops.init_table(n, d, 42, 1, d ** -0.5)
+    c0, x0 = row_checksums(c), row_checksums(x)
+    tp = ops.train_params(1, d, 10, 5)
+    ops.cbow_step(g, tp, wk, 42, 0, 0, 0.0, c, x)  # lr = 0: identity
+    assert torch.equal(row_checksums(c), c0) and torch.equal(row_checksums(x), x0)
+    ops.stats_reset(g)
+    ops.cbow_step(g, tp, wk, 42, 0, 0, 0.01, c, x)
+    st = ops.stats_read(g)
+    # every walk position is a centre; its contexts are the pairs of the closed form
+    assert st["centres"] == n_walks * 128 and st["pairs"] == n_walks * PAIRS_PER_WALK, st
+    assert all_finite(c) and all_finite(x)
+    visited = torch.zeros(n, dtype=torch.bool, device="cuda")
+    visited[wk.long().flatten() & 0xFFFFFFFF] = True
+    c1, x1 = row_checksums(c), row_checksums(x)
+    assert torch.equal(x1[~visited], x0[~visited])  # contextual rows move only for walk nodes
+    assert float((x1[visited] != x0[visited]).float().mean()) > 0.99
+    assert float((c1[visited] != c0[visited]).float().mean()) > 0.99  # every walk node is a centre
+    assert int((c1 != c0).sum()) > int(visited.sum())  # negatives reach beyond the walk nodes
+    del c, x, c1, x1
+    torch.cuda.empty_cache()
+    kw = dict(embedding_size=d, epochs=1, walk_length=128, iterations=10, window_size=5,
+              number_of_negative_samples=10, verbose=False)
+    m = E.models.CBOW(learning_rate=0.0, **kw)
+    c, x, st = m.fit_transform_device(g, max_walks_per_epoch=n_walks)
+    assert m.last_plan is None  # CBOW has no block path
+    assert st["centres"] == n_walks * 128 and st["pairs"] == n_walks * PAIRS_PER_WALK, st
+    assert torch.equal(row_checksums(c), c0) and torch.equal(row_checksums(x), x0)
+    del c, x
+    torch.cuda.empty_cache()
+    m = E.models.CBOW(learning_rate=0.01, **kw)
+    c, x, st = m.fit_transform_device(g, max_walks_per_epoch=n_walks)
+    assert st["centres"] == n_walks * 128 and all_finite(c) and all_finite(x)
+    x1 = row_checksums(x)
+    assert torch.equal(x1[~visited], x0[~visited])
+    assert float((x1[visited] != x0[visited]).float().mean()) > 0.99
+    return st
+
+
+def test_config4_products_shaped_cbow_full_size_properties():
+    """BASELINE config 4's shape (2 449 029 nodes / 61 M edges), CBOW, d = 128."""
+    g = E.barabasi_albert(2_449_029, 25, 42, name="BA-shaped-like-ogbn-products")
+    cbow_full_size_properties(g, 1 << 16)
+
+
+def test_config5a_bench_graph_cbow_full_size_properties():
+    """The roofline configuration (BA 10 M / 100 M), CBOW, d = 128: what ``bench.py --model cbow``
+    times."""
+    g = E.barabasi_albert(10_000_000, 10, 42)
+    cbow_full_size_properties(g, 1 << 16)
+
+
 def test_config3_arxiv_shaped_block_path_full_size_properties():
     """BASELINE config 3's shape (169 343 nodes, p = 0.5 / q = 2): resident cells since round 4
     -- 4 parts x 256 cells of 166 rows, each trained by one workgroup in its LDS (rounds 2-3: 1 x 8
