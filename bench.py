@@ -569,7 +569,8 @@ def main():
                 # the rule of gn2v_train_blocks / models.fit_transform_blocks
                 from embiggen_amd.distributed import rounds_per_epoch
 
-                shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "") or 1 << 14)
+                shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "")
+                               or (1 << 19 if t_world > 1 else 1 << 14))
                 auto_walks = min(auto_walks, max(shortest, -(-n * 10 // (rounds_per_epoch(1) * max(t_world, stripes)))))
             args.round_walks = stripes * auto_walks
             # equal rounds (as gn2v_train_blocks cuts an epoch): 20 steps of 2^20 walks are three

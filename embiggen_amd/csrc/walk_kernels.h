@@ -287,8 +287,10 @@ __device__ __forceinline__ ThresholdBounds threshold_bounds(const GraphView &g,
 // exact fallback after max_trials rejections (rare: only for extreme weights on low-weight rows;
 // the one step of a weighted row under a sub-sample); returns the chosen edge
 template <bool TYPED>
+// (the view BY VALUE: a reference would take the address of the caller's view and park it -- a
+// loop-carried variable of every trial -- in scratch memory: 21 % of the sampler's rate)
 __device__ __noinline__ uint64_t exact_scan(const GraphView &g, const WalkConsts &c, uint64_t r,
-                                            uint32_t cur, const RowView &v, uint32_t prev,
+                                            uint32_t cur, const RowView v, uint32_t prev,
                                             uint64_t pstart, uint64_t pend, uint32_t ptype) {
     const uint64_t n = v.n;
     if (g.cumw == nullptr) {

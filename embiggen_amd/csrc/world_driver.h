@@ -146,8 +146,11 @@ extern "C" int gn2v_train_world(gn2v_graph *g, const gn2v_walk_params *wp,
         if (permute) {  // 16-64 rounds an epoch (gn2v_train_blocks: the same rule)
             const uint64_t rounds = gn2v_host::rounds_per_epoch(tp->epochs);
             const uint64_t epoch = g->view.n_sources * (uint64_t)wp->iterations;
-            const uint64_t shortest =
-                std::max<uint64_t>(1, env_size("GN2V_ROUND_MIN_WALKS", 1ull << 14));
+            // (several ranks: a training launch is ONE part of one rank -- round x 1 250 / parts
+            // pairs -- so a rank's round keeps at least 2^19 walks: a rank of 8 on the bench graph
+            // ran at 1.73e9 pairs/s with rounds of 194 k walks, at 1.88e9 with 874 k)
+            const uint64_t shortest = std::max<uint64_t>(
+                1, env_size("GN2V_ROUND_MIN_WALKS", world > 1 ? 1ull << 19 : 1ull << 14));
             mine[0] = std::min(mine[0], std::max<uint64_t>(
                                             shortest, (epoch + rounds * world - 1) / (rounds * world)));
         }

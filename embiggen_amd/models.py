@@ -322,7 +322,9 @@ class _WalkBasedModel:
                     from .distributed import rounds_per_epoch
 
                     rounds = rounds_per_epoch(self.epochs)
-                    shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "") or 1 << 14)
+                    # (several ranks: a launch is one part of one rank: rounds of >= 2^19 walks)
+                    shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "")
+                                   or (1 << 19 if comm.world > 1 else 1 << 14))
                     epoch_walks = csr.get_number_of_unique_source_nodes() * self.iterations
                     auto_walks = min(auto_walks,
                                      max(shortest, -(-epoch_walks // (rounds * lanes))))

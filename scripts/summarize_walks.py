@@ -12,6 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONFIGS = ["untyped rw.25/ew4", "typed graph unit weights", "first order", "first order + node x2",
            "first order + edge x0.5", "rw.25/ew4 + node x2 + edge x0.5", "rw2/ew.5",
            "rw2/ew.5 typed", "rw4/ew.25", "rw.5/ew2"]
+# round 6: the lines above run at the reference's default max_neighbours = 100; then the exact
+# walks (None) and the smoke configuration's 10 (scripts/typed_walk_probe.py)
+CONFIGS_R6 = CONFIGS + [f"{name}, max_neighbours {mn}" for mn in ("None", "10")
+                        for name in ("rw.25/ew4", "first order", "rw2/ew.5",
+                                     "rw.25/ew4 + node x2 + edge x0.5")]
 STEPS = (1 << 19) * 127
 
 
@@ -34,7 +39,8 @@ def main(tag):
              if is_walk(r["Kernel_Name"])]
     fetch = [r for r in csv.DictReader(open(one(f"{src}/fetch/**/*counter_collection.csv")))
              if is_walk(r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE"]
-    assert len(trace) == 4 * len(CONFIGS) == len(fetch), (len(trace), len(fetch))
+    configs = CONFIGS_R6 if len(trace) == 4 * len(CONFIGS_R6) else CONFIGS
+    assert len(trace) == 4 * len(configs) == len(fetch), (len(trace), len(fetch))
     stats = list(csv.DictReader(open(one(f"{src}/stats/**/*kernel_stats.csv"))))
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
         w = csv.writer(f)
@@ -51,7 +57,7 @@ def main(tag):
              "",
              "| configuration | kernel | ms / launch | steps/s | FETCH B / step | fetch GB/s | 64 B sectors / s |",
              "|---|---|---|---|---|---|---|"]
-    for i, name in enumerate(CONFIGS):
+    for i, name in enumerate(configs):
         rows = trace[4 * i + 1:4 * i + 4]
         ms = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows) / 3 / 1e6
         kib = sum(float(r["Counter_Value"]) for r in fetch[4 * i + 1:4 * i + 4]) / 3
