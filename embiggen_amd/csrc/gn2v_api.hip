@@ -484,14 +484,7 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
     // (160 KB).  The lazy CBOW window may take up to 64 KB -- rows of 132-256 floats, three or two
     // workgroups per CU, which is what their registers allow anyway: + 19 % at d = 200, + 9 % at
     // d = 256 over the uncached kernel on one box; the eager window cache loses there (-5 %).
-    // GN2V_CTX_CACHE_LDS_KB / GN2V_CBOW_LAZY_LDS_KB override both budgets (A/B, up to 64).
-    static const auto budget_kb = [](const char *name, long def) {
-        const char *e = getenv(name);
-        const long kb = e ? atol(e) : def;
-        return (size_t)(kb < 1 ? 1 : kb > 64 ? 64 : kb) * 1024;
-    };
-    static const size_t cache_budget = budget_kb("GN2V_CTX_CACHE_LDS_KB", 40);
-    static const size_t lazy_budget = budget_kb("GN2V_CBOW_LAZY_LDS_KB", 64);
+    constexpr size_t cache_budget = 40 * 1024, lazy_budget = 64 * 1024;
     const bool cacheable = !det && wm != gn2v::kAtomic && !a.split && !a.ctx_delta &&
                            !a.walk_rows && !a.neg_pool && !(tp->flags & GN2V_TRAIN_NO_CTX_CACHE) &&
                            L > 2 * tp->window &&
@@ -532,13 +525,12 @@ int launch_train(gn2v_graph *g, bool cbow, const gn2v_train_params *tp, const gn
         }
     }
     const size_t lazy_lds = (size_t)lazy_wpb * lazy_words * 4;
-    // A/B switches, read once: GN2V_CBOW_LAZY=0 keeps cbow_cached_kernel, GN2V_BLOCK_NO_FULL=1 the
-    // kernels that do not know the row stride at compile time
+    // A/B switch, read once: GN2V_CBOW_LAZY=0 keeps cbow_cached_kernel
     static const bool lazy_off = [] {
         const char *e = getenv("GN2V_CBOW_LAZY");
         return e && e[0] == '0';
     }();
-    static const bool no_full = getenv("GN2V_BLOCK_NO_FULL") != nullptr;
+    constexpr bool no_full = false;
     const bool use_lazy = cacheable && cbow && a.min_dist == 1 && lazy_lds <= lazy_budget &&
                           (long)lazy_waves_cu >= lazy_min_waves && !lazy_off;
     uint64_t lazy_blocks = (n_walks + lazy_wpb - 1) / lazy_wpb;

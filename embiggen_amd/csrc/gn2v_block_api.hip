@@ -83,11 +83,7 @@ size_t block_lds_words_per_wave(uint32_t ld, uint32_t record, uint32_t k) {
 // the extraction stages, per wave, the walk and three words per position, plus one counter per cell
 // walks of at most 128 nodes and windows of at most 31 take block_extract_fast_kernel
 bool extract_fast(uint32_t walk_length, uint32_t window) {
-    static const size_t fast_env = []() {
-        const char *v = getenv("GN2V_EXTRACT_FAST");
-        return v && *v ? (size_t)strtoull(v, nullptr, 10) : (size_t)1;
-    }();  // 0: the slot-by-slot kernel always (A/B)
-    return fast_env && walk_length <= 128 && window <= 31;
+    return walk_length <= 128 && window <= 31;
 }
 
 size_t extract_lds_bytes(uint32_t walk_length, uint32_t cells) {
@@ -222,8 +218,7 @@ bool slices_are_xcd_exclusive(const gn2v_graph *g, uint32_t slices) {
 namespace {
 // Device buffers of one gn2v_train_blocks call, given back on every exit path -- to the graph
 // handle, which keeps them for its next fit (up to a third of the device's memory;
-// gn2v_graph_release_buffers or gn2v_graph_destroy frees them; GN2V_KEEP_BUFFERS=0: freed at
-// once).  A second fit on the same handle found its 65 GB of round buffers only after the driver
+// gn2v_graph_release_buffers or gn2v_graph_destroy frees them).  A second fit on the same handle found its 65 GB of round buffers only after the driver
 // had cleared them again: 1.6-2.0 s of a 15 s call (profiles/r05_logs/r5_var.log).
 struct Buffers {
     gn2v_graph *g;
@@ -284,11 +279,10 @@ struct Buffers {
     }
     // the most recent allocation goes back (to the handle, or to the driver)
     void release_last() {
-        static const size_t keep = env_size("GN2V_KEEP_BUFFERS", 1);
         const auto b = ptrs.back();
         ptrs.pop_back();
         size_t total = 0, free_b = 0;
-        if (keep && b.second >= ((size_t)1 << 20) && hipMemGetInfo(&free_b, &total) == hipSuccess) {
+        if (b.second >= ((size_t)1 << 20) && hipMemGetInfo(&free_b, &total) == hipSuccess) {
             std::lock_guard<std::mutex> lock(g->kept_mu);
             if (g->kept_bytes + b.second <= total / 3) {
                 g->kept_buffers.push_back(b);
@@ -620,6 +614,9 @@ int gn2v_block_extract(gn2v_graph *g, const gn2v_block_plan *plan, const uint32_
     const uint32_t end_bit = std::max(d.ctx_bits + 1, d.ctx_bits + d.row_bits + cell_bits(d));
     // resident plans: (cell, the centre's highest bits) -- GN2V_RESIDENT_CENTRE_SORT_BITS
     uint32_t begin_bit = d.ctx_bits;
+    // (round 6, same box, bench graph: 4 bits 2.09e9 pairs/s, 8 bits 2.20, 12 / 16 bits 2.16-2.17;
+    // no key on the centre at all -- the counted scatter -- 2.15: profiles/r06_logs/
+    // r6_sort_centre_bits_ab.log, r6_scatter_vs_sort_ab.log)
     if (d.slices > gn2v_host::kCursorSlices && d.row_bits > GN2V_RESIDENT_CENTRE_SORT_BITS)
         begin_bit += d.row_bits - GN2V_RESIDENT_CENTRE_SORT_BITS;
     return sort_words(t + head, temp_bytes - head, unsorted, (unsigned long long *)d_pairs,
@@ -652,9 +649,8 @@ static void allow_lds(K kernel, size_t lds) {
 template <int CH>
 static void launch_block_ch(int wmx, int wmc, bool det, dim3 grid, dim3 block, size_t lds,
                             hipStream_t s, const gn2v::BlockArgs &a) {
-    // the row stride is a compile-time constant (GN2V_BLOCK_NO_FULL=1: the general kernel, for A/Bs)
-    static const bool no_full = getenv("GN2V_BLOCK_NO_FULL") != nullptr;
-    const bool full = a.ld == (uint32_t)CH * 64 && !no_full;
+    // the row stride is a compile-time constant where it fills its instantiation
+    const bool full = a.ld == (uint32_t)CH * 64;
 #define GN2V_BLOCK(WMX, WMC, DT)                                                                  \
     do {                                                                                          \
         if (full && !DT)                                                                          \
@@ -885,7 +881,7 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     // read-modify-writes of its 64 concurrent 16-lane groups, so updates that meet on a row
     // within ~100 cycles lose one (block_kernels.h; counted in tests/test_gpu_resident.py).
     // GN2V_TRAIN_DETERMINISTIC runs the same kernel's deterministic instantiation.
-    static const size_t resident_env = env_size("GN2V_BLOCK_RESIDENT", 1);  // 0: never (A/B)
+    constexpr size_t resident_env = 1;
     const uint64_t max_cell_rows =
         gn2v::stripe_count(gn2v::stripe_count(g->view.n_nodes, 0, d.parts), 0, d.slices);
     const uint32_t res_record = resident_record(tp->ld, d.record, tp->k, max_cell_rows);
@@ -1020,8 +1016,7 @@ static int block_step(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_blo
     // (profiles/r05_logs/r5_skew_ab*.log): its rows stay ordinary rows.  (The in-degrees are
     // known here: the hot list was made from them.)
     if (wide && g->max_in_degree_known &&
-        (double)g->max_in_degree * g->n_cus > (double)g->view.n_edges &&
-        !getenv("GN2V_HOT_ROWS_ON_HUB_GRAPHS"))  // (set: round 4's behaviour, for A/Bs)
+        (double)g->max_in_degree * g->n_cus > (double)g->view.n_edges)
         wide = false;
     const int waves_per_block = det ? 1 : wide ? 16 : gn2v::kTrainBlock / 64;
     size_t lds = (size_t)waves_per_block * per_wave_words * 4;
@@ -1399,7 +1394,7 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
         // resident cells: the whole group in one launch (its workgroups are handed to the CUs
         // as they fall free; a launch per part would wait for the part's heaviest cell)
         bool took_group = false;
-        if (pn > 1 && !getenv("GN2V_RESIDENT_PART_LAUNCHES")) {
+        if (pn > 1) {
             std::vector<float *> ptrs(io->context_parts, io->context_parts + parts);
             if (!g->part_ptrs_dev || ptrs != g->part_ptrs_host) {
                 HIP_TRY(hipStreamSynchronize(s));  // no launch may still read the old pointers

@@ -323,8 +323,8 @@ int gn2v_edge_embedding(const float *d_src_table, const float *d_dst_table, uint
  * hands its round buffers -- walks, pair words, sort storage: tens of GB on large graphs -- back
  * to the graph handle, which keeps up to a third of the device's memory for the handle's next
  * fit (a second fit otherwise waits 1.5-2 s for the driver to clear the same 65 GB again).  This
- * frees them now; gn2v_graph_destroy does too; GN2V_KEEP_BUFFERS=0 in the environment never
- * keeps any.  The Python classes call it after every fit unless told to keep the buffers. */
+ * frees them now; gn2v_graph_destroy does too.  The Python classes call it after every fit
+ * unless told to keep the buffers. */
 int gn2v_graph_release_buffers(gn2v_graph *g);
 
 /* Which accelerators of the walk sampler the handle holds right now (they are built on the first

@@ -641,10 +641,13 @@ def test_multi_gpu_is_an_explicit_opt_in(karate):
     assert out[0].shape == (34, 8) and np.isfinite(out[0]).all()
 
 
-def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
+@pytest.mark.parametrize("loop", ["python", "c"])
+def test_public_fit_transform_on_two_gloo_ranks(tmp_path, loop):
     """``Node2VecSkipGramEnsmallen.fit_transform`` with ``model._model.comm = TorchComm()`` under
     ``torch.distributed.run`` (2 ranks, gloo, one shared GPU): both ranks return the same full
-    tables, of single-GPU quality; CBOW inside the same job falls back to its own device."""
+    tables, of single-GPU quality; CBOW inside the same job falls back to its own device.
+    ``loop = "c"`` (``GN2V_WORLD_LOOP=c``): the ranks' rounds are driven by ``gn2v_train_world``
+    with the gloo communicator behind its four callbacks -- two PROCESSES through the C loop."""
     import os
     import socket
     import subprocess
@@ -657,7 +660,7 @@ def test_public_fit_transform_on_two_gloo_ranks(tmp_path):
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                           "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
                           str(port), script, str(tmp_path)], capture_output=True, text=True,
-                         timeout=900)
+                         timeout=900, env=dict(os.environ, GN2V_WORLD_LOOP=loop))
     assert res.returncode == 0, res.stderr[-3000:]
     ok = [l for l in res.stdout.splitlines() if l.startswith("OK ")]
     assert len(ok) == 1 and "'world': 2" in ok[0] and float(ok[0].split()[-1]) > 0.9, res.stdout
@@ -1340,3 +1343,27 @@ def test_small_graph_through_the_block_path_learns_what_atomics_learn():
         got[name] = tuple(np.mean(scores, axis=0))
     assert got["atomic"][0] > 0.98 and got["atomic"][1] > 0.98
     assert got["blocks"][0] > got["atomic"][0] - 0.004 and got["blocks"][1] > got["atomic"][1] - 0.008
+
+
+def test_a_handles_second_fit_plans_like_its_first():
+    """``gn2v_train_blocks`` sizes its rounds and groups from the free device memory; the round
+    buffers a handle keeps from its last fit are this fit's to reuse and count as free (ADVICE
+    r5): two fits on one handle must report the same rounds and groups -- the round ids, hence
+    the placements and the embeddings of a seed, depend on them."""
+    from embiggen_amd import models
+
+    g = E.barabasi_albert(300_000, 5, 42)
+    plans = []
+    for _ in range(3):
+        m = models.SkipGram(embedding_size=64, epochs=1, iterations=2, walk_length=32,
+                            window_size=3, verbose=False)
+        m.keep_buffers = True  # the handle keeps the round buffers between the fits
+        c, x, st = m.fit_transform_device(g)
+        assert st["pairs"] == 2 * 300_000 * (2 * 3 * 32 - 3 * 4)
+        assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(x).all())
+        plans.append(dict(m.last_plan))
+        del c, x
+    assert plans[0] == plans[1] == plans[2], plans
+    assert plans[0]["slices"] > 16  # resident cells: the path that keeps buffers
+    from embiggen_amd import _lib
+    _lib.check(_lib.lib().gn2v_graph_release_buffers(g.device_graph(0).handle))

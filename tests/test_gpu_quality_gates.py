@@ -102,24 +102,46 @@ def compare(g, kw, reference_mode, n_each=100_000, floor=False):
     reference-semantic fit against itself under other negatives (same walks)."""
     from embiggen_amd import _lib
 
+    from embiggen_amd import ops
+
+    def moved(central, contextual):
+        """How far the two tables went from their (seeded) start: Frobenius norms, in slabs."""
+        d, n = kw["embedding_size"], central.shape[0]
+        out = []
+        for table, tid in ((central, 0), (contextual, 1)):
+            acc = 0.0
+            for lo in range(0, n, 1 << 21):
+                hi = min(n, lo + (1 << 21))
+                init = ops.init_table_rows(hi - lo, d, kw["random_state"], tid, d ** -0.5, lo, 1,
+                                           ld=table.shape[1])
+                acc += float((table[lo:hi] - init).double().pow(2).sum())
+            out.append(acc ** 0.5)
+        return out
+
     fast = models.SkipGram(**kw)
-    c_fast, _, st_fast = fast.fit_transform_device(g)
+    c_fast, x_fast, st_fast = fast.fit_transform_device(g)
     assert fast.last_plan is not None and fast.last_plan["slices"] > 16, fast.last_plan
     assert st_fast["resident_launches"] > 0, st_fast
     u, v = _pairs(g, n_each, 7)
     cos_fast = _cos(c_fast, u, v)
-    del c_fast
+    moved_fast = moved(c_fast, x_fast)
+    del c_fast, x_fast
     torch.cuda.empty_cache()
     ref = models.SkipGram(block_path=False, update_mode=reference_mode, **kw)
-    c_ref, _, st_ref = ref.fit_transform_device(g)
+    c_ref, x_ref, st_ref = ref.fit_transform_device(g)
     assert ref.last_plan is None and st_ref["pairs"] == st_fast["pairs"]
     cos_ref = _cos(c_ref, u, v)
-    del c_ref
+    moved_ref = moved(c_ref, x_ref)
+    del c_ref, x_ref
     torch.cuda.empty_cache()
     res = dict(auc_default=_auc(cos_fast[:n_each], cos_fast[n_each:]),
                auc_reference=_auc(cos_ref[:n_each], cos_ref[n_each:]),
                spearman=_spearman(cos_fast, cos_ref),
                mean_abs=float((cos_fast - cos_ref).abs().mean()),
+               # what racing read-modify-writes inside a cell lose, at scale: how far the default
+               # moved its tables relative to the reference-semantic fit (central, contextual)
+               moved_central=moved_fast[0] / moved_ref[0],
+               moved_contextual=moved_fast[1] / moved_ref[1],
                pairs=st_fast["pairs"], seconds_default=fast.last_seconds,
                seconds_reference=ref.last_seconds, plan=fast.last_plan)
     if floor:
@@ -157,6 +179,9 @@ def _gate(name, res):
         assert res["mean_abs"] <= res["floor_mean_abs"] + gate["above_floor"], res
     assert res["spearman"] >= gate["spearman"], res
     assert res["mean_abs"] <= gate["mean_abs"], res
+    # lost updates bounded at scale: the default's tables travel about as far as the reference's
+    lo, hi = gate.get("moved", (0.85, 1.15))
+    assert lo <= res["moved_central"] <= hi and lo <= res["moved_contextual"] <= hi, res
 
 
 @pytest.mark.timeout(1500)
