@@ -254,3 +254,37 @@ def test_cache_key_depends_on_graph_content(tmp_path, monkeypatch):
     named = E.CSRGraph.from_edge_list([0, 1, 2], [1, 2, 3], number_of_nodes=4,
                                       node_names=["a", "b", "c", "d"])
     assert named.content_digest() != g1.content_digest()
+
+
+def test_gn2v_negatives_environment_reaches_the_reference_semantic_schedule(monkeypatch):
+    """``GN2V_NEGATIVES=global``: the drop-in classes (which have no such kwarg: their signature is
+    the reference's, node2vec_skipgram.py:9-36) train through the walk-ordered schedule -- every
+    negative the endpoint of a uniform random edge of the whole graph (:101-102) -- instead of the
+    block path's draw among the context's cell-mates.  A model that chose itself keeps its
+    choice; anything but 'global' / 'cell' is refused."""
+    from embiggen_amd import _lib, models
+
+    m = E.Node2VecSkipGramEnsmallen(embedding_size=8, verbose=False)._model
+    monkeypatch.delenv("GN2V_NEGATIVES", raising=False)
+    assert not m.train_params().flags & (_lib.TRAIN_WALK_ORDERED | _lib.TRAIN_BLOCK_PATH)
+    monkeypatch.setenv("GN2V_NEGATIVES", "global")
+    assert m.train_params().flags & _lib.TRAIN_WALK_ORDERED
+    assert models.SkipGram(embedding_size=8, block_path=True).train_params().flags \
+        & _lib.TRAIN_BLOCK_PATH
+    monkeypatch.setenv("GN2V_NEGATIVES", "cell")
+    assert not m.train_params().flags & _lib.TRAIN_WALK_ORDERED
+    monkeypatch.setenv("GN2V_NEGATIVES", "everywhere")
+    with pytest.raises(ValueError, match="GN2V_NEGATIVES"):
+        m.train_params()
+
+
+def test_rounds_per_epoch_rule(monkeypatch):
+    """Resident cells: 192 placements over a fit, 16 to 64 an epoch (csrc/handle.h
+    rounds_per_epoch; the Python trainer's mirror)."""
+    from embiggen_amd.distributed import rounds_per_epoch
+
+    monkeypatch.delenv("GN2V_ROUNDS_PER_EPOCH", raising=False)
+    assert [rounds_per_epoch(e) for e in (1, 2, 3, 4, 6, 12, 13, 30, 100)] == \
+        [64, 64, 64, 48, 32, 16, 16, 16, 16]
+    monkeypatch.setenv("GN2V_ROUNDS_PER_EPOCH", "5")
+    assert rounds_per_epoch(30) == 5

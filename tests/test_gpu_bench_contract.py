@@ -45,6 +45,13 @@ def test_single_gpu_line():
     assert "frac_hbm" in r and (r["traffic"] is not None or "no committed" in r["traffic_missing_reason"])
     assert r["mean_centre_run"] >= 1
     assert "traffic_key" in d["config"]
+    # round 6: the counters behind the ceiling (committed TCC passes of kernel and probe), the
+    # vector instructions REALLY issued, and what `value` leaves out (the first fit of a handle)
+    busy = r["atomic_unit_busy"]
+    assert 0.9 < busy["tcc_busy"] <= 1 and busy["of_probe_per_cycle"] > 0.95, busy
+    assert 0 < r["valu_issued_frac"] < 1 and r["valu_issued_per_pair"] > r["valu_floor_per_pair"]
+    assert d["first_fit_s"] > 0 and d["first_fit"]["steps"] == 1
+    assert "max_neighbours 100" in d["config"]["workload"]
     pairs = 2 * 16384 * 1250
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - pairs) < 1e-3 * pairs
     c = d["cpu_baseline"]

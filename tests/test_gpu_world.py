@@ -87,3 +87,40 @@ def test_c_world_loop_with_one_rank_and_a_copying_communicator():
 
     with pytest.raises(RuntimeError, match="the fabric is down"):
         models.SkipGram(**kw).fit_transform_world(g, Broken(), max_walks_per_epoch=2_000)
+
+
+@pytest.mark.timeout(1500)
+def test_config4_at_full_size_with_eight_ranks_through_the_c_loop():
+    """BASELINE config 4 ("embedding table row-sharded across 8 x MI355X": 2 449 029 nodes /
+    61 M edges, d = 128) with eight rank-threads on one GPU, every rank with a graph handle of its
+    own, their rounds driven by ``gn2v_train_world`` in its shipping (parallel) form: 16
+    travelling parts of resident cells under a placement per round.  Every pair of every walk is
+    trained exactly once on some rank, every rank receives the same full tables, they are finite
+    and separate edges from random pairs."""
+    from sharded_helpers import link_auc_device
+
+    nodes, world, budget = 2_449_029, 8, 1 << 21
+    kw = dict(embedding_size=128, epochs=1, walk_length=128, iterations=10, window_size=5,
+              number_of_negative_samples=10, learning_rate=0.025, random_state=42, verbose=False)
+
+    def rank_fn(comm):
+        g = E.barabasi_albert(nodes, 25, 42)  # a handle of its own
+        model = models.SkipGram(**kw)
+        c, x = model.fit_transform_world(g, comm, max_walks_per_epoch=budget)
+        torch.cuda.synchronize()
+        out = (dict(model.last_stats), dict(model.last_plan),
+               bool(torch.isfinite(c).all() and torch.isfinite(x).all()),
+               int(c.view(torch.int32).sum(dtype=torch.int64)),
+               int(x.view(torch.int32).sum(dtype=torch.int64)))
+        if comm.rank == 0:
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(1)
+            out += (link_auc_device(g, c, x, gen),)
+        return out
+
+    res = run_ranks(world, rank_fn)
+    assert sum(r[0]["pairs"] for r in res) == budget * (2 * 5 * 128 - 5 * 6)
+    assert all(r[1]["world"] == 8 and r[1]["parts"] == 16 and r[1]["slices"] > 16 for r in res)
+    assert all(r[0]["resident_launches"] > 0 and r[2] for r in res)
+    assert len({(r[3], r[4]) for r in res}) == 1  # bit-identical tables on every rank
+    assert res[0][5] > 0.6, res[0][5]  # one walk per node (the simulated-rank test of config 4: 0.6+)
