@@ -74,12 +74,14 @@ __device__ __forceinline__ float sigmoid_med3(float dot, float clip) {
 // One step of a group: two samples (rows ra, rb of the cell; positives flagged) against the
 // register row u.  SEQ: one after the other, exactly (deterministic form); else side by side --
 // two independent chains -- with a row named twice updated once by the summed coefficient.
-template <int CH, bool SEQ>
+// POS: sample a is the FIRST of its pair's list -- the context, label 1; every other sample of a
+// list is a negative (label 0): the label follows from the position, not from the staged word.
+template <int CH, bool SEQ, bool POS>
 __device__ __forceinline__ void res_step2(const ResCell &c, const Row<CH> &u, Row<CH> &g,
                                           uint32_t pa, uint32_t pb, float lrc, float clip, int q,
                                           uint32_t nchunks) {
     const uint32_t ra = pa & kPkRowMask, rb = pb & kPkRowMask;
-    const float lab_a = (pa & kPkPositive) ? 1.f : 0.f, lab_b = (pb & kPkPositive) ? 1.f : 0.f;
+    constexpr float lab_a = POS ? 1.f : 0.f, lab_b = 0.f;
     float *wa = c.rows + ra * c.ld, *wb = c.rows + rb * c.ld;
     if constexpr (SEQ) {
         float *w[2] = {wa, wb};
@@ -158,12 +160,12 @@ __device__ __forceinline__ void res_step2(const ResCell &c, const Row<CH> &u, Ro
 }
 
 // a single sample (the odd one of a list)
-template <int CH>
+template <int CH, bool POS>
 __device__ __forceinline__ void res_step1(const ResCell &c, const Row<CH> &u, Row<CH> &g,
                                           uint32_t pa, float lrc, float clip, int q,
                                           uint32_t nchunks) {
     const uint32_t ra = pa & kPkRowMask;
-    const float lab_a = (pa & kPkPositive) ? 1.f : 0.f;
+    constexpr float lab_a = POS ? 1.f : 0.f;
     float *wa = c.rows + ra * c.ld;
     Row<CH> xa;
 #pragma unroll
@@ -194,7 +196,7 @@ __device__ __forceinline__ void res_step1(const ResCell &c, const Row<CH> &u, Ro
 // A step of the wave = the two samples (packed in `w`: a | b << 16; ONE: only a) of each of its
 // four groups.  All of phase 0 -- nearly always --: one pass.  Otherwise one pass per phase, the
 // samples of the other phases naming the dummy row meanwhile (coefficient 0).
-template <int CH, bool SEQ, bool ONE>
+template <int CH, bool SEQ, bool ONE, bool POS>
 __device__ __forceinline__ void res_step(const ResCell &c, const Row<CH> &u, Row<CH> &g,
                                          uint32_t w, float lrc, float clip, int q,
                                          uint32_t nchunks) {
@@ -203,23 +205,23 @@ __device__ __forceinline__ void res_step(const ResCell &c, const Row<CH> &u, Row
         // rows of 512 floats: two samples side by side do not fit the 256 registers of a lane
         // next to u, g and the prefetched central row -- one after the other (their phases, counted
         // over both samples of the earlier groups, serialise each half at least as strictly)
-        res_step<CH, SEQ, true>(c, u, g, pa, lrc, clip, q, nchunks);
-        res_step<CH, SEQ, true>(c, u, g, pb, lrc, clip, q, nchunks);
+        res_step<CH, SEQ, true, POS>(c, u, g, pa, lrc, clip, q, nchunks);
+        res_step<CH, SEQ, true, false>(c, u, g, pb, lrc, clip, q, nchunks);
         return;
     }
     if constexpr (SEQ) {  // deterministic form: no phases are staged
         if constexpr (ONE)
-            res_step1<CH>(c, u, g, pa, lrc, clip, q, nchunks);
+            res_step1<CH, POS>(c, u, g, pa, lrc, clip, q, nchunks);
         else
-            res_step2<CH, true>(c, u, g, pa, pb, lrc, clip, q, nchunks);
+            res_step2<CH, true, POS>(c, u, g, pa, pb, lrc, clip, q, nchunks);
         return;
     }
     const uint32_t phases = ONE ? (w & kPkPhaseMask) : (w & (kPkPhaseMask | (kPkPhaseMask << 16)));
     if (__builtin_expect(__ballot(phases != 0) == 0, 1)) {
         if constexpr (ONE)
-            res_step1<CH>(c, u, g, pa, lrc, clip, q, nchunks);
+            res_step1<CH, POS>(c, u, g, pa, lrc, clip, q, nchunks);
         else
-            res_step2<CH, false>(c, u, g, pa, pb, lrc, clip, q, nchunks);
+            res_step2<CH, false, POS>(c, u, g, pa, pb, lrc, clip, q, nchunks);
         return;
     }
     const uint32_t pha = (pa & kPkPhaseMask) >> kPkPhaseShift;
@@ -228,9 +230,9 @@ __device__ __forceinline__ void res_step(const ResCell &c, const Row<CH> &u, Row
         const uint32_t ea = pha == pass ? (pa & ~kPkPhaseMask) : c.n;
         const uint32_t eb = phb == pass ? (pb & ~kPkPhaseMask) : c.n;
         if constexpr (ONE)
-            res_step1<CH>(c, u, g, ea, lrc, clip, q, nchunks);
+            res_step1<CH, POS>(c, u, g, ea, lrc, clip, q, nchunks);
         else
-            res_step2<CH, false>(c, u, g, ea, eb, lrc, clip, q, nchunks);
+            res_step2<CH, false, POS>(c, u, g, ea, eb, lrc, clip, q, nchunks);
         if (__ballot(pha > pass || phb > pass) == 0) break;
         // the next phase reads what this one stored
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -242,20 +244,33 @@ template <int CH, bool SEQ>
 __device__ __forceinline__ void res_score_list(const ResCell &c, const Row<CH> &u, Row<CH> &g,
                                                const uint32_t *list, uint32_t kk, float lrc,
                                                float clip, int q, uint32_t nchunks) {
+    // the list's first sample is the pair's context (label 1), every other one a negative
     uint32_t s = 0;
+    if (kk >= 4) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(list);
+        res_step<CH, SEQ, false, true>(c, u, g, w.x, lrc, clip, q, nchunks);
+        res_step<CH, SEQ, false, false>(c, u, g, w.y, lrc, clip, q, nchunks);
+        s = 4;
+    }
     for (; s + 4 <= kk; s += 4) {  // four samples = one 8-byte read
         const uint2 w = *reinterpret_cast<const uint2 *>(list + (s >> 1));
-        res_step<CH, SEQ, false>(c, u, g, w.x, lrc, clip, q, nchunks);
-        res_step<CH, SEQ, false>(c, u, g, w.y, lrc, clip, q, nchunks);
+        res_step<CH, SEQ, false, false>(c, u, g, w.x, lrc, clip, q, nchunks);
+        res_step<CH, SEQ, false, false>(c, u, g, w.y, lrc, clip, q, nchunks);
     }
     const uint32_t rem = kk - s;  // the same for every pair: uniform branches
     if (rem) {
         const uint2 w = *reinterpret_cast<const uint2 *>(list + (s >> 1));
-        if (rem >= 2)
-            res_step<CH, SEQ, false>(c, u, g, w.x, lrc, clip, q, nchunks);
-        else
-            res_step<CH, SEQ, true>(c, u, g, w.x, lrc, clip, q, nchunks);
-        if (rem == 3) res_step<CH, SEQ, true>(c, u, g, w.y, lrc, clip, q, nchunks);
+        if (s == 0) {  // lists of fewer than four samples (k < 3): the context is in here
+            if (rem >= 2)
+                res_step<CH, SEQ, false, true>(c, u, g, w.x, lrc, clip, q, nchunks);
+            else
+                res_step<CH, SEQ, true, true>(c, u, g, w.x, lrc, clip, q, nchunks);
+        } else if (rem >= 2) {
+            res_step<CH, SEQ, false, false>(c, u, g, w.x, lrc, clip, q, nchunks);
+        } else {
+            res_step<CH, SEQ, true, false>(c, u, g, w.x, lrc, clip, q, nchunks);
+        }
+        if (rem == 3) res_step<CH, SEQ, true, false>(c, u, g, w.y, lrc, clip, q, nchunks);
     }
 }
 
