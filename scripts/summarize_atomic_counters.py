@@ -102,6 +102,14 @@ def markdown(d):
     big = max(v["atomic_sectors_per_channel_cycle"]
               for v in d["atomic_probe_10000000_rows"].values() if v.get("TCC_ATOMIC_SECTORS_sum"))
     clock = r["TCC_CYCLE_sum"] / (r["launch_ms"] * 1e-3) / 1e9 / 128
+    issued = "161 VALU + 21 SALU + 27 LDS"
+    try:  # the SQ pass of the same tree, when it is there
+        per = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
+            __file__))), "profiles", "r06_resident_counters.json")))["per_pair"]
+        issued = (f"{per['SQ_INSTS_VALU']:.0f} VALU + {per['SQ_INSTS_SALU']:.0f} SALU + "
+                  f"{per['SQ_INSTS_LDS']:.0f} LDS")
+    except (OSError, ValueError, KeyError):
+        pass
     out += ["",
             f"Bench line of the first pass: {b['value']:.4g} pairs/s end to end, kernel "
             f"{b['kernel_pairs_per_s']:.4g} pairs/s, `roofline.frac` {b['frac']:.3f} (128 atomic "
@@ -127,9 +135,9 @@ def markdown(d):
             "* Fewer atomic dwords per pair alone do not make the kernel faster either: folding the "
             "gradients of neighbouring same-centre pairs before the atomics (17 % fewer atomic rows "
             "with the pairs sorted by the whole centre) left it at 2.32 against 2.31e9 pairs/s "
-            "(`profiles/r06_logs/r6_fold_ab.log`) -- instruction issue (161 VALU + 21 SALU + 27 LDS "
-            "wave-instructions per pair, `profiles/r06_resident_counters.json`) stands right behind "
-            "the atomic units.", ""]
+            f"(`profiles/r06_logs/r6_fold_ab.log`) -- instruction issue ({issued} wave-instructions "
+            "per pair, `profiles/r06_resident_counters.json`) stands right behind the atomic units.",
+            ""]
     return "\n".join(out)
 
 
