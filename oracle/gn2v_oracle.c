@@ -26,6 +26,10 @@
  *   - batch form of walk + window ........ sequences/tensorflow_sequences/node2vec_sequence.py
  *       :115-128,:190-203  (contexts[n,2w], words[n]; n = walks*(walk_length-2w)).
  *   - CSR convention ..................... pecanpy_embedders/node2vec.py:139-163.
+ *   - max_neighbours ..................... node2vec_skipgram.py:22,78-81 ("approximated walks
+ *       ... for graphs containing nodes with high degrees"): rows longer than it are walked over
+ *       a per-visit sub-sample, one edge per bucket of the row -- the sorted unique sub-sampling
+ *       its authors published for it (GRAPE, Cappelletti et al. 2023); see row_view below.
  *
  * Everything random is counter based (splitmix64 finaliser keyed by seed/epoch/walk/draw) so the
  * HIP implementation can reproduce walks bit-exactly and training to float tolerance.
