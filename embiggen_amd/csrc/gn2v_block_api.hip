@@ -422,8 +422,10 @@ int gn2v_block_alias(gn2v_graph *g, const gn2v_block_plan *plan, uint64_t *d_ali
     unsigned long long *weight = (unsigned long long *)(t + 2 * align256(n * 4));
     if (d_hub_bits) HIP_TRY(hipMemsetAsync(d_hub_bits, 0, ((n + 31) / 32) * sizeof(uint32_t), s));
     if (d_hot_slot) HIP_TRY(hipMemsetAsync(d_hot_slot, 0xFF, n, s));
-    hipLaunchKernelGGL(gn2v::cell_rows_kernel, dim3(1), dim3(64), 0, s, n, plan->parts,
-                       plan->slices, (unsigned long long *)d_cell_rows);
+    hipLaunchKernelGGL(gn2v::cell_rows_kernel,
+                       dim3((unsigned)(((uint64_t)plan->parts * plan->slices + 256) / 256)),
+                       dim3(256), 0, s, n, plan->parts, plan->slices,
+                       (unsigned long long *)d_cell_rows);
     HIP_TRY(hipGetLastError());
     const uint32_t cells = plan->parts * plan->slices;
     hipLaunchKernelGGL(gn2v::alias_kernel, dim3((cells + 63) / 64), dim3(64), 0, s, indeg, n,
