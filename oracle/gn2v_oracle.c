@@ -38,6 +38,8 @@
  * float sums in the written order; THE CHECKER of every parity test) and libgn2v_oracle_fast.so
  * (-ffast-math -DO_FAST: reassociated sums + prefetch hints; only bench.py's cpu_baseline times it,
  * so that the CPU figure beside the GPU's is a tuned Hogwild trainer, not a serial-latency one).
+ * gn2v_cpu.c (same libraries) wraps the walk sampler, the trainers and the whole fit in the argument
+ * lists of include/gn2v.h's entry points (gn2v_cpu.h: the boundary's "CPU twins").
  */
 #include <math.h>
 #include <stdint.h>
@@ -762,6 +764,26 @@ void o_train_walks(const o_graph *g, const o_train_params *tp, const uint32_t *w
     o_train_walks_ex(g, tp, &io, n_walks, L, seed, epoch, first_walk, lr, threads);
 }
 
+/* The units a batch of walks amounts to (what the device's counters report: gn2v_stats):
+ * out[0] += (centre, context) pairs of the centres that are trained, out[1] += walk steps
+ * (transitions made), out[2] += trained centres (those with at least one context). */
+void o_count_units(const o_graph *g, const o_train_params *tp, const uint32_t *walks,
+                   uint64_t n_walks, uint32_t L, uint64_t seed, uint64_t epoch,
+                   uint64_t first_walk, uint64_t out[3]) {
+    uint64_t ekey = o_epoch_key(seed, epoch);
+    for (uint64_t b = 0; b < n_walks; ++b) {
+        uint32_t Le = effective_len(walks + b * L, L);
+        uint64_t wkey = o_draw(ekey, first_walk + b);
+        if (Le) out[1] += Le - 1;
+        for (uint32_t i = 0; i < Le; ++i) {
+            if (!keep_centre(g, tp, wkey, i, walks[b * L + i])) continue;
+            uint32_t n = context_count(i, Le, tp->window, min_dist_of(tp));
+            out[0] += n;
+            out[2] += n != 0;
+        }
+    }
+}
+
 /* Full fit: init both tables, then per epoch generate all walks and train on them in order.
  * Returns the number of (centre, context) training pairs processed. */
 uint64_t o_fit(const o_graph *g, const o_walk_params *wp, const o_train_params *tp,
@@ -778,14 +800,9 @@ uint64_t o_fit(const o_graph *g, const o_walk_params *wp, const o_train_params *
         o_walks(g, wp, sources, n_sources, seed, e, 0, n_walks, walks);
         o_train_walks(g, tp, walks, n_walks, L, seed, e, 0, lr, central, contextual, NULL,
                       threads);
-        uint64_t ekey = o_epoch_key(seed, e);
-        for (uint64_t b = 0; b < n_walks; ++b) { /* pairs of the centres that were trained */
-            uint32_t Le = effective_len(walks + b * L, L);
-            uint64_t wkey = o_draw(ekey, b);
-            for (uint32_t i = 0; i < Le; ++i)
-                if (keep_centre(g, tp, wkey, i, walks[b * L + i]))
-                    pairs += context_count(i, Le, tp->window, min_dist_of(tp));
-        }
+        uint64_t units[3] = {0, 0, 0}; /* pairs of the centres that were trained */
+        o_count_units(g, tp, walks, n_walks, L, seed, e, 0, units);
+        pairs += units[0];
         lr *= tp->lr_decay;
     }
     free(walks);

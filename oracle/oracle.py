@@ -71,12 +71,15 @@ def build(force: bool = False, asan: bool = False, fast: bool = False) -> str:
     ``fast``: the tuned build of the same source (``-ffast-math -DO_FAST``: vectorised dot
     products, software prefetch) that only ``bench.py``'s ``cpu_baseline`` times; with neither
     flag both the strict and the tuned library are brought up to date."""
-    src = os.path.join(_HERE, "gn2v_oracle.c")
+    srcs = [os.path.join(_HERE, "gn2v_oracle.c"), os.path.join(_HERE, "gn2v_cpu.c"),
+            os.path.join(_HERE, "gn2v_cpu.h"),
+            os.path.join(os.path.dirname(_HERE), "include", "gn2v.h")]
+    newest = max(os.path.getmtime(f) for f in srcs)
     names = (["libgn2v_oracle_asan.so"] if asan else ["libgn2v_oracle_fast.so"] if fast
              else ["libgn2v_oracle.so", "libgn2v_oracle_fast.so"])
     for target in names:
         path = os.path.join(_HERE, target)
-        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < newest:
             subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
     return os.path.join(_HERE, names[0])
 
@@ -95,6 +98,7 @@ def _declare(L):
     L.o_fit.restype = C.c_uint64
     L.o_window_batch.restype = C.c_uint64
     L.o_walk_pairs.restype = C.c_uint64
+    L.gn2v_cpu_last_error.restype = C.c_char_p
     return L
 
 
@@ -507,3 +511,95 @@ def init_table_rows(n_rows: int, d: int, ld: int, seed: int, table_id: int, scal
 def block_record_stride(n_records: int) -> int:
     lib().o_block_record_stride.restype = C.c_uint64
     return int(lib().o_block_record_stride(C.c_uint64(n_records)))
+
+
+# ---------------------------------------------------------------------------------------------
+# The CPU twins of include/gn2v.h's compute entry points (oracle/gn2v_cpu.h): same argument
+# lists as the device library's, host arrays in place of device pointers.
+
+
+class CpuTwinError(RuntimeError):
+    pass
+
+
+def cpu_check(rc: int):
+    if rc != 0:
+        raise CpuTwinError(lib().gn2v_cpu_last_error().decode())
+
+
+class CpuGraph:
+    """gn2v_cpu_graph over host CSR arrays (borrowed: kept alive here).  ``threads`` <= 1: the
+    sequential checker; > 1: Hogwild over walks."""
+
+    def __init__(self, row_ptr, col_idx, cumw=None, sources=None, threads: int = 1):
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        self.col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        self.cumw = None if cumw is None else np.ascontiguousarray(cumw, dtype=np.float32)
+        self.sources = None if sources is None else np.ascontiguousarray(sources, dtype=np.uint32)
+        self.n_nodes = len(self.row_ptr) - 1
+        self.handle = C.c_void_p()
+        self._types = (None, None)
+        cpu_check(lib().gn2v_cpu_graph_create(
+            _ptr(self.row_ptr), _ptr(self.col_idx), _ptr(self.cumw), _ptr(self.sources),
+            C.c_uint64(self.n_nodes), C.c_uint64(len(self.col_idx)),
+            C.c_uint64(0 if self.sources is None else len(self.sources)), C.c_uint32(0),
+            C.c_int(threads), C.byref(self.handle)))
+
+    def set_types(self, node_types=None, edge_types=None):
+        nt = None if node_types is None else np.ascontiguousarray(node_types, dtype=np.uint32)
+        et = None if edge_types is None else np.ascontiguousarray(edge_types, dtype=np.uint32)
+        self._types = (nt, et)
+        cpu_check(lib().gn2v_cpu_graph_set_types(self.handle, _ptr(nt), _ptr(et)))
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().gn2v_cpu_graph_destroy(self.handle)
+            self.handle = None
+
+
+def cpu_walks(g: CpuGraph, wp, seed: int, epoch: int, first_walk: int, n_walks: int):
+    """gn2v_cpu_walks: the arguments of gn2v_walks (``wp`` any struct of gn2v_walk_params' layout)."""
+    out = np.empty((n_walks, wp.walk_length), dtype=np.uint32)
+    cpu_check(lib().gn2v_cpu_walks(g.handle, C.byref(wp), C.c_uint64(seed), C.c_uint64(epoch),
+                                   C.c_uint64(first_walk), C.c_uint64(n_walks), _ptr(out), None))
+    return out
+
+
+def cpu_window_batch(walks_arr, window: int):
+    wk = np.ascontiguousarray(walks_arr, dtype=np.uint32)
+    n = wk.shape[0] * (wk.shape[1] - 2 * window)
+    contexts = np.empty((max(n, 0), 2 * window), dtype=np.int32)
+    words = np.empty((max(n, 0),), dtype=np.int32)
+    cpu_check(lib().gn2v_cpu_window_batch(_ptr(wk), C.c_uint64(wk.shape[0]), C.c_uint32(wk.shape[1]),
+                                          C.c_uint32(window), _ptr(contexts), _ptr(words), None))
+    return contexts, words
+
+
+def cpu_init_table(n_rows: int, d: int, ld: int, seed: int, table_id: int, scale: float):
+    t = np.empty((n_rows, ld), dtype=np.float32)
+    cpu_check(lib().gn2v_cpu_init_table(_ptr(t), C.c_uint64(n_rows), C.c_uint32(d), C.c_uint32(ld),
+                                        C.c_uint64(seed), C.c_uint32(table_id), C.c_float(scale),
+                                        None))
+    return t
+
+
+def cpu_step(g: CpuGraph, tp, model: int, walks_arr, seed: int, epoch: int, first_walk: int,
+             lr: float, central, contextual, neg_override=None):
+    """gn2v_cpu_sgns_step (model 0) / gn2v_cpu_cbow_step (model 1): tables updated in place."""
+    wk = np.ascontiguousarray(walks_arr, dtype=np.uint32)
+    ov = None if neg_override is None else np.ascontiguousarray(neg_override, dtype=np.uint32)
+    fn = lib().gn2v_cpu_cbow_step if model else lib().gn2v_cpu_sgns_step
+    cpu_check(fn(g.handle, C.byref(tp), _ptr(wk), C.c_uint64(wk.shape[0]), C.c_uint32(wk.shape[1]),
+                 C.c_uint64(seed), C.c_uint64(epoch), C.c_uint64(first_walk), C.c_float(lr),
+                 _ptr(central), _ptr(contextual), _ptr(ov), None))
+
+
+def cpu_train(g: CpuGraph, wp, tp, seed: int, max_walks_per_epoch: int = 0, stats=None):
+    """gn2v_cpu_train: (central, contextual) float32 [n_nodes, ld]; ``stats`` (optional) any
+    struct of gn2v_stats' layout, filled with pairs / walk_steps / centres."""
+    central = np.empty((g.n_nodes, tp.ld), dtype=np.float32)
+    contextual = np.empty((g.n_nodes, tp.ld), dtype=np.float32)
+    cpu_check(lib().gn2v_cpu_train(g.handle, C.byref(wp), C.byref(tp), C.c_uint64(seed),
+                                   C.c_uint64(max_walks_per_epoch), _ptr(central), _ptr(contextual),
+                                   None if stats is None else C.byref(stats), None))
+    return central, contextual

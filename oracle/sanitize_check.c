@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include "gn2v_oracle.c"
+#define GN2V_ORACLE_INLINE
+#include "gn2v_cpu.c"
 
 int main(void) {
     /* ring of 6 cliques of 5 nodes, plus one isolated node and one directed trap */
@@ -76,6 +78,26 @@ int main(void) {
                 o_train_params tp = {model, 10, 12, 2, 4, 3, 0.02f, 0.9f, 6.0f, flags, 0.3f, md};
                 o_fit(&g, &wp, &tp, sources, ns, 11, c, x, flags & 1 ? 2 : 1);
             }
+    /* the CPU twins of the boundary (gn2v_cpu.h): graph, walks, batch, steps, whole fits */
+    {
+        gn2v_cpu_graph *cg = NULL;
+        if (gn2v_cpu_graph_create(row_ptr, col, NULL, sources, N, e, ns, 0, 2, &cg)) return 1;
+        gn2v_walk_params wp = {20, 2, 0.5f, 2.0f, 4, 0, 0.f, 0.f};
+        if (gn2v_cpu_walks(cg, &wp, 3, 0, 5, ns * 2, walks, NULL)) return 1;
+        if (gn2v_cpu_window_batch(walks, ns * 2, 20, 3, ctx, words, NULL)) return 1;
+        for (uint32_t model = 0; model < 2; ++model) {
+            gn2v_train_params tp = {model, 10, 12, 2, 4, 3, 0.02f, 0.9f, 6.0f, 1u | 8u, 0.3f, 0};
+            gn2v_stats st;
+            if (gn2v_cpu_init_table(c, N, 10, 12, 3, 0, 0.3f, NULL)) return 1;
+            if (gn2v_cpu_init_table(x, N, 10, 12, 3, 1, 0.3f, NULL)) return 1;
+            if (gn2v_cpu_sgns_step(cg, &tp, walks, ns * 2, 20, 3, 0, 5, 0.02f, c, x, NULL, NULL)) return 1;
+            if (gn2v_cpu_cbow_step(cg, &tp, walks, ns * 2, 20, 3, 0, 5, 0.02f, c, x, NULL, NULL)) return 1;
+            if (gn2v_cpu_train(cg, &wp, &tp, 5, ns + 3, c, x, &st, NULL)) return 1;
+            if (st.walk_steps == 0 || st.pairs == 0) return 1;
+        }
+        if (!gn2v_cpu_walks(cg, NULL, 3, 0, 5, 1, walks, NULL)) return 1; /* refused, with a message */
+        gn2v_cpu_graph_destroy(cg);
+    }
     /* two-node walks through the general step with a pool and row indirection */
     o_train_params tp = {0, 10, 12, 1, 4, 1, 0.02f, 0.9f, 6.0f, 1, 0.3f, 1};
     uint32_t *rows = malloc(sizeof(uint32_t) * np * 2);
