@@ -235,7 +235,8 @@ class CComm:
     to ``gn2v_train_world`` so that the C loop moves its walks and parts through
     torch.distributed (RCCL: ``TorchComm``), through the threads of a test, or not at all
     (``LoopbackComm``).  The callbacks see raw device pointers and byte counts and wrap them as
-    uint8 tensors without a copy; they run on the calling thread with the GIL held.  Keep the
+    uint8 tensors without a copy; they run on the calling thread with the GIL held and make the
+    stream they are handed torch's current one.  Keep the
     object alive for as long as the C call runs (it owns the ctypes callbacks)."""
 
     def __init__(self, comm, device):
@@ -249,11 +250,18 @@ class CComm:
         def view(ptr, nbytes):
             return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=self.device)
 
-        def guarded(fn):
+        def guarded(fn, stream_arg):
             def call(*args):
                 try:
                     with torch.cuda.device(self.device):
-                        fn(*args)
+                        # the caller's stream (args[stream_arg], a hipStream_t) becomes torch's
+                        # current one for the call: the communicators order their work after it
+                        raw = args[stream_arg]
+                        if raw:
+                            with torch.cuda.stream(torch.cuda.ExternalStream(int(raw))):
+                                fn(*args)
+                        else:
+                            fn(*args)
                     return 0
                 except Exception as e:  # noqa: BLE001 -- a Python error must not cross the C frame
                     self.error = e
@@ -277,10 +285,10 @@ class CComm:
         def broadcast(_ctx, buf, nbytes, root, _stream):
             comm.broadcast(view(buf, nbytes), int(root))
 
-        self._callbacks = (_lib.COMM_ALL_GATHER(guarded(all_gather)),
-                           _lib.COMM_SENDRECV_START(guarded(sendrecv_start)),
-                           _lib.COMM_SENDRECV_WAIT(guarded(sendrecv_wait)),
-                           _lib.COMM_BROADCAST(guarded(broadcast)))
+        self._callbacks = (_lib.COMM_ALL_GATHER(guarded(all_gather, 4)),
+                           _lib.COMM_SENDRECV_START(guarded(sendrecv_start, 7)),
+                           _lib.COMM_SENDRECV_WAIT(guarded(sendrecv_wait, 2)),
+                           _lib.COMM_BROADCAST(guarded(broadcast, 4)))
         self.struct = _lib.Comm(None, comm.rank, comm.world, *self._callbacks)
 
 
