@@ -556,22 +556,24 @@ def main():
         torch.cuda.empty_cache()  # what building the graph left in the allocator's cache
         # walks one pass extracts from (times the stripes that share them) and the parts whose
         # pairs are held at a time, from what is free now
+        cap = args.round_walks // max(1, stripes)
+        if not args.round_walks and getattr(blocks, "permute", False):
+            # resident cells: at least 16 rounds per epoch of the graph (10 walks a node),
+            # the rule of gn2v_train_blocks / models.fit_transform_blocks
+            from embiggen_amd.distributed import rounds_per_epoch
+
+            shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "")
+                           or (1 << 19 if t_world > 1 else 1 << 14))
+            cap = max(shortest, -(-n * 10 // (rounds_per_epoch(1) * max(t_world, stripes))))
+        # (the plan is made for the round that will be trained: its cap)
         auto_walks, auto_group = round_plan(
             torch.cuda.mem_get_info()[0], n, 128, 5, max(t_world, stripes), blocks.parts,
-            blocks.slices, overlap and stripes == 1)
+            blocks.slices, overlap and stripes == 1, cap=cap)
         if world > 1:  # every rank the same round size and groups
             agreed = torch.tensor([auto_walks, auto_group], dtype=torch.int64, device="cuda")
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
             auto_walks, auto_group = int(agreed[0]), int(agreed[1])
         if not args.round_walks:
-            if getattr(blocks, "permute", False):
-                # resident cells: at least 16 rounds per epoch of the graph (10 walks a node),
-                # the rule of gn2v_train_blocks / models.fit_transform_blocks
-                from embiggen_amd.distributed import rounds_per_epoch
-
-                shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "")
-                               or (1 << 19 if t_world > 1 else 1 << 14))
-                auto_walks = min(auto_walks, max(shortest, -(-n * 10 // (rounds_per_epoch(1) * max(t_world, stripes)))))
             args.round_walks = stripes * auto_walks
             # equal rounds (as gn2v_train_blocks cuts an epoch): 20 steps of 2^20 walks are three
             # rounds of 6.99 M, not two of 2^23 and a half one

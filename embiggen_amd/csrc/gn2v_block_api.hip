@@ -1228,6 +1228,11 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     const double want = 64.0 * (double)n_nodes * parts * slices / ((double)world * pairs);
     uint64_t r = 1ull << 20;
     while ((double)r < want && r < (1ull << 23)) r *= 2;
+    // *round_walks on entry: the caller's cap (0 = none) -- the rounds-per-epoch rule of resident
+    // cells, a walk budget: the groups below are sized for the round that will really be trained
+    // (a rank of 8 on the bench graph trains rounds of 2^19 walks: ONE group holds them, where
+    // the 2^23 this function would take by itself needed three)
+    if (*round_walks && *round_walks < r) r = *round_walks;
     // Memory, three quarters of what is free: the round's walks (this rank's and, with several
     // ranks, the gathered ones), and per group of parts the pair words once sorted (twice when a
     // second group is prepared while the first trains) and once unsorted.  Groups: at least four
@@ -1246,9 +1251,11 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
     // (six on one GPU in resident cells: the first group of a round is prepared in line, and the
     // pair buffers of a quarter of a round -- two sets -- are more than a handle keeps between
     // two fits: the second fit of the bench waited 1.8 s for the driver to clear them again)
-    // (several ranks in resident cells: two -- every scan of a group reads the walks of ALL ranks,
-    // and a group may be wide there: more cells than the counting pass has LDS counters)
-    const uint64_t min_groups = slices > 16 ? (world == 1 ? 6 : 2) : 4;
+    // (several ranks in resident cells: ONE when memory allows -- every scan of a group reads the
+    // walks of ALL ranks, and a group may be wide there: more cells than the counting pass has
+    // LDS counters; a rank of 8 on the bench graph, one group a round against two: 2.07 against
+    // 2.01e9 pairs/s, a rank of 4 2.21 / 2.16, profiles/r06_logs/r6_kernel_alone_and_preparation.log)
+    const uint64_t min_groups = slices > 16 ? (world == 1 ? 6 : 1) : 4;
     uint64_t gp = std::max<uint64_t>(1, (parts + min_groups - 1) / min_groups);
     // the extraction counts the cells of a group in LDS: kMaxGroupCells at most, and fewer when
     // the walk's staging leaves less of the 64 KB
@@ -1601,13 +1608,6 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
             std::lock_guard<std::mutex> lock(g->kept_mu);
             free_b += g->kept_bytes;
         }
-        uint64_t auto_walks = 0;
-        if (gn2v_block_round_plan(free_b, n, L, w, V, parts, plan.slices, overlap ? 1 : 0,
-                                  &auto_walks, &group_parts))
-            return 1;
-        if (automatic) round_walks = auto_walks;
-    }
-    if (automatic && permute) {
         // Resident cells draw a pair's negatives among the ~220 cell-mates its context has THIS
         // round: an epoch trained as one or two rounds shows every context two or three sets of
         // mates, and the cosine of the central rows pays for it -- config 3's shape (169 k
@@ -1621,11 +1621,19 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         // (iterations x sources walks, whatever the caller's walk budget) is cut into
         // 192 / epochs rounds, at least 16 and at most 64 (rounds_per_epoch), none shorter than
         // 2^14 walks.  Cost of 64 against 16: 1.6 % on the bench graph, 12 % at 169 k nodes.
-        const uint64_t rounds = gn2v_host::rounds_per_epoch(tp->epochs);
-        const uint64_t epoch = g->view.n_sources * (uint64_t)wp->iterations;
-        const uint64_t shortest = std::max<uint64_t>(1, env_size("GN2V_ROUND_MIN_WALKS", 1ull << 14));
-        const uint64_t mixed = std::max<uint64_t>(shortest, (epoch + rounds * V - 1) / (rounds * V));
-        round_walks = std::min(round_walks, mixed);
+        // The plan is made for that round (its cap), or for the caller's.
+        uint64_t auto_walks = round_walks;
+        if (automatic && permute) {
+            const uint64_t rounds = gn2v_host::rounds_per_epoch(tp->epochs);
+            const uint64_t epoch = g->view.n_sources * (uint64_t)wp->iterations;
+            const uint64_t shortest =
+                std::max<uint64_t>(1, env_size("GN2V_ROUND_MIN_WALKS", 1ull << 14));
+            auto_walks = std::max<uint64_t>(shortest, (epoch + rounds * V - 1) / (rounds * V));
+        }
+        if (gn2v_block_round_plan(free_b, n, L, w, V, parts, plan.slices, overlap ? 1 : 0,
+                                  &auto_walks, &group_parts))
+            return 1;
+        if (automatic) round_walks = auto_walks;
     }
     const uint64_t planned_walks = round_walks;
     round_walks = std::max<uint64_t>(1, std::min(round_walks, (walks_per_epoch + V - 1) / V));

@@ -138,12 +138,8 @@ extern "C" int gn2v_train_world(gn2v_graph *g, const gn2v_walk_params *wp,
             std::lock_guard<std::mutex> lock(g->kept_mu);
             free_b += g->kept_bytes;
         }
-        uint64_t mine[2] = {0, 0};
-        if (gn2v_block_round_plan(free_b, n, L, w, world, parts, plan.slices, 0, &mine[0],
-                                  &group_parts))
-            return 1;
-        mine[1] = group_parts;
-        if (permute) {  // 16-64 rounds an epoch (gn2v_train_blocks: the same rule)
+        uint64_t mine[2] = {round_walks, 0};  // the plan's cap: the caller's round, or ...
+        if (round_walks == 0 && permute) {  // ... 16-64 rounds an epoch (gn2v_train_blocks: the same rule)
             const uint64_t rounds = gn2v_host::rounds_per_epoch(tp->epochs);
             const uint64_t epoch = g->view.n_sources * (uint64_t)wp->iterations;
             // (several ranks: a training launch is ONE part of one rank -- round x 1 250 / parts
@@ -151,9 +147,12 @@ extern "C" int gn2v_train_world(gn2v_graph *g, const gn2v_walk_params *wp,
             // ran at 1.73e9 pairs/s with rounds of 194 k walks, at 1.88e9 with 874 k)
             const uint64_t shortest = std::max<uint64_t>(
                 1, env_size("GN2V_ROUND_MIN_WALKS", world > 1 ? 1ull << 19 : 1ull << 14));
-            mine[0] = std::min(mine[0], std::max<uint64_t>(
-                                            shortest, (epoch + rounds * world - 1) / (rounds * world)));
+            mine[0] = std::max<uint64_t>(shortest, (epoch + rounds * world - 1) / (rounds * world));
         }
+        if (gn2v_block_round_plan(free_b, n, L, w, world, parts, plan.slices, 0, &mine[0],
+                                  &group_parts))
+            return 1;
+        mine[1] = group_parts;
         HIP_TRY(hipMemcpyAsync(agree, mine, 16, hipMemcpyHostToDevice, s));
         COMM_TRY(comm->all_gather(comm->ctx, agree, agreed, 16, stream), "all_gather");
         std::vector<uint64_t> all(2 * (size_t)world);

@@ -67,18 +67,20 @@ MIN_ROWS_PER_CELL = 32768
 
 
 def round_plan(free_bytes: int, n_nodes: int, walk_length: int, window: int, world: int,
-               parts: int, slices: int, overlap: bool) -> Tuple[int, int]:
+               parts: int, slices: int, overlap: bool, cap: int = 0) -> Tuple[int, int]:
     """(walks per rank and round, parts per extraction group) for ``free_bytes`` of HBM
     (``gn2v_block_round_plan``: a round long enough for 64 pairs per (cell, centre) within
-    [2^20, 2^23] walks; equal groups of parts -- at least four per round (resident cells: six on
-    one GPU, two with several ranks; include/gn2v.h) -- whose pair words, held once
-    sorted (twice when the next group is prepared meanwhile) and once unsorted, fit three quarters
-    of it beside the walks).  Every rank must use the same values."""
+    [2^20, 2^23] walks, at most ``cap`` when given -- the rounds-per-epoch rule, a caller's round:
+    the groups are sized for the round that will be trained; equal groups of parts -- at least
+    four per round (resident cells: six on one GPU, one with several ranks when memory allows;
+    include/gn2v_internal.h) -- whose pair words, held once sorted (twice when the next group is
+    prepared meanwhile) and once unsorted, fit three quarters of it beside the walks).  Every rank
+    must use the same values."""
     import ctypes as C
 
     from . import _lib
 
-    walks, group = C.c_uint64(), C.c_uint32()
+    walks, group = C.c_uint64(max(0, int(cap))), C.c_uint32()
     _lib.check(_lib.lib().gn2v_block_round_plan(int(free_bytes), n_nodes, walk_length, window,
                                                 world, parts, slices, int(bool(overlap)),
                                                 C.byref(walks), C.byref(group)))

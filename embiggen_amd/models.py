@@ -307,14 +307,7 @@ class _WalkBasedModel:
                 torch.cuda.empty_cache()
                 holds = comm.world > 1 and (root is None or root == comm.rank)
                 result = (2 if holds else 0) * trainer.n_nodes * self.padded_size * 4
-                auto_walks, auto_group = round_plan(
-                    max(0, torch.cuda.mem_get_info(dev)[0] - result), trainer.n_nodes, L,
-                    self.window_size, lanes, trainer.parts, trainer.slices,
-                    overlap and stripes == 1)
-                if comm.world > 1:  # every rank must use the same round size and groups
-                    mine = torch.tensor([auto_walks, auto_group], dtype=torch.int64, device=dev)
-                    agreed = comm.all_gather(mine).view(-1, 2).min(0).values
-                    auto_walks, auto_group = int(agreed[0]), int(agreed[1])
+                cap = 0 if round_walks is None else int(round_walks)
                 if round_walks is None and getattr(trainer, "permute", False):
                     # resident cells: 192 rounds -- sets of cell-mates -- over the fit, 16 to 64
                     # per epoch of the graph, none shorter than 2^14 walks (gn2v_train_blocks:
@@ -326,8 +319,16 @@ class _WalkBasedModel:
                     shortest = int(os.environ.get("GN2V_ROUND_MIN_WALKS", "")
                                    or (1 << 19 if comm.world > 1 else 1 << 14))
                     epoch_walks = csr.get_number_of_unique_source_nodes() * self.iterations
-                    auto_walks = min(auto_walks,
-                                     max(shortest, -(-epoch_walks // (rounds * lanes))))
+                    cap = max(shortest, -(-epoch_walks // (rounds * lanes)))
+                # (the plan is made for the round that will be trained: its cap)
+                auto_walks, auto_group = round_plan(
+                    max(0, torch.cuda.mem_get_info(dev)[0] - result), trainer.n_nodes, L,
+                    self.window_size, lanes, trainer.parts, trainer.slices,
+                    overlap and stripes == 1, cap=cap)
+                if comm.world > 1:  # every rank must use the same round size and groups
+                    mine = torch.tensor([auto_walks, auto_group], dtype=torch.int64, device=dev)
+                    agreed = comm.all_gather(mine).view(-1, 2).min(0).values
+                    auto_walks, auto_group = int(agreed[0]), int(agreed[1])
                 round_walks = auto_walks if round_walks is None else round_walks
                 group_parts = auto_group if group_parts is None else group_parts
             trainer.group_parts = max(1, min(int(group_parts), trainer.parts))

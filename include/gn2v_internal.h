@@ -254,8 +254,11 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
  * at least four groups a round; resident plans on one GPU at least six, where a group is one launch
  * and holds at least 4 096 cells when the plan has them (the round is shortened down to 2^20 walks
  * before such a group is cut; groups above that floor are cut to a third of free_bytes, what a
- * handle keeps between fits); resident plans on several ranks at least two (every scan of a group
- * reads the walks of ALL ranks).  Resident groups may be wide (GN2V_BLOCK_MAX_WIDE_GROUP_CELLS).
+ * handle keeps between fits); resident plans on several ranks ONE group when memory allows (every
+ * scan of a group reads the walks of ALL ranks).  Resident groups may be wide
+ * (GN2V_BLOCK_MAX_WIDE_GROUP_CELLS).  *round_walks on entry = the caller's cap on the round
+ * (0 = none: resident cells cut an epoch into 16-64 rounds, gn2v_train_blocks) -- the groups are
+ * sized for the round that will be trained.
  * More, smaller groups when three quarters of free_bytes do not hold the walks plus, per group,
  * its pair words once sorted (twice with `overlap`: the next group is prepared while this one
  * trains) and once unsorted, 8 B per pair.  Pure host function; every rank of a job must use the

@@ -165,12 +165,19 @@ def test_round_size_and_groups_follow_the_free_memory():
     assert round_plan(270 * GB, 1_000_000, 128, 5, 1, 18, 256, True) == (1 << 21, 18)
     assert round_plan(270 * GB, 2_449_029, 128, 5, 1, 44, 256, True) == (1 << 22, 15)
     assert round_plan(270 * GB, 169_343, 128, 5, 1, 4, 256, True) == (1 << 21, 4)
-    # several ranks: every scan of a group reads the walks of ALL ranks -- two groups a round when
+    # several ranks: every scan of a group reads the walks of ALL ranks -- ONE group a round when
     # memory allows (wide groups: their cell offsets follow the sort), more when it does not
     # (equal groups: 6 + 6 + 4, never 7 + 7 + 2)
     assert round_plan(300 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 8)
-    assert round_plan(285 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 6)
     assert round_plan(250 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 6)
+    assert round_plan(150 * GB, 10_000_000, 128, 5, 8, 16, 2841, True) == (1 << 23, 2)
+    # the plan is made for the round that will be trained (cap: the rounds-per-epoch rule of
+    # resident cells, a caller's round): a rank of 8 holds its round of 2^19 walks in one group
+    assert round_plan(300 * GB, 10_000_000, 128, 5, 8, 16, 2841, True, cap=1 << 19) == (1 << 19, 16)
+    assert round_plan(150 * GB, 10_000_000, 128, 5, 8, 16, 2841, True, cap=1 << 19) == (1 << 19, 16)
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, True, cap=1_562_500) == (1_562_500, 30)
+    assert round_plan(270 * GB, 169_343, 128, 5, 1, 4, 256, True, cap=26_460) == (26_460, 4)
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, True, cap=1 << 25) == (1 << 23, 30)
     # (longer walks: four to six times the pairs per walk -- the groups above the floor of 16
     # parts are cut to what a handle keeps, then the round is shortened)
     assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False) == (8388608, 20)
