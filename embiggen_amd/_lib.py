@@ -11,10 +11,11 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libgn2v.so")
-_UNITS = ["gn2v_api.hip", "gn2v_block_api.hip"]  # translation units of libgn2v.so
+_UNITS = ["gn2v_api.hip", "gn2v_block_api.hip", "gn2v_rccl.hip"]  # translation units of libgn2v.so
 _HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v.h")
 _HEADER_EXPERIMENTAL = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v_experimental.h")
 _HEADER_INTERNAL = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v_internal.h")
+_HEADER_RCCL = os.path.join(os.path.dirname(_CSRC), "..", "include", "gn2v_rccl.h")
 
 SENTINEL = 0xFFFFFFFF
 GRAPH_DEVICE_PTRS = 1
@@ -56,6 +57,9 @@ INTERNAL_EXPORTS = [
     "gn2v_graph_xcds", "gn2v_graph_reserve_cus", "gn2v_touch_rows",
 ]
 EXPORTS = BOUNDARY_EXPORTS + INTERNAL_EXPORTS
+# include/gn2v_rccl.h: a gn2v_comm filled with RCCL calls, for hosts without Python (RCCL is
+# dlopen'ed on first use; this package hands torch.distributed's communicator over instead)
+RCCL_EXPORTS = ["gn2v_rccl_unique_id", "gn2v_rccl_comm_create", "gn2v_rccl_comm_destroy"]
 
 
 class WalkParams(C.Structure):
@@ -233,7 +237,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     # every header and unit in csrc/ is a dependency: a stale library must never survive an edit
     srcs = sorted(glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_CSRC, "*.hip")))
-    srcs += [_HEADER, _HEADER_EXPERIMENTAL, _HEADER_INTERNAL]
+    srcs += [_HEADER, _HEADER_EXPERIMENTAL, _HEADER_INTERNAL, _HEADER_RCCL]
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(s) for s in srcs)
         if os.path.getmtime(LIB_PATH) >= newest:

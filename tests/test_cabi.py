@@ -15,6 +15,7 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 
 EXPERIMENTAL = os.path.join(os.path.dirname(HEADER), "gn2v_experimental.h")
 INTERNAL = os.path.join(os.path.dirname(HEADER), "gn2v_internal.h")
+RCCL = os.path.join(os.path.dirname(HEADER), "gn2v_rccl.h")
 
 
 def declared_symbols(header=HEADER):
@@ -32,13 +33,36 @@ def test_header_and_binding_agree():
     # rejected designs live in a header of their own, outside the drop-in boundary
     assert declared_symbols(EXPERIMENTAL) == sorted(_lib.EXPERIMENTAL_EXPORTS)
     assert not set(_lib.EXPERIMENTAL_EXPORTS) & set(_lib.EXPORTS)
+    # the RCCL-filled communicator of gn2v_train_world, for hosts without Python
+    assert declared_symbols(RCCL) == sorted(_lib.RCCL_EXPORTS)
+    # nothing else lives in include/
+    assert sorted(os.listdir(os.path.dirname(HEADER))) == [
+        "gn2v.h", "gn2v_experimental.h", "gn2v_internal.h", "gn2v_rccl.h"]
 
 
 def test_library_exports_every_declared_symbol():
     L = C.CDLL(_lib.build())
-    for name in declared_symbols() + declared_symbols(INTERNAL) + declared_symbols(EXPERIMENTAL):
+    for name in (declared_symbols() + declared_symbols(INTERNAL) + declared_symbols(EXPERIMENTAL)
+                 + declared_symbols(RCCL)):
         assert hasattr(L, name), name
     assert _lib.lib().gn2v_version() == 320
+
+
+def test_rccl_communicator_refuses_bad_arguments_without_a_gpu():
+    """include/gn2v_rccl.h: RCCL is loaded on first use, not linked -- the library loads and
+    these calls return 1 with a message where there is no RCCL device (or no RCCL at all)."""
+    L = C.CDLL(_lib.build())
+    L.gn2v_last_error.restype = C.c_char_p
+    comm = _lib.Comm()
+    assert L.gn2v_rccl_comm_create(None, 0, 1, 0, C.byref(comm)) == 1
+    assert b"NULL" in L.gn2v_last_error()
+    ident = (C.c_ubyte * 128)()
+    assert L.gn2v_rccl_comm_create(ident, 3, 2, 0, C.byref(comm)) == 1
+    assert b"rank < world" in L.gn2v_last_error()
+    assert L.gn2v_rccl_comm_destroy(C.byref(comm)) == 0  # nothing to release
+    import subprocess
+    deps = subprocess.run(["ldd", _lib.build()], capture_output=True, text=True).stdout
+    assert "rccl" not in deps and "nccl" not in deps, deps
 
 
 def test_struct_layouts_match_header():

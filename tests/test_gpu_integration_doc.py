@@ -69,6 +69,32 @@ def test_whole_fit_from_a_plain_c_program(tmp_path):
     assert lines[-1] == "ok" and lines[0].startswith("model 0") and lines[1].startswith("model 1")
 
 
+def test_multi_gpu_fit_from_a_plain_c_program_over_rccl(tmp_path):
+    """tests/c/fit_world_rccl.c: gn2v_train_world with the communicator of include/gn2v_rccl.h --
+    RCCL loaded by libgn2v.so itself, neither Python nor PyTorch in the process.  One GPU here:
+    world = 1 (RCCL initialised, the ranks' agreement all-gathered through it); the same program
+    is what a launcher starts once per GPU."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("needs gcc and the ROCm headers")
+    lib_dir = os.path.dirname(_lib.build())
+    exe = str(tmp_path / "fit_world_rccl")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__",
+                    "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "c", "fit_world_rccl.c"),
+                    "-L", lib_dir, "-lgn2v", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+                    f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    res = subprocess.run([exe, "0", "1", str(tmp_path / "job.id")], capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, (res.stdout, res.stderr)
+    lines = res.stdout.strip().splitlines()
+    # (RCCL prints its version banner first)
+    assert lines[-1] == "ok" and any(ln.startswith("rank 0 of 1: pairs ") for ln in lines), lines
+    assert not (tmp_path / "job.id").exists()  # rank 0 removes the id file at the end
+
+
 def test_the_readme_quick_start_runs_as_written():
     text = open(os.path.join(ROOT, "README.md")).read()
     block = re.search(r"```python\n(import embiggen_amd as E\ngraph = .*?)```", text, re.S).group(1)
