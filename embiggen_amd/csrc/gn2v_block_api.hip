@@ -1248,14 +1248,19 @@ int gn2v_block_round_plan(uint64_t free_bytes, uint64_t n_nodes, uint32_t walk_l
         return copies * 8 * (per_part * gp + per_part * gp / 8);
     };
     while (r > (1ull << 14) && walk_bytes(r) + group_bytes(r, 1) > budget) r /= 2;
-    // (six on one GPU in resident cells: the first group of a round is prepared in line, and the
-    // pair buffers of a quarter of a round -- two sets -- are more than a handle keeps between
-    // two fits: the second fit of the bench waited 1.8 s for the driver to clear them again)
+    // (one GPU in resident cells: ONE too when the group fits what a handle keeps between fits
+    // and the cells a group may hold -- with the rounds of the rounds-per-epoch rule it does on
+    // the bench graph: every group scans the round's walks twice, a launch of all 45 568 cells
+    // ends on a shorter tail than one of 7 680, and beside-the-training preparation hides a
+    // seventh of itself only.  Bench graph, preparation in line, groups a round: 6 2.198e9,
+    // 3 2.237, 2 2.250, 1 2.263 pairs/s -- against 2.222 with 6 groups prepared beside the
+    // training (profiles/r06_logs/r6_kernel_alone_and_preparation.log).  Round 5 took six because
+    // rounds of 2^23 walks made a group's pair buffers larger than a handle keeps)
     // (several ranks in resident cells: ONE when memory allows -- every scan of a group reads the
     // walks of ALL ranks, and a group may be wide there: more cells than the counting pass has
     // LDS counters; a rank of 8 on the bench graph, one group a round against two: 2.07 against
     // 2.01e9 pairs/s, a rank of 4 2.21 / 2.16, profiles/r06_logs/r6_kernel_alone_and_preparation.log)
-    const uint64_t min_groups = slices > 16 ? (world == 1 ? 6 : 1) : 4;
+    const uint64_t min_groups = slices > 16 ? 1 : 4;
     uint64_t gp = std::max<uint64_t>(1, (parts + min_groups - 1) / min_groups);
     // the extraction counts the cells of a group in LDS: kMaxGroupCells at most, and fewer when
     // the walk's staging leaves less of the 64 KB

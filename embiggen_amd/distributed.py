@@ -72,7 +72,7 @@ def round_plan(free_bytes: int, n_nodes: int, walk_length: int, window: int, wor
     (``gn2v_block_round_plan``: a round long enough for 64 pairs per (cell, centre) within
     [2^20, 2^23] walks, at most ``cap`` when given -- the rounds-per-epoch rule, a caller's round:
     the groups are sized for the round that will be trained; equal groups of parts -- at least
-    four per round (resident cells: six on one GPU, one with several ranks when memory allows;
+    four per round (resident cells: ONE when memory allows, on one GPU and with several ranks;
     include/gn2v_internal.h) -- whose pair words, held once sorted (twice when the next group is
     prepared meanwhile) and once unsorted, fit three quarters of it beside the walks).  Every rank
     must use the same values."""

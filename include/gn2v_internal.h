@@ -251,7 +251,7 @@ int gn2v_block_auto_plan_graph(gn2v_graph *g, uint32_t world, uint32_t ld, uint3
  * cell (its row is read once per such run: kernel 0.82 / 0.92 / 0.96 of the roofline at 2^20 /
  * 2^22 / 2^23 walks on the bench graph): the power of two in [2^20, 2^23] that gives 64 pairs per
  * (cell, centre), less when memory is short (>= 2^14).  group_parts, in equal groups: XCD plans
- * at least four groups a round; resident plans on one GPU at least six, where a group is one launch
+ * at least four groups a round; resident plans on one GPU as few as fit, where a group is one launch
  * and holds at least 4 096 cells when the plan has them (the round is shortened down to 2^20 walks
  * before such a group is cut; groups above that floor are cut to a third of free_bytes, what a
  * handle keeps between fits); resident plans on several ranks ONE group when memory allows (every

@@ -177,17 +177,17 @@ def test_round_size_and_groups_follow_the_free_memory():
     GB = 10 ** 9
     # the bench graph on one GPU: 38 x 8 cells, rounds at the cap, four groups of <= 10 parts
     assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 38, 8, False) == (1 << 23, 10)
-    # the same graph in resident cells (178 x 256): six groups on one GPU; the extraction counts
-    # the cells of a group in LDS, 13 824 of them beside the staging of a walk of 128 (16 384 at
-    # most), and fewer when a long walk's staging leaves less room
-    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, False) == (1 << 23, 30)
+    # the same graph in resident cells (178 x 256): as few groups as a third of the memory (what
+    # a handle keeps between fits) allows -- three at rounds of 2^23 walks, ONE at the rounds the
+    # rounds-per-epoch rule trains (below)
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, False) == (1 << 23, 60)
     # (a wide group: more cells than LDS counters -- 7 groups a round where 13 824 counters gave 33)
     assert round_plan(150 * GB, 100_000_000, 128, 5, 1, 1776, 256, False) == (1 << 23, 254)
     # a group is one launch: at least 4 096 cells when the plan has them, the round shortened (not
     # the group) until the pair words fit a third of the memory -- 1 M nodes: the whole round of
-    # 2^21 walks in one launch of 4 608 cells; 2.4 M: three groups of 15 parts, rounds of 2^22
+    # 2^21 walks in one launch of 4 608 cells; 2.4 M: two groups of 22 parts, rounds of 2^22
     assert round_plan(270 * GB, 1_000_000, 128, 5, 1, 18, 256, True) == (1 << 21, 18)
-    assert round_plan(270 * GB, 2_449_029, 128, 5, 1, 44, 256, True) == (1 << 22, 15)
+    assert round_plan(270 * GB, 2_449_029, 128, 5, 1, 44, 256, True) == (1 << 22, 22)
     assert round_plan(270 * GB, 169_343, 128, 5, 1, 4, 256, True) == (1 << 21, 4)
     # several ranks: every scan of a group reads the walks of ALL ranks -- ONE group a round when
     # memory allows (wide groups: their cell offsets follow the sort), more when it does not
@@ -199,9 +199,10 @@ def test_round_size_and_groups_follow_the_free_memory():
     # resident cells, a caller's round): a rank of 8 holds its round of 2^19 walks in one group
     assert round_plan(300 * GB, 10_000_000, 128, 5, 8, 16, 2841, True, cap=1 << 19) == (1 << 19, 16)
     assert round_plan(150 * GB, 10_000_000, 128, 5, 8, 16, 2841, True, cap=1 << 19) == (1 << 19, 16)
-    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, True, cap=1_562_500) == (1_562_500, 30)
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, True, cap=1_562_500) == (1_562_500, 178)
+    assert round_plan(270 * GB, 2_449_029, 128, 5, 1, 44, 256, True, cap=382_661) == (382_661, 44)
     assert round_plan(270 * GB, 169_343, 128, 5, 1, 4, 256, True, cap=26_460) == (26_460, 4)
-    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, True, cap=1 << 25) == (1 << 23, 30)
+    assert round_plan(270 * GB, 10_000_000, 128, 5, 1, 178, 256, True, cap=1 << 25) == (1 << 23, 45)
     # (longer walks: four to six times the pairs per walk -- the groups above the floor of 16
     # parts are cut to what a handle keeps, then the round is shortened)
     assert round_plan(270 * GB, 10_000_000, 512, 5, 1, 178, 256, False) == (8388608, 20)

@@ -221,10 +221,11 @@ def test_config4_block_path_with_the_parts_trained_in_node_order(monkeypatch):
 
 def test_config5a_bench_graph_block_path_full_size_properties():
     """The roofline configuration (BA 10 M / 100 M) through the path the bench times: resident
-    cells, 178 parts x 256 cells of 220 rows, six groups of parts per round."""
+    cells, 178 parts x 256 cells of 220 rows, a round's pairs extracted and trained in one group
+    (one launch of all 45 568 cells)."""
     g = E.barabasi_albert(10_000_000, 10, 42)
     plan, _ = block_path_properties(g, 1 << 17, {"parts": 178, "slices": 256})
-    assert plan["group_parts"] == 30
+    assert plan["group_parts"] == 178
 
 
 def test_config5a_bench_graph_with_xcd_cells(monkeypatch):
