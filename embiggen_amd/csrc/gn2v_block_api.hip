@@ -1678,9 +1678,13 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
         cap = buffer_walks * pairs_per_walk / parts * group_parts;
         cap += cap / 8 + 1024;
         gn2v_block_extract_temp_bytes(cap, &tb);
+        // (the second set of pair words only where a round has a second unit to prepare beside
+        // the first: a round that is one group of one stripe trains what it has just prepared)
+        const bool second_set = overlap && (group_parts < parts || V > 1);
+        pairs2 = nullptr;
         if (!(buf.alloc(&walks, V * buffer_walks * L * 4) ||
               (permute && buf.alloc(&placed, V * buffer_walks * L * 4)) ||
-              (overlap && buf.alloc(&pairs2, cap * 8)) || buf.alloc(&pairs, cap * 8) ||
+              (second_set && buf.alloc(&pairs2, cap * 8)) || buf.alloc(&pairs, cap * 8) ||
               buf.alloc(&tmp, tb)))
             break;
         // somebody else took the memory between the query and here: smaller groups, then an
