@@ -169,6 +169,7 @@ class BlockRoundIO(C.Structure):
         ("d_pairs2", C.c_void_p),
         ("d_cell_offsets2", C.c_void_p),
         ("d_work2", C.c_void_p),
+        ("train_after", C.c_void_p),  # optional hipEvent_t the training launches wait for
     ]
 
 

@@ -860,6 +860,11 @@ int gn2v_graph_destroy(gn2v_graph *g) {
             (void)hipEventDestroy(g->train_done[i]);
         }
     }
+    for (int i = 0; i < 2; ++i) {
+        if (g->lane_stream[i]) (void)hipStreamDestroy(g->lane_stream[i]);
+        if (g->lane_done[i]) (void)hipEventDestroy(g->lane_done[i]);
+    }
+    if (g->lane_start) (void)hipEventDestroy(g->lane_start);
     if (g->cursors) (void)hipFree(g->cursors);
     if (g->lpt) (void)hipFree(g->lpt);
     if (g->lpt_temp) (void)hipFree(g->lpt_temp);

@@ -1392,6 +1392,7 @@ int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_bloc
         const uint32_t j = u / groups, p0 = (u % groups) * gp, pn = std::min(gp, parts - p0);
         const gn2v_block_plan *pj = &plans[j];
         if (overlapped) HIP_TRY(hipStreamWaitEvent(s, g->prep_done[slot], 0));
+        if (io->train_after) HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)io->train_after, 0));
         gn2v_block_io step{};
         step.d_pairs = pairs_of[slot];
         step.d_cell_offsets = offsets_of[slot];
@@ -1758,44 +1759,131 @@ int gn2v_train_blocks(gn2v_graph *g, const gn2v_walk_params *wp, const gn2v_trai
     rio.d_work2 = work2;
 
     mark("tables initialised");
+    // Two lanes of round buffers (a round that is ONE unit: one group of one stripe under a
+    // placement): round t + 1 -- its walks, placement, alias tables, placed walks, count,
+    // extraction and sort -- is enqueued on the other lane's stream while round t trains; only
+    // its training launch waits for round t's (two rounds in training at once would stage the
+    // same contextual rows in two cells).  What it hides: the host's wait for a round's pair
+    // count and a dozen small launches per round -- a tenth of the time when a round trains for
+    // 17 ms -- and the share of the preparation that runs beside a training kernel at all (a
+    // seventh to a third: DESIGN.md 7).  What it costs: a second set of round buffers.  Same
+    // box, pairs/s with two lanes against one, and the second set: config 3's shape (rounds of
+    // 26 k walks) 1.94 / 1.75e9, 0.8 GB; config 4's (383 k) 2.28 / 2.23e9, 9.5 GB; the bench
+    // graph (1.5 M) 2.30 / 2.27e9, 38 GB -- a seventh of the device for 1 %: two lanes are taken
+    // while the second set stays under 16 GiB (GN2V_ROUND_LANES_MAX_BYTES;
+    // profiles/r06_logs/r6_round_lanes_ab.log).  The two lanes share the temporary storage of
+    // placement and alias tables: the host reads a round's pair count (one stream
+    // synchronisation) after enqueueing them, so the other lane's are over before the next ones
+    // are enqueued.  GN2V_ROUND_LANES=1: one lane.
+    struct Lane {
+        uint32_t *walks = nullptr, *placed = nullptr, *place = nullptr, *inv = nullptr;
+        uint64_t *alias = nullptr, *cell_rows = nullptr;
+        gn2v_block_round_io rio{};
+    } lane[2];
+    lane[0].walks = walks;
+    lane[0].placed = placed;
+    lane[0].place = place;
+    lane[0].inv = inv;
+    lane[0].alias = alias;
+    lane[0].cell_rows = cell_rows;
+    lane[0].rio = rio;
+    const uint64_t rounds_per_epoch_here = (walks_per_epoch + super_walks - 1) / super_walks;
+    const uint64_t second_set = 2 * V * buffer_walks * L * 4 + (uint64_t)n * 16 + cap * 8 + tb;
+    bool lanes = permute && V == 1 && group_parts >= parts && overlap && !pairs2 &&
+                 !(tp->flags & GN2V_TRAIN_DETERMINISTIC) &&
+                 rounds_per_epoch_here * tp->epochs >= 2 && env_size("GN2V_ROUND_LANES", 2) >= 2 &&
+                 second_set <= env_size("GN2V_ROUND_LANES_MAX_BYTES", 16ull << 30);
+    if (lanes) {
+        const size_t before = buf.ptrs.size();
+        Lane &b = lane[1];
+        uint64_t *pairs_b = nullptr;
+        void *tmp_b = nullptr;
+        if (buf.alloc(&b.walks, V * buffer_walks * L * 4) ||
+            buf.alloc(&b.placed, V * buffer_walks * L * 4) || buf.alloc(&b.place, n * 4) ||
+            buf.alloc(&b.inv, n * 4) || (alias && buf.alloc(&b.alias, n * 8)) ||
+            (cell_rows && buf.alloc(&b.cell_rows, (cells + 1) * 8)) ||
+            buf.alloc(&pairs_b, cap * 8) || buf.alloc(&tmp_b, tb)) {
+            while (buf.ptrs.size() > before) buf.free_last();  // no room: one lane
+            lanes = false;
+        } else {
+            b.rio = rio;
+            b.rio.d_walks = b.walks;
+            b.rio.d_placed_walks = b.placed;
+            b.rio.d_inv = b.inv;
+            b.rio.d_alias = b.alias;
+            b.rio.d_cell_rows = b.cell_rows;
+            b.rio.d_work = work2;
+            b.rio.d_cell_offsets = cell_offsets2;
+            b.rio.d_pairs = pairs_b;
+            b.rio.d_temp = tmp_b;
+            for (int i = 0; i < 2; ++i) {
+                lane[i].rio.d_pairs2 = nullptr;
+                lane[i].rio.d_cell_offsets2 = nullptr;
+                lane[i].rio.d_work2 = nullptr;
+                if (!g->lane_stream[i]) {
+                    HIP_TRY(hipStreamCreateWithFlags(&g->lane_stream[i], hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&g->lane_done[i], hipEventDisableTiming));
+                }
+            }
+            if (!g->lane_start)
+                HIP_TRY(hipEventCreateWithFlags(&g->lane_start, hipEventDisableTiming));
+            // the tables initialised on the caller's stream come before both lanes
+            HIP_TRY(hipEventRecord(g->lane_start, s));
+            for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(g->lane_stream[i], g->lane_start, 0));
+        }
+    }
     float lr = tp->lr;
     uint64_t round_id = 0;
     for (uint32_t e = 0; e < tp->epochs; ++e) {
         for (uint64_t first = 0; first < walks_per_epoch; first += super_walks, ++round_id) {
             const uint64_t nw = std::min(super_walks, walks_per_epoch - first);
-            if (gn2v_walks(g, wp, seed, e, first, nw, walks, s)) return 1;
+            const int li = lanes ? (int)(round_id & 1) : 0;
+            Lane &ln = lane[li];
+            hipStream_t ls = lanes ? g->lane_stream[li] : s;
+            if (gn2v_walks(g, wp, seed, e, first, nw, ln.walks, ls)) return 1;
             if (permute) {  // this round's cells
-                if (gn2v_block_placement(g, 1, seed, round_id, place, inv, place_tmp, place_tb, s))
+                if (gn2v_block_placement(g, 1, seed, round_id, ln.place, ln.inv, place_tmp,
+                                         place_tb, ls))
                     return 1;
-                if (alias && gn2v_block_alias(g, &plan, alias, cell_rows, nullptr, nullptr, nullptr,
-                                              inv, alias_tmp, alias_tb, s))
+                if (ln.alias && gn2v_block_alias(g, &plan, ln.alias, ln.cell_rows, nullptr, nullptr,
+                                                 nullptr, ln.inv, alias_tmp, alias_tb, ls))
                     return 1;
-                if (gn2v_block_place_walks(place, walks, nw * L, placed, s)) return 1;
+                if (gn2v_block_place_walks(ln.place, ln.walks, nw * L, ln.placed, ls)) return 1;
             }
-            rio.next_unit = 0;
+            ln.rio.next_unit = 0;
+            ln.rio.train_after = lanes && round_id > 0 ? (void *)g->lane_done[li ^ 1] : nullptr;
             for (;;) {
-                const int rc = gn2v_block_round(g, tp, plans.data(), V, &rio, nw, seed, e, first,
-                                                lr, round_id, s);
+                const int rc = gn2v_block_round(g, tp, plans.data(), V, &ln.rio, nw, seed, e, first,
+                                                lr, round_id, ls);
                 if (rc == 0) break;
                 if (rc != GN2V_ROUND_GROW) return 1;
+                if (lanes)
+                    return fail("a round of two lanes outgrew buffers sized for its upper bound");
                 // a group heavier than the head room allows: grow (the driver has waited for
                 // whatever still trained from these buffers)
                 buf.free_last();  // tmp
                 buf.free_last();  // pairs
                 if (pairs2) buf.free_last();
-                cap = rio.needed_pairs + rio.needed_pairs / 16;
+                cap = ln.rio.needed_pairs + ln.rio.needed_pairs / 16;
                 gn2v_block_extract_temp_bytes(cap, &tb);
                 if ((pairs2 && buf.alloc(&pairs2, cap * 8)) || buf.alloc(&pairs, cap * 8) ||
                     buf.alloc(&tmp, tb))
                     return 1;
-                rio.d_pairs2 = pairs2;
-                rio.d_pairs = pairs;
-                rio.pairs_capacity = cap;
-                rio.d_temp = tmp;
-                rio.temp_bytes = tb;
+                ln.rio.d_pairs2 = pairs2;
+                ln.rio.d_pairs = pairs;
+                ln.rio.pairs_capacity = cap;
+                ln.rio.d_temp = tmp;
+                ln.rio.temp_bytes = tb;
             }
+            if (lanes) HIP_TRY(hipEventRecord(g->lane_done[li], ls));
         }
         lr *= tp->lr_decay;
+    }
+    if (lanes) {  // the caller's stream continues after both lanes
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventRecord(g->lane_done[i], g->lane_stream[i]));
+            HIP_TRY(hipStreamWaitEvent(s, g->lane_done[i], 0));
+        }
     }
     HIP_TRY(hipStreamSynchronize(s));
     mark("rounds");

@@ -95,6 +95,10 @@ struct gn2v_graph {
     // events that order it against the training (created on first use)
     hipStream_t prep_stream = nullptr;
     hipEvent_t prep_done[2] = {nullptr, nullptr}, train_done[2] = {nullptr, nullptr};
+    // gn2v_train_blocks with two lanes of round buffers: round t + 1 is prepared on the other
+    // lane's stream while round t trains (created on first use)
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipEvent_t lane_done[2] = {nullptr, nullptr}, lane_start = nullptr;
     // resident cells, a group of parts per launch: the parts' row pointers on the device
     std::vector<float *> part_ptrs_host;
     float **part_ptrs_dev = nullptr;

@@ -314,6 +314,10 @@ typedef struct {
     uint64_t *d_pairs2;
     uint64_t *d_cell_offsets2;
     uint64_t *d_work2;
+    /* optional: a hipEvent_t the TRAINING launches of this call wait for (its preparation does
+     * not) -- the caller that prepares round t + 1 on another stream while round t trains
+     * (gn2v_train_blocks: two lanes of round buffers) hands over round t's "trained" event      */
+    void *train_after;
 } gn2v_block_round_io;
 int gn2v_block_round(gn2v_graph *g, const gn2v_train_params *tp, const gn2v_block_plan *plans,
                      uint32_t stripes, gn2v_block_round_io *io, uint64_t n_walks, uint64_t seed,
