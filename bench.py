@@ -903,8 +903,14 @@ def main():
                               f"{min(args.round_walks, args.steps * args.walks)} walks per GPU "
                               f"prepared {blocks_view.group_parts if blocks_view else 0} parts at a time"
                               + (f" trained in {stripes} centre stripes" if stripes > 1 else "")
-                              + (", the next group prepared beside the training (second pair "
-                                 "buffer, own stream)"
+                              + ((", a round = one extraction group = one launch of all its cells "
+                                  "(the next round is prepared on a second lane of round buffers "
+                                  "only while that second set stays under 16 GiB: "
+                                  "gn2v_train_blocks)"
+                                  if blocks_view is not None and stripes <= 1
+                                  and blocks_view.group_parts >= blocks_view.parts
+                                  else ", the next group prepared beside the training (second pair "
+                                       "buffer, own stream)")
                                  if c_entry and os.environ.get("GN2V_BLOCK_OVERLAP", "1") != "0"
                                  else f", preparation "
                                       f"{'overlapped' if overlap and stripes == 1 else 'in line'}"),
