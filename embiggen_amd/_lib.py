@@ -41,6 +41,7 @@ MODEL_CBOW = 1
 BOUNDARY_EXPORTS = [
     "gn2v_version", "gn2v_last_error", "gn2v_device_count", "gn2v_graph_create",
     "gn2v_graph_destroy", "gn2v_graph_set_types", "gn2v_ba_edges", "gn2v_walks",
+    "gn2v_walks_strided",
     "gn2v_window_batch", "gn2v_walk_pairs", "gn2v_init_table",
     "gn2v_sgns_step", "gn2v_cbow_step", "gn2v_train", "gn2v_train_blocks", "gn2v_train_world",
     "gn2v_edge_embedding", "gn2v_cooc_slots", "gn2v_glove_step",
@@ -288,6 +289,7 @@ def lib():
     L.gn2v_graph_set_types.argtypes = [vp, vp, vp]
     L.gn2v_ba_edges.argtypes = [u64, u32, u64, vp, vp, vp]
     L.gn2v_walks.argtypes = [vp, C.POINTER(WalkParams), u64, u64, u64, u64, vp, vp]
+    L.gn2v_walks_strided.argtypes = [vp, C.POINTER(WalkParams), u64, u64, u64, u64, u32, u64, vp, vp]
     L.gn2v_window_batch.argtypes = [vp, u64, u32, u32, vp, vp, vp]
     L.gn2v_walk_pairs.argtypes = [vp, u64, u32, u32, u32, vp, vp]
     L.gn2v_init_table.argtypes = [vp, u64, u32, u32, u64, u32, f32, vp]

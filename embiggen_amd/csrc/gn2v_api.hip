@@ -319,7 +319,8 @@ int max_out_degree(gn2v_graph *g, hipStream_t s, uint64_t *out) {
 }
 
 int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
-                 uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, hipStream_t s) {
+                 uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, hipStream_t s,
+                 uint32_t id_group = 0, uint64_t id_stride = 0) {
     if (n_walks == 0) return 0;
     const gn2v::WalkConsts c = walk_consts(g, wp);
     const bool typed = c.node_bias || c.edge_bias;
@@ -348,7 +349,7 @@ int launch_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint6
 #define GN2V_LAUNCH_WALK(KERNEL, TYPED, SUB)                                                       \
     hipLaunchKernelGGL((gn2v::KERNEL<TYPED, SUB>), dim3((unsigned)blocks), dim3(gn2v::kWalkBlock), \
                        0, s, g->view, c, gn2v::epoch_key(seed, epoch), first_walk, n_walks, d_out, \
-                       g->counters)
+                       g->counters, id_group, id_stride)
     switch ((typed ? 4 : 0) | (rec ? 2 : 0) | (sub ? 1 : 0)) {
         case 0: GN2V_LAUNCH_WALK(walk_kernel, false, false); break;
         case 1: GN2V_LAUNCH_WALK(walk_kernel, false, true); break;
@@ -908,6 +909,20 @@ int gn2v_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_
     DeviceGuard guard(g->device);
     if (!guard.ok()) return fail("cannot select the graph's HIP device");
     return launch_walks(g, wp, seed, epoch, first_walk, n_walks, d_out, (hipStream_t)stream);
+}
+
+int gn2v_walks_strided(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
+                       uint64_t first_walk, uint64_t n_walks, uint32_t group, uint64_t stride,
+                       uint32_t *d_out, void *stream) {
+    if (!g) return fail("graph handle is NULL");
+    if (check_walk_params(wp)) return 1;
+    if (group == 0) return fail("group must be at least 1");
+    if (n_walks == 0) return 0;
+    if (!d_out) return fail("NULL output pointer");
+    DeviceGuard guard(g->device);
+    if (!guard.ok()) return fail("cannot select the graph's HIP device");
+    return launch_walks(g, wp, seed, epoch, first_walk, n_walks, d_out, (hipStream_t)stream, group,
+                        stride);
 }
 
 int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,

@@ -128,6 +128,17 @@ struct WalkConsts {
     uint32_t max_neighbours;
 };
 
+// gn2v_walks_strided: walk b of a launch has id first_walk + (b / id_group) * id_stride +
+// b % id_group (a Node2VecSequence batch: id_group sources x iterations); id_group 0:
+// first_walk + b.  (Kernel arguments of their own, not members of WalkConsts: the constants
+// live in the scratch frame of the out-of-line exact scan.)
+__device__ __forceinline__ uint64_t walk_id_of(uint32_t id_group, uint64_t id_stride,
+                                               uint64_t first_walk, uint64_t b) {
+    if (id_group == 0) return first_walk + b;
+    const uint32_t b32 = (uint32_t)b, q = b32 / id_group;  // a launch holds < 2^31 walks
+    return first_walk + (uint64_t)q * id_stride + (b32 - q * id_group);
+}
+
 // The row a step chooses from: all `deg` edges of the node, or -- degree > max_neighbours -- this
 // visit's SUB-SAMPLE of max_neighbours of them (node2vec_skipgram.py:78-81; the oracle's row_view
 // states the algorithm and its source): the row is cut into n buckets of step + (j < rem) edges,
@@ -342,7 +353,8 @@ template <bool TYPED, bool SUB>
 __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConsts c, uint64_t ekey,
                                                           uint64_t first_walk, uint64_t n_walks,
                                                           uint32_t *__restrict__ out,
-                                                          unsigned long long *__restrict__ counters) {
+                                                          unsigned long long *__restrict__ counters,
+                                                          uint32_t id_group, uint64_t id_stride) {
     __shared__ uint32_t tile[kWalkBlock / 64][64][kTileSteps + 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(kWalkBlock) void walk_kernel(GraphView g, WalkConst
     uint32_t cur = kSentinel, prev = kSentinel, ptype = 0;
     uint64_t pstart = 0, pend = 0;
     if (live) {
-        const uint64_t wid = first_walk + b;
+        const uint64_t wid = walk_id_of(id_group, id_stride, first_walk, b);
         const uint64_t si = wid % g.n_sources;
         cur = g.sources ? g.sources[si] : (uint32_t)si;
         wkey = draw(ekey, wid);
@@ -659,7 +671,9 @@ __global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, Wa
                                                                   uint64_t ekey, uint64_t first_walk,
                                                                   uint64_t n_walks,
                                                                   uint32_t *__restrict__ out,
-                                                                  unsigned long long *__restrict__ counters) {
+                                                                  unsigned long long *__restrict__ counters,
+                                                                  uint32_t id_group,
+                                                                  uint64_t id_stride) {
     __shared__ uint32_t tile[kWalkBlock / 64][64][kTileSteps + 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -680,7 +694,7 @@ __global__ __launch_bounds__(kWalkBlock, 3) void walk_rec_kernel(GraphView g, Wa
     NodeRow cur{kSentinel, 0, 0, 0}, prev{kSentinel, 0, 0, 0};
     uint32_t cur_ntype = 0, ptype = 0;
     if (live) {
-        const uint64_t wid = first_walk + b;
+        const uint64_t wid = walk_id_of(id_group, id_stride, first_walk, b);
         const uint64_t si = wid % g.n_sources;
         cur.id = g.sources ? g.sources[si] : (uint32_t)si;
         cur.start = g.row_ptr[cur.id];

@@ -97,13 +97,22 @@ class Node2VecSequence:
                              self._change_node_type_weight, self._change_edge_type_weight)
         seed = self._random_state + idx + self.elapsed_epochs
         first_source = (idx * self._batch_size) % self._sample_number
-        parts = [
-            # ids spaced by 2 * n_sources per iteration keep wrapped-around sources distinct
-            ops.walks(self._graph, wp, seed, 0, 2 * it * self._sample_number + first_source,
-                      self._batch_size, device=self._device)
-            for it in range(self._iterations)
-        ]
-        return torch.cat(parts, dim=0)
+        # the whole batch in ONE launch (gn2v_walks_strided): walk b = source b % batch_size in
+        # iteration b // batch_size, its id 2 * iteration * n_sources + first_source + b % batch_size
+        # (ids spaced by 2 * n_sources per iteration keep wrapped-around sources distinct) -- a
+        # walk is 127 dependent steps, so sixteen launches of 256 walks took sixteen times as long
+        import ctypes as C
+
+        from .. import _lib
+
+        dev = torch.device("cuda", self._device)
+        out = torch.empty((self._iterations * self._batch_size, self._walk_length),
+                          dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().gn2v_walks_strided(
+            self._graph.device_graph(self._device).handle, C.byref(wp), seed, 0, first_source,
+            self._iterations * self._batch_size, self._batch_size, 2 * self._sample_number,
+            out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        return out
 
     def __getitem__(self, idx: int):
         contexts, words = ops.window_batch(self.walks(idx), self._window_size)

@@ -176,6 +176,14 @@ int gn2v_ba_edges(uint64_t n_nodes, uint32_t m, uint64_t seed, uint32_t *d_src, 
 int gn2v_walks(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
                uint64_t first_walk, uint64_t n_walks, uint32_t *d_out, void *stream);
 
+/* The same with ids in groups: walk b of the launch has id first_walk + (b / group) * stride +
+ * b % group -- the walks of a whole Node2VecSequence batch, `group` = batch_size source nodes x
+ * iterations (stride between the iterations' ids), in ONE launch (node2vec_sequence.py:190-201:
+ * one Graph.node2vec call per batch).  Same walks as the calls of gn2v_walks it stands for. */
+int gn2v_walks_strided(gn2v_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
+                       uint64_t first_walk, uint64_t n_walks, uint32_t group, uint64_t stride,
+                       uint32_t *d_out, void *stream);
+
 /* Node2VecSequence batch (node2vec_sequence.py:115-128): every walk position with a full window
  * -> d_words i32[n], d_contexts i32[n][2w], n = n_walks * (walk_length - 2w). */
 int gn2v_window_batch(const uint32_t *d_walks, uint64_t n_walks, uint32_t walk_length,

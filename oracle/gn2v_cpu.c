@@ -103,6 +103,19 @@ int gn2v_cpu_walks(gn2v_cpu_graph *g, const gn2v_walk_params *wp, uint64_t seed,
     return 0;
 }
 
+int gn2v_cpu_walks_strided(gn2v_cpu_graph *g, const gn2v_walk_params *wp, uint64_t seed,
+                           uint64_t epoch, uint64_t first_walk, uint64_t n_walks, uint32_t group,
+                           uint64_t stride, uint32_t *out, void *stream) {
+    if (group == 0) return fail("group must be at least 1");
+    for (uint64_t b = 0, q = 0; b < n_walks; b += group, ++q) {
+        const uint64_t nb = n_walks - b < group ? n_walks - b : group;
+        if (gn2v_cpu_walks(g, wp, seed, epoch, first_walk + q * stride, nb,
+                           out ? out + b * wp->walk_length : NULL, stream))
+            return 1;
+    }
+    return 0;
+}
+
 int gn2v_cpu_window_batch(const uint32_t *walks, uint64_t n_walks, uint32_t walk_length,
                           uint32_t window, int32_t *contexts, int32_t *words, void *stream) {
     (void)stream;

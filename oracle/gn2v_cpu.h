@@ -46,6 +46,10 @@ int gn2v_cpu_graph_set_types(gn2v_cpu_graph *g, const uint32_t *node_types,
  * (sequences/tensorflow_sequences/node2vec_sequence.py:190-201) */
 int gn2v_cpu_walks(gn2v_cpu_graph *g, const gn2v_walk_params *wp, uint64_t seed, uint64_t epoch,
                    uint64_t first_walk, uint64_t n_walks, uint32_t *out, void *stream);
+/* twin of gn2v_walks_strided: walk b has id first_walk + (b / group) * stride + b % group */
+int gn2v_cpu_walks_strided(gn2v_cpu_graph *g, const gn2v_walk_params *wp, uint64_t seed,
+                           uint64_t epoch, uint64_t first_walk, uint64_t n_walks, uint32_t group,
+                           uint64_t stride, uint32_t *out, void *stream);
 /* twin of gn2v_window_batch: the Node2VecSequence batch (node2vec_sequence.py:115-128) */
 int gn2v_cpu_window_batch(const uint32_t *walks, uint64_t n_walks, uint32_t walk_length,
                           uint32_t window, int32_t *contexts, int32_t *words, void *stream);

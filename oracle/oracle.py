@@ -565,6 +565,17 @@ def cpu_walks(g: CpuGraph, wp, seed: int, epoch: int, first_walk: int, n_walks: 
     return out
 
 
+def cpu_walks_strided(g: CpuGraph, wp, seed: int, epoch: int, first_walk: int, n_walks: int,
+                      group: int, stride: int):
+    """gn2v_cpu_walks_strided: walk b has id first_walk + (b // group) * stride + b % group."""
+    out = np.empty((n_walks, wp.walk_length), dtype=np.uint32)
+    cpu_check(lib().gn2v_cpu_walks_strided(g.handle, C.byref(wp), C.c_uint64(seed),
+                                           C.c_uint64(epoch), C.c_uint64(first_walk),
+                                           C.c_uint64(n_walks), C.c_uint32(group),
+                                           C.c_uint64(stride), _ptr(out), None))
+    return out
+
+
 def cpu_window_batch(walks_arr, window: int):
     wk = np.ascontiguousarray(walks_arr, dtype=np.uint32)
     n = wk.shape[0] * (wk.shape[1] - 2 * window)

@@ -66,6 +66,10 @@ def test_walks_window_batch_and_tables_are_the_oracles(graphs):
     owp = O.WalkParams(24, 2, 0.5, 2.0, 100, 0)
     got = O.cpu_walks(cg, wp, 9, 1, 17, 200)
     assert np.array_equal(got, O.walks(og, owp, 9, 1, 17, 200))
+    # ids in groups: 3 groups of 70 walks (the last one short), 1 000 ids apart
+    strided = O.cpu_walks_strided(cg, wp, 9, 1, 17, 200, 70, 1000)
+    assert np.array_equal(strided, np.concatenate(
+        [O.walks(og, owp, 9, 1, 17 + q * 1000, min(70, 200 - 70 * q)) for q in range(3)]))
     ctx, words = O.cpu_window_batch(got, 3)
     want_ctx, want_words = O.window_batch(got, 3)
     assert np.array_equal(ctx, want_ctx) and np.array_equal(words, want_words)

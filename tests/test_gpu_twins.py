@@ -44,6 +44,24 @@ def test_walks(pair, weights, max_neighbours):
     assert np.array_equal(dev.cpu().numpy().view(np.uint32), host)
 
 
+@pytest.mark.parametrize("group,stride,n", [(256, 4000, 4096), (100, 7, 250), (1, 3, 64), (5000, 1, 700)])
+def test_walks_strided(pair, group, stride, n):
+    """A Node2VecSequence batch in one launch: the same walks as one gn2v_walks call per group,
+    and the twin's."""
+    g, cg = pair
+    wp = _lib.WalkParams(24, 2, 0.5, 2.0, 100, 0, 0.0, 0.0)
+    dev = torch.empty((n, 24), dtype=torch.int32, device="cuda")
+    host = np.empty((n, 24), dtype=np.uint32)
+    common = (C.byref(wp), C.c_uint64(5), C.c_uint64(0), C.c_uint64(31), C.c_uint64(n),
+              C.c_uint32(group), C.c_uint64(stride))
+    _call_both("walks_strided", g, cg, common + (C.c_void_p(dev.data_ptr()),),
+               common + (host.ctypes.data_as(C.c_void_p),))
+    assert np.array_equal(dev.cpu().numpy().view(np.uint32), host)
+    parts = [ops.walks(g, wp, 5, 0, 31 + q * stride, min(group, n - q * group))
+             for q in range(-(-n // group))]
+    assert torch.equal(torch.cat(parts), dev)
+
+
 def test_window_batch_and_init_table(pair):
     g, cg = pair
     wk = O.cpu_walks(cg, _lib.WalkParams(20, 1, 1.0, 1.0, 0, 0, 0.0, 0.0), 1, 0, 0, 500)
