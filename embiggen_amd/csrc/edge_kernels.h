@@ -22,6 +22,9 @@ __global__ __launch_bounds__(256) void edge_embedding_kernel(
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 4, q = lane & 15;
     const uint32_t nchunks = ld >> 2;
+    // whole 16-byte stores where the output rows allow them (d and out_ld multiples of 4 floats,
+    // out aligned: the transformers' case) -- the element-wise operators write as much as they read
+    const bool vec = (d & 3u) == 0 && (out_ld & 3u) == 0 && ((uintptr_t)out & 15u) == 0;
     const uint64_t groups = (uint64_t)gridDim.x * (blockDim.x >> 4);
     for (uint64_t e = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; ; e += groups) {
         // all lanes of a wave must reach the DPP reductions together
@@ -68,6 +71,8 @@ __global__ __launch_bounds__(256) void edge_embedding_kernel(
             if (!live || ci >= nchunks) continue;
             const float *x = reinterpret_cast<const float *>(&a.c[cc]);
             const float *y = reinterpret_cast<const float *>(&b.c[cc]);
+            float4 rv;
+            float *rr = reinterpret_cast<float *>(&rv);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const uint32_t col = ci * 4 + t;
@@ -85,8 +90,15 @@ __global__ __launch_bounds__(256) void edge_embedding_kernel(
                     case kMax: r = fmaxf(x[t], y[t]); break;
                     default: r = x[t]; break;  // kConcatenate: first half
                 }
-                o[col] = r;
-                if (method == kConcatenate) o[d + col] = y[t];
+                rr[t] = r;
+                if (!vec) {
+                    o[col] = r;
+                    if (method == kConcatenate) o[d + col] = y[t];
+                }
+            }
+            if (vec && ci * 4 < d) {
+                *reinterpret_cast<float4 *>(o + ci * 4) = rv;
+                if (method == kConcatenate) *reinterpret_cast<float4 *>(o + d + ci * 4) = b.c[cc];
             }
         }
     }
